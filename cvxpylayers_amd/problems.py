@@ -1,0 +1,163 @@
+"""Cone-level synthetic problem kit (no CVXPY needed).
+
+Generates batches of cone programs  min c^T x  s.t.  A x + s = b, s in K  that are strictly
+primal-dual feasible by construction:  b = A x0 + s0,  c = -A^T y0  with
+s0 in int K, y0 in int K*.  Also builds the canonical *template* the plugin boundary consumes:
+the CSC structure of CVXPY's augmented matrix [A_cvx | b_cvx] (m x (n+1)), where the solver
+sees A = -A_cvx, b = b_cvx (reference: cvxpylayers/interfaces/diffcp_if.py:59-67,114-118).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import numpy as np
+
+
+def cone_rows(cones: dict) -> int:
+    return (int(cones.get("z", 0)) + int(cones.get("l", 0)) + sum(int(d) for d in cones.get("q", []))
+            + sum(int(k) * (int(k) + 1) // 2 for k in cones.get("s", [])))
+
+
+@dataclass
+class ConeTemplate:
+    """What CVXPY's ParamConeProg hands a solver plugin once per layer (host side).
+
+    indices/indptr: CSC structure of the augmented m x (n+1) matrix [A_cvx | b_cvx]
+    (param_prob.reduced_A.problem_data_index, interfaces/__init__.py:26-33)."""
+    n: int
+    m: int
+    indices: np.ndarray
+    indptr: np.ndarray
+    cones: dict = field(default_factory=dict)
+
+    @property
+    def nnz_aug(self) -> int:
+        return int(self.indptr[-1])
+
+    @property
+    def nnzA(self) -> int:
+        return int(self.indptr[-2])
+
+    @property
+    def b_idx(self) -> np.ndarray:
+        return self.indices[self.indptr[-2]:self.indptr[-1]]
+
+    @property
+    def problem_data_index(self):
+        return (self.indices, self.indptr, (self.m, self.n + 1))
+
+    def dense_from_values(self, A_eval: np.ndarray, q_eval: np.ndarray):
+        """(nnz_aug,B),(n+1,B) boundary values -> solver-form dense (A (B,m,n), b (B,m), c (B,n)).
+        Follows _build_diffcp_matrices (diffcp_if.py:46-70): A = -A_aug[:, :-1], b = A_aug[:, -1], c = q[:-1]."""
+        A_eval = np.asarray(A_eval, dtype=np.float64)
+        q_eval = np.asarray(q_eval, dtype=np.float64)
+        if A_eval.ndim == 1:
+            A_eval = A_eval[:, None]
+            q_eval = q_eval[:, None]
+        B = A_eval.shape[1]
+        aug = np.zeros((B, self.m, self.n + 1))
+        cols = np.repeat(np.arange(self.n + 1), np.diff(self.indptr))
+        aug[:, self.indices, cols] = A_eval.T
+        return -aug[:, :, :self.n].copy(), aug[:, :, self.n].copy(), q_eval[:self.n].T.copy()
+
+    def values_from_dense(self, A: np.ndarray, b: np.ndarray, c: np.ndarray):
+        """inverse of dense_from_values: solver-form (A,b,c) -> boundary (A_eval (nnz_aug,B), q_eval (n+1,B))."""
+        B = A.shape[0]
+        aug = np.concatenate([-A, b[:, :, None]], axis=2)
+        cols = np.repeat(np.arange(self.n + 1), np.diff(self.indptr))
+        A_eval = aug[:, self.indices, cols].T.copy()
+        q_eval = np.concatenate([c.T, np.zeros((1, B))], axis=0)
+        return A_eval, q_eval
+
+
+def dense_template(n: int, cones: dict, pattern: np.ndarray | None = None, b_pattern: np.ndarray | None = None) -> ConeTemplate:
+    """Template with a given (m x n) boolean sparsity pattern for A (default: dense) and b (default: all rows)."""
+    m = cone_rows(cones)
+    if pattern is None:
+        pattern = np.ones((m, n), dtype=bool)
+    if b_pattern is None:
+        b_pattern = np.ones(m, dtype=bool)
+    full = np.concatenate([pattern, b_pattern[:, None]], axis=1)
+    indices, indptr = [], [0]
+    for j in range(n + 1):
+        rows = np.nonzero(full[:, j])[0]
+        indices.extend(rows.tolist())
+        indptr.append(len(indices))
+    return ConeTemplate(n=n, m=m, indices=np.asarray(indices, dtype=np.int32), indptr=np.asarray(indptr, dtype=np.int32), cones=dict(cones))
+
+
+def _interior_point(rng, cones: dict, B: int):
+    """s0 in int K, y0 in int K* blockwise."""
+    z, l = int(cones.get("z", 0)), int(cones.get("l", 0))
+    s_parts, y_parts = [], []
+    if z:
+        s_parts.append(np.zeros((B, z)))
+        y_parts.append(rng.standard_normal((B, z)))
+    if l:
+        s_parts.append(np.abs(rng.standard_normal((B, l))) + 0.1)
+        y_parts.append(np.abs(rng.standard_normal((B, l))) + 0.1)
+    for d in cones.get("q", []):
+        for parts in (s_parts, y_parts):
+            u = rng.standard_normal((B, d - 1))
+            t = np.linalg.norm(u, axis=1, keepdims=True) + 0.1 + np.abs(rng.standard_normal((B, 1)))
+            parts.append(np.concatenate([t, u], axis=1))
+    for k in cones.get("s", []):
+        for parts in (s_parts, y_parts):
+            G = rng.standard_normal((B, k, k))
+            S = G @ np.swapaxes(G, 1, 2) / k + 0.1 * np.eye(k)
+            parts.append(sym_to_svec(S))
+    return np.concatenate(s_parts, axis=1), np.concatenate(y_parts, axis=1)
+
+
+def sym_to_svec(S: np.ndarray) -> np.ndarray:
+    """(...,k,k) symmetric -> lower-triangular column-major svec with sqrt(2) off-diagonals."""
+    k = S.shape[-1]
+    out = []
+    for j in range(k):
+        for i in range(j, k):
+            out.append(S[..., i, j] * (1.0 if i == j else np.sqrt(2.0)))
+    return np.stack(out, axis=-1)
+
+
+def svec_to_sym(v: np.ndarray, k: int) -> np.ndarray:
+    S = np.zeros(v.shape[:-1] + (k, k))
+    idx = 0
+    for j in range(k):
+        for i in range(j, k):
+            val = v[..., idx] * (1.0 if i == j else 1.0 / np.sqrt(2.0))
+            S[..., i, j] = val
+            S[..., j, i] = val
+            idx += 1
+    return S
+
+
+def generate(n: int, cones: dict, B: int, seed: int = 0, batched=("A", "b", "c"), pattern: np.ndarray | None = None):
+    """Synthetic batch G(n, cones, B, seed, batched) -> (A (B,m,n), b (B,m), c (B,n)) float64, solver form."""
+    rng = np.random.default_rng(seed)
+    m = cone_rows(cones)
+    A0 = rng.standard_normal((m, n)) / np.sqrt(n)
+    if "A" in batched:
+        A = A0[None] + 0.1 * rng.standard_normal((B, m, n)) / np.sqrt(n)
+    else:
+        A = np.broadcast_to(A0, (B, m, n)).copy()
+    if pattern is not None:
+        A = A * pattern[None]
+    x0 = rng.standard_normal((B, n))
+    s0, y0 = _interior_point(rng, cones, B)
+    if "b" not in batched:
+        x0[:] = x0[0]
+        s0[:] = s0[0]
+    if "c" not in batched:
+        y0[:] = y0[0]
+    b = np.einsum("bij,bj->bi", A, x0) + s0
+    c = -np.einsum("bij,bi->bj", A, y0)
+    return A, b, c
+
+
+# The configurations BASELINE.json names, at cone level
+CONFIGS = {
+    "M": dict(n=50, cones={"z": 0, "l": 20, "q": [10] * 8}, B=4096),            # metric: n=50, m=100 SOC
+    "C2": dict(n=50, cones={"z": 0, "l": 100, "q": []}, B=4096),                 # box-QP-like nonneg only
+    "C3": dict(n=100, cones={"z": 0, "l": 10, "q": [11] * 10}, B=4096),          # SOCP n=100, 10 SOC cones
+    "C4": dict(n=210, cones={"z": 20, "l": 0, "q": [], "s": [20]}, B=1024),      # SDP one 20x20 PSD cone
+}

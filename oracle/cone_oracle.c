@@ -1,0 +1,570 @@
+/*
+ * oracle/cone_oracle.c  --  TEST INFRASTRUCTURE ONLY (never shipped, never on the product path)
+ *
+ * CPU restatement, in plain C, of the arithmetic behind the reference hot path
+ *     cvxpylayers.torch.CvxpyLayer.forward/backward
+ *       -> cvxpylayers/interfaces/diffcp_if.py:329-403  (_CvxpyLayer.forward / backward)
+ *       -> diffcp.solve_and_derivative_batch / adj_batch   (diffcp_if.py:365-371, :86)
+ *       -> SCS (direct linear-system variant)
+ * diffcp (pin 1.1.4, uv.lock:590-592) and SCS (pin 3.2.9, uv.lock:2352-2354) are NOT vendored in
+ * /root/reference and are not installable here, so this file restates their PUBLISHED algorithms:
+ *   forward : O'Donoghue, "Operator splitting for a homogeneous embedding of the linear
+ *             complementarity problem" (SCS 3): Ruiz equilibration, Douglas-Rachford on the
+ *             homogeneous self-dual embedding with the diagonal metric R = diag(rho_x I, 1/scale I, 10),
+ *             direct factorisation of the reduced KKT system, over-relaxation alpha, adaptive
+ *             scale, inf-norm termination + infeasibility certificates.
+ *   backward: Agrawal et al., "Differentiating through a cone program" (diffcp):
+ *             z=(x, y-s, 1), M = (Q-I) DPi(z) + I, solve M^T r = dz (LSQR, or dense elimination),
+ *             dA = r_y x^T - y r_x^T (antisymmetrised outer products), db, dc.
+ * PARITY PIN: there are no golden vectors for this path in the reference and the
+ * reference cannot be executed in this image, so SCS/diffcp ITERATE parity is UNPINNED.  What is
+ * pinned (tests/test_oracle_known_answers.py): every closed-form known-answer problem the
+ * reference's own tests assert (ridge LS, min-norm equality, box QP/ReLU, LP vertex, SOC, SDP,
+ * infeasible/unbounded status) and central finite differences of the forward solve.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this file.
+ *
+ * Conventions (reference: diffcp_if.py:59-67): solver form  min c^T x  s.t.  A x + s = b, s in K,
+ * K = zero(z) x nonneg(l) x SOC(q_1) x ... x PSD(s_1) x ...  (SCS row order z,l,q,s),
+ * SOC = (t, x) with ||x|| <= t; PSD = lower-triangular column-major svec with sqrt(2) off-diagonals
+ * (cvxpylayers/torch/cvxpylayer.py:201-222).  A is dense row-major (m x n) per instance here; the
+ * python wrapper densifies the CSC template.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+typedef struct {
+    int z, l, nq, ns;
+    const int *q;
+    const int *s;
+} oc_cones;
+
+typedef struct {
+    double eps_abs, eps_rel, eps_infeas, alpha, rho_x, scale;
+    int max_iters, normalize, adaptive_scale;
+    /* backward */
+    int adj_mode;          /* 0 = lsqr (diffcp default), 1 = dense elimination */
+    double lsqr_atol, lsqr_btol, lsqr_conlim;
+    int lsqr_iter_lim;     /* <=0: 2*N */
+} oc_opts;
+
+enum { OC_SOLVED = 1, OC_SOLVED_INACCURATE = 2, OC_UNBOUNDED = -1, OC_INFEASIBLE = -2,
+       OC_UNBOUNDED_INACCURATE = -6, OC_INFEASIBLE_INACCURATE = -7, OC_FAILED = -4 };
+
+#define MIN_SCALE 1e-4
+#define MAX_SCALE 1e4
+#define NUM_RUIZ_PASSES 25
+#define NUM_L2_PASSES 1
+#define TAU_FACTOR 10.0
+#define CONVERGED_INTERVAL 25
+#define RESCALING_MIN_ITERS 100
+#define MIN_SCALE_VALUE 1e-6
+#define MAX_SCALE_VALUE 1e6
+#define ZERO_CONE_FACTOR 1000.0
+
+void oc_default_opts(oc_opts *o) {
+    o->eps_abs = 1e-4; o->eps_rel = 1e-4; o->eps_infeas = 1e-7; o->alpha = 1.5;
+    o->rho_x = 1e-6; o->scale = 0.1; o->max_iters = 100000; o->normalize = 1;
+    o->adaptive_scale = 1; o->adj_mode = 0; o->lsqr_atol = 1e-8; o->lsqr_btol = 1e-8;
+    o->lsqr_conlim = 1e8; o->lsqr_iter_lim = -1;
+}
+
+static int cone_rows(const oc_cones *k) {
+    int m = k->z + k->l;
+    for (int i = 0; i < k->nq; i++) m += k->q[i];
+    for (int i = 0; i < k->ns; i++) m += k->s[i] * (k->s[i] + 1) / 2;
+    return m;
+}
+
+/* ------------------------------------------------------------------ small dense helpers */
+static double dot(const double *a, const double *b, int n) { double s = 0; for (int i = 0; i < n; i++) s += a[i] * b[i]; return s; }
+static double norm2(const double *a, int n) { return sqrt(dot(a, a, n)); }
+static double norm_inf(const double *a, int n) { double s = 0; for (int i = 0; i < n; i++) { double v = fabs(a[i]); if (v > s) s = v; } return s; }
+/* y = A x (A m x n row-major) */
+static void matvec(const double *A, const double *x, double *y, int m, int n) {
+    for (int i = 0; i < m; i++) y[i] = dot(A + (size_t)i * n, x, n);
+}
+/* x = A^T y */
+static void matvec_t(const double *A, const double *y, double *x, int m, int n) {
+    memset(x, 0, sizeof(double) * n);
+    for (int i = 0; i < m; i++) { const double *r = A + (size_t)i * n; double yi = y[i]; for (int j = 0; j < n; j++) x[j] += r[j] * yi; }
+}
+
+/* symmetric eigendecomposition, cyclic Jacobi.  S (k x k, row-major, destroyed) -> w (eigvals), V (columns = eigvecs) */
+static void jacobi_eig(double *S, int k, double *w, double *V) {
+    for (int i = 0; i < k; i++) for (int j = 0; j < k; j++) V[i * k + j] = (i == j);
+    for (int sweep = 0; sweep < 60; sweep++) {
+        double off = 0, diag = 0;
+        for (int i = 0; i < k; i++) { diag += S[i * k + i] * S[i * k + i]; for (int j = i + 1; j < k; j++) off += S[i * k + j] * S[i * k + j]; }
+        if (off <= 1e-32 * (diag + off) || off == 0) break;
+        for (int p = 0; p < k - 1; p++) for (int q = p + 1; q < k; q++) {
+            double apq = S[p * k + q];
+            if (apq == 0) continue;
+            double theta = (S[q * k + q] - S[p * k + p]) / (2 * apq);
+            double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1));
+            double c = 1 / sqrt(t * t + 1), s = t * c;
+            for (int r = 0; r < k; r++) { double a = S[r * k + p], b = S[r * k + q]; S[r * k + p] = c * a - s * b; S[r * k + q] = s * a + c * b; }
+            for (int r = 0; r < k; r++) { double a = S[p * k + r], b = S[q * k + r]; S[p * k + r] = c * a - s * b; S[q * k + r] = s * a + c * b; }
+            for (int r = 0; r < k; r++) { double a = V[r * k + p], b = V[r * k + q]; V[r * k + p] = c * a - s * b; V[r * k + q] = s * a + c * b; }
+        }
+    }
+    for (int i = 0; i < k; i++) w[i] = S[i * k + i];
+}
+static void svec_to_mat(const double *v, int k, double *S) {
+    int idx = 0; const double r = 1 / sqrt(2.0);
+    for (int j = 0; j < k; j++) for (int i = j; i < k; i++) { double val = v[idx++]; if (i != j) val *= r; S[i * k + j] = val; S[j * k + i] = val; }
+}
+static void mat_to_svec(const double *S, int k, double *v) {
+    int idx = 0; const double r = sqrt(2.0);
+    for (int j = 0; j < k; j++) for (int i = j; i < k; i++) v[idx++] = (i == j) ? S[i * k + j] : r * 0.5 * (S[i * k + j] + S[j * k + i]);
+}
+
+/* ------------------------------------------------------------------ cone projections (onto the DUAL cone K*) */
+static void proj_soc(double *v, int d) {
+    if (d == 0) return;
+    if (d == 1) { if (v[0] < 0) v[0] = 0; return; }
+    double t = v[0], nz = norm2(v + 1, d - 1);
+    if (nz <= t) return;
+    if (nz <= -t) { memset(v, 0, sizeof(double) * d); return; }
+    double a = 0.5 * (t + nz);
+    v[0] = a; double f = a / nz;
+    for (int i = 1; i < d; i++) v[i] *= f;
+}
+static void proj_psd(double *v, int k) {
+    if (k == 0) return;
+    double *S = malloc(sizeof(double) * k * k * 3 + sizeof(double) * k), *V = S + k * k, *T = V + k * k, *w = T + k * k;
+    svec_to_mat(v, k, S); jacobi_eig(S, k, w, V);
+    for (int i = 0; i < k; i++) for (int j = 0; j < k; j++) { double a = 0; for (int r = 0; r < k; r++) if (w[r] > 0) a += V[i * k + r] * w[r] * V[j * k + r]; T[i * k + j] = a; }
+    mat_to_svec(T, k, v); free(S);
+}
+/* y <- Pi_{K*}(y): zero cone K={0} has K* = R^z (free) */
+static void proj_dual_cone(double *y, const oc_cones *k) {
+    int off = k->z;
+    for (int i = 0; i < k->l; i++) if (y[off + i] < 0) y[off + i] = 0;
+    off += k->l;
+    for (int c = 0; c < k->nq; c++) { proj_soc(y + off, k->q[c]); off += k->q[c]; }
+    for (int c = 0; c < k->ns; c++) { proj_psd(y + off, k->s[c]); off += k->s[c] * (k->s[c] + 1) / 2; }
+}
+
+/* ------------------------------------------------------------------ Cholesky of SPD n x n (row-major, lower) */
+static int chol_factor(double *S, int n) {
+    for (int j = 0; j < n; j++) {
+        double d = S[j * n + j];
+        for (int k = 0; k < j; k++) d -= S[j * n + k] * S[j * n + k];
+        if (!(d > 0)) return -1;
+        d = sqrt(d); S[j * n + j] = d;
+        for (int i = j + 1; i < n; i++) { double v = S[i * n + j]; for (int k = 0; k < j; k++) v -= S[i * n + k] * S[j * n + k]; S[i * n + j] = v / d; }
+    }
+    return 0;
+}
+static void chol_solve(const double *L, int n, double *x) {
+    for (int i = 0; i < n; i++) { double v = x[i]; for (int k = 0; k < i; k++) v -= L[i * n + k] * x[k]; x[i] = v / L[i * n + i]; }
+    for (int i = n - 1; i >= 0; i--) { double v = x[i]; for (int k = i + 1; k < n; k++) v -= L[k * n + i] * x[k]; x[i] = v / L[i * n + i]; }
+}
+
+/* ------------------------------------------------------------------ forward solve, one instance */
+typedef struct { int iters, status; double pobj, dobj, res_pri, res_dual, gap, scale; int n_rescale; } oc_info;
+
+/* average the row scalings inside each SOC / PSD block so the scaled cone is still the cone */
+static void block_average(double *D, const oc_cones *k) {
+    int off = k->z + k->l;
+    for (int c = 0; c < k->nq; c++) { int d = k->q[c]; if (d > 0) { double s = 0; for (int i = 0; i < d; i++) s += D[off + i]; s /= d; for (int i = 0; i < d; i++) D[off + i] = s; } off += d; }
+    for (int c = 0; c < k->ns; c++) { int d = k->s[c] * (k->s[c] + 1) / 2; if (d > 0) { double s = 0; for (int i = 0; i < d; i++) s += D[off + i]; s /= d; for (int i = 0; i < d; i++) D[off + i] = s; } off += d; }
+}
+static double clamp_scale(double v) { if (v < MIN_SCALE) return 1.0; if (v > MAX_SCALE) return MAX_SCALE; return v; }
+
+static void set_ry(double *ry, int m, const oc_cones *k, double scale) {
+    for (int i = 0; i < m; i++) ry[i] = (i < k->z) ? 1.0 / (ZERO_CONE_FACTOR * scale) : 1.0 / scale;
+}
+
+/* factor S = rho_x I + A^T diag(1/ry) A ; returns 0 ok */
+static int factor_kkt(const double *A, const double *ry, double rho_x, int m, int n, double *L) {
+    memset(L, 0, sizeof(double) * n * n);
+    for (int i = 0; i < m; i++) { const double *r = A + (size_t)i * n; double w = 1.0 / ry[i];
+        for (int a = 0; a < n; a++) { double ra = r[a] * w; if (ra == 0) continue; for (int b2 = 0; b2 <= a; b2++) L[a * n + b2] += ra * r[b2]; } }
+    for (int a = 0; a < n; a++) { L[a * n + a] += rho_x; for (int b2 = a + 1; b2 < n; b2++) L[a * n + b2] = L[b2 * n + a]; }
+    return chol_factor(L, n);
+}
+/* solve [[rho_x I, A^T],[A, -R_y]] (x,y) = (a, bb):  x = S^{-1}(a + A^T (bb/ry)),  y = (A x - bb)/ry  */
+static void kkt_solve(const double *A, const double *L, const double *ry, int m, int n, const double *a, const double *bb, double *x, double *y, double *tmp_m) {
+    for (int i = 0; i < m; i++) tmp_m[i] = bb[i] / ry[i];
+    matvec_t(A, tmp_m, x, m, n);
+    for (int j = 0; j < n; j++) x[j] += a[j];
+    chol_solve(L, n, x);
+    matvec(A, x, y, m, n);
+    for (int i = 0; i < m; i++) y[i] = (y[i] - bb[i]) / ry[i];
+}
+
+static int solve_one(int n, int m, const double *A0, const double *b0, const double *c0, const oc_cones *K, const oc_opts *o,
+                     double *xo, double *yo, double *so, oc_info *info) {
+    int l = n + m + 1;
+    size_t szA = (size_t)m * n;
+    double *buf = calloc(szA + (size_t)n * n + 16 * (size_t)l + 4 * (size_t)(m + n) + 64, sizeof(double));
+    if (!buf) return OC_FAILED;
+    double *A = buf, *L = A + szA, *p = L + (size_t)n * n;
+    double *b = p; p += m; double *c = p; p += n; double *D = p; p += m; double *E = p; p += n;
+    double *ry = p; p += m; double *g = p; p += l; double *w = p; p += l; double *ut = p; p += l; double *u = p; p += l;
+    double *rsk = p; p += l; double *pp = p; p += l; double *t1 = p; p += l; double *t2 = p; p += l; double *t3 = p; p += l;
+    double *Dt = p; p += m; double *Et = p; p += n; double *xs = p; p += n; double *ys = p; p += m; double *ss = p; p += m;
+    memcpy(A, A0, sizeof(double) * szA); memcpy(b, b0, sizeof(double) * m); memcpy(c, c0, sizeof(double) * n);
+    for (int i = 0; i < m; i++) D[i] = 1; for (int j = 0; j < n; j++) E[j] = 1;
+    double sigma = 1.0;
+    /* ---- equilibration (SCS normalize: NUM_RUIZ_PASSES inf-norm passes + NUM_L2_PASSES 2-norm pass) */
+    if (o->normalize) {
+        for (int pass = 0; pass < NUM_RUIZ_PASSES + NUM_L2_PASSES; pass++) {
+            int l2 = pass >= NUM_RUIZ_PASSES;
+            for (int i = 0; i < m; i++) { const double *r = A + (size_t)i * n; Dt[i] = l2 ? norm2(r, n) : norm_inf(r, n); }
+            for (int j = 0; j < n; j++) Et[j] = 0;
+            for (int i = 0; i < m; i++) { const double *r = A + (size_t)i * n; for (int j = 0; j < n; j++) { if (l2) Et[j] += r[j] * r[j]; else { double v = fabs(r[j]); if (v > Et[j]) Et[j] = v; } } }
+            if (l2) for (int j = 0; j < n; j++) Et[j] = sqrt(Et[j]);
+            block_average(Dt, K);
+            for (int i = 0; i < m; i++) Dt[i] = 1.0 / sqrt(clamp_scale(Dt[i]));
+            for (int j = 0; j < n; j++) Et[j] = 1.0 / sqrt(clamp_scale(Et[j]));
+            for (int i = 0; i < m; i++) { double *r = A + (size_t)i * n; for (int j = 0; j < n; j++) r[j] *= Dt[i] * Et[j]; D[i] *= Dt[i]; }
+            for (int j = 0; j < n; j++) E[j] *= Et[j];
+        }
+        for (int i = 0; i < m; i++) b[i] *= D[i];
+        for (int j = 0; j < n; j++) c[j] *= E[j];
+        double nb = norm_inf(b, m), nc = norm_inf(c, n), mx = nb > nc ? nb : nc;
+        sigma = 1.0 / clamp_scale(mx);
+        for (int i = 0; i < m; i++) b[i] *= sigma;
+        for (int j = 0; j < n; j++) c[j] *= sigma;
+    }
+    double nrm_b0 = norm_inf(b0, m), nrm_c0 = norm_inf(c0, n);
+    double scale = o->scale, rtau = TAU_FACTOR, rho_x = o->rho_x;
+    set_ry(ry, m, K, scale);
+    if (factor_kkt(A, ry, rho_x, m, n, L)) { free(buf); info->status = OC_FAILED; return OC_FAILED; }
+    /* g = (R_z + M_zz)^{-1} h, h=(c,b):  kkt rhs (c, -b) */
+    for (int i = 0; i < m; i++) t1[i] = -b[i];
+    kkt_solve(A, L, ry, m, n, c, t1, g, g + n, t2);
+    double hg = dot(c, g, n) + dot(b, g + n, m);
+    /* cold start */
+    memset(w, 0, sizeof(double) * l); w[l - 1] = 1.0;
+    int status = 0, iter, last_scale_iter = 0, n_rescale = 0; double sum_log = 0; int n_log = 0;
+    double res_pri = NAN, res_dual = NAN, gap = NAN, pobj = NAN, dobj = NAN;
+    for (iter = 0; iter < o->max_iters; iter++) {
+        int check = (iter % CONVERGED_INTERVAL) == 0;
+        if (check && iter > 0) { /* keep the homogeneous iterate in range (iteration map is positively homogeneous) */
+            double nw = norm2(w, l); if (nw > 0) { double f = sqrt((double)l) / nw; for (int i = 0; i < l; i++) w[i] *= f; }
+        }
+        /* (1) linear-system step: p = (R_z+M_zz)^{-1} R_z w_z : kkt rhs (rho_x w_x, -r_y w_y) */
+        for (int j = 0; j < n; j++) t1[j] = rho_x * w[j];
+        for (int i = 0; i < m; i++) t2[i] = -ry[i] * w[n + i];
+        kkt_solve(A, L, ry, m, n, t1, t2, pp, pp + n, t3);
+        double tau_t = (rtau * w[l - 1] + dot(c, pp, n) + dot(b, pp + n, m)) / (rtau + hg);
+        for (int i = 0; i < l - 1; i++) ut[i] = pp[i] - tau_t * g[i];
+        ut[l - 1] = tau_t;
+        /* (2) cone step */
+        for (int i = 0; i < l; i++) u[i] = 2 * ut[i] - w[i];
+        proj_dual_cone(u + n, K);
+        if (u[l - 1] < 0) u[l - 1] = 0;
+        /* (3) (s, kappa) = R (u + w - 2 ut) */
+        for (int j = 0; j < n; j++) rsk[j] = rho_x * (u[j] + w[j] - 2 * ut[j]);
+        for (int i = 0; i < m; i++) rsk[n + i] = ry[i] * (u[n + i] + w[n + i] - 2 * ut[n + i]);
+        rsk[l - 1] = rtau * (u[l - 1] + w[l - 1] - 2 * ut[l - 1]);
+        /* (4) termination test on un-normalised residuals (inf-norms) */
+        if (check) {
+            double tau = fabs(u[l - 1]), kap = fabs(rsk[l - 1]);
+            /* un-normalise: x = E xh / sigma, y = D yh / sigma, s = sh / (D sigma) */
+            for (int j = 0; j < n; j++) xs[j] = E[j] * u[j] / sigma;
+            for (int i = 0; i < m; i++) { ys[i] = D[i] * u[n + i] / sigma; ss[i] = rsk[n + i] / (D[i] * sigma); }
+            matvec(A0, xs, t1, m, n);           /* Ax */
+            matvec_t(A0, ys, t2, m, n);         /* A^T y */
+            double nax = norm_inf(t1, m), ns = norm_inf(ss, m), naty = norm_inf(t2, n);
+            double rp = 0, rd = 0, naxs = 0;
+            for (int i = 0; i < m; i++) { double v = t1[i] + ss[i]; if (fabs(v) > naxs) naxs = fabs(v); v -= b0[i] * tau; if (fabs(v) > rp) rp = fabs(v); }
+            for (int j = 0; j < n; j++) { double v = t2[j] + c0[j] * tau; if (fabs(v) > rd) rd = fabs(v); }
+            double ctx = dot(c0, xs, n), bty = dot(b0, ys, m);
+            (void)kap;
+            if (tau > 0) {
+                res_pri = rp / tau; res_dual = rd / tau; gap = fabs(ctx + bty) / tau; pobj = ctx / tau; dobj = -bty / tau;
+                double prl = fmax(fmax(nrm_b0 * tau, ns), nax) / tau, drl = fmax(nrm_c0 * tau, naty) / tau, grl = fmax(fabs(ctx), fabs(bty)) / tau;
+                if (res_pri <= o->eps_abs + o->eps_rel * prl && res_dual <= o->eps_abs + o->eps_rel * drl && gap <= o->eps_abs + o->eps_rel * grl) { status = OC_SOLVED; break; }
+            }
+            if (bty < 0 && naty / (-bty) <= o->eps_infeas) { status = OC_INFEASIBLE; break; }
+            if (ctx < 0 && naxs / (-ctx) <= o->eps_infeas) { status = OC_UNBOUNDED; break; }
+            /* (5) adaptive scale (SCS 3 heuristic: running geometric mean of relative residual ratio) */
+            if (o->adaptive_scale && iter > 0) {
+                double dp = fmax(fmax(nax, ns), nrm_b0 * tau), dd = fmax(naty, nrm_c0 * tau);
+                double rel_p = rp / (dp > 0 ? dp : 1), rel_d = rd / (dd > 0 ? dd : 1);
+                if (rel_p > 0 && rel_d > 0 && isfinite(rel_p) && isfinite(rel_d)) {
+                    sum_log += log(rel_p) - log(rel_d); n_log++;
+                    double factor = sqrt(exp(sum_log / n_log));
+                    if (iter - last_scale_iter >= RESCALING_MIN_ITERS) {
+                        double ns2 = fmin(fmax(scale * factor, MIN_SCALE_VALUE), MAX_SCALE_VALUE);
+                        if (ns2 != scale && (factor > sqrt(10.0) || factor < 1.0 / sqrt(10.0))) {
+                            sum_log = 0; n_log = 0; last_scale_iter = iter; scale = ns2; n_rescale++;
+                            set_ry(ry, m, K, scale);
+                            if (factor_kkt(A, ry, rho_x, m, n, L)) { status = OC_FAILED; break; }
+                            for (int i = 0; i < m; i++) t1[i] = -b[i];
+                            kkt_solve(A, L, ry, m, n, c, t1, g, g + n, t2);
+                            hg = dot(c, g, n) + dot(b, g + n, m);
+                            /* keep (s,kappa): R+ (w+ + u - 2ut) = rsk */
+                            for (int i = 0; i < m; i++) w[n + i] = rsk[n + i] / ry[i] + 2 * ut[n + i] - u[n + i];
+                        }
+                    }
+                }
+            }
+        }
+        /* (6) relaxed dual update */
+        for (int i = 0; i < l; i++) w[i] += o->alpha * (u[i] - ut[i]);
+    }
+    double tau = fabs(u[l - 1]), kap = fabs(rsk[l - 1]);
+    if (status == 0) { /* ran out of iterations: SCS set_unfinished */
+        for (int j = 0; j < n; j++) xs[j] = E[j] * u[j] / sigma;
+        for (int i = 0; i < m; i++) ys[i] = D[i] * u[n + i] / sigma;
+        double ctx = dot(c0, xs, n), bty = dot(b0, ys, m);
+        if (tau > kap) status = OC_SOLVED_INACCURATE; else if (bty < ctx) status = OC_INFEASIBLE_INACCURATE; else status = OC_UNBOUNDED_INACCURATE;
+    }
+    if (status == OC_SOLVED || status == OC_SOLVED_INACCURATE) {
+        for (int j = 0; j < n; j++) xo[j] = E[j] * u[j] / (sigma * tau);
+        for (int i = 0; i < m; i++) { yo[i] = D[i] * u[n + i] / (sigma * tau); so[i] = rsk[n + i] / (D[i] * sigma * tau); }
+    } else if (status == OC_INFEASIBLE || status == OC_INFEASIBLE_INACCURATE) {
+        for (int j = 0; j < n; j++) xo[j] = NAN;
+        for (int i = 0; i < m; i++) { yo[i] = D[i] * u[n + i] / sigma; so[i] = NAN; }
+    } else {
+        for (int j = 0; j < n; j++) xo[j] = E[j] * u[j] / sigma;
+        for (int i = 0; i < m; i++) { yo[i] = NAN; so[i] = rsk[n + i] / (D[i] * sigma); }
+    }
+    info->iters = iter; info->status = status; info->pobj = pobj; info->dobj = dobj; info->res_pri = res_pri;
+    info->res_dual = res_dual; info->gap = gap; info->scale = scale; info->n_rescale = n_rescale;
+    free(buf);
+    return status;
+}
+
+/* ------------------------------------------------------------------ derivative of the dual-cone projection */
+/* out = DPi_{K*}(v) h   (block diagonal, symmetric for every cone here).  psd_ws: per-PSD-cone eigen cache or NULL */
+typedef struct { double *V, *w; } psd_cache;
+
+static void dproj_soc(const double *v, int d, const double *h, double *out) {
+    if (d == 0) return;
+    if (d == 1) { out[0] = v[0] >= 0 ? h[0] : 0; return; }
+    double t = v[0], nz = norm2(v + 1, d - 1);
+    if (nz <= t) { memcpy(out, h, sizeof(double) * d); return; }
+    if (nz <= -t) { memset(out, 0, sizeof(double) * d); return; }
+    /* DPi = 1/(2 nz) [[nz, z^T],[z, (t+nz) I - t z z^T / nz^2]] */
+    double zh = dot(v + 1, h + 1, d - 1);
+    out[0] = (nz * h[0] + zh) / (2 * nz);
+    for (int i = 1; i < d; i++) out[i] = (v[i] * h[0] + (t + nz) * h[i] - t * v[i] * zh / (nz * nz)) / (2 * nz);
+}
+static void dproj_psd(const psd_cache *pc, int k, const double *h, double *out) {
+    double *H = malloc(sizeof(double) * k * k * 3), *T = H + k * k, *T2 = T + k * k;
+    const double *V = pc->V, *w = pc->w;
+    svec_to_mat(h, k, H);
+    /* T = V^T H V */
+    for (int i = 0; i < k; i++) for (int j = 0; j < k; j++) { double a = 0; for (int r = 0; r < k; r++) a += H[i * k + r] * V[r * k + j]; T2[i * k + j] = a; }
+    for (int i = 0; i < k; i++) for (int j = 0; j < k; j++) { double a = 0; for (int r = 0; r < k; r++) a += V[r * k + i] * T2[r * k + j]; T[i * k + j] = a; }
+    for (int i = 0; i < k; i++) for (int j = 0; j < k; j++) {
+        double wi = w[i], wj = w[j], bij;
+        double pi = wi > 0 ? wi : 0, pj = wj > 0 ? wj : 0;
+        if (wi > 0 && wj > 0) bij = 1; else if (wi <= 0 && wj <= 0) bij = 0; else bij = (pi - pj) / (wi - wj);
+        T[i * k + j] *= bij;
+    }
+    for (int i = 0; i < k; i++) for (int j = 0; j < k; j++) { double a = 0; for (int r = 0; r < k; r++) a += V[i * k + r] * T[r * k + j]; T2[i * k + j] = a; }
+    for (int i = 0; i < k; i++) for (int j = 0; j < k; j++) { double a = 0; for (int r = 0; r < k; r++) a += T2[i * k + r] * V[j * k + r]; H[i * k + j] = a; }
+    mat_to_svec(H, k, out); free(H);
+}
+static void dproj_dual_cone(const double *v, const oc_cones *K, const psd_cache *pcs, const double *h, double *out) {
+    int off = 0;
+    for (int i = 0; i < K->z; i++) out[i] = h[i];                      /* dual of zero cone is free: identity */
+    off = K->z;
+    for (int i = 0; i < K->l; i++) out[off + i] = v[off + i] > 0 ? h[off + i] : (v[off + i] < 0 ? 0 : 0.5 * h[off + i]);
+    off += K->l;
+    for (int c = 0; c < K->nq; c++) { dproj_soc(v + off, K->q[c], h + off, out + off); off += K->q[c]; }
+    for (int c = 0; c < K->ns; c++) { dproj_psd(&pcs[c], K->s[c], h + off, out + off); off += K->s[c] * (K->s[c] + 1) / 2; }
+}
+
+typedef struct { int n, m; const double *A, *b, *c, *v; const oc_cones *K; const psd_cache *pcs; double *t1, *t2; } adj_op;
+
+/* out = M^T r,  M = (Q - I) DPi(z) + I,  Q = [[0,A^T,c],[-A,0,b],[-c^T,-b^T,0]]
+ *   M^T r = DPi^T ( -Q r - r ) + r                                                   */
+static void apply_MT(const adj_op *op, const double *r, double *out) {
+    int n = op->n, m = op->m; const double *rx = r, *ry = r + n; double rt = r[n + m];
+    /* x block: -A^T ry - c rt */
+    matvec_t(op->A, ry, out, m, n);
+    for (int j = 0; j < n; j++) out[j] = -out[j] - op->c[j] * rt;
+    /* y block: D (A rx - b rt - ry) + ry */
+    matvec(op->A, rx, op->t1, m, n);
+    for (int i = 0; i < m; i++) op->t1[i] = op->t1[i] - op->b[i] * rt - ry[i];
+    dproj_dual_cone(op->v, op->K, op->pcs, op->t1, op->t2);
+    for (int i = 0; i < m; i++) out[n + i] = op->t2[i] + ry[i];
+    /* tau block (DPi = 1): c^T rx + b^T ry */
+    out[n + m] = dot(op->c, rx, n) + dot(op->b, ry, m);
+}
+/* out = M p */
+static void apply_M(const adj_op *op, const double *p, double *out) {
+    int n = op->n, m = op->m;
+    /* q = DPi p */
+    double *qy = op->t1; dproj_dual_cone(op->v, op->K, op->pcs, p + n, qy);
+    const double *qx = p; double qt = p[n + m];
+    /* (Q - I) q + p */
+    matvec_t(op->A, qy, out, m, n);
+    for (int j = 0; j < n; j++) out[j] = out[j] + op->c[j] * qt - qx[j] + p[j];
+    matvec(op->A, qx, op->t2, m, n);
+    for (int i = 0; i < m; i++) out[n + i] = -op->t2[i] + op->b[i] * qt - qy[i] + p[n + i];
+    out[n + m] = -dot(op->c, qx, n) - dot(op->b, qy, m) - qt + p[n + m];
+}
+
+/* LSQR (Paige & Saunders 1982), solving min || MT r - dz ||, zero start -> minimum-norm solution */
+static int lsqr_MT(const adj_op *op, const double *bvec, int N, double *x, const oc_opts *o, double *work) {
+    double *u = work, *v = u + N, *wv = v + N, *tmp = wv + N;
+    int iter_lim = o->lsqr_iter_lim > 0 ? o->lsqr_iter_lim : 2 * N;
+    double atol = o->lsqr_atol, btol = o->lsqr_btol, ctol = o->lsqr_conlim > 0 ? 1.0 / o->lsqr_conlim : 0;
+    memset(x, 0, sizeof(double) * N);
+    memcpy(u, bvec, sizeof(double) * N);
+    double bnorm = norm2(bvec, N), beta = bnorm, alfa = 0;
+    if (beta > 0) { for (int i = 0; i < N; i++) u[i] /= beta; apply_M(op, u, v); alfa = norm2(v, N); } else { memset(v, 0, sizeof(double) * N); }
+    if (alfa > 0) for (int i = 0; i < N; i++) v[i] /= alfa;
+    memcpy(wv, v, sizeof(double) * N);
+    double rhobar = alfa, phibar = beta, anorm = 0, acond = 0, ddnorm = 0, xnorm = 0, xxnorm = 0, z = 0, cs2 = -1, sn2 = 0, res2 = 0;
+    double arnorm = alfa * beta;
+    if (arnorm == 0) return 0;
+    int itn = 0;
+    while (itn < iter_lim) {
+        itn++;
+        /* u = MT v - alfa u */
+        apply_MT(op, v, tmp);
+        for (int i = 0; i < N; i++) u[i] = tmp[i] - alfa * u[i];
+        beta = norm2(u, N);
+        if (beta > 0) {
+            for (int i = 0; i < N; i++) u[i] /= beta;
+            anorm = sqrt(anorm * anorm + alfa * alfa + beta * beta);
+            apply_M(op, u, tmp);
+            for (int i = 0; i < N; i++) v[i] = tmp[i] - beta * v[i];
+            alfa = norm2(v, N);
+            if (alfa > 0) for (int i = 0; i < N; i++) v[i] /= alfa;
+        }
+        double rho = sqrt(rhobar * rhobar + beta * beta), cs = rhobar / rho, sn = beta / rho;
+        double theta = sn * alfa; rhobar = -cs * alfa; double phi = cs * phibar; phibar = sn * phibar; double tau = sn * phi;
+        double t1 = phi / rho, t2 = -theta / rho;
+        double dd = 0;
+        for (int i = 0; i < N; i++) { double dk = wv[i] / rho; dd += dk * dk; x[i] += t1 * wv[i]; wv[i] = v[i] + t2 * wv[i]; }
+        ddnorm += dd;
+        double delta = sn2 * rho, gambar = -cs2 * rho, rhs = phi - delta * z, zbar = rhs / gambar;
+        xnorm = sqrt(xxnorm + zbar * zbar);
+        double gamma = sqrt(gambar * gambar + theta * theta); cs2 = gambar / gamma; sn2 = theta / gamma; z = rhs / gamma; xxnorm += z * z;
+        acond = anorm * sqrt(ddnorm);
+        double res1 = phibar * phibar; double rnorm = sqrt(res1 + res2);
+        arnorm = alfa * fabs(tau);
+        double test1 = rnorm / bnorm, test2 = arnorm / (anorm * rnorm + 1e-300), test3 = 1 / (acond + 1e-300);
+        double tt1 = test1 / (1 + anorm * xnorm / bnorm), rtol = btol + atol * anorm * xnorm / bnorm;
+        if (1 + test3 <= 1 || 1 + test2 <= 1 || 1 + tt1 <= 1) break;
+        if (test3 <= ctol || test2 <= atol || test1 <= rtol) break;
+    }
+    return itn;
+}
+
+/* dense: build MT column by column, Gaussian elimination with complete pivoting, rank-revealing (the
+ * embedding makes M singular along z; the system is consistent; free variables set to zero). */
+static void dense_solve_MT(const adj_op *op, const double *bvec, int N, double *x) {
+    double *Mt = malloc(sizeof(double) * ((size_t)N * N + 3 * N)); double *e = Mt + (size_t)N * N, *col = e + N, *rhs = col + N;
+    int *cp = malloc(sizeof(int) * N);
+    for (int k = 0; k < N; k++) { memset(e, 0, sizeof(double) * N); e[k] = 1; apply_MT(op, e, col); for (int i = 0; i < N; i++) Mt[(size_t)i * N + k] = col[i]; }
+    memcpy(rhs, bvec, sizeof(double) * N);
+    for (int i = 0; i < N; i++) cp[i] = i;
+    double amax0 = 0; for (size_t i = 0; i < (size_t)N * N; i++) if (fabs(Mt[i]) > amax0) amax0 = fabs(Mt[i]);
+    int rank = N;
+    for (int k = 0; k < N; k++) {
+        int pi = k, pj = k; double best = 0;
+        for (int i = k; i < N; i++) for (int j = k; j < N; j++) { double v = fabs(Mt[(size_t)i * N + j]); if (v > best) { best = v; pi = i; pj = j; } }
+        if (best <= 1e-11 * amax0) { rank = k; break; }
+        if (pi != k) { for (int j = 0; j < N; j++) { double t = Mt[(size_t)k * N + j]; Mt[(size_t)k * N + j] = Mt[(size_t)pi * N + j]; Mt[(size_t)pi * N + j] = t; } double t = rhs[k]; rhs[k] = rhs[pi]; rhs[pi] = t; }
+        if (pj != k) { for (int i = 0; i < N; i++) { double t = Mt[(size_t)i * N + k]; Mt[(size_t)i * N + k] = Mt[(size_t)i * N + pj]; Mt[(size_t)i * N + pj] = t; } int t = cp[k]; cp[k] = cp[pj]; cp[pj] = t; }
+        double piv = Mt[(size_t)k * N + k];
+        for (int i = k + 1; i < N; i++) { double f = Mt[(size_t)i * N + k] / piv; if (f == 0) continue; for (int j = k; j < N; j++) Mt[(size_t)i * N + j] -= f * Mt[(size_t)k * N + j]; rhs[i] -= f * rhs[k]; }
+    }
+    double *xp = col; memset(xp, 0, sizeof(double) * N);
+    for (int k = rank - 1; k >= 0; k--) { double v = rhs[k]; for (int j = k + 1; j < rank; j++) v -= Mt[(size_t)k * N + j] * xp[j]; xp[k] = v / Mt[(size_t)k * N + k]; }
+    for (int k = 0; k < N; k++) x[cp[k]] = xp[k];
+    free(Mt); free(cp);
+}
+
+static int adjoint_one(int n, int m, const double *A, const double *b, const double *c, const oc_cones *K, const oc_opts *o,
+                       const double *x, const double *y, const double *s, const double *dx, const double *dy, const double *ds,
+                       double *dA, double *db, double *dc) {
+    int N = n + m + 1;
+    double *buf = calloc((size_t)12 * N + 4 * m, sizeof(double));
+    double *v = buf, *dz = v + m, *r = dz + N, *t1 = r + N, *t2 = t1 + m, *t3 = t2 + m, *work = t3 + m;
+    for (int i = 0; i < m; i++) v[i] = y[i] - s[i];
+    psd_cache *pcs = NULL;
+    if (K->ns > 0) {
+        pcs = malloc(sizeof(psd_cache) * K->ns);
+        int off = K->z + K->l; for (int q = 0; q < K->nq; q++) off += K->q[q];
+        for (int cidx = 0; cidx < K->ns; cidx++) { int k = K->s[cidx]; double *S = malloc(sizeof(double) * k * k);
+            pcs[cidx].V = malloc(sizeof(double) * k * k); pcs[cidx].w = malloc(sizeof(double) * k);
+            svec_to_mat(v + off, k, S); jacobi_eig(S, k, pcs[cidx].w, pcs[cidx].V); free(S); off += k * (k + 1) / 2; }
+    }
+    adj_op op = { n, m, A, b, c, v, K, pcs, t1, t2 };
+    /* dz = (dx, DPi^T (dy + ds) - ds, -(x.dx + y.dy + s.ds)) */
+    memcpy(dz, dx, sizeof(double) * n);
+    for (int i = 0; i < m; i++) t3[i] = dy[i] + (ds ? ds[i] : 0);
+    dproj_dual_cone(v, K, pcs, t3, dz + n);
+    double dw = -(dot(x, dx, n) + dot(y, dy, m));
+    if (ds) { for (int i = 0; i < m; i++) dz[n + i] -= ds[i]; dw -= dot(s, ds, m); }
+    dz[N - 1] = dw;
+    int itn = 0;
+    if (norm_inf(dz, N) == 0) memset(r, 0, sizeof(double) * N);
+    else if (o->adj_mode == 1) dense_solve_MT(&op, dz, N, r);
+    else itn = lsqr_MT(&op, dz, N, r, o, work);
+    /* dQ = r Pi(z)^T antisymmetrised, Pi(z) = (x, y, 1) */
+    const double *rx = r, *ry = r + n; double rt = r[N - 1];
+    for (int i = 0; i < m; i++) for (int j = 0; j < n; j++) dA[(size_t)i * n + j] = x[j] * ry[i] - y[i] * rx[j];
+    for (int i = 0; i < m; i++) db[i] = y[i] * rt - ry[i];
+    for (int j = 0; j < n; j++) dc[j] = x[j] * rt - rx[j];
+    if (pcs) { for (int cidx = 0; cidx < K->ns; cidx++) { free(pcs[cidx].V); free(pcs[cidx].w); } free(pcs); }
+    free(buf);
+    return itn;
+}
+
+/* ------------------------------------------------------------------ batch entry points (ctypes) */
+int oc_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/* A: [B][m][n] row-major dense, b: [B][m], c: [B][n]; outputs x [B][n], y,s [B][m], iters/status [B], resid [B][3] */
+int oc_solve_batch(int B, int n, int m, const double *A, const double *b, const double *c,
+                   int z, int l, int nq, const int *q, int ns, const int *s, const oc_opts *o,
+                   double *x, double *y, double *sv, int *iters, int *status, double *resid, int nthreads) {
+    oc_cones K = { z, l, nq, ns, q, s };
+    if (cone_rows(&K) != m) return -1;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+    #pragma omp parallel for schedule(dynamic, 1)
+    for (int i = 0; i < B; i++) {
+        oc_info info; memset(&info, 0, sizeof(info));
+        solve_one(n, m, A + (size_t)i * m * n, b + (size_t)i * m, c + (size_t)i * n, &K, o, x + (size_t)i * n, y + (size_t)i * m, sv + (size_t)i * m, &info);
+        iters[i] = info.iters; status[i] = info.status;
+        if (resid) { resid[3 * i] = info.res_pri; resid[3 * i + 1] = info.res_dual; resid[3 * i + 2] = info.gap; }
+    }
+    return 0;
+}
+
+/* ds may be NULL (the layer passes ds = 0, diffcp_if.py:84).  dA: [B][m][n] dense. lsqr_iters may be NULL. */
+int oc_adjoint_batch(int B, int n, int m, const double *A, const double *b, const double *c,
+                     int z, int l, int nq, const int *q, int ns, const int *s, const oc_opts *o,
+                     const double *x, const double *y, const double *sv, const double *dx, const double *dy, const double *ds,
+                     double *dA, double *db, double *dc, int *lsqr_iters, int nthreads) {
+    oc_cones K = { z, l, nq, ns, q, s };
+    if (cone_rows(&K) != m) return -1;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+    #pragma omp parallel for schedule(dynamic, 1)
+    for (int i = 0; i < B; i++) {
+        int it = adjoint_one(n, m, A + (size_t)i * m * n, b + (size_t)i * m, c + (size_t)i * n, &K, o,
+                             x + (size_t)i * n, y + (size_t)i * m, sv + (size_t)i * m, dx + (size_t)i * n, dy + (size_t)i * m,
+                             ds ? ds + (size_t)i * m : NULL, dA + (size_t)i * m * n, db + (size_t)i * m, dc + (size_t)i * n);
+        if (lsqr_iters) lsqr_iters[i] = it;
+    }
+    return 0;
+}

@@ -1,0 +1,120 @@
+"""ctypes wrapper around oracle/libcone_oracle.so  --  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module
+(see the header of cone_oracle.c).  The product path (cvxpylayers_amd/) never does.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+STATUS_NAMES = {1: "solved", 2: "solved_inaccurate", -1: "unbounded", -2: "infeasible",
+                -6: "unbounded_inaccurate", -7: "infeasible_inaccurate", -4: "failed", 0: "unfinished"}
+
+
+class Opts(C.Structure):
+    _fields_ = [("eps_abs", C.c_double), ("eps_rel", C.c_double), ("eps_infeas", C.c_double),
+                ("alpha", C.c_double), ("rho_x", C.c_double), ("scale", C.c_double),
+                ("max_iters", C.c_int), ("normalize", C.c_int), ("adaptive_scale", C.c_int),
+                ("adj_mode", C.c_int), ("lsqr_atol", C.c_double), ("lsqr_btol", C.c_double),
+                ("lsqr_conlim", C.c_double), ("lsqr_iter_lim", C.c_int)]
+
+
+def build(force: bool = False) -> str:
+    so = os.path.join(_HERE, "libcone_oracle.so")
+    src = os.path.join(_HERE, "cone_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libcone_oracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.oc_default_opts.argtypes = [C.POINTER(Opts)]
+        _LIB.oc_num_threads.restype = C.c_int
+    return _LIB
+
+
+def make_opts(**kw) -> Opts:
+    """Accepts the reference's solver_args keys (eps, max_iters, ...; diffcp maps eps -> eps_abs & eps_rel)."""
+    o = Opts()
+    lib().oc_default_opts(C.byref(o))
+    kw = dict(kw)
+    if "eps" in kw:
+        e = kw.pop("eps")
+        o.eps_abs = e
+        o.eps_rel = e
+    mode = kw.pop("mode", None)
+    if mode is not None:
+        o.adj_mode = {"lsqr": 0, "dense": 1}[mode]
+    kw.pop("acceleration_lookback", None)  # Anderson acceleration is not restated (off on both sides)
+    kw.pop("verbose", None)
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise KeyError(f"unknown oracle option {k}")
+        setattr(o, k, v)
+    return o
+
+
+def _p(a, t=C.c_double):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def _cones(cones):
+    q = np.ascontiguousarray(cones.get("q", []), dtype=np.int32)
+    s = np.ascontiguousarray(cones.get("s", []), dtype=np.int32)
+    return int(cones.get("z", 0)), int(cones.get("l", 0)), q, s
+
+
+def solve_batch(A, b, c, cones, nthreads=0, **opts):
+    """A (B,m,n) dense, b (B,m), c (B,n) float64.  Returns dict(x,y,s,iters,status,resid)."""
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    c = np.ascontiguousarray(c, dtype=np.float64)
+    B, m, n = A.shape
+    z, l, q, s = _cones(cones)
+    o = make_opts(**opts)
+    x = np.empty((B, n)); y = np.empty((B, m)); sv = np.empty((B, m))
+    iters = np.zeros(B, dtype=np.int32); status = np.zeros(B, dtype=np.int32); resid = np.zeros((B, 3))
+    rc = lib().oc_solve_batch(B, n, m, _p(A), _p(b), _p(c), z, l, len(q), _p(q, C.c_int), len(s), _p(s, C.c_int),
+                              C.byref(o), _p(x), _p(y), _p(sv), _p(iters, C.c_int), _p(status, C.c_int), _p(resid),
+                              int(nthreads))
+    if rc != 0:
+        raise ValueError("cone dims do not match m")
+    return dict(x=x, y=y, s=sv, iters=iters, status=status, resid=resid)
+
+
+def adjoint_batch(A, b, c, cones, x, y, s, dx, dy, ds=None, nthreads=0, **opts):
+    """diffcp adj_batch restatement: returns dA (B,m,n) dense, db (B,m), dc (B,n), lsqr_iters (B,)."""
+    A = np.ascontiguousarray(A, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    c = np.ascontiguousarray(c, dtype=np.float64)
+    B, m, n = A.shape
+    z, l, q, sd = _cones(cones)
+    o = make_opts(**opts)
+    x = np.ascontiguousarray(x, dtype=np.float64); y = np.ascontiguousarray(y, dtype=np.float64)
+    s = np.ascontiguousarray(s, dtype=np.float64)
+    dx = np.ascontiguousarray(dx, dtype=np.float64); dy = np.ascontiguousarray(dy, dtype=np.float64)
+    dsp = None
+    if ds is not None:
+        ds = np.ascontiguousarray(ds, dtype=np.float64)
+        dsp = _p(ds)
+    dA = np.empty((B, m, n)); db = np.empty((B, m)); dc = np.empty((B, n)); it = np.zeros(B, dtype=np.int32)
+    rc = lib().oc_adjoint_batch(B, n, m, _p(A), _p(b), _p(c), z, l, len(q), _p(q, C.c_int), len(sd), _p(sd, C.c_int),
+                                C.byref(o), _p(x), _p(y), _p(s), _p(dx), _p(dy), dsp, _p(dA), _p(db), _p(dc),
+                                _p(it, C.c_int), int(nthreads))
+    if rc != 0:
+        raise ValueError("cone dims do not match m")
+    return dict(dA=dA, db=db, dc=dc, lsqr_iters=it)
+
+
+def num_threads() -> int:
+    return int(lib().oc_num_threads())

@@ -1,0 +1,125 @@
+"""Hand-canonicalised known-answer cone programs (no CVXPY), restating the closed-form cases the
+reference's own tests assert (SURVEY.md section 8c list).  Each builder returns solver-form dense
+(A (m,n), b (m,), c (n,), cones) plus whatever closed form the case has.
+
+Rotated-cone trick used throughout:  ||r||^2 <= t   <=>   ||(1 - t, 2 r)|| <= 1 + t,
+i.e. s = (1 + t, 1 - t, 2 r) in SOC(len(r) + 2).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def _soc_sumsq_rows(R, r0, tcol, nvar):
+    """rows of  s = (1 + t, 1 - t, 2 (R x + r0)) = b - A x   for variable vector of length nvar (t at column tcol)."""
+    k = R.shape[0]
+    A = np.zeros((k + 2, nvar))
+    b = np.zeros(k + 2)
+    A[0, tcol] = -1.0; b[0] = 1.0          # s0 = 1 + t
+    A[1, tcol] = 1.0; b[1] = 1.0           # s1 = 1 - t
+    A[2:, :R.shape[1]] = -2.0 * R; b[2:] = 2.0 * r0
+    return A, b
+
+
+def ridge_ls(F, g):
+    """min ||F x - g||^2 + ||x||^2  (reference tests/test_torch.py:90-118).  vars (x, t1, t2).
+    closed form x = (F^T F + I)^{-1} F^T g."""
+    mF, n = F.shape
+    nv = n + 2
+    A1, b1 = _soc_sumsq_rows(F, -g, n, nv)
+    A2, b2 = _soc_sumsq_rows(np.eye(n), np.zeros(n), n + 1, nv)
+    A = np.vstack([A1, A2]); b = np.concatenate([b1, b2])
+    c = np.zeros(nv); c[n] = 1; c[n + 1] = 1
+    cones = {"z": 0, "l": 0, "q": [mF + 2, n + 2]}
+    x = np.linalg.solve(F.T @ F + np.eye(n), F.T @ g)
+    return A, b, c, cones, x
+
+
+def min_norm_eq(F, g):
+    """min ||x||^2 s.t. F x = g  (tests/test_diffcp_optional_deps.py:30-58) -> x = F^T (F F^T)^{-1} g. vars (x, t)."""
+    k, n = F.shape
+    nv = n + 1
+    Az = np.zeros((k, nv)); Az[:, :n] = F
+    A2, b2 = _soc_sumsq_rows(np.eye(n), np.zeros(n), n, nv)
+    A = np.vstack([Az, A2]); b = np.concatenate([g, b2])
+    c = np.zeros(nv); c[n] = 1
+    cones = {"z": k, "l": 0, "q": [n + 2]}
+    x = F.T @ np.linalg.solve(F @ F.T, g)
+    return A, b, c, cones, x
+
+
+def box_qp(t):
+    """min ||x - t||^2 s.t. 0 <= x <= 1 -> clip(t, 0, 1)  (tests/test_moreau.py:258-269). vars (x, u)."""
+    n = len(t); nv = n + 1
+    Al = np.zeros((2 * n, nv)); bl = np.zeros(2 * n)
+    Al[:n, :n] = -np.eye(n)                   # x >= 0  : s = x
+    Al[n:, :n] = np.eye(n); bl[n:] = 1.0      # x <= 1  : s = 1 - x
+    A2, b2 = _soc_sumsq_rows(np.eye(n), -np.asarray(t, float), n, nv)
+    A = np.vstack([Al, A2]); b = np.concatenate([bl, b2])
+    c = np.zeros(nv); c[n] = 1
+    return A, b, c, {"z": 0, "l": 2 * n, "q": [n + 2]}, np.clip(t, 0, 1)
+
+
+def relu_proj(t):
+    """min ||x - t||^2 s.t. x >= 0 -> max(t, 0), d x/d t = 1[t>0]  (tests/test_mlx.py:669-695)."""
+    n = len(t); nv = n + 1
+    Al = np.zeros((n, nv)); Al[:, :n] = -np.eye(n)
+    A2, b2 = _soc_sumsq_rows(np.eye(n), -np.asarray(t, float), n, nv)
+    A = np.vstack([Al, A2]); b = np.concatenate([np.zeros(n), b2])
+    c = np.zeros(nv); c[n] = 1
+    return A, b, c, {"z": 0, "l": n, "q": [n + 2]}, np.maximum(t, 0)
+
+
+def simplex_lp(cvec, total=1.0):
+    """min c^T x s.t. sum x = total, x >= 0 (tests/test_dual_variables.py:14-42): vertex at argmin c."""
+    n = len(cvec)
+    A = np.vstack([np.ones((1, n)), -np.eye(n)]); b = np.concatenate([[total], np.zeros(n)])
+    x = np.zeros(n); x[int(np.argmin(cvec))] = total
+    return A, b, np.asarray(cvec, float), {"z": 1, "l": n, "q": []}, x
+
+
+def soc_lin(cvec, t):
+    """min c^T x s.t. ||x|| <= t -> x = -t c/||c||  (tests/test_dual_variables.py:316-343).  s = (t, x)."""
+    n = len(cvec)
+    A = np.vstack([np.zeros((1, n)), -np.eye(n)]); b = np.concatenate([[t], np.zeros(n)])
+    cvec = np.asarray(cvec, float)
+    return A, b, cvec, {"z": 0, "l": 0, "q": [n + 1]}, -t * cvec / np.linalg.norm(cvec)
+
+
+def svec_index(k):
+    idx = {}
+    p = 0
+    for j in range(k):
+        for i in range(j, k):
+            idx[(i, j)] = p; idx[(j, i)] = p; p += 1
+    return idx
+
+
+def sdp_min_eig(Cm):
+    """min tr(C X) s.t. tr X = 1, X PSD -> X = v v^T (min eigvec), dual of PSD constraint = C - lmin I
+    (tests/test_dual_variables.py:523-550).  x = svec(X) scaled: variable is svec (sqrt2 off-diag)."""
+    k = Cm.shape[0]; d = k * (k + 1) // 2
+    idx = svec_index(k)
+    c = np.zeros(d); tr = np.zeros(d)
+    for j in range(k):
+        for i in range(j, k):
+            p = idx[(i, j)]
+            c[p] = Cm[i, j] * (1.0 if i == j else np.sqrt(2.0))
+            if i == j:
+                tr[p] = 1.0
+    A = np.vstack([tr[None, :], -np.eye(d)]); b = np.concatenate([[1.0], np.zeros(d)])
+    w, V = np.linalg.eigh(Cm)
+    X = np.outer(V[:, 0], V[:, 0])
+    return A, b, c, {"z": 1, "l": 0, "q": [], "s": [k]}, X, Cm - w[0] * np.eye(k)
+
+
+def infeasible():
+    """x >= 1 and x <= -1  (tests/test_torch.py:299-316)."""
+    A = np.array([[-1.0], [1.0]]); b = np.array([-1.0, -1.0]); c = np.array([0.0])
+    return A, b, c, {"z": 0, "l": 2, "q": []}
+
+
+def unbounded(p=1.0):
+    """min x s.t. x <= p."""
+    A = np.array([[1.0]]); b = np.array([p]); c = np.array([1.0])
+    return A, b, c, {"z": 0, "l": 1, "q": []}

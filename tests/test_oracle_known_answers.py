@@ -1,0 +1,146 @@
+"""Pins the CPU oracle (oracle/cone_oracle.c) against every closed-form known-answer case the
+reference's own tests hold for this path and against central finite differences.
+The reference stores no golden vectors and cannot run here, so these are the oracle's pin."""
+import numpy as np
+import pytest
+
+import kit
+from oracle import oracle
+
+TIGHT = dict(eps=1e-10, max_iters=100000)
+
+
+def solve1(A, b, c, cones, **kw):
+    r = oracle.solve_batch(A[None], b[None], c[None], cones, **{**TIGHT, **kw})
+    return r["x"][0], r["y"][0], r["s"][0], int(r["status"][0]), int(r["iters"][0])
+
+
+def test_ridge_ls_value_and_gradient():
+    # reference tests/test_torch.py:90-118 (m=100, n=20, seed 243, eps=1e-10, atol 1e-6)
+    rng = np.random.default_rng(243)
+    F = rng.standard_normal((100, 20)); g = rng.standard_normal(100)
+    A, b, c, cones, xstar = kit.ridge_ls(F, g)
+    x, y, s, st, it = solve1(A, b, c, cones)
+    assert st == 1
+    np.testing.assert_allclose(x[:20], xstar, atol=1e-6)
+    # gradient of sum(x) wrt g:  d x/d g = (F^T F + I)^{-1} F^T  -> d sum/d g = F (F^T F + I)^{-1} 1
+    dx = np.zeros_like(x); dx[:20] = 1.0
+    gr = oracle.adjoint_batch(A[None], b[None], c[None], cones, x[None], y[None], s[None], dx[None], np.zeros_like(y)[None], mode="dense")
+    # b rows 2..102 of the first SOC are 2*(-g)  => d/dg = -2 * db[2:102]
+    dg = -2.0 * gr["db"][0][2:102]
+    np.testing.assert_allclose(dg, F @ np.linalg.solve(F.T @ F + np.eye(20), np.ones(20)), atol=1e-6)
+
+
+def test_min_norm_equality():
+    A, b, c, cones, xstar = kit.min_norm_eq(np.array([[1.0, 1.0]]), np.array([2.0]))
+    x, *_ , st, it = solve1(A, b, c, cones)
+    assert st == 1
+    np.testing.assert_allclose(x[:2], [1.0, 1.0], atol=1e-6)
+    rng = np.random.default_rng(0)
+    F = rng.standard_normal((3, 7)); g = rng.standard_normal(3)
+    A, b, c, cones, xstar = kit.min_norm_eq(F, g)
+    x, *_ , st, it = solve1(A, b, c, cones)
+    np.testing.assert_allclose(x[:7], xstar, atol=1e-6)
+
+
+def test_box_qp_clip():
+    A, b, c, cones, xstar = kit.box_qp(np.array([2.0, 0.5, -1.0]))
+    x, *_ , st, it = solve1(A, b, c, cones)
+    assert st == 1
+    np.testing.assert_allclose(x[:3], xstar, atol=1e-5)
+
+
+def test_relu_projection_and_gradient():
+    t = np.linspace(-5, 5, 21)
+    A, b, c, cones, xstar = kit.relu_proj(t)
+    x, y, s, st, it = solve1(A, b, c, cones)
+    assert st == 1
+    np.testing.assert_allclose(x[:21], xstar, atol=1e-5)
+    dx = np.zeros_like(x); dx[:21] = 1.0
+    gr = oracle.adjoint_batch(A[None], b[None], c[None], cones, x[None], y[None], s[None], dx[None], np.zeros_like(y)[None], mode="dense")
+    # t enters b rows (21+2 ...) as 2*(-t): d/dt = -2*db
+    dt = -2.0 * gr["db"][0][21 + 2:]
+    mask = np.abs(t) > 1e-3
+    np.testing.assert_allclose(dt[mask], (t > 0).astype(float)[mask], atol=1e-4)
+
+
+def test_simplex_lp_vertex_and_duals():
+    A, b, c, cones, xstar = kit.simplex_lp(np.array([1.0, 2.0]))
+    x, y, s, st, it = solve1(A, b, c, cones)
+    assert st == 1
+    np.testing.assert_allclose(x, [1.0, 0.0], atol=1e-6)
+    # KKT: A^T y + c = 0, equality dual nu = -1, reduced costs (0, 1)
+    np.testing.assert_allclose(y, [-1.0, 0.0, 1.0], atol=1e-6)
+
+
+def test_soc_linear():
+    A, b, c, cones, xstar = kit.soc_lin(np.array([1.0, 0.5, -0.5]), 2.0)
+    x, y, s, st, it = solve1(A, b, c, cones)
+    assert st == 1
+    np.testing.assert_allclose(x, xstar, atol=1e-6)
+    np.testing.assert_allclose(s, np.concatenate([[2.0], xstar]), atol=1e-6)
+
+
+def test_sdp_min_eig():
+    Cm = np.array([[1.0, 0.5], [0.5, 2.0]])
+    A, b, c, cones, X, Zdual = kit.sdp_min_eig(Cm)
+    x, y, s, st, it = solve1(A, b, c, cones)
+    assert st == 1
+    from cvxpylayers_amd.problems import svec_to_sym
+    np.testing.assert_allclose(svec_to_sym(x, 2), X, atol=1e-5)
+    np.testing.assert_allclose(svec_to_sym(y[1:], 2), Zdual, atol=1e-5)
+    rng = np.random.default_rng(1)
+    G = rng.standard_normal((4, 4)); Cm = G + G.T
+    A, b, c, cones, X, Zdual = kit.sdp_min_eig(Cm)
+    x, y, s, st, it = solve1(A, b, c, cones)
+    np.testing.assert_allclose(svec_to_sym(x, 4), X, atol=1e-5)
+
+
+def test_infeasible_and_unbounded_status():
+    A, b, c, cones = kit.infeasible()
+    *_, st, it = solve1(A, b, c, cones, eps=1e-6)
+    assert st == -2
+    A, b, c, cones = kit.unbounded()
+    *_, st, it = solve1(A, b, c, cones, eps=1e-6)
+    assert st == -1
+
+
+def test_max_iters_one_gives_inaccurate_not_error():
+    # reference tests/test_torch.py:705-752: max_iters=1 must return (an unconverged) answer
+    A, b, c, cones, xstar = kit.box_qp(np.array([2.0, 0.5, -1.0]))
+    x, y, s, st, it = solve1(A, b, c, cones, max_iters=1)
+    assert st == 2 and it == 1
+    assert np.abs(x[:3] - xstar).max() > 1e-3
+
+
+@pytest.mark.parametrize("cones,n", [({"z": 3, "l": 8, "q": [5, 4]}, 10), ({"z": 0, "l": 4, "q": [3], "s": [3]}, 8)])
+def test_adjoint_matches_finite_differences(cones, n):
+    from cvxpylayers_amd import problems as P
+    A, b, c = P.generate(n, cones, 1, seed=3)
+    r = oracle.solve_batch(A, b, c, cones, eps=1e-12, max_iters=200000)
+    assert r["status"][0] == 1
+    x, y, s = r["x"], r["y"], r["s"]
+    rng = np.random.default_rng(5)
+    dx = rng.standard_normal(x.shape); dy = rng.standard_normal(y.shape)
+    g = oracle.adjoint_batch(A, b, c, cones, x, y, s, dx, dy, mode="dense")
+    gl = oracle.adjoint_batch(A, b, c, cones, x, y, s, dx, dy, mode="lsqr", lsqr_iter_lim=5000, lsqr_atol=1e-13, lsqr_btol=1e-13)
+
+    def f(A_, b_, c_):
+        rr = oracle.solve_batch(A_, b_, c_, cones, eps=1e-12, max_iters=200000)
+        return float((rr["x"] * dx).sum() + (rr["y"] * dy).sum())
+    h = 1e-6
+    for k in range(0, b.shape[1], 3):
+        bp = b.copy(); bp[0, k] += h; bm = b.copy(); bm[0, k] -= h
+        fd = (f(A, bp, c) - f(A, bm, c)) / (2 * h)
+        assert abs(fd - g["db"][0, k]) < 2e-5 * (1 + abs(fd)), (k, fd, g["db"][0, k])
+    for k in range(0, n, 3):
+        cp = c.copy(); cp[0, k] += h; cm = c.copy(); cm[0, k] -= h
+        fd = (f(A, b, cp) - f(A, b, cm)) / (2 * h)
+        assert abs(fd - g["dc"][0, k]) < 2e-5 * (1 + abs(fd)), (k, fd, g["dc"][0, k])
+    for (i, j) in [(0, 0), (2, 5), (A.shape[1] - 1, n - 1), (5, 1)]:
+        Ap = A.copy(); Ap[0, i, j] += h; Am = A.copy(); Am[0, i, j] -= h
+        fd = (f(Ap, b, c) - f(Am, b, c)) / (2 * h)
+        assert abs(fd - g["dA"][0, i, j]) < 2e-5 * (1 + abs(fd)), (i, j, fd, g["dA"][0, i, j])
+    # LSQR (diffcp default mode) converges to the same gradient
+    for k in ("dA", "db", "dc"):
+        np.testing.assert_allclose(gl[k], g[k], atol=1e-6 * (1 + np.abs(g[k]).max()))
