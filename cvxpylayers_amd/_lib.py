@@ -1,0 +1,79 @@
+"""ctypes binding of the C ABI declared in include/cone_engine.h (csrc/libcone_engine.so).
+
+There is NO fallback: if the HIP library is missing or fails to load this raises, loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "csrc", "libcone_engine.so")
+
+# every symbol include/cone_engine.h declares
+SYMBOLS = ["ce_default_settings", "ce_create", "ce_destroy", "ce_last_error", "ce_solve", "ce_vjp",
+           "ce_transpose", "ce_set_profiling", "ce_get_profile", "ce_reset_profile", "ce_get_launch_info"]
+
+
+class CeTemplate(C.Structure):
+    _fields_ = [("n", C.c_int), ("m", C.c_int), ("nnz_aug", C.c_int), ("indices", C.POINTER(C.c_int)),
+                ("indptr", C.POINTER(C.c_int)), ("z", C.c_int), ("l", C.c_int), ("nq", C.c_int),
+                ("q", C.POINTER(C.c_int)), ("ns", C.c_int), ("s", C.POINTER(C.c_int)), ("nep", C.c_int),
+                ("np", C.c_int)]
+
+
+class CeSettings(C.Structure):
+    _fields_ = [("eps_abs", C.c_double), ("eps_rel", C.c_double), ("eps_infeas", C.c_double), ("alpha", C.c_double),
+                ("rho_x", C.c_double), ("scale", C.c_double), ("max_iters", C.c_int), ("normalize", C.c_int),
+                ("adaptive_scale", C.c_int), ("reserved", C.c_int)]
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "csrc", "cone_engine.hip")
+    hdr = os.path.join(_HERE, "..", "include", "cone_engine.h")
+    stale = (not os.path.exists(SO_PATH) or os.path.getmtime(SO_PATH) < os.path.getmtime(src)
+             or os.path.getmtime(SO_PATH) < os.path.getmtime(hdr))
+    if force or stale:
+        subprocess.check_call([os.path.join(_HERE, "csrc", "build.sh")])
+    return SO_PATH
+
+
+_LIB = None
+
+
+def lib():
+    """Loads csrc/libcone_engine.so.  Raises (never falls back) when it is absent."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(SO_PATH):
+        raise RuntimeError(
+            f"{SO_PATH} is missing: the HIP engine is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(cvxpylayers_amd has no CPU fallback).")
+    L = C.CDLL(SO_PATH)
+    vp, dp, ip, lg = C.c_void_p, C.c_void_p, C.c_void_p, C.c_long
+    L.ce_default_settings.argtypes = [C.POINTER(CeSettings)]
+    L.ce_default_settings.restype = None
+    L.ce_create.argtypes = [C.POINTER(CeTemplate), C.c_int, C.POINTER(vp)]
+    L.ce_destroy.argtypes = [vp]
+    L.ce_last_error.restype = C.c_char_p
+    L.ce_solve.argtypes = [vp, C.c_int, dp, lg, lg, dp, lg, lg, C.POINTER(CeSettings), dp, dp, dp, ip, ip, dp, vp]
+    L.ce_vjp.argtypes = [vp, C.c_int, dp, lg, lg, dp, lg, lg, dp, dp, dp, dp, dp, dp, lg, lg, dp, lg, lg, ip, vp]
+    L.ce_transpose.argtypes = [vp, C.c_int, C.c_int, dp, dp, vp]
+    L.ce_set_profiling.argtypes = [vp, C.c_int]
+    L.ce_get_profile.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    L.ce_reset_profile.argtypes = [vp]
+    L.ce_get_launch_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    _LIB = L
+    return L
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = lib().ce_last_error()
+        raise EngineError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,130 @@
+/*
+ * cone_engine.h -- C ABI of the MI355X-native batched cone-program solve + differentiate engine.
+ *
+ * This is the drop-in boundary underneath the Python solver plugin
+ * (cvxpylayers_amd/interfaces/mi355_if.py), which mirrors the reference plugin
+ * cvxpylayers/interfaces/diffcp_if.py.  The reference has NO FFI for this path (its arithmetic is
+ * in the third-party diffcp/SCS packages, reached through Python calls), so every entry point
+ * below cites the reference *call site* whose work it replaces:
+ *
+ *   ce_create   <- DIFFCP_ctx.__init__            (diffcp_if.py:105-120; interfaces/__init__.py:26-33)
+ *                  : keeps the CSC structure of the augmented matrix [A_cvx | b_cvx] and the cone dims.
+ *   ce_solve    <- _build_diffcp_matrices + diffcp.solve_and_derivative_batch / solve_only_batch
+ *                  (diffcp_if.py:46-70, 365-372): cuts (A,b,c) out of A_eval / q_eval, A = -A_cvx,
+ *                  solves every instance, returns primal (B,n), dual (B,m) (+ slack, status).
+ *   ce_vjp      <- _compute_gradients -> adj_batch(dxs, dys, dss=0)   (diffcp_if.py:73-96, 385-403):
+ *                  returns d/dA_eval = [-dA.data, db[b_idx]] and d/dq_eval = [dc, 0].
+ *   ce_destroy  <- (garbage collection of DIFFCP_ctx)
+ *
+ * All data pointers are CALLER-OWNED DEVICE memory (fp64 / int32), valid on the device the handle
+ * was created for; `stream` is a hipStream_t (NULL = default stream).  Calls only enqueue work:
+ * there is no hidden host synchronisation.  The handle owns workspace only and is not thread-safe
+ * (reference contract: one layer, one caller thread -- moreau_if.py:14-15).
+ * Return value: 0 on success, negative CE_E_* otherwise; per-instance solver status is written to
+ * `status[]` with SCS's codes (1 solved, 2 solved/inaccurate, -1 unbounded, -2 infeasible,
+ * -6/-7 inaccurate certificates, -4 failed).
+ */
+#ifndef CONE_ENGINE_H
+#define CONE_ENGINE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ce_engine *ce_handle;
+
+enum {
+    CE_OK = 0,
+    CE_E_BADARG = -1,        /* inconsistent template / null pointer */
+    CE_E_UNSUPPORTED = -2,   /* cone type not implemented on the device path (exp / power / PSD in this round) */
+    CE_E_TOO_LARGE = -3,     /* instance does not fit the implemented residency modes */
+    CE_E_HIP = -4,           /* a HIP runtime call failed (ce_last_error has the string) */
+    CE_E_STATE = -5          /* ce_vjp called without the retained forward state it was asked to reuse */
+};
+
+/* One-time, host-side description of the canonical template (what CVXPY's ParamConeProg gives a plugin). */
+typedef struct {
+    int n;                 /* canonical variables */
+    int m;                 /* cone rows */
+    int nnz_aug;           /* structural non-zeros of the augmented m x (n+1) matrix [A_cvx | b_cvx] */
+    const int *indices;    /* [nnz_aug] CSC row indices   (HOST memory) */
+    const int *indptr;     /* [n+2]     CSC column starts (HOST memory); column n holds b */
+    int z;                 /* zero-cone rows    (dims_to_solver_dict key "z") */
+    int l;                 /* nonnegative rows  ("l") */
+    int nq;                /* number of second-order cones */
+    const int *q;          /* [nq] SOC dimensions ("q"), layout (t, x) */
+    int ns;                /* number of PSD cones ("s") */
+    const int *s;          /* [ns] PSD orders; svec lower-tri column-major, sqrt(2) off-diagonals */
+    int nep;               /* exponential cones ("ep")  -- must be 0 this round */
+    int np;                /* power cones ("p")         -- must be 0 this round */
+} ce_template;
+
+/* Solver settings; names follow SCS / diffcp keyword arguments (diffcp maps eps -> eps_abs, eps_rel). */
+typedef struct {
+    double eps_abs, eps_rel, eps_infeas;
+    double alpha;          /* over-relaxation, 1.5 */
+    double rho_x;          /* 1e-6 */
+    double scale;          /* initial dual scale, 0.1 */
+    int max_iters;         /* 100000 */
+    int normalize;         /* Ruiz + l2 equilibration, 1 */
+    int adaptive_scale;    /* 1 */
+    int reserved;
+} ce_settings;
+
+void ce_default_settings(ce_settings *s);
+
+int ce_create(const ce_template *tpl, int device, ce_handle *out);
+int ce_destroy(ce_handle h);
+const char *ce_last_error(void);
+
+/*
+ * Forward.  Element (k, i) of the reference's A_eval (nnz_aug x B) is read at A_vals[k*sA_k + i*sA_b];
+ * element (k, i) of q_eval ((n+1) x B) at q_vals[k*sq_k + i*sq_b] (strides in elements), so both the
+ * reference layout (batch-minor: sA_k = B, sA_b = 1) and the engine-native batch-major layout
+ * (sA_k = 1, sA_b = nnz_aug) are accepted; the former costs one transpose pass.
+ * Outputs (row-major, contiguous): x [B][n], y [B][m], s [B][m]; iters [B], status [B] int32;
+ * resid [B][3] = (primal residual, dual residual, gap) or NULL.
+ * The batch-major copy of A_vals and (x,y,s) pointers are retained for ce_vjp(reuse_forward=1).
+ */
+int ce_solve(ce_handle h, int B,
+             const double *A_vals, long sA_k, long sA_b,
+             const double *q_vals, long sq_k, long sq_b,
+             const ce_settings *settings,
+             double *x, double *y, double *s, int *iters, int *status, double *resid,
+             void *stream);
+
+/*
+ * Backward (vector-Jacobian product), diffcp adjoint with ds = 0 (diffcp_if.py:84).
+ * dx [B][n], dy [B][m] contiguous.  Gradients are written in the *boundary* convention
+ * dA_vals (k, i) at [k*sdA_k + i*sdA_b] = [-dA.data, db[b_idx]],  dq_vals (k,i) at [k*sdq_k + i*sdq_b] = [dc, 0].
+ * If A_vals == NULL the batch-major copy retained by the last ce_solve on this handle is used.
+ * adj_status [B] (or NULL): 0 ok, 1 = active set larger than the direct solve supports / singular pivot.
+ */
+int ce_vjp(ce_handle h, int B,
+           const double *A_vals, long sA_k, long sA_b,
+           const double *q_vals, long sq_k, long sq_b,
+           const double *x, const double *y, const double *s,
+           const double *dx, const double *dy,
+           double *dA_vals, long sdA_k, long sdA_b,
+           double *dq_vals, long sdq_k, long sdq_b,
+           int *adj_status,
+           void *stream);
+
+/* Layout helper: out (cols x rows, row-major) = transpose of in (rows x cols, row-major), fp64, caller-owned
+ * device buffers.  Used by the plugin to turn the reference's batch-minor A_eval (nnz_aug x B) into the
+ * engine-native batch-major (B x nnz_aug) once, into a tensor it keeps for backward. */
+int ce_transpose(ce_handle h, int rows, int cols, const double *in, double *out, void *stream);
+
+/* Introspection used by bench.py / tests: per-kernel HIP-event timing on the launch stream. */
+int ce_set_profiling(ce_handle h, int enable);
+/* which: 0 forward kernel, 1 backward kernel, 2 layout (transpose) kernels.  Returns the mean ms per launch
+ * since the last ce_reset_profile and the launch count; synchronises the recorded events. */
+int ce_get_profile(ce_handle h, int which, double *mean_ms, int *launches);
+int ce_reset_profile(ce_handle h);
+/* LDS bytes per workgroup and residency mode chosen for (forward, backward); for DESIGN/bench reporting. */
+int ce_get_launch_info(ce_handle h, int *fwd_lds_bytes, int *bwd_lds_bytes, int *fwd_mode, int *bwd_mode);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CONE_ENGINE_H */
