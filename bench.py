@@ -1,0 +1,151 @@
+"""bench.py -- forward+backward problems/sec on the BASELINE.json metric configuration.
+
+One "step" = one pass of the hot path over one batch: the plugin boundary call
+    primal, dual = _CvxpyLayer.apply(None, q_eval, A_eval, ctx, solver_args, needs_grad=True)
+    primal.sum().backward()
+on B=4096 synthetic instances of the metric config (n=50, m=100: 20 nonneg rows + 8 SOC(10), dense A; A, b, c all
+batched) with q_eval / A_eval already resident in HBM in the reference's batch-minor layout.  The layout pass,
+the solve, the status read-back and the adjoint are all inside the timed region.
+N>1: each rank holds its own 4096 instances (weak scaling); the step includes the all-gather of primal/dual.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from cvxpylayers_amd import problems as P  # noqa: E402
+from cvxpylayers_amd.interfaces.mi355_if import MI355_ctx, _CvxpyLayer  # noqa: E402
+from cvxpylayers_amd.parallel import gather_rows  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+FP64_VALU_PEAK_TF = 78.6     # half the 157.3 TF fp32 vector peak
+
+
+def cpu_baseline(n, cones, solver_args, sample, seed):
+    """The oracle ("port": CPU restatement of the diffcp/SCS path, OpenMP over instances) timed on the host cores."""
+    from oracle import oracle
+    A, b, c = P.generate(n, cones, sample, seed=seed)
+    threads = oracle.num_threads()
+    oracle.solve_batch(A[:threads], b[:threads], c[:threads], cones, **solver_args)   # warm
+    t0 = time.perf_counter()
+    r = oracle.solve_batch(A, b, c, cones, **solver_args)
+    g = oracle.adjoint_batch(A, b, c, cones, r["x"], r["y"], r["s"], np.ones_like(r["x"]), np.zeros_like(r["y"]), mode="lsqr")
+    dt = time.perf_counter() - t0
+    return dict(value=sample / dt, unit="problems/s", cores=threads, kind="port",
+                sample=f"{sample} instances of the same workload, forward + LSQR adjoint (diffcp default mode), {dt:.2f} s",
+                mean_iters=float(r["iters"].mean()), mean_lsqr_iters=float(g["lsqr_iters"].mean()))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=4096)
+    ap.add_argument("--config", default="M")
+    ap.add_argument("--eps", type=float, default=1e-4, help="eps_abs=eps_rel (SCS default 1e-4)")
+    ap.add_argument("--cpu-sample", type=int, default=1024)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    cfg = P.CONFIGS[args.config]
+    n, cones, B = cfg["n"], cfg["cones"], args.batch
+    tpl = P.dense_template(n, cones)
+    solver_args = {"eps": args.eps, "max_iters": 10000, "acceleration_lookback": 0}
+    A, b, c = P.generate(n, cones, B, seed=rank)
+    A_eval, q_eval = tpl.values_from_dense(A, b, c)
+    ctx = MI355_ctx(None, tpl.problem_data_index, cones, options=solver_args)
+    A_t = torch.from_numpy(A_eval).to(dev).requires_grad_()      # (nnz_aug, B) batch-minor, as the frontend hands it over
+    q_t = torch.from_numpy(q_eval).to(dev).requires_grad_()
+    eng = ctx.engine(dev)
+
+    def step():
+        A_t.grad = None
+        q_t.grad = None
+        primal, dual, info, _ = _CvxpyLayer.apply(None, q_t, A_t, ctx, {}, True, None)
+        if world > 1:
+            primal = gather_rows(primal)
+            dual = gather_rows(dual)
+        primal.sum().backward()
+        return info
+
+    for _ in range(args.warmup):
+        info = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    eng.set_profiling(True)
+    eng.reset_profile()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        info = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tdt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
+        dt = float(tdt.item())
+    fwd_ms, nf = eng.profile(0)
+    bwd_ms, nb = eng.profile(1)
+    lay_ms, nl = eng.profile(2)
+    eng.set_profiling(False)
+
+    if rank == 0:
+        ms_per_step = 1e3 * dt / args.steps
+        value = world * B * args.steps / dt
+        m, nnzA = tpl.m, tpl.nnzA
+        iters = info["iters"].cpu().numpy().astype(np.float64)
+        # algorithmic HBM bytes per instance: forward 8(nnzA+m+n) read + 8(n+2m) written
+        fwd_bytes = 8 * (nnzA + m + n) + 8 * (n + 2 * m)
+        bwd_bytes = 8 * (nnzA + 2 * n + 3 * m) + 8 * (nnzA + m + n)
+        ach = fwd_bytes * B / (fwd_ms * 1e-3) / 1e9 if fwd_ms > 0 else 0.0
+        # algorithmic fp64 flops of the forward kernel: setup m n^2 + n^3/3, per iteration 4 nnzA + 2 n^2 + 10(n+m)
+        flops = B * (m * n * n + n ** 3 / 3.0) + float(iters.sum()) * (4 * nnzA + 2 * n * n + 10 * (n + m))
+        out = {
+            "metric": "forward+backward problems/sec, batch=4096 n=50 m=100 SOC", "value": value, "unit": "problems/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"config {args.config}: n={n} m={m} cones l={cones.get('l', 0)} q={cones.get('q', [])} dense A "
+                                   f"(nnzA={nnzA}), A,b,c batched, B={B} per GPU, eps_abs=eps_rel={args.eps}, max_iters=10000, "
+                                   "acceleration off; step = plugin forward (layout pass + solve + status) + backward (adjoint VJP of sum(x))",
+                       "batch_per_gpu": B, "parallelism": f"batch-shard x{world}"},
+            "roofline": {"bound": "hbm", "kernel": "k_forward", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                         "note": "LDS-resident iteration: one-touch HBM by construction; the binding resource is fp64 VALU / LDS bandwidth",
+                         "valu_f64": {"achieved": flops / (fwd_ms * 1e-3) / 1e12 if fwd_ms > 0 else 0.0, "peak": FP64_VALU_PEAK_TF,
+                                      "unit": "TFLOP/s", "frac": flops / (fwd_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TF if fwd_ms > 0 else 0.0}},
+            "kernels_ms": {"k_forward": fwd_ms, "k_backward": bwd_ms, "k_transpose": lay_ms, "launches": [nf, nb, nl],
+                           "bwd_algorithmic_GBps": bwd_bytes * B / (bwd_ms * 1e-3) / 1e9 if bwd_ms > 0 else 0.0},
+            "iters": {"mean": float(iters.mean()), "max": float(iters.max())},
+            "launch": eng.launch_info(),
+        }
+        if not args.no_cpu and world == 1:
+            out["cpu_baseline"] = cpu_baseline(n, cones, solver_args, args.cpu_sample, seed=0)
+            out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

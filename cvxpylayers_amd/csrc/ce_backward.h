@@ -1,0 +1,256 @@
+// ce_backward.h -- structured direct adjoint kernel
+#pragma once
+// ================================================================================================
+// BACKWARD
+// ================================================================================================
+// row kinds after classifying DPi_{K*}(v), v = y - s
+enum { RK_EQ = 0, RK_FREE = 1, RK_SOCB = 2 };
+
+template <bool A_LDS, bool K_LDS>
+__global__ void __launch_bounds__(NT)
+k_backward(DevT T, int nkcap, int ldk, const double *__restrict__ Avals, const double *__restrict__ xg,
+           const double *__restrict__ yg, const double *__restrict__ sg, const double *__restrict__ dxg,
+           const double *__restrict__ dyg, double *__restrict__ dAo, double *__restrict__ dqo, long sdqk, long sdqb,
+           int *__restrict__ adj_status, double *gwsA, double *gwsK) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int tid = threadIdx.x, inst = blockIdx.x;
+    const int n = T.n, m = T.m, lda = T.lda, nq = T.nq, z = T.z;
+    const int PB = max(NT, max(n, m));
+    const int nqs = nq > 0 ? nq : 1;
+
+    double *p = sm;
+    double *A, *K;
+    if constexpr (A_LDS) { A = p; p += m * lda; } else { A = gwsA + (size_t)inst * m * lda; }
+    if constexpr (K_LDS) { K = p; p += nkcap * ldk; } else { K = gwsK + (size_t)inst * nkcap * ldk; }
+    double *bv = p; p += m;          // (unused values; load_instance fills b)
+    double *xv = p; p += n;
+    double *yv = p; p += m;
+    double *vv = p; p += m;          // v = y - s ; later r_y
+    double *dv = p; p += m;          // d = DPi dy
+    double *qv2 = p; p += m;         // A r_x
+    double *rx = p; p += n;
+    double *ay = p; p += nqs * n;    // A_c^T e_y
+    double *as = p; p += nqs * n;    // A_c^T e_s
+    double *cinfo = p; p += 6 * nqs; // per cone: lambda, nz, e_y.d, e_s.d, (spare)
+    double *part = p; p += PB;
+    double *red = p; p += NW * 8;
+    int *ip = (int *)p;
+    int *rkind = ip; ip += m;        // row kind
+    int *eqrow = ip; ip += m;        // equality index of row (RK_EQ) or -1
+    int *ckind = ip; ip += nqs;      // cone kind: 0 = interior of K* (all EQ), 1 = in -K (all FREE), 2 = boundary
+    int *ceq = ip; ip += nqs;        // equality index of the e_y row of a boundary cone
+    int *perm = ip; ip += nkcap;
+    int *misc = ip; ip += 4;         // [0] n_eq, [1] pivot row, [2] flags
+
+    load_instance(T, Avals + (size_t)inst * T.nnz_aug, A, bv);
+    for (int j = tid; j < n; j += NT) xv[j] = xg[(size_t)inst * n + j];
+    for (int i = tid; i < m; i += NT) {
+        const double yi = yg[(size_t)inst * m + i];
+        yv[i] = yi; vv[i] = yi - sg[(size_t)inst * m + i];
+    }
+    __syncthreads();
+    // ---- classify
+    for (int i = tid; i < z + T.l; i += NT) rkind[i] = (i < z || vv[i] > 0) ? RK_EQ : RK_FREE;
+    for (int c = tid; c < nq; c += NT) {
+        const int r0 = T.qoff[c], r1 = T.qoff[c + 1], d = r1 - r0;
+        int kind; double lam = 0, nz = 0;
+        if (d == 1) kind = vv[r0] >= 0 ? 0 : 1;
+        else {
+            for (int i = r0 + 1; i < r1; i++) nz = fma(vv[i], vv[i], nz);
+            nz = sqrt(nz);
+            const double t0 = vv[r0];
+            if (nz <= t0) kind = 0; else if (nz <= -t0) kind = 1; else { kind = 2; lam = (t0 + nz) / (2 * nz); }
+        }
+        ckind[c] = kind; cinfo[6 * c] = lam; cinfo[6 * c + 1] = nz;
+        for (int i = r0; i < r1; i++) rkind[i] = kind == 0 ? RK_EQ : (kind == 1 ? RK_FREE : RK_SOCB);
+    }
+    __syncthreads();
+    if (tid == 0) {   // equality numbering (serial scan; m is small)
+        int ne = 0;
+        for (int i = 0; i < m; i++) eqrow[i] = (rkind[i] == RK_EQ) ? ne++ : -1;
+        for (int c = 0; c < nq; c++) ceq[c] = (ckind[c] == 2) ? ne++ : -1;
+        misc[0] = ne; misc[2] = 0;
+    }
+    __syncthreads();
+    const int neq = misc[0];
+    const int NK = n + neq;
+    if (NK > nkcap) {   // more active rows than the direct solve holds: degenerate instance (flagged, zero gradient)
+        for (int k = tid; k < T.nnz_aug; k += NT) dAo[(size_t)inst * T.nnz_aug + k] = 0.0;
+        for (int j = tid; j <= n; j += NT) dqo[j * sdqk + inst * sdqb] = 0.0;
+        if (tid == 0 && adj_status) adj_status[inst] = 2;
+        return;
+    }
+    // ---- d = DPi(v) dy   (symmetric), per-cone scalars e_y.d, e_s.d
+    for (int i = tid; i < z + T.l; i += NT) dv[i] = rkind[i] == RK_EQ ? dyg[(size_t)inst * m + i] : 0.0;
+    for (int c = tid; c < nq; c += NT) {
+        const int r0 = T.qoff[c], r1 = T.qoff[c + 1];
+        const double *h = dyg + (size_t)inst * m;
+        if (ckind[c] == 0) { for (int i = r0; i < r1; i++) dv[i] = h[i]; }
+        else if (ckind[c] == 1) { for (int i = r0; i < r1; i++) dv[i] = 0.0; }
+        else {
+            const double t0 = vv[r0], nz = cinfo[6 * c + 1];
+            double zh = 0; for (int i = r0 + 1; i < r1; i++) zh = fma(vv[i], h[i], zh);
+            dv[r0] = (nz * h[r0] + zh) / (2 * nz);
+            for (int i = r0 + 1; i < r1; i++) dv[i] = (vv[i] * h[r0] + (t0 + nz) * h[i] - t0 * vv[i] * zh / (nz * nz)) / (2 * nz);
+            // e_y = (1, zhat)/sqrt2, e_s = (1, -zhat)/sqrt2
+            double zd = 0; for (int i = r0 + 1; i < r1; i++) zd = fma(vv[i], dv[i], zd);
+            zd /= nz;
+            cinfo[6 * c + 2] = (dv[r0] + zd) * M_SQRT1_2;   // e_y . d
+            cinfo[6 * c + 3] = (dv[r0] - zd) * M_SQRT1_2;   // e_s . d
+        }
+    }
+    __syncthreads();
+    // ---- a_y, a_s for boundary cones
+    for (int idx = tid; idx < nq * n; idx += NT) {
+        const int c = idx / n, j = idx % n;
+        if (ckind[c] != 2) continue;
+        const int r0 = T.qoff[c], r1 = T.qoff[c + 1];
+        const double inz = 1.0 / cinfo[6 * c + 1];
+        double a = 0; for (int i = r0 + 1; i < r1; i++) a = fma(A[i * lda + j], vv[i], a);
+        a *= inz;
+        ay[c * n + j] = (A[r0 * lda + j] + a) * M_SQRT1_2;
+        as[c * n + j] = (A[r0 * lda + j] - a) * M_SQRT1_2;
+    }
+    __syncthreads();
+    // ---- assemble K = [[H, -B^T],[B, 0]] | rhs
+    for (int idx = tid; idx < NK * (NK + 1); idx += NT) {
+        const int r = idx / (NK + 1), cidx = idx % (NK + 1);
+        double val = 0;
+        if (r < n && cidx < n) {            // H[a][b] = sum_c theta_c (A_c^T A_c - a_y a_y^T - a_s a_s^T)
+            for (int c = 0; c < nq; c++) {
+                if (ckind[c] != 2) continue;
+                const double lam = cinfo[6 * c], th = lam / (1 - lam);
+                const int r0 = T.qoff[c], r1 = T.qoff[c + 1];
+                double a = 0; for (int i = r0; i < r1; i++) a = fma(A[i * lda + r], A[i * lda + cidx], a);
+                a -= ay[c * n + r] * ay[c * n + cidx] + as[c * n + r] * as[c * n + cidx];
+                val = fma(th, a, val);
+            }
+        } else if (r < n && cidx == NK) {   // f = dx + sum_FREE a_i d_i + sum_B [ a_s (e_s.d) + A_c^T P d / (1-lam) ]
+            val = dxg[(size_t)inst * n + r];
+            for (int i = 0; i < z + T.l; i++) if (rkind[i] == RK_FREE) val = fma(A[i * lda + r], dv[i], val);
+            for (int c = 0; c < nq; c++) {
+                const int r0 = T.qoff[c], r1 = T.qoff[c + 1];
+                if (ckind[c] == 1) { for (int i = r0; i < r1; i++) val = fma(A[i * lda + r], dv[i], val); }
+                else if (ckind[c] == 2) {
+                    const double lam = cinfo[6 * c], eyd = cinfo[6 * c + 2], esd = cinfo[6 * c + 3];
+                    double a = 0; for (int i = r0; i < r1; i++) a = fma(A[i * lda + r], dv[i], a);
+                    a -= ay[c * n + r] * eyd + as[c * n + r] * esd;      // A_c^T P d
+                    val += as[c * n + r] * esd + a / (1 - lam);
+                }
+            }
+        } else if (r >= n && cidx == NK) {  // d_B  (filled below by the owning row / cone)
+            val = 0;
+        } else val = 0;
+        K[r * ldk + cidx] = val;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < m * n; idx += NT) {   // B rows of plain equality rows
+        const int i = idx / n, j = idx % n; const int e = eqrow[i];
+        if (e >= 0) { const double a = A[i * lda + j]; K[(n + e) * ldk + j] = a; K[j * ldk + (n + e)] = -a; }
+    }
+    for (int idx = tid; idx < nq * n; idx += NT) {  // B rows of boundary cones (e_y rows)
+        const int c = idx / n, j = idx % n; const int e = ceq[c];
+        if (e >= 0) { const double a = ay[c * n + j]; K[(n + e) * ldk + j] = a; K[j * ldk + (n + e)] = -a; }
+    }
+    for (int i = tid; i < m; i += NT) if (eqrow[i] >= 0) K[(n + eqrow[i]) * ldk + NK] = dv[i];
+    for (int c = tid; c < nq; c += NT) if (ceq[c] >= 0) K[(n + ceq[c]) * ldk + NK] = cinfo[6 * c + 2];
+    for (int i = tid; i < NK; i += NT) perm[i] = i;
+    __syncthreads();
+    // ---- Gauss-Jordan with partial pivoting on [K | rhs]
+    double kmax;
+    {
+        double r[1] = {0};
+        for (int idx = tid; idx < NK * NK; idx += NT) r[0] = fmax(r[0], fabs(K[(idx / NK) * ldk + idx % NK]));
+        block_reduce<1>(r, 1u, red);
+        kmax = r[0];
+    }
+    const double ptol = 1e-13 * (kmax > 0 ? kmax : 1.0);
+    for (int k = 0; k < NK; k++) {
+        if (tid < 64) {   // pivot search by wave 0 over logical rows k..NK-1
+            double best = -1; int bi = k;
+            for (int i = k + tid; i < NK; i += 64) { const double v = fabs(K[perm[i] * ldk + k]); if (v > best) { best = v; bi = i; } }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const double ob = __shfl_xor(best, o); const int oi = __shfl_xor(bi, o);
+                if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+            }
+            if (tid == 0) {
+                const int t = perm[k]; perm[k] = perm[bi]; perm[bi] = t;
+                if (best < ptol) { misc[2] = 1; }
+            }
+        }
+        __syncthreads();
+        const int pk = perm[k];
+        double piv = K[pk * ldk + k];
+        if (fabs(piv) < ptol) piv = (piv < 0 ? -ptol : ptol);
+        const double pinv = 1.0 / piv;
+        const int wcols = NK - k;   // columns k+1 .. NK
+        for (int idx = tid; idx < NK * wcols; idx += NT) {
+            const int i = idx / wcols, j = k + 1 + idx % wcols;
+            if (i == k) continue;
+            const int pi = perm[i];
+            const double f = K[pi * ldk + k] * pinv;
+            if (f != 0.0) K[pi * ldk + j] = fma(-f, K[pk * ldk + j], K[pi * ldk + j]);
+        }
+        __syncthreads();
+    }
+    // solution: sol_k = rhs[perm[k]] / K[perm[k]][k];  r_x -> rx, multipliers rho -> bv (b is not needed by the adjoint)
+    for (int k = tid; k < NK; k += NT) {
+        const int pk = perm[k];
+        double piv = K[pk * ldk + k];
+        if (fabs(piv) < ptol) piv = (piv < 0 ? -ptol : ptol);
+        const double sol = K[pk * ldk + NK] / piv;
+        if (k < n) rx[k] = sol; else bv[k - n] = sol;
+    }
+    __syncthreads();
+    // ---- q = A r_x ; r_y
+    mv_rows_partial(A, lda, m, n, rx, part);
+    __syncthreads();
+    for (int i = tid; i < m; i += NT) qv2[i] = sum_parts(part, m, i);
+    __syncthreads();
+    for (int i = tid; i < z + T.l; i += NT) vv[i] = (eqrow[i] >= 0) ? bv[eqrow[i]] : dv[i];
+    for (int c = tid; c < nq; c += NT) {
+        const int r0 = T.qoff[c], r1 = T.qoff[c + 1];
+        if (ckind[c] == 0) { for (int i = r0; i < r1; i++) vv[i] = bv[eqrow[i]]; }
+        else if (ckind[c] == 1) { for (int i = r0; i < r1; i++) vv[i] = dv[i]; }
+        else {
+            // r_y = rho_y e_y + (e_s.d) e_s + (P d - lam P q) / (1 - lam),   P = I - e_y e_y^T - e_s e_s^T
+            const double lam = cinfo[6 * c], inz = 1.0 / cinfo[6 * c + 1], eyd = cinfo[6 * c + 2], esd = cinfo[6 * c + 3];
+            const double rhoy = bv[ceq[c]];
+            double zq = 0; for (int i = r0 + 1; i < r1; i++) zq = fma(vv[i], qv2[i], zq);
+            zq *= inz;
+            const double eyq = (qv2[r0] + zq) * M_SQRT1_2, esq = (qv2[r0] - zq) * M_SQRT1_2;
+            const double il = 1.0 / (1 - lam);
+            // coefficients on e_y and e_s after expanding P
+            const double cy = rhoy - il * (eyd - lam * eyq), cs = esd - il * (esd - lam * esq);
+            // component form: e_y = (1, zhat)/sqrt2 ; e_s = (1, -zhat)/sqrt2
+            const double k0 = (cy + cs) * M_SQRT1_2, kz = (cy - cs) * M_SQRT1_2;
+            // careful: vv[] (zbar) is overwritten in place -> do row 0 last, scale zhat on the fly
+            for (int i = r0 + 1; i < r1; i++) { const double zh = vv[i] * inz; vv[i] = il * (dv[i] - lam * qv2[i]) + kz * zh; }
+            vv[r0] = il * (dv[r0] - lam * qv2[r0]) + k0;
+        }
+    }
+    __syncthreads();
+    // ---- outputs in the boundary convention: dA_eval = [-dA.data, db[b_idx]], dq_eval = [dc, 0]
+    //      dA_ij = x_j r_y,i - y_i r_x,j ; db = -r_y ; dc = -r_x     (r_tau pinned to 0)
+    for (int k = tid; k < T.nnz_aug; k += NT) {
+        const int i = T.rowidx[k], j = T.colidx[k];
+        const double val = (j < n) ? -(xv[j] * vv[i] - yv[i] * rx[j]) : -vv[i];
+        dAo[(size_t)inst * T.nnz_aug + k] = val;
+    }
+    for (int j = tid; j <= n; j += NT) dqo[j * sdqk + inst * sdqb] = (j < n) ? -rx[j] : 0.0;
+    if (tid == 0 && adj_status) adj_status[inst] = misc[2];
+}
+
+// ================================================================================================
+// layout kernels: (R x C) row-major <-> (C x R) row-major, fp64, 32x32 LDS tiles (+1 pad)
+// ================================================================================================
+__global__ void __launch_bounds__(256) k_transpose(const double *__restrict__ in, double *__restrict__ out, int R, int C) {
+    __shared__ double tile[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int r = ty; r < 32; r += 8) { const int rr = by + r, cc = bx + tx; if (rr < R && cc < C) tile[r][tx] = in[(size_t)rr * C + cc]; }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) { const int cc = bx + r, rr = by + tx; if (rr < R && cc < C) out[(size_t)cc * R + rr] = tile[tx][r]; }
+}
+

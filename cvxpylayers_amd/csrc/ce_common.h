@@ -1,0 +1,120 @@
+// ce_common.h -- shared device helpers of the cone engine (included inside an anonymous namespace)
+#pragma once
+
+
+constexpr int NT = 256;            // threads per workgroup
+constexpr int NW = NT / 64;        // waves per workgroup
+constexpr int CONVERGED_INTERVAL = 25;
+constexpr int RESCALING_MIN_ITERS = 100;
+constexpr int NUM_RUIZ_PASSES = 25;
+constexpr int NUM_L2_PASSES = 1;
+constexpr double MIN_SCALE = 1e-4, MAX_SCALE = 1e4;
+constexpr double MIN_SCALE_VALUE = 1e-6, MAX_SCALE_VALUE = 1e6;
+constexpr double TAU_FACTOR = 10.0, ZERO_CONE_FACTOR = 1000.0;
+
+struct DevT {
+    int n, m, nnz_aug, nnzA, z, l, nq, lda, ldg, maxq;
+    const int *rowidx;    // [nnz_aug] row of structural entry k
+    const int *colidx;    // [nnz_aug] column (n == the b column)
+    const int *rowcone;   // [m] -1 for zero / nonneg rows, else SOC index
+    const int *qoff;      // [nq+1] first row of SOC c
+};
+
+thread_local std::string g_err;
+
+// ------------------------------------------------------------------------------------------------
+// workgroup reductions
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    return v;
+}
+// reduces K values over the workgroup; bit k of maxmask selects max instead of sum.  red: NW*K doubles of LDS.
+template <int K>
+__device__ __forceinline__ void block_reduce(double (&v)[K], unsigned maxmask, double *red) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < K; k++) v[k] = ((maxmask >> k) & 1u) ? wave_max(v[k]) : wave_sum(v[k]);
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < K; k++) red[wid * K + k] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        double a = red[k];
+#pragma unroll
+        for (int w = 1; w < NW; w++) a = ((maxmask >> k) & 1u) ? fmax(a, red[w * K + k]) : a + red[w * K + k];
+        v[k] = a;
+    }
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------
+// matvec building blocks on an LDS (or L2-resident) row-major matrix  Mat[rows][ld]
+// P1:  part[ch][j] = sum_{i in chunk ch} Mat[i][j] * v[i]       (out indexed by COLUMN; lanes walk j -> conflict-free)
+__device__ __forceinline__ int chunks_for(int outs) { int c = NT / outs; return c < 1 ? 1 : c; }
+
+__device__ __forceinline__ void mv_cols_partial(const double *Mat, int ld, int rows, int cols, const double *v, double *part) {
+    const int CH = chunks_for(cols);
+    const int len = (rows + CH - 1) / CH;
+    for (int idx = threadIdx.x; idx < cols * CH; idx += NT) {
+        const int j = idx % cols, ch = idx / cols;
+        const int i0 = ch * len, i1 = min(rows, i0 + len);
+        double a0 = 0, a1 = 0;
+        int i = i0;
+        for (; i + 1 < i1; i += 2) {
+            a0 = fma(Mat[i * ld + j], v[i], a0);
+            a1 = fma(Mat[(i + 1) * ld + j], v[i + 1], a1);
+        }
+        if (i < i1) a0 = fma(Mat[i * ld + j], v[i], a0);
+        part[ch * cols + j] = a0 + a1;
+    }
+}
+__device__ __forceinline__ double sum_parts(const double *part, int outs, int idx) {
+    const int CH = chunks_for(outs);
+    double a = part[idx];
+    for (int c = 1; c < CH; c++) a += part[c * outs + idx];
+    return a;
+}
+// P2:  part[ch][i] = sum_{j in chunk ch} Mat[i][j] * v[j]       (out indexed by ROW; ld odd -> conflict-free ds_read_b64)
+__device__ __forceinline__ void mv_rows_partial(const double *Mat, int ld, int rows, int cols, const double *v, double *part) {
+    const int CH = chunks_for(rows);
+    const int len = (cols + CH - 1) / CH;
+    for (int idx = threadIdx.x; idx < rows * CH; idx += NT) {
+        const int i = idx % rows, ch = idx / rows;
+        const int j0 = ch * len, j1 = min(cols, j0 + len);
+        const double *r = Mat + i * ld;
+        double a0 = 0, a1 = 0;
+        int j = j0;
+        for (; j + 1 < j1; j += 2) {
+            a0 = fma(r[j], v[j], a0);
+            a1 = fma(r[j + 1], v[j + 1], a1);
+        }
+        if (j < j1) a0 = fma(r[j], v[j], a0);
+        part[ch * rows + i] = a0 + a1;
+    }
+}
+
+__device__ __forceinline__ double clamp_scale(double v) { return v < MIN_SCALE ? 1.0 : (v > MAX_SCALE ? MAX_SCALE : v); }
+
+// scatter one instance's boundary values (batch-major row of [A_cvx | b_cvx] values) into dense solver form
+__device__ __forceinline__ void load_instance(const DevT &T, const double *vals, double *A, double *bv) {
+    const int n = T.n, m = T.m, lda = T.lda;
+    for (int i = threadIdx.x; i < m * lda; i += NT) A[i] = 0.0;
+    for (int i = threadIdx.x; i < m; i += NT) bv[i] = 0.0;
+    __syncthreads();
+    for (int k = threadIdx.x; k < T.nnz_aug; k += NT) {
+        const double val = vals[k];
+        const int r = T.rowidx[k], c = T.colidx[k];
+        if (c < n) A[r * lda + c] = -val;      // solver sees A = -A_cvx (diffcp_if.py:65)
+        else bv[r] = val;                      // b = b_cvx          (diffcp_if.py:66)
+    }
+    __syncthreads();
+}
+

@@ -1,0 +1,355 @@
+// ce_forward_generic.h -- size-generic LDS/L2-resident forward kernel (fallback path)
+#pragma once
+// ================================================================================================
+// FORWARD
+// ================================================================================================
+template <bool A_LDS, bool G_LDS>
+__global__ void __launch_bounds__(NT)
+k_forward(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__restrict__ qv, long sqk, long sqb,
+          double *__restrict__ xo, double *__restrict__ yo, double *__restrict__ so, int *__restrict__ iters_o,
+          int *__restrict__ status_o, double *__restrict__ resid_o, double *gwsA, double *gwsG) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int tid = threadIdx.x, inst = blockIdx.x;
+    const int n = T.n, m = T.m, l = n + m + 1, lda = T.lda, ldg = T.ldg, nq = T.nq, z = T.z;
+    const int PB = max(NT, max(n, m));      // partial-sum buffer length
+
+    double *p = sm;
+    double *A, *G;
+    if constexpr (A_LDS) { A = p; p += m * lda; } else { A = gwsA + (size_t)inst * m * lda; }
+    if constexpr (G_LDS) { G = p; p += n * ldg; } else { G = gwsG + (size_t)inst * n * ldg; }
+    double *bv = p; p += m;      // b-hat
+    double *cv = p; p += n;      // c-hat
+    double *Dv = p; p += m;      // row equilibration
+    double *Ev = p; p += n;      // column equilibration
+    double *g = p; p += l;       // (R_z + M_zz)^{-1} h
+    double *w = p; p += l;       // DR iterate
+    double *ut = p; p += l;      // u-tilde
+    double *u = p; p += l;       // cone iterate
+    double *phi = p; p += l;     // functional giving the tau-tilde numerator
+    double *tv = p; p += max(n, m); // scratch vector
+    double *part = p; p += PB;
+    double *part2 = p; p += PB;
+    double *red = p; p += NW * 8;
+    double *socc = p; p += 2 * (nq > 0 ? nq : 1);
+    double *wpart = p; p += NW;  // per-wave partials of phi . w
+    double *sc = p; p += 2 * n;  // refactor() right-hand sides (keeps u / ut intact across a rescale)
+
+    // ---------------------------------------------------------------- load
+    load_instance(T, Avals + (size_t)inst * T.nnz_aug, A, bv);
+    for (int j = tid; j < n; j += NT) { cv[j] = qv[j * sqk + inst * sqb]; Ev[j] = 1.0; }
+    for (int i = tid; i < m; i += NT) Dv[i] = 1.0;
+    __syncthreads();
+    double nrm_b0, nrm_c0;
+    {
+        double r[2] = {0, 0};
+        for (int i = tid; i < m; i += NT) r[0] = fmax(r[0], fabs(bv[i]));
+        for (int j = tid; j < n; j += NT) r[1] = fmax(r[1], fabs(cv[j]));
+        block_reduce<2>(r, 3u, red);
+        nrm_b0 = r[0]; nrm_c0 = r[1];
+    }
+    // ---------------------------------------------------------------- equilibration (SCS normalize)
+    double sigma = 1.0;
+    if (S.normalize) {
+        for (int pass = 0; pass < NUM_RUIZ_PASSES + NUM_L2_PASSES; pass++) {
+            const bool l2 = pass >= NUM_RUIZ_PASSES;
+            {   // row norms -> part (indexed by row), column norms -> part2 (indexed by column)
+                const int CH = chunks_for(m), len = (n + CH - 1) / CH;
+                for (int idx = tid; idx < m * CH; idx += NT) {
+                    const int i = idx % m, ch = idx / m, j0 = ch * len, j1 = min(n, j0 + len);
+                    const double *r = A + i * lda; double a = 0;
+                    for (int j = j0; j < j1; j++) { const double v = r[j]; a = l2 ? fma(v, v, a) : fmax(a, fabs(v)); }
+                    part[ch * m + i] = a;
+                }
+                const int CH2 = chunks_for(n), len2 = (m + CH2 - 1) / CH2;
+                for (int idx = tid; idx < n * CH2; idx += NT) {
+                    const int j = idx % n, ch = idx / n, i0 = ch * len2, i1 = min(m, i0 + len2);
+                    double a = 0;
+                    for (int i = i0; i < i1; i++) { const double v = A[i * lda + j]; a = l2 ? fma(v, v, a) : fmax(a, fabs(v)); }
+                    part2[ch * n + j] = a;
+                }
+            }
+            __syncthreads();
+            for (int i = tid; i < m; i += NT) {
+                const int CH = chunks_for(m); double a = part[i];
+                for (int c = 1; c < CH; c++) a = l2 ? a + part[c * m + i] : fmax(a, part[c * m + i]);
+                if (l2) a = sqrt(a);
+                tv[i] = (T.rowcone[i] < 0) ? 1.0 / sqrt(clamp_scale(a)) : a;   // SOC rows: raw norm, averaged below
+            }
+            for (int j = tid; j < n; j += NT) {
+                const int CH = chunks_for(n); double a = part2[j];
+                for (int c = 1; c < CH; c++) a = l2 ? a + part2[c * n + j] : fmax(a, part2[c * n + j]);
+                if (l2) a = sqrt(a);
+                u[j] = 1.0 / sqrt(clamp_scale(a));                                // Et (u is free scratch here)
+            }
+            __syncthreads();
+            if (nq > 0) {   // block-average the row scaling inside each SOC so the scaled cone is still the cone
+                for (int c = tid; c < nq; c += NT) {
+                    const int r0 = T.qoff[c], r1 = T.qoff[c + 1]; double a = 0;
+                    for (int i = r0; i < r1; i++) a += tv[i];
+                    if (r1 > r0) { a = 1.0 / sqrt(clamp_scale(a / (r1 - r0))); for (int i = r0; i < r1; i++) tv[i] = a; }
+                }
+                __syncthreads();
+            }
+            for (int idx = tid; idx < m * n; idx += NT) { const int i = idx / n, j = idx % n; A[i * lda + j] *= tv[i] * u[j]; }
+            for (int i = tid; i < m; i += NT) Dv[i] *= tv[i];
+            for (int j = tid; j < n; j += NT) Ev[j] *= u[j];
+            __syncthreads();
+        }
+        double r[2] = {0, 0};
+        for (int i = tid; i < m; i += NT) { bv[i] *= Dv[i]; r[0] = fmax(r[0], fabs(bv[i])); }
+        for (int j = tid; j < n; j += NT) { cv[j] *= Ev[j]; r[1] = fmax(r[1], fabs(cv[j])); }
+        block_reduce<2>(r, 3u, red);
+        sigma = 1.0 / clamp_scale(fmax(r[0], r[1]));
+        for (int i = tid; i < m; i += NT) bv[i] *= sigma;
+        for (int j = tid; j < n; j += NT) cv[j] *= sigma;
+        __syncthreads();
+    }
+
+    double scale = S.scale;
+    const double rho_x = S.rho_x, rtau = TAU_FACTOR, alpha = S.alpha;
+    double hg = 0;
+    auto dyv = [&](int i) -> double { return (i < z) ? ZERO_CONE_FACTOR * scale : scale; };   // 1 / r_y
+
+    // ---- (re)factor: G = (rho_x I + A^T Dy A)^{-1}, g, h.g, phi    (uniform control flow; ends synchronised)
+    auto refactor = [&]() {
+        for (int idx = tid; idx < n * n; idx += NT) {
+            const int a = idx / n, b2 = idx % n;
+            double acc0 = 0, acc1 = 0; int i = 0;
+            for (; i + 1 < m; i += 2) {
+                acc0 = fma(A[i * lda + a] * dyv(i), A[i * lda + b2], acc0);
+                acc1 = fma(A[(i + 1) * lda + a] * dyv(i + 1), A[(i + 1) * lda + b2], acc1);
+            }
+            if (i < m) acc0 = fma(A[i * lda + a] * dyv(i), A[i * lda + b2], acc0);
+            G[a * ldg + b2] = acc0 + acc1 + (a == b2 ? rho_x : 0.0);
+        }
+        __syncthreads();
+        // in-place Gauss-Jordan inversion (SPD: no pivoting needed)
+        double *colk = part, *rowk = part2;
+        for (int k = 0; k < n; k++) {
+            for (int i = tid; i < n; i += NT) { colk[i] = G[i * ldg + k]; rowk[i] = G[k * ldg + i]; }
+            __syncthreads();
+            const double pinv = 1.0 / rowk[k];
+            for (int idx = tid; idx < n * n; idx += NT) {
+                const int i = idx / n, j = idx % n;
+                double v;
+                if (i == k) v = (j == k) ? pinv : rowk[j] * pinv;
+                else if (j == k) v = -colk[i] * pinv;
+                else v = fma(-colk[i] * pinv, rowk[j], G[i * ldg + j]);
+                G[i * ldg + j] = v;
+            }
+            __syncthreads();
+        }
+        // tv = Dy*b  (m) ;  part = A^T tv partials
+        for (int i = tid; i < m; i += NT) tv[i] = dyv(i) * bv[i];
+        __syncthreads();
+        mv_cols_partial(A, lda, m, n, tv, part);
+        __syncthreads();
+        // sc[0:n] = c - A^T Dy b   (rhs for g_x) ;  sc[n:2n] = c + A^T Dy b  (k, for phi)
+        for (int j = tid; j < n; j += NT) { const double a = sum_parts(part, n, j); sc[j] = cv[j] - a; sc[n + j] = cv[j] + a; }
+        __syncthreads();
+        mv_cols_partial(G, ldg, n, n, sc, part);      // G symmetric: column form == row form
+        mv_cols_partial(G, ldg, n, n, sc + n, part2);
+        __syncthreads();
+        for (int j = tid; j < n; j += NT) { g[j] = sum_parts(part, n, j); tv[j] = sum_parts(part2, n, j); }   // tv[0:n] = G k
+        __syncthreads();
+        mv_rows_partial(A, lda, m, n, g, part);      // A g_x
+        mv_rows_partial(A, lda, m, n, tv, part2);    // A G k
+        __syncthreads();
+        double r[1] = {0};
+        for (int i = tid; i < m; i += NT) {
+            const double gy = dyv(i) * (sum_parts(part, m, i) + bv[i]);
+            g[n + i] = gy; r[0] += bv[i] * gy;
+            phi[n + i] = bv[i] - sum_parts(part2, m, i);
+        }
+        for (int j = tid; j < n; j += NT) { r[0] += cv[j] * g[j]; phi[j] = rho_x * tv[j]; }
+        block_reduce<1>(r, 0u, red);
+        hg = r[0];
+    };
+    // phi . w  (z part), as per-wave partials consumed one iteration later
+    auto phiw_partials = [&]() {
+        double a = 0;
+        for (int e = tid; e < l - 1; e += NT) a += phi[e] * w[e];
+        a = wave_sum(a);
+        if ((tid & 63) == 0) wpart[tid >> 6] = a;
+    };
+
+    refactor();
+    for (int e = tid; e < l; e += NT) w[e] = (e == l - 1) ? 1.0 : 0.0;    // cold start
+    if (tid < NW) wpart[tid] = 0.0;
+    __syncthreads();
+
+    int status = 0, iter = 0, last_scale_iter = 0, n_log = 0;
+    double sum_log = 0, res_pri = NAN, res_dual = NAN, gap = NAN;
+    double tau = 0, kap = 0, ctx = 0, bty = 0;
+
+    for (iter = 0; iter < S.max_iters; iter++) {
+        const bool check = (iter % CONVERGED_INTERVAL) == 0;
+        if (check && iter > 0) {   // keep the homogeneous iterate in range
+            double r[1] = {0};
+            for (int e = tid; e < l; e += NT) r[0] += w[e] * w[e];
+            block_reduce<1>(r, 0u, red);
+            const double nw = sqrt(r[0]);
+            if (nw > 0) { const double f = sqrt((double)l) / nw; for (int e = tid; e < l; e += NT) w[e] *= f; }
+            __syncthreads();
+            phiw_partials();
+            __syncthreads();
+        }
+        // S1: A^T w_y
+        mv_cols_partial(A, lda, m, n, w + n, part);
+        __syncthreads();
+        // S2: t = rho_x w_x - A^T w_y
+        for (int j = tid; j < n; j += NT) tv[j] = rho_x * w[j] - sum_parts(part, n, j);
+        __syncthreads();
+        // S3: G t
+        mv_cols_partial(G, ldg, n, n, tv, part);
+        __syncthreads();
+        // S4: p_x
+        for (int j = tid; j < n; j += NT) ut[j] = sum_parts(part, n, j);
+        __syncthreads();
+        // S5: A p_x
+        mv_rows_partial(A, lda, m, n, ut, part);
+        __syncthreads();
+        // S6/S7: tau-tilde, u-tilde, cone input
+        double numer = rtau * w[l - 1];
+#pragma unroll
+        for (int k = 0; k < NW; k++) numer += wpart[k];
+        const double tau_t = numer / (rtau + hg);
+        for (int e = tid; e < l; e += NT) {
+            double ute, ue;
+            if (e < n) { ute = ut[e] - tau_t * g[e]; ue = 2 * ute - w[e]; }
+            else if (e < l - 1) {
+                const int i = e - n;
+                const double py = w[e] + dyv(i) * sum_parts(part, m, i);
+                ute = py - tau_t * g[e]; ue = 2 * ute - w[e];
+                if (i >= z && T.rowcone[i] < 0 && ue < 0) ue = 0;      // nonneg rows; zero-cone dual is free
+            } else { ute = tau_t; ue = fmax(0.0, 2 * tau_t - w[e]); }
+            ut[e] = ute; u[e] = ue;
+        }
+        __syncthreads();
+        // S8: SOC projection coefficients  u_c = (c0, f * zbar)
+        if (nq > 0) {
+            for (int c = tid; c < nq; c += NT) {
+                const int r0 = n + T.qoff[c], r1 = n + T.qoff[c + 1];
+                if (r1 - r0 == 1) { socc[2 * c] = fmax(u[r0], 0.0); socc[2 * c + 1] = 0.0; continue; }
+                const double t0 = u[r0]; double nz = 0;
+                for (int e = r0 + 1; e < r1; e++) nz = fma(u[e], u[e], nz);
+                nz = sqrt(nz);
+                double c0, f;
+                if (nz <= t0) { c0 = t0; f = 1.0; }
+                else if (nz <= -t0) { c0 = 0.0; f = 0.0; }
+                else { c0 = 0.5 * (t0 + nz); f = c0 / nz; }
+                socc[2 * c] = c0; socc[2 * c + 1] = f;
+            }
+            __syncthreads();
+            for (int i = tid + (z + T.l); i < m; i += NT) {
+                const int c = T.rowcone[i];
+                u[n + i] = (i == T.qoff[c]) ? socc[2 * c] : socc[2 * c + 1] * u[n + i];
+            }
+            __syncthreads();
+        }
+        // ---- termination test / adaptive scale (uniform branch)
+        bool stop = false;
+        if (check) {
+            mv_rows_partial(A, lda, m, n, u, part);          // A-hat x-hat
+            mv_cols_partial(A, lda, m, n, u + n, part2);     // A-hat^T y-hat
+            __syncthreads();
+            tau = fabs(u[l - 1]);
+            kap = fabs(rtau * (u[l - 1] + w[l - 1] - 2 * ut[l - 1]));
+            const double isg = 1.0 / sigma;
+            double r[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // rp, nax, ns, naxs, rd, naty (max) ; ctx, bty (sum)
+            for (int i = tid; i < m; i += NT) {
+                const double sc = isg / Dv[i];
+                const double ax = sum_parts(part, m, i) * sc;
+                const double sh = (u[n + i] + w[n + i] - 2 * ut[n + i]) / dyv(i) * sc;
+                const double bt = bv[i] * tau * sc;
+                r[0] = fmax(r[0], fabs(ax + sh - bt)); r[1] = fmax(r[1], fabs(ax)); r[2] = fmax(r[2], fabs(sh));
+                r[3] = fmax(r[3], fabs(ax + sh));
+                r[7] += bv[i] * u[n + i] * isg * isg;
+            }
+            for (int j = tid; j < n; j += NT) {
+                const double sc = isg / Ev[j];
+                const double aty = sum_parts(part2, n, j) * sc;
+                r[4] = fmax(r[4], fabs(aty + cv[j] * tau * sc)); r[5] = fmax(r[5], fabs(aty));
+                r[6] += cv[j] * u[j] * isg * isg;
+            }
+            block_reduce<8>(r, 0x3Fu, red);
+            const double rp = r[0], nax = r[1], ns = r[2], naxs = r[3], rd = r[4], naty = r[5];
+            ctx = r[6]; bty = r[7];
+            if (tau > 0) {
+                res_pri = rp / tau; res_dual = rd / tau; gap = fabs(ctx + bty) / tau;
+                const double prl = fmax(fmax(nrm_b0 * tau, ns), nax) / tau, drl = fmax(nrm_c0 * tau, naty) / tau;
+                const double grl = fmax(fabs(ctx), fabs(bty)) / tau;
+                if (res_pri <= S.eps_abs + S.eps_rel * prl && res_dual <= S.eps_abs + S.eps_rel * drl &&
+                    gap <= S.eps_abs + S.eps_rel * grl) { status = 1; stop = true; }
+            }
+            if (!stop && bty < 0 && naty / (-bty) <= S.eps_infeas) { status = -2; stop = true; }
+            if (!stop && ctx < 0 && naxs / (-ctx) <= S.eps_infeas) { status = -1; stop = true; }
+            if (!stop && S.adaptive_scale && iter > 0) {
+                const double dp = fmax(fmax(nax, ns), nrm_b0 * tau), dd = fmax(naty, nrm_c0 * tau);
+                const double rel_p = rp / (dp > 0 ? dp : 1), rel_d = rd / (dd > 0 ? dd : 1);
+                if (rel_p > 0 && rel_d > 0 && isfinite(rel_p) && isfinite(rel_d)) {
+                    sum_log += log(rel_p) - log(rel_d); n_log++;
+                    const double factor = sqrt(exp(sum_log / n_log));
+                    if (iter - last_scale_iter >= RESCALING_MIN_ITERS) {
+                        const double ns2 = fmin(fmax(scale * factor, MIN_SCALE_VALUE), MAX_SCALE_VALUE);
+                        if (ns2 != scale && (factor > sqrt(10.0) || factor < 1.0 / sqrt(10.0))) {
+                            // keep (s, kappa):  R+ (w+ + u - 2 ut) = rsk  ->  w_y+ = rsk_y / r_y+ + 2 ut_y - u_y
+                            const double dy_ratio = ns2 / scale;       // Dy+ / Dy, same for zero and cone rows
+                            for (int i = tid; i < m; i += NT) {
+                                const double d0 = u[n + i] + w[n + i] - 2 * ut[n + i];   // = rsk_y * Dy
+                                w[n + i] = d0 * dy_ratio + 2 * ut[n + i] - u[n + i];
+                            }
+                            sum_log = 0; n_log = 0; last_scale_iter = iter; scale = ns2;
+                            __syncthreads();
+                            refactor();
+                            phiw_partials();
+                            __syncthreads();
+                        }
+                    }
+                }
+            }
+        }
+        if (stop) break;
+        if (iter + 1 >= S.max_iters) { iter++; break; }   // keep w pre-update so (s, kappa) match the last cone step
+        // S9: relaxed update of w, and phi.w for the next iteration
+        {
+            double a = 0;
+            for (int e = tid; e < l; e += NT) {
+                const double we = w[e] + alpha * (u[e] - ut[e]);
+                w[e] = we;
+                if (e < l - 1) a += phi[e] * we;
+            }
+            a = wave_sum(a);
+            if ((tid & 63) == 0) wpart[tid >> 6] = a;
+        }
+        __syncthreads();
+    }
+
+    if (status == 0) {   // ran out of iterations (SCS set_unfinished)
+        tau = fabs(u[l - 1]);
+        kap = fabs(rtau * (u[l - 1] + w[l - 1] - 2 * ut[l - 1]));
+        double r[2] = {0, 0};
+        const double isg = 1.0 / sigma;
+        for (int j = tid; j < n; j += NT) r[0] += cv[j] * u[j] * isg * isg;
+        for (int i = tid; i < m; i += NT) r[1] += bv[i] * u[n + i] * isg * isg;
+        block_reduce<2>(r, 0u, red);
+        if (tau > kap) status = 2; else if (r[1] < r[0]) status = -7; else status = -6;
+    }
+    // ---------------------------------------------------------------- write back (un-normalise)
+    {
+        const bool solved = (status == 1 || status == 2);
+        const bool infeas = (status == -2 || status == -7);
+        const double it = solved ? 1.0 / (sigma * tau) : 1.0 / sigma;
+        for (int j = tid; j < n; j += NT) xo[(size_t)inst * n + j] = infeas ? NAN : Ev[j] * u[j] * it;
+        for (int i = tid; i < m; i += NT) {
+            const double sh = (u[n + i] + w[n + i] - 2 * ut[n + i]) / dyv(i);
+            yo[(size_t)inst * m + i] = (solved || infeas) ? Dv[i] * u[n + i] * it : NAN;
+            so[(size_t)inst * m + i] = infeas ? NAN : sh / Dv[i] * it;
+        }
+        if (tid == 0) {
+            iters_o[inst] = iter; status_o[inst] = status;
+            if (resid_o) { resid_o[3 * inst] = res_pri; resid_o[3 * inst + 1] = res_dual; resid_o[3 * inst + 2] = gap; }
+        }
+    }
+}
+

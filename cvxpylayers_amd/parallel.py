@@ -1,0 +1,87 @@
+"""Multi-GPU batch sharding (one process per GPU, torch.distributed; backend "nccl" is RCCL on ROCm).
+
+Instances are independent: every rank solves a contiguous slice of the batch with no
+data-path collective.  The only exchange step the path has is reassembling solutions into one autograd
+graph: an all-gather of primal/dual rows whose backward is the matching reduce-scatter (sum), so each
+rank ends up with the gradient of ITS shard and dA/dq for batched parameters stay sharded.
+Gradients of broadcast (unbatched) parameters are sums over the batch (expand backward,
+torch/cvxpylayer.py:111-117) -> `allreduce_broadcast_grad`.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(total: int, rank: int, world: int) -> tuple[int, int]:
+    """Contiguous, balanced slice [lo, hi) of `total` instances for `rank`."""
+    base, rem = divmod(total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class _AllGatherRows(torch.autograd.Function):
+    """out = concat over ranks of x (rows);  backward = reduce-scatter(sum) of the incoming gradient."""
+
+    @staticmethod
+    def forward(ctx, x, sizes, group):
+        world = dist.get_world_size(group)
+        ctx.group, ctx.sizes, ctx.rank = group, sizes, dist.get_rank(group)
+        x = x.contiguous()
+        if len(set(sizes)) == 1:
+            out = torch.empty((sizes[0] * world,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+            dist.all_gather_into_tensor(out, x, group=group)
+            return out
+        parts = [torch.empty((s,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device) for s in sizes]
+        dist.all_gather(parts, x, group=group)
+        return torch.cat(parts, dim=0)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        sizes, rank = ctx.sizes, ctx.rank
+        backend = dist.get_backend(ctx.group)
+        if backend == "nccl" and len(set(sizes)) == 1:
+            out = torch.empty((sizes[0],) + tuple(g.shape[1:]), dtype=g.dtype, device=g.device)
+            dist.reduce_scatter_tensor(out, g, op=dist.ReduceOp.SUM, group=ctx.group)
+            return out, None, None
+        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=ctx.group)   # gloo / ragged: all-reduce then slice
+        lo = sum(sizes[:rank])
+        return g[lo:lo + sizes[rank]].clone(), None, None
+
+
+def gather_rows(x: torch.Tensor, sizes=None, group=None) -> torch.Tensor:
+    """All-gather the leading (batch) axis across ranks, differentiable."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return x
+    world = dist.get_world_size(group)
+    if sizes is None:
+        sizes = [x.shape[0]] * world
+    return _AllGatherRows.apply(x, list(sizes), group)
+
+
+def allreduce_broadcast_grad(g: torch.Tensor, group=None) -> torch.Tensor:
+    """Sum a broadcast-parameter gradient over ranks (each rank holds the sum over its shard)."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group)
+    return g
+
+
+def sharded_apply(layer_cls, q_eval, A_eval, ctx, solver_args, needs_grad=True, total=None, gather=True, group=None):
+    """Solve this rank's slice of a replicated (…, B_total) batch and (optionally) all-gather primal/dual.
+
+    q_eval (n+1, B_total), A_eval (nnz_aug, B_total) replicated on every rank (or pass already-local slices with
+    total=None).  Returns primal (B_total, n), dual (B_total, m) when gather else the local rows."""
+    if dist.is_initialized() and total is not None:
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        lo, hi = shard_bounds(total, rank, world)
+        q_eval = q_eval[:, lo:hi]
+        A_eval = A_eval[:, lo:hi]
+        sizes = [shard_bounds(total, r, world)[1] - shard_bounds(total, r, world)[0] for r in range(world)]
+    else:
+        sizes = None
+    primal, dual, info, data = layer_cls.apply(None, q_eval, A_eval, ctx, solver_args, needs_grad, None)
+    if gather:
+        primal = gather_rows(primal, sizes, group)
+        dual = gather_rows(dual, sizes, group)
+    return primal, dual, info
