@@ -32,9 +32,13 @@ class _AllGatherRows(torch.autograd.Function):
             out = torch.empty((sizes[0] * world,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
             dist.all_gather_into_tensor(out, x, group=group)
             return out
-        parts = [torch.empty((s,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device) for s in sizes]
-        dist.all_gather(parts, x, group=group)
-        return torch.cat(parts, dim=0)
+        # ragged shards: pad every shard to the largest one (collectives need equal sizes), gather, drop the pads
+        smax = max(sizes)
+        pad = torch.zeros((smax,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        pad[:x.shape[0]] = x
+        out = torch.empty((smax * world,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        dist.all_gather_into_tensor(out, pad, group=group)
+        return torch.cat([out[r * smax:r * smax + sizes[r]] for r in range(world)], dim=0)
 
     @staticmethod
     def backward(ctx, g):

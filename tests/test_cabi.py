@@ -1,0 +1,66 @@
+"""The C-ABI library loads without a GPU and exports every entry point include/cone_engine.h declares; argument
+validation that needs no device works.  (No compute calls here: those are the -m gpu tests.)"""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from cvxpylayers_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "cone_engine.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(ce_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_header_and_binding_agree():
+    assert declared_symbols() == sorted(_lib.SYMBOLS)
+
+
+def test_library_exports_every_declared_symbol():
+    L = _lib.lib()
+    for sym in declared_symbols():
+        assert hasattr(L, sym), sym
+
+
+def test_default_settings_are_scs_defaults():
+    s = _lib.CeSettings()
+    _lib.lib().ce_default_settings(C.byref(s))
+    assert (s.eps_abs, s.eps_rel, s.eps_infeas, s.alpha, s.rho_x, s.scale) == (1e-4, 1e-4, 1e-7, 1.5, 1e-6, 0.1)
+    assert (s.max_iters, s.normalize, s.adaptive_scale) == (100000, 1, 1)
+
+
+def test_bad_template_is_rejected_before_touching_a_device():
+    L = _lib.lib()
+    t = _lib.CeTemplate()
+    idx = np.zeros(1, dtype=np.int32)
+    t.n, t.m, t.nnz_aug = 0, 0, 0
+    t.indices = idx.ctypes.data_as(C.POINTER(C.c_int)); t.indptr = idx.ctypes.data_as(C.POINTER(C.c_int))
+    h = C.c_void_p()
+    assert L.ce_create(C.byref(t), 0, C.byref(h)) == -1      # CE_E_BADARG
+    assert b"template" in L.ce_last_error()
+    assert L.ce_destroy(None) == 0
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(_lib, "_LIB", None)
+    monkeypatch.setattr(_lib, "SO_PATH", "/nonexistent/libcone_engine.so")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.lib()
+
+
+def test_plugin_refuses_cpu_only_host():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from cvxpylayers_amd import problems as P
+    from cvxpylayers_amd.interfaces.mi355_if import MI355_ctx, _CvxpyLayer
+    tpl = P.dense_template(3, {"z": 0, "l": 4, "q": []})
+    ctx = MI355_ctx(None, tpl.problem_data_index, tpl.cones)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _CvxpyLayer.apply(None, torch.zeros(4, 2, dtype=torch.double), torch.zeros(tpl.nnz_aug, 2, dtype=torch.double), ctx, {}, False, None)
