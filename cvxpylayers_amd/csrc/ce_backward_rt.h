@@ -1,0 +1,349 @@
+// ce_backward_rt.h -- register-tiled structured direct adjoint (hot path for instances with n + min(m,n) + 1 <= 16*TJ).
+//
+// Same mathematics as ce_backward.h (diffcp adjoint M^T r = dz, r_tau pinned to 0, reduced cone block by cone block to the
+// saddle system  K [r_x; mu] = [f; d_B],  K = [[H, -B^T],[B, 0]]  of order NK = n + #equality rows), different machine mapping:
+//   * K (with the right-hand side as column NK) lives in REGISTERS: the 256 threads of a workgroup form a 16 x 16 grid,
+//     thread (ra, cb) owns K[ra + 16 i][cb + 16 j], i < TI, j < TJ (2-D cyclic: the live part of every thread's tile shrinks
+//     evenly as elimination proceeds, and the outer loop over j-slots is unrolled so the shrinking is static).
+//   * Gauss-Jordan with partial pivoting: per pivot the 16 lanes that own column k (one DPP row of one wave) find the pivot
+//     with a 4-stage butterfly and publish the column through LDS; the owners of the pivot row publish the row; every thread
+//     then applies the rank-1 update to its tile.  Two workgroup barriers per pivot, no integer division, no LDS-resident K.
+//   * LDS holds only the dense instance matrix (needed for assembly and for q = A r_x) and vectors: ~52 KB per workgroup at
+//     the metric configuration -> 3 workgroups (12 waves) per CU instead of 1.
+//   * H = sum_c theta_c (A_c^T A_c - a_y a_y^T - a_s a_s^T) is accumulated directly in tile layout with 4x4-style register
+//     blocking (rows {ra+16i} x columns {cb+16j}: TI + TJ LDS reads feed TI*TJ FMAs per cone row).
+#pragma once
+
+constexpr int BG = 16;   // thread grid is BG x BG
+
+__host__ __device__ inline int bwd_rt_union_doubles(int n, int m, int nqs, int TI, int TJ) {
+    int a = 2 * nqs * n, b = 2 * BG * TI + 2 * BG * TJ, c = (NT > m ? NT : m) + m;
+    int r = a > b ? a : b;
+    return r > c ? r : c;
+}
+
+template <int TI, int TJ, int TH>
+__global__ void __launch_bounds__(NT, 3)
+k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict__ xg, const double *__restrict__ yg,
+              const double *__restrict__ sg, const double *__restrict__ dxg, const double *__restrict__ dyg,
+              double *__restrict__ dAo, double *__restrict__ dqo, long sdqk, long sdqb, int *__restrict__ adj_status) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int tid = threadIdx.x, inst = blockIdx.x;
+    const int n = T.n, m = T.m, lda = T.lda, nq = T.nq, z = T.z;
+    const int nqs = nq > 0 ? nq : 1;
+    const int ra = tid & (BG - 1), cb = tid >> 4;
+    constexpr int NKCAP = BG * TJ - 1;          // column NK (the right-hand side) must exist: NK <= 16*TJ - 1, rows NK <= 16*TI
+
+    // ---- LDS carve.  U is a union region: {a_y, a_s} during assembly, {colbuf, rowbuf} during elimination, {part, A r_x} after.
+    double *p = sm;
+    double *A = p; p += m * lda;
+    double *bv = p; p += m;          // b (unused by the adjoint) ; later: multipliers mu[e]
+    double *xv = p; p += n;
+    double *yv = p; p += m;
+    double *vv = p; p += m;          // v = y - s ; later r_y
+    double *dv = p; p += m;          // d = DPi dy
+    double *rx = p; p += n;
+    double *fvec = p; p += n;        // sum over boundary cones of [ a_s (e_s.d) + A_c^T P d / (1 - lam) ]
+    double *cinfo = p; p += 6 * nqs; // per cone: lambda, nz, e_y.d, e_s.d
+    double *pivrow = p; p += BG * TI;   // pivot value of the row that served as pivot
+    double *red = p; p += NW * 8;
+    double *U = p; p += bwd_rt_union_doubles(n, m, nqs, TI, TJ);
+    double *ay = U, *as = U + nqs * n;                              // A_c^T e_y, A_c^T e_s
+    double *colbuf = U, *rowbuf = U + 2 * BG * TI;
+    double *part = U, *qv2 = U + max(NT, m);                        // A r_x
+    int *ip = (int *)p;
+    int *rkind = ip; ip += m;
+    int *eqrow = ip; ip += m;
+    int *ckind = ip; ip += nqs;
+    int *ceq = ip; ip += nqs;
+    int *esrc = ip; ip += BG * TJ;      // equality e -> source: row index (>= 0) or -1 - cone
+    int *colof = ip; ip += BG * TI;     // pivot row r -> column it eliminated
+    int *wcnt = ip; ip += NW + 1;
+    int *misc = ip; ip += 8;            // [0] n_eq, [2] flags, [4],[5] pivot row per buffer
+
+    load_instance(T, Avals + (size_t)inst * T.nnz_aug, A, bv);
+    for (int j = tid; j < n; j += NT) xv[j] = xg[(size_t)inst * n + j];
+    for (int i = tid; i < m; i += NT) {
+        const double yi = yg[(size_t)inst * m + i];
+        yv[i] = yi; vv[i] = yi - sg[(size_t)inst * m + i];
+    }
+    if (tid < 8) misc[tid] = 0;
+    __syncthreads();
+    // ---- classify
+    for (int i = tid; i < z + T.l; i += NT) rkind[i] = (i < z || vv[i] > 0) ? RK_EQ : RK_FREE;
+    for (int c = tid; c < nq; c += NT) {
+        const int r0 = T.qoff[c], r1 = T.qoff[c + 1], d = r1 - r0;
+        int kind; double lam = 0, nz = 0;
+        if (d == 1) kind = vv[r0] >= 0 ? 0 : 1;
+        else {
+            for (int i = r0 + 1; i < r1; i++) nz = fma(vv[i], vv[i], nz);
+            nz = sqrt(nz);
+            const double t0 = vv[r0];
+            if (nz <= t0) kind = 0; else if (nz <= -t0) kind = 1; else { kind = 2; lam = (t0 + nz) / (2 * nz); }
+        }
+        ckind[c] = kind; cinfo[6 * c] = lam; cinfo[6 * c + 1] = nz;
+        for (int i = r0; i < r1; i++) rkind[i] = kind == 0 ? RK_EQ : (kind == 1 ? RK_FREE : RK_SOCB);
+    }
+    __syncthreads();
+    // ---- equality numbering: ballot prefix sums (rows in order, then one e_y row per boundary cone)
+    {
+        int base = 0;
+        for (int i0 = 0; i0 < m; i0 += NT) {
+            const int i = i0 + tid;
+            const bool f = (i < m) && (rkind[i] == RK_EQ);
+            const unsigned long long bal = __ballot(f);
+            const int lane = tid & 63, wid = tid >> 6;
+            if (lane == 0) wcnt[wid] = __popcll(bal);
+            __syncthreads();
+            int off = base;
+            for (int w = 0; w < wid; w++) off += wcnt[w];
+            int tot = 0;
+            for (int w = 0; w < NW; w++) tot += wcnt[w];
+            if (i < m) {
+                const int e = f ? off + __popcll(bal & ((1ull << lane) - 1ull)) : -1;
+                eqrow[i] = e;
+                if (f && e < BG * TJ) esrc[e] = i;
+            }
+            base += tot;
+            __syncthreads();
+        }
+        if (tid == 0) {
+            int ne = base;
+            for (int c = 0; c < nq; c++) { if (ckind[c] == 2) { if (ne < BG * TJ) esrc[ne] = -1 - c; ceq[c] = ne++; } else ceq[c] = -1; }
+            misc[0] = ne;
+        }
+        __syncthreads();
+    }
+    const int neq = misc[0];
+    const int NK = n + neq;
+    if (NK > NKCAP || NK > BG * TI) {   // more active rows than the register tile holds: degenerate instance (flagged, zero gradient)
+        for (int k = tid; k < T.nnz_aug; k += NT) dAo[(size_t)inst * T.nnz_aug + k] = 0.0;
+        for (int j = tid; j <= n; j += NT) dqo[j * sdqk + inst * sdqb] = 0.0;
+        if (tid == 0 && adj_status) adj_status[inst] = 2;
+        return;
+    }
+    // ---- d = DPi(v) dy, per-cone scalars
+    for (int i = tid; i < z + T.l; i += NT) dv[i] = rkind[i] == RK_EQ ? dyg[(size_t)inst * m + i] : 0.0;
+    for (int c = tid; c < nq; c += NT) {
+        const int r0 = T.qoff[c], r1 = T.qoff[c + 1];
+        const double *h = dyg + (size_t)inst * m;
+        if (ckind[c] == 0) { for (int i = r0; i < r1; i++) dv[i] = h[i]; }
+        else if (ckind[c] == 1) { for (int i = r0; i < r1; i++) dv[i] = 0.0; }
+        else {
+            const double t0 = vv[r0], nz = cinfo[6 * c + 1];
+            double zh = 0; for (int i = r0 + 1; i < r1; i++) zh = fma(vv[i], h[i], zh);
+            dv[r0] = (nz * h[r0] + zh) / (2 * nz);
+            for (int i = r0 + 1; i < r1; i++) dv[i] = (vv[i] * h[r0] + (t0 + nz) * h[i] - t0 * vv[i] * zh / (nz * nz)) / (2 * nz);
+            double zd = 0; for (int i = r0 + 1; i < r1; i++) zd = fma(vv[i], dv[i], zd);
+            zd /= nz;
+            cinfo[6 * c + 2] = (dv[r0] + zd) * M_SQRT1_2;   // e_y . d
+            cinfo[6 * c + 3] = (dv[r0] - zd) * M_SQRT1_2;   // e_s . d
+        }
+    }
+    __syncthreads();
+    // ---- a_y, a_s for boundary cones
+    for (int idx = tid; idx < nq * n; idx += NT) {
+        const int c = idx / n, j = idx - c * n;
+        if (ckind[c] != 2) continue;
+        const int r0 = T.qoff[c], r1 = T.qoff[c + 1];
+        const double inz = 1.0 / cinfo[6 * c + 1];
+        double a = 0;
+        for (int i = r0 + 1; i < r1; i++) a = fma(A[i * lda + j], vv[i], a);
+        a *= inz;
+        ay[idx] = (A[r0 * lda + j] + a) * M_SQRT1_2;
+        as[idx] = (A[r0 * lda + j] - a) * M_SQRT1_2;
+    }
+    __syncthreads();
+    // ---- fvec[j] = sum_c [ a_s (e_s.d) + (A_c^T d - a_y (e_y.d) - a_s (e_s.d)) / (1 - lam) ]   (deterministic order)
+    for (int j = tid; j < n; j += NT) {
+        double acc = 0;
+        for (int c = 0; c < nq; c++) {
+            if (ckind[c] != 2) continue;
+            const int r0 = T.qoff[c], r1 = T.qoff[c + 1];
+            const double lam = cinfo[6 * c], eyd = cinfo[6 * c + 2], esd = cinfo[6 * c + 3];
+            double g = 0;
+            for (int i = r0; i < r1; i++) g = fma(A[i * lda + j], dv[i], g);
+            const double a = g - ay[c * n + j] * eyd - as[c * n + j] * esd;      // A_c^T P d
+            acc += as[c * n + j] * esd + a / (1 - lam);
+        }
+        fvec[j] = acc;
+    }
+    __syncthreads();
+    // ---- assemble the register tile of [K | rhs]
+    double kt[TI][TJ];
+#pragma unroll
+    for (int i = 0; i < TI; i++)
+#pragma unroll
+        for (int j = 0; j < TJ; j++) kt[i][j] = 0.0;
+    // H block (r < n, c < n): H = sum_c theta_c (A_c^T A_c - a_y a_y^T - a_s a_s^T), accumulated straight into the tile
+    for (int c = 0; c < nq; c++) {
+        if (ckind[c] != 2) continue;                       // uniform
+        const double lam = cinfo[6 * c], th = lam / (1 - lam);
+        const int r0 = T.qoff[c], r1 = T.qoff[c + 1];
+        for (int ii = r0; ii < r1; ii++) {
+            const double *row = A + ii * lda;
+            double ar[TH], ac[TH];
+#pragma unroll
+            for (int i = 0; i < TH; i++) ar[i] = (ra + BG * i < n) ? th * row[ra + BG * i] : 0.0;
+#pragma unroll
+            for (int j = 0; j < TH; j++) ac[j] = (cb + BG * j < n) ? row[cb + BG * j] : 0.0;
+#pragma unroll
+            for (int i = 0; i < TH; i++)
+#pragma unroll
+                for (int j = 0; j < TH; j++) kt[i][j] = fma(ar[i], ac[j], kt[i][j]);
+        }
+        const double *ayc = ay + c * n, *asc = as + c * n;
+#pragma unroll
+        for (int i = 0; i < TH; i++)
+#pragma unroll
+            for (int j = 0; j < TH; j++) {
+                const int r = ra + BG * i, cc = cb + BG * j;
+                if (r < n && cc < n) kt[i][j] = fma(-th, ayc[r] * ayc[cc] + asc[r] * asc[cc], kt[i][j]);
+            }
+    }
+    // B / -B^T blocks and the right-hand side
+#pragma unroll
+    for (int i = 0; i < TI; i++)
+#pragma unroll
+        for (int j = 0; j < TJ; j++) {
+            const int r = ra + BG * i, cc = cb + BG * j;
+            if (r >= NK || cc > NK) continue;
+            if (cc == NK) {
+                double val;
+                if (r < n) {
+                    val = dxg[(size_t)inst * n + r] + fvec[r];
+                } else {
+                    const int src = esrc[r - n];
+                    val = src >= 0 ? dv[src] : cinfo[6 * (-1 - src) + 2];
+                }
+                kt[i][j] = val;
+            } else if (r < n && cc >= n) {
+                const int src = esrc[cc - n];
+                kt[i][j] = -(src >= 0 ? A[src * lda + r] : ay[(-1 - src) * n + r]);
+            } else if (r >= n && cc < n) {
+                const int src = esrc[r - n];
+                kt[i][j] = src >= 0 ? A[src * lda + cc] : ay[(-1 - src) * n + cc];
+            }
+        }
+    // ---- pivot tolerance
+    double ptol;
+    {
+        double r[1] = {0};
+#pragma unroll
+        for (int i = 0; i < TI; i++)
+#pragma unroll
+            for (int j = 0; j < TJ; j++) if (cb + BG * j < NK) r[0] = fmax(r[0], fabs(kt[i][j]));
+        block_reduce<1>(r, 1u, red);
+        ptol = 1e-13 * (r[0] > 0 ? r[0] : 1.0);
+    }
+    __syncthreads();                 // a_y / a_s are dead: the union region becomes colbuf / rowbuf
+    for (int i = tid; i < 2 * BG * TI; i += NT) colbuf[i] = 0.0;
+    for (int i = tid; i < 2 * BG * TJ; i += NT) rowbuf[i] = 0.0;
+    __syncthreads();
+    // ---- Gauss-Jordan with partial pivoting on the register tiles
+    unsigned rowdone = 0;     // bit i: row ra + 16 i has served as pivot
+#pragma unroll
+    for (int jk = 0; jk < TJ; jk++) {
+        for (int ck = 0; ck < BG; ck++) {
+            const int k = BG * jk + ck;
+            if (k >= NK) break;
+            const int buf = k & 1;
+            double *cbuf = colbuf + buf * BG * TI, *rbuf = rowbuf + buf * BG * TJ;
+            if (cb == ck) {   // the 16 lanes owning column k: pivot search + publish the column
+                double best = -1.0; int bi = 0;
+#pragma unroll
+                for (int i = 0; i < TI; i++) {
+                    const int r = ra + BG * i;
+                    const double v = fabs(kt[i][jk]);
+                    if (r < NK && !((rowdone >> i) & 1u) && v > best) { best = v; bi = r; }
+                }
+#pragma unroll
+                for (int o = 1; o < BG; o <<= 1) {
+                    const double ob = __shfl_xor(best, o); const int oi = __shfl_xor(bi, o);
+                    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+                }
+#pragma unroll
+                for (int i = 0; i < TI; i++) cbuf[ra + BG * i] = kt[i][jk];
+                if (ra == 0) { misc[4 + buf] = bi; if (best < ptol) misc[2] = 1; }
+            }
+            __syncthreads();
+            const int prow = misc[4 + buf];
+            if (ra == (prow & (BG - 1))) {   // owners of the pivot row publish it
+                const int ipv = prow >> 4;
+#pragma unroll
+                for (int i = 0; i < TI; i++) if (i == ipv) {
+#pragma unroll
+                    for (int j = jk; j < TJ; j++) rbuf[cb + BG * j] = kt[i][j];
+                }
+                rowdone |= 1u << ipv;
+                if (cb == 0) colof[prow] = k;
+            }
+            __syncthreads();
+            double piv = cbuf[prow];
+            if (fabs(piv) < ptol) piv = (piv < 0 ? -ptol : ptol);
+            const double pinv = 1.0 / piv;
+            if (tid == 0) pivrow[prow] = piv;
+            double f[TI], rw[TJ];
+#pragma unroll
+            for (int i = 0; i < TI; i++) { const int r = ra + BG * i; f[i] = (r == prow) ? 0.0 : cbuf[r] * pinv; }
+#pragma unroll
+            for (int j = jk; j < TJ; j++) rw[j] = rbuf[cb + BG * j];
+            if (cb <= ck) rw[jk] = 0.0;      // columns <= k of this slot are finished
+#pragma unroll
+            for (int j = jk; j < TJ; j++) {
+                if (BG * j > NK) continue;   // uniform: nothing lives beyond the right-hand-side column
+#pragma unroll
+                for (int i = 0; i < TI; i++) kt[i][j] = fma(-f[i], rw[j], kt[i][j]);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- solution: sol[colof[r]] = rhs[r] / pivot(r);  r_x -> rx, multipliers -> bv
+#pragma unroll
+    for (int j = 0; j < TJ; j++) {
+        if (cb + BG * j != NK) continue;
+#pragma unroll
+        for (int i = 0; i < TI; i++) {
+            const int r = ra + BG * i;
+            if (r < NK) {
+                const int k = colof[r];
+                const double sol = kt[i][j] / pivrow[r];
+                if (k < n) rx[k] = sol; else bv[k - n] = sol;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- q = A r_x ; r_y
+    mv_rows_partial(A, lda, m, n, rx, part);
+    __syncthreads();
+    for (int i = tid; i < m; i += NT) qv2[i] = sum_parts(part, m, i);
+    __syncthreads();
+    for (int i = tid; i < z + T.l; i += NT) vv[i] = (eqrow[i] >= 0) ? bv[eqrow[i]] : dv[i];
+    for (int c = tid; c < nq; c += NT) {
+        const int r0 = T.qoff[c], r1 = T.qoff[c + 1];
+        if (ckind[c] == 0) { for (int i = r0; i < r1; i++) vv[i] = bv[eqrow[i]]; }
+        else if (ckind[c] == 1) { for (int i = r0; i < r1; i++) vv[i] = dv[i]; }
+        else {
+            // r_y = rho_y e_y + (e_s.d) e_s + (P d - lam P q) / (1 - lam),   P = I - e_y e_y^T - e_s e_s^T
+            const double lam = cinfo[6 * c], inz = 1.0 / cinfo[6 * c + 1], eyd = cinfo[6 * c + 2], esd = cinfo[6 * c + 3];
+            const double rhoy = bv[ceq[c]];
+            double zq = 0; for (int i = r0 + 1; i < r1; i++) zq = fma(vv[i], qv2[i], zq);
+            zq *= inz;
+            const double eyq = (qv2[r0] + zq) * M_SQRT1_2, esq = (qv2[r0] - zq) * M_SQRT1_2;
+            const double il = 1.0 / (1 - lam);
+            const double cy = rhoy - il * (eyd - lam * eyq), cs = esd - il * (esd - lam * esq);
+            const double k0 = (cy + cs) * M_SQRT1_2, kz = (cy - cs) * M_SQRT1_2;
+            for (int i = r0 + 1; i < r1; i++) { const double zh = vv[i] * inz; vv[i] = il * (dv[i] - lam * qv2[i]) + kz * zh; }
+            vv[r0] = il * (dv[r0] - lam * qv2[r0]) + k0;
+        }
+    }
+    __syncthreads();
+    // ---- outputs in the boundary convention: dA_eval = [-dA.data, db[b_idx]], dq_eval = [dc, 0]   (diffcp_if.py:91-92)
+    for (int k = tid; k < T.nnz_aug; k += NT) {
+        const int i = T.rowidx[k], j = T.colidx[k];
+        const double val = (j < n) ? -(xv[j] * vv[i] - yv[i] * rx[j]) : -vv[i];
+        dAo[(size_t)inst * T.nnz_aug + k] = val;
+    }
+    for (int j = tid; j <= n; j += NT) dqo[j * sdqk + inst * sdqb] = (j < n) ? -rx[j] : 0.0;
+    if (tid == 0 && adj_status) adj_status[inst] = misc[2];
+}

@@ -35,6 +35,7 @@ namespace {
 #include "ce_forward_generic.h"
 #include "ce_forward_rt.h"
 #include "ce_backward.h"
+#include "ce_backward_rt.h"
 }  // namespace
 
 // ================================================================================================
@@ -53,6 +54,7 @@ struct ce_engine {
     // launch plan
     int fwd_mode = 0, bwd_mode = 0; size_t fwd_lds = 0, bwd_lds = 0; int nkcap = 0, ldk = 0;
     int rt_variant = -1, rt_vp = 0, rt_lda = 0;   // register-tiled forward kernel variant (-1: generic kernel)
+    int brt_variant = -1;                          // register-tiled backward kernel variant (-1: generic kernel)
     // profiling
     bool prof = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[3];
@@ -98,6 +100,15 @@ static size_t bwd_lds_bytes(const DevT &T, bool a_lds, bool k_lds, int nkcap, in
     if (k_lds) d += (size_t)nkcap * ldk;
     d += 5 * (size_t)m + 2 * (size_t)n + 2 * (size_t)nqs * n + 6 * nqs + PB + NW * 8;
     size_t ints = 2 * (size_t)m + 2 * nqs + nkcap + 4;
+    return d * 8 + ints * 4 + 16;
+}
+
+// register-tiled backward variants {TI, TJ, TH}: K tile 16*TI x 16*TJ per workgroup, H tile 16*TH
+static const int BRT_VARIANTS[3][3] = {{4, 4, 4}, {7, 7, 4}, {7, 7, 7}};
+static size_t bwd_rt_lds_bytes(const DevT &T, int TI, int TJ) {
+    const int n = T.n, m = T.m, nqs = std::max(T.nq, 1);
+    size_t d = (size_t)m * n /* lda = n */ + 4 * (size_t)m + 3 * (size_t)n + 6 * nqs + BG * TI + NW * 8 + bwd_rt_union_doubles(n, m, nqs, TI, TJ);
+    size_t ints = 2 * (size_t)m + 2 * nqs + BG * TJ + BG * TI + NW + 1 + 8;
     return d * 8 + ints * 4 + 16;
 }
 
@@ -159,9 +170,18 @@ int ce_create(const ce_template *tpl, int device, ce_handle *out) {
     else if (bwd_lds_bytes(T, false, false, h->nkcap, h->ldk) <= LDS_LIMIT) h->bwd_mode = 2;
     else { ce_destroy(h); g_err = "instance vectors do not fit LDS"; return CE_E_TOO_LARGE; }
     h->bwd_lds = bwd_lds_bytes(T, h->bwd_mode <= 1, h->bwd_mode == 0, h->nkcap, h->ldk);
+    if (!getenv("CE_FORCE_GENERIC")) {
+        for (int v = 0; v < 3; v++) {
+            const int TI = BRT_VARIANTS[v][0], TJ = BRT_VARIANTS[v][1], TH = BRT_VARIANTS[v][2];
+            if (h->nkcap <= BG * TJ - 1 && h->nkcap <= BG * TI && T.n <= BG * TH && bwd_rt_lds_bytes(T, TI, TJ) <= LDS_LIMIT) {
+                h->brt_variant = v; h->bwd_mode = 3; h->bwd_lds = bwd_rt_lds_bytes(T, TI, TJ); break;
+            }
+        }
+    }
 #define SETATTR(kern, bytes) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)))
     SETATTR((k_forward<true, true>), LDS_LIMIT);  SETATTR((k_forward<true, false>), LDS_LIMIT);  SETATTR((k_forward<false, false>), LDS_LIMIT);
     SETATTR((k_forward_rt<8, 13, 7, 4, 13, 160, 4>), LDS_LIMIT); SETATTR((k_forward_rt<8, 16, 8, 4, 16, 208, 4>), LDS_LIMIT); SETATTR((k_forward_rt<4, 32, 32, 4, 32, 272, 2>), LDS_LIMIT);
+    SETATTR((k_backward_rt<4, 4, 4>), LDS_LIMIT); SETATTR((k_backward_rt<7, 7, 4>), LDS_LIMIT); SETATTR((k_backward_rt<7, 7, 7>), LDS_LIMIT);
     SETATTR((k_backward<true, true>), LDS_LIMIT); SETATTR((k_backward<true, false>), LDS_LIMIT); SETATTR((k_backward<false, false>), LDS_LIMIT);
 #undef SETATTR
     *out = h;
@@ -263,7 +283,7 @@ int ce_vjp(ce_handle h, int B, const double *A_vals, long sA_k, long sA_b, const
     else if (sdA_b == 1 && sdA_k == B) { rc = ensure(&h->wsdA, &h->wsdA_bytes, sizeof(double) * (size_t)B * K); if (rc) return rc; dAbm = h->wsdA; need_tr = true; }
     else { g_err = "dA_vals must be contiguous batch-minor or batch-major"; return CE_E_BADARG; }
     double *gA = nullptr, *gK = nullptr;
-    if (h->bwd_mode > 0) {
+    if (h->bwd_mode > 0 && h->bwd_mode < 3) {
         size_t perA = (h->bwd_mode == 2) ? (size_t)T.m * T.lda : 0, perK = (size_t)h->nkcap * h->ldk;
         rc = ensure(&h->gws, &h->gws_bytes, sizeof(double) * (size_t)B * (perA + perK));
         if (rc) return rc;
@@ -273,7 +293,12 @@ int ce_vjp(ce_handle h, int B, const double *A_vals, long sA_k, long sA_b, const
         ProfScope ps(h, 1, st);
         dim3 grid(B), block(NT);
 #define LAUNCH_B(AL, KL) hipLaunchKernelGGL((k_backward<AL, KL>), grid, block, h->bwd_lds, st, T, h->nkcap, h->ldk, Abm, x, y, s, dx, dy, dAbm, dq_vals, sdq_k, sdq_b, adj_status, gA, gK)
-        if (h->bwd_mode == 0) LAUNCH_B(true, true); else if (h->bwd_mode == 1) LAUNCH_B(true, false); else LAUNCH_B(false, false);
+        DevT Tb = T; Tb.lda = T.n;
+#define LAUNCH_BRT(...) hipLaunchKernelGGL((k_backward_rt<__VA_ARGS__>), grid, block, h->bwd_lds, st, Tb, Abm, x, y, s, dx, dy, dAbm, dq_vals, sdq_k, sdq_b, adj_status)
+        if (h->bwd_mode == 3) {
+            if (h->brt_variant == 0) LAUNCH_BRT(4, 4, 4); else if (h->brt_variant == 1) LAUNCH_BRT(7, 7, 4); else LAUNCH_BRT(7, 7, 7);
+        } else if (h->bwd_mode == 0) LAUNCH_B(true, true); else if (h->bwd_mode == 1) LAUNCH_B(true, false); else LAUNCH_B(false, false);
+#undef LAUNCH_BRT
 #undef LAUNCH_B
     }
     if (need_tr) {

@@ -43,7 +43,10 @@ def test_engine_matches_golden(path):
     from cvxpylayers_amd.interfaces.mi355_if import ConeEngine, make_settings
     d, n, cones, A, b, c = load(path)
     tpl = P.dense_template(n, cones)
-    eng = ConeEngine(tpl.indices, tpl.indptr, tpl.n, tpl.m, tpl.cones, torch.device("cuda", 0))
+    try:
+        eng = ConeEngine(tpl.indices, tpl.indptr, tpl.n, tpl.m, tpl.cones, torch.device("cuda", 0))
+    except NotImplementedError as e:       # cone type the device path rejects explicitly (CE_E_UNSUPPORTED)
+        pytest.skip(str(e))
     A_eval, q_eval = tpl.values_from_dense(A, b, c)
     A_bm = eng.to_batch_major(torch.from_numpy(A_eval).cuda())
     x, y, s, iters, status, resid = eng.solve(A_bm, torch.from_numpy(q_eval).cuda(), make_settings(dict(eps=1e-10, max_iters=200000)))
