@@ -16,6 +16,12 @@
 
 constexpr int BG = 16;   // thread grid is BG x BG
 
+#ifdef CE_TIMING   // debug build: phase durations (shader cycles) of every workgroup overwrite the first entries of its dA row
+#define CE_STAMP(i) do { __syncthreads(); if (threadIdx.x == 0) tstamp[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define CE_STAMP(i) do { } while (0)
+#endif
+
 __host__ __device__ inline int bwd_rt_union_doubles(int n, int m, int nqs, int TI, int TJ) {
     int a = 2 * nqs * n, b = 2 * BG * TI + 2 * BG * TJ, c = (NT > m ? NT : m) + m;
     int r = a > b ? a : b;
@@ -38,14 +44,13 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
     double *p = sm;
     double *A = p; p += m * lda;
     double *bv = p; p += m;          // b (unused by the adjoint) ; later: multipliers mu[e]
-    double *xv = p; p += n;
-    double *yv = p; p += m;
     double *vv = p; p += m;          // v = y - s ; later r_y
     double *dv = p; p += m;          // d = DPi dy
     double *rx = p; p += n;
     double *fvec = p; p += n;        // sum over boundary cones of [ a_s (e_s.d) + A_c^T P d / (1 - lam) ]
     double *cinfo = p; p += 6 * nqs; // per cone: lambda, nz, e_y.d, e_s.d
     double *pivrow = p; p += BG * TI;   // pivot value of the row that served as pivot
+    double *pinfo = p; p += 2;          // pivot value per buffer
     double *red = p; p += NW * 8;
     double *U = p; p += bwd_rt_union_doubles(n, m, nqs, TI, TJ);
     double *ay = U, *as = U + nqs * n;                              // A_c^T e_y, A_c^T e_s
@@ -61,14 +66,15 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
     int *wcnt = ip; ip += NW + 1;
     int *misc = ip; ip += 8;            // [0] n_eq, [2] flags, [4],[5] pivot row per buffer
 
+#ifdef CE_TIMING
+    __shared__ long long tstamp[12];
+#endif
+    CE_STAMP(0);
     load_instance(T, Avals + (size_t)inst * T.nnz_aug, A, bv);
-    for (int j = tid; j < n; j += NT) xv[j] = xg[(size_t)inst * n + j];
-    for (int i = tid; i < m; i += NT) {
-        const double yi = yg[(size_t)inst * m + i];
-        yv[i] = yi; vv[i] = yi - sg[(size_t)inst * m + i];
-    }
+    for (int i = tid; i < m; i += NT) vv[i] = yg[(size_t)inst * m + i] - sg[(size_t)inst * m + i];
     if (tid < 8) misc[tid] = 0;
     __syncthreads();
+    CE_STAMP(1);
     // ---- classify
     for (int i = tid; i < z + T.l; i += NT) rkind[i] = (i < z || vv[i] > 0) ? RK_EQ : RK_FREE;
     for (int c = tid; c < nq; c += NT) {
@@ -122,6 +128,7 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
         if (tid == 0 && adj_status) adj_status[inst] = 2;
         return;
     }
+    CE_STAMP(2);
     // ---- d = DPi(v) dy, per-cone scalars
     for (int i = tid; i < z + T.l; i += NT) dv[i] = rkind[i] == RK_EQ ? dyg[(size_t)inst * m + i] : 0.0;
     for (int c = tid; c < nq; c += NT) {
@@ -154,21 +161,27 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
         as[idx] = (A[r0 * lda + j] - a) * M_SQRT1_2;
     }
     __syncthreads();
-    // ---- fvec[j] = sum_c [ a_s (e_s.d) + (A_c^T d - a_y (e_y.d) - a_s (e_s.d)) / (1 - lam) ]   (deterministic order)
-    for (int j = tid; j < n; j += NT) {
+    // ---- fvec[j] = sum_c [ a_s (e_s.d) + (A_c^T d - a_y (e_y.d) - a_s (e_s.d)) / (1 - lam) ]
+    //      4 lanes per column, each takes every 4th cone; fixed summation order (deterministic)
+    for (int j0 = 0; j0 < n; j0 += NT / 4) {
+        const int j = j0 + (tid >> 2), part = tid & 3;
         double acc = 0;
-        for (int c = 0; c < nq; c++) {
-            if (ckind[c] != 2) continue;
-            const int r0 = T.qoff[c], r1 = T.qoff[c + 1];
-            const double lam = cinfo[6 * c], eyd = cinfo[6 * c + 2], esd = cinfo[6 * c + 3];
-            double g = 0;
-            for (int i = r0; i < r1; i++) g = fma(A[i * lda + j], dv[i], g);
-            const double a = g - ay[c * n + j] * eyd - as[c * n + j] * esd;      // A_c^T P d
-            acc += as[c * n + j] * esd + a / (1 - lam);
+        if (j < n) {
+            for (int c = part; c < nq; c += 4) {
+                if (ckind[c] != 2) continue;
+                const int r0 = T.qoff[c], r1 = T.qoff[c + 1];
+                const double lam = cinfo[6 * c], eyd = cinfo[6 * c + 2], esd = cinfo[6 * c + 3];
+                double g = 0;
+                for (int i = r0; i < r1; i++) g = fma(A[i * lda + j], dv[i], g);
+                const double a = g - ay[c * n + j] * eyd - as[c * n + j] * esd;      // A_c^T P d
+                acc += as[c * n + j] * esd + a / (1 - lam);
+            }
         }
-        fvec[j] = acc;
+        acc = group_reduce<4, false>(acc);
+        if (j < n && part == 0) fvec[j] = acc;
     }
     __syncthreads();
+    CE_STAMP(3);
     // ---- assemble the register tile of [K | rhs]
     double kt[TI][TJ];
 #pragma unroll
@@ -180,6 +193,7 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
         if (ckind[c] != 2) continue;                       // uniform
         const double lam = cinfo[6 * c], th = lam / (1 - lam);
         const int r0 = T.qoff[c], r1 = T.qoff[c + 1];
+#pragma unroll 2
         for (int ii = r0; ii < r1; ii++) {
             const double *row = A + ii * lda;
             double ar[TH], ac[TH];
@@ -201,30 +215,39 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
                 if (r < n && cc < n) kt[i][j] = fma(-th, ayc[r] * ayc[cc] + asc[r] * asc[cc], kt[i][j]);
             }
     }
-    // B / -B^T blocks and the right-hand side
+    // B / -B^T blocks and the right-hand side.  The source of equality e (a row of A or a_y of a boundary cone) is resolved
+    // once per tile row / column into an LDS base pointer, so each entry costs one independent LDS read.
+    {
+        const double *prow_src[TI], *pcol_src[TJ];
+        double rhs_eq[TI];
 #pragma unroll
-    for (int i = 0; i < TI; i++)
-#pragma unroll
-        for (int j = 0; j < TJ; j++) {
-            const int r = ra + BG * i, cc = cb + BG * j;
-            if (r >= NK || cc > NK) continue;
-            if (cc == NK) {
-                double val;
-                if (r < n) {
-                    val = dxg[(size_t)inst * n + r] + fvec[r];
-                } else {
-                    const int src = esrc[r - n];
-                    val = src >= 0 ? dv[src] : cinfo[6 * (-1 - src) + 2];
-                }
-                kt[i][j] = val;
-            } else if (r < n && cc >= n) {
-                const int src = esrc[cc - n];
-                kt[i][j] = -(src >= 0 ? A[src * lda + r] : ay[(-1 - src) * n + r]);
-            } else if (r >= n && cc < n) {
+        for (int i = 0; i < TI; i++) {
+            const int r = ra + BG * i;
+            prow_src[i] = A; rhs_eq[i] = 0.0;
+            if (r >= n && r < NK) {
                 const int src = esrc[r - n];
-                kt[i][j] = src >= 0 ? A[src * lda + cc] : ay[(-1 - src) * n + cc];
+                prow_src[i] = src >= 0 ? A + src * lda : ay + (-1 - src) * n;
+                rhs_eq[i] = src >= 0 ? dv[src] : cinfo[6 * (-1 - src) + 2];
             }
         }
+#pragma unroll
+        for (int j = 0; j < TJ; j++) {
+            const int cc = cb + BG * j;
+            pcol_src[j] = A;
+            if (cc >= n && cc < NK) { const int src = esrc[cc - n]; pcol_src[j] = src >= 0 ? A + src * lda : ay + (-1 - src) * n; }
+        }
+#pragma unroll
+        for (int i = 0; i < TI; i++)
+#pragma unroll
+            for (int j = 0; j < TJ; j++) {
+                const int r = ra + BG * i, cc = cb + BG * j;
+                if (r >= NK || cc > NK) continue;
+                if (cc == NK) kt[i][j] = (r < n) ? dxg[(size_t)inst * n + r] + fvec[r] : rhs_eq[i];
+                else if (r < n && cc >= n) kt[i][j] = -pcol_src[j][r];
+                else if (r >= n && cc < n) kt[i][j] = prow_src[i][cc];
+            }
+    }
+    CE_STAMP(4);
     // ---- pivot tolerance
     double ptol;
     {
@@ -238,66 +261,86 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
     }
     __syncthreads();                 // a_y / a_s are dead: the union region becomes colbuf / rowbuf
     for (int i = tid; i < 2 * BG * TI; i += NT) colbuf[i] = 0.0;
-    for (int i = tid; i < 2 * BG * TJ; i += NT) rowbuf[i] = 0.0;
     __syncthreads();
-    // ---- Gauss-Jordan with partial pivoting on the register tiles
+    // ---- Gauss-Jordan with partial pivoting on the register tiles.  One workgroup barrier per pivot:
+    //   (1) the 16 lanes owning column k (one DPP row) find the pivot with a DPP butterfly and publish the column
+    //       (pivot entry zeroed, pivot value separately) -> barrier
+    //   (2) the pivot row is broadcast INSIDE each 16-lane row with ds_bpermute (the lane with ra == prow % 16 holds exactly
+    //       the entries K[prow][cb + 16 j] its row-mates need), so no second LDS round trip / barrier is required
+    //   (3) rank-1 update of the live part of the tile (row slots >= ceil(NK/16) and column slots < jk are skipped)
     unsigned rowdone = 0;     // bit i: row ra + 16 i has served as pivot
+    const int ilim = (NK + BG - 1) / BG;          // row slots in use
+    const int lane_base = ((tid & 63) & ~(BG - 1)) << 2;      // byte address of lane 0 of this DPP row for ds_bpermute
 #pragma unroll
     for (int jk = 0; jk < TJ; jk++) {
         for (int ck = 0; ck < BG; ck++) {
             const int k = BG * jk + ck;
             if (k >= NK) break;
             const int buf = k & 1;
-            double *cbuf = colbuf + buf * BG * TI, *rbuf = rowbuf + buf * BG * TJ;
+            double *cbuf = colbuf + buf * BG * TI;
             if (cb == ck) {   // the 16 lanes owning column k: pivot search + publish the column
-                double best = -1.0; int bi = 0;
+                // arg max |K[r][k]| over the rows not yet used, as ONE v_max_f64 per candidate: positive doubles order like their
+                // bit patterns, so the row index rides in the 8 lowest mantissa bits (255 - r: ties go to the smallest row)
+                double best = 0.0;       // key 0: no candidate
 #pragma unroll
                 for (int i = 0; i < TI; i++) {
                     const int r = ra + BG * i;
                     const double v = fabs(kt[i][jk]);
-                    if (r < NK && !((rowdone >> i) & 1u) && v > best) { best = v; bi = r; }
+                    const int lo = (__double2loint(v) & ~0xFF) | (255 - r);
+                    const double key = __hiloint2double(__double2hiint(v), lo);
+                    if (r < NK && !((rowdone >> i) & 1u)) best = fmax(best, key);
                 }
+                best = fmax(best, dpp_mov<0xB1>(best));     // quad_perm [1,0,3,2]
+                best = fmax(best, dpp_mov<0x4E>(best));     // quad_perm [2,3,0,1]
+                best = fmax(best, dpp_mov<0x141>(best));    // row_half_mirror
+                best = fmax(best, dpp_mov<0x140>(best));    // row_mirror
+                const int bi = 255 - (__double2loint(best) & 0xFF);
 #pragma unroll
-                for (int o = 1; o < BG; o <<= 1) {
-                    const double ob = __shfl_xor(best, o); const int oi = __shfl_xor(bi, o);
-                    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+                for (int i = 0; i < TI; i++) {
+                    const int r = ra + BG * i;
+                    const double v = kt[i][jk];
+                    if (r == bi) { pinfo[buf] = v; cbuf[r] = 0.0; } else cbuf[r] = v;
                 }
-#pragma unroll
-                for (int i = 0; i < TI; i++) cbuf[ra + BG * i] = kt[i][jk];
                 if (ra == 0) { misc[4 + buf] = bi; if (best < ptol) misc[2] = 1; }
             }
             __syncthreads();
-            const int prow = misc[4 + buf];
-            if (ra == (prow & (BG - 1))) {   // owners of the pivot row publish it
-                const int ipv = prow >> 4;
-#pragma unroll
-                for (int i = 0; i < TI; i++) if (i == ipv) {
-#pragma unroll
-                    for (int j = jk; j < TJ; j++) rbuf[cb + BG * j] = kt[i][j];
-                }
-                rowdone |= 1u << ipv;
-                if (cb == 0) colof[prow] = k;
-            }
-            __syncthreads();
-            double piv = cbuf[prow];
+            const int prow = __builtin_amdgcn_readfirstlane(misc[4 + buf]);
+            const int ipv = prow >> 4;
+            double piv = pinfo[buf];
             if (fabs(piv) < ptol) piv = (piv < 0 ? -ptol : ptol);
-            const double pinv = 1.0 / piv;
-            if (tid == 0) pivrow[prow] = piv;
-            double f[TI], rw[TJ];
+            double pinv = __builtin_amdgcn_rcp(piv);           // hardware seed + two Newton steps (the IEEE divide expansion is
+            pinv = fma(fma(-piv, pinv, 1.0), pinv, pinv);      // three times as long and sits on the critical path of every pivot)
+            pinv = fma(fma(-piv, pinv, 1.0), pinv, pinv);
+            if (ra == (prow & (BG - 1))) {
+                rowdone |= 1u << ipv;
+                if (cb == 0) { colof[prow] = k; pivrow[prow] = piv; }
+            }
+            // pivot row: broadcast inside each 16-lane row
+            double rw[TJ];
+            const int src = lane_base + ((prow & (BG - 1)) << 2);
 #pragma unroll
-            for (int i = 0; i < TI; i++) { const int r = ra + BG * i; f[i] = (r == prow) ? 0.0 : cbuf[r] * pinv; }
+            for (int i = 0; i < TI; i++) {
+                if (ipv == i) {      // uniform
 #pragma unroll
-            for (int j = jk; j < TJ; j++) rw[j] = rbuf[cb + BG * j];
+                    for (int j = jk; j < TJ; j++) {
+                        const double v = kt[i][j];
+                        const int lo = __builtin_amdgcn_ds_bpermute(src, __double2loint(v)), hi = __builtin_amdgcn_ds_bpermute(src, __double2hiint(v));
+                        rw[j] = __hiloint2double(hi, lo);
+                    }
+                }
+            }
             if (cb <= ck) rw[jk] = 0.0;      // columns <= k of this slot are finished
 #pragma unroll
-            for (int j = jk; j < TJ; j++) {
-                if (BG * j > NK) continue;   // uniform: nothing lives beyond the right-hand-side column
+            for (int i = 0; i < TI; i++) {
+                if (i >= ilim) continue;     // uniform: pad row slots
+                const double f = cbuf[ra + BG * i] * pinv;      // the pivot row's own entry was published as 0
 #pragma unroll
-                for (int i = 0; i < TI; i++) kt[i][j] = fma(-f[i], rw[j], kt[i][j]);
+                for (int j = jk; j < TJ; j++) kt[i][j] = fma(-f, rw[j], kt[i][j]);
             }
         }
     }
     __syncthreads();
+    CE_STAMP(5);
     // ---- solution: sol[colof[r]] = rhs[r] / pivot(r);  r_x -> rx, multipliers -> bv
 #pragma unroll
     for (int j = 0; j < TJ; j++) {
@@ -338,12 +381,19 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
         }
     }
     __syncthreads();
+    CE_STAMP(6);
     // ---- outputs in the boundary convention: dA_eval = [-dA.data, db[b_idx]], dq_eval = [dc, 0]   (diffcp_if.py:91-92)
+#pragma unroll 4
     for (int k = tid; k < T.nnz_aug; k += NT) {
         const int i = T.rowidx[k], j = T.colidx[k];
-        const double val = (j < n) ? -(xv[j] * vv[i] - yv[i] * rx[j]) : -vv[i];
+        const double val = (j < n) ? -(xg[(size_t)inst * n + j] * vv[i] - yg[(size_t)inst * m + i] * rx[j]) : -vv[i];   // x, y: L1-resident gathers
         dAo[(size_t)inst * T.nnz_aug + k] = val;
     }
     for (int j = tid; j <= n; j += NT) dqo[j * sdqk + inst * sdqb] = (j < n) ? -rx[j] : 0.0;
     if (tid == 0 && adj_status) adj_status[inst] = misc[2];
+#ifdef CE_TIMING
+    CE_STAMP(7);
+    if (tid < 7) dAo[(size_t)inst * T.nnz_aug + tid] = (double)(tstamp[tid + 1] - tstamp[tid]);
+    if (tid == 7) dAo[(size_t)inst * T.nnz_aug + 7] = (double)NK;
+#endif
 }

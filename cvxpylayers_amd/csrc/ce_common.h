@@ -109,6 +109,7 @@ __device__ __forceinline__ void load_instance(const DevT &T, const double *vals,
     for (int i = threadIdx.x; i < m * lda; i += NT) A[i] = 0.0;
     for (int i = threadIdx.x; i < m; i += NT) bv[i] = 0.0;
     __syncthreads();
+#pragma unroll 4
     for (int k = threadIdx.x; k < T.nnz_aug; k += NT) {
         const double val = vals[k];
         const int r = T.rowidx[k], c = T.colidx[k];

@@ -1,0 +1,621 @@
+// ce_forward_v2.h -- forward kernel, second generation: one instance per 256-thread workgroup (4 wave64), 3 workgroups
+// per CU, BOTH operand layouts of A-hat in registers, G in LDS.
+//
+//   at[T1] : thread (j1 = tid / CHT, c1 = tid % CHT) holds the column segment  A[T1*c1 + k][j1],  k < T1      -> A^T v
+//   ar[T2] : thread (i2 = tid / CHA, c2 = tid % CHA) holds the row segment     A[i2][T2*c2 + k],  k < T2      -> A v
+//   G      : (rho_x I + A^T Dy A)^{-1}, n x ldg doubles in LDS; thread (jg = tid / CHG, cg = tid % CHG) multiplies
+//            the row segment G[jg][TG*cg + k], k < TG                                                          -> G v
+// Segments are BLOCKED (contiguous, even length), so every vector operand is fetched with ds_read_b128 (two doubles per
+// LDS instruction; segments of the lanes of one 16-lane LDS group are a multiple of 16 B apart and fall on distinct
+// banks), and every product ends in a DPP butterfly over CHT / CHA / CHG (<= 16) adjacent lanes -- no LDS round trip for
+// partial sums.  Compared with ce_forward_rt.h (512 threads, A rows in LDS): half the threads per instance (fewer
+// reduction stages, fewer waves per barrier), no matrix traffic on the LDS pipe, 41 KB of LDS per instance -> 3
+// instances per CU, and a register budget of 168 VGPRs with 104 of them holding the two tiles -> no scratch spills.
+//
+// The reduced KKT matrix is formed from row panels staged through the (not yet used) G region and inverted by
+// Gauss-Jordan on a register tile (one barrier per pivot, pivot order k = kk + TG*cg so that register slots are static).
+// Algorithm, constants and the order of operations per iterate are those of oracle/cone_oracle.c (SCS 3 restated).
+#pragma once
+
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
+template <int CHT, int T1, int CHA, int T2, int CHG, int TG>
+struct F2 {
+    static constexpr int MP = CHT * T1;                       // padded rows
+    static constexpr int NPa = CHA * T2, NPg = CHG * TG;
+    static constexpr int NP = NPa > NPg ? NPa : NPg;          // padded columns
+    static constexpr int VP = MP + NP + 2;                    // one (y | x | tau) vector
+    static constexpr int OY = 0, OX = MP, OT = MP + NP;
+    static constexpr int O_W = 0, O_UT = VP, O_U = 2 * VP, O_ZB = 3 * VP, O_GV = 4 * VP, O_PHI = 5 * VP;
+    static constexpr int O_BV = 6 * VP, O_DV = O_BV + MP, O_CV = O_DV + MP, O_EV = O_CV + NP, O_TV = O_EV + NP, O_PX = O_TV + NP,
+                         O_S1 = O_PX + NP, O_S2 = O_S1 + NP, O_S3 = O_S2 + NP, O_S4 = O_S3 + NP,
+                         O_RED = O_S4 + NP, O_WP = O_RED + NW * 8, O_SC = O_WP + NW, O_G = O_SC + 16;
+    static_assert(T1 % 2 == 0 && T2 % 2 == 0 && TG % 2 == 0, "segments must be even for 16-byte LDS reads");
+    static_assert(CHT <= 16 && CHA <= 16 && CHG <= 16, "DPP butterflies stay inside a row of 16 lanes");
+};
+
+// a value that is equal in every lane, moved to scalar registers (frees VGPRs in the iteration loop)
+__device__ __forceinline__ double uniform_d(double v) {
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+
+// sqrt(q) and 1/sqrt(q) to ~1 ulp without the fp64 sqrt + divide expansions (~60 VALU ops): hardware seed (v_rsq_f64) and two
+// coupled Goldschmidt steps.  q > 0 and finite; callers guard q == 0.
+__device__ __forceinline__ void sqrt_rsqrt(double q, double &s, double &rinv) {
+    const double y = __builtin_amdgcn_rsq(q);
+    double g = q * y, h = 0.5 * y;
+    double r = fma(-h, g, 0.5);
+    g = fma(g, r, g); h = fma(h, r, h);
+    r = fma(-h, g, 0.5);
+    g = fma(g, r, g); h = fma(h, r, h);
+    s = g; rinv = 2.0 * h;
+}
+
+// blocked register tile . LDS vector (vec already offset to the lane's segment, 16-byte aligned)
+template <int CH, int TT>
+__device__ __forceinline__ double seg_dot(const double (&tile)[TT], const double *vec) {
+    const double2 *v2 = reinterpret_cast<const double2 *>(vec);
+    double a0 = 0, a1 = 0;
+#pragma unroll
+    for (int k = 0; k < TT / 2; k++) {
+        const double2 v = v2[k];
+        a0 = fma(tile[2 * k], v.x, a0);
+        a1 = fma(tile[2 * k + 1], v.y, a1);
+    }
+    return group_reduce<CH, false>(a0 + a1);
+}
+// LDS row segment . LDS vector
+template <int CH, int TT>
+__device__ __forceinline__ double seg_dot_lds(const double *row, const double *vec) {
+    const double2 *r2 = reinterpret_cast<const double2 *>(row), *v2 = reinterpret_cast<const double2 *>(vec);
+    double a0 = 0, a1 = 0;
+#pragma unroll
+    for (int k = 0; k < TT / 2; k++) {
+        const double2 r = r2[k], v = v2[k];
+        a0 = fma(r.x, v.x, a0);
+        a1 = fma(r.y, v.y, a1);
+    }
+    return group_reduce<CH, false>(a0 + a1);
+}
+
+// thread coordinates, re-derived from an opaque copy of the thread id wherever they are needed: they then are short-lived
+// values (a handful of VALU ops) instead of kernel-lived registers competing with the tiles
+template <int CHT, int CHA, int CHG>
+struct F2Co {
+    int t, j1, c1, i2, c2, jg, cg;
+    // wave = index of the wave in the workgroup (kept in a scalar register); the lane id is recomputed by volatile asm so
+    // that no VGPR has to carry the thread id through the kernel (the allocator would spill it and reload it from scratch
+    // at the top of every iteration)
+    __device__ __forceinline__ static int thread_id(int wave) {
+        int lane;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+        return (wave << 6) + lane;
+    }
+    __device__ __forceinline__ explicit F2Co(int wave) {
+        t = thread_id(wave);
+        j1 = t / CHT; c1 = t % CHT; i2 = t / CHA; c2 = t % CHA; jg = t / CHG; cg = t % CHG;
+    }
+};
+
+#ifndef F2_WPS
+#define F2_WPS 3
+#endif
+template <int CHT, int T1, int CHA, int T2, int CHG, int TG>
+__global__ void __launch_bounds__(NT, F2_WPS)
+k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__restrict__ qv, long sqk, long sqb,
+       const int *__restrict__ idx_at, const int *__restrict__ idx_ar, const int *__restrict__ idx_b,
+       double *__restrict__ xo, double *__restrict__ yo, double *__restrict__ so, int *__restrict__ iters_o,
+       int *__restrict__ status_o, double *__restrict__ resid_o) {
+    using L = F2<CHT, T1, CHA, T2, CHG, TG>;
+    using Co = F2Co<CHT, CHA, CHG>;
+    constexpr int MP = L::MP, NP = L::NP, VP = L::VP, OY = L::OY, OX = L::OX, OT = L::OT;
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    enum { SC_NB0 = 0, SC_NC0, SC_SIGMA, SC_SUMLOG, SC_RP, SC_RD, SC_GAP };
+    double *const sc = sm + L::O_SC;
+    double *const red = sm + L::O_RED;
+    int *const socr = reinterpret_cast<int *>(sm + L::O_G);       // [MP] first row of the row's SOC (or -1)
+    int *const socd = socr + MP;                                   // [MP] its dimension (0: not an SOC row)
+    double *const Gm = sm + L::O_G + MP;                           // 2*MP ints = MP doubles
+
+    const int tid = threadIdx.x, inst = blockIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = T.n, m = T.m, l = n + m + 1, ldg = T.ldg, nq = T.nq, z = T.z;
+    const double *const vals = Avals + (size_t)inst * T.nnz_aug;
+
+    for (int i = tid; i < L::O_G; i += NT) sm[i] = 0.0;
+    for (int i = tid; i < MP; i += NT) {
+        int r0 = -1, d = 0;
+        if (i < m) { const int c = T.rowcone[i]; if (c >= 0) { r0 = T.qoff[c]; d = T.qoff[c + 1] - r0; } }
+        socr[i] = r0; socd[i] = d;
+    }
+    __syncthreads();
+    for (int i = tid; i < m; i += NT) { const int ix = idx_b[i]; sm[L::O_BV + i] = ix >= 0 ? vals[ix] : 0.0; sm[L::O_DV + i] = 1.0; }
+    for (int j = tid; j < n; j += NT) { sm[L::O_CV + j] = qv[j * sqk + inst * sqb]; sm[L::O_EV + j] = 1.0; }
+    __syncthreads();
+    {
+        double r[2] = {0, 0};
+        for (int i = tid; i < m; i += NT) r[0] = fmax(r[0], fabs(sm[L::O_BV + i]));
+        for (int j = tid; j < n; j += NT) r[1] = fmax(r[1], fabs(sm[L::O_CV + j]));
+        block_reduce_n<2, NW>(r, 3u, red);
+        sc[SC_NB0] = r[0]; sc[SC_NC0] = r[1]; sc[SC_SIGMA] = 1.0;
+    }
+    // ---------------------------------------------------------------- equilibration on register tiles (live only here)
+    if (S.normalize) {
+        const Co co(wave);
+        const int j1 = co.j1, c1 = co.c1, i2 = co.i2, c2 = co.c2;
+        const bool own1 = (c1 == 0) && (j1 < n), own2 = (c2 == 0) && (i2 < m);
+        double at[T1], ar[T2];
+#pragma unroll
+        for (int k = 0; k < T1; k++) { const int ix = idx_at[k * NT + tid]; at[k] = ix >= 0 ? -vals[ix] : 0.0; }   // A = -A_cvx (diffcp_if.py:65)
+#pragma unroll
+        for (int k = 0; k < T2; k++) { const int ix = idx_ar[k * NT + tid]; ar[k] = ix >= 0 ? -vals[ix] : 0.0; }
+        for (int pass = 0; pass < NUM_RUIZ_PASSES + NUM_L2_PASSES; pass++) {
+            const bool l2 = pass >= NUM_RUIZ_PASSES;
+            const int oEt = (pass & 1) ? L::O_S2 : L::O_S1;                 // column scaling of this pass (x-indexed)
+            const int oDt = ((pass & 1) ? L::O_UT : L::O_U) + OY;           // row scaling of this pass (y-indexed)
+            double cn = 0, rn = 0;
+            if (l2) {
+#pragma unroll
+                for (int k = 0; k < T1; k++) cn = fma(at[k], at[k], cn);
+#pragma unroll
+                for (int k = 0; k < T2; k++) rn = fma(ar[k], ar[k], rn);
+                cn = sqrt(group_reduce<CHT, false>(cn)); rn = sqrt(group_reduce<CHA, false>(rn));
+            } else {
+#pragma unroll
+                for (int k = 0; k < T1; k++) cn = fmax(cn, fabs(at[k]));
+                cn = group_reduce<CHT, true>(cn);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < T2; k++) rn = fmax(rn, fabs(ar[k]));
+                rn = group_reduce<CHA, true>(rn);
+            }
+            if (own1) { double sq, ri; sqrt_rsqrt(clamp_scale(cn), sq, ri); sm[oEt + j1] = ri; }
+            if (own2) sm[L::O_ZB + OY + i2] = rn;          // raw row norms
+            __syncthreads();
+            if (own2) {
+                double a = rn;
+                const int r0 = socr[i2], d = socd[i2];
+                if (d > 0) {   // block-average inside the SOC so the scaled cone is still the cone
+                    a = 0; for (int i = r0; i < r0 + d; i++) a += sm[L::O_ZB + OY + i];
+                    a /= (double)d;
+                }
+                double sq, ri; sqrt_rsqrt(clamp_scale(a), sq, ri);
+                sm[oDt + i2] = ri;
+            }
+            __syncthreads();
+            {
+                const double ej = sm[oEt + (j1 < NP ? j1 : 0)];            // pad entries are 0
+                const double2 *d2 = reinterpret_cast<const double2 *>(sm + oDt + T1 * c1);
+#pragma unroll
+                for (int k = 0; k < T1 / 2; k++) { const double2 d = d2[k]; at[2 * k] *= d.x * ej; at[2 * k + 1] *= d.y * ej; asm volatile("" : "+v"(at[2 * k]), "+v"(at[2 * k + 1])); }   // pin the product here (no sinking into the next pass)
+                __builtin_amdgcn_sched_barrier(0);        // keep the two scaling sweeps apart (register peak of the pass)
+                const double di = sm[oDt + (i2 < MP ? i2 : 0)];
+                const double2 *e2 = reinterpret_cast<const double2 *>(sm + oEt + T2 * c2);
+#pragma unroll
+                for (int k = 0; k < T2 / 2; k++) { const double2 ee = e2[k]; ar[2 * k] *= di * ee.x; ar[2 * k + 1] *= di * ee.y; asm volatile("" : "+v"(ar[2 * k]), "+v"(ar[2 * k + 1])); }
+                if (own1) sm[L::O_EV + j1] *= ej;
+                if (own2) sm[L::O_DV + i2] *= di;
+            }
+            // no barrier: the next pass writes the other ping-pong buffers (and ZB, last read before the barrier above)
+        }
+        __syncthreads();
+        double r[2] = {0, 0};
+        for (int i = tid; i < m; i += NT) { const double v = sm[L::O_BV + i] * sm[L::O_DV + i]; sm[L::O_BV + i] = v; r[0] = fmax(r[0], fabs(v)); }
+        for (int j = tid; j < n; j += NT) { const double v = sm[L::O_CV + j] * sm[L::O_EV + j]; sm[L::O_CV + j] = v; r[1] = fmax(r[1], fabs(v)); }
+        block_reduce_n<2, NW>(r, 3u, red);
+        const double sigma = 1.0 / clamp_scale(fmax(r[0], r[1]));
+        sc[SC_SIGMA] = sigma;
+        for (int i = tid; i < m; i += NT) sm[L::O_BV + i] *= sigma;
+        for (int j = tid; j < n; j += NT) sm[L::O_CV + j] *= sigma;
+        for (int i = tid; i < VP; i += NT) { sm[L::O_U + i] = 0.0; sm[L::O_UT + i] = 0.0; sm[L::O_ZB + i] = 0.0; }
+        for (int i = tid; i < NP; i += NT) { sm[L::O_S1 + i] = 0.0; sm[L::O_S2 + i] = 0.0; }
+        __syncthreads();
+    }
+
+    double scale = S.scale, hg = 0, inv_den = 0;
+    const double rho_x = S.rho_x, rtau = TAU_FACTOR, alpha = S.alpha;
+    auto dyv = [&](int i) -> double { return (i < z) ? ZERO_CONE_FACTOR * scale : scale; };   // 1 / r_y
+
+    // The iteration tiles.  They are (RE-)MATERIALISED from the instance's values (L2) and the final scalings D, E (LDS):
+    // A-hat[r][j] = (-A_cvx[r][j]) * (D[r] * E[j]), the same expression for both layouts (bitwise consistent).  Not keeping
+    // them alive across refactor() splits their live ranges around the register-hungry factorisation.
+    double at[T1], ar[T2];
+    auto materialize_at = [&](const Co &co) {
+        const double ej = sm[L::O_EV + (co.j1 < NP ? co.j1 : 0)];
+        const double2 *d2 = reinterpret_cast<const double2 *>(sm + L::O_DV + T1 * co.c1);
+#pragma unroll
+        for (int k = 0; k < T1 / 2; k++) {
+            const int ix0 = idx_at[(2 * k) * NT + co.t], ix1 = idx_at[(2 * k + 1) * NT + co.t];
+            const double2 d = d2[k];
+            at[2 * k] = ix0 >= 0 ? -vals[ix0] * (d.x * ej) : 0.0;
+            at[2 * k + 1] = ix1 >= 0 ? -vals[ix1] * (d.y * ej) : 0.0;
+            if (k % 4 == 3) __builtin_amdgcn_sched_barrier(0);       // bounded number of loads in flight (register peak)
+        }
+    };
+    auto materialize_ar = [&](const Co &co) {
+        const double di = sm[L::O_DV + (co.i2 < MP ? co.i2 : 0)];
+        const double2 *e2 = reinterpret_cast<const double2 *>(sm + L::O_EV + T2 * co.c2);
+#pragma unroll
+        for (int k = 0; k < T2 / 2; k++) {
+            const int ix0 = idx_ar[(2 * k) * NT + co.t], ix1 = idx_ar[(2 * k + 1) * NT + co.t];
+            const double2 ee = e2[k];
+            ar[2 * k] = ix0 >= 0 ? -vals[ix0] * (di * ee.x) : 0.0;
+            ar[2 * k + 1] = ix1 >= 0 ? -vals[ix1] * (di * ee.y) : 0.0;
+            if (k % 4 == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // The column groups j1 == n and j1 == n + 1 (idle in the A^T product) carry phi as two extra "columns", so that the
+    // A^T w_y phase also yields phi_y . w_y and phi_x . w_x (the numerator of tau-tilde) without a separate reduction.
+    auto load_phi_tile = [&](const Co &co) {
+        if (co.j1 == n) {
+#pragma unroll
+            for (int k = 0; k < T1; k++) at[k] = sm[L::O_PHI + OY + T1 * co.c1 + k];       // pads of PHI are zero
+        } else if (co.j1 == n + 1) {
+#pragma unroll
+            for (int k = 0; k < T1; k++) at[k] = (T1 * co.c1 + k < n) ? sm[L::O_PHI + OX + T1 * co.c1 + k] : 0.0;
+        }
+    };
+
+    // ---- (re)factor:  G <- (rho_x I + A^T Dy A)^{-1} (LDS);  g, h.g, phi.   Clobbers ZB, TV, PX, S1..S4.
+    auto refactor = [&]() {
+        const Co co(wave);
+        const int tid = co.t;
+        const int j1 = co.j1, c1 = co.c1, i2 = co.i2, c2 = co.c2, jg = co.jg, cg = co.cg;
+        const bool own1 = (c1 == 0) && (j1 < n), own2 = (c2 == 0) && (i2 < m), owng = (cg == 0) && (jg < n);
+        materialize_ar(co);
+        double sreg[TG];
+#pragma unroll
+        for (int s = 0; s < TG; s++) sreg[s] = 0.0;
+        // S = A^T Dy A from row panels staged through the G region (row pitch NP)
+        {
+            constexpr int LDP = NP;
+            const int PR = min(m, (n * ldg) / LDP);            // rows per panel
+            if constexpr (L::NPa < NP) {   // panel columns the row tiles do not cover stay zero
+                for (int i = tid; i < PR * (NP - L::NPa); i += NT) Gm[(i / (NP - L::NPa)) * LDP + L::NPa + i % (NP - L::NPa)] = 0.0;
+            }
+            for (int p0 = 0; p0 < m; p0 += PR) {
+                const int p1 = min(m, p0 + PR);
+                if (i2 >= p0 && i2 < p1) {
+                    double2 *dst = reinterpret_cast<double2 *>(Gm + (i2 - p0) * LDP + T2 * c2);
+#pragma unroll
+                    for (int k = 0; k < T2 / 2; k++) dst[k] = make_double2(ar[2 * k], ar[2 * k + 1]);
+                }
+                __syncthreads();
+                if (jg < n) {
+                    const double *r = Gm;
+                    for (int i = p0; i < p1; i++, r += LDP) {
+                        const double aj = r[jg] * dyv(i);
+                        const double2 *r2 = reinterpret_cast<const double2 *>(r + TG * cg);
+#pragma unroll
+                        for (int s = 0; s < TG / 2; s++) { const double2 v = r2[s]; sreg[2 * s] = fma(v.x, aj, sreg[2 * s]); sreg[2 * s + 1] = fma(v.y, aj, sreg[2 * s + 1]); }
+                    }
+                }
+                __syncthreads();
+            }
+#pragma unroll
+            for (int s = 0; s < TG; s++) if (jg < n && TG * cg + s == jg) sreg[s] += rho_x;
+        }
+        // Gauss-Jordan inversion on the register tile; pivot order k = kk + TG*cgk (kk static).  Pivot row / column are
+        // published through LDS, double buffered: row -> S1/S3, column -> S2/S4.
+        auto publish = [&](auto slot_c, int cgn, int bufn) {
+            constexpr int slot = decltype(slot_c)::value;
+            const int kn = TG * cgn + slot;
+            double *rowk = sm + (bufn ? L::O_S3 : L::O_S1), *colk = sm + (bufn ? L::O_S4 : L::O_S2);
+            if (jg < n && cg == cgn) colk[jg] = sreg[slot];
+            if (jg == kn) {
+                double2 *dst = reinterpret_cast<double2 *>(rowk + TG * cg);
+#pragma unroll
+                for (int s = 0; s < TG / 2; s++) dst[s] = make_double2(sreg[2 * s], sreg[2 * s + 1]);
+            }
+        };
+        int cnt = 0;
+        publish(std::integral_constant<int, 0>{}, 0, 0);
+        __syncthreads();
+        static_for<TG>([&](auto kkc) {
+            constexpr int kk = decltype(kkc)::value;
+            const int nv = (kk < n) ? (n - 1 - kk) / TG + 1 : 0;        // pivots of this slot: cgk = 0 .. nv-1
+            const int nvn = (kk + 1 < TG && kk + 1 < n) ? 1 : 0;        // does the next slot have a pivot?
+            for (int cgk = 0; cgk < nv; cgk++) {
+                const int k = TG * cgk + kk, buf = cnt & 1;
+                const double *rowk = sm + (buf ? L::O_S3 : L::O_S1), *colk = sm + (buf ? L::O_S4 : L::O_S2);
+                if (jg < n) {
+                    const double pinv = 1.0 / rowk[k];
+                    const bool prow_thread = (jg == k);
+                    const double cj0 = colk[jg] * pinv;
+                    const double2 *r2 = reinterpret_cast<const double2 *>(rowk + TG * cg);
+                    if (prow_thread) {      // divergent only in the one wave that holds the pivot row
+#pragma unroll
+                        for (int s2 = 0; s2 < TG / 2; s2++) { const double2 rv = r2[s2]; sreg[2 * s2] = rv.x * pinv; sreg[2 * s2 + 1] = rv.y * pinv; }
+                    } else {
+#pragma unroll
+                        for (int s2 = 0; s2 < TG / 2; s2++) {
+                            const double2 rv = r2[s2];
+                            sreg[2 * s2] = fma(-cj0, rv.x, sreg[2 * s2]);
+                            sreg[2 * s2 + 1] = fma(-cj0, rv.y, sreg[2 * s2 + 1]);
+                        }
+                    }
+                    if (cg == cgk) sreg[kk] = prow_thread ? pinv : -cj0;       // the pivot column itself
+                }
+                if (cgk + 1 < nv) publish(std::integral_constant<int, kk>{}, cgk + 1, buf ^ 1);
+                else if (nvn) publish(std::integral_constant<int, (kk + 1 < TG ? kk + 1 : kk)>{}, 0, buf ^ 1);
+                cnt++;
+                __syncthreads();
+            }
+        });
+        // G to LDS (the panel data in that region is dead), scratch back to zero
+        if (jg < n) {
+            double2 *dst = reinterpret_cast<double2 *>(Gm + jg * ldg + TG * cg);
+#pragma unroll
+            for (int s = 0; s < TG / 2; s++) dst[s] = make_double2(sreg[2 * s], sreg[2 * s + 1]);
+        }
+        for (int i = tid; i < NP; i += NT) { sm[L::O_S1 + i] = 0.0; sm[L::O_S2 + i] = 0.0; sm[L::O_S3 + i] = 0.0; sm[L::O_S4 + i] = 0.0; }
+        for (int i = tid; i < m; i += NT) sm[L::O_ZB + OY + i] = dyv(i) * sm[L::O_BV + i];
+        __syncthreads();
+        materialize_at(co);
+        {
+            const double a = seg_dot<CHT, T1>(at, sm + L::O_ZB + OY + T1 * c1);
+            if (own1) { const double cj = sm[L::O_CV + j1]; sm[L::O_S1 + j1] = cj - a; sm[L::O_S2 + j1] = cj + a; }   // rhs for g_x ; k = c + A^T Dy b
+        }
+        __syncthreads();
+        {
+            const double *grow = Gm + (jg < n ? jg : 0) * ldg + TG * cg;
+            const double gx = seg_dot_lds<CHG, TG>(grow, sm + L::O_S1 + TG * cg), gk = seg_dot_lds<CHG, TG>(grow, sm + L::O_S2 + TG * cg);
+            if (owng) { sm[L::O_GV + OX + jg] = gx; sm[L::O_PX + jg] = gk; }
+        }
+        __syncthreads();
+        materialize_ar(co);
+        double r[1] = {0};
+        {
+            const double agx = seg_dot<CHA, T2>(ar, sm + L::O_GV + OX + T2 * c2), agk = seg_dot<CHA, T2>(ar, sm + L::O_PX + T2 * c2);
+            if (own2) {
+                const double bi = sm[L::O_BV + i2];
+                const double gy = dyv(i2) * (agx + bi);
+                sm[L::O_GV + OY + i2] = gy; r[0] += bi * gy;
+                sm[L::O_PHI + OY + i2] = bi - agk;
+            }
+            if (tid < n) { r[0] += sm[L::O_CV + tid] * sm[L::O_GV + OX + tid]; sm[L::O_PHI + OX + tid] = rho_x * sm[L::O_PX + tid]; }
+        }
+        block_reduce_n<1, NW>(r, 0u, red);
+        hg = uniform_d(r[0]);
+        inv_den = uniform_d(1.0 / (rtau + hg));
+        load_phi_tile(co);
+        for (int i = tid; i < NP; i += NT) { sm[L::O_S1 + i] = 0.0; sm[L::O_S2 + i] = 0.0; sm[L::O_PX + i] = 0.0; }
+        for (int i = tid; i < m; i += NT) sm[L::O_ZB + OY + i] = 0.0;
+        __syncthreads();
+    };
+
+    if (threadIdx.x == 0) sm[L::O_W + OT] = 1.0;    // cold start: w = (0, 0, 1)
+    __syncthreads();
+
+    int status = 0, iter = 0, last_scale_iter = 0, n_log = 0;
+    const bool big_soc = T.maxq > SOC_SMALL;
+    bool resume = false;     // true: the iteration interrupted by a rescale still owes its relaxed update
+
+    // cone projection of element e (LDS slot ve) from ZB (pre-projection values); small cones: recomputed by every row thread
+    auto project_e = [&](int e, int ve) -> double {
+        double ue = sm[L::O_ZB + ve];
+        const int soc_d = (e < m) ? socd[e] : 0;
+        if (soc_d > 1 && !big_soc) {
+            const int soc_r0 = socr[e];
+            const double *zc = sm + L::O_ZB + OY + soc_r0;
+            const double t0 = zc[0];
+            double q0 = 0, q1 = 0;
+            for (int k = 1; k < soc_d; k += 4) {
+                const double z0 = zc[k], z1 = (k + 1 < soc_d) ? zc[k + 1] : 0.0, z2 = (k + 2 < soc_d) ? zc[k + 2] : 0.0, z3 = (k + 3 < soc_d) ? zc[k + 3] : 0.0;
+                q0 = fma(z0, z0, q0); q1 = fma(z1, z1, q1); q0 = fma(z2, z2, q0); q1 = fma(z3, z3, q1);
+            }
+            const double q = q0 + q1;
+            double nz = 0, rinv = 0;
+            if (q > 0) sqrt_rsqrt(q, nz, rinv);
+            if (nz <= t0) { /* inside */ }
+            else if (nz <= -t0) ue = 0.0;
+            else { const double c0 = 0.5 * (t0 + nz); ue = (e == soc_r0) ? c0 : ue * (c0 * rinv); }
+        } else if (soc_d == 1) ue = fmax(ue, 0.0);
+        return ue;
+    };
+    auto slot_of = [&](int e) -> int { return (e < m) ? OY + e : (e < m + n ? OX + (e - m) : OT); };
+
+    for (bool done = false; !done;) {
+    refactor();
+    if (resume) {   // relaxed update w += alpha (u - ut) owed by the iteration a rescale interrupted
+        const int e = Co::thread_id(wave);
+        if (e < l) { const int ve = slot_of(e); sm[L::O_W + ve] += alpha * (sm[L::O_U + ve] - sm[L::O_UT + ve]); }
+        __syncthreads();
+        resume = false; iter++;
+    }
+    for (;;) {
+        if (iter >= S.max_iters) { done = true; break; }
+        const Co co(wave);
+        const int j1 = co.j1, c1 = co.c1, i2 = co.i2, c2 = co.c2, jg = co.jg, cg = co.cg;
+        const bool own1 = (c1 == 0) && (j1 < n), own2 = (c2 == 0) && (i2 < m), owng = (cg == 0) && (jg < n);
+        const int e = co.t;
+        const int ve = slot_of(e);
+        const bool ev = e < l;
+        const bool check = (iter % CONVERGED_INTERVAL) == 0;
+        const bool last = iter + 1 >= S.max_iters;
+        if (check && iter > 0) {   // keep the homogeneous iterate in range
+            const double we = ev ? sm[L::O_W + ve] : 0.0;
+            double r[1] = {we * we};
+            block_reduce_n<1, NW>(r, 0u, red);
+            const double nw = sqrt(r[0]);
+            if (nw > 0 && ev) sm[L::O_W + ve] = we * (sqrt((double)l) / nw);
+            __syncthreads();
+        }
+        // P1a: t = rho_x w_x - A^T w_y   (+ phi . w from the two spare column groups)
+        {
+            const double *wvec = sm + L::O_W + ((j1 == n + 1 && T1 * c1 < n) ? OX : OY) + T1 * c1;
+            const double a = seg_dot<CHT, T1>(at, wvec);
+            if (own1) sm[L::O_TV + j1] = rho_x * sm[L::O_W + OX + j1] - a;
+            else if (c1 == 0 && j1 <= n + 1) sm[L::O_WP + (j1 - n)] = a;          // phi_y . w_y , phi_x . w_x
+        }
+        __syncthreads();
+        // P1b: p_x = G t
+        {
+            const double a = seg_dot_lds<CHG, TG>(Gm + (jg < n ? jg : 0) * ldg + TG * cg, sm + L::O_TV + TG * cg);
+            if (owng) sm[L::O_PX + jg] = a;
+        }
+        __syncthreads();
+        // P2: q = A p_x ; tau-tilde ; u-tilde ; cone input
+        {
+            const double tau_t = (rtau * sm[L::O_W + OT] + sm[L::O_WP] + sm[L::O_WP + 1]) * inv_den;
+            const double q = seg_dot<CHA, T2>(ar, sm + L::O_PX + T2 * c2);
+            if (own2) {
+                const int ee = OY + i2;
+                const double we = sm[L::O_W + ee];
+                const double py = we + dyv(i2) * q;
+                const double ute = py - tau_t * sm[L::O_GV + ee];
+                double ze = 2 * ute - we;
+                if (i2 >= z && i2 < z + T.l && ze < 0) ze = 0;        // nonnegative rows
+                sm[L::O_UT + ee] = ute; sm[L::O_ZB + ee] = ze;
+            }
+            if (e < n) {
+                const int ee = OX + e;
+                const double ute = sm[L::O_PX + e] - tau_t * sm[L::O_GV + ee];
+                sm[L::O_UT + ee] = ute; sm[L::O_ZB + ee] = 2 * ute - sm[L::O_W + ee];
+            }
+            if (e == NT - 1) { sm[L::O_UT + OT] = tau_t; sm[L::O_ZB + OT] = fmax(0.0, 2 * tau_t - sm[L::O_W + OT]); }
+        }
+        __syncthreads();
+        if (big_soc) {   // large cones: one leader per cone computes (c0, f) -> S3/S4, then rows apply (uniform branch)
+            for (int c = e; c < nq; c += NT) {
+                const int r0 = OY + T.qoff[c], r1 = OY + T.qoff[c + 1];
+                const double t0 = sm[L::O_ZB + r0]; double nz = 0;
+                for (int k = r0 + 1; k < r1; k++) nz = fma(sm[L::O_ZB + k], sm[L::O_ZB + k], nz);
+                nz = sqrt(nz);
+                double c0, f;
+                if (r1 - r0 == 1) { c0 = fmax(t0, 0.0); f = 0.0; }
+                else if (nz <= t0) { c0 = t0; f = 1.0; }
+                else if (nz <= -t0) { c0 = 0.0; f = 0.0; }
+                else { c0 = 0.5 * (t0 + nz); f = c0 / nz; }
+                sm[L::O_S3 + c] = c0; sm[L::O_S4 + c] = f;
+            }
+            __syncthreads();
+            if (e < m && socd[e] > 0) { const int c = T.rowcone[e]; sm[L::O_ZB + ve] = (e == socr[e]) ? sm[L::O_S3 + c] : sm[L::O_S4 + c] * sm[L::O_ZB + ve]; }
+            __syncthreads();
+        }
+        if (!check && !last) {
+            // P3 (fast path): project, relaxed update
+            if (ev) {
+                const double ue = project_e(e, ve);
+                sm[L::O_U + ve] = ue;
+                sm[L::O_W + ve] += alpha * (ue - sm[L::O_UT + ve]);
+            }
+            __syncthreads();
+            iter++;
+            continue;
+        }
+        // ---- slow path (every CONVERGED_INTERVAL iterations, and the last one)
+        if (ev) sm[L::O_U + ve] = project_e(e, ve);
+        __syncthreads();
+        bool stop = false, rescale = false;
+        if (check) {
+            const double ax_raw = seg_dot<CHA, T2>(ar, sm + L::O_U + OX + T2 * c2);       // A-hat x-hat   (valid in row groups)
+            __builtin_amdgcn_sched_barrier(0);        // one product at a time: the check must not raise the loop's register peak
+            const double aty_raw = seg_dot<CHT, T1>(at, sm + L::O_U + OY + T1 * c1);      // A-hat^T y-hat (valid in column groups)
+            __builtin_amdgcn_sched_barrier(0);
+            const double tau = fabs(sm[L::O_U + OT]);
+            const double isg = 1.0 / sc[SC_SIGMA];
+            double r[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // rp, nax, ns, naxs, rd, naty (max) ; ctx, bty (sum)
+            if (own2) {
+                const int i = i2;
+                const double sc_ = isg / sm[L::O_DV + i];
+                const double ax = ax_raw * sc_;
+                const double uy = sm[L::O_U + OY + i];
+                const double sh = (uy + sm[L::O_W + OY + i] - 2 * sm[L::O_UT + OY + i]) / dyv(i) * sc_;
+                const double bt = sm[L::O_BV + i] * tau * sc_;
+                r[0] = fabs(ax + sh - bt); r[1] = fabs(ax); r[2] = fabs(sh); r[3] = fabs(ax + sh);
+                r[7] = sm[L::O_BV + i] * uy * isg * isg;
+            }
+            if (own1) {
+                const int j = j1;
+                const double sc_ = isg / sm[L::O_EV + j];
+                const double aty = aty_raw * sc_;
+                const double cj = sm[L::O_CV + j];
+                r[4] = fabs(aty + cj * tau * sc_); r[5] = fabs(aty);
+                r[6] = cj * sm[L::O_U + OX + j] * isg * isg;
+            }
+            block_reduce_n<8, NW>(r, 0x3Fu, red);
+            const double rp = r[0], nax = r[1], ns = r[2], naxs = r[3], rd = r[4], naty = r[5], ctx = r[6], bty = r[7];
+            const double nrm_b0 = sc[SC_NB0], nrm_c0 = sc[SC_NC0];
+            if (tau > 0) {
+                const double res_pri = rp / tau, res_dual = rd / tau, gap = fabs(ctx + bty) / tau;
+                sc[SC_RP] = res_pri; sc[SC_RD] = res_dual; sc[SC_GAP] = gap;
+                const double prl = fmax(fmax(nrm_b0 * tau, ns), nax) / tau, drl = fmax(nrm_c0 * tau, naty) / tau;
+                const double grl = fmax(fabs(ctx), fabs(bty)) / tau;
+                if (res_pri <= S.eps_abs + S.eps_rel * prl && res_dual <= S.eps_abs + S.eps_rel * drl &&
+                    gap <= S.eps_abs + S.eps_rel * grl) { status = 1; stop = true; }
+            }
+            if (!stop && bty < 0 && naty / (-bty) <= S.eps_infeas) { status = -2; stop = true; }
+            if (!stop && ctx < 0 && naxs / (-ctx) <= S.eps_infeas) { status = -1; stop = true; }
+            if (!stop && S.adaptive_scale && iter > 0) {
+                const double dp = fmax(fmax(nax, ns), nrm_b0 * tau), dd = fmax(naty, nrm_c0 * tau);
+                const double rel_p = rp / (dp > 0 ? dp : 1), rel_d = rd / (dd > 0 ? dd : 1);
+                if (rel_p > 0 && rel_d > 0 && isfinite(rel_p) && isfinite(rel_d)) {
+                    const double sum_log = sc[SC_SUMLOG] + log(rel_p) - log(rel_d); n_log++;
+                    __syncthreads();                 // everyone has read SC_SUMLOG before it is rewritten
+                    sc[SC_SUMLOG] = sum_log;
+                    const double factor = sqrt(exp(sum_log / n_log));
+                    if (iter - last_scale_iter >= RESCALING_MIN_ITERS) {
+                        const double ns2 = fmin(fmax(scale * factor, MIN_SCALE_VALUE), MAX_SCALE_VALUE);
+                        if (ns2 != scale && (factor > sqrt(10.0) || factor < 1.0 / sqrt(10.0))) {
+                            // keep (s, kappa):  w_y+ = rsk_y / r_y+ + 2 ut_y - u_y
+                            const double dy_ratio = ns2 / scale;
+                            if (e < m) {
+                                const double ue = sm[L::O_U + ve], ute = sm[L::O_UT + ve];
+                                const double d0 = ue + sm[L::O_W + ve] - 2 * ute;
+                                sm[L::O_W + ve] = d0 * dy_ratio + 2 * ute - ue;
+                            }
+                            n_log = 0; last_scale_iter = iter; scale = uniform_d(ns2);
+                            __syncthreads();
+                            sc[SC_SUMLOG] = 0.0;
+                            rescale = true;
+                        }
+                    }
+                }
+            }
+        }
+        if (stop) { done = true; break; }
+        if (last) { iter++; done = true; break; }
+        if (rescale) { resume = true; break; }      // -> refactor() with the new scale, then finish this iteration
+        if (ev) sm[L::O_W + ve] += alpha * (sm[L::O_U + ve] - sm[L::O_UT + ve]);
+        __syncthreads();
+        iter++;
+    }
+    }
+
+    __syncthreads();
+    const int tid_w = Co::thread_id(wave);
+    const double tau = fabs(sm[L::O_U + OT]);
+    const double sigma = sc[SC_SIGMA];
+    if (status == 0) {   // ran out of iterations (SCS set_unfinished)
+        const double kap = fabs(rtau * (sm[L::O_U + OT] + sm[L::O_W + OT] - 2 * sm[L::O_UT + OT]));
+        double r[2] = {0, 0};
+        const double isg = 1.0 / sigma;
+        const int e = tid_w;
+        if (e < m) r[1] = sm[L::O_BV + e] * sm[L::O_U + OY + e] * isg * isg;
+        else if (e < m + n) r[0] = sm[L::O_CV + (e - m)] * sm[L::O_U + OX + (e - m)] * isg * isg;
+        block_reduce_n<2, NW>(r, 0u, red);
+        if (tau > kap) status = 2; else if (r[1] < r[0]) status = -7; else status = -6;
+    }
+    // ---------------------------------------------------------------- write back (un-normalise)
+    {
+        const bool solved = (status == 1 || status == 2);
+        const bool infeas = (status == -2 || status == -7);
+        const double it = solved ? 1.0 / (sigma * tau) : 1.0 / sigma;
+        for (int j = tid_w; j < n; j += NT) xo[(size_t)inst * n + j] = infeas ? NAN : sm[L::O_EV + j] * sm[L::O_U + OX + j] * it;
+        for (int i = tid_w; i < m; i += NT) {
+            const double uy = sm[L::O_U + OY + i], di = sm[L::O_DV + i];
+            const double sh = (uy + sm[L::O_W + OY + i] - 2 * sm[L::O_UT + OY + i]) / dyv(i);
+            yo[(size_t)inst * m + i] = (solved || infeas) ? di * uy * it : NAN;
+            so[(size_t)inst * m + i] = infeas ? NAN : sh / di * it;
+        }
+        if (tid_w == 0) {
+            iters_o[inst] = iter; status_o[inst] = status;
+            if (resid_o) { resid_o[3 * inst] = sc[SC_RP]; resid_o[3 * inst + 1] = sc[SC_RD]; resid_o[3 * inst + 2] = sc[SC_GAP]; }
+        }
+    }
+}

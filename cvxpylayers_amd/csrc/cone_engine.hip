@@ -26,6 +26,8 @@
 #include <cstring>
 #include <algorithm>
 #include <string>
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "cone_engine.h"
@@ -34,6 +36,7 @@ namespace {
 #include "ce_common.h"
 #include "ce_forward_generic.h"
 #include "ce_forward_rt.h"
+#include "ce_forward_v2.h"
 #include "ce_backward.h"
 #include "ce_backward_rt.h"
 }  // namespace
@@ -54,6 +57,7 @@ struct ce_engine {
     // launch plan
     int fwd_mode = 0, bwd_mode = 0; size_t fwd_lds = 0, bwd_lds = 0; int nkcap = 0, ldk = 0;
     int rt_variant = -1, rt_vp = 0, rt_lda = 0;   // register-tiled forward kernel variant (-1: generic kernel)
+    int f2_variant = -1; int *d_idx_at = nullptr, *d_idx_ar = nullptr, *d_idx_b = nullptr; int f2_ldg = 0;   // second-generation forward kernel
     int brt_variant = -1;                          // register-tiled backward kernel variant (-1: generic kernel)
     // profiling
     bool prof = false;
@@ -69,7 +73,11 @@ struct ce_engine {
         }                                                                            \
     } while (0)
 
+#ifdef CE_TIMING
+static constexpr size_t LDS_LIMIT = 160 * 1024 - 512;   // debug build: room for the static time-stamp array
+#else
 static constexpr size_t LDS_LIMIT = 160 * 1024;
+#endif
 
 static size_t fwd_lds_bytes(const DevT &T, bool a_lds, bool g_lds) {
     const int n = T.n, m = T.m, l = n + m + 1, PB = std::max(NT, std::max(n, m));
@@ -107,9 +115,45 @@ static size_t bwd_lds_bytes(const DevT &T, bool a_lds, bool k_lds, int nkcap, in
 static const int BRT_VARIANTS[3][3] = {{4, 4, 4}, {7, 7, 4}, {7, 7, 7}};
 static size_t bwd_rt_lds_bytes(const DevT &T, int TI, int TJ) {
     const int n = T.n, m = T.m, nqs = std::max(T.nq, 1);
-    size_t d = (size_t)m * n /* lda = n */ + 4 * (size_t)m + 3 * (size_t)n + 6 * nqs + BG * TI + NW * 8 + bwd_rt_union_doubles(n, m, nqs, TI, TJ);
+    size_t d = (size_t)m * n /* lda = n */ + 3 * (size_t)m + 2 * (size_t)n + 6 * nqs + BG * TI + 2 + NW * 8 + bwd_rt_union_doubles(n, m, nqs, TI, TJ);
     size_t ints = 2 * (size_t)m + 2 * nqs + BG * TJ + BG * TI + NW + 1 + 8;
     return d * 8 + ints * 4 + 16;
+}
+
+// second-generation forward variants {CHT, T1, CHA, T2, CHG, TG}
+static const int F2_VARIANTS[3][6] = {{16, 2, 8, 2, 16, 2}, {8, 8, 4, 8, 8, 4}, {4, 26, 2, 26, 4, 14}};
+struct F2Dims { int MP, NPa, NPg, NP, VP, O_G; };
+static F2Dims f2_dims(int v) {
+    const int *V = F2_VARIANTS[v];
+    F2Dims d; d.MP = V[0] * V[1]; d.NPa = V[2] * V[3]; d.NPg = V[4] * V[5]; d.NP = std::max(d.NPa, d.NPg); d.VP = d.MP + d.NP + 2;
+    d.O_G = 6 * d.VP + 2 * d.MP + 8 * d.NP + NW * 8 + NW + 16;
+    return d;
+}
+// leading dimension of G in LDS: smallest even ld >= NPg for which the 16 lanes of an LDS group (CHG segments x 16/CHG rows)
+// read 16 distinct 16-byte bank groups with ds_read_b128
+static int f2_pick_ldg(int v) {
+    const int CHG = F2_VARIANTS[v][4], TG = F2_VARIANTS[v][5], NPg = CHG * TG;
+    for (int ld = NPg; ld < NPg + 64; ld += 2) {
+        bool used[16] = {false}; bool ok = true;
+        for (int lane = 0; lane < 16 && ok; lane++) {
+            const int jg = lane / CHG, cg = lane % CHG;
+            const int g = ((jg * ld + TG * cg) / 2) % 16;
+            if (used[g]) ok = false; used[g] = true;
+        }
+        if (ok) return ld;
+    }
+    return NPg;
+}
+static bool f2_fits(const DevT &T, int v, int *ldg, size_t *bytes) {
+    const int *V = F2_VARIANTS[v];
+    const F2Dims d = f2_dims(v);
+    if ((T.n + 2) * V[0] > NT || T.m * V[2] > NT || T.n * V[4] > NT) return false;   // two extra column groups carry phi
+    if (T.m > d.MP || T.n > d.NPa || T.n > d.NPg || T.n + T.m + 1 > NT) return false;
+    if (T.maxq > SOC_SMALL && T.nq > d.NP) return false;
+    *ldg = f2_pick_ldg(v);
+    if ((size_t)T.n * *ldg < (size_t)d.NPa) return false;
+    *bytes = ((size_t)d.O_G + d.MP /* SOC row info (2 int arrays) */ + (size_t)T.n * *ldg) * 8;
+    return *bytes <= LDS_LIMIT;
 }
 
 extern "C" {
@@ -163,6 +207,34 @@ int ce_create(const ce_template *tpl, int device, ce_handle *out) {
     if (!getenv("CE_FORCE_GENERIC")) {
         for (int v = 0; v < 3; v++) { int vp, ld; size_t by; if (rt_fits(T, v, &vp, &by, &ld)) { h->rt_variant = v; h->rt_vp = vp; h->fwd_lds = by; h->fwd_mode = 3; h->rt_lda = ld; break; } }
     }
+    const char *fwd_env = getenv("CE_FWD");      // "v2" (default when it fits), "rt", "generic": A/B switch for benchmarking
+    if (!getenv("CE_FORCE_GENERIC") && !(fwd_env && (!strcmp(fwd_env, "rt") || !strcmp(fwd_env, "generic")))) {
+        for (int v = 0; v < 3; v++) {
+            int ldg; size_t by;
+            if (!f2_fits(T, v, &ldg, &by)) continue;
+            const int *V = F2_VARIANTS[v];
+            const int CHT = V[0], T1 = V[1], CHA = V[2], T2 = V[3];
+            std::vector<int> pos((size_t)T.m * T.n, -1), ib(T.m, -1), iat((size_t)T1 * NT, -1), iar((size_t)T2 * NT, -1);
+            for (int j = 0; j <= T.n; j++)
+                for (int k = tpl->indptr[j]; k < tpl->indptr[j + 1]; k++) { if (j < T.n) pos[(size_t)tpl->indices[k] * T.n + j] = k; else ib[tpl->indices[k]] = k; }
+            for (int t = 0; t < NT; t++) {
+                const int j1 = t / CHT, c1 = t % CHT, i2 = t / CHA, c2 = t % CHA;
+                for (int k = 0; k < T1; k++) { const int r = T1 * c1 + k; if (j1 < T.n && r < T.m) iat[(size_t)k * NT + t] = pos[(size_t)r * T.n + j1]; }
+                for (int k = 0; k < T2; k++) { const int c = T2 * c2 + k; if (i2 < T.m && c < T.n) iar[(size_t)k * NT + t] = pos[(size_t)i2 * T.n + c]; }
+            }
+            HIPCHK(hipMalloc(&h->d_idx_at, sizeof(int) * iat.size())); HIPCHK(hipMalloc(&h->d_idx_ar, sizeof(int) * iar.size())); HIPCHK(hipMalloc(&h->d_idx_b, sizeof(int) * T.m));
+            HIPCHK(hipMemcpy(h->d_idx_at, iat.data(), sizeof(int) * iat.size(), hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(h->d_idx_ar, iar.data(), sizeof(int) * iar.size(), hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(h->d_idx_b, ib.data(), sizeof(int) * T.m, hipMemcpyHostToDevice));
+            h->f2_variant = v; h->f2_ldg = ldg; h->fwd_lds = by; h->fwd_mode = 4;
+            break;
+        }
+    }
+    if (fwd_env && !strcmp(fwd_env, "generic") && h->fwd_mode == 3) {   // forced generic kernel
+        h->rt_variant = -1;
+        if (fwd_lds_bytes(T, true, true) <= LDS_LIMIT) h->fwd_mode = 0; else if (fwd_lds_bytes(T, true, false) <= LDS_LIMIT) h->fwd_mode = 1; else h->fwd_mode = 2;
+        h->fwd_lds = fwd_lds_bytes(T, h->fwd_mode <= 1, h->fwd_mode == 0);
+    }
     h->nkcap = T.n + std::min(T.m, T.n);
     h->ldk = (h->nkcap + 1) | 1;
     if (bwd_lds_bytes(T, true, true, h->nkcap, h->ldk) <= LDS_LIMIT) h->bwd_mode = 0;
@@ -181,6 +253,7 @@ int ce_create(const ce_template *tpl, int device, ce_handle *out) {
 #define SETATTR(kern, bytes) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)))
     SETATTR((k_forward<true, true>), LDS_LIMIT);  SETATTR((k_forward<true, false>), LDS_LIMIT);  SETATTR((k_forward<false, false>), LDS_LIMIT);
     SETATTR((k_forward_rt<8, 13, 7, 4, 13, 160, 4>), LDS_LIMIT); SETATTR((k_forward_rt<8, 16, 8, 4, 16, 208, 4>), LDS_LIMIT); SETATTR((k_forward_rt<4, 32, 32, 4, 32, 272, 2>), LDS_LIMIT);
+    SETATTR((k_fwd2<16, 2, 8, 2, 16, 2>), LDS_LIMIT); SETATTR((k_fwd2<8, 8, 4, 8, 8, 4>), LDS_LIMIT); SETATTR((k_fwd2<4, 26, 2, 26, 4, 14>), LDS_LIMIT);
     SETATTR((k_backward_rt<4, 4, 4>), LDS_LIMIT); SETATTR((k_backward_rt<7, 7, 4>), LDS_LIMIT); SETATTR((k_backward_rt<7, 7, 7>), LDS_LIMIT);
     SETATTR((k_backward<true, true>), LDS_LIMIT); SETATTR((k_backward<true, false>), LDS_LIMIT); SETATTR((k_backward<false, false>), LDS_LIMIT);
 #undef SETATTR
@@ -192,7 +265,7 @@ int ce_destroy(ce_handle h) {
     if (!h) return CE_OK;
     hipSetDevice(h->device);
     hipFree(h->d_rowidx); hipFree(h->d_colidx); hipFree(h->d_rowcone); hipFree(h->d_qoff);
-    hipFree(h->wsA); hipFree(h->wsdA); hipFree(h->gws);
+    hipFree(h->wsA); hipFree(h->wsdA); hipFree(h->gws); hipFree(h->d_idx_at); hipFree(h->d_idx_ar); hipFree(h->d_idx_b);
     for (auto &v : h->ev) for (auto &p : v) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
     delete h;
     return CE_OK;
@@ -243,7 +316,7 @@ int ce_solve(ce_handle h, int B, const double *A_vals, long sA_k, long sA_b, con
     h->retained_A = Abm; h->retained_B = B;
     const DevT &T = h->T;
     double *gA = nullptr, *gG = nullptr;
-    if (h->fwd_mode > 0 && h->fwd_mode < 3) {
+    if (h->fwd_mode == 1 || h->fwd_mode == 2) {
         size_t perA = (h->fwd_mode == 2) ? (size_t)T.m * T.lda : 0, perG = (size_t)T.n * T.ldg;
         rc = ensure(&h->gws, &h->gws_bytes, sizeof(double) * (size_t)B * (perA + perG));
         if (rc) return rc;
@@ -255,10 +328,15 @@ int ce_solve(ce_handle h, int B, const double *A_vals, long sA_k, long sA_b, con
 #define LAUNCH_F(AL, GL) hipLaunchKernelGGL((k_forward<AL, GL>), grid, block, h->fwd_lds, st, T, S, Abm, q_vals, sq_k, sq_b, x, y, s, iters, status, resid, gA, gG)
         DevT Trt = T; Trt.lda = h->rt_lda;
 #define LAUNCH_RT(...) hipLaunchKernelGGL((k_forward_rt<__VA_ARGS__>), grid, dim3(NT2), h->fwd_lds, st, Trt, S, Abm, q_vals, sq_k, sq_b, x, y, s, iters, status, resid)
-        if (h->fwd_mode == 3) {
+        DevT Tf2 = T; Tf2.ldg = h->f2_ldg;
+#define LAUNCH_F2(...) hipLaunchKernelGGL((k_fwd2<__VA_ARGS__>), grid, dim3(NT), h->fwd_lds, st, Tf2, S, Abm, q_vals, sq_k, sq_b, h->d_idx_at, h->d_idx_ar, h->d_idx_b, x, y, s, iters, status, resid)
+        if (h->fwd_mode == 4) {
+            if (h->f2_variant == 0) LAUNCH_F2(16, 2, 8, 2, 16, 2); else if (h->f2_variant == 1) LAUNCH_F2(8, 8, 4, 8, 8, 4); else LAUNCH_F2(4, 26, 2, 26, 4, 14);
+        } else if (h->fwd_mode == 3) {
             if (h->rt_variant == 0) LAUNCH_RT(8, 13, 7, 4, 13, 160, 4); else if (h->rt_variant == 1) LAUNCH_RT(8, 16, 8, 4, 16, 208, 4); else LAUNCH_RT(4, 32, 32, 4, 32, 272, 2);
         } else if (h->fwd_mode == 0) LAUNCH_F(true, true); else if (h->fwd_mode == 1) LAUNCH_F(true, false); else LAUNCH_F(false, false);
 #undef LAUNCH_RT
+#undef LAUNCH_F2
 #undef LAUNCH_F
     }
     HIPCHK(hipGetLastError());
