@@ -29,19 +29,42 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s
 FP64_VALU_PEAK_TF = 78.6     # half the 157.3 TF fp32 vector peak
 
 
-def cpu_baseline(n, cones, solver_args, sample, seed):
-    """The oracle ("port": CPU restatement of the diffcp/SCS path, OpenMP over instances) timed on the host cores."""
+def cpu_baseline(n, cones, solver_args, sample, seed, budget_s=12.0):
+    """The oracle ("port": CPU restatement of the diffcp/SCS path, OpenMP over instances) timed on the host cores.
+    Bounded sample: whole passes (forward solve + LSQR adjoint, diffcp's default mode) over `sample` instances of the same
+    workload are repeated until about `budget_s` seconds of wall time have been spent; value = instances / time."""
     from oracle import oracle
     A, b, c = P.generate(n, cones, sample, seed=seed)
     threads = oracle.num_threads()
-    oracle.solve_batch(A[:threads], b[:threads], c[:threads], cones, **solver_args)   # warm
-    t0 = time.perf_counter()
-    r = oracle.solve_batch(A, b, c, cones, **solver_args)
-    g = oracle.adjoint_batch(A, b, c, cones, r["x"], r["y"], r["s"], np.ones_like(r["x"]), np.zeros_like(r["y"]), mode="lsqr")
-    dt = time.perf_counter() - t0
-    return dict(value=sample / dt, unit="problems/s", cores=threads, kind="port",
-                sample=f"{sample} instances of the same workload, forward + LSQR adjoint (diffcp default mode), {dt:.2f} s",
+    oracle.solve_batch(A[:threads], b[:threads], c[:threads], cones, **solver_args)   # warm (threads, page faults)
+    done, passes, t0 = 0, 0, time.perf_counter()
+    while True:
+        r = oracle.solve_batch(A, b, c, cones, **solver_args)
+        g = oracle.adjoint_batch(A, b, c, cones, r["x"], r["y"], r["s"], np.ones_like(r["x"]), np.zeros_like(r["y"]), mode="lsqr")
+        done += sample; passes += 1
+        dt = time.perf_counter() - t0
+        if dt >= budget_s or passes >= 200:
+            break
+    return dict(value=done / dt, unit="problems/s", cores=threads, kind="port",
+                sample=f"{passes} passes over {sample} instances of the same workload (forward + LSQR adjoint, diffcp's default mode), {dt:.1f} s of wall time",
                 mean_iters=float(r["iters"].mean()), mean_lsqr_iters=float(g["lsqr_iters"].mean()))
+
+
+def pmc_traffic(kernel_short):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/*/?_pmc_summary.json,
+    made by scripts/gpu_round.sh: separate FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE doubled per MI355X_MICROARCH.md).
+    Returns (bytes, source) or (None, None)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "*pmc_summary.json")))
+    for f in reversed(files):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        for k, v in d.items():
+            if k.startswith(kernel_short) and "FETCH_SIZE_bytes_per_launch" in v and "WRITE_SIZE_bytes_per_launch" in v:
+                return v["FETCH_SIZE_bytes_per_launch"] + v["WRITE_SIZE_bytes_per_launch"], os.path.relpath(f, ROOT)
+    return None, None
 
 
 def main():
@@ -52,7 +75,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--config", default="M")
     ap.add_argument("--eps", type=float, default=1e-4, help="eps_abs=eps_rel (SCS default 1e-4)")
-    ap.add_argument("--cpu-sample", type=int, default=1024)
+    ap.add_argument("--cpu-sample", type=int, default=4096)
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
@@ -119,6 +142,7 @@ def main():
         fwd_bytes = 8 * (nnzA + m + n) + 8 * (n + 2 * m)
         bwd_bytes = 8 * (nnzA + 2 * n + 3 * m) + 8 * (nnzA + m + n)
         ach = fwd_bytes * B / (fwd_ms * 1e-3) / 1e9 if fwd_ms > 0 else 0.0
+        traffic, traffic_src = pmc_traffic("k_fwd")
         # algorithmic fp64 flops of the forward kernel: setup m n^2 + n^3/3, per iteration 4 nnzA + 2 n^2 + 10(n+m)
         flops = B * (m * n * n + n ** 3 / 3.0) + float(iters.sum()) * (4 * nnzA + 2 * n * n + 10 * (n + m))
         out = {
@@ -129,8 +153,9 @@ def main():
                                    f"(nnzA={nnzA}), A,b,c batched, B={B} per GPU, eps_abs=eps_rel={args.eps}, max_iters=10000, "
                                    "acceleration off; step = plugin forward (layout pass + solve + status) + backward (adjoint VJP of sum(x))",
                        "batch_per_gpu": B, "parallelism": f"batch-shard x{world}"},
-            "roofline": {"bound": "hbm", "kernel": "k_forward", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": None,
+            "roofline": {"bound": "hbm", "kernel": "forward (k_fwd2 / k_forward_rt / k_forward): the longest kernel of the step", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes_per_launch": fwd_bytes * B,
                          "note": "LDS-resident iteration: one-touch HBM by construction; the binding resource is fp64 VALU / LDS bandwidth",
                          "valu_f64": {"achieved": flops / (fwd_ms * 1e-3) / 1e12 if fwd_ms > 0 else 0.0, "peak": FP64_VALU_PEAK_TF,
                                       "unit": "TFLOP/s", "frac": flops / (fwd_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TF if fwd_ms > 0 else 0.0}},

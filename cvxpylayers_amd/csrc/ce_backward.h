@@ -254,3 +254,19 @@ __global__ void __launch_bounds__(256) k_transpose(const double *__restrict__ in
     for (int r = ty; r < 32; r += 8) { const int cc = bx + r, rr = by + tx; if (rr < R && cc < C) out[(size_t)cc * R + rr] = tile[tx][r]; }
 }
 
+
+// ================================================================================================
+// parameter-map evaluation, batch-major:  out (B x rows) = P (B x cols) . map^T,  map in CSR (rows x cols)
+// one thread per (row, instance); lanes walk rows -> coalesced 8-byte stores, gathers of P stay inside one instance's row
+// ================================================================================================
+__global__ void __launch_bounds__(256) k_parammap(int rows, const int *__restrict__ indptr, const int *__restrict__ indices,
+                                                  const double *__restrict__ vals, const double *__restrict__ P, long ldp,
+                                                  double *__restrict__ out, long ldo) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    const double *p = P + (size_t)blockIdx.y * ldp;
+    const int t0 = indptr[r], t1 = indptr[r + 1];
+    double a = 0.0;
+    for (int t = t0; t < t1; t++) a = fma(vals[t], p[indices[t]], a);
+    out[(size_t)blockIdx.y * ldo + r] = a;
+}

@@ -401,6 +401,16 @@ int ce_transpose(ce_handle h, int rows, int cols, const double *in, double *out,
     return CE_OK;
 }
 
+int ce_parammap_apply(int device, int B, int rows, const int *indptr, const int *indices, const double *vals,
+                      const double *P, long ld_p, double *out, long ld_out, void *stream) {
+    if (B <= 0 || rows <= 0 || !indptr || !P || !out) { g_err = "null argument"; return CE_E_BADARG; }   // indices / vals may be null for an all-zero map
+    HIPCHK(hipSetDevice(device));
+    dim3 grid((rows + 255) / 256, B);
+    hipLaunchKernelGGL(k_parammap, grid, dim3(256), 0, (hipStream_t)stream, rows, indptr, indices, vals, P, ld_p, out, ld_out);
+    HIPCHK(hipGetLastError());
+    return CE_OK;
+}
+
 int ce_set_profiling(ce_handle h, int enable) { if (!h) return CE_E_BADARG; h->prof = enable != 0; return CE_OK; }
 int ce_reset_profile(ce_handle h) {
     if (!h) return CE_E_BADARG;

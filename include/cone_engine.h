@@ -115,6 +115,17 @@ int ce_vjp(ce_handle h, int B,
  * engine-native batch-major (B x nnz_aug) once, into a tensor it keeps for backward. */
 int ce_transpose(ce_handle h, int rows, int cols, const double *in, double *out, void *stream);
 
+/*
+ * Parameter-map evaluation on the device, batch-major  <- CvxpyLayer.forward's  A_eval = A_map @ p_stack,
+ * q_eval = q_map @ p_stack  (torch/cvxpylayer.py:433-451; _ScipySparseMatmul :12-37) and, called with the transposed map,
+ * their backward (grad_p_stack = map^T @ grad, :32-37).  The map is CSR (rows x cols; indptr/indices/vals are DEVICE arrays):
+ *     out[b*ld_out + r] = sum_{t = indptr[r] .. indptr[r+1]-1} vals[t] * P[b*ld_p + indices[t]]      b < B, r < rows
+ * i.e. parameters and results are (B, .) row-major, so the result is already in the engine-native batch-major layout and the
+ * reference's p_stack transpose and the layout pass of ce_solve both disappear.  No handle: any device pointer set works.
+ */
+int ce_parammap_apply(int device, int B, int rows, const int *indptr, const int *indices, const double *vals,
+                      const double *P, long ld_p, double *out, long ld_out, void *stream);
+
 /* Introspection used by bench.py / tests: per-kernel HIP-event timing on the launch stream. */
 int ce_set_profiling(ce_handle h, int enable);
 /* which: 0 forward kernel, 1 backward kernel, 2 layout (transpose) kernels.  Returns the mean ms per launch

@@ -1,0 +1,151 @@
+"""The torch frontend (cvxpylayers_amd.torch.CvxpyLayer), restating the reference's API / shape / error contract tests
+(tests/test_torch.py:251-352, :626-702; tests/test_parse_args.py:25-101) and closed-form value + gradient tests
+(tests/test_torch.py:90-118 ridge LS, :355-384 broadcasting; tests/test_moreau.py:258-269 box QP; README.md:84-101)
+on hand-canonicalised templates (CVXPY is not installable here)."""
+import numpy as np
+import pytest
+import torch
+
+import kit
+from cvxpylayers_amd.torch import CvxpyLayer, VariableRecovery
+from cvxpylayers_amd.torch.templates import template_from_affine_builder
+
+torch.set_default_dtype(torch.double)
+
+
+def ridge_template(mF, n):
+    """min ||F x - g||^2 + ||x||^2 with parameters F (mF, n), g (mF,); variable x."""
+    def builder(F, g):
+        A, b, c, cones, _ = kit.ridge_ls(F, g)
+        return A, b, c
+    cones = {"z": 0, "l": 0, "q": [mF + 2, n + 2]}
+    return template_from_affine_builder(builder, [(mF, n), (mF,)], cones, [VariableRecovery(slice(0, n), None, (n,))])
+
+
+def boxqp_template(n):
+    def builder(t):
+        A, b, c, cones, _ = kit.box_qp(t)
+        return A, b, c
+    return template_from_affine_builder(builder, [(n,)], {"z": 0, "l": 2 * n, "q": [n + 2]}, [VariableRecovery(slice(0, n), None, (n,))])
+
+
+# ------------------------------------------------------------------ CPU: template construction + API contract
+def test_affine_probing_reproduces_the_builder():
+    rng = np.random.default_rng(0)
+    tpl = ridge_template(5, 3)
+    F = rng.standard_normal((5, 3)); g = rng.standard_normal(5)
+    p = np.concatenate([F.flatten(order="F"), g, [1.0]])
+    A, b, c, cones, _ = kit.ridge_ls(F, g)
+    indices, indptr, (m, np1) = tpl.A_structure
+    cols = np.repeat(np.arange(np1), np.diff(indptr))
+    aug = np.concatenate([-A, b[:, None]], axis=1)
+    np.testing.assert_allclose(tpl.A_map @ p, aug[indices, cols], atol=1e-14)
+    np.testing.assert_allclose((tpl.q_map @ p)[:-1], c, atol=1e-14)
+    assert len(indices) == np.count_nonzero(aug)        # structural zeros are not part of the pattern
+
+
+def test_param_count_shape_and_batch_errors():
+    layer = CvxpyLayer(template=ridge_template(5, 3))
+    with pytest.raises(ValueError, match="A tensor must be provided for each CVXPY parameter"):
+        layer(torch.zeros(5, 3))
+    with pytest.raises(ValueError, match="Invalid parameter shape for parameter 1"):
+        layer(torch.zeros(5, 3), torch.zeros(4))
+    with pytest.raises(ValueError, match="Invalid parameter dimensionality for parameter 0"):
+        layer(torch.zeros(2, 2, 5, 3), torch.zeros(5))
+    with pytest.raises(ValueError, match="Inconsistent batch sizes"):
+        layer(torch.zeros(2, 5, 3), torch.zeros(3, 5))
+    with pytest.raises(ValueError, match="warm_start=True is only supported"):
+        layer(torch.zeros(5, 3), torch.zeros(5), warm_start=True)
+    assert layer.validate_params([torch.zeros(5, 3), torch.zeros(5)]) == ()
+    assert layer.validate_params([torch.zeros(7, 5, 3), torch.zeros(5)]) == (7,)
+
+
+def test_unknown_solver_key():
+    with pytest.raises(RuntimeError, match="Unknown solver"):
+        CvxpyLayer(template=ridge_template(3, 2), solver="NOPE")
+
+
+def test_cpu_tensors_are_refused_loudly():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    layer = CvxpyLayer(template=boxqp_template(3))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        layer(torch.tensor([2.0, 0.5, -1.0]))
+
+
+# ------------------------------------------------------------------ GPU: values and gradients through the whole layer
+@pytest.mark.gpu
+def test_ridge_ls_gradient_matches_closed_form():
+    # reference tests/test_torch.py:90-118 (m=100, n=20, seed 243): gradients of sum(x*) wrt F, g vs autograd of the closed form
+    torch.manual_seed(243)
+    mF, n = 100, 20
+    layer = CvxpyLayer(template=ridge_template(mF, n), solver_args={"eps": 1e-10, "max_iters": 50000})
+    F = torch.randn(mF, n, device="cuda", requires_grad=True)
+    g = torch.randn(mF, device="cuda", requires_grad=True)
+    (x,) = layer(F, g)
+    assert x.shape == (n,)
+    x.sum().backward()
+    F2 = F.detach().clone().requires_grad_(); g2 = g.detach().clone().requires_grad_()
+    xc = torch.linalg.solve(F2.t() @ F2 + torch.eye(n, device="cuda"), F2.t() @ g2)
+    xc.sum().backward()
+    assert torch.allclose(x, xc, atol=1e-6)
+    assert torch.allclose(F.grad, F2.grad, atol=1e-6) and torch.allclose(g.grad, g2.grad, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_broadcast_unbatched_parameter_sums_gradient_over_batch():
+    # reference tests/test_torch.py:355-384: batched g, unbatched (broadcast) F; d/dF is the SUM over the batch
+    torch.manual_seed(0)
+    mF, n, B = 12, 4, 5
+    layer = CvxpyLayer(template=ridge_template(mF, n), solver_args={"eps": 1e-10, "max_iters": 50000})
+    F = torch.randn(mF, n, device="cuda", requires_grad=True)
+    g = torch.randn(B, mF, device="cuda", requires_grad=True)
+    (x,) = layer(F, g)
+    assert x.shape == (B, n)
+    x.sum().backward()
+    F2 = F.detach().clone().requires_grad_(); g2 = g.detach().clone().requires_grad_()
+    xc = torch.linalg.solve(F2.t() @ F2 + torch.eye(n, device="cuda"), F2.t() @ g2.t()).t()
+    xc.sum().backward()
+    assert torch.allclose(x, xc, atol=1e-6)
+    assert torch.allclose(F.grad, F2.grad, atol=1e-5) and torch.allclose(g.grad, g2.grad, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_box_qp_clip_and_batch_of_one_keeps_its_axis():
+    # tests/test_moreau.py:258-269 (clip) and tests/test_torch.py:668-702 (batch of 1 != unbatched)
+    layer = CvxpyLayer(template=boxqp_template(3), solver_args={"eps": 1e-9})
+    t = torch.tensor([2.0, 0.5, -1.0], device="cuda", requires_grad=True)
+    (x,) = layer(t)
+    assert x.shape == (3,) and torch.allclose(x, torch.tensor([1.0, 0.5, 0.0], device="cuda"), atol=1e-5)
+    x.sum().backward()
+    assert t.grad.shape == (3,) and torch.allclose(t.grad, torch.tensor([0.0, 1.0, 0.0], device="cuda"), atol=1e-4)
+    tb = t.detach().clone()[None].requires_grad_()
+    (xb,) = layer(tb)
+    assert xb.shape == (1, 3)
+    xb.sum().backward()
+    assert tb.grad.shape == (1, 3)
+
+
+@pytest.mark.gpu
+def test_no_grad_and_solver_args_reach_the_engine():
+    # tests/test_torch.py:626-665 (no grad) and :705-752 (solver_args reach the solver: max_iters=1 vs many)
+    layer = CvxpyLayer(template=boxqp_template(3))
+    t = torch.tensor([2.0, 0.5, -1.0], device="cuda")
+    with torch.no_grad():
+        (x1,) = layer(t, solver_args={"max_iters": 1, "raise_on_error": False})
+    (x2,) = layer(t, solver_args={"max_iters": 10000, "eps": 1e-9})
+    assert not x2.requires_grad
+    assert (x1 - x2).abs().max() > 1e-3
+    assert int(layer.info["iters"][0]) > 1
+
+
+@pytest.mark.gpu
+def test_infeasible_raises_solver_error():
+    from cvxpylayers_amd.interfaces.mi355_if import SolverError
+
+    def builder(p):          # x >= 1 and x <= -p  (infeasible for p = 1), tests/test_torch.py:299-316
+        return np.array([[-1.0], [1.0]]), np.array([-1.0, -float(p[0])]), np.array([0.0])
+    tpl = template_from_affine_builder(builder, [(1,)], {"z": 0, "l": 2, "q": []}, [VariableRecovery(slice(0, 1), None, (1,))])
+    layer = CvxpyLayer(template=tpl)
+    with pytest.raises(SolverError):
+        layer(torch.tensor([1.0], device="cuda"))
