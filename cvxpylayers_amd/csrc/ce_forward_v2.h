@@ -43,6 +43,18 @@ __device__ __forceinline__ double uniform_d(double v) {
     return __hiloint2double(hi, lo);
 }
 
+// FP32 all-reduce inside aligned groups of CH lanes (DPP, same stages as group_reduce)
+template <int CH, bool MAX>
+__device__ __forceinline__ float group_reduce_f(float v) {
+    auto op = [](float a, float b) { return MAX ? fmaxf(a, b) : a + b; };
+    auto mov = [](float x, auto ctrl) { constexpr int CTRL = decltype(ctrl)::value; return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), CTRL, 0xF, 0xF, false)); };
+    if constexpr (CH >= 2) v = op(v, mov(v, std::integral_constant<int, 0xB1>{}));
+    if constexpr (CH >= 4) v = op(v, mov(v, std::integral_constant<int, 0x4E>{}));
+    if constexpr (CH >= 8) v = op(v, mov(v, std::integral_constant<int, 0x141>{}));
+    if constexpr (CH >= 16) v = op(v, mov(v, std::integral_constant<int, 0x140>{}));
+    return v;
+}
+
 // sqrt(q) and 1/sqrt(q) to ~1 ulp without the fp64 sqrt + divide expansions (~60 VALU ops): hardware seed (v_rsq_f64) and two
 // coupled Goldschmidt steps.  q > 0 and finite; callers guard q == 0.
 __device__ __forceinline__ void sqrt_rsqrt(double q, double &s, double &rinv) {
@@ -101,6 +113,12 @@ struct F2Co {
     }
 };
 
+#ifdef CE_TIMING
+#define F2_STAMP(i) do { __syncthreads(); if (threadIdx.x == 0) f2_tstamp[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define F2_STAMP(i) do { } while (0)
+#endif
+
 #ifndef F2_WPS
 #define F2_WPS 3
 #endif
@@ -126,6 +144,11 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
     const int n = T.n, m = T.m, l = n + m + 1, ldg = T.ldg, nq = T.nq, z = T.z;
     const double *const vals = Avals + (size_t)inst * T.nnz_aug;
 
+#ifdef CE_TIMING
+    __shared__ long long f2_tstamp[16];
+    if (threadIdx.x < 16) f2_tstamp[threadIdx.x] = 0;
+#endif
+    F2_STAMP(0);
     for (int i = tid; i < L::O_G; i += NT) sm[i] = 0.0;
     for (int i = tid; i < MP; i += NT) {
         int r0 = -1, d = 0;
@@ -143,64 +166,73 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
         block_reduce_n<2, NW>(r, 3u, red);
         sc[SC_NB0] = r[0]; sc[SC_NC0] = r[1]; sc[SC_SIGMA] = 1.0;
     }
-    // ---------------------------------------------------------------- equilibration on register tiles (live only here)
+    F2_STAMP(1);
+    // ---------------------------------------------------------------- equilibration (SCS normalize: 25 Ruiz passes + 1 l2 pass)
+    // The passes run on FP32 copies of the tiles: D and E are preconditioners -- any positive diagonal scaling gives an equivalent
+    // problem, and termination is tested on un-normalised residuals -- so the Ruiz factors only need single precision (they
+    // are accumulated in double).  The fp64 iteration tiles are afterwards built as A * (D * E) in double from the final D, E
+    // (materialize_*), so both layouts hold exactly the same matrix.  FP32 halves the VALU cost and the registers of this phase.
     if (S.normalize) {
         const Co co(wave);
         const int j1 = co.j1, c1 = co.c1, i2 = co.i2, c2 = co.c2;
         const bool own1 = (c1 == 0) && (j1 < n), own2 = (c2 == 0) && (i2 < m);
-        double at[T1], ar[T2];
+        float atf[T1], arf[T2];
 #pragma unroll
-        for (int k = 0; k < T1; k++) { const int ix = idx_at[k * NT + tid]; at[k] = ix >= 0 ? -vals[ix] : 0.0; }   // A = -A_cvx (diffcp_if.py:65)
+        for (int k = 0; k < T1; k++) { const int ix = idx_at[k * NT + tid]; atf[k] = ix >= 0 ? (float)(-vals[ix]) : 0.0f; }   // A = -A_cvx (diffcp_if.py:65)
 #pragma unroll
-        for (int k = 0; k < T2; k++) { const int ix = idx_ar[k * NT + tid]; ar[k] = ix >= 0 ? -vals[ix] : 0.0; }
+        for (int k = 0; k < T2; k++) { const int ix = idx_ar[k * NT + tid]; arf[k] = ix >= 0 ? (float)(-vals[ix]) : 0.0f; }
+        float *const fEt0 = reinterpret_cast<float *>(sm + L::O_S1), *const fEt1 = reinterpret_cast<float *>(sm + L::O_S2);
+        float *const fDt0 = reinterpret_cast<float *>(sm + L::O_U + OY), *const fDt1 = reinterpret_cast<float *>(sm + L::O_UT + OY);
+        float *const fRn = reinterpret_cast<float *>(sm + L::O_ZB + OY);
+        auto clampf = [](float v) -> float { return v < (float)MIN_SCALE ? 1.0f : (v > (float)MAX_SCALE ? (float)MAX_SCALE : v); };
         for (int pass = 0; pass < NUM_RUIZ_PASSES + NUM_L2_PASSES; pass++) {
             const bool l2 = pass >= NUM_RUIZ_PASSES;
-            const int oEt = (pass & 1) ? L::O_S2 : L::O_S1;                 // column scaling of this pass (x-indexed)
-            const int oDt = ((pass & 1) ? L::O_UT : L::O_U) + OY;           // row scaling of this pass (y-indexed)
-            double cn = 0, rn = 0;
+            float *const fEt = (pass & 1) ? fEt1 : fEt0;                  // column scaling of this pass (x-indexed)
+            float *const fDt = (pass & 1) ? fDt1 : fDt0;                  // row scaling of this pass (y-indexed)
+            float cn = 0, rn = 0;
             if (l2) {
 #pragma unroll
-                for (int k = 0; k < T1; k++) cn = fma(at[k], at[k], cn);
+                for (int k = 0; k < T1; k++) cn = fmaf(atf[k], atf[k], cn);
 #pragma unroll
-                for (int k = 0; k < T2; k++) rn = fma(ar[k], ar[k], rn);
-                cn = sqrt(group_reduce<CHT, false>(cn)); rn = sqrt(group_reduce<CHA, false>(rn));
+                for (int k = 0; k < T2; k++) rn = fmaf(arf[k], arf[k], rn);
+                cn = sqrtf(group_reduce_f<CHT, false>(cn)); rn = sqrtf(group_reduce_f<CHA, false>(rn));
             } else {
+                float c0 = 0, c1_ = 0, r0 = 0, r1 = 0;
 #pragma unroll
-                for (int k = 0; k < T1; k++) cn = fmax(cn, fabs(at[k]));
-                cn = group_reduce<CHT, true>(cn);
-                __builtin_amdgcn_sched_barrier(0);
+                for (int k = 0; k < T1; k += 2) { c0 = fmaxf(c0, fabsf(atf[k])); c1_ = fmaxf(c1_, fabsf(atf[k + 1])); }
 #pragma unroll
-                for (int k = 0; k < T2; k++) rn = fmax(rn, fabs(ar[k]));
-                rn = group_reduce<CHA, true>(rn);
+                for (int k = 0; k < T2; k += 2) { r0 = fmaxf(r0, fabsf(arf[k])); r1 = fmaxf(r1, fabsf(arf[k + 1])); }
+                cn = group_reduce_f<CHT, true>(fmaxf(c0, c1_)); rn = group_reduce_f<CHA, true>(fmaxf(r0, r1));
             }
-            if (own1) { double sq, ri; sqrt_rsqrt(clamp_scale(cn), sq, ri); sm[oEt + j1] = ri; }
-            if (own2) sm[L::O_ZB + OY + i2] = rn;          // raw row norms
+            if (own1) fEt[j1] = 1.0f / sqrtf(clampf(cn));
+            if (own2) fRn[i2] = rn;          // raw row norms
             __syncthreads();
             if (own2) {
-                double a = rn;
+                float a = rn;
                 const int r0 = socr[i2], d = socd[i2];
                 if (d > 0) {   // block-average inside the SOC so the scaled cone is still the cone
-                    a = 0; for (int i = r0; i < r0 + d; i++) a += sm[L::O_ZB + OY + i];
-                    a /= (double)d;
+                    float s0 = 0, s1 = 0;
+                    int i = 0;
+                    for (; i + 1 < d; i += 2) { s0 += fRn[r0 + i]; s1 += fRn[r0 + i + 1]; }
+                    if (i < d) s0 += fRn[r0 + i];
+                    a = (s0 + s1) / (float)d;
                 }
-                double sq, ri; sqrt_rsqrt(clamp_scale(a), sq, ri);
-                sm[oDt + i2] = ri;
+                fDt[i2] = 1.0f / sqrtf(clampf(a));
             }
             __syncthreads();
             {
-                const double ej = sm[oEt + (j1 < NP ? j1 : 0)];            // pad entries are 0
-                const double2 *d2 = reinterpret_cast<const double2 *>(sm + oDt + T1 * c1);
+                const float ej = fEt[j1 < NP ? j1 : 0];            // pad entries are 0
+                const float2 *d2 = reinterpret_cast<const float2 *>(fDt + T1 * c1);
 #pragma unroll
-                for (int k = 0; k < T1 / 2; k++) { const double2 d = d2[k]; at[2 * k] *= d.x * ej; at[2 * k + 1] *= d.y * ej; asm volatile("" : "+v"(at[2 * k]), "+v"(at[2 * k + 1])); }   // pin the product here (no sinking into the next pass)
-                __builtin_amdgcn_sched_barrier(0);        // keep the two scaling sweeps apart (register peak of the pass)
-                const double di = sm[oDt + (i2 < MP ? i2 : 0)];
-                const double2 *e2 = reinterpret_cast<const double2 *>(sm + oEt + T2 * c2);
+                for (int k = 0; k < T1 / 2; k++) { const float2 d = d2[k]; atf[2 * k] *= d.x * ej; atf[2 * k + 1] *= d.y * ej; }
+                const float di = fDt[i2 < MP ? i2 : 0];
+                const float2 *e2 = reinterpret_cast<const float2 *>(fEt + T2 * c2);
 #pragma unroll
-                for (int k = 0; k < T2 / 2; k++) { const double2 ee = e2[k]; ar[2 * k] *= di * ee.x; ar[2 * k + 1] *= di * ee.y; asm volatile("" : "+v"(ar[2 * k]), "+v"(ar[2 * k + 1])); }
-                if (own1) sm[L::O_EV + j1] *= ej;
-                if (own2) sm[L::O_DV + i2] *= di;
+                for (int k = 0; k < T2 / 2; k++) { const float2 ee = e2[k]; arf[2 * k] *= di * ee.x; arf[2 * k + 1] *= di * ee.y; }
+                if (own1) sm[L::O_EV + j1] *= (double)ej;
+                if (own2) sm[L::O_DV + i2] *= (double)di;
             }
-            // no barrier: the next pass writes the other ping-pong buffers (and ZB, last read before the barrier above)
+            // no barrier: the next pass writes the other ping-pong buffers (and the row norms, last read before the barrier above)
         }
         __syncthreads();
         double r[2] = {0, 0};
@@ -216,6 +248,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
         __syncthreads();
     }
 
+    F2_STAMP(2);
     double scale = S.scale, hg = 0, inv_den = 0;
     const double rho_x = S.rho_x, rtau = TAU_FACTOR, alpha = S.alpha;
     auto dyv = [&](int i) -> double { return (i < z) ? ZERO_CONE_FACTOR * scale : scale; };   // 1 / r_y
@@ -262,6 +295,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
 
     // ---- (re)factor:  G <- (rho_x I + A^T Dy A)^{-1} (LDS);  g, h.g, phi.   Clobbers ZB, TV, PX, S1..S4.
     auto refactor = [&]() {
+        F2_STAMP(7);
         const Co co(wave);
         const int tid = co.t;
         const int j1 = co.j1, c1 = co.c1, i2 = co.i2, c2 = co.c2, jg = co.jg, cg = co.cg;
@@ -287,6 +321,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
                 __syncthreads();
                 if (jg < n) {
                     const double *r = Gm;
+#pragma unroll 2
                     for (int i = p0; i < p1; i++, r += LDP) {
                         const double aj = r[jg] * dyv(i);
                         const double2 *r2 = reinterpret_cast<const double2 *>(r + TG * cg);
@@ -299,6 +334,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
 #pragma unroll
             for (int s = 0; s < TG; s++) if (jg < n && TG * cg + s == jg) sreg[s] += rho_x;
         }
+        F2_STAMP(8);
         // Gauss-Jordan inversion on the register tile; pivot order k = kk + TG*cgk (kk static).  Pivot row / column are
         // published through LDS, double buffered: row -> S1/S3, column -> S2/S4.
         auto publish = [&](auto slot_c, int cgn, int bufn) {
@@ -323,7 +359,10 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
                 const int k = TG * cgk + kk, buf = cnt & 1;
                 const double *rowk = sm + (buf ? L::O_S3 : L::O_S1), *colk = sm + (buf ? L::O_S4 : L::O_S2);
                 if (jg < n) {
-                    const double pinv = 1.0 / rowk[k];
+                    const double pv = rowk[k];
+                    double pinv = __builtin_amdgcn_rcp(pv);                 // seed + two Newton steps instead of the IEEE divide
+                    pinv = fma(fma(-pv, pinv, 1.0), pinv, pinv);            // expansion: it sits on the critical path of every pivot
+                    pinv = fma(fma(-pv, pinv, 1.0), pinv, pinv);
                     const bool prow_thread = (jg == k);
                     const double cj0 = colk[jg] * pinv;
                     const double2 *r2 = reinterpret_cast<const double2 *>(rowk + TG * cg);
@@ -346,6 +385,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
                 __syncthreads();
             }
         });
+        F2_STAMP(9);
         // G to LDS (the panel data in that region is dead), scratch back to zero
         if (jg < n) {
             double2 *dst = reinterpret_cast<double2 *>(Gm + jg * ldg + TG * cg);
@@ -386,6 +426,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
         for (int i = tid; i < NP; i += NT) { sm[L::O_S1 + i] = 0.0; sm[L::O_S2 + i] = 0.0; sm[L::O_PX + i] = 0.0; }
         for (int i = tid; i < m; i += NT) sm[L::O_ZB + OY + i] = 0.0;
         __syncthreads();
+        F2_STAMP(10);
     };
 
     if (threadIdx.x == 0) sm[L::O_W + OT] = 1.0;    // cold start: w = (0, 0, 1)
@@ -421,6 +462,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
 
     for (bool done = false; !done;) {
     refactor();
+    F2_STAMP(3);
     if (resume) {   // relaxed update w += alpha (u - ut) owed by the iteration a rescale interrupted
         const int e = Co::thread_id(wave);
         if (e < l) { const int ve = slot_of(e); sm[L::O_W + ve] += alpha * (sm[L::O_U + ve] - sm[L::O_UT + ve]); }
@@ -441,7 +483,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
             const double we = ev ? sm[L::O_W + ve] : 0.0;
             double r[1] = {we * we};
             block_reduce_n<1, NW>(r, 0u, red);
-            const double nw = sqrt(r[0]);
+            const double nw = uniform_d(sqrt(r[0]));
             if (nw > 0 && ev) sm[L::O_W + ve] = we * (sqrt((double)l) / nw);
             __syncthreads();
         }
@@ -517,8 +559,8 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
             __builtin_amdgcn_sched_barrier(0);        // one product at a time: the check must not raise the loop's register peak
             const double aty_raw = seg_dot<CHT, T1>(at, sm + L::O_U + OY + T1 * c1);      // A-hat^T y-hat (valid in column groups)
             __builtin_amdgcn_sched_barrier(0);
-            const double tau = fabs(sm[L::O_U + OT]);
-            const double isg = 1.0 / sc[SC_SIGMA];
+            const double tau = uniform_d(fabs(sm[L::O_U + OT]));
+            const double isg = uniform_d(1.0 / sc[SC_SIGMA]);
             double r[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // rp, nax, ns, naxs, rd, naty (max) ; ctx, bty (sum)
             if (own2) {
                 const int i = i2;
@@ -539,8 +581,11 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
                 r[6] = cj * sm[L::O_U + OX + j] * isg * isg;
             }
             block_reduce_n<8, NW>(r, 0x3Fu, red);
-            const double rp = r[0], nax = r[1], ns = r[2], naxs = r[3], rd = r[4], naty = r[5], ctx = r[6], bty = r[7];
-            const double nrm_b0 = sc[SC_NB0], nrm_c0 = sc[SC_NC0];
+            // the reduced values are equal in every lane: move them to scalar registers so that the convergence logic below
+            // is scalar code with uniform branches (and n_log / last_scale_iter / status stay scalar)
+            const double rp = uniform_d(r[0]), nax = uniform_d(r[1]), ns = uniform_d(r[2]), naxs = uniform_d(r[3]), rd = uniform_d(r[4]),
+                         naty = uniform_d(r[5]), ctx = uniform_d(r[6]), bty = uniform_d(r[7]);
+            const double nrm_b0 = uniform_d(sc[SC_NB0]), nrm_c0 = uniform_d(sc[SC_NC0]);
             if (tau > 0) {
                 const double res_pri = rp / tau, res_dual = rd / tau, gap = fabs(ctx + bty) / tau;
                 sc[SC_RP] = res_pri; sc[SC_RD] = res_dual; sc[SC_GAP] = gap;
@@ -555,7 +600,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
                 const double dp = fmax(fmax(nax, ns), nrm_b0 * tau), dd = fmax(naty, nrm_c0 * tau);
                 const double rel_p = rp / (dp > 0 ? dp : 1), rel_d = rd / (dd > 0 ? dd : 1);
                 if (rel_p > 0 && rel_d > 0 && isfinite(rel_p) && isfinite(rel_d)) {
-                    const double sum_log = sc[SC_SUMLOG] + log(rel_p) - log(rel_d); n_log++;
+                    const double sum_log = uniform_d(sc[SC_SUMLOG]) + log(rel_p) - log(rel_d); n_log++;
                     __syncthreads();                 // everyone has read SC_SUMLOG before it is rewritten
                     sc[SC_SUMLOG] = sum_log;
                     const double factor = sqrt(exp(sum_log / n_log));
@@ -588,6 +633,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
     }
 
     __syncthreads();
+    F2_STAMP(4);
     const int tid_w = Co::thread_id(wave);
     const double tau = fabs(sm[L::O_U + OT]);
     const double sigma = sc[SC_SIGMA];
@@ -618,4 +664,8 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
             if (resid_o) { resid_o[3 * inst] = sc[SC_RP]; resid_o[3 * inst + 1] = sc[SC_RD]; resid_o[3 * inst + 2] = sc[SC_GAP]; }
         }
     }
+#ifdef CE_TIMING
+    F2_STAMP(5);
+    if (threadIdx.x < 12) so[(size_t)inst * m + threadIdx.x] = (double)f2_tstamp[threadIdx.x];
+#endif
 }

@@ -12,6 +12,13 @@ dev = torch.device("cuda", 0)
 eng = ConeEngine(tpl.indices, tpl.indptr, tpl.n, tpl.m, cones, dev)
 A_bm = torch.from_numpy(A_eval).to(dev).t().contiguous(); q_t = torch.from_numpy(q_eval).to(dev)
 x, y, s, it, st, res = eng.solve(A_bm, q_t, make_settings(dict(eps=1e-4, max_iters=10000)))
+torch.cuda.synchronize()
+ts = s[:, :12].cpu().numpy()
+print("forward phases (cycles, mean over instances); iters mean", it.float().mean().item())
+for nm, a, b2 in (("init+load b,c", 0, 1), ("equilibration", 1, 2), ("refactor: materialize+S", 7, 8), ("refactor: GJ", 8, 9), ("refactor: g,phi", 9, 10),
+                  ("first refactor total (2->3 includes)", 2, 3), ("iterations (incl. later refactors)", 3, 4), ("writeback", 4, 5), ("total", 0, 5)):
+    print(f"  {nm:38s} {(ts[:, b2] - ts[:, a]).mean():12.1f}")
+x, y, s, it, st, res = eng.solve(A_bm, q_t, make_settings(dict(eps=1e-4, max_iters=10000)))
 dx = torch.ones_like(x); dy = torch.zeros_like(y)
 dA, dq, adj = eng.vjp(A_bm, x, y, s, dx, dy)
 torch.cuda.synchronize()
