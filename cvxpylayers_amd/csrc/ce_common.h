@@ -18,6 +18,9 @@ struct DevT {
     const int *colidx;    // [nnz_aug] column (n == the b column)
     const int *rowcone;   // [m] -1 for zero / nonneg rows, else SOC index
     const int *qoff;      // [nq+1] first row of SOC c
+    int ns, maxs;         // PSD cones, largest order
+    const int *soff;      // [ns+1] first row of PSD cone c (svec blocks follow the SOCs, SCS row order z,l,q,s)
+    const int *sord;      // [ns] order k of PSD cone c
 };
 
 thread_local std::string g_err;

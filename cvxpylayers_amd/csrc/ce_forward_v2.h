@@ -119,10 +119,90 @@ struct F2Co {
 #define F2_STAMP(i) do { } while (0)
 #endif
 
+// ------------------------------------------------------------------------------------------------------------------
+// PSD cone: projection of svec(S) onto the PSD cone by a workgroup-parallel cyclic Jacobi eigensolver in LDS.
+//   Sm, Vm : k x k scratch (row-major), cs : (c, s) per pair.  All NT threads take part; ends synchronised.
+// Rounds follow the round-robin tournament (k-1 rounds of k/2 DISJOINT pairs, whose rotations commute): per round one thread
+// per pair computes the rotation, then all threads apply S <- S J, V <- V J (column pass) and S <- J^T S (row pass).
+// Same rotation formulas and svec convention (lower triangle, column-major, sqrt(2) off-diagonals) as oracle/cone_oracle.c.
+__device__ __forceinline__ void psd_project(double *zsvec, int k, double *Sm, double *Vm, double *cs, double *red) {
+    const int tid = threadIdx.x;
+    const int K = (k + 1) & ~1;               // players of the tournament (a dummy if k is odd)
+    // svec -> symmetric matrix
+    for (int idx = tid; idx < k * k; idx += NT) {
+        const int i = idx / k, j = idx - i * k;
+        const int a = i >= j ? i : j, b = i >= j ? j : i;                 // lower-triangle entry (a, b), column-major packed
+        const int pos = b * k - (b * (b - 1)) / 2 + (a - b);
+        const double v = zsvec[pos];
+        Sm[idx] = (a == b) ? v : v * M_SQRT1_2;
+        Vm[idx] = (i == j) ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    for (int sweep = 0; sweep < 40; sweep++) {
+        double r[2] = {0, 0};                    // off-diagonal and diagonal squared norms
+        for (int idx = tid; idx < k * k; idx += NT) { const int i = idx / k, j = idx - i * k; const double v = Sm[idx]; if (i == j) r[1] = fma(v, v, r[1]); else r[0] = fma(v, v, r[0]); }
+        block_reduce_n<2, NW>(r, 0u, red);
+        if (r[0] <= 1e-30 * (r[0] + r[1]) || r[0] == 0.0) break;          // uniform
+        for (int rd = 0; rd < K - 1; rd++) {
+            if (tid < K / 2) {
+                int p = (tid == 0) ? K - 1 : (rd + tid) % (K - 1);
+                int q = (rd + K - 1 - tid) % (K - 1);
+                if (p > q) { const int t_ = p; p = q; q = t_; }
+                double c = 1.0, sn = 0.0;
+                if (q < k) {
+                    const double apq = Sm[p * k + q];
+                    if (apq != 0.0) {
+                        const double theta = (Sm[q * k + q] - Sm[p * k + p]) / (2 * apq);
+                        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1));
+                        c = 1 / sqrt(t * t + 1); sn = t * c;
+                    }
+                } else { p = -1; }
+                cs[4 * tid] = c; cs[4 * tid + 1] = sn; cs[4 * tid + 2] = (double)p; cs[4 * tid + 3] = (double)q;
+            }
+            __syncthreads();
+            // column pass on S and V:  (x_p, x_q) <- (c x_p - s x_q, s x_p + c x_q) for every row
+            for (int idx = tid; idx < (K / 2) * k * 2; idx += NT) {
+                const int which = idx / ((K / 2) * k), rem = idx - which * (K / 2) * k;
+                const int pi = rem / k, row = rem - pi * k;
+                const int p = (int)cs[4 * pi + 2], q = (int)cs[4 * pi + 3];
+                if (p < 0) continue;
+                const double c = cs[4 * pi], sn = cs[4 * pi + 1];
+                double *M = which ? Vm : Sm;
+                const double a = M[row * k + p], b = M[row * k + q];
+                M[row * k + p] = c * a - sn * b; M[row * k + q] = sn * a + c * b;
+            }
+            __syncthreads();
+            // row pass on S
+            for (int idx = tid; idx < (K / 2) * k; idx += NT) {
+                const int pi = idx / k, col = idx - pi * k;
+                const int p = (int)cs[4 * pi + 2], q = (int)cs[4 * pi + 3];
+                if (p < 0) continue;
+                const double c = cs[4 * pi], sn = cs[4 * pi + 1];
+                const double a = Sm[p * k + col], b = Sm[q * k + col];
+                Sm[p * k + col] = c * a - sn * b; Sm[q * k + col] = sn * a + c * b;
+            }
+            __syncthreads();
+        }
+    }
+    // eigenvalues -> cs (clipped at 0), then svec of V diag(w+) V^T
+    for (int i = tid; i < k; i += NT) cs[i] = fmax(Sm[i * k + i], 0.0);
+    __syncthreads();
+    for (int pos = tid; pos < k * (k + 1) / 2; pos += NT) {
+        // unpack pos -> (a, b), a >= b, column-major lower triangle
+        int b = 0, rem = pos;
+        while (rem >= k - b) { rem -= k - b; b++; }
+        const int a = b + rem;
+        double acc = 0;
+        for (int e = 0; e < k; e++) acc = fma(Vm[a * k + e] * cs[e], Vm[b * k + e], acc);
+        zsvec[pos] = (a == b) ? acc : acc * M_SQRT2;
+    }
+    __syncthreads();
+}
+
 #ifndef F2_WPS
 #define F2_WPS 3
 #endif
-template <int CHT, int T1, int CHA, int T2, int CHG, int TG>
+template <int CHT, int T1, int CHA, int T2, int CHG, int TG, bool PSD = false>
 __global__ void __launch_bounds__(NT, F2_WPS)
 k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__restrict__ qv, long sqk, long sqb,
        const int *__restrict__ idx_at, const int *__restrict__ idx_ar, const int *__restrict__ idx_b,
@@ -153,6 +233,9 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
     for (int i = tid; i < MP; i += NT) {
         int r0 = -1, d = 0;
         if (i < m) { const int c = T.rowcone[i]; if (c >= 0) { r0 = T.qoff[c]; d = T.qoff[c + 1] - r0; } }
+        if constexpr (PSD) {      // rows of PSD cones: block start and NEGATIVE block length (same block averaging, separate projection)
+            for (int c = 0; c < T.ns; c++) if (i >= T.soff[c] && i < T.soff[c + 1]) { r0 = T.soff[c]; d = -(T.soff[c + 1] - r0); }
+        }
         socr[i] = r0; socd[i] = d;
     }
     __syncthreads();
@@ -209,8 +292,8 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
             __syncthreads();
             if (own2) {
                 float a = rn;
-                const int r0 = socr[i2], d = socd[i2];
-                if (d > 0) {   // block-average inside the SOC so the scaled cone is still the cone
+                const int r0 = socr[i2], d = abs(socd[i2]);
+                if (d > 0) {   // block-average inside the SOC / PSD block so the scaled cone is still the cone
                     float s0 = 0, s1 = 0;
                     int i = 0;
                     for (; i + 1 < d; i += 2) { s0 += fRn[r0 + i]; s1 += fRn[r0 + i + 1]; }
@@ -538,6 +621,10 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
             __syncthreads();
             if (e < m && socd[e] > 0) { const int c = T.rowcone[e]; sm[L::O_ZB + ve] = (e == socr[e]) ? sm[L::O_S3 + c] : sm[L::O_S4 + c] * sm[L::O_ZB + ve]; }
             __syncthreads();
+        }
+        if constexpr (PSD) {   // PSD blocks of the cone input are projected in place (all threads, one cone after the other)
+            double *psdS = Gm + n * ldg, *psdV = psdS + T.maxs * T.maxs, *psdC = psdV + T.maxs * T.maxs;
+            for (int c = 0; c < T.ns; c++) psd_project(sm + L::O_ZB + OY + T.soff[c], T.sord[c], psdS, psdV, psdC, red);
         }
         if (!check && !last) {
             // P3 (fast path): project, relaxed update

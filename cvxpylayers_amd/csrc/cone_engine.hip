@@ -48,7 +48,7 @@ struct ce_engine {
     int device = 0;
     DevT T{};
     std::vector<int> q, s;
-    int *d_rowidx = nullptr, *d_colidx = nullptr, *d_rowcone = nullptr, *d_qoff = nullptr;
+    int *d_rowidx = nullptr, *d_colidx = nullptr, *d_rowcone = nullptr, *d_qoff = nullptr, *d_soff = nullptr, *d_sord = nullptr;
     // workspace
     double *wsA = nullptr; size_t wsA_bytes = 0;          // batch-major copy of A_vals  [B][nnz_aug]
     double *wsdA = nullptr; size_t wsdA_bytes = 0;        // batch-major dA              [B][nnz_aug]
@@ -111,6 +111,9 @@ static size_t bwd_lds_bytes(const DevT &T, bool a_lds, bool k_lds, int nkcap, in
     return d * 8 + ints * 4 + 16;
 }
 
+#ifndef BRT_HAS_PSD
+#define BRT_HAS_PSD 0
+#endif
 // register-tiled backward variants {TI, TJ, TH}: K tile 16*TI x 16*TJ per workgroup, H tile 16*TH
 static const int BRT_VARIANTS[3][3] = {{4, 4, 4}, {7, 7, 4}, {7, 7, 7}};
 static size_t bwd_rt_lds_bytes(const DevT &T, int TI, int TJ) {
@@ -152,7 +155,8 @@ static bool f2_fits(const DevT &T, int v, int *ldg, size_t *bytes) {
     if (T.maxq > SOC_SMALL && T.nq > d.NP) return false;
     *ldg = f2_pick_ldg(v);
     if ((size_t)T.n * *ldg < (size_t)d.NPa) return false;
-    *bytes = ((size_t)d.O_G + d.MP /* SOC row info (2 int arrays) */ + (size_t)T.n * *ldg) * 8;
+    const size_t psd = T.ns > 0 ? 2 * (size_t)T.maxs * T.maxs + 2 * (size_t)T.maxs + 8 : 0;      // Jacobi scratch: S, V, (c, s, p, q) per pair
+    *bytes = ((size_t)d.O_G + d.MP /* SOC row info (2 int arrays) */ + (size_t)T.n * *ldg + psd) * 8;
     return *bytes <= LDS_LIMIT;
 }
 
@@ -167,9 +171,10 @@ void ce_default_settings(ce_settings *s) {
 
 int ce_create(const ce_template *tpl, int device, ce_handle *out) {
     if (!tpl || !out || tpl->n <= 0 || tpl->m <= 0 || !tpl->indices || !tpl->indptr) { g_err = "bad template"; return CE_E_BADARG; }
-    if (tpl->ns > 0 || tpl->nep > 0 || tpl->np > 0) { g_err = "PSD / exponential / power cones are not implemented on the device path yet"; return CE_E_UNSUPPORTED; }
+    if (tpl->nep > 0 || tpl->np > 0) { g_err = "exponential / power cones are not implemented on the device path"; return CE_E_UNSUPPORTED; }
     int rows = tpl->z + tpl->l;
     for (int i = 0; i < tpl->nq; i++) { if (tpl->q[i] < 1) { g_err = "bad SOC dim"; return CE_E_BADARG; } rows += tpl->q[i]; }
+    for (int i = 0; i < tpl->ns; i++) { if (tpl->s[i] < 1) { g_err = "bad PSD order"; return CE_E_BADARG; } rows += tpl->s[i] * (tpl->s[i] + 1) / 2; }
     if (rows != tpl->m) { g_err = "cone dims do not add up to m"; return CE_E_BADARG; }
     if (tpl->indptr[tpl->n + 1] != tpl->nnz_aug) { g_err = "indptr[n+1] != nnz_aug"; return CE_E_BADARG; }
     HIPCHK(hipSetDevice(device));
@@ -188,6 +193,10 @@ int ce_create(const ce_template *tpl, int device, ce_handle *out) {
     int r = tpl->z + tpl->l;
     for (int c = 0; c < tpl->nq; c++) { qoff[c] = r; for (int i = 0; i < tpl->q[c]; i++) rowcone[r + i] = c; r += tpl->q[c]; }
     qoff[tpl->nq] = r;
+    std::vector<int> soff(tpl->ns + 1, r), sord(std::max(tpl->ns, 1), 0);
+    T.ns = tpl->ns; T.maxs = 0;
+    for (int c = 0; c < tpl->ns; c++) { soff[c] = r; sord[c] = tpl->s[c]; T.maxs = std::max(T.maxs, tpl->s[c]); r += tpl->s[c] * (tpl->s[c] + 1) / 2; }
+    soff[tpl->ns] = r;
     h->q.assign(tpl->q, tpl->q + tpl->nq);
     HIPCHK(hipMalloc(&h->d_rowidx, sizeof(int) * tpl->nnz_aug));
     HIPCHK(hipMalloc(&h->d_colidx, sizeof(int) * tpl->nnz_aug));
@@ -197,6 +206,10 @@ int ce_create(const ce_template *tpl, int device, ce_handle *out) {
     HIPCHK(hipMemcpy(h->d_colidx, colidx.data(), sizeof(int) * tpl->nnz_aug, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->d_rowcone, rowcone.data(), sizeof(int) * tpl->m, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->d_qoff, qoff.data(), sizeof(int) * (tpl->nq + 1), hipMemcpyHostToDevice));
+    HIPCHK(hipMalloc(&h->d_soff, sizeof(int) * (tpl->ns + 1))); HIPCHK(hipMalloc(&h->d_sord, sizeof(int) * std::max(tpl->ns, 1)));
+    HIPCHK(hipMemcpy(h->d_soff, soff.data(), sizeof(int) * (tpl->ns + 1), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->d_sord, sord.data(), sizeof(int) * std::max(tpl->ns, 1), hipMemcpyHostToDevice));
+    T.soff = h->d_soff; T.sord = h->d_sord;
     T.rowidx = h->d_rowidx; T.colidx = h->d_colidx; T.rowcone = h->d_rowcone; T.qoff = h->d_qoff;
     // residency plan: mode 0 = everything in LDS, 1 = A in LDS / big matrix in global, 2 = both in global
     if (fwd_lds_bytes(T, true, true) <= LDS_LIMIT) h->fwd_mode = 0;
@@ -235,6 +248,7 @@ int ce_create(const ce_template *tpl, int device, ce_handle *out) {
         if (fwd_lds_bytes(T, true, true) <= LDS_LIMIT) h->fwd_mode = 0; else if (fwd_lds_bytes(T, true, false) <= LDS_LIMIT) h->fwd_mode = 1; else h->fwd_mode = 2;
         h->fwd_lds = fwd_lds_bytes(T, h->fwd_mode <= 1, h->fwd_mode == 0);
     }
+    if (T.ns > 0 && h->fwd_mode != 4) { ce_destroy(h); g_err = "PSD cones: the instance does not fit the LDS-resident forward kernel (n <= 50, m <= 104 this round)"; return CE_E_UNSUPPORTED; }
     h->nkcap = T.n + std::min(T.m, T.n);
     h->ldk = (h->nkcap + 1) | 1;
     if (bwd_lds_bytes(T, true, true, h->nkcap, h->ldk) <= LDS_LIMIT) h->bwd_mode = 0;
@@ -253,6 +267,7 @@ int ce_create(const ce_template *tpl, int device, ce_handle *out) {
 #define SETATTR(kern, bytes) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)))
     SETATTR((k_forward<true, true>), LDS_LIMIT);  SETATTR((k_forward<true, false>), LDS_LIMIT);  SETATTR((k_forward<false, false>), LDS_LIMIT);
     SETATTR((k_forward_rt<8, 13, 7, 4, 13, 160, 4>), LDS_LIMIT); SETATTR((k_forward_rt<8, 16, 8, 4, 16, 208, 4>), LDS_LIMIT); SETATTR((k_forward_rt<4, 32, 32, 4, 32, 272, 2>), LDS_LIMIT);
+    SETATTR((k_fwd2<16, 2, 8, 2, 16, 2, true>), LDS_LIMIT); SETATTR((k_fwd2<8, 8, 4, 8, 8, 4, true>), LDS_LIMIT); SETATTR((k_fwd2<4, 26, 2, 26, 4, 14, true>), LDS_LIMIT);
     SETATTR((k_fwd2<16, 2, 8, 2, 16, 2>), LDS_LIMIT); SETATTR((k_fwd2<8, 8, 4, 8, 8, 4>), LDS_LIMIT); SETATTR((k_fwd2<4, 26, 2, 26, 4, 14>), LDS_LIMIT);
     SETATTR((k_backward_rt<4, 4, 4>), LDS_LIMIT); SETATTR((k_backward_rt<7, 7, 4>), LDS_LIMIT); SETATTR((k_backward_rt<7, 7, 7>), LDS_LIMIT);
     SETATTR((k_backward<true, true>), LDS_LIMIT); SETATTR((k_backward<true, false>), LDS_LIMIT); SETATTR((k_backward<false, false>), LDS_LIMIT);
@@ -264,7 +279,7 @@ int ce_create(const ce_template *tpl, int device, ce_handle *out) {
 int ce_destroy(ce_handle h) {
     if (!h) return CE_OK;
     hipSetDevice(h->device);
-    hipFree(h->d_rowidx); hipFree(h->d_colidx); hipFree(h->d_rowcone); hipFree(h->d_qoff);
+    hipFree(h->d_rowidx); hipFree(h->d_colidx); hipFree(h->d_rowcone); hipFree(h->d_qoff); hipFree(h->d_soff); hipFree(h->d_sord);
     hipFree(h->wsA); hipFree(h->wsdA); hipFree(h->gws); hipFree(h->d_idx_at); hipFree(h->d_idx_ar); hipFree(h->d_idx_b);
     for (auto &v : h->ev) for (auto &p : v) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
     delete h;
@@ -330,7 +345,9 @@ int ce_solve(ce_handle h, int B, const double *A_vals, long sA_k, long sA_b, con
 #define LAUNCH_RT(...) hipLaunchKernelGGL((k_forward_rt<__VA_ARGS__>), grid, dim3(NT2), h->fwd_lds, st, Trt, S, Abm, q_vals, sq_k, sq_b, x, y, s, iters, status, resid)
         DevT Tf2 = T; Tf2.ldg = h->f2_ldg;
 #define LAUNCH_F2(...) hipLaunchKernelGGL((k_fwd2<__VA_ARGS__>), grid, dim3(NT), h->fwd_lds, st, Tf2, S, Abm, q_vals, sq_k, sq_b, h->d_idx_at, h->d_idx_ar, h->d_idx_b, x, y, s, iters, status, resid)
-        if (h->fwd_mode == 4) {
+        if (h->fwd_mode == 4 && T.ns > 0) {
+            if (h->f2_variant == 0) LAUNCH_F2(16, 2, 8, 2, 16, 2, true); else if (h->f2_variant == 1) LAUNCH_F2(8, 8, 4, 8, 8, 4, true); else LAUNCH_F2(4, 26, 2, 26, 4, 14, true);
+        } else if (h->fwd_mode == 4) {
             if (h->f2_variant == 0) LAUNCH_F2(16, 2, 8, 2, 16, 2); else if (h->f2_variant == 1) LAUNCH_F2(8, 8, 4, 8, 8, 4); else LAUNCH_F2(4, 26, 2, 26, 4, 14);
         } else if (h->fwd_mode == 3) {
             if (h->rt_variant == 0) LAUNCH_RT(8, 13, 7, 4, 13, 160, 4); else if (h->rt_variant == 1) LAUNCH_RT(8, 16, 8, 4, 16, 208, 4); else LAUNCH_RT(4, 32, 32, 4, 32, 272, 2);
@@ -351,6 +368,7 @@ int ce_vjp(ce_handle h, int B, const double *A_vals, long sA_k, long sA_b, const
     HIPCHK(hipSetDevice(h->device));
     hipStream_t st = (hipStream_t)stream;
     const DevT &T = h->T;
+    if (T.ns > 0 && (h->bwd_mode != 3 || !BRT_HAS_PSD)) { g_err = "PSD cones: adjoint not available for this template size"; return CE_E_UNSUPPORTED; }
     const double *Abm = nullptr;
     int rc;
     if (A_vals) { rc = to_batch_major(h, B, A_vals, sA_k, sA_b, st, &Abm); if (rc) return rc; }

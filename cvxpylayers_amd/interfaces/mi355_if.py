@@ -140,18 +140,25 @@ class ConeEngine:
         _lib.check(rc, "ce_solve")
         return x, y, s, iters, status, resid
 
-    def vjp(self, A_bm, x, y, s, dx, dy):
-        """Returns dA (nnz_aug, B) [a transposed view of a batch-major buffer], dq (n+1, B), adj_status (B,)."""
+    def vjp(self, A_bm, x, y, s, dx, dy, batch_minor_out: bool = False):
+        """Returns dA (nnz_aug, B), dq (n+1, B), adj_status (B,).  dA is a transposed view of a batch-major buffer (the
+        engine-native layout, no extra pass) unless batch_minor_out: then it is (nnz_aug, B) contiguous -- the layout of a
+        reference-style A_eval, so that autograd can accumulate it into the leaf without a strided copy (one engine layout pass)."""
         B = A_bm.shape[0]
         dev = self.device
-        dA_bm = torch.empty((B, self.nnz_aug), dtype=torch.float64, device=dev)
         dq = torch.empty((self.n + 1, B), dtype=torch.float64, device=dev)
         adj = torch.empty((B,), dtype=torch.int32, device=dev)
+        if batch_minor_out:
+            dA = torch.empty((self.nnz_aug, B), dtype=torch.float64, device=dev)
+            sk, sb = B, 1
+        else:
+            dA = torch.empty((B, self.nnz_aug), dtype=torch.float64, device=dev)
+            sk, sb = 1, self.nnz_aug
         rc = _lib.lib().ce_vjp(self._h, B, A_bm.data_ptr(), 1, self.nnz_aug, None, 0, 0, x.data_ptr(), y.data_ptr(),
-                               s.data_ptr(), dx.data_ptr(), dy.data_ptr(), dA_bm.data_ptr(), 1, self.nnz_aug,
+                               s.data_ptr(), dx.data_ptr(), dy.data_ptr(), dA.data_ptr(), sk, sb,
                                dq.data_ptr(), B, 1, adj.data_ptr(), self._stream())
         _lib.check(rc, "ce_vjp")
-        return dA_bm.t(), dq, adj
+        return (dA if batch_minor_out else dA.t()), dq, adj
 
     # introspection (bench / tests)
     def set_profiling(self, on: bool):
@@ -226,6 +233,7 @@ class _CvxpyLayer(torch.autograd.Function):
         with torch.cuda.device(dev):
             A_dev = A_eval.detach().to(device=dev, dtype=torch.float64)
             q_dev = q_eval.detach().to(device=dev, dtype=torch.float64)
+            batch_minor_in = A_dev.dim() == 2 and A_dev.is_contiguous() and A_dev.shape[1] > 1
             A_bm = eng.to_batch_major(A_dev)
             x, y, s, iters, status, resid = eng.solve(A_bm, q_dev, settings)
             st = status.cpu()
@@ -238,7 +246,7 @@ class _CvxpyLayer(torch.autograd.Function):
         primal = x.to(in_device)
         dual = y.to(in_device)
         info = dict(iters=iters, status=status, resid=resid)
-        saved = (eng, A_bm, x, y, s) if needs_grad else None
+        saved = (eng, A_bm, x, y, s, batch_minor_in) if needs_grad else None
         return primal, dual, info, (saved, batch_size, originally_unbatched, in_device)
 
     @staticmethod
@@ -253,11 +261,11 @@ class _CvxpyLayer(torch.autograd.Function):
         saved, batch_size, originally_unbatched, in_device = ctx.backward_data
         if saved is None:
             raise RuntimeError("backward called on a layer evaluated with needs_grad=False")
-        eng, A_bm, x, y, s = saved
+        eng, A_bm, x, y, s, batch_minor_in = saved
         with torch.cuda.device(eng.device):
             dx = dprimal.to(device=eng.device, dtype=torch.float64).contiguous()
             dy = ddual.to(device=eng.device, dtype=torch.float64).contiguous()
-            dA, dq, adj = eng.vjp(A_bm, x, y, s, dx, dy)
+            dA, dq, adj = eng.vjp(A_bm, x, y, s, dx, dy, batch_minor_out=batch_minor_in)
         ctx.adj_status = adj
         dA = dA.to(in_device)
         dq = dq.to(in_device)

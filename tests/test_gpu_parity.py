@@ -127,3 +127,40 @@ def test_infeasible_unbounded_status_on_gpu():
         tpl = P.dense_template(A.shape[1], cones)
         *_, iters, status, resid = gpu_solve(tpl, A[None], b[None], c[None], eps=1e-6)
         assert status[0] == want
+
+
+def _forward_parity(n, cones, B, seed, eps, max_iters=100000):
+    from oracle import oracle
+    tpl = P.dense_template(n, cones)
+    A, b, c = P.generate(n, cones, B, seed=seed)
+    ref = oracle.solve_batch(A, b, c, cones, eps=eps, max_iters=max_iters)
+    eng, A_bm, x, y, s, iters, status, resid = gpu_solve(tpl, A, b, c, eps=eps, max_iters=max_iters)
+    assert (ref["status"] == 1).all() and (status == 1).all(), (status, ref["status"])
+    tol = max(1e-6, 20 * eps)
+    for got, want in ((x, ref["x"]), (y, ref["y"]), (s, ref["s"])):
+        err = np.abs(got.cpu().numpy() - want).max(axis=1) / (1 + np.abs(want).max(axis=1))
+        assert err.max() < tol, err.max()
+    return eng, A_bm, ref
+
+
+def test_psd_forward_parity_small():
+    _forward_parity(6, {"z": 2, "l": 3, "q": [4], "s": [3]}, 8, seed=5, eps=1e-9)
+
+
+def test_psd_forward_parity_two_cones_odd_order():
+    _forward_parity(12, {"z": 1, "l": 2, "q": [], "s": [5, 4]}, 6, seed=8, eps=1e-9)
+
+
+def test_psd_forward_parity_c4_lite():
+    _forward_parity(36, {"z": 6, "l": 0, "q": [], "s": [8]}, 4, seed=6, eps=1e-9)
+
+
+def test_sdp_min_eigenvector_known_answer_on_gpu():
+    # min tr(C X) s.t. tr X = 1, X PSD -> X = v v^T, dual = C - lmin I  (reference tests/test_dual_variables.py:523-550)
+    Cm = np.array([[1.0, 0.5], [0.5, 2.0]])
+    A, b, c, cones, X, Z = kit.sdp_min_eig(Cm)
+    tpl = P.dense_template(A.shape[1], cones)
+    *_, x, y, s, iters, status, resid = gpu_solve(tpl, A[None], b[None], c[None], eps=1e-10, max_iters=100000)
+    assert status[0] == 1
+    np.testing.assert_allclose(P.svec_to_sym(x.cpu().numpy()[0], 2), X, atol=1e-5)
+    np.testing.assert_allclose(P.svec_to_sym(y.cpu().numpy()[0][1:], 2), Z, atol=1e-5)
