@@ -4,7 +4,7 @@
 // BACKWARD
 // ================================================================================================
 // row kinds after classifying DPi_{K*}(v), v = y - s
-enum { RK_EQ = 0, RK_FREE = 1, RK_SOCB = 2 };
+enum { RK_EQ = 0, RK_FREE = 1, RK_SOCB = 2, RK_MIX = 3 };   // RK_MIX: rotated PSD row with 0 < DPi eigenvalue < 1
 
 template <bool A_LDS, bool K_LDS>
 __global__ void __launch_bounds__(NT)

@@ -28,7 +28,7 @@ __host__ __device__ inline int bwd_rt_union_doubles(int n, int m, int nqs, int T
     return r > c ? r : c;
 }
 
-template <int TI, int TJ, int TH>
+template <int TI, int TJ, int TH, bool PSD = false>
 __global__ void __launch_bounds__(NT, 3)
 k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict__ xg, const double *__restrict__ yg,
               const double *__restrict__ sg, const double *__restrict__ dxg, const double *__restrict__ dyg,
@@ -52,6 +52,8 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
     double *pivrow = p; p += BG * TI;   // pivot value of the row that served as pivot
     double *pinfo = p; p += 2;          // pivot value per buffer
     double *red = p; p += NW * 8;
+    double *psdU = p, *psdEv = p, *lamr = p, *psdScr = p;     // PSD: eigenvectors per cone, eigenvalues, DPi eigenvalue per rotated row, scratch
+    if constexpr (PSD) { psdU = p; p += T.ns * T.maxs * T.maxs; psdEv = p; p += T.ns * T.maxs; lamr = p; p += m; psdScr = p; p += 8 * T.maxs * T.maxs + 2 * T.maxs + 8; }
     double *U = p; p += bwd_rt_union_doubles(n, m, nqs, TI, TJ);
     double *ay = U, *as = U + nqs * n;                              // A_c^T e_y, A_c^T e_s
     double *colbuf = U, *rowbuf = U + 2 * BG * TI;
@@ -91,6 +93,58 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
         for (int i = r0; i < r1; i++) rkind[i] = kind == 0 ? RK_EQ : (kind == 1 ? RK_FREE : RK_SOCB);
     }
     __syncthreads();
+    if constexpr (PSD) {
+        // PSD cones: V = smat(v_c) = U Lambda U^T.  DPi(v) is diagonal in the orthonormal basis E_ab = svec(sym(u_a u_b^T)) with
+        // eigenvalue B_ab (1: both eigenvalues positive, 0: both non-positive, l+/(l+ - l-): mixed).  The rows of the cone are
+        // ROTATED into that basis in place, A_c <- Q^T A_c with Q^T x = svec(U^T smat(x) U): afterwards every rotated row is an
+        // ordinary equality (B=1) / free (B=0) / weighted (theta = B/(1-B)) row and the generic machinery below applies.
+        const int lane = tid & 63, wid = tid >> 6;
+        for (int c = 0; c < T.ns; c++) {
+            const int k = T.sord[c], r0 = T.soff[c], d = k * (k + 1) / 2;
+            double *Um = psdU + c * T.maxs * T.maxs, *ev = psdEv + c * T.maxs;
+            psd_jacobi(vv + r0, k, psdScr, Um, psdScr + 2 * T.maxs * T.maxs, red);     // eigenvalues on diag(psdScr), vectors in Um
+            for (int i = tid; i < k; i += NT) ev[i] = psdScr[i * k + i];
+            __syncthreads();
+            // rotate the n columns of A_c and (as column n) the incoming dy_c; one column per wave at a time
+            for (int g0 = 0; g0 <= n; g0 += NW) {
+                const int col = g0 + wid;
+                double *X = psdScr + wid * 2 * T.maxs * T.maxs, *W = X + T.maxs * T.maxs;
+                if (col <= n) {
+                    for (int idx = lane; idx < k * k; idx += 64) {
+                        const int i = idx / k, j = idx - i * k, a = i >= j ? i : j, b = i >= j ? j : i;
+                        const int pos = b * k - (b * (b - 1)) / 2 + (a - b);
+                        const double v = (col < n) ? A[(r0 + pos) * lda + col] : dyg[(size_t)inst * m + r0 + pos];
+                        X[idx] = (a == b) ? v : v * M_SQRT1_2;
+                    }
+                }
+                __syncthreads();
+                if (col <= n) {
+                    for (int idx = lane; idx < k * k; idx += 64) {       // W = X U
+                        const int i = idx / k, j = idx - i * k;
+                        double acc = 0; for (int a = 0; a < k; a++) acc = fma(X[i * k + a], Um[a * k + j], acc);
+                        W[idx] = acc;
+                    }
+                }
+                __syncthreads();
+                if (col <= n) {
+                    for (int pos = lane; pos < d; pos += 64) {           // T = U^T W, packed back as svec
+                        int b = 0, rem = pos; while (rem >= k - b) { rem -= k - b; b++; }
+                        const int a = b + rem;
+                        double acc = 0; for (int i = 0; i < k; i++) acc = fma(Um[i * k + a], W[i * k + b], acc);
+                        const double t = (a == b) ? acc : acc * M_SQRT2;
+                        if (col < n) A[(r0 + pos) * lda + col] = t;
+                        else {
+                            const double la = ev[a], lb = ev[b];
+                            const double Bv = (la > 0 && lb > 0) ? 1.0 : ((la <= 0 && lb <= 0) ? 0.0 : fmax(la, lb) / (fmax(la, lb) - fmin(la, lb)));
+                            lamr[r0 + pos] = Bv; dv[r0 + pos] = Bv * t;
+                            rkind[r0 + pos] = (Bv == 1.0) ? RK_EQ : (Bv == 0.0 ? RK_FREE : RK_MIX);
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
     // ---- equality numbering: ballot prefix sums (rows in order, then one e_y row per boundary cone)
     {
         int base = 0;
@@ -176,6 +230,10 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
                 const double a = g - ay[c * n + j] * eyd - as[c * n + j] * esd;      // A_c^T P d
                 acc += as[c * n + j] * esd + a / (1 - lam);
             }
+            if constexpr (PSD) {
+                for (int t = T.soff[0] + part; t < T.soff[T.ns]; t += 4)
+                    if (rkind[t] == RK_MIX) acc = fma(A[t * lda + j], dv[t] / (1 - lamr[t]), acc);
+            }
         }
         acc = group_reduce<4, false>(acc);
         if (j < n && part == 0) fvec[j] = acc;
@@ -214,6 +272,22 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
                 const int r = ra + BG * i, cc = cb + BG * j;
                 if (r < n && cc < n) kt[i][j] = fma(-th, ayc[r] * ayc[cc] + asc[r] * asc[cc], kt[i][j]);
             }
+    }
+    if constexpr (PSD) {   // weighted rows of rotated PSD blocks: H += theta_t a_t^T a_t
+        for (int t = T.soff[0]; t < T.soff[T.ns]; t++) {
+            if (rkind[t] != RK_MIX) continue;              // uniform
+            const double th = lamr[t] / (1 - lamr[t]);
+            const double *row = A + t * lda;
+            double ar[TH], ac[TH];
+#pragma unroll
+            for (int i = 0; i < TH; i++) ar[i] = (ra + BG * i < n) ? th * row[ra + BG * i] : 0.0;
+#pragma unroll
+            for (int j = 0; j < TH; j++) ac[j] = (cb + BG * j < n) ? row[cb + BG * j] : 0.0;
+#pragma unroll
+            for (int i = 0; i < TH; i++)
+#pragma unroll
+                for (int j = 0; j < TH; j++) kt[i][j] = fma(ar[i], ac[j], kt[i][j]);
+        }
     }
     // B / -B^T blocks and the right-hand side.  The source of equality e (a row of A or a_y of a boundary cone) is resolved
     // once per tile row / column into an LDS base pointer, so each entry costs one independent LDS read.
@@ -381,6 +455,37 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
         }
     }
     __syncthreads();
+    if constexpr (PSD) {   // r~ in the rotated basis, then r_y,c = Q r~ = svec(U smat(r~) U^T)
+        for (int t = T.soff[0] + tid; t < T.soff[T.ns]; t += NT) {
+            const int rk = rkind[t];
+            vv[t] = (rk == RK_EQ) ? bv[eqrow[t]] : (rk == RK_FREE ? dv[t] : (dv[t] - lamr[t] * qv2[t]) / (1 - lamr[t]));
+        }
+        __syncthreads();
+        for (int c = 0; c < T.ns; c++) {
+            const int k = T.sord[c], r0 = T.soff[c], d = k * (k + 1) / 2;
+            const double *Um = psdU + c * T.maxs * T.maxs;
+            double *X = psdScr, *W = X + T.maxs * T.maxs;
+            for (int idx = tid; idx < k * k; idx += NT) {
+                const int i = idx / k, j = idx - i * k, a = i >= j ? i : j, b = i >= j ? j : i;
+                const double v = vv[r0 + b * k - (b * (b - 1)) / 2 + (a - b)];
+                X[idx] = (a == b) ? v : v * M_SQRT1_2;
+            }
+            __syncthreads();
+            for (int idx = tid; idx < k * k; idx += NT) {           // W = U X
+                const int i = idx / k, j = idx - i * k;
+                double acc = 0; for (int a = 0; a < k; a++) acc = fma(Um[i * k + a], X[a * k + j], acc);
+                W[idx] = acc;
+            }
+            __syncthreads();
+            for (int pos = tid; pos < d; pos += NT) {               // T = W U^T
+                int b = 0, rem = pos; while (rem >= k - b) { rem -= k - b; b++; }
+                const int a = b + rem;
+                double acc = 0; for (int e = 0; e < k; e++) acc = fma(W[a * k + e], Um[b * k + e], acc);
+                vv[r0 + pos] = (a == b) ? acc : acc * M_SQRT2;
+            }
+            __syncthreads();
+        }
+    }
     CE_STAMP(6);
     // ---- outputs in the boundary convention: dA_eval = [-dA.data, db[b_idx]], dq_eval = [dc, 0]   (diffcp_if.py:91-92)
 #pragma unroll 4

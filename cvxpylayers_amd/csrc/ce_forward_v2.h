@@ -125,7 +125,8 @@ struct F2Co {
 // Rounds follow the round-robin tournament (k-1 rounds of k/2 DISJOINT pairs, whose rotations commute): per round one thread
 // per pair computes the rotation, then all threads apply S <- S J, V <- V J (column pass) and S <- J^T S (row pass).
 // Same rotation formulas and svec convention (lower triangle, column-major, sqrt(2) off-diagonals) as oracle/cone_oracle.c.
-__device__ __forceinline__ void psd_project(double *zsvec, int k, double *Sm, double *Vm, double *cs, double *red) {
+// psd_jacobi: eigendecomposition only -- on return diag(Sm) holds the eigenvalues and the COLUMNS of Vm the eigenvectors.
+__device__ __forceinline__ void psd_jacobi(const double *zsvec, int k, double *Sm, double *Vm, double *cs, double *red) {
     const int tid = threadIdx.x;
     const int K = (k + 1) & ~1;               // players of the tournament (a dummy if k is odd)
     // svec -> symmetric matrix
@@ -184,6 +185,10 @@ __device__ __forceinline__ void psd_project(double *zsvec, int k, double *Sm, do
             __syncthreads();
         }
     }
+}
+__device__ __forceinline__ void psd_project(double *zsvec, int k, double *Sm, double *Vm, double *cs, double *red) {
+    const int tid = threadIdx.x;
+    psd_jacobi(zsvec, k, Sm, Vm, cs, red);
     // eigenvalues -> cs (clipped at 0), then svec of V diag(w+) V^T
     for (int i = tid; i < k; i += NT) cs[i] = fmax(Sm[i * k + i], 0.0);
     __syncthreads();

@@ -112,13 +112,14 @@ static size_t bwd_lds_bytes(const DevT &T, bool a_lds, bool k_lds, int nkcap, in
 }
 
 #ifndef BRT_HAS_PSD
-#define BRT_HAS_PSD 0
+#define BRT_HAS_PSD 1
 #endif
 // register-tiled backward variants {TI, TJ, TH}: K tile 16*TI x 16*TJ per workgroup, H tile 16*TH
 static const int BRT_VARIANTS[3][3] = {{4, 4, 4}, {7, 7, 4}, {7, 7, 7}};
 static size_t bwd_rt_lds_bytes(const DevT &T, int TI, int TJ) {
     const int n = T.n, m = T.m, nqs = std::max(T.nq, 1);
     size_t d = (size_t)m * n /* lda = n */ + 3 * (size_t)m + 2 * (size_t)n + 6 * nqs + BG * TI + 2 + NW * 8 + bwd_rt_union_doubles(n, m, nqs, TI, TJ);
+    if (T.ns > 0) d += (size_t)T.ns * T.maxs * T.maxs + (size_t)T.ns * T.maxs + m + 8 * (size_t)T.maxs * T.maxs + 2 * T.maxs + 8;
     size_t ints = 2 * (size_t)m + 2 * nqs + BG * TJ + BG * TI + NW + 1 + 8;
     return d * 8 + ints * 4 + 16;
 }
@@ -269,6 +270,7 @@ int ce_create(const ce_template *tpl, int device, ce_handle *out) {
     SETATTR((k_forward_rt<8, 13, 7, 4, 13, 160, 4>), LDS_LIMIT); SETATTR((k_forward_rt<8, 16, 8, 4, 16, 208, 4>), LDS_LIMIT); SETATTR((k_forward_rt<4, 32, 32, 4, 32, 272, 2>), LDS_LIMIT);
     SETATTR((k_fwd2<16, 2, 8, 2, 16, 2, true>), LDS_LIMIT); SETATTR((k_fwd2<8, 8, 4, 8, 8, 4, true>), LDS_LIMIT); SETATTR((k_fwd2<4, 26, 2, 26, 4, 14, true>), LDS_LIMIT);
     SETATTR((k_fwd2<16, 2, 8, 2, 16, 2>), LDS_LIMIT); SETATTR((k_fwd2<8, 8, 4, 8, 8, 4>), LDS_LIMIT); SETATTR((k_fwd2<4, 26, 2, 26, 4, 14>), LDS_LIMIT);
+    SETATTR((k_backward_rt<4, 4, 4, true>), LDS_LIMIT); SETATTR((k_backward_rt<7, 7, 4, true>), LDS_LIMIT); SETATTR((k_backward_rt<7, 7, 7, true>), LDS_LIMIT);
     SETATTR((k_backward_rt<4, 4, 4>), LDS_LIMIT); SETATTR((k_backward_rt<7, 7, 4>), LDS_LIMIT); SETATTR((k_backward_rt<7, 7, 7>), LDS_LIMIT);
     SETATTR((k_backward<true, true>), LDS_LIMIT); SETATTR((k_backward<true, false>), LDS_LIMIT); SETATTR((k_backward<false, false>), LDS_LIMIT);
 #undef SETATTR
@@ -391,7 +393,9 @@ int ce_vjp(ce_handle h, int B, const double *A_vals, long sA_k, long sA_b, const
 #define LAUNCH_B(AL, KL) hipLaunchKernelGGL((k_backward<AL, KL>), grid, block, h->bwd_lds, st, T, h->nkcap, h->ldk, Abm, x, y, s, dx, dy, dAbm, dq_vals, sdq_k, sdq_b, adj_status, gA, gK)
         DevT Tb = T; Tb.lda = T.n;
 #define LAUNCH_BRT(...) hipLaunchKernelGGL((k_backward_rt<__VA_ARGS__>), grid, block, h->bwd_lds, st, Tb, Abm, x, y, s, dx, dy, dAbm, dq_vals, sdq_k, sdq_b, adj_status)
-        if (h->bwd_mode == 3) {
+        if (h->bwd_mode == 3 && T.ns > 0) {
+            if (h->brt_variant == 0) LAUNCH_BRT(4, 4, 4, true); else if (h->brt_variant == 1) LAUNCH_BRT(7, 7, 4, true); else LAUNCH_BRT(7, 7, 7, true);
+        } else if (h->bwd_mode == 3) {
             if (h->brt_variant == 0) LAUNCH_BRT(4, 4, 4); else if (h->brt_variant == 1) LAUNCH_BRT(7, 7, 4); else LAUNCH_BRT(7, 7, 7);
         } else if (h->bwd_mode == 0) LAUNCH_B(true, true); else if (h->bwd_mode == 1) LAUNCH_B(true, false); else LAUNCH_B(false, false);
 #undef LAUNCH_BRT

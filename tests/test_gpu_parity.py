@@ -164,3 +164,11 @@ def test_sdp_min_eigenvector_known_answer_on_gpu():
     assert status[0] == 1
     np.testing.assert_allclose(P.svec_to_sym(x.cpu().numpy()[0], 2), X, atol=1e-5)
     np.testing.assert_allclose(P.svec_to_sym(y.cpu().numpy()[0][1:], 2), Z, atol=1e-5)
+
+
+def test_psd_forward_and_adjoint_parity():
+    run_parity(6, {"z": 2, "l": 3, "q": [4], "s": [3]}, 8, seed=5, eps=1e-9, max_iters=100000)
+
+
+def test_psd_two_cones_adjoint_parity():
+    run_parity(12, {"z": 1, "l": 2, "q": [], "s": [5, 4]}, 6, seed=8, eps=1e-9, max_iters=100000)
