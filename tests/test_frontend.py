@@ -149,3 +149,35 @@ def test_infeasible_raises_solver_error():
     layer = CvxpyLayer(template=tpl)
     with pytest.raises(SolverError):
         layer(torch.tensor([1.0], device="cuda"))
+
+
+@pytest.mark.gpu
+def test_sdp_min_eigenvector_value_dual_and_gradient():
+    # min tr(C X) s.t. tr X = 1, X PSD  ->  X = v v^T (min eigenvector), PSD dual = C - lmin I
+    # (reference tests/test_dual_variables.py:523-550 values; tests/test_torch.py:233-248 3x3 SDP gradient)
+    k = 3
+    d = k * (k + 1) // 2
+
+    def builder(Cm):
+        A, b, c, cones, _, _ = kit.sdp_min_eig(0.5 * (Cm + Cm.T))
+        return A, b, c
+    tpl = template_from_affine_builder(builder, [(k, k)], {"z": 1, "l": 0, "q": [], "s": [k]},
+                                       [VariableRecovery(slice(0, d), None, (k, k), source="primal", unpack_fn="svec_dual"),
+                                        VariableRecovery(None, slice(1, 1 + d), (k, k), source="dual", unpack_fn="svec_dual")])
+    layer = CvxpyLayer(template=tpl, solver_args={"eps": 1e-10, "max_iters": 200000})
+    torch.manual_seed(3)
+    G = torch.randn(k, k)
+    C0 = (G + G.t()) / 2 + torch.diag(torch.tensor([0.0, 1.0, 2.5]))
+    C = C0.cuda().requires_grad_()
+    X, Z = layer(C)
+    w, V = torch.linalg.eigh(C0)
+    v = V[:, 0]
+    assert torch.allclose(X.cpu(), torch.outer(v, v), atol=1e-5)
+    assert torch.allclose(Z.cpu(), C0 - w[0] * torch.eye(k), atol=1e-5)
+    Wt = torch.randn(k, k)
+    Wt = (Wt + Wt.t()) / 2
+    (X * Wt.cuda()).sum().backward()
+    C2 = C0.clone().requires_grad_()
+    w2, V2 = torch.linalg.eigh((C2 + C2.t()) / 2)
+    (torch.outer(V2[:, 0], V2[:, 0]) * Wt).sum().backward()
+    assert torch.allclose(C.grad.cpu(), C2.grad, atol=1e-5), (C.grad.cpu(), C2.grad)
