@@ -184,13 +184,16 @@ k_backward(DevT T, int nkcap, int ldk, const double *__restrict__ Avals, const d
         double piv = K[pk * ldk + k];
         if (fabs(piv) < ptol) piv = (piv < 0 ? -ptol : ptol);
         const double pinv = 1.0 / piv;
-        const int wcols = NK - k;   // columns k+1 .. NK
-        for (int idx = tid; idx < NK * wcols; idx += NT) {
-            const int i = idx / wcols, j = k + 1 + idx % wcols;
-            if (i == k) continue;
-            const int pi = perm[i];
-            const double f = K[pi * ldk + k] * pinv;
-            if (f != 0.0) K[pi * ldk + j] = fma(-f, K[pk * ldk + j], K[pi * ldk + j]);
+        // rank-1 update of columns k+1 .. NK: a 16 x 16 thread grid walks rows / columns (no integer division in the loop)
+        {
+            const int ty = tid >> 4, tx = tid & 15;
+            const double *prow = K + pk * ldk;
+            for (int i = ty; i < NK; i += 16) {
+                if (i == k) continue;
+                double *row = K + perm[i] * ldk;
+                const double f = row[k] * pinv;
+                if (f != 0.0) for (int j = k + 1 + tx; j <= NK; j += 16) row[j] = fma(-f, prow[j], row[j]);
+            }
         }
         __syncthreads();
     }

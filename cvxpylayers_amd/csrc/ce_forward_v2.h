@@ -647,27 +647,35 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
         __syncthreads();
         bool stop = false, rescale = false;
         if (check) {
-            const double ax_raw = seg_dot<CHA, T2>(ar, sm + L::O_U + OX + T2 * c2);       // A-hat x-hat   (valid in row groups)
-            __builtin_amdgcn_sched_barrier(0);        // one product at a time: the check must not raise the loop's register peak
-            const double aty_raw = seg_dot<CHT, T1>(at, sm + L::O_U + OY + T1 * c1);      // A-hat^T y-hat (valid in column groups)
+            // The two products of the residual test are parked in LDS (ZB is free here) and the residuals are evaluated in a
+            // separate elementwise phase: the tile-using code then has the register footprint of the iteration's own
+            // products, and the check does not raise the loop's register peak.
+            {
+                const double ax_raw = seg_dot<CHA, T2>(ar, sm + L::O_U + OX + T2 * c2);       // A-hat x-hat
+                if (own2) sm[L::O_ZB + OY + i2] = ax_raw;
+            }
             __builtin_amdgcn_sched_barrier(0);
+            {
+                const double aty_raw = seg_dot<CHT, T1>(at, sm + L::O_U + OY + T1 * c1);      // A-hat^T y-hat
+                if (own1) sm[L::O_ZB + OX + j1] = aty_raw;
+            }
+            __syncthreads();
             const double tau = uniform_d(fabs(sm[L::O_U + OT]));
             const double isg = uniform_d(1.0 / sc[SC_SIGMA]);
             double r[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // rp, nax, ns, naxs, rd, naty (max) ; ctx, bty (sum)
-            if (own2) {
-                const int i = i2;
+            if (e < m) {
+                const int i = e;
                 const double sc_ = isg / sm[L::O_DV + i];
-                const double ax = ax_raw * sc_;
+                const double ax = sm[L::O_ZB + OY + i] * sc_;
                 const double uy = sm[L::O_U + OY + i];
                 const double sh = (uy + sm[L::O_W + OY + i] - 2 * sm[L::O_UT + OY + i]) / dyv(i) * sc_;
                 const double bt = sm[L::O_BV + i] * tau * sc_;
                 r[0] = fabs(ax + sh - bt); r[1] = fabs(ax); r[2] = fabs(sh); r[3] = fabs(ax + sh);
                 r[7] = sm[L::O_BV + i] * uy * isg * isg;
-            }
-            if (own1) {
-                const int j = j1;
+            } else if (e < m + n) {
+                const int j = e - m;
                 const double sc_ = isg / sm[L::O_EV + j];
-                const double aty = aty_raw * sc_;
+                const double aty = sm[L::O_ZB + OX + j] * sc_;
                 const double cj = sm[L::O_CV + j];
                 r[4] = fabs(aty + cj * tau * sc_); r[5] = fabs(aty);
                 r[6] = cj * sm[L::O_U + OX + j] * isg * isg;
