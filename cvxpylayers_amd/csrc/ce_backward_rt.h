@@ -102,7 +102,7 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
         for (int c = 0; c < T.ns; c++) {
             const int k = T.sord[c], r0 = T.soff[c], d = k * (k + 1) / 2;
             double *Um = psdU + c * T.maxs * T.maxs, *ev = psdEv + c * T.maxs;
-            psd_jacobi(vv + r0, k, psdScr, Um, psdScr + 2 * T.maxs * T.maxs, red);     // eigenvalues on diag(psdScr), vectors in Um
+            psd_jacobi<NT>(vv + r0, k, psdScr, Um, psdScr + 2 * T.maxs * T.maxs, red);     // eigenvalues on diag(psdScr), vectors in Um
             for (int i = tid; i < k; i += NT) ev[i] = psdScr[i * k + i];
             __syncthreads();
             // rotate the n columns of A_c and (as column n) the incoming dy_c; one column per wave at a time

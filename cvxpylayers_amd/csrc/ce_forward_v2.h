@@ -22,7 +22,7 @@ __device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int
 template <int N, class F>
 __device__ __forceinline__ void static_for(F &&f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
-template <int CHT, int T1, int CHA, int T2, int CHG, int TG>
+template <int CHT, int T1, int CHA, int T2, int CHG, int TG, int NWARP = 4>
 struct F2 {
     static constexpr int MP = CHT * T1;                       // padded rows
     static constexpr int NPa = CHA * T2, NPg = CHG * TG;
@@ -32,7 +32,7 @@ struct F2 {
     static constexpr int O_W = 0, O_UT = VP, O_U = 2 * VP, O_ZB = 3 * VP, O_GV = 4 * VP, O_PHI = 5 * VP;
     static constexpr int O_BV = 6 * VP, O_DV = O_BV + MP, O_CV = O_DV + MP, O_EV = O_CV + NP, O_TV = O_EV + NP, O_PX = O_TV + NP,
                          O_S1 = O_PX + NP, O_S2 = O_S1 + NP, O_S3 = O_S2 + NP, O_S4 = O_S3 + NP,
-                         O_RED = O_S4 + NP, O_WP = O_RED + NW * 8, O_SC = O_WP + NW, O_G = O_SC + 16;
+                         O_RED = O_S4 + NP, O_WP = O_RED + NWARP * 8, O_SC = O_WP + NWARP, O_G = O_SC + 16;
     static_assert(T1 % 2 == 0 && T2 % 2 == 0 && TG % 2 == 0, "segments must be even for 16-byte LDS reads");
     static_assert(CHT <= 16 && CHA <= 16 && CHG <= 16, "DPP butterflies stay inside a row of 16 lanes");
 };
@@ -126,7 +126,9 @@ struct F2Co {
 // per pair computes the rotation, then all threads apply S <- S J, V <- V J (column pass) and S <- J^T S (row pass).
 // Same rotation formulas and svec convention (lower triangle, column-major, sqrt(2) off-diagonals) as oracle/cone_oracle.c.
 // psd_jacobi: eigendecomposition only -- on return diag(Sm) holds the eigenvalues and the COLUMNS of Vm the eigenvectors.
+template <int NTH = 256>
 __device__ __forceinline__ void psd_jacobi(const double *zsvec, int k, double *Sm, double *Vm, double *cs, double *red) {
+    constexpr int NT = NTH, NW = NTH / 64;
     const int tid = threadIdx.x;
     const int K = (k + 1) & ~1;               // players of the tournament (a dummy if k is odd)
     // svec -> symmetric matrix
@@ -186,9 +188,11 @@ __device__ __forceinline__ void psd_jacobi(const double *zsvec, int k, double *S
         }
     }
 }
+template <int NTH = 256>
 __device__ __forceinline__ void psd_project(double *zsvec, int k, double *Sm, double *Vm, double *cs, double *red) {
+    constexpr int NT = NTH;
     const int tid = threadIdx.x;
-    psd_jacobi(zsvec, k, Sm, Vm, cs, red);
+    psd_jacobi<NTH>(zsvec, k, Sm, Vm, cs, red);
     // eigenvalues -> cs (clipped at 0), then svec of V diag(w+) V^T
     for (int i = tid; i < k; i += NT) cs[i] = fmax(Sm[i * k + i], 0.0);
     __syncthreads();
@@ -207,13 +211,14 @@ __device__ __forceinline__ void psd_project(double *zsvec, int k, double *Sm, do
 #ifndef F2_WPS
 #define F2_WPS 3
 #endif
-template <int CHT, int T1, int CHA, int T2, int CHG, int TG, bool PSD = false>
-__global__ void __launch_bounds__(NT, F2_WPS)
+template <int CHT, int T1, int CHA, int T2, int CHG, int TG, bool PSD = false, int NTH = 256>
+__global__ void __launch_bounds__(NTH, (NTH == 256 ? F2_WPS : 2))
 k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__restrict__ qv, long sqk, long sqb,
        const int *__restrict__ idx_at, const int *__restrict__ idx_ar, const int *__restrict__ idx_b,
        double *__restrict__ xo, double *__restrict__ yo, double *__restrict__ so, int *__restrict__ iters_o,
        int *__restrict__ status_o, double *__restrict__ resid_o) {
-    using L = F2<CHT, T1, CHA, T2, CHG, TG>;
+    constexpr int NT = NTH, NW = NTH / 64;        // threads / waves per workgroup of this instantiation (shadow the file-level defaults)
+    using L = F2<CHT, T1, CHA, T2, CHG, TG, NW>;
     using Co = F2Co<CHT, CHA, CHG>;
     constexpr int MP = L::MP, NP = L::NP, VP = L::VP, OY = L::OY, OX = L::OX, OT = L::OT;
     extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -629,7 +634,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
         }
         if constexpr (PSD) {   // PSD blocks of the cone input are projected in place (all threads, one cone after the other)
             double *psdS = Gm + n * ldg, *psdV = psdS + T.maxs * T.maxs, *psdC = psdV + T.maxs * T.maxs;
-            for (int c = 0; c < T.ns; c++) psd_project(sm + L::O_ZB + OY + T.soff[c], T.sord[c], psdS, psdV, psdC, red);
+            for (int c = 0; c < T.ns; c++) psd_project<NTH>(sm + L::O_ZB + OY + T.soff[c], T.sord[c], psdS, psdV, psdC, red);
         }
         if (!check && !last) {
             // P3 (fast path): project, relaxed update

@@ -125,12 +125,15 @@ static size_t bwd_rt_lds_bytes(const DevT &T, int TI, int TJ) {
 }
 
 // second-generation forward variants {CHT, T1, CHA, T2, CHG, TG}
-static const int F2_VARIANTS[3][6] = {{16, 2, 8, 2, 16, 2}, {8, 8, 4, 8, 8, 4}, {4, 26, 2, 26, 4, 14}};
+// {CHT, T1, CHA, T2, CHG, TG, threads per workgroup}
+constexpr int F2_NV = 4;
+static const int F2_VARIANTS[F2_NV][7] = {{16, 2, 8, 2, 16, 2, 256}, {8, 8, 4, 8, 8, 4, 256}, {4, 26, 2, 26, 4, 14, 256}, {4, 30, 4, 26, 4, 26, 512}};
 struct F2Dims { int MP, NPa, NPg, NP, VP, O_G; };
 static F2Dims f2_dims(int v) {
     const int *V = F2_VARIANTS[v];
     F2Dims d; d.MP = V[0] * V[1]; d.NPa = V[2] * V[3]; d.NPg = V[4] * V[5]; d.NP = std::max(d.NPa, d.NPg); d.VP = d.MP + d.NP + 2;
-    d.O_G = 6 * d.VP + 2 * d.MP + 8 * d.NP + NW * 8 + NW + 16;
+    const int nw = V[6] / 64;
+    d.O_G = 6 * d.VP + 2 * d.MP + 8 * d.NP + nw * 8 + nw + 16;
     return d;
 }
 // leading dimension of G in LDS: smallest even ld >= NPg for which the 16 lanes of an LDS group (CHG segments x 16/CHG rows)
@@ -151,8 +154,9 @@ static int f2_pick_ldg(int v) {
 static bool f2_fits(const DevT &T, int v, int *ldg, size_t *bytes) {
     const int *V = F2_VARIANTS[v];
     const F2Dims d = f2_dims(v);
-    if ((T.n + 2) * V[0] > NT || T.m * V[2] > NT || T.n * V[4] > NT) return false;   // two extra column groups carry phi
-    if (T.m > d.MP || T.n > d.NPa || T.n > d.NPg || T.n + T.m + 1 > NT) return false;
+    const int NTH = V[6];
+    if ((T.n + 2) * V[0] > NTH || T.m * V[2] > NTH || T.n * V[4] > NTH) return false;   // two extra column groups carry phi
+    if (T.m > d.MP || T.n > d.NPa || T.n > d.NPg || T.n + T.m + 1 > NTH) return false;
     if (T.maxq > SOC_SMALL && T.nq > d.NP) return false;
     *ldg = f2_pick_ldg(v);
     if ((size_t)T.n * *ldg < (size_t)d.NPa) return false;
@@ -223,18 +227,19 @@ int ce_create(const ce_template *tpl, int device, ce_handle *out) {
     }
     const char *fwd_env = getenv("CE_FWD");      // "v2" (default when it fits), "rt", "generic": A/B switch for benchmarking
     if (!getenv("CE_FORCE_GENERIC") && !(fwd_env && (!strcmp(fwd_env, "rt") || !strcmp(fwd_env, "generic")))) {
-        for (int v = 0; v < 3; v++) {
+        for (int v = 0; v < F2_NV; v++) {
             int ldg; size_t by;
             if (!f2_fits(T, v, &ldg, &by)) continue;
+            if (T.ns > 0 && F2_VARIANTS[v][6] != 256) continue;     // PSD kernels are instantiated for the 256-thread variants only
             const int *V = F2_VARIANTS[v];
-            const int CHT = V[0], T1 = V[1], CHA = V[2], T2 = V[3];
-            std::vector<int> pos((size_t)T.m * T.n, -1), ib(T.m, -1), iat((size_t)T1 * NT, -1), iar((size_t)T2 * NT, -1);
+            const int CHT = V[0], T1 = V[1], CHA = V[2], T2 = V[3], NTH = V[6];
+            std::vector<int> pos((size_t)T.m * T.n, -1), ib(T.m, -1), iat((size_t)T1 * NTH, -1), iar((size_t)T2 * NTH, -1);
             for (int j = 0; j <= T.n; j++)
                 for (int k = tpl->indptr[j]; k < tpl->indptr[j + 1]; k++) { if (j < T.n) pos[(size_t)tpl->indices[k] * T.n + j] = k; else ib[tpl->indices[k]] = k; }
-            for (int t = 0; t < NT; t++) {
+            for (int t = 0; t < NTH; t++) {
                 const int j1 = t / CHT, c1 = t % CHT, i2 = t / CHA, c2 = t % CHA;
-                for (int k = 0; k < T1; k++) { const int r = T1 * c1 + k; if (j1 < T.n && r < T.m) iat[(size_t)k * NT + t] = pos[(size_t)r * T.n + j1]; }
-                for (int k = 0; k < T2; k++) { const int c = T2 * c2 + k; if (i2 < T.m && c < T.n) iar[(size_t)k * NT + t] = pos[(size_t)i2 * T.n + c]; }
+                for (int k = 0; k < T1; k++) { const int r = T1 * c1 + k; if (j1 < T.n && r < T.m) iat[(size_t)k * NTH + t] = pos[(size_t)r * T.n + j1]; }
+                for (int k = 0; k < T2; k++) { const int c = T2 * c2 + k; if (i2 < T.m && c < T.n) iar[(size_t)k * NTH + t] = pos[(size_t)i2 * T.n + c]; }
             }
             HIPCHK(hipMalloc(&h->d_idx_at, sizeof(int) * iat.size())); HIPCHK(hipMalloc(&h->d_idx_ar, sizeof(int) * iar.size())); HIPCHK(hipMalloc(&h->d_idx_b, sizeof(int) * T.m));
             HIPCHK(hipMemcpy(h->d_idx_at, iat.data(), sizeof(int) * iat.size(), hipMemcpyHostToDevice));
@@ -269,6 +274,7 @@ int ce_create(const ce_template *tpl, int device, ce_handle *out) {
     SETATTR((k_forward<true, true>), LDS_LIMIT);  SETATTR((k_forward<true, false>), LDS_LIMIT);  SETATTR((k_forward<false, false>), LDS_LIMIT);
     SETATTR((k_forward_rt<8, 13, 7, 4, 13, 160, 4>), LDS_LIMIT); SETATTR((k_forward_rt<8, 16, 8, 4, 16, 208, 4>), LDS_LIMIT); SETATTR((k_forward_rt<4, 32, 32, 4, 32, 272, 2>), LDS_LIMIT);
     SETATTR((k_fwd2<16, 2, 8, 2, 16, 2, true>), LDS_LIMIT); SETATTR((k_fwd2<8, 8, 4, 8, 8, 4, true>), LDS_LIMIT); SETATTR((k_fwd2<4, 26, 2, 26, 4, 14, true>), LDS_LIMIT);
+    SETATTR((k_fwd2<4, 30, 4, 26, 4, 26, false, 512>), LDS_LIMIT);
     SETATTR((k_fwd2<16, 2, 8, 2, 16, 2>), LDS_LIMIT); SETATTR((k_fwd2<8, 8, 4, 8, 8, 4>), LDS_LIMIT); SETATTR((k_fwd2<4, 26, 2, 26, 4, 14>), LDS_LIMIT);
     SETATTR((k_backward_rt<4, 4, 4, true>), LDS_LIMIT); SETATTR((k_backward_rt<7, 7, 4, true>), LDS_LIMIT); SETATTR((k_backward_rt<7, 7, 7, true>), LDS_LIMIT);
     SETATTR((k_backward_rt<4, 4, 4>), LDS_LIMIT); SETATTR((k_backward_rt<7, 7, 4>), LDS_LIMIT); SETATTR((k_backward_rt<7, 7, 7>), LDS_LIMIT);
@@ -346,11 +352,11 @@ int ce_solve(ce_handle h, int B, const double *A_vals, long sA_k, long sA_b, con
         DevT Trt = T; Trt.lda = h->rt_lda;
 #define LAUNCH_RT(...) hipLaunchKernelGGL((k_forward_rt<__VA_ARGS__>), grid, dim3(NT2), h->fwd_lds, st, Trt, S, Abm, q_vals, sq_k, sq_b, x, y, s, iters, status, resid)
         DevT Tf2 = T; Tf2.ldg = h->f2_ldg;
-#define LAUNCH_F2(...) hipLaunchKernelGGL((k_fwd2<__VA_ARGS__>), grid, dim3(NT), h->fwd_lds, st, Tf2, S, Abm, q_vals, sq_k, sq_b, h->d_idx_at, h->d_idx_ar, h->d_idx_b, x, y, s, iters, status, resid)
+#define LAUNCH_F2(...) hipLaunchKernelGGL((k_fwd2<__VA_ARGS__>), grid, dim3(F2_VARIANTS[h->f2_variant][6]), h->fwd_lds, st, Tf2, S, Abm, q_vals, sq_k, sq_b, h->d_idx_at, h->d_idx_ar, h->d_idx_b, x, y, s, iters, status, resid)
         if (h->fwd_mode == 4 && T.ns > 0) {
             if (h->f2_variant == 0) LAUNCH_F2(16, 2, 8, 2, 16, 2, true); else if (h->f2_variant == 1) LAUNCH_F2(8, 8, 4, 8, 8, 4, true); else LAUNCH_F2(4, 26, 2, 26, 4, 14, true);
         } else if (h->fwd_mode == 4) {
-            if (h->f2_variant == 0) LAUNCH_F2(16, 2, 8, 2, 16, 2); else if (h->f2_variant == 1) LAUNCH_F2(8, 8, 4, 8, 8, 4); else LAUNCH_F2(4, 26, 2, 26, 4, 14);
+            if (h->f2_variant == 0) LAUNCH_F2(16, 2, 8, 2, 16, 2); else if (h->f2_variant == 1) LAUNCH_F2(8, 8, 4, 8, 8, 4); else if (h->f2_variant == 2) LAUNCH_F2(4, 26, 2, 26, 4, 14); else LAUNCH_F2(4, 30, 4, 26, 4, 26, false, 512);
         } else if (h->fwd_mode == 3) {
             if (h->rt_variant == 0) LAUNCH_RT(8, 13, 7, 4, 13, 160, 4); else if (h->rt_variant == 1) LAUNCH_RT(8, 16, 8, 4, 16, 208, 4); else LAUNCH_RT(4, 32, 32, 4, 32, 272, 2);
         } else if (h->fwd_mode == 0) LAUNCH_F(true, true); else if (h->fwd_mode == 1) LAUNCH_F(true, false); else LAUNCH_F(false, false);
