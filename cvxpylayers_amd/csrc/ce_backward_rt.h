@@ -14,7 +14,8 @@
 //     blocking (rows {ra+16i} x columns {cb+16j}: TI + TJ LDS reads feed TI*TJ FMAs per cone row).
 #pragma once
 
-constexpr int BG = 16;   // thread grid is BG x BG
+constexpr int BG = 16;   // default thread grid is BG x BG
+constexpr int BGC = 16;  // column residues (always one DPP row wide)
 
 #ifdef CE_TIMING   // debug build: phase durations (shader cycles) of every workgroup overwrite the first entries of its dA row
 #define CE_STAMP(i) do { __syncthreads(); if (threadIdx.x == 0) tstamp[i] = __builtin_readcyclecounter(); } while (0)
@@ -22,14 +23,14 @@ constexpr int BG = 16;   // thread grid is BG x BG
 #define CE_STAMP(i) do { } while (0)
 #endif
 
-__host__ __device__ inline int bwd_rt_union_doubles(int n, int m, int nqs, int TI, int TJ) {
-    int a = 2 * nqs * n, b = 2 * BG * TI + 2 * BG * TJ, c = (NT > m ? NT : m) + m;
+__host__ __device__ inline int bwd_rt_union_doubles(int n, int m, int nqs, int TI, int TJ, int BGR = 16) {
+    int a = 2 * nqs * n, b = 2 * BGR * TI + 2 * BGC * TJ, c = (NT > m ? NT : m) + m;
     int r = a > b ? a : b;
     return r > c ? r : c;
 }
 
-template <int TI, int TJ, int TH, bool PSD = false>
-__global__ void __launch_bounds__(NT, 3)
+template <int TI, int TJ, int TH, bool PSD = false, int BGR = 16>
+__global__ void __launch_bounds__(BGR * 16, (BGR == 16 ? 3 : 2))
 k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict__ xg, const double *__restrict__ yg,
               const double *__restrict__ sg, const double *__restrict__ dxg, const double *__restrict__ dyg,
               double *__restrict__ dAo, double *__restrict__ dqo, long sdqk, long sdqb, int *__restrict__ adj_status) {
@@ -37,8 +38,9 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
     const int tid = threadIdx.x, inst = blockIdx.x;
     const int n = T.n, m = T.m, lda = T.lda, nq = T.nq, z = T.z;
     const int nqs = nq > 0 ? nq : 1;
-    const int ra = tid & (BG - 1), cb = tid >> 4;
-    constexpr int NKCAP = BG * TJ - 1;          // column NK (the right-hand side) must exist: NK <= 16*TJ - 1, rows NK <= 16*TI
+    constexpr int NTB = BGR * BGC, NWB = NTB / 64;      // threads / waves of this instantiation
+    const int ra = tid & (BGR - 1), cb = tid / BGR;
+    constexpr int NKCAP = BGC * TJ - 1;          // column NK (the right-hand side) must exist: NK <= 16*TJ - 1, rows NK <= 16*TI
 
     // ---- LDS carve.  U is a union region: {a_y, a_s} during assembly, {colbuf, rowbuf} during elimination, {part, A r_x} after.
     double *p = sm;
@@ -49,23 +51,23 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
     double *rx = p; p += n;
     double *fvec = p; p += n;        // sum over boundary cones of [ a_s (e_s.d) + A_c^T P d / (1 - lam) ]
     double *cinfo = p; p += 6 * nqs; // per cone: lambda, nz, e_y.d, e_s.d
-    double *pivrow = p; p += BG * TI;   // pivot value of the row that served as pivot
+    double *pivrow = p; p += BGR * TI;   // pivot value of the row that served as pivot
     double *pinfo = p; p += 2;          // pivot value per buffer
-    double *red = p; p += NW * 8;
+    double *red = p; p += NWB * 8;
     double *psdU = p, *psdEv = p, *lamr = p, *psdScr = p;     // PSD: eigenvectors per cone, eigenvalues, DPi eigenvalue per rotated row, scratch
     if constexpr (PSD) { psdU = p; p += T.ns * T.maxs * T.maxs; psdEv = p; p += T.ns * T.maxs; lamr = p; p += m; psdScr = p; p += 8 * T.maxs * T.maxs + 2 * T.maxs + 8; }
-    double *U = p; p += bwd_rt_union_doubles(n, m, nqs, TI, TJ);
+    double *U = p; p += bwd_rt_union_doubles(n, m, nqs, TI, TJ, BGR);
     double *ay = U, *as = U + nqs * n;                              // A_c^T e_y, A_c^T e_s
-    double *colbuf = U, *rowbuf = U + 2 * BG * TI;
+    double *colbuf = U, *rowbuf = U + 2 * BGR * TI;
     double *part = U, *qv2 = U + max(NT, m);                        // A r_x
     int *ip = (int *)p;
     int *rkind = ip; ip += m;
     int *eqrow = ip; ip += m;
     int *ckind = ip; ip += nqs;
     int *ceq = ip; ip += nqs;
-    int *esrc = ip; ip += BG * TJ;      // equality e -> source: row index (>= 0) or -1 - cone
-    int *colof = ip; ip += BG * TI;     // pivot row r -> column it eliminated
-    int *wcnt = ip; ip += NW + 1;
+    int *esrc = ip; ip += BGC * TJ;      // equality e -> source: row index (>= 0) or -1 - cone
+    int *colof = ip; ip += BGR * TI;     // pivot row r -> column it eliminated
+    int *wcnt = ip; ip += NWB + 1;
     int *misc = ip; ip += 8;            // [0] n_eq, [2] flags, [4],[5] pivot row per buffer
 
 #ifdef CE_TIMING
@@ -73,13 +75,13 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
 #endif
     CE_STAMP(0);
     load_instance(T, Avals + (size_t)inst * T.nnz_aug, A, bv);
-    for (int i = tid; i < m; i += NT) vv[i] = yg[(size_t)inst * m + i] - sg[(size_t)inst * m + i];
+    for (int i = tid; i < m; i += NTB) vv[i] = yg[(size_t)inst * m + i] - sg[(size_t)inst * m + i];
     if (tid < 8) misc[tid] = 0;
     __syncthreads();
     CE_STAMP(1);
     // ---- classify
-    for (int i = tid; i < z + T.l; i += NT) rkind[i] = (i < z || vv[i] > 0) ? RK_EQ : RK_FREE;
-    for (int c = tid; c < nq; c += NT) {
+    for (int i = tid; i < z + T.l; i += NTB) rkind[i] = (i < z || vv[i] > 0) ? RK_EQ : RK_FREE;
+    for (int c = tid; c < nq; c += NTB) {
         const int r0 = T.qoff[c], r1 = T.qoff[c + 1], d = r1 - r0;
         int kind; double lam = 0, nz = 0;
         if (d == 1) kind = vv[r0] >= 0 ? 0 : 1;
@@ -102,11 +104,11 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
         for (int c = 0; c < T.ns; c++) {
             const int k = T.sord[c], r0 = T.soff[c], d = k * (k + 1) / 2;
             double *Um = psdU + c * T.maxs * T.maxs, *ev = psdEv + c * T.maxs;
-            psd_jacobi<NT>(vv + r0, k, psdScr, Um, psdScr + 2 * T.maxs * T.maxs, red);     // eigenvalues on diag(psdScr), vectors in Um
-            for (int i = tid; i < k; i += NT) ev[i] = psdScr[i * k + i];
+            psd_jacobi<NTB>(vv + r0, k, psdScr, Um, psdScr + 2 * T.maxs * T.maxs, red);     // eigenvalues on diag(psdScr), vectors in Um
+            for (int i = tid; i < k; i += NTB) ev[i] = psdScr[i * k + i];
             __syncthreads();
             // rotate the n columns of A_c and (as column n) the incoming dy_c; one column per wave at a time
-            for (int g0 = 0; g0 <= n; g0 += NW) {
+            for (int g0 = 0; g0 <= n; g0 += NWB) {
                 const int col = g0 + wid;
                 double *X = psdScr + wid * 2 * T.maxs * T.maxs, *W = X + T.maxs * T.maxs;
                 if (col <= n) {
@@ -148,7 +150,7 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
     // ---- equality numbering: ballot prefix sums (rows in order, then one e_y row per boundary cone)
     {
         int base = 0;
-        for (int i0 = 0; i0 < m; i0 += NT) {
+        for (int i0 = 0; i0 < m; i0 += NTB) {
             const int i = i0 + tid;
             const bool f = (i < m) && (rkind[i] == RK_EQ);
             const unsigned long long bal = __ballot(f);
@@ -158,34 +160,34 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
             int off = base;
             for (int w = 0; w < wid; w++) off += wcnt[w];
             int tot = 0;
-            for (int w = 0; w < NW; w++) tot += wcnt[w];
+            for (int w = 0; w < NWB; w++) tot += wcnt[w];
             if (i < m) {
                 const int e = f ? off + __popcll(bal & ((1ull << lane) - 1ull)) : -1;
                 eqrow[i] = e;
-                if (f && e < BG * TJ) esrc[e] = i;
+                if (f && e < BGC * TJ) esrc[e] = i;
             }
             base += tot;
             __syncthreads();
         }
         if (tid == 0) {
             int ne = base;
-            for (int c = 0; c < nq; c++) { if (ckind[c] == 2) { if (ne < BG * TJ) esrc[ne] = -1 - c; ceq[c] = ne++; } else ceq[c] = -1; }
+            for (int c = 0; c < nq; c++) { if (ckind[c] == 2) { if (ne < BGC * TJ) esrc[ne] = -1 - c; ceq[c] = ne++; } else ceq[c] = -1; }
             misc[0] = ne;
         }
         __syncthreads();
     }
     const int neq = misc[0];
     const int NK = n + neq;
-    if (NK > NKCAP || NK > BG * TI) {   // more active rows than the register tile holds: degenerate instance (flagged, zero gradient)
-        for (int k = tid; k < T.nnz_aug; k += NT) dAo[(size_t)inst * T.nnz_aug + k] = 0.0;
-        for (int j = tid; j <= n; j += NT) dqo[j * sdqk + inst * sdqb] = 0.0;
+    if (NK > NKCAP || NK > BGR * TI) {   // more active rows than the register tile holds: degenerate instance (flagged, zero gradient)
+        for (int k = tid; k < T.nnz_aug; k += NTB) dAo[(size_t)inst * T.nnz_aug + k] = 0.0;
+        for (int j = tid; j <= n; j += NTB) dqo[j * sdqk + inst * sdqb] = 0.0;
         if (tid == 0 && adj_status) adj_status[inst] = 2;
         return;
     }
     CE_STAMP(2);
     // ---- d = DPi(v) dy, per-cone scalars
-    for (int i = tid; i < z + T.l; i += NT) dv[i] = rkind[i] == RK_EQ ? dyg[(size_t)inst * m + i] : 0.0;
-    for (int c = tid; c < nq; c += NT) {
+    for (int i = tid; i < z + T.l; i += NTB) dv[i] = rkind[i] == RK_EQ ? dyg[(size_t)inst * m + i] : 0.0;
+    for (int c = tid; c < nq; c += NTB) {
         const int r0 = T.qoff[c], r1 = T.qoff[c + 1];
         const double *h = dyg + (size_t)inst * m;
         if (ckind[c] == 0) { for (int i = r0; i < r1; i++) dv[i] = h[i]; }
@@ -203,7 +205,7 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
     }
     __syncthreads();
     // ---- a_y, a_s for boundary cones
-    for (int idx = tid; idx < nq * n; idx += NT) {
+    for (int idx = tid; idx < nq * n; idx += NTB) {
         const int c = idx / n, j = idx - c * n;
         if (ckind[c] != 2) continue;
         const int r0 = T.qoff[c], r1 = T.qoff[c + 1];
@@ -217,7 +219,7 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
     __syncthreads();
     // ---- fvec[j] = sum_c [ a_s (e_s.d) + (A_c^T d - a_y (e_y.d) - a_s (e_s.d)) / (1 - lam) ]
     //      4 lanes per column, each takes every 4th cone; fixed summation order (deterministic)
-    for (int j0 = 0; j0 < n; j0 += NT / 4) {
+    for (int j0 = 0; j0 < n; j0 += NTB / 4) {
         const int j = j0 + (tid >> 2), part = tid & 3;
         double acc = 0;
         if (j < n) {
@@ -256,9 +258,9 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
             const double *row = A + ii * lda;
             double ar[TH], ac[TH];
 #pragma unroll
-            for (int i = 0; i < TH; i++) ar[i] = (ra + BG * i < n) ? th * row[ra + BG * i] : 0.0;
+            for (int i = 0; i < TH; i++) ar[i] = (ra + BGR * i < n) ? th * row[ra + BGR * i] : 0.0;
 #pragma unroll
-            for (int j = 0; j < TH; j++) ac[j] = (cb + BG * j < n) ? row[cb + BG * j] : 0.0;
+            for (int j = 0; j < TH; j++) ac[j] = (cb + BGC * j < n) ? row[cb + BGC * j] : 0.0;
 #pragma unroll
             for (int i = 0; i < TH; i++)
 #pragma unroll
@@ -269,7 +271,7 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
         for (int i = 0; i < TH; i++)
 #pragma unroll
             for (int j = 0; j < TH; j++) {
-                const int r = ra + BG * i, cc = cb + BG * j;
+                const int r = ra + BGR * i, cc = cb + BGC * j;
                 if (r < n && cc < n) kt[i][j] = fma(-th, ayc[r] * ayc[cc] + asc[r] * asc[cc], kt[i][j]);
             }
     }
@@ -280,15 +282,16 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
             const double *row = A + t * lda;
             double ar[TH], ac[TH];
 #pragma unroll
-            for (int i = 0; i < TH; i++) ar[i] = (ra + BG * i < n) ? th * row[ra + BG * i] : 0.0;
+            for (int i = 0; i < TH; i++) ar[i] = (ra + BGR * i < n) ? th * row[ra + BGR * i] : 0.0;
 #pragma unroll
-            for (int j = 0; j < TH; j++) ac[j] = (cb + BG * j < n) ? row[cb + BG * j] : 0.0;
+            for (int j = 0; j < TH; j++) ac[j] = (cb + BGC * j < n) ? row[cb + BGC * j] : 0.0;
 #pragma unroll
             for (int i = 0; i < TH; i++)
 #pragma unroll
                 for (int j = 0; j < TH; j++) kt[i][j] = fma(ar[i], ac[j], kt[i][j]);
         }
     }
+    CE_STAMP(8);
     // B / -B^T blocks and the right-hand side.  The source of equality e (a row of A or a_y of a boundary cone) is resolved
     // once per tile row / column into an LDS base pointer, so each entry costs one independent LDS read.
     {
@@ -296,7 +299,7 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
         double rhs_eq[TI];
 #pragma unroll
         for (int i = 0; i < TI; i++) {
-            const int r = ra + BG * i;
+            const int r = ra + BGR * i;
             prow_src[i] = A; rhs_eq[i] = 0.0;
             if (r >= n && r < NK) {
                 const int src = esrc[r - n];
@@ -306,7 +309,7 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
         }
 #pragma unroll
         for (int j = 0; j < TJ; j++) {
-            const int cc = cb + BG * j;
+            const int cc = cb + BGC * j;
             pcol_src[j] = A;
             if (cc >= n && cc < NK) { const int src = esrc[cc - n]; pcol_src[j] = src >= 0 ? A + src * lda : ay + (-1 - src) * n; }
         }
@@ -314,7 +317,7 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
         for (int i = 0; i < TI; i++)
 #pragma unroll
             for (int j = 0; j < TJ; j++) {
-                const int r = ra + BG * i, cc = cb + BG * j;
+                const int r = ra + BGR * i, cc = cb + BGC * j;
                 if (r >= NK || cc > NK) continue;
                 if (cc == NK) kt[i][j] = (r < n) ? dxg[(size_t)inst * n + r] + fvec[r] : rhs_eq[i];
                 else if (r < n && cc >= n) kt[i][j] = -pcol_src[j][r];
@@ -329,12 +332,12 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
 #pragma unroll
         for (int i = 0; i < TI; i++)
 #pragma unroll
-            for (int j = 0; j < TJ; j++) if (cb + BG * j < NK) r[0] = fmax(r[0], fabs(kt[i][j]));
-        block_reduce<1>(r, 1u, red);
+            for (int j = 0; j < TJ; j++) if (cb + BGC * j < NK) r[0] = fmax(r[0], fabs(kt[i][j]));
+        block_reduce_n<1, NWB>(r, 1u, red);
         ptol = 1e-13 * (r[0] > 0 ? r[0] : 1.0);
     }
     __syncthreads();                 // a_y / a_s are dead: the union region becomes colbuf / rowbuf
-    for (int i = tid; i < 2 * BG * TI; i += NT) colbuf[i] = 0.0;
+    for (int i = tid; i < 2 * BGR * TI; i += NTB) colbuf[i] = 0.0;
     __syncthreads();
     // ---- Gauss-Jordan with partial pivoting on the register tiles.  One workgroup barrier per pivot:
     //   (1) the 16 lanes owning column k (one DPP row) find the pivot with a DPP butterfly and publish the column
@@ -343,22 +346,22 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
     //       the entries K[prow][cb + 16 j] its row-mates need), so no second LDS round trip / barrier is required
     //   (3) rank-1 update of the live part of the tile (row slots >= ceil(NK/16) and column slots < jk are skipped)
     unsigned rowdone = 0;     // bit i: row ra + 16 i has served as pivot
-    const int ilim = (NK + BG - 1) / BG;          // row slots in use
-    const int lane_base = ((tid & 63) & ~(BG - 1)) << 2;      // byte address of lane 0 of this DPP row for ds_bpermute
+    const int ilim = (NK + BGR - 1) / BGR;          // row slots in use
+    const int lane_base = ((tid & 63) & ~(BGR - 1)) << 2;     // byte address of the first lane of this thread's row group for ds_bpermute
 #pragma unroll
     for (int jk = 0; jk < TJ; jk++) {
-        for (int ck = 0; ck < BG; ck++) {
-            const int k = BG * jk + ck;
+        for (int ck = 0; ck < BGC; ck++) {
+            const int k = BGC * jk + ck;
             if (k >= NK) break;
             const int buf = k & 1;
-            double *cbuf = colbuf + buf * BG * TI;
+            double *cbuf = colbuf + buf * BGR * TI;
             if (cb == ck) {   // the 16 lanes owning column k: pivot search + publish the column
                 // arg max |K[r][k]| over the rows not yet used, as ONE v_max_f64 per candidate: positive doubles order like their
                 // bit patterns, so the row index rides in the 8 lowest mantissa bits (255 - r: ties go to the smallest row)
                 double best = 0.0;       // key 0: no candidate
 #pragma unroll
                 for (int i = 0; i < TI; i++) {
-                    const int r = ra + BG * i;
+                    const int r = ra + BGR * i;
                     const double v = fabs(kt[i][jk]);
                     const int lo = (__double2loint(v) & ~0xFF) | (255 - r);
                     const double key = __hiloint2double(__double2hiint(v), lo);
@@ -368,10 +371,11 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
                 best = fmax(best, dpp_mov<0x4E>(best));     // quad_perm [2,3,0,1]
                 best = fmax(best, dpp_mov<0x141>(best));    // row_half_mirror
                 best = fmax(best, dpp_mov<0x140>(best));    // row_mirror
+                if constexpr (BGR == 32) best = fmax(best, __shfl_xor(best, 16));      // the column's owners span two DPP rows
                 const int bi = 255 - (__double2loint(best) & 0xFF);
 #pragma unroll
                 for (int i = 0; i < TI; i++) {
-                    const int r = ra + BG * i;
+                    const int r = ra + BGR * i;
                     const double v = kt[i][jk];
                     if (r == bi) { pinfo[buf] = v; cbuf[r] = 0.0; } else cbuf[r] = v;
                 }
@@ -379,19 +383,19 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
             }
             __syncthreads();
             const int prow = __builtin_amdgcn_readfirstlane(misc[4 + buf]);
-            const int ipv = prow >> 4;
+            const int ipv = prow / BGR;
             double piv = pinfo[buf];
             if (fabs(piv) < ptol) piv = (piv < 0 ? -ptol : ptol);
             double pinv = __builtin_amdgcn_rcp(piv);           // hardware seed + two Newton steps (the IEEE divide expansion is
             pinv = fma(fma(-piv, pinv, 1.0), pinv, pinv);      // three times as long and sits on the critical path of every pivot)
             pinv = fma(fma(-piv, pinv, 1.0), pinv, pinv);
-            if (ra == (prow & (BG - 1))) {
+            if (ra == (prow & (BGR - 1))) {
                 rowdone |= 1u << ipv;
                 if (cb == 0) { colof[prow] = k; pivrow[prow] = piv; }
             }
             // pivot row: broadcast inside each 16-lane row
             double rw[TJ];
-            const int src = lane_base + ((prow & (BG - 1)) << 2);
+            const int src = lane_base + ((prow & (BGR - 1)) << 2);
 #pragma unroll
             for (int i = 0; i < TI; i++) {
                 if (ipv == i) {      // uniform
@@ -407,7 +411,7 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
 #pragma unroll
             for (int i = 0; i < TI; i++) {
                 if (i >= ilim) continue;     // uniform: pad row slots
-                const double f = cbuf[ra + BG * i] * pinv;      // the pivot row's own entry was published as 0
+                const double f = cbuf[ra + BGR * i] * pinv;      // the pivot row's own entry was published as 0
 #pragma unroll
                 for (int j = jk; j < TJ; j++) kt[i][j] = fma(-f, rw[j], kt[i][j]);
             }
@@ -418,10 +422,10 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
     // ---- solution: sol[colof[r]] = rhs[r] / pivot(r);  r_x -> rx, multipliers -> bv
 #pragma unroll
     for (int j = 0; j < TJ; j++) {
-        if (cb + BG * j != NK) continue;
+        if (cb + BGC * j != NK) continue;
 #pragma unroll
         for (int i = 0; i < TI; i++) {
-            const int r = ra + BG * i;
+            const int r = ra + BGR * i;
             if (r < NK) {
                 const int k = colof[r];
                 const double sol = kt[i][j] / pivrow[r];
@@ -433,10 +437,10 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
     // ---- q = A r_x ; r_y
     mv_rows_partial(A, lda, m, n, rx, part);
     __syncthreads();
-    for (int i = tid; i < m; i += NT) qv2[i] = sum_parts(part, m, i);
+    for (int i = tid; i < m; i += NTB) qv2[i] = sum_parts(part, m, i);
     __syncthreads();
-    for (int i = tid; i < z + T.l; i += NT) vv[i] = (eqrow[i] >= 0) ? bv[eqrow[i]] : dv[i];
-    for (int c = tid; c < nq; c += NT) {
+    for (int i = tid; i < z + T.l; i += NTB) vv[i] = (eqrow[i] >= 0) ? bv[eqrow[i]] : dv[i];
+    for (int c = tid; c < nq; c += NTB) {
         const int r0 = T.qoff[c], r1 = T.qoff[c + 1];
         if (ckind[c] == 0) { for (int i = r0; i < r1; i++) vv[i] = bv[eqrow[i]]; }
         else if (ckind[c] == 1) { for (int i = r0; i < r1; i++) vv[i] = dv[i]; }
@@ -456,7 +460,7 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
     }
     __syncthreads();
     if constexpr (PSD) {   // r~ in the rotated basis, then r_y,c = Q r~ = svec(U smat(r~) U^T)
-        for (int t = T.soff[0] + tid; t < T.soff[T.ns]; t += NT) {
+        for (int t = T.soff[0] + tid; t < T.soff[T.ns]; t += NTB) {
             const int rk = rkind[t];
             vv[t] = (rk == RK_EQ) ? bv[eqrow[t]] : (rk == RK_FREE ? dv[t] : (dv[t] - lamr[t] * qv2[t]) / (1 - lamr[t]));
         }
@@ -465,19 +469,19 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
             const int k = T.sord[c], r0 = T.soff[c], d = k * (k + 1) / 2;
             const double *Um = psdU + c * T.maxs * T.maxs;
             double *X = psdScr, *W = X + T.maxs * T.maxs;
-            for (int idx = tid; idx < k * k; idx += NT) {
+            for (int idx = tid; idx < k * k; idx += NTB) {
                 const int i = idx / k, j = idx - i * k, a = i >= j ? i : j, b = i >= j ? j : i;
                 const double v = vv[r0 + b * k - (b * (b - 1)) / 2 + (a - b)];
                 X[idx] = (a == b) ? v : v * M_SQRT1_2;
             }
             __syncthreads();
-            for (int idx = tid; idx < k * k; idx += NT) {           // W = U X
+            for (int idx = tid; idx < k * k; idx += NTB) {           // W = U X
                 const int i = idx / k, j = idx - i * k;
                 double acc = 0; for (int a = 0; a < k; a++) acc = fma(Um[i * k + a], X[a * k + j], acc);
                 W[idx] = acc;
             }
             __syncthreads();
-            for (int pos = tid; pos < d; pos += NT) {               // T = W U^T
+            for (int pos = tid; pos < d; pos += NTB) {               // T = W U^T
                 int b = 0, rem = pos; while (rem >= k - b) { rem -= k - b; b++; }
                 const int a = b + rem;
                 double acc = 0; for (int e = 0; e < k; e++) acc = fma(W[a * k + e], Um[b * k + e], acc);
@@ -489,16 +493,17 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
     CE_STAMP(6);
     // ---- outputs in the boundary convention: dA_eval = [-dA.data, db[b_idx]], dq_eval = [dc, 0]   (diffcp_if.py:91-92)
 #pragma unroll 4
-    for (int k = tid; k < T.nnz_aug; k += NT) {
+    for (int k = tid; k < T.nnz_aug; k += NTB) {
         const int i = T.rowidx[k], j = T.colidx[k];
         const double val = (j < n) ? -(xg[(size_t)inst * n + j] * vv[i] - yg[(size_t)inst * m + i] * rx[j]) : -vv[i];   // x, y: L1-resident gathers
         dAo[(size_t)inst * T.nnz_aug + k] = val;
     }
-    for (int j = tid; j <= n; j += NT) dqo[j * sdqk + inst * sdqb] = (j < n) ? -rx[j] : 0.0;
+    for (int j = tid; j <= n; j += NTB) dqo[j * sdqk + inst * sdqb] = (j < n) ? -rx[j] : 0.0;
     if (tid == 0 && adj_status) adj_status[inst] = misc[2];
 #ifdef CE_TIMING
     CE_STAMP(7);
     if (tid < 7) dAo[(size_t)inst * T.nnz_aug + tid] = (double)(tstamp[tid + 1] - tstamp[tid]);
+    if (tid == 8) dAo[(size_t)inst * T.nnz_aug + 8] = (double)(tstamp[8] - tstamp[3]);
     if (tid == 7) dAo[(size_t)inst * T.nnz_aug + 7] = (double)NK;
 #endif
 }

@@ -115,12 +115,14 @@ static size_t bwd_lds_bytes(const DevT &T, bool a_lds, bool k_lds, int nkcap, in
 #define BRT_HAS_PSD 1
 #endif
 // register-tiled backward variants {TI, TJ, TH}: K tile 16*TI x 16*TJ per workgroup, H tile 16*TH
-static const int BRT_VARIANTS[3][3] = {{4, 4, 4}, {7, 7, 4}, {7, 7, 7}};
-static size_t bwd_rt_lds_bytes(const DevT &T, int TI, int TJ) {
+// {TI, TJ, TH, row residues BGR}: K tile BGR*TI x 16*TJ per workgroup of BGR*16 threads
+constexpr int BRT_NV = 4;
+static const int BRT_VARIANTS[BRT_NV][4] = {{4, 4, 4, 16}, {7, 7, 4, 16}, {7, 7, 7, 16}, {7, 13, 7, 32}};
+static size_t bwd_rt_lds_bytes(const DevT &T, int TI, int TJ, int BGR) {
     const int n = T.n, m = T.m, nqs = std::max(T.nq, 1);
-    size_t d = (size_t)m * n /* lda = n */ + 3 * (size_t)m + 2 * (size_t)n + 6 * nqs + BG * TI + 2 + NW * 8 + bwd_rt_union_doubles(n, m, nqs, TI, TJ);
+    size_t d = (size_t)m * n /* lda = n */ + 3 * (size_t)m + 2 * (size_t)n + 6 * nqs + BGR * TI + 2 + (BGR * 16 / 64) * 8 + bwd_rt_union_doubles(n, m, nqs, TI, TJ, BGR);
     if (T.ns > 0) d += (size_t)T.ns * T.maxs * T.maxs + (size_t)T.ns * T.maxs + m + 8 * (size_t)T.maxs * T.maxs + 2 * T.maxs + 8;
-    size_t ints = 2 * (size_t)m + 2 * nqs + BG * TJ + BG * TI + NW + 1 + 8;
+    size_t ints = 2 * (size_t)m + 2 * nqs + BGC * TJ + BGR * TI + (BGR * 16 / 64) + 1 + 8;
     return d * 8 + ints * 4 + 16;
 }
 
@@ -263,10 +265,11 @@ int ce_create(const ce_template *tpl, int device, ce_handle *out) {
     else { ce_destroy(h); g_err = "instance vectors do not fit LDS"; return CE_E_TOO_LARGE; }
     h->bwd_lds = bwd_lds_bytes(T, h->bwd_mode <= 1, h->bwd_mode == 0, h->nkcap, h->ldk);
     if (!getenv("CE_FORCE_GENERIC")) {
-        for (int v = 0; v < 3; v++) {
-            const int TI = BRT_VARIANTS[v][0], TJ = BRT_VARIANTS[v][1], TH = BRT_VARIANTS[v][2];
-            if (h->nkcap <= BG * TJ - 1 && h->nkcap <= BG * TI && T.n <= BG * TH && bwd_rt_lds_bytes(T, TI, TJ) <= LDS_LIMIT) {
-                h->brt_variant = v; h->bwd_mode = 3; h->bwd_lds = bwd_rt_lds_bytes(T, TI, TJ); break;
+        for (int v = 0; v < BRT_NV; v++) {
+            const int TI = BRT_VARIANTS[v][0], TJ = BRT_VARIANTS[v][1], TH = BRT_VARIANTS[v][2], BGR = BRT_VARIANTS[v][3];
+            if (T.ns > 0 && BGR != 16) continue;        // PSD kernels are instantiated for the 256-thread variants only
+            if (h->nkcap <= BGC * TJ - 1 && h->nkcap <= BGR * TI && T.n <= BGC * TH && bwd_rt_lds_bytes(T, TI, TJ, BGR) <= LDS_LIMIT) {
+                h->brt_variant = v; h->bwd_mode = 3; h->bwd_lds = bwd_rt_lds_bytes(T, TI, TJ, BGR); break;
             }
         }
     }
@@ -277,6 +280,7 @@ int ce_create(const ce_template *tpl, int device, ce_handle *out) {
     SETATTR((k_fwd2<4, 30, 4, 26, 4, 26, false, 512>), LDS_LIMIT);
     SETATTR((k_fwd2<16, 2, 8, 2, 16, 2>), LDS_LIMIT); SETATTR((k_fwd2<8, 8, 4, 8, 8, 4>), LDS_LIMIT); SETATTR((k_fwd2<4, 26, 2, 26, 4, 14>), LDS_LIMIT);
     SETATTR((k_backward_rt<4, 4, 4, true>), LDS_LIMIT); SETATTR((k_backward_rt<7, 7, 4, true>), LDS_LIMIT); SETATTR((k_backward_rt<7, 7, 7, true>), LDS_LIMIT);
+    SETATTR((k_backward_rt<7, 13, 7, false, 32>), LDS_LIMIT);
     SETATTR((k_backward_rt<4, 4, 4>), LDS_LIMIT); SETATTR((k_backward_rt<7, 7, 4>), LDS_LIMIT); SETATTR((k_backward_rt<7, 7, 7>), LDS_LIMIT);
     SETATTR((k_backward<true, true>), LDS_LIMIT); SETATTR((k_backward<true, false>), LDS_LIMIT); SETATTR((k_backward<false, false>), LDS_LIMIT);
 #undef SETATTR
@@ -398,11 +402,11 @@ int ce_vjp(ce_handle h, int B, const double *A_vals, long sA_k, long sA_b, const
         dim3 grid(B), block(NT);
 #define LAUNCH_B(AL, KL) hipLaunchKernelGGL((k_backward<AL, KL>), grid, block, h->bwd_lds, st, T, h->nkcap, h->ldk, Abm, x, y, s, dx, dy, dAbm, dq_vals, sdq_k, sdq_b, adj_status, gA, gK)
         DevT Tb = T; Tb.lda = T.n;
-#define LAUNCH_BRT(...) hipLaunchKernelGGL((k_backward_rt<__VA_ARGS__>), grid, block, h->bwd_lds, st, Tb, Abm, x, y, s, dx, dy, dAbm, dq_vals, sdq_k, sdq_b, adj_status)
+#define LAUNCH_BRT(...) hipLaunchKernelGGL((k_backward_rt<__VA_ARGS__>), grid, dim3(h->brt_variant >= 0 ? BRT_VARIANTS[h->brt_variant][3] * 16 : NT), h->bwd_lds, st, Tb, Abm, x, y, s, dx, dy, dAbm, dq_vals, sdq_k, sdq_b, adj_status)
         if (h->bwd_mode == 3 && T.ns > 0) {
             if (h->brt_variant == 0) LAUNCH_BRT(4, 4, 4, true); else if (h->brt_variant == 1) LAUNCH_BRT(7, 7, 4, true); else LAUNCH_BRT(7, 7, 7, true);
         } else if (h->bwd_mode == 3) {
-            if (h->brt_variant == 0) LAUNCH_BRT(4, 4, 4); else if (h->brt_variant == 1) LAUNCH_BRT(7, 7, 4); else LAUNCH_BRT(7, 7, 7);
+            if (h->brt_variant == 0) LAUNCH_BRT(4, 4, 4); else if (h->brt_variant == 1) LAUNCH_BRT(7, 7, 4); else if (h->brt_variant == 2) LAUNCH_BRT(7, 7, 7); else LAUNCH_BRT(7, 13, 7, false, 32);
         } else if (h->bwd_mode == 0) LAUNCH_B(true, true); else if (h->bwd_mode == 1) LAUNCH_B(true, false); else LAUNCH_B(false, false);
 #undef LAUNCH_BRT
 #undef LAUNCH_B

@@ -22,8 +22,9 @@ x, y, s, it, st, res = eng.solve(A_bm, q_t, make_settings(dict(eps=1e-4, max_ite
 dx = torch.ones_like(x); dy = torch.zeros_like(y)
 dA, dq, adj = eng.vjp(A_bm, x, y, s, dx, dy)
 torch.cuda.synchronize()
-t = dA.t()[:, :8].cpu().numpy()
+t = dA.t()[:, :9].cpu().numpy()
 names = ["load", "classify+number", "dv,ay,as,fvec", "assemble", "ptol+GJ", "solve+q+ry", "output", "NK"]
 for k, nm in enumerate(names):
     print(f"{nm:18s} mean {t[:, k].mean():12.1f}  max {t[:, k].max():12.1f}")
+print("assemble: H part", t[:, 8].mean())
 print("sum of phases", t[:, :7].sum(1).mean())
