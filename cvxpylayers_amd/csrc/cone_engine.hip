@@ -39,6 +39,7 @@ namespace {
 #include "ce_forward_v2.h"
 #include "ce_backward.h"
 #include "ce_backward_rt.h"
+#include "ce_const_a.h"
 }  // namespace
 
 // ================================================================================================
@@ -429,6 +430,40 @@ int ce_transpose(ce_handle h, int rows, int cols, const double *in, double *out,
         dim3 grid((cols + 31) / 32, (rows + 31) / 32);
         hipLaunchKernelGGL(k_transpose, grid, dim3(256), 0, st, in, out, rows, cols);
     }
+    HIPCHK(hipGetLastError());
+    return CE_OK;
+}
+
+int ce_ca_step(ce_handle h, int B, int lp, double *W, double *UT, double *U, const double *PX, long ld_px, const double *QY, long ld_qy,
+               const double *G, const double *PHI, const double *scale, const double *inv_den, const int *active,
+               int update_w, int norm_after, double alpha, void *stream) {
+    if (!h || B <= 0 || !W || !UT || !U || !PX || !QY || !G || !PHI || !scale || !inv_den || !active) { g_err = "null argument"; return CE_E_BADARG; }
+    HIPCHK(hipSetDevice(h->device));
+    const DevT &T = h->T;
+    const size_t lds = ((size_t)(T.n + T.m + 1) + 2 * std::max(T.nq, 1) + NW * 8) * 8;
+    if (lds > 64 * 1024) { g_err = "constant-A path: instance vectors do not fit LDS"; return CE_E_TOO_LARGE; }
+    hipLaunchKernelGGL(k_ca_step, dim3(B), dim3(NT), lds, (hipStream_t)stream, T, lp, W, UT, U, PX, ld_px, QY, ld_qy, G, PHI, scale, inv_den, active, update_w, norm_after, alpha);
+    HIPCHK(hipGetLastError());
+    return CE_OK;
+}
+int ce_ca_check(ce_handle h, int B, int lp, int iter, const ce_settings *settings, double *W, const double *UT, const double *U,
+                const double *AX, long ld_ax, const double *ATY, long ld_aty, const double *D, const double *E,
+                const double *b_hat, const double *c_hat, const double *sigma, const double *nrm_b0, const double *nrm_c0,
+                double *scale, double *sum_log, int *n_log, int *last_scale_iter, int *active, int *status, int *iters,
+                double *resid, int *rescaled, void *stream) {
+    if (!h || B <= 0 || !settings || !W || !UT || !U || !AX || !ATY || !D || !E || !b_hat || !c_hat || !sigma || !scale || !active || !status || !iters || !resid || !rescaled) { g_err = "null argument"; return CE_E_BADARG; }
+    HIPCHK(hipSetDevice(h->device));
+    hipLaunchKernelGGL(k_ca_check, dim3(B), dim3(NT), NW * 8 * 8, (hipStream_t)stream, h->T, *settings, lp, iter, W, UT, U, AX, ld_ax, ATY, ld_aty, D, E, b_hat, c_hat,
+                       sigma, nrm_b0, nrm_c0, scale, sum_log, n_log, last_scale_iter, active, status, iters, resid, rescaled);
+    HIPCHK(hipGetLastError());
+    return CE_OK;
+}
+int ce_ca_finish(ce_handle h, int B, int lp, int max_iters, const double *W, const double *UT, const double *U, const double *D,
+                 const double *E, const double *b_hat, const double *c_hat, const double *sigma, const double *scale,
+                 const int *active, int *status, int *iters, double *x, double *y, double *s, void *stream) {
+    if (!h || B <= 0 || !W || !UT || !U || !x || !y || !s) { g_err = "null argument"; return CE_E_BADARG; }
+    HIPCHK(hipSetDevice(h->device));
+    hipLaunchKernelGGL(k_ca_finish, dim3(B), dim3(NT), NW * 8 * 8, (hipStream_t)stream, h->T, lp, max_iters, W, UT, U, D, E, b_hat, c_hat, sigma, scale, active, status, iters, x, y, s);
     HIPCHK(hipGetLastError());
     return CE_OK;
 }

@@ -83,6 +83,8 @@ class ConeEngine:
         self._indices = np.ascontiguousarray(indices, dtype=np.int32)
         self._indptr = np.ascontiguousarray(indptr, dtype=np.int32)
         self.nnz_aug = int(self._indptr[-1])
+        self.nnzA = int(self._indptr[self.n])
+        self.cone_dict = {k: (list(v) if isinstance(v, (list, tuple, np.ndarray)) else v) for k, v in dict(cone_dict).items()}
         q = np.ascontiguousarray(cone_dict.get("q", []), dtype=np.int32)
         s = np.ascontiguousarray(cone_dict.get("s", []), dtype=np.int32)
         t = _lib.CeTemplate()
@@ -128,6 +130,11 @@ class ConeEngine:
         """A_bm (B, nnz_aug) contiguous, q_eval (n+1, B) any strides.  Returns x, y, s, iters, status, resid."""
         B = A_bm.shape[0]
         dev = self.device
+        if self._use_const_a(A_bm):
+            from cvxpylayers_amd.interfaces.const_a import solve_const_a
+            self.last_path = "const_a"
+            return solve_const_a(self, A_bm, q_eval, settings)
+        self.last_path = "per_instance"
         x = torch.empty((B, self.n), dtype=torch.float64, device=dev)
         y = torch.empty((B, self.m), dtype=torch.float64, device=dev)
         s = torch.empty((B, self.m), dtype=torch.float64, device=dev)
@@ -139,6 +146,18 @@ class ConeEngine:
                                  iters.data_ptr(), status.data_ptr(), resid.data_ptr(), self._stream())
         _lib.check(rc, "ce_solve")
         return x, y, s, iters, status, resid
+
+    def _use_const_a(self, A_bm) -> bool:
+        """The batch-GEMM path pays off when the instance is too large for the register / LDS-resident kernels (those are
+        faster for small instances even when A is shared).  CE_CONST_A=1 forces it whenever A is batch-invariant, =0 disables it."""
+        import os
+        from cvxpylayers_amd.interfaces.const_a import is_constant_A
+        env = os.environ.get("CE_CONST_A")
+        if env == "0" or self.cone_dict.get("s") or A_bm.shape[0] < 2:
+            return False
+        if env != "1" and self.launch_info()["fwd_mode"] not in (1, 2):
+            return False
+        return is_constant_A(A_bm, self.nnzA)
 
     def vjp(self, A_bm, x, y, s, dx, dy, batch_minor_out: bool = False):
         """Returns dA (nnz_aug, B), dq (n+1, B), adj_status (B,).  dA is a transposed view of a batch-major buffer (the

@@ -126,6 +126,27 @@ int ce_transpose(ce_handle h, int rows, int cols, const double *in, double *out,
 int ce_parammap_apply(int device, int B, int rows, const int *indptr, const int *indices, const double *vals,
                       const double *P, long ld_p, double *out, long ld_out, void *stream);
 
+/*
+ * Constant-A path (A batch-invariant; only b, c vary): the matrix products of the iteration are batch GEMMs done by the
+ * caller with rocBLAS (cvxpylayers_amd/interfaces/const_a.py); these entry points are the per-instance elementwise part.
+ * All vectors are (B, lp) row-major with layout (x[n] | y[m] | tau); per-instance scalars are arrays of length B.
+ *   ce_ca_step   : tau-tilde, u-tilde, cone projection, (optionally) relaxed update + renormalisation of w
+ *   ce_ca_check  : termination test / certificates / adaptive scale of a check iteration, then that iteration's update
+ *   ce_ca_finish : classification of unfinished instances and un-normalised write-back of x (B,n), y (B,m), s (B,m)
+ * They replace the same steps of diffcp.solve_and_derivative_batch -> SCS (diffcp_if.py:365-372) as ce_solve does.
+ */
+int ce_ca_step(ce_handle h, int B, int lp, double *W, double *UT, double *U, const double *PX, long ld_px, const double *QY, long ld_qy,
+               const double *G, const double *PHI, const double *scale, const double *inv_den, const int *active,
+               int update_w, int norm_after, double alpha, void *stream);
+int ce_ca_check(ce_handle h, int B, int lp, int iter, const ce_settings *settings, double *W, const double *UT, const double *U,
+                const double *AX, long ld_ax, const double *ATY, long ld_aty, const double *D, const double *E,
+                const double *b_hat, const double *c_hat, const double *sigma, const double *nrm_b0, const double *nrm_c0,
+                double *scale, double *sum_log, int *n_log, int *last_scale_iter, int *active, int *status, int *iters,
+                double *resid, int *rescaled, void *stream);
+int ce_ca_finish(ce_handle h, int B, int lp, int max_iters, const double *W, const double *UT, const double *U, const double *D,
+                 const double *E, const double *b_hat, const double *c_hat, const double *sigma, const double *scale,
+                 const int *active, int *status, int *iters, double *x, double *y, double *s, void *stream);
+
 /* Introspection used by bench.py / tests: per-kernel HIP-event timing on the launch stream. */
 int ce_set_profiling(ce_handle h, int enable);
 /* which: 0 forward kernel, 1 backward kernel, 2 layout (transpose) kernels.  Returns the mean ms per launch

@@ -172,3 +172,27 @@ def test_psd_forward_and_adjoint_parity():
 
 def test_psd_two_cones_adjoint_parity():
     run_parity(12, {"z": 1, "l": 2, "q": [], "s": [5, 4]}, 6, seed=8, eps=1e-9, max_iters=100000)
+
+
+def test_constant_A_gemm_path_matches_oracle(monkeypatch):
+    """A batch-invariant (only b, c vary): the batch-GEMM forward (interfaces/const_a.py) against the oracle, forced on a small
+    mixed zero / nonneg / SOC instance; same iteration counts up to one check interval."""
+    from oracle import oracle
+    from cvxpylayers_amd.interfaces.mi355_if import make_settings
+    monkeypatch.setenv("CE_CONST_A", "1")
+    n, cones, B = 12, {"z": 2, "l": 6, "q": [4, 5]}, 24
+    tpl = P.dense_template(n, cones)
+    A, b, c = P.generate(n, cones, B, seed=21, batched=("b", "c"))
+    for eps in (1e-4, 1e-9):
+        ref = oracle.solve_batch(A, b, c, cones, eps=eps, max_iters=100000)
+        eng = _engine_for(tpl)
+        A_eval, q_eval = tpl.values_from_dense(A, b, c)
+        A_bm = eng.to_batch_major(torch.from_numpy(A_eval).cuda())
+        x, y, s, iters, status, resid = eng.solve(A_bm, torch.from_numpy(q_eval).cuda(), make_settings(dict(eps=eps, max_iters=100000)))
+        assert eng.last_path == "const_a"
+        assert (status.cpu().numpy() == ref["status"]).all() and (ref["status"] == 1).all()
+        tol = max(1e-6, 20 * eps)
+        for got, want in ((x, ref["x"]), (y, ref["y"]), (s, ref["s"])):
+            err = np.abs(got.cpu().numpy() - want).max(axis=1) / (1 + np.abs(want).max(axis=1))
+            assert err.max() < tol, err.max()
+        assert np.abs(iters.cpu().numpy() - ref["iters"]).max() <= 25
