@@ -109,10 +109,22 @@ def solve_const_a(eng, A_bm: torch.Tensor, q_eval: torch.Tensor, settings):
         pk = (((ch + a) @ Q) * Dinv) @ Qt
         gy = dyv * (gx @ At + bh)
         hg = (ch * gx).sum(dim=1) + (bh * gy).sum(dim=1)
-        G = torch.zeros((B, lp), **f64); PHI = torch.zeros((B, lp), **f64)
+        Bc = scale.shape[0]
+        G = torch.zeros((Bc, lp), **f64); PHI = torch.zeros((Bc, lp), **f64)
         G[:, :n] = gx; G[:, n:n + m] = gy
         PHI[:, :n] = rho_x * pk; PHI[:, n:n + m] = bh - pk @ At
         state.update(Dinv=Dinv, G=G, PHI=PHI, inv_den=(1.0 / (TAU_FACTOR + hg)).contiguous())
+
+    # The working set is COMPACTED as instances finish: rows of converged instances are written back and dropped once fewer
+    # than half of the current rows are active, so the tail of slow instances does not pay for GEMMs over the whole batch.
+    B0 = B
+    out_x = torch.empty((B0, n), **f64); out_y = torch.empty((B0, m), **f64); out_s = torch.empty((B0, m), **f64)
+    out_iters = torch.zeros(B0, dtype=torch.int32, device=dev); out_status = torch.zeros(B0, dtype=torch.int32, device=dev)
+    out_resid = torch.full((B0, 3), float("nan"), **f64)
+    rows = torch.arange(B0, device=dev)              # original index of every current row
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    h = eng._h
+    max_iters = int(settings.max_iters)
 
     refresh()
     W = torch.zeros((B, lp), **f64); W[:, l - 1] = 1.0
@@ -125,25 +137,35 @@ def solve_const_a(eng, A_bm: torch.Tensor, q_eval: torch.Tensor, settings):
     n_log = torch.zeros(B, dtype=torch.int32, device=dev)
     last_sc = torch.zeros(B, dtype=torch.int32, device=dev)
     rescaled = torch.zeros(B, dtype=torch.int32, device=dev)
-    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-    h = eng._h
-    max_iters = int(settings.max_iters)
-    Wx, Wy = W[:, :n], W[:, n:n + m]
-    Ux, Uy = U[:, :n], U[:, n:n + m]
+
+    def write_back(sel_rows=None):
+        """un-normalise the current rows (ce_ca_finish) and store those selected (default: all) at their original positions"""
+        Bc = W.shape[0]
+        x = torch.empty((Bc, n), **f64); y = torch.empty((Bc, m), **f64); sv = torch.empty((Bc, m), **f64)
+        st, itc = status.clone(), iters.clone()
+        _lib.check(L.ce_ca_finish(h, Bc, lp, max_iters, W.data_ptr(), UT.data_ptr(), U.data_ptr(), D.data_ptr(), E.data_ptr(), bh.data_ptr(),
+                                  ch.data_ptr(), sigma.data_ptr(), scale.data_ptr(), active.data_ptr(), st.data_ptr(), itc.data_ptr(),
+                                  x.data_ptr(), y.data_ptr(), sv.data_ptr(), stream), "ce_ca_finish")
+        k = slice(None) if sel_rows is None else sel_rows
+        dst = rows[k]
+        out_x[dst] = x[k]; out_y[dst] = y[k]; out_s[dst] = sv[k]; out_iters[dst] = itc[k]; out_status[dst] = st[k]; out_resid[dst] = resid[k]
+
     for it in range(max_iters):
         check = (it % CONVERGED_INTERVAL) == 0
         last = it + 1 >= max_iters
+        Bc = W.shape[0]
+        Wx, Wy = W[:, :n], W[:, n:n + m]
         T = torch.addmm(Wx, Wy, A, beta=rho_x, alpha=-1.0)             # rho_x w_x - A^T w_y      (B, n)
         PX = ((T @ Q) * state["Dinv"]) @ Qt                              # p_x = G_b t
         QY = PX @ At                                                     # A p_x                    (B, m)
-        _lib.check(L.ce_ca_step(h, B, lp, W.data_ptr(), UT.data_ptr(), U.data_ptr(), PX.data_ptr(), PX.stride(0), QY.data_ptr(),
+        _lib.check(L.ce_ca_step(h, Bc, lp, W.data_ptr(), UT.data_ptr(), U.data_ptr(), PX.data_ptr(), PX.stride(0), QY.data_ptr(),
                                 QY.stride(0), state["G"].data_ptr(), state["PHI"].data_ptr(), scale.data_ptr(),
                                 state["inv_den"].data_ptr(), active.data_ptr(), int(not (check or last)),
                                 int(((it + 1) % CONVERGED_INTERVAL) == 0), alpha, stream), "ce_ca_step")
         if check:
-            AX = Ux @ At
-            ATY = Uy @ A
-            _lib.check(L.ce_ca_check(h, B, lp, it, C.byref(settings), W.data_ptr(), UT.data_ptr(), U.data_ptr(), AX.data_ptr(), AX.stride(0),
+            AX = U[:, :n] @ At
+            ATY = U[:, n:n + m] @ A
+            _lib.check(L.ce_ca_check(h, Bc, lp, it, C.byref(settings), W.data_ptr(), UT.data_ptr(), U.data_ptr(), AX.data_ptr(), AX.stride(0),
                                      ATY.data_ptr(), ATY.stride(0), D.data_ptr(), E.data_ptr(), bh.data_ptr(), ch.data_ptr(),
                                      sigma.data_ptr(), nrm_b0.data_ptr(), nrm_c0.data_ptr(), scale.data_ptr(), sum_log.data_ptr(),
                                      n_log.data_ptr(), last_sc.data_ptr(), active.data_ptr(), status.data_ptr(), iters.data_ptr(),
@@ -154,8 +176,16 @@ def solve_const_a(eng, A_bm: torch.Tensor, q_eval: torch.Tensor, settings):
             if n_resc:
                 refresh()
                 rescaled.zero_()
-    x = torch.empty((B, n), **f64); y = torch.empty((B, m), **f64); s = torch.empty((B, m), **f64)
-    _lib.check(L.ce_ca_finish(h, B, lp, max_iters, W.data_ptr(), UT.data_ptr(), U.data_ptr(), D.data_ptr(), E.data_ptr(), bh.data_ptr(),
-                              ch.data_ptr(), sigma.data_ptr(), scale.data_ptr(), active.data_ptr(), status.data_ptr(), iters.data_ptr(),
-                              x.data_ptr(), y.data_ptr(), s.data_ptr(), stream), "ce_ca_finish")
-    return x, y, s, iters, status, resid
+            if 2 * n_active <= Bc and Bc > 64:          # compact
+                done_rows = (active == 0).nonzero().flatten()
+                keep = (active != 0).nonzero().flatten()
+                write_back(done_rows)
+                rows = rows[keep]
+                W, UT, U = W[keep].contiguous(), UT[keep].contiguous(), U[keep].contiguous()
+                bh, ch, sigma, nrm_b0, nrm_c0 = bh[keep].contiguous(), ch[keep].contiguous(), sigma[keep].contiguous(), nrm_b0[keep].contiguous(), nrm_c0[keep].contiguous()
+                scale, sum_log, n_log, last_sc = scale[keep].contiguous(), sum_log[keep].contiguous(), n_log[keep].contiguous(), last_sc[keep].contiguous()
+                active, status, iters, resid, rescaled = active[keep].contiguous(), status[keep].contiguous(), iters[keep].contiguous(), resid[keep].contiguous(), rescaled[keep].contiguous()
+                for key in ("Dinv", "G", "PHI", "inv_den"):
+                    state[key] = state[key][keep].contiguous()
+    write_back()
+    return out_x, out_y, out_s, out_iters, out_status, out_resid
