@@ -189,3 +189,123 @@ def solve_const_a(eng, A_bm: torch.Tensor, q_eval: torch.Tensor, settings):
                     state[key] = state[key][keep].contiguous()
     write_back()
     return out_x, out_y, out_s, out_iters, out_status, out_resid
+
+
+# ======================================================================================================================
+# Adjoint for the constant-A path: batched LSQR on the reduced system  N r = (dx, DPi dy),  N(r_x, r_y) = (-A^T r_y, DPi(A r_x - r_y) + r_y)
+# (the tau row / column of diffcp's M^T r = dz is dropped: dA, db, dc do not depend on the null component, r_tau = 0; this
+# is the same reduced system the per-instance kernels eliminate directly).  diffcp itself solves its system with LSQR
+# (mode="lsqr" is its default); here every operator application is a GEMM over the batch plus elementwise cone derivatives.
+# ======================================================================================================================
+def _dproj(v, h, z, nl, qs):
+    """DPi_{K*}(v) h, blockwise: zero rows (dual cone free) -> h; nonneg -> h [v > 0]; SOC -> closed form (cone_oracle.c dproj_soc)."""
+    out = h.clone()
+    if nl:
+        out[:, z:z + nl] = h[:, z:z + nl] * (v[:, z:z + nl] > 0)
+    off = z + nl
+    for d in qs:
+        vb, hb = v[:, off:off + d], h[:, off:off + d]
+        if d == 1:
+            out[:, off] = hb[:, 0] * (vb[:, 0] >= 0)
+        else:
+            t, zz = vb[:, :1], vb[:, 1:]
+            nz = zz.norm(dim=1, keepdim=True)
+            zh = (zz * hb[:, 1:]).sum(dim=1, keepdim=True)
+            nzs = torch.clamp(nz, min=1e-300)
+            o0 = (nz * hb[:, :1] + zh) / (2 * nzs)
+            oz = (zz * hb[:, :1] + (t + nz) * hb[:, 1:] - t * zz * zh / (nzs * nzs)) / (2 * nzs)
+            mid = torch.cat([o0, oz], dim=1)
+            inside = nz <= t
+            polar = (nz <= -t) & ~inside
+            out[:, off:off + d] = torch.where(inside, hb, torch.where(polar, torch.zeros_like(hb), mid))
+        off += d
+    return out
+
+
+def vjp_const_a(eng, A_bm, x, y, s, dx, dy, batch_minor_out=False, atol=1e-12, btol=1e-12, iter_factor=4):
+    """Returns dA (nnz_aug, B), dq (n+1, B), adj_status (B,) in the boundary convention (diffcp_if.py:91-92)."""
+    dev = A_bm.device
+    n, m, B = eng.n, eng.m, A_bm.shape[0]
+    indices, indptr = eng._indices, eng._indptr
+    nnzA = eng.nnzA
+    cols_np = np.repeat(np.arange(n + 1), np.diff(indptr))
+    f64 = dict(dtype=torch.float64, device=dev)
+    rows_t = torch.from_numpy(indices.astype(np.int64)).to(dev)
+    cols_t = torch.from_numpy(cols_np.astype(np.int64)).to(dev)
+    A = torch.zeros((m, n), **f64)
+    A[rows_t[:nnzA], cols_t[:nnzA]] = -A_bm[0, :nnzA]
+    At = A.t().contiguous()
+    cone = eng.cone_dict
+    z, nl, qs = int(cone.get("z", 0)), int(cone.get("l", 0)), [int(v) for v in cone.get("q", [])]
+    v = y - s
+
+    def N(rx, ry):          # (B,n),(B,m) -> (B,n),(B,m)
+        return -(ry @ A), _dproj(v, rx @ At - ry, z, nl, qs) + ry
+
+    def NT(px, py):
+        q = _dproj(v, py, z, nl, qs)
+        return q @ A, -(px @ At) - q + py
+
+    def nrm(a, b_):
+        return torch.sqrt((a * a).sum(dim=1) + (b_ * b_).sum(dim=1))
+
+    bx, by = dx.to(torch.float64), _dproj(v, dy.to(torch.float64), z, nl, qs)
+    # LSQR (Paige & Saunders), batched; rows that met a stopping test are frozen
+    bnorm = nrm(bx, by)
+    live = bnorm > 0
+    safe = lambda t: torch.where(t > 0, t, torch.ones_like(t))
+    beta = bnorm.clone()
+    ux, uy = bx / safe(beta)[:, None], by / safe(beta)[:, None]
+    vx, vy = NT(ux, uy)
+    alfa = nrm(vx, vy)
+    vx, vy = vx / safe(alfa)[:, None], vy / safe(alfa)[:, None]
+    wx, wy = vx.clone(), vy.clone()
+    rx, ry = torch.zeros_like(bx), torch.zeros_like(by)
+    rhobar, phibar = alfa.clone(), beta.clone()
+    anorm = torch.zeros(B, **f64); ddnorm = torch.zeros(B, **f64); xxnorm = torch.zeros(B, **f64)
+    zz = torch.zeros(B, **f64); cs2 = -torch.ones(B, **f64); sn2 = torch.zeros(B, **f64)
+    live = live & (alfa * beta > 0)
+    itn_lim = iter_factor * (n + m)
+    itn = 0
+    while itn < itn_lim:
+        itn += 1
+        tx, ty = N(vx, vy)
+        ux, uy = tx - alfa[:, None] * ux, ty - alfa[:, None] * uy
+        beta = nrm(ux, uy)
+        ux, uy = ux / safe(beta)[:, None], uy / safe(beta)[:, None]
+        anorm = torch.sqrt(anorm * anorm + alfa * alfa + beta * beta)
+        tx, ty = NT(ux, uy)
+        vx, vy = tx - beta[:, None] * vx, ty - beta[:, None] * vy
+        alfa = nrm(vx, vy)
+        vx, vy = vx / safe(alfa)[:, None], vy / safe(alfa)[:, None]
+        rho = torch.sqrt(rhobar * rhobar + beta * beta)
+        cs, sn = rhobar / safe(rho), beta / safe(rho)
+        theta = sn * alfa; rhobar = -cs * alfa; phi = cs * phibar; phibar = sn * phibar; tau = sn * phi
+        t1, t2 = phi / safe(rho), -theta / safe(rho)
+        lm = live.to(torch.float64)[:, None]
+        ddnorm = ddnorm + ((wx * wx).sum(dim=1) + (wy * wy).sum(dim=1)) / safe(rho * rho)
+        rx = rx + lm * t1[:, None] * wx; ry = ry + lm * t1[:, None] * wy
+        wx, wy = vx + t2[:, None] * wx, vy + t2[:, None] * wy
+        delta = sn2 * rho; gambar = -cs2 * rho; rhs = phi - delta * zz; zbar = rhs / safe(gambar.abs()) * torch.sign(gambar)
+        xnorm = torch.sqrt(xxnorm + zbar * zbar)
+        gamma = torch.sqrt(gambar * gambar + theta * theta); cs2 = gambar / safe(gamma); sn2 = theta / safe(gamma); zz = rhs / safe(gamma); xxnorm = xxnorm + zz * zz
+        rnorm = phibar
+        arnorm = alfa * tau.abs()
+        test1 = rnorm / safe(bnorm); test2 = arnorm / (anorm * rnorm + 1e-300)
+        rtol = btol + atol * anorm * xnorm / safe(bnorm)
+        done = (test1 <= rtol) | (test2 <= atol)
+        live = live & ~done
+        if itn % 16 == 0 and not bool(live.any().item()):
+            break
+    adj = live.to(torch.int32)           # 1: LSQR hit its iteration limit for this instance
+    # outputs: dA_ij = x_j r_y,i - y_i r_x,j ; db = -r_y ; dc = -r_x   (r_tau = 0), packed as [-dA.data, db[b_idx]], [dc, 0]
+    K = eng.nnz_aug
+    dA_bm = torch.empty((B, K), **f64)
+    ra, ca = rows_t[:nnzA], cols_t[:nnzA]
+    dA_bm[:, :nnzA] = -(x[:, ca] * ry[:, ra] - y[:, ra] * rx[:, ca])
+    if K > nnzA:
+        dA_bm[:, nnzA:] = -ry[:, rows_t[nnzA:]]
+    dq = torch.zeros((n + 1, B), **f64)
+    dq[:n] = -rx.t()
+    dA = dA_bm.t().contiguous() if batch_minor_out else dA_bm.t()
+    return dA, dq, adj

@@ -165,6 +165,9 @@ class ConeEngine:
         reference-style A_eval, so that autograd can accumulate it into the leaf without a strided copy (one engine layout pass)."""
         B = A_bm.shape[0]
         dev = self.device
+        if getattr(self, "last_path", None) == "const_a" and (self.launch_info()["bwd_mode"] in (1, 2) or __import__("os").environ.get("CE_CONST_A") == "1"):
+            from cvxpylayers_amd.interfaces.const_a import vjp_const_a      # shared A: batched LSQR with GEMMs over the batch
+            return vjp_const_a(self, A_bm, x, y, s, dx, dy, batch_minor_out=batch_minor_out)
         dq = torch.empty((self.n + 1, B), dtype=torch.float64, device=dev)
         adj = torch.empty((B,), dtype=torch.int32, device=dev)
         if batch_minor_out:

@@ -196,3 +196,50 @@ def test_constant_A_gemm_path_matches_oracle(monkeypatch):
             err = np.abs(got.cpu().numpy() - want).max(axis=1) / (1 + np.abs(want).max(axis=1))
             assert err.max() < tol, err.max()
         assert np.abs(iters.cpu().numpy() - ref["iters"]).max() <= 25
+        if eps < 1e-6:       # batched-LSQR adjoint of the constant-A path against the oracle's dense adjoint
+            rng = np.random.default_rng(5)
+            dx = rng.standard_normal(ref["x"].shape); dy = rng.standard_normal(ref["y"].shape)
+            g = oracle.adjoint_batch(A, b, c, cones, ref["x"], ref["y"], ref["s"], dx, dy, mode="dense")
+            xr, yr, sr = (torch.from_numpy(ref[k]).cuda() for k in ("x", "y", "s"))
+            dA, dq, adj = eng.vjp(A_bm, xr, yr, sr, torch.from_numpy(dx).cuda(), torch.from_numpy(dy).cuda())
+            assert (adj.cpu().numpy() == 0).all()
+            dA = dA.cpu().numpy(); dq = dq.cpu().numpy()
+            cols = np.repeat(np.arange(n + 1), np.diff(tpl.indptr))
+            want = np.empty_like(dA)
+            for k in range(tpl.nnz_aug):
+                i, j = tpl.indices[k], cols[k]
+                want[k] = -g["dA"][:, i, j] if j < n else g["db"][:, i]
+            assert np.abs(dA - want).max() < 1e-5 * (1 + np.abs(want).max()), np.abs(dA - want).max()
+            assert np.abs(dq[:n] - g["dc"].T).max() < 1e-5 * (1 + np.abs(g["dc"]).max())
+
+
+def test_constant_A_path_is_selected_for_large_shared_templates():
+    """Portfolio-shaped template (1^T w = 1, w >= 0, ||F^T w|| <= t; only the returns vary) too large for the LDS-resident
+    kernels: the engine picks the batch-GEMM forward and the batched-LSQR adjoint by itself; both agree with the oracle."""
+    from oracle import oracle
+    from cvxpylayers_amd.interfaces.mi355_if import make_settings
+    nw, kf, B = 140, 12, 6
+    rng = np.random.default_rng(0)
+    F = rng.standard_normal((nw, kf)) / np.sqrt(kf) * 0.3
+    n = nw + 1; cones = {"z": 1, "l": nw, "q": [kf + 1]}; m = P.cone_rows(cones)
+    A = np.zeros((m, n)); b = np.zeros(m)
+    A[0, :nw] = 1.0; b[0] = 1.0
+    A[1:1 + nw, :nw] = -np.eye(nw)
+    A[1 + nw, nw] = -1.0
+    A[2 + nw:, :nw] = -F.T
+    tpl = P.dense_template(n, cones, pattern=(A != 0), b_pattern=(b != 0))
+    mu = 0.05 + 0.1 * rng.random((B, nw))
+    c = np.concatenate([-mu, np.ones((B, 1))], axis=1)
+    Ab = np.broadcast_to(A, (B, m, n)).copy(); bb = np.broadcast_to(b, (B, m)).copy()
+    eps = 1e-8
+    ref = oracle.solve_batch(Ab, bb, c, cones, eps=eps, max_iters=200000)
+    assert (ref["status"] == 1).all()
+    eng, A_bm, x, y, s, iters, status, resid = gpu_solve(tpl, Ab, bb, c, eps=eps, max_iters=200000)
+    assert eng.last_path == "const_a" and (status == 1).all()
+    assert np.abs(x.cpu().numpy() - ref["x"]).max() < 1e-6 and np.abs(y.cpu().numpy() - ref["y"]).max() < 1e-6
+    dx = rng.standard_normal(ref["x"].shape)
+    g = oracle.adjoint_batch(Ab, bb, c, cones, ref["x"], ref["y"], ref["s"], dx, np.zeros_like(ref["y"]), mode="dense")
+    xr, yr, sr = (torch.from_numpy(ref[k]).cuda() for k in ("x", "y", "s"))
+    dA, dq, adj = eng.vjp(A_bm, xr, yr, sr, torch.from_numpy(dx).cuda(), torch.zeros_like(yr))
+    assert (adj.cpu().numpy() == 0).all()
+    assert np.abs(dq.cpu().numpy()[:n] - g["dc"].T).max() < 1e-5 * (1 + np.abs(g["dc"]).max())
