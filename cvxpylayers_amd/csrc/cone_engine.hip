@@ -257,7 +257,6 @@ int ce_create(const ce_template *tpl, int device, ce_handle *out) {
         if (fwd_lds_bytes(T, true, true) <= LDS_LIMIT) h->fwd_mode = 0; else if (fwd_lds_bytes(T, true, false) <= LDS_LIMIT) h->fwd_mode = 1; else h->fwd_mode = 2;
         h->fwd_lds = fwd_lds_bytes(T, h->fwd_mode <= 1, h->fwd_mode == 0);
     }
-    if (T.ns > 0 && h->fwd_mode != 4) { ce_destroy(h); g_err = "PSD cones: the instance does not fit the LDS-resident forward kernel (n <= 50, m <= 104 this round)"; return CE_E_UNSUPPORTED; }
     h->nkcap = T.n + std::min(T.m, T.n);
     h->ldk = (h->nkcap + 1) | 1;
     if (bwd_lds_bytes(T, true, true, h->nkcap, h->ldk) <= LDS_LIMIT) h->bwd_mode = 0;
@@ -337,6 +336,7 @@ int ce_solve(ce_handle h, int B, const double *A_vals, long sA_k, long sA_b, con
     if (!h || B <= 0 || !A_vals || !q_vals || !x || !y || !s || !iters || !status) { g_err = "null argument"; return CE_E_BADARG; }
     HIPCHK(hipSetDevice(h->device));
     hipStream_t st = (hipStream_t)stream;
+    if (h->T.ns > 0 && h->fwd_mode != 4) { g_err = "PSD cones: per-instance A does not fit the LDS-resident forward kernel (n <= 50, m <= 104 this round); only batch-invariant A is supported at this size (constant-A path)"; return CE_E_UNSUPPORTED; }
     ce_settings S; if (settings) S = *settings; else ce_default_settings(&S);
     const double *Abm = nullptr;
     int rc = to_batch_major(h, B, A_vals, sA_k, sA_b, st, &Abm);

@@ -33,6 +33,41 @@ def _clamp_scale(v: torch.Tensor) -> torch.Tensor:
     return torch.where(v < MIN_SCALE, torch.ones_like(v), torch.clamp(v, max=MAX_SCALE))
 
 
+class _PsdBlock:
+    """svec <-> symmetric matrix for one PSD block (lower triangle, column-major, sqrt(2) off-diagonals; torch/cvxpylayer.py:201-222)."""
+
+    def __init__(self, k: int, off: int, dev):
+        self.k, self.off, self.d = k, off, k * (k + 1) // 2
+        ri, cj = [], []
+        for j in range(k):
+            for i in range(j, k):
+                ri.append(i); cj.append(j)
+        self.ri = torch.tensor(ri, device=dev); self.cj = torch.tensor(cj, device=dev)
+        diag = self.ri == self.cj
+        one = torch.ones(len(ri), dtype=torch.float64, device=dev)      # (python scalars in torch.where would make float32 constants)
+        self.to_mat = torch.where(diag, one, one * (2.0 ** -0.5))
+        self.to_vec = torch.where(diag, one, one * (2.0 ** 0.5))
+
+    def smat(self, v):
+        S = torch.zeros(v.shape[0], self.k, self.k, dtype=torch.float64, device=v.device)
+        val = v * self.to_mat
+        S[:, self.ri, self.cj] = val
+        S[:, self.cj, self.ri] = val
+        return S
+
+    def svec(self, S):
+        return S[:, self.ri, self.cj] * self.to_vec
+
+
+def _psd_blocks(cone, dev):
+    z, nl, qs = int(cone.get("z", 0)), int(cone.get("l", 0)), [int(v) for v in cone.get("q", [])]
+    off = z + nl + sum(qs)
+    out = []
+    for k in [int(v) for v in cone.get("s", [])]:
+        out.append(_PsdBlock(k, off, dev)); off += k * (k + 1) // 2
+    return out
+
+
 def is_constant_A(A_bm: torch.Tensor, nnzA: int) -> bool:
     """True when the A part of the value rows is identical for every instance (one pass over the values, one sync)."""
     if A_bm.shape[0] == 1:
@@ -61,23 +96,25 @@ def solve_const_a(eng, A_bm: torch.Tensor, q_eval: torch.Tensor, settings):
     c = q_eval[:n].t().to(torch.float64).contiguous()
     cone = eng.cone_dict
     z, nl, qs = int(cone.get("z", 0)), int(cone.get("l", 0)), [int(v) for v in cone.get("q", [])]
+    psd = _psd_blocks(cone, dev)
     # ---- equilibration of the one shared matrix (25 Ruiz passes + 1 l2 pass, row scalings averaged inside SOC blocks)
     D = torch.ones(m, **f64); E = torch.ones(n, **f64)
     if settings.normalize:
         blk = torch.full((m,), -1, dtype=torch.int64, device=dev)
         off = z + nl
-        for k, d in enumerate(qs):
+        blocks = qs + [pb.d for pb in psd]          # row scalings are averaged inside SOC and PSD blocks alike
+        for k, d in enumerate(blocks):
             blk[off:off + d] = k
             off += d
         soc_rows = (blk >= 0).nonzero().flatten()
-        cnt = torch.tensor(qs, **f64) if qs else None
+        cnt = torch.tensor(blocks, **f64) if blocks else None
         for p in range(NUM_RUIZ_PASSES + NUM_L2_PASSES):
             if p >= NUM_RUIZ_PASSES:
                 Dt, Et = A.norm(dim=1), A.norm(dim=0)
             else:
                 Dt, Et = A.abs().amax(dim=1), A.abs().amax(dim=0)
-            if qs:
-                avg = torch.zeros(len(qs), **f64).index_add_(0, blk[soc_rows], Dt[soc_rows]) / cnt
+            if blocks:
+                avg = torch.zeros(len(blocks), **f64).index_add_(0, blk[soc_rows], Dt[soc_rows]) / cnt
                 Dt = Dt.clone(); Dt[soc_rows] = avg[blk[soc_rows]]
             Dt = 1.0 / torch.sqrt(_clamp_scale(Dt)); Et = 1.0 / torch.sqrt(_clamp_scale(Et))
             A = Dt[:, None] * A * Et[None, :]
@@ -160,8 +197,21 @@ def solve_const_a(eng, A_bm: torch.Tensor, q_eval: torch.Tensor, settings):
         QY = PX @ At                                                     # A p_x                    (B, m)
         _lib.check(L.ce_ca_step(h, Bc, lp, W.data_ptr(), UT.data_ptr(), U.data_ptr(), PX.data_ptr(), PX.stride(0), QY.data_ptr(),
                                 QY.stride(0), state["G"].data_ptr(), state["PHI"].data_ptr(), scale.data_ptr(),
-                                state["inv_den"].data_ptr(), active.data_ptr(), int(not (check or last)),
+                                state["inv_den"].data_ptr(), active.data_ptr(), int(not (check or last) and not psd),
                                 int(((it + 1) % CONVERGED_INTERVAL) == 0), alpha, stream), "ce_ca_step")
+        if psd:
+            # PSD blocks: the step kernel leaves the cone input in U; project it here (batched symmetric eigendecomposition,
+            # rocSOLVER through torch), then do the relaxed update / renormalisation the kernel skipped
+            for pb in psd:
+                blk_ = U[:, n + pb.off:n + pb.off + pb.d]
+                wv, Vv = torch.linalg.eigh(pb.smat(blk_))
+                U[:, n + pb.off:n + pb.off + pb.d] = pb.svec((Vv * torch.clamp(wv, min=0.0)[:, None, :]) @ Vv.transpose(1, 2))
+            if not (check or last):
+                am = active.to(torch.float64)[:, None]
+                W.add_(am * (U - UT), alpha=alpha)
+                if ((it + 1) % CONVERGED_INTERVAL) == 0:
+                    nw = W[:, :l].norm(dim=1, keepdim=True)
+                    W.mul_(torch.where((nw > 0) & (am > 0), (l ** 0.5) / torch.clamp(nw, min=1e-300), torch.ones_like(nw)))
         if check:
             AX = U[:, :n] @ At
             ATY = U[:, n:n + m] @ A
@@ -197,7 +247,7 @@ def solve_const_a(eng, A_bm: torch.Tensor, q_eval: torch.Tensor, settings):
 # is the same reduced system the per-instance kernels eliminate directly).  diffcp itself solves its system with LSQR
 # (mode="lsqr" is its default); here every operator application is a GEMM over the batch plus elementwise cone derivatives.
 # ======================================================================================================================
-def _dproj(v, h, z, nl, qs):
+def _dproj(v, h, z, nl, qs, psd=(), psd_eig=None):
     """DPi_{K*}(v) h, blockwise: zero rows (dual cone free) -> h; nonneg -> h [v > 0]; SOC -> closed form (cone_oracle.c dproj_soc)."""
     out = h.clone()
     if nl:
@@ -219,6 +269,22 @@ def _dproj(v, h, z, nl, qs):
             polar = (nz <= -t) & ~inside
             out[:, off:off + d] = torch.where(inside, hb, torch.where(polar, torch.zeros_like(hb), mid))
         off += d
+    for pb, (Uv, Bm) in zip(psd, psd_eig or ()):      # DPi(V)[H] = U (B o (U^T H U)) U^T
+        Hm = pb.smat(h[:, pb.off:pb.off + pb.d])
+        out[:, pb.off:pb.off + pb.d] = pb.svec(Uv @ (Bm * (Uv.transpose(1, 2) @ Hm @ Uv)) @ Uv.transpose(1, 2))
+    return out
+
+
+def _psd_eig(v, psd):
+    """eigenvectors of smat(v_c) and the divided-difference matrix B (1: both positive, 0: both non-positive, l+/(l+ - l-): mixed)"""
+    out = []
+    for pb in psd:
+        w, Uv = torch.linalg.eigh(pb.smat(v[:, pb.off:pb.off + pb.d]))
+        wi, wj = w[:, :, None], w[:, None, :]
+        pi, pj = torch.clamp(wi, min=0.0), torch.clamp(wj, min=0.0)
+        den = wi - wj
+        Bm = torch.where((wi > 0) & (wj > 0), torch.ones_like(den), torch.where((wi <= 0) & (wj <= 0), torch.zeros_like(den), (pi - pj) / torch.where(den == 0, torch.ones_like(den), den)))
+        out.append((Uv, Bm))
     return out
 
 
@@ -238,18 +304,20 @@ def vjp_const_a(eng, A_bm, x, y, s, dx, dy, batch_minor_out=False, atol=1e-12, b
     cone = eng.cone_dict
     z, nl, qs = int(cone.get("z", 0)), int(cone.get("l", 0)), [int(v) for v in cone.get("q", [])]
     v = y - s
+    psd = _psd_blocks(cone, dev)
+    peig = _psd_eig(v, psd)
 
     def N(rx, ry):          # (B,n),(B,m) -> (B,n),(B,m)
-        return -(ry @ A), _dproj(v, rx @ At - ry, z, nl, qs) + ry
+        return -(ry @ A), _dproj(v, rx @ At - ry, z, nl, qs, psd, peig) + ry
 
     def NT(px, py):
-        q = _dproj(v, py, z, nl, qs)
+        q = _dproj(v, py, z, nl, qs, psd, peig)
         return q @ A, -(px @ At) - q + py
 
     def nrm(a, b_):
         return torch.sqrt((a * a).sum(dim=1) + (b_ * b_).sum(dim=1))
 
-    bx, by = dx.to(torch.float64), _dproj(v, dy.to(torch.float64), z, nl, qs)
+    bx, by = dx.to(torch.float64), _dproj(v, dy.to(torch.float64), z, nl, qs, psd, peig)
     # LSQR (Paige & Saunders), batched; rows that met a stopping test are frozen
     bnorm = nrm(bx, by)
     live = bnorm > 0

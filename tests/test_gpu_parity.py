@@ -243,3 +243,28 @@ def test_constant_A_path_is_selected_for_large_shared_templates():
     dA, dq, adj = eng.vjp(A_bm, xr, yr, sr, torch.from_numpy(dx).cuda(), torch.zeros_like(yr))
     assert (adj.cpu().numpy() == 0).all()
     assert np.abs(dq.cpu().numpy()[:n] - g["dc"].T).max() < 1e-5 * (1 + np.abs(g["dc"]).max())
+
+
+def test_constant_A_path_with_psd_cone(monkeypatch):
+    """PSD blocks on the batch-GEMM path (projection and its derivative by batched symmetric eigendecompositions)."""
+    from oracle import oracle
+    from cvxpylayers_amd.interfaces.mi355_if import make_settings
+    monkeypatch.setenv("CE_CONST_A", "1")
+    n, cones, B = 10, {"z": 2, "l": 3, "q": [4], "s": [4]}, 12
+    tpl = P.dense_template(n, cones)
+    A, b, c = P.generate(n, cones, B, seed=31, batched=("b", "c"))
+    eps = 1e-9
+    ref = oracle.solve_batch(A, b, c, cones, eps=eps, max_iters=200000)
+    assert (ref["status"] == 1).all()
+    eng, A_bm, x, y, s, iters, status, resid = gpu_solve(tpl, A, b, c, eps=eps, max_iters=200000)
+    assert eng.last_path == "const_a" and (status == 1).all()
+    for got, want in ((x, ref["x"]), (y, ref["y"]), (s, ref["s"])):
+        assert np.abs(got.cpu().numpy() - want).max() < 1e-6 * (1 + np.abs(want).max())
+    assert np.abs(iters - ref["iters"]).max() <= 25
+    rng = np.random.default_rng(2)
+    dx = rng.standard_normal(ref["x"].shape); dy = rng.standard_normal(ref["y"].shape)
+    g = oracle.adjoint_batch(A, b, c, cones, ref["x"], ref["y"], ref["s"], dx, dy, mode="dense")
+    xr, yr, sr = (torch.from_numpy(ref[k]).cuda() for k in ("x", "y", "s"))
+    dA, dq, adj = eng.vjp(A_bm, xr, yr, sr, torch.from_numpy(dx).cuda(), torch.from_numpy(dy).cuda())
+    assert (adj.cpu().numpy() == 0).all()
+    assert np.abs(dq.cpu().numpy()[:n] - g["dc"].T).max() < 1e-5 * (1 + np.abs(g["dc"]).max())
