@@ -201,3 +201,14 @@ k_ca_finish(DevT T, int lp, int max_iters, const double *__restrict__ Wg, const 
         so[(size_t)inst * m + i] = infeas ? NAN : sh / di * it;
     }
 }
+
+// K4: PSD blocks of the cone input (B, lp) projected in place; one workgroup per (instance, cone), Jacobi in LDS (psd_project).
+__global__ void __launch_bounds__(NT)
+k_ca_psd(DevT T, int lp, double *__restrict__ Ug, const int *__restrict__ active) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int inst = blockIdx.x, c = blockIdx.y;
+    if (!active[inst]) return;
+    const int k = T.sord[c];
+    double *Sm = sm, *Vm = Sm + T.maxs * T.maxs, *cs = Vm + T.maxs * T.maxs, *red = cs + 2 * T.maxs + 8;
+    psd_project<NT>(Ug + (size_t)inst * lp + T.n + T.soff[c], k, Sm, Vm, cs, red);
+}

@@ -458,6 +458,16 @@ int ce_ca_check(ce_handle h, int B, int lp, int iter, const ce_settings *setting
     HIPCHK(hipGetLastError());
     return CE_OK;
 }
+int ce_ca_psd(ce_handle h, int B, int lp, double *U, const int *active, void *stream) {
+    if (!h || B <= 0 || !U || !active) { g_err = "null argument"; return CE_E_BADARG; }
+    if (h->T.ns == 0) return CE_OK;
+    HIPCHK(hipSetDevice(h->device));
+    const size_t lds = (2 * (size_t)h->T.maxs * h->T.maxs + 2 * h->T.maxs + 8 + NW * 8) * 8;
+    if (lds > 64 * 1024) { g_err = "PSD order too large for the LDS-resident Jacobi projection"; return CE_E_TOO_LARGE; }
+    hipLaunchKernelGGL(k_ca_psd, dim3(B, h->T.ns), dim3(NT), lds, (hipStream_t)stream, h->T, lp, U, active);
+    HIPCHK(hipGetLastError());
+    return CE_OK;
+}
 int ce_ca_finish(ce_handle h, int B, int lp, int max_iters, const double *W, const double *UT, const double *U, const double *D,
                  const double *E, const double *b_hat, const double *c_hat, const double *sigma, const double *scale,
                  const int *active, int *status, int *iters, double *x, double *y, double *s, void *stream) {

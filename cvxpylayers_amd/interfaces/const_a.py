@@ -200,12 +200,9 @@ def solve_const_a(eng, A_bm: torch.Tensor, q_eval: torch.Tensor, settings):
                                 state["inv_den"].data_ptr(), active.data_ptr(), int(not (check or last) and not psd),
                                 int(((it + 1) % CONVERGED_INTERVAL) == 0), alpha, stream), "ce_ca_step")
         if psd:
-            # PSD blocks: the step kernel leaves the cone input in U; project it here (batched symmetric eigendecomposition,
-            # rocSOLVER through torch), then do the relaxed update / renormalisation the kernel skipped
-            for pb in psd:
-                blk_ = U[:, n + pb.off:n + pb.off + pb.d]
-                wv, Vv = torch.linalg.eigh(pb.smat(blk_))
-                U[:, n + pb.off:n + pb.off + pb.d] = pb.svec((Vv * torch.clamp(wv, min=0.0)[:, None, :]) @ Vv.transpose(1, 2))
+            # PSD blocks: the step kernel leaves the cone input in U; project it in place (ce_ca_psd: workgroup-parallel Jacobi,
+            # ~600x faster than batched rocSOLVER eigh at 20x20), then do the relaxed update / renormalisation the kernel skipped
+            _lib.check(L.ce_ca_psd(h, Bc, lp, U.data_ptr(), active.data_ptr(), stream), "ce_ca_psd")     # Jacobi in LDS, one workgroup per block
             if not (check or last):
                 am = active.to(torch.float64)[:, None]
                 W.add_(am * (U - UT), alpha=alpha)

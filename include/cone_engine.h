@@ -132,6 +132,7 @@ int ce_parammap_apply(int device, int B, int rows, const int *indptr, const int 
  * All vectors are (B, lp) row-major with layout (x[n] | y[m] | tau); per-instance scalars are arrays of length B.
  *   ce_ca_step   : tau-tilde, u-tilde, cone projection, (optionally) relaxed update + renormalisation of w
  *   ce_ca_check  : termination test / certificates / adaptive scale of a check iteration, then that iteration's update
+ *   ce_ca_psd    : in-place projection of the PSD blocks of U (the step kernel leaves the cone input there)
  *   ce_ca_finish : classification of unfinished instances and un-normalised write-back of x (B,n), y (B,m), s (B,m)
  * They replace the same steps of diffcp.solve_and_derivative_batch -> SCS (diffcp_if.py:365-372) as ce_solve does.
  */
@@ -143,6 +144,7 @@ int ce_ca_check(ce_handle h, int B, int lp, int iter, const ce_settings *setting
                 const double *b_hat, const double *c_hat, const double *sigma, const double *nrm_b0, const double *nrm_c0,
                 double *scale, double *sum_log, int *n_log, int *last_scale_iter, int *active, int *status, int *iters,
                 double *resid, int *rescaled, void *stream);
+int ce_ca_psd(ce_handle h, int B, int lp, double *U, const int *active, void *stream);
 int ce_ca_finish(ce_handle h, int B, int lp, int max_iters, const double *W, const double *UT, const double *U, const double *D,
                  const double *E, const double *b_hat, const double *c_hat, const double *sigma, const double *scale,
                  const int *active, int *status, int *iters, double *x, double *y, double *s, void *stream);
