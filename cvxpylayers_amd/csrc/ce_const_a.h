@@ -212,3 +212,21 @@ k_ca_psd(DevT T, int lp, double *__restrict__ Ug, const int *__restrict__ active
     double *Sm = sm, *Vm = Sm + T.maxs * T.maxs, *cs = Vm + T.maxs * T.maxs, *red = cs + 2 * T.maxs + 8;
     psd_project<NT>(Ug + (size_t)inst * lp + T.n + T.soff[c], k, Sm, Vm, cs, red);
 }
+
+// K5: the relaxed update (and renormalisation) split off k_ca_step, for templates whose PSD blocks are projected in between.
+__global__ void __launch_bounds__(NT)
+k_ca_update(int l, int lp, double *__restrict__ Wg, const double *__restrict__ UTg, const double *__restrict__ Ug,
+            const int *__restrict__ active, int norm_after, double alpha) {
+    __shared__ double red[NW * 8];
+    const int inst = blockIdx.x, tid = threadIdx.x;
+    if (!active[inst]) return;
+    double *W = Wg + (size_t)inst * lp;
+    const double *UT = UTg + (size_t)inst * lp, *U = Ug + (size_t)inst * lp;
+    double nrm[1] = {0};
+    for (int e = tid; e < l; e += NT) { const double we = W[e] + alpha * (U[e] - UT[e]); W[e] = we; nrm[0] = fma(we, we, nrm[0]); }
+    if (norm_after) {
+        block_reduce<1>(nrm, 0u, red);
+        const double nw = sqrt(nrm[0]);
+        if (nw > 0) { const double f = sqrt((double)l) / nw; for (int e = tid; e < l; e += NT) W[e] *= f; }
+    }
+}

@@ -468,6 +468,13 @@ int ce_ca_psd(ce_handle h, int B, int lp, double *U, const int *active, void *st
     HIPCHK(hipGetLastError());
     return CE_OK;
 }
+int ce_ca_update(ce_handle h, int B, int lp, double *W, const double *UT, const double *U, const int *active, int norm_after, double alpha, void *stream) {
+    if (!h || B <= 0 || !W || !UT || !U || !active) { g_err = "null argument"; return CE_E_BADARG; }
+    HIPCHK(hipSetDevice(h->device));
+    hipLaunchKernelGGL(k_ca_update, dim3(B), dim3(NT), 0, (hipStream_t)stream, h->T.n + h->T.m + 1, lp, W, UT, U, active, norm_after, alpha);
+    HIPCHK(hipGetLastError());
+    return CE_OK;
+}
 int ce_ca_finish(ce_handle h, int B, int lp, int max_iters, const double *W, const double *UT, const double *U, const double *D,
                  const double *E, const double *b_hat, const double *c_hat, const double *sigma, const double *scale,
                  const int *active, int *status, int *iters, double *x, double *y, double *s, void *stream) {

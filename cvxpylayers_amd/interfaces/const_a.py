@@ -77,6 +77,14 @@ def is_constant_A(A_bm: torch.Tensor, nnzA: int) -> bool:
 
 def solve_const_a(eng, A_bm: torch.Tensor, q_eval: torch.Tensor, settings):
     """eng: ConeEngine; A_bm (B, nnz_aug) batch-major values of [A_cvx | b_cvx]; q_eval (n+1, B).  Returns x, y, s, iters, status, resid."""
+    import os, time
+    _timing = os.environ.get("CE_CA_TIMING") == "1"
+    def _tick(tag, _t=[None]):
+        if _timing:
+            torch.cuda.synchronize(); now = time.perf_counter()
+            if _t[0] is not None: print(f"[const_a] {tag}: {(now - _t[0]) * 1e3:.1f} ms")
+            _t[0] = now
+    _tick("start")
     L = _lib.lib()
     dev = A_bm.device
     n, m = eng.n, eng.m
@@ -119,6 +127,7 @@ def solve_const_a(eng, A_bm: torch.Tensor, q_eval: torch.Tensor, settings):
             Dt = 1.0 / torch.sqrt(_clamp_scale(Dt)); Et = 1.0 / torch.sqrt(_clamp_scale(Et))
             A = Dt[:, None] * A * Et[None, :]
             D = D * Dt; E = E * Et
+    _tick("extract + equilibrate")
     At = A.t().contiguous()
     nrm_b0 = b.abs().amax(dim=1) if m else torch.zeros(B, **f64)
     nrm_c0 = c.abs().amax(dim=1)
@@ -133,6 +142,7 @@ def solve_const_a(eng, A_bm: torch.Tensor, q_eval: torch.Tensor, settings):
     lam, Q = torch.linalg.eigh(At @ (d0[:, None] * A))
     lam = torch.clamp(lam, min=0.0)
     Qt = Q.t().contiguous()
+    _tick("eigh")
     rho_x, alpha = float(settings.rho_x), float(settings.alpha)
     scale = torch.full((B,), float(settings.scale), **f64)
     state = {}
@@ -150,7 +160,12 @@ def solve_const_a(eng, A_bm: torch.Tensor, q_eval: torch.Tensor, settings):
         G = torch.zeros((Bc, lp), **f64); PHI = torch.zeros((Bc, lp), **f64)
         G[:, :n] = gx; G[:, n:n + m] = gy
         PHI[:, :n] = rho_x * pk; PHI[:, n:n + m] = bh - pk @ At
-        state.update(Dinv=Dinv, G=G, PHI=PHI, inv_den=(1.0 / (TAU_FACTOR + hg)).contiguous())
+        new = dict(Dinv=Dinv, G=G, PHI=PHI, inv_den=(1.0 / (TAU_FACTOR + hg)).contiguous())
+        for key, val in new.items():      # in place when possible: a captured HIP graph keeps pointing at these buffers
+            if key in state and state[key].shape == val.shape:
+                state[key].copy_(val)
+            else:
+                state[key] = val
 
     # The working set is COMPACTED as instances finish: rows of converged instances are written back and dropped once fewer
     # than half of the current rows are active, so the tail of slow instances does not pay for GEMMs over the whole batch.
@@ -187,28 +202,54 @@ def solve_const_a(eng, A_bm: torch.Tensor, q_eval: torch.Tensor, settings):
         dst = rows[k]
         out_x[dst] = x[k]; out_y[dst] = y[k]; out_s[dst] = sv[k]; out_iters[dst] = itc[k]; out_status[dst] = st[k]; out_resid[dst] = resid[k]
 
-    for it in range(max_iters):
+    def iteration(it, strm):
+        """GEMMs + elementwise kernels of iteration `it` (everything but the check), enqueued on stream handle `strm`"""
         check = (it % CONVERGED_INTERVAL) == 0
         last = it + 1 >= max_iters
         Bc = W.shape[0]
-        Wx, Wy = W[:, :n], W[:, n:n + m]
-        T = torch.addmm(Wx, Wy, A, beta=rho_x, alpha=-1.0)             # rho_x w_x - A^T w_y      (B, n)
-        PX = ((T @ Q) * state["Dinv"]) @ Qt                              # p_x = G_b t
-        QY = PX @ At                                                     # A p_x                    (B, m)
+        T = torch.addmm(W[:, :n], W[:, n:n + m], A, beta=rho_x, alpha=-1.0)      # rho_x w_x - A^T w_y      (B, n)
+        PX = ((T @ Q) * state["Dinv"]) @ Qt                                        # p_x = G_b t
+        QY = PX @ At                                                               # A p_x                    (B, m)
+        norm_after = int(((it + 1) % CONVERGED_INTERVAL) == 0)
         _lib.check(L.ce_ca_step(h, Bc, lp, W.data_ptr(), UT.data_ptr(), U.data_ptr(), PX.data_ptr(), PX.stride(0), QY.data_ptr(),
                                 QY.stride(0), state["G"].data_ptr(), state["PHI"].data_ptr(), scale.data_ptr(),
                                 state["inv_den"].data_ptr(), active.data_ptr(), int(not (check or last) and not psd),
-                                int(((it + 1) % CONVERGED_INTERVAL) == 0), alpha, stream), "ce_ca_step")
+                                norm_after, alpha, strm), "ce_ca_step")
         if psd:
             # PSD blocks: the step kernel leaves the cone input in U; project it in place (ce_ca_psd: workgroup-parallel Jacobi,
-            # ~600x faster than batched rocSOLVER eigh at 20x20), then do the relaxed update / renormalisation the kernel skipped
-            _lib.check(L.ce_ca_psd(h, Bc, lp, U.data_ptr(), active.data_ptr(), stream), "ce_ca_psd")     # Jacobi in LDS, one workgroup per block
+            # ~600x faster than batched rocSOLVER eigh at 20x20), then the relaxed update / renormalisation the kernel skipped
+            _lib.check(L.ce_ca_psd(h, Bc, lp, U.data_ptr(), active.data_ptr(), strm), "ce_ca_psd")
             if not (check or last):
-                am = active.to(torch.float64)[:, None]
-                W.add_(am * (U - UT), alpha=alpha)
-                if ((it + 1) % CONVERGED_INTERVAL) == 0:
-                    nw = W[:, :l].norm(dim=1, keepdim=True)
-                    W.mul_(torch.where((nw > 0) & (am > 0), (l ** 0.5) / torch.clamp(nw, min=1e-300), torch.ones_like(nw)))
+                _lib.check(L.ce_ca_update(h, Bc, lp, W.data_ptr(), UT.data_ptr(), U.data_ptr(), active.data_ptr(), norm_after, alpha, strm), "ce_ca_update")
+
+    # The 24 iterations between two checks are always the same launch sequence on the same buffers: they are captured once in a
+    # HIP graph and replayed (the eager Python loop is host-bound for small batches: ~10 launches per iteration).  The graph is
+    # re-captured only when a compaction replaces the buffers.
+    _tick("refresh + state")
+    use_graph = os.environ.get("CE_CA_GRAPH", "1") != "0"
+    graph = None
+    it = 0
+    while it < max_iters:
+        check = (it % CONVERGED_INTERVAL) == 0
+        if not check:
+            nblk = CONVERGED_INTERVAL - (it % CONVERGED_INTERVAL)            # iterations up to (not including) the next check
+            if use_graph and (it % CONVERGED_INTERVAL) == 1 and it + nblk < max_iters:
+                if graph is None:
+                    torch.cuda.synchronize(dev)
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph):
+                        cs_ = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+                        for j in range(nblk):
+                            iteration(1 + j, cs_)
+                graph.replay()                                 # (capture records, it does not execute)
+                it += nblk
+                continue
+            iteration(it, stream)
+            it += 1
+            continue
+        last = it + 1 >= max_iters
+        Bc = W.shape[0]
+        iteration(it, stream)
         if check:
             AX = U[:, :n] @ At
             ATY = U[:, n:n + m] @ A
@@ -234,7 +275,11 @@ def solve_const_a(eng, A_bm: torch.Tensor, q_eval: torch.Tensor, settings):
                 active, status, iters, resid, rescaled = active[keep].contiguous(), status[keep].contiguous(), iters[keep].contiguous(), resid[keep].contiguous(), rescaled[keep].contiguous()
                 for key in ("Dinv", "G", "PHI", "inv_den"):
                     state[key] = state[key][keep].contiguous()
+                graph = None                                  # buffers replaced: capture again
+        it += 1
+    _tick("iterations")
     write_back()
+    _tick("write back")
     return out_x, out_y, out_s, out_iters, out_status, out_resid
 
 

@@ -145,6 +145,8 @@ int ce_ca_check(ce_handle h, int B, int lp, int iter, const ce_settings *setting
                 double *scale, double *sum_log, int *n_log, int *last_scale_iter, int *active, int *status, int *iters,
                 double *resid, int *rescaled, void *stream);
 int ce_ca_psd(ce_handle h, int B, int lp, double *U, const int *active, void *stream);
+/* w += alpha (u - ut) (+ renormalisation) as its own launch, for templates whose PSD blocks are projected after ce_ca_step */
+int ce_ca_update(ce_handle h, int B, int lp, double *W, const double *UT, const double *U, const int *active, int norm_after, double alpha, void *stream);
 int ce_ca_finish(ce_handle h, int B, int lp, int max_iters, const double *W, const double *UT, const double *U, const double *D,
                  const double *E, const double *b_hat, const double *c_hat, const double *sigma, const double *scale,
                  const int *active, int *status, int *iters, double *x, double *y, double *s, void *stream);

@@ -28,6 +28,7 @@ print("launch info", eng.launch_info(), "nnz_aug", tpl.nnz_aug)
 A_bm = torch.from_numpy(A_eval).to(dev).t().contiguous(); q_t = torch.from_numpy(q_eval).to(dev)
 st = make_settings(dict(eps=1e-6, max_iters=20000))
 eng.set_profiling(True)
+if B >= 1024: eng.solve(A_bm[:64].contiguous(), q_t[:, :64].contiguous(), make_settings(dict(eps=1e-6, max_iters=200))); torch.cuda.synchronize()   # warm-up
 t0 = time.perf_counter(); x, y, s, it, status, res = eng.solve(A_bm, q_t, st); torch.cuda.synchronize(); t1 = time.perf_counter()
 print("path", eng.last_path, "B", B)
 print("fwd wall %.1f ms  kernel %.1f ms  iters mean %.0f  status ok %.2f" % ((t1 - t0) * 1e3, eng.profile(0)[0], it.float().mean().item(), (status == 1).float().mean().item()))

@@ -27,9 +27,11 @@ dev = torch.device("cuda", 0)
 eng = ConeEngine(tpl.indices, tpl.indptr, tpl.n, tpl.m, cones, dev)
 A_bm = torch.from_numpy(A_eval).to(dev).t().contiguous(); q_t = torch.from_numpy(q_eval).to(dev)
 st = make_settings(dict(eps=eps, max_iters=20000))
+eng.solve(A_bm, q_t, st); torch.cuda.synchronize()      # warm-up: rocBLAS / rocSOLVER initialisation, kernel loading
 t0 = time.perf_counter(); x, y, s, it, status, res = eng.solve(A_bm, q_t, st); torch.cuda.synchronize(); t1 = time.perf_counter()
 print("path", eng.last_path, "B", B, "eps", eps, "fwd %.1f ms  iters mean %.0f max %d  solved %.3f" % ((t1 - t0) * 1e3, it.float().mean().item(), int(it.max()), (status == 1).float().mean().item()))
 dx = torch.ones_like(x); dy = torch.zeros_like(y)
+eng.vjp(A_bm, x, y, s, dx, dy); torch.cuda.synchronize()
 t0 = time.perf_counter(); dA, dq, adj = eng.vjp(A_bm, x, y, s, dx, dy); torch.cuda.synchronize(); t1 = time.perf_counter()
 print("bwd %.1f ms, LSQR not converged for %d" % ((t1 - t0) * 1e3, int((adj != 0).sum())))
 nb = min(B, 8)
