@@ -129,8 +129,8 @@ static size_t bwd_rt_lds_bytes(const DevT &T, int TI, int TJ, int BGR) {
 
 // second-generation forward variants {CHT, T1, CHA, T2, CHG, TG}
 // {CHT, T1, CHA, T2, CHG, TG, threads per workgroup}
-constexpr int F2_NV = 4;
-static const int F2_VARIANTS[F2_NV][7] = {{16, 2, 8, 2, 16, 2, 256}, {8, 8, 4, 8, 8, 4, 256}, {4, 26, 2, 26, 4, 14, 256}, {4, 30, 4, 26, 4, 26, 512}};
+constexpr int F2_NV = 5;
+static const int F2_VARIANTS[F2_NV][7] = {{16, 2, 8, 2, 16, 2, 256}, {8, 8, 4, 8, 8, 4, 256}, {4, 26, 2, 26, 4, 14, 256}, {8, 20, 2, 32, 8, 8, 512}, {4, 30, 4, 26, 4, 26, 512}};
 struct F2Dims { int MP, NPa, NPg, NP, VP, O_G; };
 static F2Dims f2_dims(int v) {
     const int *V = F2_VARIANTS[v];
@@ -277,7 +277,7 @@ int ce_create(const ce_template *tpl, int device, ce_handle *out) {
     SETATTR((k_forward<true, true>), LDS_LIMIT);  SETATTR((k_forward<true, false>), LDS_LIMIT);  SETATTR((k_forward<false, false>), LDS_LIMIT);
     SETATTR((k_forward_rt<8, 13, 7, 4, 13, 160, 4>), LDS_LIMIT); SETATTR((k_forward_rt<8, 16, 8, 4, 16, 208, 4>), LDS_LIMIT); SETATTR((k_forward_rt<4, 32, 32, 4, 32, 272, 2>), LDS_LIMIT);
     SETATTR((k_fwd2<16, 2, 8, 2, 16, 2, true>), LDS_LIMIT); SETATTR((k_fwd2<8, 8, 4, 8, 8, 4, true>), LDS_LIMIT); SETATTR((k_fwd2<4, 26, 2, 26, 4, 14, true>), LDS_LIMIT);
-    SETATTR((k_fwd2<4, 30, 4, 26, 4, 26, false, 512>), LDS_LIMIT);
+    SETATTR((k_fwd2<4, 30, 4, 26, 4, 26, false, 512>), LDS_LIMIT); SETATTR((k_fwd2<8, 20, 2, 32, 8, 8, false, 512>), LDS_LIMIT);
     SETATTR((k_fwd2<16, 2, 8, 2, 16, 2>), LDS_LIMIT); SETATTR((k_fwd2<8, 8, 4, 8, 8, 4>), LDS_LIMIT); SETATTR((k_fwd2<4, 26, 2, 26, 4, 14>), LDS_LIMIT);
     SETATTR((k_backward_rt<4, 4, 4, true>), LDS_LIMIT); SETATTR((k_backward_rt<7, 7, 4, true>), LDS_LIMIT); SETATTR((k_backward_rt<7, 7, 7, true>), LDS_LIMIT);
     SETATTR((k_backward_rt<7, 13, 7, false, 32>), LDS_LIMIT);
@@ -361,7 +361,7 @@ int ce_solve(ce_handle h, int B, const double *A_vals, long sA_k, long sA_b, con
         if (h->fwd_mode == 4 && T.ns > 0) {
             if (h->f2_variant == 0) LAUNCH_F2(16, 2, 8, 2, 16, 2, true); else if (h->f2_variant == 1) LAUNCH_F2(8, 8, 4, 8, 8, 4, true); else LAUNCH_F2(4, 26, 2, 26, 4, 14, true);
         } else if (h->fwd_mode == 4) {
-            if (h->f2_variant == 0) LAUNCH_F2(16, 2, 8, 2, 16, 2); else if (h->f2_variant == 1) LAUNCH_F2(8, 8, 4, 8, 8, 4); else if (h->f2_variant == 2) LAUNCH_F2(4, 26, 2, 26, 4, 14); else LAUNCH_F2(4, 30, 4, 26, 4, 26, false, 512);
+            if (h->f2_variant == 0) LAUNCH_F2(16, 2, 8, 2, 16, 2); else if (h->f2_variant == 1) LAUNCH_F2(8, 8, 4, 8, 8, 4); else if (h->f2_variant == 2) LAUNCH_F2(4, 26, 2, 26, 4, 14); else if (h->f2_variant == 3) LAUNCH_F2(8, 20, 2, 32, 8, 8, false, 512); else LAUNCH_F2(4, 30, 4, 26, 4, 26, false, 512);
         } else if (h->fwd_mode == 3) {
             if (h->rt_variant == 0) LAUNCH_RT(8, 13, 7, 4, 13, 160, 4); else if (h->rt_variant == 1) LAUNCH_RT(8, 16, 8, 4, 16, 208, 4); else LAUNCH_RT(4, 32, 32, 4, 32, 272, 2);
         } else if (h->fwd_mode == 0) LAUNCH_F(true, true); else if (h->fwd_mode == 1) LAUNCH_F(true, false); else LAUNCH_F(false, false);

@@ -157,7 +157,29 @@ def generate(n: int, cones: dict, B: int, seed: int = 0, batched=("A", "b", "c")
 # The configurations BASELINE.json names, at cone level
 CONFIGS = {
     "M": dict(n=50, cones={"z": 0, "l": 20, "q": [10] * 8}, B=4096),            # metric: n=50, m=100 SOC
-    "C2": dict(n=50, cones={"z": 0, "l": 100, "q": []}, B=4096),                 # box-QP-like nonneg only
+    "C2": dict(n=50, cones={"z": 0, "l": 100, "q": []}, B=4096),                 # nonneg cone only (LP)
+    "C2Q": dict(n=51, cones={"z": 0, "l": 100, "q": [52]}, B=4096),              # box QP n=50 in the SOC-epigraph form DIFFCP sees (box_qp_batch)
     "C3": dict(n=100, cones={"z": 0, "l": 10, "q": [11] * 10}, B=4096),          # SOCP n=100, 10 SOC cones
     "C4": dict(n=210, cones={"z": 20, "l": 0, "q": [], "s": [20]}, B=1024),      # SDP one 20x20 PSD cone
 }
+
+
+def box_qp_batch(nx: int, B: int, seed: int = 0):
+    """BASELINE config 2 as DIFFCP would see it: min ||F x - g||^2 s.t. lo <= x <= hi (F shared, g / lo / hi batched), written
+    with the epigraph variable u and the rotated cone  ||(1 - u, 2 (F x - g))|| <= 1 + u.  Variables (x, u): n = nx + 1; rows:
+    x - lo >= 0 (nx), hi - x >= 0 (nx), SOC(nx + 2): m = 3 nx + 2.  Returns solver-form (A (B,m,n), b (B,m), c (B,n), cones)."""
+    rng = np.random.default_rng(seed)
+    F = rng.standard_normal((nx, nx)) / np.sqrt(nx)
+    g = rng.standard_normal((B, nx))
+    lo = -0.5 - 0.5 * rng.random((B, nx)); hi = 0.5 + 0.5 * rng.random((B, nx))
+    n = nx + 1; m = 3 * nx + 2
+    A = np.zeros((m, n)); b = np.zeros((B, m))
+    A[:nx, :nx] = -np.eye(nx); b[:, :nx] = -lo                    # s = x - lo
+    A[nx:2 * nx, :nx] = np.eye(nx); b[:, nx:2 * nx] = hi          # s = hi - x
+    r = 2 * nx
+    A[r, nx] = -1.0; b[:, r] = 1.0                                # s0 = 1 + u
+    A[r + 1, nx] = 1.0; b[:, r + 1] = 1.0                         # s1 = 1 - u
+    A[r + 2:, :nx] = -2.0 * F; b[:, r + 2:] = -2.0 * g            # s_ = 2 (F x - g)
+    c = np.zeros((B, n)); c[:, nx] = 1.0
+    cones = {"z": 0, "l": 2 * nx, "q": [nx + 2]}
+    return np.broadcast_to(A, (B, m, n)).copy(), b, c, cones

@@ -268,3 +268,22 @@ def test_constant_A_path_with_psd_cone(monkeypatch):
     dA, dq, adj = eng.vjp(A_bm, xr, yr, sr, torch.from_numpy(dx).cuda(), torch.from_numpy(dy).cuda())
     assert (adj.cpu().numpy() == 0).all()
     assert np.abs(dq.cpu().numpy()[:n] - g["dc"].T).max() < 1e-5 * (1 + np.abs(g["dc"]).max())
+
+
+def test_box_qp_config2_epigraph_form():
+    """BASELINE config 2 (box-constrained QP, n=50) in the SOC-epigraph form DIFFCP canonicalises it to; the optimum is also
+    checked against projected gradient descent on the QP itself."""
+    from oracle import oracle
+    A, b, c, cones = P.box_qp_batch(50, 12, seed=3)
+    n = A.shape[2]
+    tpl = P.dense_template(n, cones, pattern=(A[0] != 0))
+    ref = oracle.solve_batch(A, b, c, cones, eps=1e-9, max_iters=100000)
+    eng, A_bm, x, y, s, iters, status, resid = gpu_solve(tpl, A, b, c, eps=1e-9, max_iters=100000)
+    assert (status == 1).all() and (ref["status"] == 1).all()
+    assert np.abs(x.cpu().numpy() - ref["x"]).max() < 1e-6 and np.abs(iters - ref["iters"]).max() <= 25
+    F = -A[0, 102:, :50] / 2.0; g = -b[:, 102:] / 2.0; lo = -b[:, :50]; hi = b[:, 50:100]
+    xq = np.clip(np.zeros((12, 50)), lo, hi)
+    Lc = np.linalg.norm(F, 2) ** 2
+    for _ in range(20000):
+        xq = np.clip(xq - (xq @ F.T - g) @ F / Lc, lo, hi)
+    assert np.abs(x.cpu().numpy()[:, :50] - xq).max() < 1e-5
