@@ -376,9 +376,10 @@ def vjp_const_a(eng, A_bm, x, y, s, dx, dy, batch_minor_out=False, atol=1e-12, b
     zz = torch.zeros(B, **f64); cs2 = -torch.ones(B, **f64); sn2 = torch.zeros(B, **f64)
     live = live & (alfa * beta > 0)
     itn_lim = iter_factor * (n + m)
-    itn = 0
-    while itn < itn_lim:
-        itn += 1
+
+    def lsqr_iter(st):
+        """one LSQR iteration as a pure function of the state tuple (so that a block of them can be captured in a HIP graph)"""
+        ux, uy, vx, vy, wx, wy, rx, ry, alfa, rhobar, phibar, anorm, ddnorm, xxnorm, zz, cs2, sn2, live = st
         tx, ty = N(vx, vy)
         ux, uy = tx - alfa[:, None] * ux, ty - alfa[:, None] * uy
         beta = nrm(ux, uy)
@@ -403,10 +404,36 @@ def vjp_const_a(eng, A_bm, x, y, s, dx, dy, batch_minor_out=False, atol=1e-12, b
         arnorm = alfa * tau.abs()
         test1 = rnorm / safe(bnorm); test2 = arnorm / (anorm * rnorm + 1e-300)
         rtol = btol + atol * anorm * xnorm / safe(bnorm)
-        done = (test1 <= rtol) | (test2 <= atol)
-        live = live & ~done
-        if itn % 16 == 0 and not bool(live.any().item()):
+        live = live & ~((test1 <= rtol) | (test2 <= atol))
+        return (ux, uy, vx, vy, wx, wy, rx, ry, alfa, rhobar, phibar, anorm, ddnorm, xxnorm, zz, cs2, sn2, live)
+
+    state = [ux, uy, vx, vy, wx, wy, rx, ry, alfa, rhobar, phibar, anorm, ddnorm, xxnorm, zz, cs2, sn2, live]
+    BLK = 16
+    import os
+    graph = None
+    if os.environ.get("CE_CA_GRAPH", "1") != "0":
+        # the loop is host-bound for small batches (~60 small launches per iteration): capture BLK iterations once and replay
+        torch.cuda.synchronize(dev)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            st = tuple(state)
+            for _ in range(BLK):
+                st = lsqr_iter(st)
+            for dst, src in zip(state, st):
+                dst.copy_(src)
+    itn = 0
+    while itn < itn_lim:
+        if graph is not None:
+            graph.replay()
+        else:
+            st = tuple(state)
+            for _ in range(BLK):
+                st = lsqr_iter(st)
+            state = list(st)
+        itn += BLK
+        if not bool(state[-1].any().item()):
             break
+    rx, ry, live = state[6], state[7], state[-1]
     adj = live.to(torch.int32)           # 1: LSQR hit its iteration limit for this instance
     # outputs: dA_ij = x_j r_y,i - y_i r_x,j ; db = -r_y ; dc = -r_x   (r_tau = 0), packed as [-dA.data, db[b_idx]], [dc, 0]
     K = eng.nnz_aug
