@@ -1,0 +1,77 @@
+"""Forward + backward throughput of every BASELINE.json configuration on one MI355X (plugin boundary, inputs resident in HBM,
+frontend-native batch-major layout), one JSON line per configuration -> profiles/<round>/configs.json.
+The headline metric stays bench.py (config M); this file backs the configuration table of DESIGN.md."""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from cvxpylayers_amd import problems as P
+from cvxpylayers_amd.interfaces.mi355_if import MI355_ctx, _CvxpyLayer
+
+dev = torch.device("cuda", 0)
+
+
+def portfolio(B, nw=500, kf=50, seed=0):
+    rng = np.random.default_rng(seed)
+    F = rng.standard_normal((nw, kf)) / np.sqrt(kf) * 0.3
+    n = nw + 1; cones = {"z": 1, "l": nw, "q": [kf + 1]}; m = P.cone_rows(cones)
+    A = np.zeros((m, n)); b = np.zeros(m)
+    A[0, :nw] = 1.0; b[0] = 1.0; A[1:1 + nw, :nw] = -np.eye(nw); A[1 + nw, nw] = -1.0; A[2 + nw:, :nw] = -F.T
+    mu = 0.05 + 0.1 * rng.random((B, nw))
+    c = np.concatenate([-mu, np.ones((B, 1))], axis=1)
+    return A, np.broadcast_to(b, (B, m)).copy(), c, cones
+
+
+def sdp(B, k=20, neq=20, seed=0):
+    rng = np.random.default_rng(seed)
+    d = k * (k + 1) // 2; n = d; cones = {"z": neq, "l": 0, "q": [], "s": [k]}; m = neq + d
+    A = np.zeros((m, n)); A[:neq] = rng.standard_normal((neq, n)) / np.sqrt(n); A[neq:] = -np.eye(d)
+    mk = lambda: P.sym_to_svec(np.stack([(lambda G: G @ G.T / k + 0.1 * np.eye(k))(rng.standard_normal((k, k))) for _ in range(B)]))
+    x0 = mk(); y0 = np.concatenate([rng.standard_normal((B, neq)), mk()], axis=1)
+    b = x0 @ A.T + np.concatenate([np.zeros((B, neq)), x0], axis=1)
+    return A, b, -(y0 @ A), cones
+
+
+def run(name, tpl, cones, A_eval, q_eval, eps, reps, note):
+    ctx = MI355_ctx(None, tpl.problem_data_index, cones, options={"eps": eps, "max_iters": 20000, "raise_on_error": False})
+    A_t = torch.from_numpy(A_eval).to(dev).t().contiguous().t().requires_grad_()      # (nnz_aug, B) view of batch-major storage
+    q_t = torch.from_numpy(q_eval).to(dev).requires_grad_()
+    B = A_eval.shape[1]
+
+    def step():
+        A_t.grad = None; q_t.grad = None
+        p, d, info, _ = _CvxpyLayer.apply(None, q_t, A_t, ctx, {}, True, None)
+        p.sum().backward()
+        return info
+    info = step(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        info = step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    it = info["iters"].float()
+    out = dict(config=name, B=B, n=tpl.n, m=tpl.m, cones={k: (v if not isinstance(v, list) else (f"{len(v)}x{v[0]}" if v else "-")) for k, v in cones.items()},
+               eps=eps, ms_per_step=dt * 1e3, problems_per_s=B / dt, iters_mean=float(it.mean()), iters_max=float(it.max()),
+               solved=float((info["status"] == 1).float().mean()), path=ctx.engine(dev).last_path, note=note)
+    print(json.dumps(out), flush=True)
+    return out
+
+
+res = []
+for key, B, note in (("M", 4096, "metric configuration"), ("C2", 4096, "nonneg cone only (random LP)"), ("C3", 4096, "SOCP n=100, 10 SOC(11)")):
+    cfg = P.CONFIGS[key]
+    tpl = P.dense_template(cfg["n"], cfg["cones"])
+    A, b, c = P.generate(cfg["n"], cfg["cones"], B, seed=0)
+    res.append(run(key, tpl, cfg["cones"], *tpl.values_from_dense(A, b, c), 1e-4, 5 if key != "C2" else 2, note))
+A, b, c, cones = P.box_qp_batch(50, 4096, seed=0)
+tpl = P.dense_template(A.shape[2], cones, pattern=(A[0] != 0))
+res.append(run("C2Q", tpl, cones, *tpl.values_from_dense(A, b, c), 1e-4, 5, "box QP n=50 in SOC-epigraph form (BASELINE config 2 as DIFFCP sees it); F shared, g/lo/hi batched"))
+A, b, c, cones = sdp(1024)
+tpl = P.dense_template(A.shape[1], cones, pattern=(A != 0), b_pattern=np.ones(A.shape[0], bool))
+res.append(run("C4", tpl, cones, *tpl.values_from_dense(np.broadcast_to(A, (1024,) + A.shape).copy(), b, c), 1e-4, 3, "SDP, one 20x20 PSD cone, A shared (BASELINE config 4)"))
+Bp = int(os.environ.get("C5_BATCH", "16384"))
+A, b, c, cones = portfolio(Bp)
+tpl = P.dense_template(A.shape[1], cones, pattern=(A != 0), b_pattern=(b[0] != 0))
+res.append(run("C5", tpl, cones, *tpl.values_from_dense(np.broadcast_to(A, (Bp,) + A.shape).copy(), b, c), 1e-4, 1, "portfolio n=501, A shared, returns batched (BASELINE config 5), 1 GPU"))
+out = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/configs.json"
+os.makedirs(os.path.dirname(out), exist_ok=True)
+json.dump(res, open(out, "w"), indent=1)
