@@ -293,6 +293,8 @@ class _CvxpyLayer(torch.autograd.Function):
             dy = ddual.to(device=eng.device, dtype=torch.float64).contiguous()
             dA, dq, adj = eng.vjp(A_bm, x, y, s, dx, dy, batch_minor_out=batch_minor_in)
         ctx.adj_status = adj
+        if merged_warn := bool((adj != 0).any()):      # degenerate active set / LSQR not converged: the gradient of those instances is zero or inexact
+            warnings.warn(f"MI355 adjoint: {int((adj != 0).sum())} of {batch_size} instances were flagged (degenerate active set or iteration limit); their gradients are unreliable")
         dA = dA.to(in_device)
         dq = dq.to(in_device)
         if originally_unbatched:
