@@ -224,6 +224,20 @@ class MI355_ctx:
         return self._engines[idx]
 
 
+def _warn_flagged_adjoint(eng):
+    """Deferred check of the previous backward's per-instance flags (degenerate active set: more active rows than the direct
+    solve holds / singular pivot, or LSQR iteration limit): their gradients are zero or inexact.  Done at the next call so that
+    the backward path itself never synchronises the host."""
+    pend = getattr(eng, "_pending_adj", None)
+    if pend is not None:
+        eng._pending_adj = None
+        adj, bs = pend
+        nbad = int((adj != 0).sum())
+        if nbad:
+            warnings.warn(f"MI355 adjoint: {nbad} of {bs} instances of the previous backward pass were flagged (degenerate active "
+                          "set or iteration limit); their gradients are unreliable")
+
+
 def _detect_batch_size(con_values) -> tuple[int, bool]:
     """diffcp_if.py:34-43"""
     if con_values.dim() == 1:
@@ -248,6 +262,7 @@ class _CvxpyLayer(torch.autograd.Function):
         if not torch.cuda.is_available():
             raise RuntimeError("MI355 solver needs a ROCm GPU; there is no CPU fallback (use solver='DIFFCP' on CPU)")
         eng = ctx.engine(dev)
+        _warn_flagged_adjoint(eng)
         merged_args = {**ctx.options}
         if solver_args:
             merged_args.update(solver_args)
@@ -293,8 +308,7 @@ class _CvxpyLayer(torch.autograd.Function):
             dy = ddual.to(device=eng.device, dtype=torch.float64).contiguous()
             dA, dq, adj = eng.vjp(A_bm, x, y, s, dx, dy, batch_minor_out=batch_minor_in)
         ctx.adj_status = adj
-        if merged_warn := bool((adj != 0).any()):      # degenerate active set / LSQR not converged: the gradient of those instances is zero or inexact
-            warnings.warn(f"MI355 adjoint: {int((adj != 0).sum())} of {batch_size} instances were flagged (degenerate active set or iteration limit); their gradients are unreliable")
+        eng._pending_adj = (adj, batch_size)     # inspected at the next call (no host sync on the backward path)
         dA = dA.to(in_device)
         dq = dq.to(in_device)
         if originally_unbatched:
