@@ -13,7 +13,7 @@ SO_PATH = os.path.join(_HERE, "csrc", "libcone_engine.so")
 
 # every symbol include/cone_engine.h declares
 SYMBOLS = ["ce_default_settings", "ce_create", "ce_destroy", "ce_last_error", "ce_solve", "ce_vjp",
-           "ce_transpose", "ce_parammap_apply", "ce_ca_step", "ce_ca_check", "ce_ca_psd", "ce_ca_update", "ce_ca_finish", "ce_set_profiling", "ce_get_profile", "ce_reset_profile", "ce_get_launch_info"]
+           "ce_transpose", "ce_parammap_apply", "ce_parammap_apply2", "ce_ca_step", "ce_ca_check", "ce_ca_psd", "ce_ca_update", "ce_ca_finish", "ce_set_profiling", "ce_get_profile", "ce_reset_profile", "ce_get_launch_info"]
 
 
 class CeTemplate(C.Structure):
@@ -62,6 +62,7 @@ def lib():
     L.ce_vjp.argtypes = [vp, C.c_int, dp, lg, lg, dp, lg, lg, dp, dp, dp, dp, dp, dp, lg, lg, dp, lg, lg, ip, vp]
     L.ce_transpose.argtypes = [vp, C.c_int, C.c_int, dp, dp, vp]
     L.ce_parammap_apply.argtypes = [C.c_int, C.c_int, C.c_int, ip, ip, dp, dp, lg, dp, lg, vp]
+    L.ce_parammap_apply2.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, ip, ip, dp, dp, lg, dp, lg, vp]
     L.ce_ca_step.argtypes = [vp, C.c_int, C.c_int, dp, dp, dp, dp, lg, dp, lg, dp, dp, dp, dp, ip, C.c_int, C.c_int, C.c_double, vp]
     L.ce_ca_check.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(CeSettings), dp, dp, dp, dp, lg, dp, lg, dp, dp, dp, dp, dp, dp, dp,
                               dp, dp, ip, ip, ip, ip, ip, dp, ip, vp]

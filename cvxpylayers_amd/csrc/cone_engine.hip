@@ -485,14 +485,37 @@ int ce_ca_finish(ce_handle h, int B, int lp, int max_iters, const double *W, con
     return CE_OK;
 }
 
-int ce_parammap_apply(int device, int B, int rows, const int *indptr, const int *indices, const double *vals,
-                      const double *P, long ld_p, double *out, long ld_out, void *stream) {
+extern "C++" {
+template <bool ACC>
+static int parammap_launch(int device, int B, int rows, int cols, const int *indptr, const int *indices, const double *vals,
+                           const double *P, long ld_p, double *out, long ld_out, void *stream) {
     if (B <= 0 || rows <= 0 || !indptr || !P || !out) { g_err = "null argument"; return CE_E_BADARG; }   // indices / vals may be null for an all-zero map
     HIPCHK(hipSetDevice(device));
-    dim3 grid((rows + 255) / 256, B);
-    hipLaunchKernelGGL(k_parammap, grid, dim3(256), 0, (hipStream_t)stream, rows, indptr, indices, vals, P, ld_p, out, ld_out);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds = (size_t)cols * sizeof(double);
+    if (cols > 0 && lds <= 64 * 1024 && B >= 256) {          // source row fits LDS (2+ workgroups per CU) and the batch fills the chip
+        static bool attr_done[2] = {false, false};
+        if (!attr_done[ACC]) { HIPCHK(hipFuncSetAttribute((const void *)k_parammap_lds<ACC>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); attr_done[ACC] = true; }
+        hipLaunchKernelGGL(k_parammap_lds<ACC>, dim3(B), dim3(512), lds, st, rows, cols, indptr, indices, vals, P, ld_p, out, ld_out);
+    } else if (B >= 1024) {
+        dim3 grid((rows + 255) / 256, (B + 3) / 4);
+        hipLaunchKernelGGL((k_parammap<4, ACC>), grid, dim3(256), 0, st, rows, B, indptr, indices, vals, P, ld_p, out, ld_out);
+    } else {
+        dim3 grid((rows + 255) / 256, B);
+        hipLaunchKernelGGL((k_parammap<1, ACC>), grid, dim3(256), 0, st, rows, B, indptr, indices, vals, P, ld_p, out, ld_out);
+    }
     HIPCHK(hipGetLastError());
     return CE_OK;
+}
+}  // extern "C++"
+int ce_parammap_apply(int device, int B, int rows, const int *indptr, const int *indices, const double *vals,
+                      const double *P, long ld_p, double *out, long ld_out, void *stream) {
+    return parammap_launch<false>(device, B, rows, 0, indptr, indices, vals, P, ld_p, out, ld_out, stream);
+}
+int ce_parammap_apply2(int device, int B, int rows, int cols, int accumulate, const int *indptr, const int *indices, const double *vals,
+                       const double *P, long ld_p, double *out, long ld_out, void *stream) {
+    return accumulate ? parammap_launch<true>(device, B, rows, cols, indptr, indices, vals, P, ld_p, out, ld_out, stream)
+                      : parammap_launch<false>(device, B, rows, cols, indptr, indices, vals, P, ld_p, out, ld_out, stream);
 }
 
 int ce_set_profiling(ce_handle h, int enable) { if (!h) return CE_E_BADARG; h->prof = enable != 0; return CE_OK; }

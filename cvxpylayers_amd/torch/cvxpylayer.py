@@ -120,31 +120,39 @@ class _DeviceCSR:
         return self._dev[key]
 
 
-def _spmm_bm(arrs, P: torch.Tensor) -> torch.Tensor:
-    """out (B, rows) = P (B, cols) . map^T on the device through the C ABI (ce_parammap_apply)."""
+def _spmm_bm(arrs, P: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+    """out (B, rows) = P (B, cols) . map^T on the device through the C ABI (ce_parammap_apply2); with `out` given, accumulate."""
     indptr, indices, vals, rows = arrs
     B = P.shape[0]
-    out = torch.empty((B, rows), dtype=torch.float64, device=P.device)
-    rc = _lib.lib().ce_parammap_apply(P.device.index or 0, B, rows, indptr.data_ptr(), indices.data_ptr(), vals.data_ptr(),
-                                      P.data_ptr(), P.stride(0), out.data_ptr(), out.stride(0),
-                                      C.c_void_p(torch.cuda.current_stream(P.device).cuda_stream))
-    _lib.check(rc, "ce_parammap_apply")
+    acc = out is not None
+    if out is None:
+        out = torch.empty((B, rows), dtype=torch.float64, device=P.device)
+    rc = _lib.lib().ce_parammap_apply2(P.device.index or 0, B, rows, P.shape[1], int(acc), indptr.data_ptr(), indices.data_ptr(), vals.data_ptr(),
+                                       P.data_ptr(), P.stride(0), out.data_ptr(), out.stride(0),
+                                       C.c_void_p(torch.cuda.current_stream(P.device).cuda_stream))
+    _lib.check(rc, "ce_parammap_apply2")
     return out
 
 
 class _ParamMapApply(torch.autograd.Function):
-    """Batch-major parameter-map evaluation with its transpose as backward (reference: _ScipySparseMatmul, :12-37)."""
+    """Batch-major evaluation of both parameter maps, (A_bm, q_bm) = (p A_map^T, p q_map^T), with the transposed maps as backward
+    accumulated into one p gradient (reference: _ScipySparseMatmul applied once per map, :12-37, and autograd's add)."""
 
     @staticmethod
-    def forward(ctx, dcsr: _DeviceCSR, p_bm: torch.Tensor) -> torch.Tensor:
-        fwd, bwd = dcsr.on(p_bm.device)
-        ctx.bwd = bwd
-        return _spmm_bm(fwd, p_bm.contiguous())
+    def forward(ctx, A_csr: _DeviceCSR, q_csr: _DeviceCSR, p_bm: torch.Tensor):
+        p_bm = p_bm.contiguous()
+        fA, bA = A_csr.on(p_bm.device)
+        fq, bq = q_csr.on(p_bm.device)
+        ctx.bwd = (bA, bq)
+        return _spmm_bm(fA, p_bm), _spmm_bm(fq, p_bm)
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, g):
-        return None, _spmm_bm(ctx.bwd, g.contiguous())
+    def backward(ctx, gA, gq):
+        bA, bq = ctx.bwd
+        g = _spmm_bm(bA, gA.contiguous())
+        _spmm_bm(bq, gq.contiguous(), out=g)
+        return None, None, g
 
 
 def _svec_to_symmetric(svec, k, batch, rows, cols, scale=None):
@@ -214,8 +222,21 @@ class CvxpyLayer(torch.nn.Module):
         opts = dict(solver_args or {})
         solver_ctx = get_solver_ctx(solver, _ParamProbView(template.A_structure), template.cone_dims, {}, opts, verbose)
         self.ctx = _Ctx(solver_ctx, solver)
-        self._A = _DeviceCSR(template.A_map)
-        self._q = _DeviceCSR(template.q_map)
+        # The maps address parameters Fortran-flattened (the reference's p_stack); the device copies are re-indexed once to the
+        # parameters' native row-major layout so flattening a batched parameter is a contiguous copy, not a strided transpose.
+        colmap = np.arange(template.n_params_total + 1)
+        for shape, off in zip(template.param_shapes, template.col_offsets):
+            size = int(np.prod(shape)) if len(shape) else 1
+            if len(shape) > 1:
+                colmap[off:off + size] = off + np.arange(size).reshape(shape).reshape(-1, order="F")
+        inv = np.empty_like(colmap)
+        inv[colmap] = np.arange(colmap.size)
+
+        def recol(mat):
+            # new column c holds the parameter entry that was at Fortran column f: new = old[:, f(c)], with f(c) = position of c in colmap
+            return sp.csr_array(sp.csr_array(mat)[:, inv])
+        self._A = _DeviceCSR(recol(template.A_map))
+        self._q = _DeviceCSR(recol(template.q_map))
         self.batch_sizes: list | None = None
 
     # ---- utils/parse_args.py:94-143
@@ -249,18 +270,29 @@ class CvxpyLayer(torch.nn.Module):
         return ()
 
     def _flatten_params(self, params, batch) -> torch.Tensor:
-        """(B, Ptot+1) row-major parameter matrix: Fortran-flattened parameters at their canonical columns, then the constant 1
+        """(B, Ptot+1) row-major parameter matrix: flattened parameters at their canonical column ranges, then the constant 1
         (the batch-major transpose of the reference's p_stack, torch/cvxpylayer.py:84-141)."""
         B = batch[0] if batch else 1
         dev = params[0].device
         tot = self.template.n_params_total
-        p = torch.empty((B, tot + 1), dtype=torch.float64, device=dev)
-        p[:, tot] = 1.0
-        for i, (value, shape) in enumerate(zip(params, self.template.param_shapes)):
+        flats = []
+        for i, value in enumerate(params):
             v = value.to(torch.float64)
             if self.batch_sizes[i] == 0:
                 v = v.unsqueeze(0).expand((B,) + tuple(v.shape))
-            flat = _reshape_fortran(v, (B, -1)) if len(shape) > 1 else v.reshape(B, -1)
+            flats.append(v.reshape(B, -1))                       # row-major; the device maps were re-indexed to match (__init__)
+        order = sorted(range(len(flats)), key=lambda i: self.template.col_offsets[i])
+        pos, tiled = 0, True
+        for i in order:
+            tiled = tiled and self.template.col_offsets[i] == pos
+            pos += flats[i].shape[1]
+        if tiled and pos == tot:
+            # one concatenation: its backward hands each parameter a view of the gradient (in-place slice writes would make autograd
+            # clone the whole (B, Ptot+1) gradient once per parameter)
+            return torch.cat([flats[i] for i in order] + [torch.ones((B, 1), dtype=torch.float64, device=dev)], dim=1)
+        p = torch.zeros((B, tot + 1), dtype=torch.float64, device=dev)
+        p[:, tot] = 1.0
+        for i, flat in enumerate(flats):
             off = self.template.col_offsets[i]
             p[:, off:off + flat.shape[1]] = flat
         return p
@@ -277,8 +309,7 @@ class CvxpyLayer(torch.nn.Module):
             raise RuntimeError("MI355 solver needs parameters on a ROCm device; there is no CPU fallback (use solver='DIFFCP' on CPU)")
         with torch.cuda.device(params[0].device):
             p_bm = self._flatten_params(params, batch)
-            A_bm = _ParamMapApply.apply(self._A, p_bm)          # (B, nnz_aug) engine-native
-            q_bm = _ParamMapApply.apply(self._q, p_bm)          # (B, n+1)
+            A_bm, q_bm = _ParamMapApply.apply(self._A, self._q, p_bm)   # (B, nnz_aug) engine-native, (B, n+1)
         A_eval, q_eval = A_bm.t(), q_bm.t()                     # the reference's (nnz_aug, B) / (n+1, B), as views
         if not batch:
             A_eval, q_eval = A_eval.squeeze(1), q_eval.squeeze(1)

@@ -125,6 +125,12 @@ int ce_transpose(ce_handle h, int rows, int cols, const double *in, double *out,
  */
 int ce_parammap_apply(int device, int B, int rows, const int *indptr, const int *indices, const double *vals,
                       const double *P, long ld_p, double *out, long ld_out, void *stream);
+/* Same map, with the number of source columns known (cols > 0: when a source row fits LDS it is staged there once per instance,
+ * so maps that transpose a matrix parameter stay one pass over HBM) and optional accumulation: accumulate != 0 computes
+ * out[b, r] += ... and leaves rows without entries untouched -- the sum of the A-map and q-map gradients into one p_stack
+ * gradient (autograd's add in the reference, torch/cvxpylayer.py:32-37 called once per map). */
+int ce_parammap_apply2(int device, int B, int rows, int cols, int accumulate, const int *indptr, const int *indices, const double *vals,
+                       const double *P, long ld_p, double *out, long ld_out, void *stream);
 
 /*
  * Constant-A path (A batch-invariant; only b, c vary): the matrix products of the iteration are batch GEMMs done by the
