@@ -15,7 +15,7 @@ import numpy as np
 
 def cone_rows(cones: dict) -> int:
     return (int(cones.get("z", 0)) + int(cones.get("l", 0)) + sum(int(d) for d in cones.get("q", []))
-            + sum(int(k) * (int(k) + 1) // 2 for k in cones.get("s", [])))
+            + sum(int(k) * (int(k) + 1) // 2 for k in cones.get("s", [])) + 3 * int(cones.get("ep", 0)))
 
 
 @dataclass
@@ -106,6 +106,14 @@ def _interior_point(rng, cones: dict, B: int):
             G = rng.standard_normal((B, k, k))
             S = G @ np.swapaxes(G, 1, 2) / k + 0.1 * np.eye(k)
             parts.append(sym_to_svec(S))
+    for _ in range(int(cones.get("ep", 0))):
+        # s0 in int K_exp = {y e^(x/y) < z}; y0 in int K_exp^* = {u < 0, -u e^(v/u) < e w}
+        yy = np.abs(rng.standard_normal((B, 1))) + 0.1
+        xx = rng.standard_normal((B, 1)) * yy
+        s_parts.append(np.concatenate([xx, yy, yy * np.exp(xx / yy) + 0.1 + np.abs(rng.standard_normal((B, 1)))], axis=1))
+        u = -(np.abs(rng.standard_normal((B, 1))) + 0.1)
+        v = rng.standard_normal((B, 1)) * np.abs(u)
+        y_parts.append(np.concatenate([u, v, -u * np.exp(v / u - 1.0) + 0.1 + np.abs(rng.standard_normal((B, 1)))], axis=1))
     return np.concatenate(s_parts, axis=1), np.concatenate(y_parts, axis=1)
 
 

@@ -25,7 +25,8 @@
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this file.
  *
  * Conventions (reference: diffcp_if.py:59-67): solver form  min c^T x  s.t.  A x + s = b, s in K,
- * K = zero(z) x nonneg(l) x SOC(q_1) x ... x PSD(s_1) x ...  (SCS row order z,l,q,s),
+ * K = zero(z) x nonneg(l) x SOC(q_1) x ... x PSD(s_1) x ... x EXP^nep  (SCS row order z,l,q,s,ep),
+ * EXP = cl{(x,y,z): y > 0, y exp(x/y) <= z} (SCS / CVXPY row order inside a triple),
  * SOC = (t, x) with ||x|| <= t; PSD = lower-triangular column-major svec with sqrt(2) off-diagonals
  * (cvxpylayers/torch/cvxpylayer.py:201-222).  A is dense row-major (m x n) per instance here; the
  * python wrapper densifies the CSC template.
@@ -42,6 +43,7 @@ typedef struct {
     int z, l, nq, ns;
     const int *q;
     const int *s;
+    int nep;               /* primal exponential cones (3 rows each), after the PSD blocks (SCS row order z,l,q,s,ep) */
 } oc_cones;
 
 typedef struct {
@@ -78,6 +80,7 @@ static int cone_rows(const oc_cones *k) {
     int m = k->z + k->l;
     for (int i = 0; i < k->nq; i++) m += k->q[i];
     for (int i = 0; i < k->ns; i++) m += k->s[i] * (k->s[i] + 1) / 2;
+    m += 3 * k->nep;
     return m;
 }
 
@@ -142,6 +145,104 @@ static void proj_psd(double *v, int k) {
     for (int i = 0; i < k; i++) for (int j = 0; j < k; j++) { double a = 0; for (int r = 0; r < k; r++) if (w[r] > 0) a += V[i * k + r] * w[r] * V[j * k + r]; T[i * k + j] = a; }
     mat_to_svec(T, k, v); free(S);
 }
+
+/* ------------------------------------------------------------------ exponential cone
+ * K_exp = cl{(x,y,z): y>0, y e^{x/y} <= z},  K_exp^* = cl{(u,v,w): u<0, -u e^{v/u} <= e w}.
+ * Projection of v=(r,s,t) (Moreau decomposition v = p - d, p in K, d in K*, p.d = 0; cf. Friberg, "Projection onto the
+ * exponential cone: a univariate root-finding problem", 2023, which SCS 3.2 follows): on the boundary
+ *     p = yy (rho, 1, e^rho),   d = mu (-1, rho-1, e^-rho)        (p.d = 0 identically)
+ * and  p - d = v  gives  yy = (s + r(rho-1))/D, mu = (r - s rho)/D, D = rho^2 - rho + 1, with rho the root of
+ *     h(rho) = (s + r(rho-1)) e^rho - (r - s rho) e^-rho - t D
+ * on the interval where yy > 0 and mu > 0 (h is increasing there).  Returns the case: 0 inside K, 1 inside -K*, 2 the
+ * (r<=0, s<=0) face, 3 boundary (rho, yy, mu returned). */
+typedef struct { int kase; double rho, yy, mu; } exp_info;   /* boundary case: rho <= 0: (yy, mu e^-rho) ; rho > 0: (yy e^rho, mu) */
+
+/* h scaled by e^rho (rho <= 0) or e^-rho (rho > 0): same sign, same root, no overflow anywhere */
+static double exp_h(double rho, double r, double s, double t) {
+    double ny = s + r * (rho - 1), nm = r - s * rho, D = rho * rho - rho + 1;
+    if (rho <= 0) { double E = exp(rho); return ny * E * E - nm - t * D * E; }
+    double F = exp(-rho); return ny - nm * F * F - t * D * F;
+}
+static void proj_exp(double *v, exp_info *inf) {
+    double r = v[0], s = v[1], t = v[2];
+    exp_info loc; if (!inf) inf = &loc;
+    inf->rho = inf->yy = inf->mu = 0;
+    if ((s > 0 && s * exp(r / s) <= t) || (r <= 0 && s == 0 && t >= 0)) { inf->kase = 0; return; }
+    if ((r > 0 && r * exp(s / r) <= -2.718281828459045235 * t) || (r == 0 && s <= 0 && t <= 0)) { inf->kase = 1; v[0] = v[1] = v[2] = 0; return; }
+    if (r <= 0 && s <= 0) { inf->kase = 2; v[1] = 0; if (t < 0) v[2] = 0; return; }
+    /* bracket: yy > 0 <=> s + r(rho-1) > 0, mu > 0 <=> r - s rho > 0 */
+    double lo, hi; int lo_inf = 0, hi_inf = 0;
+    if (r > 0 && s > 0) { lo = 1 - s / r; hi = r / s; }
+    else if (r > 0) { lo = 1 - s / r; hi = 0; hi_inf = 1; }              /* s <= 0 */
+    else { hi = r / s; lo = 0; lo_inf = 1; }                             /* r <= 0, s > 0 */
+    if (hi_inf) { double st = 1; hi = lo + st; while (exp_h(hi, r, s, t) < 0 && st < 1e15) { st *= 2; hi = lo + st; } }
+    if (lo_inf) { double st = 1; lo = hi - st; while (exp_h(lo, r, s, t) > 0 && st < 1e15) { st *= 2; lo = hi - st; } }
+    double rho = 0.5 * (lo + hi);
+    for (int it = 0; it < 300; it++) {
+        rho = 0.5 * (lo + hi);
+        if (exp_h(rho, r, s, t) > 0) hi = rho; else lo = rho;
+        if (hi - lo <= 1e-16 * (1 + fabs(rho))) break;
+    }
+    double D = rho * rho - rho + 1, ny = s + r * (rho - 1), nm = r - s * rho;
+    if (ny < 0) ny = 0; if (nm < 0) nm = 0;
+    inf->kase = 3; inf->rho = rho;
+    /* two algebraically equal forms; each is the accurate one on its side (the other multiplies a cancelled numerator by a huge exponential) */
+    if (rho <= 0) {
+        double E = exp(rho), yy = ny / D;
+        v[0] = yy * rho; v[1] = yy; v[2] = yy * E;
+        inf->yy = yy; inf->mu = v[2] - t;                      /* mu e^-rho, from the third equation */
+    } else {
+        double F = exp(-rho), mu = nm / D;
+        v[0] = r - mu; v[1] = s + mu * (rho - 1); v[2] = t + mu * F; if (v[1] < 0) v[1] = 0;
+        inf->mu = mu; inf->yy = v[2];                          /* yy e^rho */
+    }
+}
+static void inv3(const double *G, double *inv) {
+    double c00 = G[4] * G[8] - G[5] * G[7], c01 = G[5] * G[6] - G[3] * G[8], c02 = G[3] * G[7] - G[4] * G[6];
+    double det = G[0] * c00 + G[1] * c01 + G[2] * c02;
+    double t[9] = { c00, G[2] * G[7] - G[1] * G[8], G[1] * G[5] - G[2] * G[4],
+                    c01, G[0] * G[8] - G[2] * G[6], G[2] * G[3] - G[0] * G[5],
+                    c02, G[1] * G[6] - G[0] * G[7], G[0] * G[4] - G[1] * G[3] };
+    for (int i = 0; i < 9; i++) inv[i] = t[i] / det;
+}
+/* J (3x3 row-major) = D Pi_{K_exp}(v).  Boundary case: the projection is p = Y a(rho), p - v = d = M b(rho), where
+ *   rho <= 0:  a = (rho, 1, E),  b = (-E, (rho-1) E, 1),  E = e^rho    (Y = yy,  M = mu / E)
+ *   rho  > 0:  a = (rho F, F, 1), b = (-1, rho-1, F),     F = e^-rho   (Y = yy / F, M = mu)
+ * so G(Y, M, rho) = Y a - M b = v,  dG = [a | -b | Y a' - M b'],  dp = a dY + Y a' drho  =>  J = [a | 0 | Y a'] dG^-1. */
+static void dproj_exp(const double *v, double *J) {
+    double w[3] = { v[0], v[1], v[2] }; exp_info inf;
+    proj_exp(w, &inf);
+    memset(J, 0, 9 * sizeof(double));
+    if (inf.kase == 0) { J[0] = J[4] = J[8] = 1; return; }
+    if (inf.kase == 1) return;
+    if (inf.kase == 2) { J[0] = 1; J[8] = v[2] > 0 ? 1 : 0; return; }
+    double rho = inf.rho, Y = inf.yy, M = inf.mu, a[3], b[3], da[3], db[3];
+    if (rho < -690) { J[0] = J[4] = 1; return; }      /* e^rho underflows: p = (r, s, 0), the flat face */
+    if (rho > 690) { J[8] = 1; return; }              /* e^-rho underflows: p = (0, 0, t) */
+    if (rho <= 0) { double E = exp(rho); a[0] = rho; a[1] = 1; a[2] = E; da[0] = 1; da[1] = 0; da[2] = E;
+                    b[0] = -E; b[1] = (rho - 1) * E; b[2] = 1; db[0] = -E; db[1] = rho * E; db[2] = 0; }
+    else { double F = exp(-rho); a[0] = rho * F; a[1] = F; a[2] = 1; da[0] = (1 - rho) * F; da[1] = -F; da[2] = 0;
+           b[0] = -1; b[1] = rho - 1; b[2] = F; db[0] = 0; db[1] = 1; db[2] = -F; }
+    double G[9], inv[9];
+    for (int i = 0; i < 3; i++) { G[i * 3] = a[i]; G[i * 3 + 1] = -b[i]; G[i * 3 + 2] = Y * da[i] - M * db[i]; }
+    inv3(G, inv);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) J[i * 3 + j] = a[i] * inv[j] + Y * da[i] * inv[6 + j];
+}
+/* dual cone by Moreau:  Pi_{K*}(v) = v + Pi_K(-v),   D Pi_{K*}(v) = I - D Pi_K(-v) */
+static void proj_exp_dual(double *v) {
+    double w[3] = { -v[0], -v[1], -v[2] };
+    proj_exp(w, NULL);
+    for (int i = 0; i < 3; i++) v[i] += w[i];
+}
+static void dproj_exp_dual(const double *v, double *J) {
+    double w[3] = { -v[0], -v[1], -v[2] };
+    dproj_exp(w, J);
+    for (int i = 0; i < 9; i++) J[i] = ((i % 4 == 0) ? 1.0 : 0.0) - J[i];
+}
+/* test hooks (ctypes): which = 0 primal, 1 dual */
+void oc_proj_exp(double *v, int which) { if (which) proj_exp_dual(v); else proj_exp(v, NULL); }
+void oc_dproj_exp(const double *v, int which, double *J) { if (which) dproj_exp_dual(v, J); else dproj_exp(v, J); }
+
 /* y <- Pi_{K*}(y): zero cone K={0} has K* = R^z (free) */
 static void proj_dual_cone(double *y, const oc_cones *k) {
     int off = k->z;
@@ -149,6 +250,7 @@ static void proj_dual_cone(double *y, const oc_cones *k) {
     off += k->l;
     for (int c = 0; c < k->nq; c++) { proj_soc(y + off, k->q[c]); off += k->q[c]; }
     for (int c = 0; c < k->ns; c++) { proj_psd(y + off, k->s[c]); off += k->s[c] * (k->s[c] + 1) / 2; }
+    for (int c = 0; c < k->nep; c++) { proj_exp_dual(y + off); off += 3; }
 }
 
 /* ------------------------------------------------------------------ Cholesky of SPD n x n (row-major, lower) */
@@ -175,6 +277,7 @@ static void block_average(double *D, const oc_cones *k) {
     int off = k->z + k->l;
     for (int c = 0; c < k->nq; c++) { int d = k->q[c]; if (d > 0) { double s = 0; for (int i = 0; i < d; i++) s += D[off + i]; s /= d; for (int i = 0; i < d; i++) D[off + i] = s; } off += d; }
     for (int c = 0; c < k->ns; c++) { int d = k->s[c] * (k->s[c] + 1) / 2; if (d > 0) { double s = 0; for (int i = 0; i < d; i++) s += D[off + i]; s /= d; for (int i = 0; i < d; i++) D[off + i] = s; } off += d; }
+    for (int c = 0; c < k->nep; c++) { double s = (D[off] + D[off + 1] + D[off + 2]) / 3; D[off] = D[off + 1] = D[off + 2] = s; off += 3; }
 }
 static double clamp_scale(double v) { if (v < MIN_SCALE) return 1.0; if (v > MAX_SCALE) return MAX_SCALE; return v; }
 
@@ -377,6 +480,11 @@ static void dproj_dual_cone(const double *v, const oc_cones *K, const psd_cache 
     off += K->l;
     for (int c = 0; c < K->nq; c++) { dproj_soc(v + off, K->q[c], h + off, out + off); off += K->q[c]; }
     for (int c = 0; c < K->ns; c++) { dproj_psd(&pcs[c], K->s[c], h + off, out + off); off += K->s[c] * (K->s[c] + 1) / 2; }
+    for (int c = 0; c < K->nep; c++) {
+        double J[9]; dproj_exp_dual(v + off, J);
+        for (int i = 0; i < 3; i++) out[off + i] = J[i * 3] * h[off] + J[i * 3 + 1] * h[off + 1] + J[i * 3 + 2] * h[off + 2];
+        off += 3;
+    }
 }
 
 typedef struct { int n, m; const double *A, *b, *c, *v; const oc_cones *K; const psd_cache *pcs; double *t1, *t2; } adj_op;
@@ -532,9 +640,9 @@ int oc_num_threads(void) {
 
 /* A: [B][m][n] row-major dense, b: [B][m], c: [B][n]; outputs x [B][n], y,s [B][m], iters/status [B], resid [B][3] */
 int oc_solve_batch(int B, int n, int m, const double *A, const double *b, const double *c,
-                   int z, int l, int nq, const int *q, int ns, const int *s, const oc_opts *o,
+                   int z, int l, int nq, const int *q, int ns, const int *s, int nep, const oc_opts *o,
                    double *x, double *y, double *sv, int *iters, int *status, double *resid, int nthreads) {
-    oc_cones K = { z, l, nq, ns, q, s };
+    oc_cones K = { z, l, nq, ns, q, s, nep };
     if (cone_rows(&K) != m) return -1;
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
@@ -551,10 +659,10 @@ int oc_solve_batch(int B, int n, int m, const double *A, const double *b, const 
 
 /* ds may be NULL (the layer passes ds = 0, diffcp_if.py:84).  dA: [B][m][n] dense. lsqr_iters may be NULL. */
 int oc_adjoint_batch(int B, int n, int m, const double *A, const double *b, const double *c,
-                     int z, int l, int nq, const int *q, int ns, const int *s, const oc_opts *o,
+                     int z, int l, int nq, const int *q, int ns, const int *s, int nep, const oc_opts *o,
                      const double *x, const double *y, const double *sv, const double *dx, const double *dy, const double *ds,
                      double *dA, double *db, double *dc, int *lsqr_iters, int nthreads) {
-    oc_cones K = { z, l, nq, ns, q, s };
+    oc_cones K = { z, l, nq, ns, q, s, nep };
     if (cone_rows(&K) != m) return -1;
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);

@@ -71,7 +71,7 @@ def _p(a, t=C.c_double):
 def _cones(cones):
     q = np.ascontiguousarray(cones.get("q", []), dtype=np.int32)
     s = np.ascontiguousarray(cones.get("s", []), dtype=np.int32)
-    return int(cones.get("z", 0)), int(cones.get("l", 0)), q, s
+    return int(cones.get("z", 0)), int(cones.get("l", 0)), q, s, int(cones.get("ep", 0))
 
 
 def solve_batch(A, b, c, cones, nthreads=0, **opts):
@@ -80,11 +80,11 @@ def solve_batch(A, b, c, cones, nthreads=0, **opts):
     b = np.ascontiguousarray(b, dtype=np.float64)
     c = np.ascontiguousarray(c, dtype=np.float64)
     B, m, n = A.shape
-    z, l, q, s = _cones(cones)
+    z, l, q, s, nep = _cones(cones)
     o = make_opts(**opts)
     x = np.empty((B, n)); y = np.empty((B, m)); sv = np.empty((B, m))
     iters = np.zeros(B, dtype=np.int32); status = np.zeros(B, dtype=np.int32); resid = np.zeros((B, 3))
-    rc = lib().oc_solve_batch(B, n, m, _p(A), _p(b), _p(c), z, l, len(q), _p(q, C.c_int), len(s), _p(s, C.c_int),
+    rc = lib().oc_solve_batch(B, n, m, _p(A), _p(b), _p(c), z, l, len(q), _p(q, C.c_int), len(s), _p(s, C.c_int), nep,
                               C.byref(o), _p(x), _p(y), _p(sv), _p(iters, C.c_int), _p(status, C.c_int), _p(resid),
                               int(nthreads))
     if rc != 0:
@@ -98,7 +98,7 @@ def adjoint_batch(A, b, c, cones, x, y, s, dx, dy, ds=None, nthreads=0, **opts):
     b = np.ascontiguousarray(b, dtype=np.float64)
     c = np.ascontiguousarray(c, dtype=np.float64)
     B, m, n = A.shape
-    z, l, q, sd = _cones(cones)
+    z, l, q, sd, nep = _cones(cones)
     o = make_opts(**opts)
     x = np.ascontiguousarray(x, dtype=np.float64); y = np.ascontiguousarray(y, dtype=np.float64)
     s = np.ascontiguousarray(s, dtype=np.float64)
@@ -108,12 +108,26 @@ def adjoint_batch(A, b, c, cones, x, y, s, dx, dy, ds=None, nthreads=0, **opts):
         ds = np.ascontiguousarray(ds, dtype=np.float64)
         dsp = _p(ds)
     dA = np.empty((B, m, n)); db = np.empty((B, m)); dc = np.empty((B, n)); it = np.zeros(B, dtype=np.int32)
-    rc = lib().oc_adjoint_batch(B, n, m, _p(A), _p(b), _p(c), z, l, len(q), _p(q, C.c_int), len(sd), _p(sd, C.c_int),
+    rc = lib().oc_adjoint_batch(B, n, m, _p(A), _p(b), _p(c), z, l, len(q), _p(q, C.c_int), len(sd), _p(sd, C.c_int), nep,
                                 C.byref(o), _p(x), _p(y), _p(s), _p(dx), _p(dy), dsp, _p(dA), _p(db), _p(dc),
                                 _p(it, C.c_int), int(nthreads))
     if rc != 0:
         raise ValueError("cone dims do not match m")
     return dict(dA=dA, db=db, dc=dc, lsqr_iters=it)
+
+
+def proj_exp(v, dual=False):
+    """Projection of v (3,) onto the exponential cone (or its dual)."""
+    w = np.array(v, dtype=np.float64)
+    lib().oc_proj_exp(_p(w), int(dual))
+    return w
+
+
+def dproj_exp(v, dual=False):
+    """Jacobian (3,3) of that projection."""
+    w = np.array(v, dtype=np.float64); J = np.zeros((3, 3))
+    lib().oc_dproj_exp(_p(w), int(dual), _p(J))
+    return J
 
 
 def num_threads() -> int:

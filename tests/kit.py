@@ -123,3 +123,40 @@ def unbounded(p=1.0):
     """min x s.t. x <= p."""
     A = np.array([[1.0]]); b = np.array([p]); c = np.array([1.0])
     return A, b, c, {"z": 0, "l": 1, "q": []}
+
+
+def entropy_max(k):
+    """max sum_i -x_i log x_i  s.t. sum x = 1  ->  x = 1/k, value log k.   v = (x[k], t[k]); min -sum t;
+    (t_i, x_i, 1) in K_exp  <=>  x_i exp(t_i / x_i) <= 1  <=>  t_i <= -x_i log x_i."""
+    n, m = 2 * k, 1 + 3 * k
+    A = np.zeros((m, n)); b = np.zeros(m); c = np.zeros(n); c[k:] = -1.0
+    A[0, :k] = 1.0; b[0] = 1.0
+    for i in range(k):
+        r = 1 + 3 * i
+        A[r, k + i] = -1.0; A[r + 1, i] = -1.0; b[r + 2] = 1.0
+    return A, b, c, dict(z=1, l=0, q=[], s=[], ep=k), np.full(k, 1.0 / k)
+
+
+def logistic_regression(X, lab, lam):
+    """min sum_i log(1 + exp(-lab_i x_i^T w)) + lam * r,  ||w|| <= r   (cone form of tests/test_torch.py's logistic layer).
+    v = (w[d], t[N], a[N], b[N], r);  log(1+e^u) <= t  <=>  e^(u-t) + e^(-t) <= 1  <=>  (u-t,1,a), (-t,1,b) in K_exp, a + b <= 1."""
+    N, d = X.shape
+    n = d + 3 * N + 1
+    m = N + (d + 1) + 6 * N
+    A = np.zeros((m, n)); b = np.zeros(m); c = np.zeros(n); c[d:d + N] = 1.0; c[-1] = lam
+    for i in range(N):
+        A[i, d + N + i] = 1.0; A[i, d + 2 * N + i] = 1.0; b[i] = 1.0           # 1 - a_i - b_i >= 0
+    r0 = N
+    A[r0, -1] = -1.0                                                          # SOC (r, w)
+    for j in range(d):
+        A[r0 + 1 + j, j] = -1.0
+    e0 = r0 + d + 1
+    for i in range(N):
+        r = e0 + 6 * i
+        A[r, :d] = lab[i] * X[i]; A[r, d + i] = 1.0                           # s_x = -lab x^T w - t
+        b[r + 1] = 1.0
+        A[r + 2, d + N + i] = -1.0                                            # s_z = a_i
+        A[r + 3, d + i] = 1.0                                                 # s_x = -t
+        b[r + 4] = 1.0
+        A[r + 5, d + 2 * N + i] = -1.0                                        # s_z = b_i
+    return A, b, c, dict(z=0, l=N, q=[d + 1], s=[], ep=2 * N)

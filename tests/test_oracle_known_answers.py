@@ -113,7 +113,8 @@ def test_max_iters_one_gives_inaccurate_not_error():
     assert np.abs(x[:3] - xstar).max() > 1e-3
 
 
-@pytest.mark.parametrize("cones,n", [({"z": 3, "l": 8, "q": [5, 4]}, 10), ({"z": 0, "l": 4, "q": [3], "s": [3]}, 8)])
+@pytest.mark.parametrize("cones,n", [({"z": 3, "l": 8, "q": [5, 4]}, 10), ({"z": 0, "l": 4, "q": [3], "s": [3]}, 8),
+                                     ({"z": 2, "l": 4, "q": [4], "s": [], "ep": 3}, 8)])
 def test_adjoint_matches_finite_differences(cones, n):
     from cvxpylayers_amd import problems as P
     A, b, c = P.generate(n, cones, 1, seed=3)
@@ -144,3 +145,58 @@ def test_adjoint_matches_finite_differences(cones, n):
     # LSQR (diffcp default mode) converges to the same gradient
     for k in ("dA", "db", "dc"):
         np.testing.assert_allclose(gl[k], g[k], atol=1e-6 * (1 + np.abs(g[k]).max()))
+
+
+# ---------------------------------------------------------------- exponential cone (SCS row order z,l,q,s,ep)
+def _in_exp(p, tol):
+    x, y, z = p[0] - tol, p[1], p[2] + tol
+    return (y > 0 and y * np.exp(min(x / y, 700.0)) <= z) or (y <= tol and x <= tol and z >= -tol)
+
+
+def _in_exp_dual(p, tol):
+    u, v, w = p[0], p[1] + tol, p[2] + tol
+    return (u < 0 and -u * np.exp(min(v / u, 700.0)) <= np.e * w) or (abs(u) <= tol and v >= -tol and w >= -tol)
+
+
+def test_exp_cone_projection_is_the_moreau_decomposition():
+    """p = Pi_K(v): p in K, p - v in K*, p.(p - v) = 0 characterise the projection uniquely; the Jacobian is checked against
+    central differences, is symmetric and has eigenvalues in [0, 1]."""
+    rng = np.random.default_rng(0)
+    for trial in range(1500):
+        v = rng.standard_normal(3) * 10 ** rng.uniform(-2, 2)
+        p = oracle.proj_exp(v); d = p - v
+        sc = 1 + np.linalg.norm(v)
+        assert _in_exp(p, 1e-9 * sc) and _in_exp_dual(d, 1e-9 * sc), (v, p)
+        assert abs(p @ d) <= 1e-12 * sc * sc
+        np.testing.assert_array_equal(oracle.proj_exp(v, dual=True), v + oracle.proj_exp(-v))
+        J = oracle.dproj_exp(v)
+        h = 1e-6 * max(1.0, np.linalg.norm(v))
+        Jfd = np.stack([(oracle.proj_exp(v + h * e) - oracle.proj_exp(v - h * e)) / (2 * h) for e in np.eye(3)], axis=1)
+        assert np.abs(J - Jfd).max() < 1e-5, (v, J, Jfd)
+        assert np.abs(J - J.T).max() < 1e-7 * (1 + np.abs(J).max())
+        ev = np.linalg.eigvalsh((J + J.T) / 2)
+        assert ev.min() > -1e-7 and ev.max() < 1 + 1e-7
+
+
+def test_entropy_maximisation_is_uniform():
+    A, b, c, cones, xstar = kit.entropy_max(5)
+    x, y, s, st, it = solve1(A, b, c, cones)
+    assert st == 1
+    np.testing.assert_allclose(x[:5], xstar, atol=1e-7)
+    np.testing.assert_allclose(-c @ x, np.log(5.0), atol=1e-7)
+    np.testing.assert_allclose(y[0], np.log(5.0) - 1.0, atol=1e-6)    # multiplier of sum x = 1:  d/dx(-x log x) = -log x - 1
+
+
+def test_logistic_regression_matches_a_smooth_solver():
+    # the layer of reference tests/test_torch.py:158-230 (logistic regression through the exponential cone), here with an l2 budget
+    from scipy.optimize import minimize
+    rng = np.random.default_rng(1)
+    N, d, lam = 12, 3, 0.5
+    X = rng.standard_normal((N, d)); lab = np.sign(X @ np.array([1.0, -2.0, 0.5]) + 0.3 * rng.standard_normal(N))
+    A, b, c, cones = kit.logistic_regression(X, lab, lam)
+    x, y, s, st, it = solve1(A, b, c, cones, eps=1e-9)
+    assert st == 1
+    obj = lambda w: np.logaddexp(0.0, -lab * (X @ w)).sum() + lam * np.linalg.norm(w)
+    ref = minimize(obj, np.ones(d), method="BFGS", options=dict(gtol=1e-10))
+    np.testing.assert_allclose(c @ x, ref.fun, atol=1e-6)
+    np.testing.assert_allclose(x[:d], ref.x, atol=2e-4)
