@@ -54,8 +54,8 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
     double *pivrow = p; p += BGR * TI;   // pivot value of the row that served as pivot
     double *pinfo = p; p += 2;          // pivot value per buffer
     double *red = p; p += NWB * 8;
-    double *psdU = p, *psdEv = p, *lamr = p, *psdScr = p;     // PSD: eigenvectors per cone, eigenvalues, DPi eigenvalue per rotated row, scratch
-    if constexpr (PSD) { psdU = p; p += T.ns * T.maxs * T.maxs; psdEv = p; p += T.ns * T.maxs; lamr = p; p += m; psdScr = p; p += 8 * T.maxs * T.maxs + 2 * T.maxs + 8; }
+    double *psdU = p, *psdEv = p, *lamr = p, *psdScr = p, *expW = p;     // PSD: eigenvectors per cone, eigenvalues, DPi eigenvalue per rotated row, scratch
+    if constexpr (PSD) { psdU = p; p += T.ns * T.maxs * T.maxs; psdEv = p; p += T.ns * T.maxs; lamr = p; p += m; psdScr = p; p += 8 * T.maxs * T.maxs + 2 * T.maxs + 8; expW = p; p += 9 * T.nep; }
     double *U = p; p += bwd_rt_union_doubles(n, m, nqs, TI, TJ, BGR);
     double *ay = U, *as = U + nqs * n;                              // A_c^T e_y, A_c^T e_s
     double *colbuf = U, *rowbuf = U + 2 * BGR * TI;
@@ -146,7 +146,36 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
                 __syncthreads();
             }
         }
-    }
+            // Exponential cones: S = D Pi_K*(v_c) = W diag(theta) W^T (3x3, one thread per cone).  The triple's rows are rotated,
+        // A_c <- W^T A_c, exactly like a PSD block: afterwards each row is an equality (theta = 1), free (0) or weighted row.
+        if (T.nep > 0) {
+            for (int c = tid; c < T.nep; c += NTB) {
+                const int r0 = T.eoff + 3 * c;
+                double W[9], th[3];
+                exp_dual_eig(vv + r0, W, th);
+                const double *h = dyg + (size_t)inst * m + r0;
+#pragma unroll
+                for (int a = 0; a < 3; a++) {
+                    const double t = W[a] * h[0] + W[3 + a] * h[1] + W[6 + a] * h[2];     // (W^T dy)_a
+                    double Bv = th[a];
+                    if (Bv < 1e-9) Bv = 0.0; else if (Bv > 1.0 - 1e-9) Bv = 1.0;
+                    lamr[r0 + a] = Bv; dv[r0 + a] = Bv * t;
+                    rkind[r0 + a] = (Bv == 1.0) ? RK_EQ : (Bv == 0.0 ? RK_FREE : RK_MIX);
+                }
+#pragma unroll
+                for (int k = 0; k < 9; k++) expW[9 * c + k] = W[k];
+            }
+            __syncthreads();
+            for (int idx = tid; idx < T.nep * n; idx += NTB) {
+                const int c = idx / n, j = idx - c * n, r0 = T.eoff + 3 * c;
+                const double *W = expW + 9 * c;
+                const double a0 = A[r0 * lda + j], a1 = A[(r0 + 1) * lda + j], a2 = A[(r0 + 2) * lda + j];
+#pragma unroll
+                for (int a = 0; a < 3; a++) A[(r0 + a) * lda + j] = W[a] * a0 + W[3 + a] * a1 + W[6 + a] * a2;
+            }
+            __syncthreads();
+        }
+}
     // ---- equality numbering: ballot prefix sums (rows in order, then one e_y row per boundary cone)
     {
         int base = 0;
@@ -233,7 +262,7 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
                 acc += as[c * n + j] * esd + a / (1 - lam);
             }
             if constexpr (PSD) {
-                for (int t = T.soff[0] + part; t < T.soff[T.ns]; t += 4)
+                for (int t = T.soff[0] + part; t < T.eoff + 3 * T.nep; t += 4)
                     if (rkind[t] == RK_MIX) acc = fma(A[t * lda + j], dv[t] / (1 - lamr[t]), acc);
             }
         }
@@ -276,7 +305,7 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
             }
     }
     if constexpr (PSD) {   // weighted rows of rotated PSD blocks: H += theta_t a_t^T a_t
-        for (int t = T.soff[0]; t < T.soff[T.ns]; t++) {
+        for (int t = T.soff[0]; t < T.eoff + 3 * T.nep; t++) {
             if (rkind[t] != RK_MIX) continue;              // uniform
             const double th = lamr[t] / (1 - lamr[t]);
             const double *row = A + t * lda;
@@ -460,7 +489,7 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
     }
     __syncthreads();
     if constexpr (PSD) {   // r~ in the rotated basis, then r_y,c = Q r~ = svec(U smat(r~) U^T)
-        for (int t = T.soff[0] + tid; t < T.soff[T.ns]; t += NTB) {
+        for (int t = T.soff[0] + tid; t < T.eoff + 3 * T.nep; t += NTB) {
             const int rk = rkind[t];
             vv[t] = (rk == RK_EQ) ? bv[eqrow[t]] : (rk == RK_FREE ? dv[t] : (dv[t] - lamr[t] * qv2[t]) / (1 - lamr[t]));
         }
@@ -489,6 +518,14 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
             }
             __syncthreads();
         }
+        for (int c = tid; c < T.nep; c += NTB) {                     // r_y,c = W r~
+            const int r0 = T.eoff + 3 * c;
+            const double *W = expW + 9 * c;
+            const double t0 = vv[r0], t1 = vv[r0 + 1], t2 = vv[r0 + 2];
+#pragma unroll
+            for (int a = 0; a < 3; a++) vv[r0 + a] = W[3 * a] * t0 + W[3 * a + 1] * t1 + W[3 * a + 2] * t2;
+        }
+        __syncthreads();
     }
     CE_STAMP(6);
     // ---- outputs in the boundary convention: dA_eval = [-dA.data, db[b_idx]], dq_eval = [dc, 0]   (diffcp_if.py:91-92)

@@ -21,6 +21,7 @@ struct DevT {
     int ns, maxs;         // PSD cones, largest order
     const int *soff;      // [ns+1] first row of PSD cone c (svec blocks follow the SOCs, SCS row order z,l,q,s)
     const int *sord;      // [ns] order k of PSD cone c
+    int nep, eoff;        // exponential cones (3 rows each) and their first row (after the PSD blocks: SCS row order z,l,q,s,ep)
 };
 
 thread_local std::string g_err;

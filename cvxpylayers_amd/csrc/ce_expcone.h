@@ -1,0 +1,140 @@
+// ce_expcone.h -- exponential cone  K_exp = cl{(x,y,z): y > 0, y e^(x/y) <= z}  (SCS / CVXPY row order inside a triple).
+//
+// Projection of v = (r,s,t) by the Moreau decomposition v = p - d, p in K, d in K*, p.d = 0: on the boundary
+//     p = yy (rho, 1, e^rho),   d = mu (-1, rho-1, e^-rho)          (p.d = 0 identically)
+// and p - d = v gives yy = (s + r(rho-1))/D, mu = (r - s rho)/D, D = rho^2 - rho + 1, with rho the root of
+//     h(rho) = (s + r(rho-1)) e^rho - (r - s rho) e^-rho - t D
+// on the interval where yy > 0 and mu > 0 (univariate root finding; Friberg 2023, the method SCS 3.2 adopted).  h is evaluated
+// scaled by e^rho (rho <= 0) or e^-rho (rho > 0) so nothing overflows; the root is found by a bracketed Newton iteration that
+// starts from the previous ADMM iteration's root of the same cone.  One thread per cone.
+// The solver projects onto the DUAL cone: Pi_K*(v) = v + Pi_K(-v), D Pi_K*(v) = I - D Pi_K(-v).
+#pragma once
+
+struct ExpInfo { int kase; double rho, Y, M; };   // kase 0 inside K, 1 inside -K*, 2 the (r<=0, s<=0) face, 3 boundary
+
+__device__ __forceinline__ void exp_g(double rho, double r, double s, double t, double &g, double &dg) {
+    const double ny = s + r * (rho - 1), nm = r - s * rho, D = rho * rho - rho + 1, dD = 2 * rho - 1;
+    if (rho <= 0) {
+        const double E = exp(rho), E2 = E * E;
+        g = ny * E2 - nm - t * D * E;
+        dg = (r + 2 * ny) * E2 + s - t * (dD + D) * E;
+    } else {
+        const double F = exp(-rho), F2 = F * F;
+        g = ny - nm * F2 - t * D * F;
+        dg = r + (s + 2 * nm) * F2 - t * (dD - D) * F;
+    }
+}
+
+// p <- Pi_K(p) in place; rho0: warm start (ignored unless inside the bracket).
+__device__ __noinline__ void exp_project(double *p, double rho0, ExpInfo *inf) {
+    const double r = p[0], s = p[1], t = p[2];
+    inf->rho = rho0; inf->Y = 0; inf->M = 0;
+    if ((s > 0 && s * exp(r / s) <= t) || (r <= 0 && s == 0 && t >= 0)) { inf->kase = 0; return; }
+    if ((r > 0 && r * exp(s / r) <= -2.718281828459045235 * t) || (r == 0 && s <= 0 && t <= 0)) { inf->kase = 1; p[0] = p[1] = p[2] = 0; return; }
+    if (r <= 0 && s <= 0) { inf->kase = 2; p[1] = 0; if (t < 0) p[2] = 0; return; }
+    // bracket: yy > 0 <=> s + r(rho-1) > 0 ; mu > 0 <=> r - s rho > 0.   g < 0 at lo, g > 0 at hi.
+    double lo, hi; bool lo_inf = false, hi_inf = false;
+    if (r > 0 && s > 0) { lo = 1 - s / r; hi = r / s; }
+    else if (r > 0) { lo = 1 - s / r; hi = 0; hi_inf = true; }
+    else { hi = r / s; lo = 0; lo_inf = true; }
+    double rho = rho0;
+    if (!(rho > lo || lo_inf) || !(rho < hi || hi_inf) || !(fabs(rho) <= 1000.0)) rho =   // (also rejects NaN / stale LDS contents)
+        hi_inf ? lo + 1 : (lo_inf ? hi - 1 : 0.5 * (lo + hi));
+    double st = 1;
+    for (int it = 0; it < 120; it++) {
+        double g, dg; exp_g(rho, r, s, t, g, dg);
+        if (g > 0) { hi = rho; hi_inf = false; } else if (g < 0) { lo = rho; lo_inf = false; } else break;
+        double nr = rho - g / dg;
+        const bool ok = (dg > 0) && (lo_inf || nr > lo) && (hi_inf || nr < hi) && fabs(nr - rho) < 64.0;
+        if (!ok) {
+            if (hi_inf) { st *= 2; nr = rho + st; }
+            else if (lo_inf) { st *= 2; nr = rho - st; }
+            else nr = 0.5 * (lo + hi);
+        }
+        const double step = fabs(nr - rho);
+        rho = nr;
+        if (step <= 4e-16 * (1 + fabs(rho))) break;
+        if (!lo_inf && !hi_inf && hi - lo <= 2e-16 * (1 + fabs(rho))) break;
+    }
+    const double D = rho * rho - rho + 1;
+    double ny = s + r * (rho - 1), nm = r - s * rho;
+    if (ny < 0) ny = 0;
+    if (nm < 0) nm = 0;
+    inf->kase = 3; inf->rho = rho;
+    // two algebraically equal forms; each is the accurate one on its side
+    if (rho <= 0) {
+        const double E = exp(rho), yy = ny / D;
+        p[0] = yy * rho; p[1] = yy; p[2] = yy * E;
+        inf->Y = yy; inf->M = p[2] - t;                 // mu e^-rho (third equation)
+    } else {
+        const double F = exp(-rho), mu = nm / D;
+        p[0] = r - mu; p[1] = fmax(s + mu * (rho - 1), 0.0); p[2] = t + mu * F;
+        inf->M = mu; inf->Y = p[2];                     // yy e^rho
+    }
+}
+
+// y-block of the ADMM cone step: v <- Pi_K*(v) = v + Pi_K(-v).   *rho_state keeps the root between iterations.
+__device__ __forceinline__ void exp_project_dual(double *v, double *rho_state) {
+    double w[3] = {-v[0], -v[1], -v[2]};
+    ExpInfo inf;
+    exp_project(w, *rho_state, &inf);
+    *rho_state = inf.rho;
+    v[0] += w[0]; v[1] += w[1]; v[2] += w[2];
+}
+
+// J (row-major 3x3) = D Pi_K(v).  Boundary: p = Y a(rho), p - v = M b(rho) with
+//   rho <= 0: a = (rho, 1, E), b = (-E, (rho-1)E, 1) ;  rho > 0: a = (rho F, F, 1), b = (-1, rho-1, F)
+// G(Y, M, rho) = Y a - M b = v  =>  dG = [a | -b | Y a' - M b'],  dp = a dY + Y a' drho  =>  J = [a | 0 | Y a'] dG^-1.
+__device__ __noinline__ void exp_dproject(const double *v, double *J) {
+    double w[3] = {v[0], v[1], v[2]};
+    ExpInfo inf;
+    exp_project(w, 0.0, &inf);
+    for (int i = 0; i < 9; i++) J[i] = 0;
+    if (inf.kase == 0) { J[0] = J[4] = J[8] = 1; return; }
+    if (inf.kase == 1) return;
+    if (inf.kase == 2) { J[0] = 1; J[8] = v[2] > 0 ? 1.0 : 0.0; return; }
+    const double rho = inf.rho, Y = inf.Y, M = inf.M;
+    if (rho < -690) { J[0] = J[4] = 1; return; }       // e^rho underflows: p = (r, s, 0)
+    if (rho > 690) { J[8] = 1; return; }               // e^-rho underflows: p = (0, 0, t)
+    double a[3], b[3], da[3], db[3];
+    if (rho <= 0) { const double E = exp(rho); a[0] = rho; a[1] = 1; a[2] = E; da[0] = 1; da[1] = 0; da[2] = E;
+                    b[0] = -E; b[1] = (rho - 1) * E; b[2] = 1; db[0] = -E; db[1] = rho * E; db[2] = 0; }
+    else { const double F = exp(-rho); a[0] = rho * F; a[1] = F; a[2] = 1; da[0] = (1 - rho) * F; da[1] = -F; da[2] = 0;
+           b[0] = -1; b[1] = rho - 1; b[2] = F; db[0] = 0; db[1] = 1; db[2] = -F; }
+    double G[9];
+    for (int i = 0; i < 3; i++) { G[i * 3] = a[i]; G[i * 3 + 1] = -b[i]; G[i * 3 + 2] = Y * da[i] - M * db[i]; }
+    const double c00 = G[4] * G[8] - G[5] * G[7], c01 = G[5] * G[6] - G[3] * G[8], c02 = G[3] * G[7] - G[4] * G[6];
+    const double idet = 1.0 / (G[0] * c00 + G[1] * c01 + G[2] * c02);
+    const double i0[3] = {c00 * idet, (G[2] * G[7] - G[1] * G[8]) * idet, (G[1] * G[5] - G[2] * G[4]) * idet};      // row 0 of G^-1
+    const double i2[3] = {c02 * idet, (G[1] * G[6] - G[0] * G[7]) * idet, (G[0] * G[4] - G[1] * G[3]) * idet};      // row 2 of G^-1
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) J[i * 3 + j] = a[i] * i0[j] + Y * da[i] * i2[j];
+}
+
+// Eigendecomposition of the symmetric 3x3  S = D Pi_K*(v) = I - D Pi_K(-v):  S = W diag(th) W^T (columns of W), cyclic Jacobi.
+__device__ __noinline__ void exp_dual_eig(const double *v, double *W, double *th) {
+    double w[3] = {-v[0], -v[1], -v[2]}, J[9];
+    exp_dproject(w, J);
+    double S[3][3];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) S[i][j] = ((i == j) ? 1.0 : 0.0) - 0.5 * (J[i * 3 + j] + J[j * 3 + i]);
+    double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    for (int sweep = 0; sweep < 12; sweep++) {
+        const double off = fabs(S[0][1]) + fabs(S[0][2]) + fabs(S[1][2]);
+        if (off <= 1e-300) break;
+#pragma unroll
+        for (int pq = 0; pq < 3; pq++) {
+            const int p = pq == 2 ? 1 : 0, q = pq == 0 ? 1 : 2;
+            const double apq = S[p][q];
+            if (fabs(apq) <= 1e-18 * (fabs(S[p][p]) + fabs(S[q][q]))) { S[p][q] = S[q][p] = 0; continue; }
+            const double tau = (S[q][q] - S[p][p]) / (2 * apq);
+            const double tt = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1 + tau * tau));
+            const double c = 1.0 / sqrt(1 + tt * tt), sn = tt * c;
+#pragma unroll
+            for (int k = 0; k < 3; k++) { const double skp = S[k][p], skq = S[k][q]; S[k][p] = c * skp - sn * skq; S[k][q] = sn * skp + c * skq; }
+#pragma unroll
+            for (int k = 0; k < 3; k++) { const double spk = S[p][k], sqk = S[q][k]; S[p][k] = c * spk - sn * sqk; S[q][k] = sn * spk + c * sqk; }
+#pragma unroll
+            for (int k = 0; k < 3; k++) { const double vkp = V[k][p], vkq = V[k][q]; V[k][p] = c * vkp - sn * vkq; V[k][q] = sn * vkp + c * vkq; }
+        }
+    }
+    for (int i = 0; i < 3; i++) { th[i] = S[i][i]; for (int j = 0; j < 3; j++) W[i * 3 + j] = V[i][j]; }
+}

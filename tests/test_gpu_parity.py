@@ -287,3 +287,32 @@ def test_box_qp_config2_epigraph_form():
     for _ in range(20000):
         xq = np.clip(xq - (xq @ F.T - g) @ F / Lc, lo, hi)
     assert np.abs(x.cpu().numpy()[:, :50] - xq).max() < 1e-5
+
+
+# ------------------------------------------------------------------ exponential cones (SCS row order z,l,q,s,ep)
+def test_exp_cone_forward_and_adjoint_parity():
+    run_parity(8, {"z": 2, "l": 4, "q": [4], "s": [], "ep": 3}, 16, seed=1, eps=1e-9, max_iters=200000)
+
+
+def test_exp_cone_with_psd_block_parity():
+    run_parity(9, {"z": 1, "l": 2, "q": [3], "s": [3], "ep": 2}, 8, seed=4, eps=1e-9, max_iters=200000)
+
+
+def test_entropy_and_logistic_known_answers_on_gpu():
+    # entropy maximisation -> uniform distribution; logistic regression against a smooth solver (tests/test_torch.py:158-230 layer)
+    from scipy.optimize import minimize
+    A, b, c, cones, xstar = kit.entropy_max(6)
+    tpl = P.dense_template(A.shape[1], cones)
+    *_, x, y, s, iters, status, resid = gpu_solve(tpl, A[None], b[None], c[None], eps=1e-10, max_iters=100000)
+    assert status[0] == 1
+    np.testing.assert_allclose(x.cpu().numpy()[0][:6], xstar, atol=1e-6)
+    rng = np.random.default_rng(1)
+    N, d, lam = 12, 3, 0.5
+    X = rng.standard_normal((N, d)); lab = np.sign(X @ np.array([1.0, -2.0, 0.5]) + 0.3 * rng.standard_normal(N))
+    A, b, c, cones = kit.logistic_regression(X, lab, lam)
+    tpl = P.dense_template(A.shape[1], cones)
+    *_, x, y, s, iters, status, resid = gpu_solve(tpl, A[None], b[None], c[None], eps=1e-9, max_iters=200000)
+    assert status[0] == 1
+    ref = minimize(lambda w: np.logaddexp(0.0, -lab * (X @ w)).sum() + lam * np.linalg.norm(w), np.ones(d), method="BFGS", options=dict(gtol=1e-10))
+    np.testing.assert_allclose(c @ x.cpu().numpy()[0], ref.fun, atol=1e-6)
+    np.testing.assert_allclose(x.cpu().numpy()[0][:d], ref.x, atol=2e-4)
