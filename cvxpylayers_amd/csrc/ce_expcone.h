@@ -9,6 +9,9 @@
 // starts from the previous ADMM iteration's root of the same cone.  One thread per cone.
 // The solver projects onto the DUAL cone: Pi_K*(v) = v + Pi_K(-v), D Pi_K*(v) = I - D Pi_K(-v).
 #pragma once
+#ifndef EXP_COUNT_ITER
+#define EXP_COUNT_ITER
+#endif
 
 struct ExpInfo { int kase; double rho, Y, M; };   // kase 0 inside K, 1 inside -K*, 2 the (r<=0, s<=0) face, 3 boundary
 
@@ -25,70 +28,72 @@ __device__ __forceinline__ void exp_g(double rho, double r, double s, double t, 
     }
 }
 
-// p <- Pi_K(p) in place; rho0: warm start (ignored unless inside the bracket).
-__device__ __noinline__ void exp_project(double *p, double rho0, ExpInfo *inf) {
-    const double r = p[0], s = p[1], t = p[2];
-    inf->rho = rho0; inf->Y = 0; inf->M = 0;
-    if ((s > 0 && s * exp(r / s) <= t) || (r <= 0 && s == 0 && t >= 0)) { inf->kase = 0; return; }
-    if ((r > 0 && r * exp(s / r) <= -2.718281828459045235 * t) || (r == 0 && s <= 0 && t <= 0)) { inf->kase = 1; p[0] = p[1] = p[2] = 0; return; }
-    if (r <= 0 && s <= 0) { inf->kase = 2; p[1] = 0; if (t < 0) p[2] = 0; return; }
+// (p0,p1,p2) <- Pi_K(p0,p1,p2) in place; rho0: warm start (ignored unless inside the bracket).  Everything stays in registers.
+__device__ __forceinline__ void exp_project(double &p0, double &p1, double &p2, double rho0, ExpInfo &inf) {
+    const double r = p0, s = p1, t = p2;
+    inf.rho = rho0; inf.Y = 0; inf.M = 0;
+    if ((s > 0 && s * exp(r / s) <= t) || (r <= 0 && s == 0 && t >= 0)) { inf.kase = 0; return; }
+    if ((r > 0 && r * exp(s / r) <= -2.718281828459045235 * t) || (r == 0 && s <= 0 && t <= 0)) { inf.kase = 1; p0 = p1 = p2 = 0; return; }
+    if (r <= 0 && s <= 0) { inf.kase = 2; p1 = 0; if (t < 0) p2 = 0; return; }
     // bracket: yy > 0 <=> s + r(rho-1) > 0 ; mu > 0 <=> r - s rho > 0.   g < 0 at lo, g > 0 at hi.
     double lo, hi; bool lo_inf = false, hi_inf = false;
     if (r > 0 && s > 0) { lo = 1 - s / r; hi = r / s; }
     else if (r > 0) { lo = 1 - s / r; hi = 0; hi_inf = true; }
     else { hi = r / s; lo = 0; lo_inf = true; }
     double rho = rho0;
-    if (!(rho > lo || lo_inf) || !(rho < hi || hi_inf) || !(fabs(rho) <= 1000.0)) rho =   // (also rejects NaN / stale LDS contents)
-        hi_inf ? lo + 1 : (lo_inf ? hi - 1 : 0.5 * (lo + hi));
+    if (!(rho > lo || lo_inf) || !(rho < hi || hi_inf) || !(fabs(rho) <= 1000.0))     // (also rejects NaN / stale LDS contents)
+        rho = hi_inf ? lo + 1 : (lo_inf ? hi - 1 : 0.5 * (lo + hi));
     double st = 1;
     for (int it = 0; it < 120; it++) {
         double g, dg; exp_g(rho, r, s, t, g, dg);
+        EXP_COUNT_ITER
         if (g > 0) { hi = rho; hi_inf = false; } else if (g < 0) { lo = rho; lo_inf = false; } else break;
         double nr = rho - g / dg;
+        // Newton converges quadratically: once a step is this small the error after taking it is ~ step^2
+        if (dg > 0 && fabs(nr - rho) <= 3e-9 * (1 + fabs(rho))) { rho = nr; break; }
         const bool ok = (dg > 0) && (lo_inf || nr > lo) && (hi_inf || nr < hi) && fabs(nr - rho) < 64.0;
         if (!ok) {
             if (hi_inf) { st *= 2; nr = rho + st; }
             else if (lo_inf) { st *= 2; nr = rho - st; }
             else nr = 0.5 * (lo + hi);
         }
-        const double step = fabs(nr - rho);
         rho = nr;
-        if (step <= 4e-16 * (1 + fabs(rho))) break;
         if (!lo_inf && !hi_inf && hi - lo <= 2e-16 * (1 + fabs(rho))) break;
     }
     const double D = rho * rho - rho + 1;
     double ny = s + r * (rho - 1), nm = r - s * rho;
     if (ny < 0) ny = 0;
     if (nm < 0) nm = 0;
-    inf->kase = 3; inf->rho = rho;
+    inf.kase = 3; inf.rho = rho;
     // two algebraically equal forms; each is the accurate one on its side
     if (rho <= 0) {
         const double E = exp(rho), yy = ny / D;
-        p[0] = yy * rho; p[1] = yy; p[2] = yy * E;
-        inf->Y = yy; inf->M = p[2] - t;                 // mu e^-rho (third equation)
+        p0 = yy * rho; p1 = yy; p2 = yy * E;
+        inf.Y = yy; inf.M = p2 - t;                     // mu e^-rho (third equation)
     } else {
         const double F = exp(-rho), mu = nm / D;
-        p[0] = r - mu; p[1] = fmax(s + mu * (rho - 1), 0.0); p[2] = t + mu * F;
-        inf->M = mu; inf->Y = p[2];                     // yy e^rho
+        p0 = r - mu; p1 = fmax(s + mu * (rho - 1), 0.0); p2 = t + mu * F;
+        inf.M = mu; inf.Y = p2;                         // yy e^rho
     }
 }
 
 // y-block of the ADMM cone step: v <- Pi_K*(v) = v + Pi_K(-v).   *rho_state keeps the root between iterations.
 __device__ __forceinline__ void exp_project_dual(double *v, double *rho_state) {
-    double w[3] = {-v[0], -v[1], -v[2]};
+    const double v0 = v[0], v1 = v[1], v2 = v[2];
+    double w0 = -v0, w1 = -v1, w2 = -v2;
     ExpInfo inf;
-    exp_project(w, *rho_state, &inf);
+    exp_project(w0, w1, w2, *rho_state, inf);
     *rho_state = inf.rho;
-    v[0] += w[0]; v[1] += w[1]; v[2] += w[2];
+    v[0] = v0 + w0; v[1] = v1 + w1; v[2] = v2 + w2;
 }
 
 // J (row-major 3x3) = D Pi_K(v).  Boundary: p = Y a(rho), p - v = M b(rho) with
 //   rho <= 0: a = (rho, 1, E), b = (-E, (rho-1)E, 1) ;  rho > 0: a = (rho F, F, 1), b = (-1, rho-1, F)
 // G(Y, M, rho) = Y a - M b = v  =>  dG = [a | -b | Y a' - M b'],  dp = a dY + Y a' drho  =>  J = [a | 0 | Y a'] dG^-1.
 __device__ __noinline__ void exp_dproject(const double *v, double *J) {
-    double w[3] = {v[0], v[1], v[2]};
+    double w0 = v[0], w1 = v[1], w2 = v[2];
     ExpInfo inf;
-    exp_project(w, 0.0, &inf);
+    exp_project(w0, w1, w2, 0.0, inf);
     for (int i = 0; i < 9; i++) J[i] = 0;
     if (inf.kase == 0) { J[0] = J[4] = J[8] = 1; return; }
     if (inf.kase == 1) return;

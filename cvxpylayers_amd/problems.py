@@ -167,6 +167,8 @@ CONFIGS = {
     "M": dict(n=50, cones={"z": 0, "l": 20, "q": [10] * 8}, B=4096),            # metric: n=50, m=100 SOC
     "C2": dict(n=50, cones={"z": 0, "l": 100, "q": []}, B=4096),                 # nonneg cone only (LP)
     "C2Q": dict(n=51, cones={"z": 0, "l": 100, "q": [52]}, B=4096),              # box QP n=50 in the SOC-epigraph form DIFFCP sees (box_qp_batch)
+    "E": dict(n=40, cones={"z": 0, "l": 12, "q": [4], "s": [], "ep": 24}, B=4096),   # 24 exponential cones (logistic-regression layer shape)
+    "E0": dict(n=40, cones={"z": 0, "l": 84, "q": [4], "s": []}, B=4096),             # same size, the exponential triples replaced by nonneg rows
     "C3": dict(n=100, cones={"z": 0, "l": 10, "q": [11] * 10}, B=4096),          # SOCP n=100, 10 SOC cones
     "C4": dict(n=210, cones={"z": 20, "l": 0, "q": [], "s": [20]}, B=1024),      # SDP one 20x20 PSD cone
 }

@@ -56,15 +56,24 @@ def run(name, tpl, cones, A_eval, q_eval, eps, reps, note):
     return out
 
 
+ONLY = os.environ.get("CONFIGS_ONLY")          # e.g. CONFIGS_ONLY=E runs just the exponential-cone row
 res = []
-for key, B, note in (("M", 4096, "metric configuration"), ("C2", 4096, "nonneg cone only (random LP)"), ("C3", 4096, "SOCP n=100, 10 SOC(11)")):
+for key, B, note in () if ONLY else (("M", 4096, "metric configuration"), ("C2", 4096, "nonneg cone only (random LP)"), ("C3", 4096, "SOCP n=100, 10 SOC(11)")):
     cfg = P.CONFIGS[key]
     tpl = P.dense_template(cfg["n"], cfg["cones"])
     A, b, c = P.generate(cfg["n"], cfg["cones"], B, seed=0)
     res.append(run(key, tpl, cfg["cones"], *tpl.values_from_dense(A, b, c), 1e-4, 5 if key != "C2" else 2, note))
-A, b, c, cones = P.box_qp_batch(50, 4096, seed=0)
+A, b, c, cones = P.box_qp_batch(50, 4096 if not ONLY else 2, seed=0)
 tpl = P.dense_template(A.shape[2], cones, pattern=(A[0] != 0))
-res.append(run("C2Q", tpl, cones, *tpl.values_from_dense(A, b, c), 1e-4, 5, "box QP n=50 in SOC-epigraph form (BASELINE config 2 as DIFFCP sees it); F shared, g/lo/hi batched"))
+if not ONLY:
+    res.append(run("C2Q", tpl, cones, *tpl.values_from_dense(A, b, c), 1e-4, 5, "box QP n=50 in SOC-epigraph form (BASELINE config 2 as DIFFCP sees it); F shared, g/lo/hi batched"))
+ecfg = dict(n=40, cones={"z": 0, "l": 12, "q": [4], "s": [], "ep": 24})      # the cone shape of a 12-sample, 3-feature logistic-regression layer
+tplE = P.dense_template(ecfg["n"], ecfg["cones"])
+Ae, be, ce_ = P.generate(ecfg["n"], ecfg["cones"], 4096, seed=0)
+res.append(run("E", tplE, ecfg["cones"], *tplE.values_from_dense(Ae, be, ce_), 1e-4, 30 if ONLY else 5, "24 exponential cones + nonneg + SOC(4), n=40, m=88 (logistic-regression layer shape), dense random A"))
+if ONLY:
+    json.dump(res, open(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/configs_E.json", "w"), indent=1)
+    sys.exit(0)
 A, b, c, cones = sdp(1024)
 tpl = P.dense_template(A.shape[1], cones, pattern=(A != 0), b_pattern=np.ones(A.shape[0], bool))
 res.append(run("C4", tpl, cones, *tpl.values_from_dense(np.broadcast_to(A, (1024,) + A.shape).copy(), b, c), 1e-4, 3, "SDP, one 20x20 PSD cone, A shared (BASELINE config 4)"))

@@ -181,3 +181,34 @@ def test_sdp_min_eigenvector_value_dual_and_gradient():
     w2, V2 = torch.linalg.eigh((C2 + C2.t()) / 2)
     (torch.outer(V2[:, 0], V2[:, 0]) * Wt).sum().backward()
     assert torch.allclose(C.grad.cpu(), C2.grad, atol=1e-5), (C.grad.cpu(), C2.grad)
+
+
+@pytest.mark.gpu
+def test_logistic_regression_layer_through_the_exponential_cone():
+    """The logistic-regression layer of reference tests/test_torch.py:158-230: data Z = lab * X is the parameter, the fitted
+    weights come back; the gradient of sum(w*) wrt the data is checked against autograd through an unrolled Newton solve."""
+    rng = np.random.default_rng(1)
+    N, d, lam = 12, 3, 0.5
+    X = rng.standard_normal((N, d)); lab = np.sign(X @ np.array([1.0, -2.0, 0.5]) + 0.3 * rng.standard_normal(N))
+
+    def builder(Z):
+        A, b, c, cones = kit.logistic_regression(Z, np.ones(N), lam)
+        return A, b, c
+    cones = kit.logistic_regression(X, lab, lam)[3]
+    tpl = template_from_affine_builder(builder, [(N, d)], cones, [VariableRecovery(slice(0, d), None, (d,))])
+    layer = CvxpyLayer(template=tpl, solver_args={"eps": 1e-10, "max_iters": 200000})
+    Z = torch.tensor(lab[:, None] * X, device="cuda", requires_grad=True)
+    (w,) = layer(Z)
+    w.sum().backward()
+
+    Z2 = Z.detach().clone().requires_grad_()
+    f = lambda wv: torch.nn.functional.softplus(-(Z2 @ wv)).sum() + lam * wv.norm()
+    wv = w.detach().clone()
+    for _ in range(6):       # Newton from the layer's answer: converged after one step, differentiable through the last ones
+        wv_ = wv if wv.requires_grad else wv.requires_grad_()
+        g = torch.autograd.grad(f(wv_), wv_, create_graph=True)[0]
+        H = torch.stack([torch.autograd.grad(g[i], wv_, create_graph=True)[0] for i in range(d)])
+        wv = wv_ - torch.linalg.solve(H, g)
+    assert torch.allclose(w, wv.detach(), atol=1e-6)
+    wv.sum().backward()
+    assert torch.allclose(Z.grad, Z2.grad, atol=1e-5), (Z.grad - Z2.grad).abs().max()
