@@ -212,3 +212,28 @@ def test_logistic_regression_layer_through_the_exponential_cone():
     assert torch.allclose(w, wv.detach(), atol=1e-6)
     wv.sum().backward()
     assert torch.allclose(Z.grad, Z2.grad, atol=1e-5), (Z.grad - Z2.grad).abs().max()
+
+
+@pytest.mark.gpu
+def test_geometric_program_layer_log_parameters_exp_variables():
+    """gp=True layers (reference torch/cvxpylayer.py:411-420, 274-282; tests/test_torch.py:429-623): parameters enter through their
+    logs, primal variables come back through exp.   min x + y  s.t.  x y >= a   ->   x = y = sqrt(a).
+    Log space (u, v) = log(x, y), alpha = log a:  min t  s.t.  log(e^u + e^v) <= t,  u + v >= alpha;
+    e^(u-t) + e^(v-t) <= 1  <=>  (u - t, 1, a1), (v - t, 1, a2) in K_exp, a1 + a2 <= 1.   Variables (u, v, t, a1, a2)."""
+    def builder(alpha):
+        A = np.zeros((8, 5)); b = np.zeros(8); c = np.zeros(5); c[2] = 1.0
+        A[0, 3] = A[0, 4] = 1.0; b[0] = 1.0                 # 1 - a1 - a2 >= 0
+        A[1, 0] = A[1, 1] = -1.0; b[1] = -alpha[0]          # u + v - alpha >= 0
+        A[2, 0] = -1.0; A[2, 2] = 1.0; b[3] = 1.0; A[4, 3] = -1.0
+        A[5, 1] = -1.0; A[5, 2] = 1.0; b[6] = 1.0; A[7, 4] = -1.0
+        return A, b, c
+    tpl = template_from_affine_builder(builder, [(1,)], {"z": 0, "l": 2, "q": [], "s": [], "ep": 2},
+                                       [VariableRecovery(slice(0, 1), None, (1,)), VariableRecovery(slice(1, 2), None, (1,))])
+    tpl.gp = True; tpl.gp_log_mask = (True,)
+    layer = CvxpyLayer(template=tpl, solver_args={"eps": 1e-10, "max_iters": 100000})
+    a = torch.tensor([[0.5], [2.0], [9.0]], device="cuda", dtype=torch.float64, requires_grad=True)
+    x, y = layer(a)
+    assert x.shape == (3, 1) and y.shape == (3, 1)
+    assert torch.allclose(x, a.detach().sqrt(), atol=1e-6) and torch.allclose(y, a.detach().sqrt(), atol=1e-6)
+    (x.sum() + 2 * y.sum()).backward()
+    assert torch.allclose(a.grad, 1.5 / a.detach().sqrt(), atol=1e-5), a.grad
