@@ -177,6 +177,20 @@ k_forward(DevT T, ce_settings S, const double *__restrict__ Avals, const double 
     for (int e = tid; e < l; e += NT) w[e] = (e == l - 1) ? 1.0 : 0.0;    // cold start
     if (tid < NW) wpart[tid] = 0.0;
     __syncthreads();
+    if (S.warm_start) {   // u = (x^, y^, 1), v = (0, s^, 0); w = u + R^-1 v  (see k_fwd2)
+        bool bad = false;
+        for (int j = tid; j < n; j += NT) bad = bad || !(fabs(xo[(size_t)inst * n + j]) < 1e300);
+        for (int i = tid; i < m; i += NT) bad = bad || !(fabs(yo[(size_t)inst * m + i]) < 1e300) || !(fabs(so[(size_t)inst * m + i]) < 1e300);
+        double rb[1] = {bad ? 1.0 : 0.0};
+        block_reduce<1>(rb, 1u, red);                // (max over the workgroup; __syncthreads_or would add static LDS)
+        if (rb[0] == 0.0) {
+            for (int j = tid; j < n; j += NT) w[j] = sigma * xo[(size_t)inst * n + j] / Ev[j];
+            for (int i = tid; i < m; i += NT) w[n + i] = sigma * yo[(size_t)inst * m + i] / Dv[i] + sigma * Dv[i] * so[(size_t)inst * m + i] * dyv(i);
+            __syncthreads();
+            phiw_partials();
+        }
+        __syncthreads();
+    }
 
     int status = 0, iter = 0, last_scale_iter = 0, n_log = 0;
     double sum_log = 0, res_pri = NAN, res_dual = NAN, gap = NAN;

@@ -524,6 +524,29 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
     };
 
     if (threadIdx.x == 0) sm[L::O_W + OT] = 1.0;    // cold start: w = (0, 0, 1)
+    if (S.warm_start) {
+        // warm start from the caller's (x, y, s): u = (x^, y^, 1), v = (0, s^, 0) in the equilibrated space, and the fixed point
+        // of the iteration map has w = u + R^-1 v.   x^ = sigma x / E, y^ = sigma y / D, s^ = sigma D s.
+        const double sg = sc[SC_SIGMA];
+        const int inst_ = blockIdx.x;
+        double wx = 0, wy = 0; bool bad = false;
+        const int e = threadIdx.x;
+        if (e < n) { wx = sg * xo[(size_t)inst_ * n + e] / sm[L::O_EV + e]; bad = !(fabs(wx) < 1e300); }
+        for (int i = e; i < m; i += NT) {
+            const double dvi = sm[L::O_DV + i];
+            const double v = sg * yo[(size_t)inst_ * m + i] / dvi + sg * dvi * so[(size_t)inst_ * m + i] * dyv(i);
+            bad = bad || !(fabs(v) < 1e300);
+        }
+        double rb[1] = {bad ? 1.0 : 0.0};
+        block_reduce_n<1, NW>(rb, 1u, red);          // (max over the workgroup; __syncthreads_or would add static LDS)
+        if (rb[0] == 0.0) {
+            if (e < n) sm[L::O_W + OX + e] = wx;
+            for (int i = e; i < m; i += NT) {
+                const double dvi = sm[L::O_DV + i];
+                sm[L::O_W + OY + i] = sg * yo[(size_t)inst_ * m + i] / dvi + sg * dvi * so[(size_t)inst_ * m + i] * dyv(i);
+            }
+        }
+    }
     __syncthreads();
 
     int status = 0, iter = 0, last_scale_iter = 0, n_log = 0;

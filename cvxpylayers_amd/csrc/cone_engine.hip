@@ -175,7 +175,7 @@ const char *ce_last_error(void) { return g_err.c_str(); }
 
 void ce_default_settings(ce_settings *s) {
     s->eps_abs = 1e-4; s->eps_rel = 1e-4; s->eps_infeas = 1e-7; s->alpha = 1.5; s->rho_x = 1e-6; s->scale = 0.1;
-    s->max_iters = 100000; s->normalize = 1; s->adaptive_scale = 1; s->reserved = 0;
+    s->max_iters = 100000; s->normalize = 1; s->adaptive_scale = 1; s->warm_start = 0;
 }
 
 int ce_create(const ce_template *tpl, int device, ce_handle *out) {

@@ -75,7 +75,7 @@ def is_constant_A(A_bm: torch.Tensor, nnzA: int) -> bool:
     return bool((A_bm[:, :nnzA] == A_bm[0:1, :nnzA]).all().item())
 
 
-def solve_const_a(eng, A_bm: torch.Tensor, q_eval: torch.Tensor, settings):
+def solve_const_a(eng, A_bm: torch.Tensor, q_eval: torch.Tensor, settings, warm=None):
     """eng: ConeEngine; A_bm (B, nnz_aug) batch-major values of [A_cvx | b_cvx]; q_eval (n+1, B).  Returns x, y, s, iters, status, resid."""
     import os, time
     _timing = os.environ.get("CE_CA_TIMING") == "1"
@@ -180,6 +180,12 @@ def solve_const_a(eng, A_bm: torch.Tensor, q_eval: torch.Tensor, settings):
 
     refresh()
     W = torch.zeros((B, lp), **f64); W[:, l - 1] = 1.0
+    if warm is not None:       # SCS warm start u = (x^, y^, 1), v = (0, s^, 0); the iteration map's fixed point has w = u + R^-1 v
+        wx0, wy0, ws0 = (t.to(device=dev, dtype=torch.float64) for t in warm)
+        Wx = sigma[:, None] * wx0 / E[None, :]
+        Wy = sigma[:, None] * wy0 / D[None, :] + sigma[:, None] * D[None, :] * ws0 * (scale[:, None] * d0[None, :])
+        ok = (torch.isfinite(Wx).all(dim=1) & torch.isfinite(Wy).all(dim=1))[:, None]
+        W[:, :n] = torch.where(ok, Wx, W[:, :n]); W[:, n:n + m] = torch.where(ok, Wy, W[:, n:n + m])
     UT = torch.zeros((B, lp), **f64); U = torch.zeros((B, lp), **f64)
     active = torch.ones(B, dtype=torch.int32, device=dev)
     status = torch.zeros(B, dtype=torch.int32, device=dev)

@@ -126,18 +126,28 @@ class ConeEngine:
         _lib.check(_lib.lib().ce_transpose(self._h, K, B, A_eval.data_ptr(), out.data_ptr(), self._stream()), "ce_transpose")
         return out
 
-    def solve(self, A_bm: torch.Tensor, q_eval: torch.Tensor, settings):
-        """A_bm (B, nnz_aug) contiguous, q_eval (n+1, B) any strides.  Returns x, y, s, iters, status, resid."""
+    def solve(self, A_bm: torch.Tensor, q_eval: torch.Tensor, settings, warm=None):
+        """A_bm (B, nnz_aug) contiguous, q_eval (n+1, B) any strides.  Returns x, y, s, iters, status, resid.
+        warm = (x, y, s) of shapes (B, n), (B, m), (B, m): initial point (instances with non-finite entries start cold)."""
         B = A_bm.shape[0]
         dev = self.device
+        if warm is not None:
+            if tuple(warm[0].shape) != (B, self.n) or tuple(warm[1].shape) != (B, self.m) or tuple(warm[2].shape) != (B, self.m):
+                raise ValueError(f"warm start: expected x {(B, self.n)}, y {(B, self.m)}, s {(B, self.m)}, got "
+                                 f"{tuple(warm[0].shape)}, {tuple(warm[1].shape)}, {tuple(warm[2].shape)}")
         if self._use_const_a(A_bm):
             from cvxpylayers_amd.interfaces.const_a import solve_const_a
             self.last_path = "const_a"
-            return solve_const_a(self, A_bm, q_eval, settings)
+            return solve_const_a(self, A_bm, q_eval, settings, warm=warm)
         self.last_path = "per_instance"
-        x = torch.empty((B, self.n), dtype=torch.float64, device=dev)
-        y = torch.empty((B, self.m), dtype=torch.float64, device=dev)
-        s = torch.empty((B, self.m), dtype=torch.float64, device=dev)
+        if warm is not None:       # the engine reads the initial point from the output buffers (ce_settings.warm_start)
+            x, y, s = (t.detach().to(device=dev, dtype=torch.float64).clone().contiguous() for t in warm)
+            settings.warm_start = 1
+        else:
+            x = torch.empty((B, self.n), dtype=torch.float64, device=dev)
+            y = torch.empty((B, self.m), dtype=torch.float64, device=dev)
+            s = torch.empty((B, self.m), dtype=torch.float64, device=dev)
+            settings.warm_start = 0
         iters = torch.empty((B,), dtype=torch.int32, device=dev)
         status = torch.empty((B,), dtype=torch.int32, device=dev)
         resid = torch.empty((B, 3), dtype=torch.float64, device=dev)
@@ -272,7 +282,15 @@ class _CvxpyLayer(torch.autograd.Function):
             q_dev = q_eval.detach().to(device=dev, dtype=torch.float64)
             batch_minor_in = A_dev.dim() == 2 and A_dev.is_contiguous() and A_dev.shape[1] > 1
             A_bm = eng.to_batch_major(A_dev)
-            x, y, s, iters, status, resid = eng.solve(A_bm, q_dev, settings)
+            warm = None
+            if warm_start is True:                                   # re-use the previous solution of this layer (same batch size)
+                prev = getattr(eng, "_last_solution", None)
+                if prev is not None and prev[0].shape[0] == A_bm.shape[0]:
+                    warm = prev
+            elif warm_start not in (None, False):
+                warm = tuple(t if t.dim() == 2 else t.unsqueeze(0) for t in warm_start)     # (x, y, s) tensors
+            x, y, s, iters, status, resid = eng.solve(A_bm, q_dev, settings, warm=warm)
+            eng._last_solution = (x.detach(), y.detach(), s)
             st = status.cpu()
         if bool((st < 0).any()) and merged_args.get("raise_on_error", True):
             bad = int((st < 0).nonzero()[0])

@@ -298,9 +298,6 @@ class CvxpyLayer(torch.nn.Module):
         return p
 
     def forward(self, *params: torch.Tensor, solver_args: dict | None = None, warm_start: bool = False):
-        if warm_start:
-            raise ValueError("warm_start=True is only supported with solver='MOREAU'. "
-                             f"Current solver is '{self.solver}'.")
         solver_args = solver_args or {}
         batch = self.validate_params(list(params))
         if self.template.gp and self.template.gp_log_mask is not None:
@@ -315,7 +312,9 @@ class CvxpyLayer(torch.nn.Module):
             A_eval, q_eval = A_eval.squeeze(1), q_eval.squeeze(1)
         needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
         layer_cls = get_torch_cvxpylayer(self.solver)
-        primal, dual, info, _ = layer_cls.apply(None, q_eval, A_eval, self.ctx, solver_args, needs_grad, None)
+        # warm_start=True: the plugin starts from this layer's previous solution when the batch size matches (the reference keeps
+        # the same cache for its MOREAU plugin, torch/cvxpylayer.py:464-487)
+        primal, dual, info, _ = layer_cls.apply(None, q_eval, A_eval, self.ctx, solver_args, needs_grad, True if warm_start else None)
         self.info = info
         return self._recover_results(primal, dual, batch)
 

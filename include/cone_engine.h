@@ -68,7 +68,9 @@ typedef struct {
     int max_iters;         /* 100000 */
     int normalize;         /* Ruiz + l2 equilibration, 1 */
     int adaptive_scale;    /* 1 */
-    int reserved;
+    int warm_start;       /* != 0: x, y, s hold an initial primal / dual / slack point on entry (SCS warm start: u = (x, y, 1), v = (0, s, 0));
+                             instances whose point is not finite start cold.  The reference's DIFFCP plugin exposes this as
+                             diffcp's `warm_starts` solve argument; MOREAU as `warm_start` (torch/cvxpylayer.py:464-487) */
 } ce_settings;
 
 void ce_default_settings(ce_settings *s);

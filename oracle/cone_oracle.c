@@ -53,6 +53,7 @@ typedef struct {
     int adj_mode;          /* 0 = lsqr (diffcp default), 1 = dense elimination */
     double lsqr_atol, lsqr_btol, lsqr_conlim;
     int lsqr_iter_lim;     /* <=0: 2*N */
+    int warm_start;        /* != 0: x, y, s hold an initial point on entry (SCS warm start u = (x, y, 1), v = (0, s, 0)) */
 } oc_opts;
 
 enum { OC_SOLVED = 1, OC_SOLVED_INACCURATE = 2, OC_UNBOUNDED = -1, OC_INFEASIBLE = -2,
@@ -73,7 +74,7 @@ void oc_default_opts(oc_opts *o) {
     o->eps_abs = 1e-4; o->eps_rel = 1e-4; o->eps_infeas = 1e-7; o->alpha = 1.5;
     o->rho_x = 1e-6; o->scale = 0.1; o->max_iters = 100000; o->normalize = 1;
     o->adaptive_scale = 1; o->adj_mode = 0; o->lsqr_atol = 1e-8; o->lsqr_btol = 1e-8;
-    o->lsqr_conlim = 1e8; o->lsqr_iter_lim = -1;
+    o->lsqr_conlim = 1e8; o->lsqr_iter_lim = -1; o->warm_start = 0;
 }
 
 static int cone_rows(const oc_cones *k) {
@@ -348,6 +349,15 @@ static int solve_one(int n, int m, const double *A0, const double *b0, const dou
     double hg = dot(c, g, n) + dot(b, g + n, m);
     /* cold start */
     memset(w, 0, sizeof(double) * l); w[l - 1] = 1.0;
+    if (o->warm_start) {   /* the fixed point of the iteration map has w = u + R^-1 v;  x^ = sigma x / E, y^ = sigma y / D, s^ = sigma D s */
+        int ok = 1;
+        for (int j = 0; j < n; j++) if (!(fabs(xo[j]) < 1e300)) ok = 0;
+        for (int i = 0; i < m; i++) if (!(fabs(yo[i]) < 1e300) || !(fabs(so[i]) < 1e300)) ok = 0;
+        if (ok) {
+            for (int j = 0; j < n; j++) w[j] = sigma * xo[j] / E[j];
+            for (int i = 0; i < m; i++) w[n + i] = sigma * yo[i] / D[i] + sigma * D[i] * so[i] / ry[i];
+        }
+    }
     int status = 0, iter, last_scale_iter = 0, n_rescale = 0; double sum_log = 0; int n_log = 0;
     double res_pri = NAN, res_dual = NAN, gap = NAN, pobj = NAN, dobj = NAN;
     for (iter = 0; iter < o->max_iters; iter++) {

@@ -23,7 +23,7 @@ class Opts(C.Structure):
                 ("alpha", C.c_double), ("rho_x", C.c_double), ("scale", C.c_double),
                 ("max_iters", C.c_int), ("normalize", C.c_int), ("adaptive_scale", C.c_int),
                 ("adj_mode", C.c_int), ("lsqr_atol", C.c_double), ("lsqr_btol", C.c_double),
-                ("lsqr_conlim", C.c_double), ("lsqr_iter_lim", C.c_int)]
+                ("lsqr_conlim", C.c_double), ("lsqr_iter_lim", C.c_int), ("warm_start", C.c_int)]
 
 
 def build(force: bool = False) -> str:
@@ -74,8 +74,8 @@ def _cones(cones):
     return int(cones.get("z", 0)), int(cones.get("l", 0)), q, s, int(cones.get("ep", 0))
 
 
-def solve_batch(A, b, c, cones, nthreads=0, **opts):
-    """A (B,m,n) dense, b (B,m), c (B,n) float64.  Returns dict(x,y,s,iters,status,resid)."""
+def solve_batch(A, b, c, cones, nthreads=0, warm=None, **opts):
+    """A (B,m,n) dense, b (B,m), c (B,n) float64.  Returns dict(x,y,s,iters,status,resid).  warm = (x, y, s): initial point."""
     A = np.ascontiguousarray(A, dtype=np.float64)
     b = np.ascontiguousarray(b, dtype=np.float64)
     c = np.ascontiguousarray(c, dtype=np.float64)
@@ -83,6 +83,9 @@ def solve_batch(A, b, c, cones, nthreads=0, **opts):
     z, l, q, s, nep = _cones(cones)
     o = make_opts(**opts)
     x = np.empty((B, n)); y = np.empty((B, m)); sv = np.empty((B, m))
+    if warm is not None:
+        o.warm_start = 1
+        x[...] = warm[0]; y[...] = warm[1]; sv[...] = warm[2]
     iters = np.zeros(B, dtype=np.int32); status = np.zeros(B, dtype=np.int32); resid = np.zeros((B, 3))
     rc = lib().oc_solve_batch(B, n, m, _p(A), _p(b), _p(c), z, l, len(q), _p(q, C.c_int), len(s), _p(s, C.c_int), nep,
                               C.byref(o), _p(x), _p(y), _p(sv), _p(iters, C.c_int), _p(status, C.c_int), _p(resid),

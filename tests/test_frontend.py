@@ -54,8 +54,6 @@ def test_param_count_shape_and_batch_errors():
         layer(torch.zeros(2, 2, 5, 3), torch.zeros(5))
     with pytest.raises(ValueError, match="Inconsistent batch sizes"):
         layer(torch.zeros(2, 5, 3), torch.zeros(3, 5))
-    with pytest.raises(ValueError, match="warm_start=True is only supported"):
-        layer(torch.zeros(5, 3), torch.zeros(5), warm_start=True)
     assert layer.validate_params([torch.zeros(5, 3), torch.zeros(5)]) == ()
     assert layer.validate_params([torch.zeros(7, 5, 3), torch.zeros(5)]) == (7,)
 
@@ -237,3 +235,94 @@ def test_geometric_program_layer_log_parameters_exp_variables():
     assert torch.allclose(x, a.detach().sqrt(), atol=1e-6) and torch.allclose(y, a.detach().sqrt(), atol=1e-6)
     (x.sum() + 2 * y.sum()).backward()
     assert torch.allclose(a.grad, 1.5 / a.detach().sqrt(), atol=1e-5), a.grad
+
+
+@pytest.mark.gpu
+def test_lml_layer_entropy_terms():
+    """Limited multi-label projection (reference tests/test_torch.py:219-230): min -x.y - sum entr(y) - sum entr(1-y), sum y = k,
+    whose solution is y = sigmoid(x + nu) with nu fixed by sum y = k.  entr(y) >= t  <=>  (t, y, 1) in K_exp.
+    Variables (y[d], t[d], r[d]); the gradient is checked against autograd through the scalar Newton solve for nu."""
+    d, k = 4, 2
+
+    def builder(x):
+        n, m = 3 * d, 1 + 6 * d
+        A = np.zeros((m, n)); b = np.zeros(m); c = np.zeros(n)
+        c[:d] = -x; c[d:] = -1.0
+        A[0, :d] = 1.0; b[0] = k
+        for i in range(d):
+            r = 1 + 6 * i
+            A[r, d + i] = -1.0; A[r + 1, i] = -1.0; b[r + 2] = 1.0                    # (t_i, y_i, 1)
+            A[r + 3, 2 * d + i] = -1.0; A[r + 4, i] = 1.0; b[r + 4] = 1.0; b[r + 5] = 1.0   # (r_i, 1 - y_i, 1)
+        return A, b, c
+    tpl = template_from_affine_builder(builder, [(d,)], {"z": 1, "l": 0, "q": [], "s": [], "ep": 2 * d}, [VariableRecovery(slice(0, d), None, (d,))])
+    layer = CvxpyLayer(template=tpl, solver_args={"eps": 1e-10, "max_iters": 200000})
+    x = torch.tensor([1.0, -1.0, -1.0, -1.0], device="cuda", dtype=torch.float64, requires_grad=True)
+    (y,) = layer(x)
+    wts = torch.tensor([1.0, 2.0, -1.0, 0.5], device="cuda", dtype=torch.float64)
+    (y * wts).sum().backward()
+
+    x2 = x.detach().clone().requires_grad_()
+    nu = torch.zeros((), device="cuda", dtype=torch.float64)
+    for _ in range(60):
+        sg = torch.sigmoid(x2 + nu)
+        nu = nu - (sg.sum() - k) / (sg * (1 - sg)).sum()
+    y2 = torch.sigmoid(x2 + nu)
+    assert torch.allclose(y, y2.detach(), atol=1e-6), (y, y2)
+    (y2 * wts).sum().backward()
+    assert torch.allclose(x.grad, x2.grad, atol=1e-5), (x.grad, x2.grad)
+
+
+@pytest.mark.gpu
+def test_matrix_variable_fortran_recovery_and_no_grad_inputs():
+    """Matrix variable recovered column-major (reference tests/test_torch.py:755-780) and inputs that do not require grad give an
+    output that does not either (:647-665).   min ||A X - B||_F^2 + ||X||_F^2  ->  X = (A^T A + I)^-1 A^T B."""
+    m, n, k = 10, 4, 3
+
+    def builder(A_, B_):
+        F = np.kron(np.eye(k), A_)                          # vec_F(A X) = (I (x) A) vec_F(X)
+        A, b, c, cones, _ = kit.ridge_ls(F, B_.reshape(-1, order="F"))
+        return A, b, c
+    cones = kit.ridge_ls(np.zeros((m * k, n * k)), np.zeros(m * k))[3]
+    tpl = template_from_affine_builder(builder, [(m, n), (m, k)], cones, [VariableRecovery(slice(0, n * k), None, (n, k))])
+    layer = CvxpyLayer(template=tpl, solver_args={"eps": 1e-10, "max_iters": 100000})
+    torch.manual_seed(123)
+    A_t = torch.randn(m, n, dtype=torch.float64, device="cuda"); B_t = torch.randn(m, k, dtype=torch.float64, device="cuda")
+    (X,) = layer(A_t, B_t)
+    assert X.shape == (n, k) and not X.requires_grad
+    Xc = torch.linalg.solve(A_t.t() @ A_t + torch.eye(n, dtype=torch.float64, device="cuda"), A_t.t() @ B_t)
+    assert torch.allclose(X, Xc, atol=1e-6)
+    # batched, float32 inputs: float64 comes back (diffcp_if.py:374-375), batch axis first
+    A_b = torch.randn(5, m, n, device="cuda"); B_b = torch.randn(5, m, k, device="cuda")
+    (Xb,) = layer(A_b, B_b)
+    assert Xb.shape == (5, n, k) and Xb.dtype == torch.float64
+    Xbc = torch.linalg.solve(A_b.double().transpose(1, 2) @ A_b.double() + torch.eye(n, dtype=torch.float64, device="cuda"), A_b.double().transpose(1, 2) @ B_b.double())
+    assert torch.allclose(Xb, Xbc, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_warm_start_reuses_the_previous_solution():
+    """warm_start=True starts from the layer's previous solution (reference: the MOREAU cache, torch/cvxpylayer.py:464-487;
+    tests/test_moreau.py:1363-1620): same answer, far fewer iterations after a small parameter change, cold start when the
+    batch size changes."""
+    n = 20
+    layer = CvxpyLayer(template=boxqp_template(n), solver_args={"eps": 1e-6, "max_iters": 100000})
+    torch.manual_seed(0)
+    t = torch.randn(64, n, device="cuda", dtype=torch.float64) * 2
+    (x0,) = layer(t)
+    cold = layer.info["iters"].float().mean().item()
+    t2 = t + 1e-3 * torch.randn_like(t)
+    (xc,) = layer(t2)
+    cold2 = layer.info["iters"].float().mean().item()
+    (x0,) = layer(t)                                     # refresh the cache with the solution at t
+    (xw,) = layer(t2, warm_start=True)
+    warm = layer.info["iters"].float().mean().item()
+    assert torch.allclose(xw, torch.clamp(t2, 0, 1), atol=1e-4) and torch.allclose(xw, xc, atol=1e-4)
+    assert warm < 0.5 * cold2, (cold, cold2, warm)
+    (xs,) = layer(t2[:7], warm_start=True)               # different batch size: cache ignored
+    assert torch.allclose(xs, torch.clamp(t2[:7], 0, 1), atol=1e-4)
+    t3 = t2.clone().requires_grad_()
+    (xg,) = layer(t3, warm_start=True)                   # gradients still flow from a warm-started solve
+    xg.sum().backward()
+    inside = ((t2 > 1e-3) & (t2 < 1 - 1e-3)).double()
+    outside = ((t2 < -1e-3) | (t2 > 1 + 1e-3)).double()
+    assert ((t3.grad - 1).abs() * inside).max() < 1e-3 and (t3.grad.abs() * outside).max() < 1e-3

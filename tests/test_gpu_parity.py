@@ -316,3 +316,31 @@ def test_entropy_and_logistic_known_answers_on_gpu():
     ref = minimize(lambda w: np.logaddexp(0.0, -lab * (X @ w)).sum() + lam * np.linalg.norm(w), np.ones(d), method="BFGS", options=dict(gtol=1e-10))
     np.testing.assert_allclose(c @ x.cpu().numpy()[0], ref.fun, atol=1e-6)
     np.testing.assert_allclose(x.cpu().numpy()[0][:d], ref.x, atol=2e-4)
+
+
+def test_warm_start_matches_oracle_warm_start():
+    """ce_settings.warm_start: the initial point (x, y, s) goes in through the output buffers; iteration counts and solutions follow
+    the oracle's warm start (SCS: u = (x, y, 1), v = (0, s, 0)); a point with NaNs falls back to a cold start per instance."""
+    from oracle import oracle
+    from cvxpylayers_amd.interfaces.mi355_if import make_settings
+    cfg = P.CONFIGS["M"]; n, cones, B = cfg["n"], cfg["cones"], 48
+    tpl = P.dense_template(n, cones)
+    A, b, c = P.generate(n, cones, B, seed=2)
+    r0 = oracle.solve_batch(A, b, c, cones, eps=1e-6, max_iters=20000)
+    rng = np.random.default_rng(9)
+    b2 = b * (1 + 1e-3 * rng.standard_normal(b.shape)); c2 = c * (1 + 1e-3 * rng.standard_normal(c.shape))
+    warm = [r0["x"].copy(), r0["y"].copy(), r0["s"].copy()]
+    warm[0][5] = np.nan                                   # instance 5 must start cold
+    rw = oracle.solve_batch(A, b2, c2, cones, eps=1e-6, max_iters=20000, warm=warm)
+    rc = oracle.solve_batch(A, b2, c2, cones, eps=1e-6, max_iters=20000)
+    assert rw["iters"][5] == rc["iters"][5] and rw["iters"].mean() < 0.7 * rc["iters"].mean()
+    eng = _engine_for(tpl)
+    A_eval, q_eval = tpl.values_from_dense(A, b2, c2)
+    A_bm = eng.to_batch_major(torch.from_numpy(A_eval).cuda())
+    wt = tuple(torch.from_numpy(w).cuda() for w in warm)
+    x, y, s, iters, status, resid = eng.solve(A_bm, torch.from_numpy(q_eval).cuda(), make_settings(dict(eps=1e-6, max_iters=20000)), warm=wt)
+    assert (status.cpu().numpy() == 1).all()
+    assert np.abs(iters.cpu().numpy() - rw["iters"]).max() <= 25, (iters.cpu().numpy(), rw["iters"])
+    for got, want in ((x, rw["x"]), (y, rw["y"]), (s, rw["s"])):
+        err = np.abs(got.cpu().numpy() - want).max(axis=1) / (1 + np.abs(want).max(axis=1))
+        assert err.max() < 2e-5, err.max()
