@@ -15,7 +15,7 @@ import numpy as np
 
 def cone_rows(cones: dict) -> int:
     return (int(cones.get("z", 0)) + int(cones.get("l", 0)) + sum(int(d) for d in cones.get("q", []))
-            + sum(int(k) * (int(k) + 1) // 2 for k in cones.get("s", [])) + 3 * int(cones.get("ep", 0)))
+            + sum(int(k) * (int(k) + 1) // 2 for k in cones.get("s", [])) + 3 * int(cones.get("ep", 0)) + 3 * len(cones.get("p", [])))
 
 
 @dataclass
@@ -114,6 +114,17 @@ def _interior_point(rng, cones: dict, B: int):
         u = -(np.abs(rng.standard_normal((B, 1))) + 0.1)
         v = rng.standard_normal((B, 1)) * np.abs(u)
         y_parts.append(np.concatenate([u, v, -u * np.exp(v / u - 1.0) + 0.1 + np.abs(rng.standard_normal((B, 1)))], axis=1))
+    for al in cones.get("p", []):
+        # K_a = {x^a y^(1-a) >= |z|}, K_a^* = {(u/a)^a (v/(1-a))^(1-a) >= |w|}; a negative entry is the dual cone (SCS convention)
+        a = abs(float(al))
+        def prim():
+            xx = np.abs(rng.standard_normal((B, 1))) + 0.1; yy = np.abs(rng.standard_normal((B, 1))) + 0.1
+            return np.concatenate([xx, yy, rng.uniform(-0.5, 0.5, (B, 1)) * xx ** a * yy ** (1 - a)], axis=1)
+        def dual():
+            t = prim(); t[:, 0] *= a; t[:, 1] *= (1 - a)
+            return t
+        s_parts.append(prim() if al > 0 else dual())
+        y_parts.append(dual() if al > 0 else prim())
     return np.concatenate(s_parts, axis=1), np.concatenate(y_parts, axis=1)
 
 

@@ -25,7 +25,7 @@
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this file.
  *
  * Conventions (reference: diffcp_if.py:59-67): solver form  min c^T x  s.t.  A x + s = b, s in K,
- * K = zero(z) x nonneg(l) x SOC(q_1) x ... x PSD(s_1) x ... x EXP^nep  (SCS row order z,l,q,s,ep),
+ * K = zero(z) x nonneg(l) x SOC(q_1) x ... x PSD(s_1) x ... x EXP^nep x POW(a_1) x ...  (SCS row order z,l,q,s,ep,p),
  * EXP = cl{(x,y,z): y > 0, y exp(x/y) <= z} (SCS / CVXPY row order inside a triple),
  * SOC = (t, x) with ||x|| <= t; PSD = lower-triangular column-major svec with sqrt(2) off-diagonals
  * (cvxpylayers/torch/cvxpylayer.py:201-222).  A is dense row-major (m x n) per instance here; the
@@ -44,6 +44,8 @@ typedef struct {
     const int *q;
     const int *s;
     int nep;               /* primal exponential cones (3 rows each), after the PSD blocks (SCS row order z,l,q,s,ep) */
+    int np;                /* 3-d power cones  x^a y^(1-a) >= |z|, x, y >= 0  (after the exponential cones; SCS "p"), a in (0,1);  */
+    const double *pw;      /* a negative entry -a means the DUAL power cone of exponent a (SCS convention)                        */
 } oc_cones;
 
 typedef struct {
@@ -81,7 +83,7 @@ static int cone_rows(const oc_cones *k) {
     int m = k->z + k->l;
     for (int i = 0; i < k->nq; i++) m += k->q[i];
     for (int i = 0; i < k->ns; i++) m += k->s[i] * (k->s[i] + 1) / 2;
-    m += 3 * k->nep;
+    m += 3 * k->nep + 3 * k->np;
     return m;
 }
 
@@ -244,6 +246,85 @@ static void dproj_exp_dual(const double *v, double *J) {
 void oc_proj_exp(double *v, int which) { if (which) proj_exp_dual(v); else proj_exp(v, NULL); }
 void oc_dproj_exp(const double *v, int which, double *J) { if (which) dproj_exp_dual(v, J); else dproj_exp(v, J); }
 
+
+/* ------------------------------------------------------------------ 3-d power cone
+ * K_a = {(x,y,z): x^a y^(1-a) >= |z|, x,y >= 0},  K_a^* = {(u,v,w): (u/a)^a (v/(1-a))^(1-a) >= |w|, u,v >= 0}.
+ * Projection (Hien, "Differential properties of Euclidean projection onto power cone", 2015; the formulation SCS uses):
+ * outside K and -K*, with z0 != 0, the projection is (x(r), y(r), sign(z0) r) with
+ *     x(r) = (x0 + sqrt(x0^2 + 4 a r (|z0| - r)))/2,  y(r) = (y0 + sqrt(y0^2 + 4 (1-a) r (|z0| - r)))/2
+ * and r in (0, |z0|) the root of Phi(r) = x(r)^a y(r)^(1-a) - r  (Phi(0) >= 0 > Phi(|z0|)).   Bisection here. */
+/* (t0 + sqrt(t0^2 + 4 q))/2 for q >= 0 without cancellation when t0 < 0 */
+static double pow_branch(double t0, double q) {
+    double sq = sqrt(t0 * t0 + 4 * q);
+    return t0 >= 0 ? 0.5 * (t0 + sq) : 2 * q / (sq - t0);
+}
+static int proj_pow(double *v, double a) {     /* returns the case: 0 inside, 1 inside -K*, 2 z0 == 0 face, 3 boundary */
+    double x0 = v[0], y0 = v[1], z0 = v[2], az = fabs(z0);
+    if (x0 >= 0 && y0 >= 0 && pow(x0, a) * pow(y0, 1 - a) >= az) return 0;
+    if (x0 <= 0 && y0 <= 0 && pow(-x0 / a, a) * pow(-y0 / (1 - a), 1 - a) >= az) { v[0] = v[1] = v[2] = 0; return 1; }
+    if (az == 0) { v[0] = x0 > 0 ? x0 : 0; v[1] = y0 > 0 ? y0 : 0; return 2; }
+    double lo = 0, hi = az, r = 0.5 * az, x = 0, y = 0;
+    for (int it = 0; it < 200; it++) {
+        r = 0.5 * (lo + hi);
+        x = pow_branch(x0, a * r * (az - r)); y = pow_branch(y0, (1 - a) * r * (az - r));
+        if (pow(x, a) * pow(y, 1 - a) - r > 0) lo = r; else hi = r;
+        if (hi - lo <= 1e-16 * az) break;
+    }
+    v[0] = x; v[1] = y; v[2] = z0 > 0 ? r : -r;
+    return 3;
+}
+/* solve the 4x4 system G X = RHS (3 right-hand sides) by Gaussian elimination with partial pivoting */
+static void solve4(double G[4][4], double R[4][3]) {
+    for (int c = 0; c < 4; c++) {
+        int p = c; for (int i = c + 1; i < 4; i++) if (fabs(G[i][c]) > fabs(G[p][c])) p = i;
+        if (p != c) { for (int j = 0; j < 4; j++) { double t = G[c][j]; G[c][j] = G[p][j]; G[p][j] = t; } for (int j = 0; j < 3; j++) { double t = R[c][j]; R[c][j] = R[p][j]; R[p][j] = t; } }
+        double d = G[c][c];
+        for (int i = 0; i < 4; i++) { if (i == c) continue; double f = G[i][c] / d; for (int j = 0; j < 4; j++) G[i][j] -= f * G[c][j]; for (int j = 0; j < 3; j++) R[i][j] -= f * R[c][j]; }
+    }
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 3; j++) R[i][j] /= G[i][i];
+}
+/* J = D Pi_{K_a}(v): on the boundary p - v = lam grad g(p), g = x^a y^(1-a) - |z| = 0, lam = |z0| - r; implicit function:
+ *   [[I - lam H, -grad g], [-grad g^T, 0]] [dp; dlam] = [dv; 0]      (H = Hessian of g) */
+static void dproj_pow(const double *v, double a, double *J) {
+    double p[3] = { v[0], v[1], v[2] };
+    int kase = proj_pow(p, a);
+    memset(J, 0, 9 * sizeof(double));
+    if (kase == 0) { J[0] = J[4] = J[8] = 1; return; }
+    if (kase == 1) return;
+    if (kase == 2) { J[0] = v[0] > 0; J[4] = v[1] > 0; return; }
+    double x = p[0], y = p[1], sg = v[2] > 0 ? 1.0 : -1.0, r = fabs(p[2]), lam = fabs(v[2]) - r;
+    if (x < 1e-100) x = 1e-100;       /* keeps the curvature terms finite on the nearly flat parts of the boundary (a near 0 or 1) */
+    if (y < 1e-100) y = 1e-100;
+    if (lam < 0) lam = 0;
+    double f = pow(x, a) * pow(y, 1 - a);
+    double g[3] = { a * f / x, (1 - a) * f / y, -sg };
+    double H[3][3] = { { a * (a - 1) * f / (x * x), a * (1 - a) * f / (x * y), 0 }, { a * (1 - a) * f / (x * y), -a * (1 - a) * f / (y * y), 0 }, { 0, 0, 0 } };
+    double G[4][4], R[4][3];
+    for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) { G[i][j] = (i == j ? 1.0 : 0.0) - lam * H[i][j]; R[i][j] = (i == j) ? 1.0 : 0.0; } G[i][3] = -g[i]; G[3][i] = -g[i]; }
+    G[3][3] = 0; R[3][0] = R[3][1] = R[3][2] = 0;
+    solve4(G, R);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) J[i * 3 + j] = R[i][j];
+}
+/* entry a > 0: primal cone K_a; a < 0: the dual cone K_|a|^*.   which = 0: project onto that cone, 1: onto ITS dual. */
+static void proj_pow_entry(double *v, double a, int onto_dual) {
+    int dualcone = (a < 0) != (onto_dual != 0);
+    double al = fabs(a);
+    if (!dualcone) { proj_pow(v, al); return; }
+    double w[3] = { -v[0], -v[1], -v[2] };
+    proj_pow(w, al);
+    for (int i = 0; i < 3; i++) v[i] += w[i];
+}
+static void dproj_pow_entry(const double *v, double a, int onto_dual, double *J) {
+    int dualcone = (a < 0) != (onto_dual != 0);
+    double al = fabs(a);
+    if (!dualcone) { dproj_pow(v, al, J); return; }
+    double w[3] = { -v[0], -v[1], -v[2] };
+    dproj_pow(w, al, J);
+    for (int i = 0; i < 9; i++) J[i] = ((i % 4 == 0) ? 1.0 : 0.0) - J[i];
+}
+void oc_proj_pow(double *v, double a, int onto_dual) { proj_pow_entry(v, a, onto_dual); }
+void oc_dproj_pow(const double *v, double a, int onto_dual, double *J) { dproj_pow_entry(v, a, onto_dual, J); }
+
 /* y <- Pi_{K*}(y): zero cone K={0} has K* = R^z (free) */
 static void proj_dual_cone(double *y, const oc_cones *k) {
     int off = k->z;
@@ -252,6 +333,7 @@ static void proj_dual_cone(double *y, const oc_cones *k) {
     for (int c = 0; c < k->nq; c++) { proj_soc(y + off, k->q[c]); off += k->q[c]; }
     for (int c = 0; c < k->ns; c++) { proj_psd(y + off, k->s[c]); off += k->s[c] * (k->s[c] + 1) / 2; }
     for (int c = 0; c < k->nep; c++) { proj_exp_dual(y + off); off += 3; }
+    for (int c = 0; c < k->np; c++) { proj_pow_entry(y + off, k->pw[c], 1); off += 3; }
 }
 
 /* ------------------------------------------------------------------ Cholesky of SPD n x n (row-major, lower) */
@@ -278,7 +360,7 @@ static void block_average(double *D, const oc_cones *k) {
     int off = k->z + k->l;
     for (int c = 0; c < k->nq; c++) { int d = k->q[c]; if (d > 0) { double s = 0; for (int i = 0; i < d; i++) s += D[off + i]; s /= d; for (int i = 0; i < d; i++) D[off + i] = s; } off += d; }
     for (int c = 0; c < k->ns; c++) { int d = k->s[c] * (k->s[c] + 1) / 2; if (d > 0) { double s = 0; for (int i = 0; i < d; i++) s += D[off + i]; s /= d; for (int i = 0; i < d; i++) D[off + i] = s; } off += d; }
-    for (int c = 0; c < k->nep; c++) { double s = (D[off] + D[off + 1] + D[off + 2]) / 3; D[off] = D[off + 1] = D[off + 2] = s; off += 3; }
+    for (int c = 0; c < k->nep + k->np; c++) { double s = (D[off] + D[off + 1] + D[off + 2]) / 3; D[off] = D[off + 1] = D[off + 2] = s; off += 3; }
 }
 static double clamp_scale(double v) { if (v < MIN_SCALE) return 1.0; if (v > MAX_SCALE) return MAX_SCALE; return v; }
 
@@ -495,6 +577,11 @@ static void dproj_dual_cone(const double *v, const oc_cones *K, const psd_cache 
         for (int i = 0; i < 3; i++) out[off + i] = J[i * 3] * h[off] + J[i * 3 + 1] * h[off + 1] + J[i * 3 + 2] * h[off + 2];
         off += 3;
     }
+    for (int c = 0; c < K->np; c++) {
+        double J[9]; dproj_pow_entry(v + off, K->pw[c], 1, J);
+        for (int i = 0; i < 3; i++) out[off + i] = J[i * 3] * h[off] + J[i * 3 + 1] * h[off + 1] + J[i * 3 + 2] * h[off + 2];
+        off += 3;
+    }
 }
 
 typedef struct { int n, m; const double *A, *b, *c, *v; const oc_cones *K; const psd_cache *pcs; double *t1, *t2; } adj_op;
@@ -650,9 +737,9 @@ int oc_num_threads(void) {
 
 /* A: [B][m][n] row-major dense, b: [B][m], c: [B][n]; outputs x [B][n], y,s [B][m], iters/status [B], resid [B][3] */
 int oc_solve_batch(int B, int n, int m, const double *A, const double *b, const double *c,
-                   int z, int l, int nq, const int *q, int ns, const int *s, int nep, const oc_opts *o,
+                   int z, int l, int nq, const int *q, int ns, const int *s, int nep, int np, const double *pw, const oc_opts *o,
                    double *x, double *y, double *sv, int *iters, int *status, double *resid, int nthreads) {
-    oc_cones K = { z, l, nq, ns, q, s, nep };
+    oc_cones K = { z, l, nq, ns, q, s, nep, np, pw };
     if (cone_rows(&K) != m) return -1;
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
@@ -669,10 +756,10 @@ int oc_solve_batch(int B, int n, int m, const double *A, const double *b, const 
 
 /* ds may be NULL (the layer passes ds = 0, diffcp_if.py:84).  dA: [B][m][n] dense. lsqr_iters may be NULL. */
 int oc_adjoint_batch(int B, int n, int m, const double *A, const double *b, const double *c,
-                     int z, int l, int nq, const int *q, int ns, const int *s, int nep, const oc_opts *o,
+                     int z, int l, int nq, const int *q, int ns, const int *s, int nep, int np, const double *pw, const oc_opts *o,
                      const double *x, const double *y, const double *sv, const double *dx, const double *dy, const double *ds,
                      double *dA, double *db, double *dc, int *lsqr_iters, int nthreads) {
-    oc_cones K = { z, l, nq, ns, q, s, nep };
+    oc_cones K = { z, l, nq, ns, q, s, nep, np, pw };
     if (cone_rows(&K) != m) return -1;
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);

@@ -71,7 +71,8 @@ def _p(a, t=C.c_double):
 def _cones(cones):
     q = np.ascontiguousarray(cones.get("q", []), dtype=np.int32)
     s = np.ascontiguousarray(cones.get("s", []), dtype=np.int32)
-    return int(cones.get("z", 0)), int(cones.get("l", 0)), q, s, int(cones.get("ep", 0))
+    pw = np.ascontiguousarray(cones.get("p", []), dtype=np.float64)
+    return int(cones.get("z", 0)), int(cones.get("l", 0)), q, s, (int(cones.get("ep", 0)), pw)
 
 
 def solve_batch(A, b, c, cones, nthreads=0, warm=None, **opts):
@@ -87,7 +88,7 @@ def solve_batch(A, b, c, cones, nthreads=0, warm=None, **opts):
         o.warm_start = 1
         x[...] = warm[0]; y[...] = warm[1]; sv[...] = warm[2]
     iters = np.zeros(B, dtype=np.int32); status = np.zeros(B, dtype=np.int32); resid = np.zeros((B, 3))
-    rc = lib().oc_solve_batch(B, n, m, _p(A), _p(b), _p(c), z, l, len(q), _p(q, C.c_int), len(s), _p(s, C.c_int), nep,
+    rc = lib().oc_solve_batch(B, n, m, _p(A), _p(b), _p(c), z, l, len(q), _p(q, C.c_int), len(s), _p(s, C.c_int), nep[0], len(nep[1]), _p(nep[1]),
                               C.byref(o), _p(x), _p(y), _p(sv), _p(iters, C.c_int), _p(status, C.c_int), _p(resid),
                               int(nthreads))
     if rc != 0:
@@ -111,7 +112,7 @@ def adjoint_batch(A, b, c, cones, x, y, s, dx, dy, ds=None, nthreads=0, **opts):
         ds = np.ascontiguousarray(ds, dtype=np.float64)
         dsp = _p(ds)
     dA = np.empty((B, m, n)); db = np.empty((B, m)); dc = np.empty((B, n)); it = np.zeros(B, dtype=np.int32)
-    rc = lib().oc_adjoint_batch(B, n, m, _p(A), _p(b), _p(c), z, l, len(q), _p(q, C.c_int), len(sd), _p(sd, C.c_int), nep,
+    rc = lib().oc_adjoint_batch(B, n, m, _p(A), _p(b), _p(c), z, l, len(q), _p(q, C.c_int), len(sd), _p(sd, C.c_int), nep[0], len(nep[1]), _p(nep[1]),
                                 C.byref(o), _p(x), _p(y), _p(s), _p(dx), _p(dy), dsp, _p(dA), _p(db), _p(dc),
                                 _p(it, C.c_int), int(nthreads))
     if rc != 0:
@@ -130,6 +131,19 @@ def dproj_exp(v, dual=False):
     """Jacobian (3,3) of that projection."""
     w = np.array(v, dtype=np.float64); J = np.zeros((3, 3))
     lib().oc_dproj_exp(_p(w), int(dual), _p(J))
+    return J
+
+
+def proj_pow(v, a, dual=False):
+    """Projection of v (3,) onto the power cone K_a (a > 0) / K_|a|^* (a < 0), or with dual=True onto that cone's dual."""
+    w = np.array(v, dtype=np.float64)
+    lib().oc_proj_pow(_p(w), C.c_double(a), int(dual))
+    return w
+
+
+def dproj_pow(v, a, dual=False):
+    w = np.array(v, dtype=np.float64); J = np.zeros((3, 3))
+    lib().oc_dproj_pow(_p(w), C.c_double(a), int(dual), _p(J))
     return J
 
 

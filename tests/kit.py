@@ -160,3 +160,12 @@ def logistic_regression(X, lab, lam):
         b[r + 4] = 1.0
         A[r + 5, d + 2 * N + i] = -1.0                                        # s_z = b_i
     return A, b, c, dict(z=0, l=N, q=[d + 1], s=[], ep=2 * N)
+
+
+def geo_mean_max(w, total, alpha=0.5):
+    """max x1^a x2^(1-a)  s.t.  w1 x1 + w2 x2 = total  ->  x1 = a total / w1, x2 = (1-a) total / w2.   v = (x1, x2, t), (x1, x2, t) in K_a."""
+    A = np.zeros((4, 3)); b = np.zeros(4); c = np.array([0.0, 0.0, -1.0])
+    A[0, :2] = w; b[0] = total
+    A[1, 0] = A[2, 1] = A[3, 2] = -1.0
+    xs = np.array([alpha * total / w[0], (1 - alpha) * total / w[1]])
+    return A, b, c, dict(z=1, l=0, q=[], s=[], ep=0, p=[alpha]), xs

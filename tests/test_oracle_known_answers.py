@@ -114,7 +114,8 @@ def test_max_iters_one_gives_inaccurate_not_error():
 
 
 @pytest.mark.parametrize("cones,n", [({"z": 3, "l": 8, "q": [5, 4]}, 10), ({"z": 0, "l": 4, "q": [3], "s": [3]}, 8),
-                                     ({"z": 2, "l": 4, "q": [4], "s": [], "ep": 3}, 8)])
+                                     ({"z": 2, "l": 4, "q": [4], "s": [], "ep": 3}, 8),
+                                     ({"z": 1, "l": 3, "q": [3], "s": [], "ep": 1, "p": [0.3, -0.6, 0.5]}, 8)])
 def test_adjoint_matches_finite_differences(cones, n):
     from cvxpylayers_amd import problems as P
     A, b, c = P.generate(n, cones, 1, seed=3)
@@ -200,3 +201,37 @@ def test_logistic_regression_matches_a_smooth_solver():
     ref = minimize(obj, np.ones(d), method="BFGS", options=dict(gtol=1e-10))
     np.testing.assert_allclose(c @ x, ref.fun, atol=1e-6)
     np.testing.assert_allclose(x[:d], ref.x, atol=2e-4)
+
+
+# ---------------------------------------------------------------- 3-d power cone (SCS "p": after the exponential cones)
+def test_power_cone_projection_is_the_moreau_decomposition():
+    rng = np.random.default_rng(0)
+
+    def in_k(p, a, tol):
+        return p[0] >= -tol and p[1] >= -tol and (max(p[0], 0) + tol) ** a * (max(p[1], 0) + tol) ** (1 - a) >= abs(p[2]) - tol
+
+    def in_kd(p, a, tol):
+        return p[0] >= -tol and p[1] >= -tol and ((max(p[0], 0) + tol) / a) ** a * ((max(p[1], 0) + tol) / (1 - a)) ** (1 - a) >= abs(p[2]) - tol
+    for trial in range(1500):
+        a = rng.uniform(0.05, 0.95)
+        v = rng.standard_normal(3) * 10 ** rng.uniform(-2, 2)
+        p = oracle.proj_pow(v, a); d = p - v
+        sc = 1 + np.linalg.norm(v)
+        assert in_k(p, a, 1e-9 * sc) and in_kd(d, a, 1e-9 * sc), (v, a, p)
+        assert abs(p @ d) <= 1e-12 * sc * sc
+        np.testing.assert_allclose(oracle.proj_pow(v, -a), v + oracle.proj_pow(-v, a), atol=1e-14 * sc)     # negative entry = dual cone
+        J = oracle.dproj_pow(v, a)
+        h = 1e-6 * max(1.0, np.linalg.norm(v))
+        Jfd = np.stack([(oracle.proj_pow(v + h * e, a) - oracle.proj_pow(v - h * e, a)) / (2 * h) for e in np.eye(3)], axis=1)
+        assert np.abs(J - Jfd).max() < 1e-5, (v, a, J, Jfd)
+        ev = np.linalg.eigvalsh((J + J.T) / 2)
+        assert ev.min() > -1e-6 and ev.max() < 1 + 1e-6
+
+
+@pytest.mark.parametrize("alpha", [0.5, 0.25])
+def test_geometric_mean_maximisation(alpha):
+    A, b, c, cones, xs = kit.geo_mean_max(np.array([1.0, 2.0]), 2.0, alpha)
+    x, y, s, st, it = solve1(A, b, c, cones)
+    assert st == 1
+    np.testing.assert_allclose(x[:2], xs, atol=1e-6)
+    np.testing.assert_allclose(x[2], xs[0] ** alpha * xs[1] ** (1 - alpha), atol=1e-6)
