@@ -20,7 +20,7 @@ class CeTemplate(C.Structure):
     _fields_ = [("n", C.c_int), ("m", C.c_int), ("nnz_aug", C.c_int), ("indices", C.POINTER(C.c_int)),
                 ("indptr", C.POINTER(C.c_int)), ("z", C.c_int), ("l", C.c_int), ("nq", C.c_int),
                 ("q", C.POINTER(C.c_int)), ("ns", C.c_int), ("s", C.POINTER(C.c_int)), ("nep", C.c_int),
-                ("np", C.c_int)]
+                ("np", C.c_int), ("p", C.POINTER(C.c_double))]
 
 
 class CeSettings(C.Structure):

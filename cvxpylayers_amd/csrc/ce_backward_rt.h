@@ -55,7 +55,7 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
     double *pinfo = p; p += 2;          // pivot value per buffer
     double *red = p; p += NWB * 8;
     double *psdU = p, *psdEv = p, *lamr = p, *psdScr = p, *expW = p;     // PSD: eigenvectors per cone, eigenvalues, DPi eigenvalue per rotated row, scratch
-    if constexpr (PSD) { psdU = p; p += T.ns * T.maxs * T.maxs; psdEv = p; p += T.ns * T.maxs; lamr = p; p += m; psdScr = p; p += 8 * T.maxs * T.maxs + 2 * T.maxs + 8; expW = p; p += 9 * T.nep; }
+    if constexpr (PSD) { psdU = p; p += T.ns * T.maxs * T.maxs; psdEv = p; p += T.ns * T.maxs; lamr = p; p += m; psdScr = p; p += 8 * T.maxs * T.maxs + 2 * T.maxs + 8; expW = p; p += 9 * (T.nep + T.np); }
     double *U = p; p += bwd_rt_union_doubles(n, m, nqs, TI, TJ, BGR);
     double *ay = U, *as = U + nqs * n;                              // A_c^T e_y, A_c^T e_s
     double *colbuf = U, *rowbuf = U + 2 * BGR * TI;
@@ -146,13 +146,13 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
                 __syncthreads();
             }
         }
-            // Exponential cones: S = D Pi_K*(v_c) = W diag(theta) W^T (3x3, one thread per cone).  The triple's rows are rotated,
+            // Exponential / power cones: S = D Pi_K*(v_c) = W diag(theta) W^T (3x3, one thread per cone).  The triple's rows are rotated,
         // A_c <- W^T A_c, exactly like a PSD block: afterwards each row is an equality (theta = 1), free (0) or weighted row.
-        if (T.nep > 0) {
-            for (int c = tid; c < T.nep; c += NTB) {
+        if (T.nep + T.np > 0) {
+            for (int c = tid; c < T.nep + T.np; c += NTB) {
                 const int r0 = T.eoff + 3 * c;
                 double W[9], th[3];
-                exp_dual_eig(vv + r0, W, th);
+                if (c < T.nep) exp_dual_eig(vv + r0, W, th); else pow_dual_eig(vv + r0, T.pw[c - T.nep], W, th);
                 const double *h = dyg + (size_t)inst * m + r0;
 #pragma unroll
                 for (int a = 0; a < 3; a++) {
@@ -166,7 +166,7 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
                 for (int k = 0; k < 9; k++) expW[9 * c + k] = W[k];
             }
             __syncthreads();
-            for (int idx = tid; idx < T.nep * n; idx += NTB) {
+            for (int idx = tid; idx < (T.nep + T.np) * n; idx += NTB) {
                 const int c = idx / n, j = idx - c * n, r0 = T.eoff + 3 * c;
                 const double *W = expW + 9 * c;
                 const double a0 = A[r0 * lda + j], a1 = A[(r0 + 1) * lda + j], a2 = A[(r0 + 2) * lda + j];
@@ -262,7 +262,7 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
                 acc += as[c * n + j] * esd + a / (1 - lam);
             }
             if constexpr (PSD) {
-                for (int t = T.soff[0] + part; t < T.eoff + 3 * T.nep; t += 4)
+                for (int t = T.soff[0] + part; t < T.eoff + 3 * (T.nep + T.np); t += 4)
                     if (rkind[t] == RK_MIX) acc = fma(A[t * lda + j], dv[t] / (1 - lamr[t]), acc);
             }
         }
@@ -305,7 +305,7 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
             }
     }
     if constexpr (PSD) {   // weighted rows of rotated PSD blocks: H += theta_t a_t^T a_t
-        for (int t = T.soff[0]; t < T.eoff + 3 * T.nep; t++) {
+        for (int t = T.soff[0]; t < T.eoff + 3 * (T.nep + T.np); t++) {
             if (rkind[t] != RK_MIX) continue;              // uniform
             const double th = lamr[t] / (1 - lamr[t]);
             const double *row = A + t * lda;
@@ -489,7 +489,7 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
     }
     __syncthreads();
     if constexpr (PSD) {   // r~ in the rotated basis, then r_y,c = Q r~ = svec(U smat(r~) U^T)
-        for (int t = T.soff[0] + tid; t < T.eoff + 3 * T.nep; t += NTB) {
+        for (int t = T.soff[0] + tid; t < T.eoff + 3 * (T.nep + T.np); t += NTB) {
             const int rk = rkind[t];
             vv[t] = (rk == RK_EQ) ? bv[eqrow[t]] : (rk == RK_FREE ? dv[t] : (dv[t] - lamr[t] * qv2[t]) / (1 - lamr[t]));
         }
@@ -518,7 +518,7 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
             }
             __syncthreads();
         }
-        for (int c = tid; c < T.nep; c += NTB) {                     // r_y,c = W r~
+        for (int c = tid; c < T.nep + T.np; c += NTB) {                     // r_y,c = W r~
             const int r0 = T.eoff + 3 * c;
             const double *W = expW + 9 * c;
             const double t0 = vv[r0], t1 = vv[r0 + 1], t2 = vv[r0 + 2];

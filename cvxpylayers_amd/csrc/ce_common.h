@@ -21,7 +21,9 @@ struct DevT {
     int ns, maxs;         // PSD cones, largest order
     const int *soff;      // [ns+1] first row of PSD cone c (svec blocks follow the SOCs, SCS row order z,l,q,s)
     const int *sord;      // [ns] order k of PSD cone c
-    int nep, eoff;        // exponential cones (3 rows each) and their first row (after the PSD blocks: SCS row order z,l,q,s,ep)
+    int nep, eoff;        // exponential cones (3 rows each) and their first row (after the PSD blocks: SCS row order z,l,q,s,ep,p)
+    int np;               // 3-d power cones, after the exponential cones
+    const double *pw;     // [np] exponent a of x^a y^(1-a) >= |z|; a < 0: the dual cone of exponent |a| (SCS convention)
 };
 
 thread_local std::string g_err;

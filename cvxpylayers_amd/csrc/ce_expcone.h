@@ -115,12 +115,10 @@ __device__ __noinline__ void exp_dproject(const double *v, double *J) {
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) J[i * 3 + j] = a[i] * i0[j] + Y * da[i] * i2[j];
 }
 
-// Eigendecomposition of the symmetric 3x3  S = D Pi_K*(v) = I - D Pi_K(-v):  S = W diag(th) W^T (columns of W), cyclic Jacobi.
-__device__ __noinline__ void exp_dual_eig(const double *v, double *W, double *th) {
-    double w[3] = {-v[0], -v[1], -v[2]}, J[9];
-    exp_dproject(w, J);
+// Eigendecomposition of a symmetric 3x3 (row-major S9; only the symmetric part is used):  S = W diag(th) W^T, cyclic Jacobi.
+__device__ __noinline__ void sym3_eig(const double *S9, double *W, double *th) {
     double S[3][3];
-    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) S[i][j] = ((i == j) ? 1.0 : 0.0) - 0.5 * (J[i * 3 + j] + J[j * 3 + i]);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) S[i][j] = 0.5 * (S9[i * 3 + j] + S9[j * 3 + i]);
     double V[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
     for (int sweep = 0; sweep < 12; sweep++) {
         const double off = fabs(S[0][1]) + fabs(S[0][2]) + fabs(S[1][2]);
@@ -142,4 +140,122 @@ __device__ __noinline__ void exp_dual_eig(const double *v, double *W, double *th
         }
     }
     for (int i = 0; i < 3; i++) { th[i] = S[i][i]; for (int j = 0; j < 3; j++) W[i * 3 + j] = V[i][j]; }
+}
+
+// S = D Pi_K*(v) = I - D Pi_K(-v) of the exponential cone, diagonalised (columns of W).
+__device__ __noinline__ void exp_dual_eig(const double *v, double *W, double *th) {
+    double w[3] = {-v[0], -v[1], -v[2]}, J[9];
+    exp_dproject(w, J);
+    for (int i = 0; i < 9; i++) J[i] = ((i % 4 == 0) ? 1.0 : 0.0) - J[i];
+    sym3_eig(J, W, th);
+}
+
+// ------------------------------------------------------------------------------------------------
+// 3-d power cone  K_a = {(x,y,z): x^a y^(1-a) >= |z|, x,y >= 0},  K_a^* = {(u,v,w): (u/a)^a (v/(1-a))^(1-a) >= |w|, u,v >= 0}.
+// Outside K and -K*, with z0 != 0, the projection is (x(r), y(r), sign(z0) r),
+//     x(r) = (x0 + sqrt(x0^2 + 4 a r (|z0| - r)))/2,  y(r) = (y0 + sqrt(y0^2 + 4 (1-a) r (|z0| - r)))/2,
+// r in (0, |z0|) the root of Phi(r) = x(r)^a y(r)^(1-a) - r  (Hien 2015; the formulation SCS uses).  Bracketed Newton, warm-started
+// from the previous iteration's r.  A template entry a < 0 denotes the dual cone K_|a|^* (SCS convention).
+__device__ __forceinline__ double pow_branch(double t0, double q) {       // (t0 + sqrt(t0^2 + 4q))/2 without cancellation for t0 < 0
+    const double sq = sqrt(t0 * t0 + 4 * q);
+    return t0 >= 0 ? 0.5 * (t0 + sq) : 2 * q / (sq - t0);
+}
+// returns the case (0 inside K, 1 inside -K*, 2 the z0 == 0 face, 3 boundary); r_io: warm start in, root out
+__device__ __forceinline__ int pow_project(double &p0, double &p1, double &p2, double a, double &r_io) {
+    const double x0 = p0, y0 = p1, z0 = p2, az = fabs(z0);
+    if (x0 >= 0 && y0 >= 0 && pow(x0, a) * pow(y0, 1 - a) >= az) return 0;
+    if (x0 <= 0 && y0 <= 0 && pow(-x0 / a, a) * pow(-y0 / (1 - a), 1 - a) >= az) { p0 = p1 = p2 = 0; return 1; }
+    if (az == 0) { p0 = x0 > 0 ? x0 : 0; p1 = y0 > 0 ? y0 : 0; return 2; }
+    double lo = 0, hi = az, r = r_io;
+    if (!(r > lo && r < hi)) r = 0.5 * az;
+    double x = 0, y = 0;
+    for (int it = 0; it < 120; it++) {
+        const double qq = r * (az - r);
+        const double sx = sqrt(x0 * x0 + 4 * a * qq), sy = sqrt(y0 * y0 + 4 * (1 - a) * qq);
+        x = x0 >= 0 ? 0.5 * (x0 + sx) : 2 * a * qq / (sx - x0);
+        y = y0 >= 0 ? 0.5 * (y0 + sy) : 2 * (1 - a) * qq / (sy - y0);
+        EXP_COUNT_ITER
+        const double f = pow(x, a) * pow(y, 1 - a), g = f - r;
+        if (g > 0) lo = r; else if (g < 0) hi = r; else break;
+        const double dq = az - 2 * r;
+        const double dg = f * (a * a * dq / (sx * x) + (1 - a) * (1 - a) * dq / (sy * y)) - 1;      // Phi'(r)
+        double nr = r - g / dg;
+        if (dg < 0 && nr > 0 && nr < az && fabs(nr - r) <= 3e-9 * fmin(nr, az - nr)) { r = nr; break; }   // quadratic convergence: error ~ step^2
+        if (!(dg < 0) || !(nr > lo) || !(nr < hi)) nr = 0.5 * (lo + hi);
+        const double step = fabs(nr - r);
+        r = nr;
+        if (step <= 4e-16 * az) break;
+        if (hi - lo <= 2e-16 * az) break;
+    }
+    const double qq = r * (az - r);
+    p0 = pow_branch(x0, a * qq); p1 = pow_branch(y0, (1 - a) * qq); p2 = z0 > 0 ? r : -r;
+    r_io = r;
+    return 3;
+}
+// projection of the solver's cone step for a template entry `a`: onto the DUAL of the entry's cone (a > 0: K_a^*, a < 0: K_|a|)
+__device__ __forceinline__ void pow_project_dual_of_entry(double *v, double a, double *r_state) {
+    const double al = fabs(a);
+    double r = *r_state;
+    if (a < 0) { double w0 = v[0], w1 = v[1], w2 = v[2]; pow_project(w0, w1, w2, al, r); v[0] = w0; v[1] = w1; v[2] = w2; }
+    else {
+        const double v0 = v[0], v1 = v[1], v2 = v[2];
+        double w0 = -v0, w1 = -v1, w2 = -v2;
+        pow_project(w0, w1, w2, al, r);
+        v[0] = v0 + w0; v[1] = v1 + w1; v[2] = v2 + w2;
+    }
+    *r_state = r;
+}
+// J = D Pi_{K_a}(v): on the boundary p - v = lam grad g(p), g = x^a y^(1-a) - |z| = 0, lam = |z0| - r; implicit function theorem:
+//   [[I - lam H, -grad g], [-grad g^T, 0]] [dp; dlam] = [dv; 0]       (H = Hessian of g), solved by 4x4 elimination with pivoting.
+__device__ __noinline__ void pow_dproject(const double *v, double a, double *J) {
+    double p0 = v[0], p1 = v[1], p2 = v[2], r = -1.0;
+    const int kase = pow_project(p0, p1, p2, a, r);
+    for (int i = 0; i < 9; i++) J[i] = 0;
+    if (kase == 0) { J[0] = J[4] = J[8] = 1; return; }
+    if (kase == 1) return;
+    if (kase == 2) { J[0] = v[0] > 0 ? 1.0 : 0.0; J[4] = v[1] > 0 ? 1.0 : 0.0; return; }
+    const double x = fmax(p0, 1e-100), y = fmax(p1, 1e-100), sg = v[2] > 0 ? 1.0 : -1.0, lam = fmax(fabs(v[2]) - fabs(p2), 0.0);
+    const double f = pow(x, a) * pow(y, 1 - a);
+    const double g[3] = {a * f / x, (1 - a) * f / y, -sg};
+    const double hxy = a * (1 - a) * f / (x * y);
+    double G[4][4] = {{1 - lam * a * (a - 1) * f / (x * x), -lam * hxy, 0, -g[0]},
+                      {-lam * hxy, 1 + lam * a * (1 - a) * f / (y * y), 0, -g[1]},
+                      {0, 0, 1, -g[2]},
+                      {-g[0], -g[1], -g[2], 0}};
+    double R[4][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}, {0, 0, 0}};
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        int pv = c;
+#pragma unroll
+        for (int i = 0; i < 4; i++) if (i > c && fabs(G[i][c]) > fabs(G[pv][c])) pv = i;
+#pragma unroll
+        for (int i = 0; i < 4; i++) if (i == pv && pv != c) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) { const double t = G[c][j]; G[c][j] = G[i][j]; G[i][j] = t; }
+#pragma unroll
+            for (int j = 0; j < 3; j++) { const double t = R[c][j]; R[c][j] = R[i][j]; R[i][j] = t; }
+        }
+        const double d = 1.0 / G[c][c];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            if (i == c) continue;
+            const double fct = G[i][c] * d;
+#pragma unroll
+            for (int j = 0; j < 4; j++) G[i][j] -= fct * G[c][j];
+#pragma unroll
+            for (int j = 0; j < 3; j++) R[i][j] -= fct * R[c][j];
+        }
+    }
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) J[i * 3 + j] = R[i][j] / G[i][i];
+}
+// S = D Pi onto the dual of the entry's cone, diagonalised
+__device__ __noinline__ void pow_dual_eig(const double *v, double a, double *W, double *th) {
+    double J[9];
+    if (a < 0) pow_dproject(v, -a, J);
+    else {
+        double w[3] = {-v[0], -v[1], -v[2]};
+        pow_dproject(w, a, J);
+        for (int i = 0; i < 9; i++) J[i] = ((i % 4 == 0) ? 1.0 : 0.0) - J[i];
+    }
+    sym3_eig(J, W, th);
 }

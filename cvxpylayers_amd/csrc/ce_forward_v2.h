@@ -245,7 +245,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
         if (i < m) { const int c = T.rowcone[i]; if (c >= 0) { r0 = T.qoff[c]; d = T.qoff[c + 1] - r0; } }
         if constexpr (PSD) {      // rows of PSD cones: block start and NEGATIVE block length (same block averaging, separate projection)
             for (int c = 0; c < T.ns; c++) if (i >= T.soff[c] && i < T.soff[c + 1]) { r0 = T.soff[c]; d = -(T.soff[c + 1] - r0); }
-            if (i >= T.eoff && i < T.eoff + 3 * T.nep) { r0 = T.eoff + 3 * ((i - T.eoff) / 3); d = -3; }      // exponential-cone triples
+            if (i >= T.eoff && i < T.eoff + 3 * (T.nep + T.np)) { r0 = T.eoff + 3 * ((i - T.eoff) / 3); d = -3; }      // exponential / power cone triples
         }
         socr[i] = r0; socd[i] = d;
     }
@@ -659,9 +659,12 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
         if constexpr (PSD) {   // PSD blocks of the cone input are projected in place (all threads, one cone after the other)
             double *psdS = Gm + n * ldg, *psdV = psdS + T.maxs * T.maxs, *psdC = psdV + T.maxs * T.maxs;
             for (int c = 0; c < T.ns; c++) psd_project<NTH>(sm + L::O_ZB + OY + T.soff[c], T.sord[c], psdS, psdV, psdC, red);
-            if (T.nep > 0) {   // exponential cones: one thread per cone, root warm-started from the previous iteration (ce_expcone.h)
+            if (T.nep + T.np > 0) {   // exponential / power cones: one thread per cone, root warm-started from the previous iteration (ce_expcone.h)
                 double *expR = Gm + n * ldg + (T.ns > 0 ? 2 * T.maxs * T.maxs + 2 * T.maxs + 8 : 0);
-                for (int c = threadIdx.x; c < T.nep; c += NTH) exp_project_dual(sm + L::O_ZB + OY + T.eoff + 3 * c, expR + c);
+                for (int c = threadIdx.x; c < T.nep + T.np; c += NTH) {
+                    double *zc = sm + L::O_ZB + OY + T.eoff + 3 * c;
+                    if (c < T.nep) exp_project_dual(zc, expR + c); else pow_project_dual_of_entry(zc, T.pw[c - T.nep], expR + c);
+                }
                 __syncthreads();
             }
         }

@@ -50,6 +50,7 @@ struct ce_engine {
     int device = 0;
     DevT T{};
     std::vector<int> q, s;
+    double *d_pw = nullptr;
     int *d_rowidx = nullptr, *d_colidx = nullptr, *d_rowcone = nullptr, *d_qoff = nullptr, *d_soff = nullptr, *d_sord = nullptr;
     // workspace
     double *wsA = nullptr; size_t wsA_bytes = 0;          // batch-major copy of A_vals  [B][nnz_aug]
@@ -123,7 +124,7 @@ static const int BRT_VARIANTS[BRT_NV][4] = {{4, 4, 4, 16}, {7, 7, 4, 16}, {7, 7,
 static size_t bwd_rt_lds_bytes(const DevT &T, int TI, int TJ, int BGR) {
     const int n = T.n, m = T.m, nqs = std::max(T.nq, 1);
     size_t d = (size_t)m * n /* lda = n */ + 3 * (size_t)m + 2 * (size_t)n + 6 * nqs + BGR * TI + 2 + (BGR * 16 / 64) * 8 + bwd_rt_union_doubles(n, m, nqs, TI, TJ, BGR);
-    if (T.ns > 0 || T.nep > 0) d += (size_t)T.ns * T.maxs * T.maxs + (size_t)T.ns * T.maxs + m + 8 * (size_t)T.maxs * T.maxs + 2 * T.maxs + 8 + 9 * (size_t)T.nep;
+    if (T.ns > 0 || T.nep + T.np > 0) d += (size_t)T.ns * T.maxs * T.maxs + (size_t)T.ns * T.maxs + m + 8 * (size_t)T.maxs * T.maxs + 2 * T.maxs + 8 + 9 * (size_t)(T.nep + T.np);
     size_t ints = 2 * (size_t)m + 2 * nqs + BGC * TJ + BGR * TI + (BGR * 16 / 64) + 1 + 8;
     return d * 8 + ints * 4 + 16;
 }
@@ -164,7 +165,7 @@ static bool f2_fits(const DevT &T, int v, int *ldg, size_t *bytes) {
     if (T.maxq > SOC_SMALL && T.nq > d.NP) return false;
     *ldg = f2_pick_ldg(v);
     if ((size_t)T.n * *ldg < (size_t)d.NPa) return false;
-    const size_t psd = (T.ns > 0 ? 2 * (size_t)T.maxs * T.maxs + 2 * (size_t)T.maxs + 8 : 0) + (size_t)T.nep;      // Jacobi scratch: S, V, (c, s, p, q) per pair; one root per exponential cone
+    const size_t psd = (T.ns > 0 ? 2 * (size_t)T.maxs * T.maxs + 2 * (size_t)T.maxs + 8 : 0) + (size_t)(T.nep + T.np);      // Jacobi scratch: S, V, (c, s, p, q) per pair; one root per exponential cone
     *bytes = ((size_t)d.O_G + d.MP /* SOC row info (2 int arrays) */ + (size_t)T.n * *ldg + psd) * 8;
     return *bytes <= LDS_LIMIT;
 }
@@ -180,12 +181,12 @@ void ce_default_settings(ce_settings *s) {
 
 int ce_create(const ce_template *tpl, int device, ce_handle *out) {
     if (!tpl || !out || tpl->n <= 0 || tpl->m <= 0 || !tpl->indices || !tpl->indptr) { g_err = "bad template"; return CE_E_BADARG; }
-    if (tpl->np > 0) { g_err = "power cones are not implemented on the device path"; return CE_E_UNSUPPORTED; }
-    if (tpl->nep < 0) { g_err = "bad exponential cone count"; return CE_E_BADARG; }
+    if (tpl->nep < 0 || tpl->np < 0 || (tpl->np > 0 && !tpl->p)) { g_err = "bad exponential / power cone description"; return CE_E_BADARG; }
+    for (int i = 0; i < tpl->np; i++) if (!(fabs(tpl->p[i]) > 0.0 && fabs(tpl->p[i]) < 1.0)) { g_err = "power cone exponent must lie in (-1, 0) or (0, 1)"; return CE_E_BADARG; }
     int rows = tpl->z + tpl->l;
     for (int i = 0; i < tpl->nq; i++) { if (tpl->q[i] < 1) { g_err = "bad SOC dim"; return CE_E_BADARG; } rows += tpl->q[i]; }
     for (int i = 0; i < tpl->ns; i++) { if (tpl->s[i] < 1) { g_err = "bad PSD order"; return CE_E_BADARG; } rows += tpl->s[i] * (tpl->s[i] + 1) / 2; }
-    rows += 3 * tpl->nep;
+    rows += 3 * tpl->nep + 3 * tpl->np;
     if (rows != tpl->m) { g_err = "cone dims do not add up to m"; return CE_E_BADARG; }
     if (tpl->indptr[tpl->n + 1] != tpl->nnz_aug) { g_err = "indptr[n+1] != nnz_aug"; return CE_E_BADARG; }
     HIPCHK(hipSetDevice(device));
@@ -208,7 +209,12 @@ int ce_create(const ce_template *tpl, int device, ce_handle *out) {
     T.ns = tpl->ns; T.maxs = 0;
     for (int c = 0; c < tpl->ns; c++) { soff[c] = r; sord[c] = tpl->s[c]; T.maxs = std::max(T.maxs, tpl->s[c]); r += tpl->s[c] * (tpl->s[c] + 1) / 2; }
     soff[tpl->ns] = r;
-    T.nep = tpl->nep; T.eoff = r;
+    T.nep = tpl->nep; T.eoff = r; T.np = tpl->np; T.pw = nullptr;
+    if (tpl->np > 0) {
+        HIPCHK(hipMalloc(&h->d_pw, sizeof(double) * tpl->np));
+        HIPCHK(hipMemcpy(h->d_pw, tpl->p, sizeof(double) * tpl->np, hipMemcpyHostToDevice));
+        T.pw = h->d_pw;
+    }
     h->q.assign(tpl->q, tpl->q + tpl->nq);
     HIPCHK(hipMalloc(&h->d_rowidx, sizeof(int) * tpl->nnz_aug));
     HIPCHK(hipMalloc(&h->d_colidx, sizeof(int) * tpl->nnz_aug));
@@ -237,7 +243,7 @@ int ce_create(const ce_template *tpl, int device, ce_handle *out) {
         for (int v = 0; v < F2_NV; v++) {
             int ldg; size_t by;
             if (!f2_fits(T, v, &ldg, &by)) continue;
-            if ((T.ns > 0 || T.nep > 0) && F2_VARIANTS[v][6] != 256) continue;     // PSD / exponential-cone kernels are instantiated for the 256-thread variants only
+            if ((T.ns > 0 || T.nep + T.np > 0) && F2_VARIANTS[v][6] != 256) continue;     // PSD / exponential-cone kernels are instantiated for the 256-thread variants only
             const int *V = F2_VARIANTS[v];
             const int CHT = V[0], T1 = V[1], CHA = V[2], T2 = V[3], NTH = V[6];
             std::vector<int> pos((size_t)T.m * T.n, -1), ib(T.m, -1), iat((size_t)T1 * NTH, -1), iar((size_t)T2 * NTH, -1);
@@ -271,7 +277,7 @@ int ce_create(const ce_template *tpl, int device, ce_handle *out) {
     if (!getenv("CE_FORCE_GENERIC")) {
         for (int v = 0; v < BRT_NV; v++) {
             const int TI = BRT_VARIANTS[v][0], TJ = BRT_VARIANTS[v][1], TH = BRT_VARIANTS[v][2], BGR = BRT_VARIANTS[v][3];
-            if ((T.ns > 0 || T.nep > 0) && BGR != 16) continue;        // PSD / exponential-cone kernels are instantiated for the 256-thread variants only
+            if ((T.ns > 0 || T.nep + T.np > 0) && BGR != 16) continue;        // PSD / exponential-cone kernels are instantiated for the 256-thread variants only
             if (h->nkcap <= BGC * TJ - 1 && h->nkcap <= BGR * TI && T.n <= BGC * TH && bwd_rt_lds_bytes(T, TI, TJ, BGR) <= LDS_LIMIT) {
                 h->brt_variant = v; h->bwd_mode = 3; h->bwd_lds = bwd_rt_lds_bytes(T, TI, TJ, BGR); break;
             }
@@ -295,7 +301,7 @@ int ce_create(const ce_template *tpl, int device, ce_handle *out) {
 int ce_destroy(ce_handle h) {
     if (!h) return CE_OK;
     hipSetDevice(h->device);
-    hipFree(h->d_rowidx); hipFree(h->d_colidx); hipFree(h->d_rowcone); hipFree(h->d_qoff); hipFree(h->d_soff); hipFree(h->d_sord);
+    hipFree(h->d_rowidx); hipFree(h->d_colidx); hipFree(h->d_rowcone); hipFree(h->d_qoff); hipFree(h->d_soff); hipFree(h->d_sord); hipFree(h->d_pw);
     hipFree(h->wsA); hipFree(h->wsdA); hipFree(h->gws); hipFree(h->d_idx_at); hipFree(h->d_idx_ar); hipFree(h->d_idx_b);
     for (auto &v : h->ev) for (auto &p : v) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
     delete h;
@@ -340,7 +346,7 @@ int ce_solve(ce_handle h, int B, const double *A_vals, long sA_k, long sA_b, con
     if (!h || B <= 0 || !A_vals || !q_vals || !x || !y || !s || !iters || !status) { g_err = "null argument"; return CE_E_BADARG; }
     HIPCHK(hipSetDevice(h->device));
     hipStream_t st = (hipStream_t)stream;
-    if (h->T.nep > 0 && h->fwd_mode != 4) { g_err = "exponential cones: the template does not fit the LDS-resident forward kernel (n <= 50, m <= 104 this round)"; return CE_E_UNSUPPORTED; }
+    if (h->T.nep + h->T.np > 0 && h->fwd_mode != 4) { g_err = "exponential / power cones: the template does not fit the LDS-resident forward kernel (n <= 50, m <= 104 this round)"; return CE_E_UNSUPPORTED; }
     if (h->T.ns > 0 && h->fwd_mode != 4) { g_err = "PSD cones: per-instance A does not fit the LDS-resident forward kernel (n <= 50, m <= 104 this round); only batch-invariant A is supported at this size (constant-A path)"; return CE_E_UNSUPPORTED; }
     ce_settings S; if (settings) S = *settings; else ce_default_settings(&S);
     const double *Abm = nullptr;
@@ -363,7 +369,7 @@ int ce_solve(ce_handle h, int B, const double *A_vals, long sA_k, long sA_b, con
 #define LAUNCH_RT(...) hipLaunchKernelGGL((k_forward_rt<__VA_ARGS__>), grid, dim3(NT2), h->fwd_lds, st, Trt, S, Abm, q_vals, sq_k, sq_b, x, y, s, iters, status, resid)
         DevT Tf2 = T; Tf2.ldg = h->f2_ldg;
 #define LAUNCH_F2(...) hipLaunchKernelGGL((k_fwd2<__VA_ARGS__>), grid, dim3(F2_VARIANTS[h->f2_variant][6]), h->fwd_lds, st, Tf2, S, Abm, q_vals, sq_k, sq_b, h->d_idx_at, h->d_idx_ar, h->d_idx_b, x, y, s, iters, status, resid)
-        if (h->fwd_mode == 4 && (T.ns > 0 || T.nep > 0)) {
+        if (h->fwd_mode == 4 && (T.ns > 0 || T.nep + T.np > 0)) {
             if (h->f2_variant == 0) LAUNCH_F2(16, 2, 8, 2, 16, 2, true); else if (h->f2_variant == 1) LAUNCH_F2(8, 8, 4, 8, 8, 4, true); else LAUNCH_F2(4, 26, 2, 26, 4, 14, true);
         } else if (h->fwd_mode == 4) {
             if (h->f2_variant == 0) LAUNCH_F2(16, 2, 8, 2, 16, 2); else if (h->f2_variant == 1) LAUNCH_F2(8, 8, 4, 8, 8, 4); else if (h->f2_variant == 2) LAUNCH_F2(4, 26, 2, 26, 4, 14); else if (h->f2_variant == 3) LAUNCH_F2(8, 20, 2, 32, 8, 8, false, 512); else LAUNCH_F2(4, 30, 4, 26, 4, 26, false, 512);
@@ -386,7 +392,7 @@ int ce_vjp(ce_handle h, int B, const double *A_vals, long sA_k, long sA_b, const
     HIPCHK(hipSetDevice(h->device));
     hipStream_t st = (hipStream_t)stream;
     const DevT &T = h->T;
-    if ((T.ns > 0 || T.nep > 0) && (h->bwd_mode != 3 || !BRT_HAS_PSD)) { g_err = "PSD / exponential cones: adjoint not available for this template size"; return CE_E_UNSUPPORTED; }
+    if ((T.ns > 0 || T.nep + T.np > 0) && (h->bwd_mode != 3 || !BRT_HAS_PSD)) { g_err = "PSD / exponential cones: adjoint not available for this template size"; return CE_E_UNSUPPORTED; }
     const double *Abm = nullptr;
     int rc;
     if (A_vals) { rc = to_batch_major(h, B, A_vals, sA_k, sA_b, st, &Abm); if (rc) return rc; }
@@ -409,7 +415,7 @@ int ce_vjp(ce_handle h, int B, const double *A_vals, long sA_k, long sA_b, const
 #define LAUNCH_B(AL, KL) hipLaunchKernelGGL((k_backward<AL, KL>), grid, block, h->bwd_lds, st, T, h->nkcap, h->ldk, Abm, x, y, s, dx, dy, dAbm, dq_vals, sdq_k, sdq_b, adj_status, gA, gK)
         DevT Tb = T; Tb.lda = T.n;
 #define LAUNCH_BRT(...) hipLaunchKernelGGL((k_backward_rt<__VA_ARGS__>), grid, dim3(h->brt_variant >= 0 ? BRT_VARIANTS[h->brt_variant][3] * 16 : NT), h->bwd_lds, st, Tb, Abm, x, y, s, dx, dy, dAbm, dq_vals, sdq_k, sdq_b, adj_status)
-        if (h->bwd_mode == 3 && (T.ns > 0 || T.nep > 0)) {
+        if (h->bwd_mode == 3 && (T.ns > 0 || T.nep + T.np > 0)) {
             if (h->brt_variant == 0) LAUNCH_BRT(4, 4, 4, true); else if (h->brt_variant == 1) LAUNCH_BRT(7, 7, 4, true); else LAUNCH_BRT(7, 7, 7, true);
         } else if (h->bwd_mode == 3) {
             if (h->brt_variant == 0) LAUNCH_BRT(4, 4, 4); else if (h->brt_variant == 1) LAUNCH_BRT(7, 7, 4); else if (h->brt_variant == 2) LAUNCH_BRT(7, 7, 7); else LAUNCH_BRT(7, 13, 7, false, 32);

@@ -94,7 +94,9 @@ class ConeEngine:
         t.z, t.l = int(cone_dict.get("z", 0)), int(cone_dict.get("l", 0))
         t.nq, t.q = len(q), q.ctypes.data_as(C.POINTER(C.c_int))
         t.ns, t.s = len(s), s.ctypes.data_as(C.POINTER(C.c_int))
-        t.nep, t.np = int(cone_dict.get("ep", 0)), len(cone_dict.get("p", []))
+        self._pw = np.ascontiguousarray(cone_dict.get("p", []), dtype=np.float64)
+        t.nep, t.np = int(cone_dict.get("ep", 0)), len(self._pw)
+        t.p = self._pw.ctypes.data_as(C.POINTER(C.c_double))
         h = C.c_void_p()
         rc = L.ce_create(C.byref(t), device.index or 0, C.byref(h))
         if rc == -2:
@@ -163,7 +165,7 @@ class ConeEngine:
         import os
         from cvxpylayers_amd.interfaces.const_a import is_constant_A
         env = os.environ.get("CE_CONST_A")
-        if env == "0" or A_bm.shape[0] < 2 or int(self.cone_dict.get("ep", 0)) > 0:     # (the batch-GEMM path has no exponential-cone step)
+        if env == "0" or A_bm.shape[0] < 2 or int(self.cone_dict.get("ep", 0)) + len(self.cone_dict.get("p", [])) > 0:     # (the batch-GEMM path has no exponential / power cone step)
             return False
         if env != "1" and self.launch_info()["fwd_mode"] not in (1, 2):
             return False

@@ -55,8 +55,9 @@ typedef struct {
     const int *q;          /* [nq] SOC dimensions ("q"), layout (t, x) */
     int ns;                /* number of PSD cones ("s") */
     const int *s;          /* [ns] PSD orders; svec lower-tri column-major, sqrt(2) off-diagonals */
-    int nep;               /* exponential cones ("ep")  -- must be 0 this round */
-    int np;                /* power cones ("p")         -- must be 0 this round */
+    int nep;               /* exponential cones ("ep"): triples (x, y, z), y exp(x/y) <= z, after the PSD blocks (SCS row order z,l,q,s,ep,p) */
+    int np;                /* 3-d power cones ("p"): triples (x, y, z), x^a y^(1-a) >= |z|, after the exponential cones */
+    const double *p;       /* [np] exponents a in (0, 1); a negative entry -a is the DUAL power cone of exponent a (SCS convention)  (HOST memory) */
 } ce_template;
 
 /* Solver settings; names follow SCS / diffcp keyword arguments (diffcp maps eps -> eps_abs, eps_rel). */

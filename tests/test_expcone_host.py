@@ -17,6 +17,7 @@ SRC = r'''
 #define __forceinline__ inline
 #define __noinline__
 #include "ce_expcone.h"
+using std::fmin; using std::fmax;
 extern "C" {
 void h_proj(double *v, double rho0, int dual, double *rho_out) {
     if (dual) { double r = rho0; exp_project_dual(v, &r); *rho_out = r; }
@@ -24,6 +25,9 @@ void h_proj(double *v, double rho0, int dual, double *rho_out) {
 }
 void h_dproj(const double *v, double *J) { exp_dproject(v, J); }
 void h_eig(const double *v, double *W, double *th) { exp_dual_eig(v, W, th); }
+void h_pproj(double *v, double a, double r0) { double r = r0; pow_project_dual_of_entry(v, a, &r); }
+void h_pdproj(const double *v, double a, double *J) { pow_dproject(v, a, J); }
+void h_peig(const double *v, double a, double *W, double *th) { pow_dual_eig(v, a, W, th); }
 }
 '''
 
@@ -37,6 +41,7 @@ def host(tmp_path_factory):
     L = C.CDLL(so)
     dp = C.POINTER(C.c_double)
     L.h_proj.argtypes = [dp, C.c_double, C.c_int, dp]; L.h_dproj.argtypes = [dp, dp]; L.h_eig.argtypes = [dp, dp, dp]
+    L.h_pproj.argtypes = [dp, C.c_double, C.c_double]; L.h_pdproj.argtypes = [dp, C.c_double, dp]; L.h_peig.argtypes = [dp, C.c_double, dp, dp]
     return L
 
 
@@ -70,3 +75,21 @@ def test_device_exp_projection_special_points(host):
         assert np.abs(w - oracle.proj_exp(v)).max() <= 1e-10 * (1 + np.linalg.norm(v)), (v, w, oracle.proj_exp(v))
         J = np.zeros((3, 3)); host.h_dproj(_p(v.copy()), _p(J))
         assert np.isfinite(J).all()
+
+
+def test_device_power_cone_routines_match_oracle(host):
+    rng = np.random.default_rng(0)
+    for t in range(4000):
+        a = rng.uniform(0.05, 0.95) * (1 if t % 3 else -1)            # negative entry: the dual cone (SCS convention)
+        v = rng.standard_normal(3) * 10 ** rng.uniform(-2, 2)
+        w = v.copy()
+        host.h_pproj(_p(w), a, float(abs(rng.standard_normal())))     # projection onto the dual of the entry's cone, any warm start
+        ref = oracle.proj_pow(v, a, dual=True)
+        assert np.abs(w - ref).max() <= 1e-12 * (1 + np.linalg.norm(v)), (v, a, w, ref)
+        if a > 0:
+            J = np.zeros((3, 3)); host.h_pdproj(_p(v.copy()), a, _p(J))
+            assert np.abs(J - oracle.dproj_pow(v, a)).max() < 1e-6, (v, a)
+        W = np.zeros((3, 3)); th = np.zeros(3)
+        host.h_peig(_p(v.copy()), a, _p(W), _p(th))
+        Sd = oracle.dproj_pow(v, a, dual=True); Sd = (Sd + Sd.T) / 2
+        assert np.abs(W @ np.diag(th) @ W.T - Sd).max() < 1e-6 and np.abs(W.T @ W - np.eye(3)).max() < 1e-12, (v, a)

@@ -344,3 +344,16 @@ def test_warm_start_matches_oracle_warm_start():
     for got, want in ((x, rw["x"]), (y, rw["y"]), (s, rw["s"])):
         err = np.abs(got.cpu().numpy() - want).max(axis=1) / (1 + np.abs(want).max(axis=1))
         assert err.max() < 2e-5, err.max()
+
+
+# ------------------------------------------------------------------ 3-d power cones (after the exponential cones; negative exponent = dual cone)
+def test_power_cone_forward_and_adjoint_parity():
+    run_parity(8, {"z": 1, "l": 3, "q": [3], "s": [], "ep": 1, "p": [0.3, -0.6, 0.5]}, 16, seed=3, eps=1e-9, max_iters=200000)
+
+
+def test_geometric_mean_known_answer_on_gpu():
+    A, b, c, cones, xs = kit.geo_mean_max(np.array([1.0, 2.0]), 2.0, 0.25)
+    tpl = P.dense_template(A.shape[1], cones)
+    *_, x, y, s, iters, status, resid = gpu_solve(tpl, A[None], b[None], c[None], eps=1e-10, max_iters=100000)
+    assert status[0] == 1
+    np.testing.assert_allclose(x.cpu().numpy()[0][:2], xs, atol=1e-6)
