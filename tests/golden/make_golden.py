@@ -26,12 +26,18 @@ CASES = {
     "socp_C3": (100, {"z": 0, "l": 10, "q": [11] * 10}, 4, 2),
     "sdp_small": (6, {"z": 2, "l": 3, "q": [4], "s": [3]}, 8, 5),
     "sdp_C4_lite": (36, {"z": 6, "l": 0, "q": [], "s": [8]}, 4, 6),
+    "expcone_mixed": (8, {"z": 2, "l": 4, "q": [4], "s": [], "ep": 3}, 8, 1),
+    "expcone_logreg_shape": (40, {"z": 0, "l": 12, "q": [4], "s": [], "ep": 24}, 4, 0),
+    "powcone_mixed": (8, {"z": 1, "l": 3, "q": [3], "s": [], "ep": 1, "p": [0.3, -0.6, 0.5]}, 8, 3),
 }
+ONLY_NEW = "--only-new" in sys.argv      # keep the fixtures already committed byte-identical
 
 
 def main():
     here = os.path.dirname(os.path.abspath(__file__))
     for name, (n, cones, B, seed) in CASES.items():
+        if ONLY_NEW and os.path.exists(os.path.join(here, name + ".npz")):
+            continue
         A, b, c = P.generate(n, cones, B, seed=seed)
         r = oracle.solve_batch(A, b, c, cones, eps=1e-10, max_iters=200000)
         assert (r["status"] == 1).all(), (name, r["status"])
@@ -41,7 +47,8 @@ def main():
         g = oracle.adjoint_batch(A, b, c, cones, r["x"], r["y"], r["s"], dx, dy, mode="dense")
         np.savez_compressed(os.path.join(here, name + ".npz"), n=n, B=B, seed=seed,
                             z=cones.get("z", 0), l=cones.get("l", 0), q=np.asarray(cones.get("q", []), dtype=np.int64),
-                            s=np.asarray(cones.get("s", []), dtype=np.int64),
+                            s=np.asarray(cones.get("s", []), dtype=np.int64), ep=int(cones.get("ep", 0)),
+                            p=np.asarray(cones.get("p", []), dtype=np.float64),
                             x=r["x"], y=r["y"], sl=r["s"], dx=dx, dy=dy, dA=g["dA"], db=g["db"], dc=g["dc"])
         print(name, "iters", r["iters"].max(), "file", name + ".npz")
 

@@ -16,6 +16,10 @@ FILES = sorted(glob.glob(os.path.join(HERE, "golden", "*.npz")))
 def load(path):
     d = np.load(path)
     cones = {"z": int(d["z"]), "l": int(d["l"]), "q": [int(v) for v in d["q"]], "s": [int(v) for v in d["s"]]}
+    if "ep" in d.files and int(d["ep"]):
+        cones["ep"] = int(d["ep"])
+    if "p" in d.files and len(d["p"]):
+        cones["p"] = [float(v) for v in d["p"]]
     n, B, seed = int(d["n"]), int(d["B"]), int(d["seed"])
     A, b, c = P.generate(n, cones, B, seed=seed)
     return d, n, cones, A, b, c
