@@ -55,7 +55,7 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
     double *pinfo = p; p += 2;          // pivot value per buffer
     double *red = p; p += NWB * 8;
     double *psdU = p, *psdEv = p, *lamr = p, *psdScr = p, *expW = p;     // PSD: eigenvectors per cone, eigenvalues, DPi eigenvalue per rotated row, scratch
-    if constexpr (PSD) { psdU = p; p += T.ns * T.maxs * T.maxs; psdEv = p; p += T.ns * T.maxs; lamr = p; p += m; psdScr = p; p += 8 * T.maxs * T.maxs + 2 * T.maxs + 8; expW = p; p += 9 * (T.nep + T.np); }
+    if constexpr (PSD) { psdU = p; p += T.ns * T.maxs * T.maxs; psdEv = p; p += T.ns * T.maxs; lamr = p; p += m; psdScr = p; p += 2 * NWB * T.maxs * T.maxs + 2 * T.maxs + 8;   /* one (X, W) pair per wave */ expW = p; p += 9 * (T.nep + T.np); }
     double *U = p; p += bwd_rt_union_doubles(n, m, nqs, TI, TJ, BGR);
     double *ay = U, *as = U + nqs * n;                              // A_c^T e_y, A_c^T e_s
     double *colbuf = U, *rowbuf = U + 2 * BGR * TI;

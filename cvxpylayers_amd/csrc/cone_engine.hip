@@ -124,7 +124,7 @@ static const int BRT_VARIANTS[BRT_NV][4] = {{4, 4, 4, 16}, {7, 7, 4, 16}, {7, 7,
 static size_t bwd_rt_lds_bytes(const DevT &T, int TI, int TJ, int BGR) {
     const int n = T.n, m = T.m, nqs = std::max(T.nq, 1);
     size_t d = (size_t)m * n /* lda = n */ + 3 * (size_t)m + 2 * (size_t)n + 6 * nqs + BGR * TI + 2 + (BGR * 16 / 64) * 8 + bwd_rt_union_doubles(n, m, nqs, TI, TJ, BGR);
-    if (T.ns > 0 || T.nep + T.np > 0) d += (size_t)T.ns * T.maxs * T.maxs + (size_t)T.ns * T.maxs + m + 8 * (size_t)T.maxs * T.maxs + 2 * T.maxs + 8 + 9 * (size_t)(T.nep + T.np);
+    if (T.ns > 0 || T.nep + T.np > 0) d += (size_t)T.ns * T.maxs * T.maxs + (size_t)T.ns * T.maxs + m + 2 * (size_t)(BGR * 16 / 64) * T.maxs * T.maxs + 2 * T.maxs + 8 + 9 * (size_t)(T.nep + T.np);
     size_t ints = 2 * (size_t)m + 2 * nqs + BGC * TJ + BGR * TI + (BGR * 16 / 64) + 1 + 8;
     return d * 8 + ints * 4 + 16;
 }
@@ -243,7 +243,6 @@ int ce_create(const ce_template *tpl, int device, ce_handle *out) {
         for (int v = 0; v < F2_NV; v++) {
             int ldg; size_t by;
             if (!f2_fits(T, v, &ldg, &by)) continue;
-            if ((T.ns > 0 || T.nep + T.np > 0) && F2_VARIANTS[v][6] != 256) continue;     // PSD / exponential-cone kernels are instantiated for the 256-thread variants only
             const int *V = F2_VARIANTS[v];
             const int CHT = V[0], T1 = V[1], CHA = V[2], T2 = V[3], NTH = V[6];
             std::vector<int> pos((size_t)T.m * T.n, -1), ib(T.m, -1), iat((size_t)T1 * NTH, -1), iar((size_t)T2 * NTH, -1);
@@ -277,7 +276,6 @@ int ce_create(const ce_template *tpl, int device, ce_handle *out) {
     if (!getenv("CE_FORCE_GENERIC")) {
         for (int v = 0; v < BRT_NV; v++) {
             const int TI = BRT_VARIANTS[v][0], TJ = BRT_VARIANTS[v][1], TH = BRT_VARIANTS[v][2], BGR = BRT_VARIANTS[v][3];
-            if ((T.ns > 0 || T.nep + T.np > 0) && BGR != 16) continue;        // PSD / exponential-cone kernels are instantiated for the 256-thread variants only
             if (h->nkcap <= BGC * TJ - 1 && h->nkcap <= BGR * TI && T.n <= BGC * TH && bwd_rt_lds_bytes(T, TI, TJ, BGR) <= LDS_LIMIT) {
                 h->brt_variant = v; h->bwd_mode = 3; h->bwd_lds = bwd_rt_lds_bytes(T, TI, TJ, BGR); break;
             }
@@ -288,9 +286,10 @@ int ce_create(const ce_template *tpl, int device, ce_handle *out) {
     SETATTR((k_forward_rt<8, 13, 7, 4, 13, 160, 4>), LDS_LIMIT); SETATTR((k_forward_rt<8, 16, 8, 4, 16, 208, 4>), LDS_LIMIT); SETATTR((k_forward_rt<4, 32, 32, 4, 32, 272, 2>), LDS_LIMIT);
     SETATTR((k_fwd2<16, 2, 8, 2, 16, 2, true>), LDS_LIMIT); SETATTR((k_fwd2<8, 8, 4, 8, 8, 4, true>), LDS_LIMIT); SETATTR((k_fwd2<4, 26, 2, 26, 4, 14, true>), LDS_LIMIT);
     SETATTR((k_fwd2<4, 30, 4, 26, 4, 26, false, 512>), LDS_LIMIT); SETATTR((k_fwd2<8, 20, 2, 32, 8, 8, false, 512>), LDS_LIMIT);
+    SETATTR((k_fwd2<4, 30, 4, 26, 4, 26, true, 512>), LDS_LIMIT); SETATTR((k_fwd2<8, 20, 2, 32, 8, 8, true, 512>), LDS_LIMIT);
     SETATTR((k_fwd2<16, 2, 8, 2, 16, 2>), LDS_LIMIT); SETATTR((k_fwd2<8, 8, 4, 8, 8, 4>), LDS_LIMIT); SETATTR((k_fwd2<4, 26, 2, 26, 4, 14>), LDS_LIMIT);
     SETATTR((k_backward_rt<4, 4, 4, true>), LDS_LIMIT); SETATTR((k_backward_rt<7, 7, 4, true>), LDS_LIMIT); SETATTR((k_backward_rt<7, 7, 7, true>), LDS_LIMIT);
-    SETATTR((k_backward_rt<7, 13, 7, false, 32>), LDS_LIMIT);
+    SETATTR((k_backward_rt<7, 13, 7, false, 32>), LDS_LIMIT); SETATTR((k_backward_rt<7, 13, 7, true, 32>), LDS_LIMIT);
     SETATTR((k_backward_rt<4, 4, 4>), LDS_LIMIT); SETATTR((k_backward_rt<7, 7, 4>), LDS_LIMIT); SETATTR((k_backward_rt<7, 7, 7>), LDS_LIMIT);
     SETATTR((k_backward<true, true>), LDS_LIMIT); SETATTR((k_backward<true, false>), LDS_LIMIT); SETATTR((k_backward<false, false>), LDS_LIMIT);
 #undef SETATTR
@@ -346,8 +345,8 @@ int ce_solve(ce_handle h, int B, const double *A_vals, long sA_k, long sA_b, con
     if (!h || B <= 0 || !A_vals || !q_vals || !x || !y || !s || !iters || !status) { g_err = "null argument"; return CE_E_BADARG; }
     HIPCHK(hipSetDevice(h->device));
     hipStream_t st = (hipStream_t)stream;
-    if (h->T.nep + h->T.np > 0 && h->fwd_mode != 4) { g_err = "exponential / power cones: the template does not fit the LDS-resident forward kernel (n <= 50, m <= 104 this round)"; return CE_E_UNSUPPORTED; }
-    if (h->T.ns > 0 && h->fwd_mode != 4) { g_err = "PSD cones: per-instance A does not fit the LDS-resident forward kernel (n <= 50, m <= 104 this round); only batch-invariant A is supported at this size (constant-A path)"; return CE_E_UNSUPPORTED; }
+    if (h->T.nep + h->T.np > 0 && h->fwd_mode != 4) { g_err = "exponential / power cones: the template does not fit the LDS-resident forward kernel (n <= 98, m <= 120 this round)"; return CE_E_UNSUPPORTED; }
+    if (h->T.ns > 0 && h->fwd_mode != 4) { g_err = "PSD cones: per-instance A does not fit the LDS-resident forward kernel (n <= 98, m <= 120 this round); only batch-invariant A is supported at this size (constant-A path)"; return CE_E_UNSUPPORTED; }
     ce_settings S; if (settings) S = *settings; else ce_default_settings(&S);
     const double *Abm = nullptr;
     int rc = to_batch_major(h, B, A_vals, sA_k, sA_b, st, &Abm);
@@ -370,7 +369,7 @@ int ce_solve(ce_handle h, int B, const double *A_vals, long sA_k, long sA_b, con
         DevT Tf2 = T; Tf2.ldg = h->f2_ldg;
 #define LAUNCH_F2(...) hipLaunchKernelGGL((k_fwd2<__VA_ARGS__>), grid, dim3(F2_VARIANTS[h->f2_variant][6]), h->fwd_lds, st, Tf2, S, Abm, q_vals, sq_k, sq_b, h->d_idx_at, h->d_idx_ar, h->d_idx_b, x, y, s, iters, status, resid)
         if (h->fwd_mode == 4 && (T.ns > 0 || T.nep + T.np > 0)) {
-            if (h->f2_variant == 0) LAUNCH_F2(16, 2, 8, 2, 16, 2, true); else if (h->f2_variant == 1) LAUNCH_F2(8, 8, 4, 8, 8, 4, true); else LAUNCH_F2(4, 26, 2, 26, 4, 14, true);
+            if (h->f2_variant == 0) LAUNCH_F2(16, 2, 8, 2, 16, 2, true); else if (h->f2_variant == 1) LAUNCH_F2(8, 8, 4, 8, 8, 4, true); else if (h->f2_variant == 2) LAUNCH_F2(4, 26, 2, 26, 4, 14, true); else if (h->f2_variant == 3) LAUNCH_F2(8, 20, 2, 32, 8, 8, true, 512); else LAUNCH_F2(4, 30, 4, 26, 4, 26, true, 512);
         } else if (h->fwd_mode == 4) {
             if (h->f2_variant == 0) LAUNCH_F2(16, 2, 8, 2, 16, 2); else if (h->f2_variant == 1) LAUNCH_F2(8, 8, 4, 8, 8, 4); else if (h->f2_variant == 2) LAUNCH_F2(4, 26, 2, 26, 4, 14); else if (h->f2_variant == 3) LAUNCH_F2(8, 20, 2, 32, 8, 8, false, 512); else LAUNCH_F2(4, 30, 4, 26, 4, 26, false, 512);
         } else if (h->fwd_mode == 3) {
@@ -416,7 +415,7 @@ int ce_vjp(ce_handle h, int B, const double *A_vals, long sA_k, long sA_b, const
         DevT Tb = T; Tb.lda = T.n;
 #define LAUNCH_BRT(...) hipLaunchKernelGGL((k_backward_rt<__VA_ARGS__>), grid, dim3(h->brt_variant >= 0 ? BRT_VARIANTS[h->brt_variant][3] * 16 : NT), h->bwd_lds, st, Tb, Abm, x, y, s, dx, dy, dAbm, dq_vals, sdq_k, sdq_b, adj_status)
         if (h->bwd_mode == 3 && (T.ns > 0 || T.nep + T.np > 0)) {
-            if (h->brt_variant == 0) LAUNCH_BRT(4, 4, 4, true); else if (h->brt_variant == 1) LAUNCH_BRT(7, 7, 4, true); else LAUNCH_BRT(7, 7, 7, true);
+            if (h->brt_variant == 0) LAUNCH_BRT(4, 4, 4, true); else if (h->brt_variant == 1) LAUNCH_BRT(7, 7, 4, true); else if (h->brt_variant == 2) LAUNCH_BRT(7, 7, 7, true); else LAUNCH_BRT(7, 13, 7, true, 32);
         } else if (h->bwd_mode == 3) {
             if (h->brt_variant == 0) LAUNCH_BRT(4, 4, 4); else if (h->brt_variant == 1) LAUNCH_BRT(7, 7, 4); else if (h->brt_variant == 2) LAUNCH_BRT(7, 7, 7); else LAUNCH_BRT(7, 13, 7, false, 32);
         } else if (h->bwd_mode == 0) LAUNCH_B(true, true); else if (h->bwd_mode == 1) LAUNCH_B(true, false); else LAUNCH_B(false, false);

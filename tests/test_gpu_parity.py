@@ -357,3 +357,14 @@ def test_geometric_mean_known_answer_on_gpu():
     *_, x, y, s, iters, status, resid = gpu_solve(tpl, A[None], b[None], c[None], eps=1e-10, max_iters=100000)
     assert status[0] == 1
     np.testing.assert_allclose(x.cpu().numpy()[0][:2], xs, atol=1e-6)
+
+
+# ------------------------------------------------------------------ PSD / exponential cones on the 512-thread kernel variants (50 < n <= 98)
+def test_psd_order_12_on_the_512_thread_variants():
+    eng, A_bm, ref = _forward_parity(78, {"z": 6, "l": 0, "q": [], "s": [12]}, 3, seed=6, eps=1e-9)
+    assert eng.launch_info()["fwd_mode"] == 4 and eng.launch_info()["bwd_mode"] == 3
+    run_parity(78, {"z": 6, "l": 0, "q": [], "s": [12]}, 3, seed=6, eps=1e-9, max_iters=200000)
+
+
+def test_exp_cones_on_the_512_thread_variants():
+    run_parity(60, {"z": 4, "l": 12, "q": [4], "s": [], "ep": 28}, 4, seed=2, eps=1e-9, max_iters=200000)
