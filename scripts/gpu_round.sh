@@ -9,19 +9,19 @@ OUT=$PWD/gpurun_out/$TAG
 mkdir -p "$OUT"
 make -C oracle -B >/dev/null 2>&1
 echo "== pytest -m gpu" | tee "$OUT/summary.txt"
-timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -8 | tee -a "$OUT/summary.txt"
+timeout 600 python -m pytest tests -m gpu -x -q 2>&1 | tail -8 | tee -a "$OUT/summary.txt"
 echo "== smoke" | tee -a "$OUT/summary.txt"
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids | tail -3 | tee -a "$OUT/summary.txt"
 echo "== bench" | tee -a "$OUT/summary.txt"
-timeout 900 python bench.py 2>"$OUT/bench.err" | tee "$OUT/bench.json" | cut -c1-600 | tee -a "$OUT/summary.txt"
+timeout 300 python bench.py 2>"$OUT/bench.err" | tee "$OUT/bench.json" | cut -c1-600 | tee -a "$OUT/summary.txt"
 echo "== bench eps=1e-8" | tee -a "$OUT/summary.txt"
-timeout 900 python bench.py --eps 1e-8 --no-cpu 2>>"$OUT/bench.err" | tee "$OUT/bench_eps8.json" | cut -c1-300 | tee -a "$OUT/summary.txt"
+timeout 300 python bench.py --eps 1e-8 --no-cpu 2>>"$OUT/bench.err" | tee "$OUT/bench_eps8.json" | cut -c1-300 | tee -a "$OUT/summary.txt"
 echo "== rocprofv3 kernel-trace stats" | tee -a "$OUT/summary.txt"
-(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OUT/prof" -o trace --output-format csv -- python "$OLDPWD/bench.py" --no-cpu > "$OUT/prof.log" 2>&1)
+(cd /tmp && timeout 240 rocprofv3 --kernel-trace --stats -d "$OUT/prof" -o trace --output-format csv -- python "$OLDPWD/bench.py" --no-cpu > "$OUT/prof.log" 2>&1)
 find "$OUT/prof" -name "*kernel_stats.csv" | head -1 | xargs -r head -12 | tee -a "$OUT/summary.txt"
 echo "== pmc FETCH_SIZE / WRITE_SIZE (separate passes)" | tee -a "$OUT/summary.txt"
-(cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -o p --output-format csv -- python "$OLDPWD/bench.py" --no-cpu --steps 2 --warmup 1 > "$OUT/pmc_fetch.log" 2>&1)
-(cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/pmc_write" -o p --output-format csv -- python "$OLDPWD/bench.py" --no-cpu --steps 2 --warmup 1 > "$OUT/pmc_write.log" 2>&1)
+(cd /tmp && timeout 240 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -o p --output-format csv -- python "$OLDPWD/bench.py" --no-cpu --steps 2 --warmup 1 > "$OUT/pmc_fetch.log" 2>&1)
+(cd /tmp && timeout 240 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d "$OUT/pmc_write" -o p --output-format csv -- python "$OLDPWD/bench.py" --no-cpu --steps 2 --warmup 1 > "$OUT/pmc_write.log" 2>&1)
 python scripts/pmc_summary.py "$OUT" 2>&1 | tee -a "$OUT/summary.txt"
 # keep the merge small: drop raw databases
 find "$OUT" -name "*.db" -delete
