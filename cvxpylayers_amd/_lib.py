@@ -13,7 +13,7 @@ SO_PATH = os.path.join(_HERE, "csrc", "libcone_engine.so")
 
 # every symbol include/cone_engine.h declares
 SYMBOLS = ["ce_default_settings", "ce_create", "ce_destroy", "ce_last_error", "ce_solve", "ce_vjp",
-           "ce_transpose", "ce_parammap_apply", "ce_parammap_apply2", "ce_ca_step", "ce_ca_check", "ce_ca_psd", "ce_ca_update", "ce_ca_finish", "ce_set_profiling", "ce_get_profile", "ce_reset_profile", "ce_get_launch_info"]
+           "ce_transpose", "ce_parammap_apply", "ce_parammap_apply2", "ce_ca_step", "ce_ca_check", "ce_ca_psd", "ce_ca_triples", "ce_ca_triple_jac", "ce_ca_update", "ce_ca_finish", "ce_set_profiling", "ce_get_profile", "ce_reset_profile", "ce_get_launch_info"]
 
 
 class CeTemplate(C.Structure):
@@ -67,6 +67,8 @@ def lib():
     L.ce_ca_check.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(CeSettings), dp, dp, dp, dp, lg, dp, lg, dp, dp, dp, dp, dp, dp, dp,
                               dp, dp, ip, ip, ip, ip, ip, dp, ip, vp]
     L.ce_ca_psd.argtypes = [vp, C.c_int, C.c_int, dp, ip, vp]
+    L.ce_ca_triples.argtypes = [vp, C.c_int, C.c_int, dp, dp, ip, vp]
+    L.ce_ca_triple_jac.argtypes = [vp, C.c_int, dp, lg, dp, vp]
     L.ce_ca_update.argtypes = [vp, C.c_int, C.c_int, dp, dp, dp, ip, C.c_int, C.c_double, vp]
     L.ce_ca_finish.argtypes = [vp, C.c_int, C.c_int, C.c_int, dp, dp, dp, dp, dp, dp, dp, dp, dp, ip, ip, ip, dp, dp, dp, vp]
     L.ce_set_profiling.argtypes = [vp, C.c_int]

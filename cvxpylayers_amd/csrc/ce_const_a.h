@@ -213,6 +213,37 @@ k_ca_psd(DevT T, int lp, double *__restrict__ Ug, const int *__restrict__ active
     psd_project<NT>(Ug + (size_t)inst * lp + T.n + T.soff[c], k, Sm, Vm, cs, red);
 }
 
+// K4b: exponential / power cone triples of the cone input (B, lp) projected in place, one thread per (instance, cone); `roots`
+// (B, nep + np) keeps each cone's root between iterations (the warm start of the bracketed Newton iteration, ce_expcone.h).
+__global__ void __launch_bounds__(NT)
+k_ca_triples(DevT T, int lp, int B, double *__restrict__ Ug, double *__restrict__ roots, const int *__restrict__ active) {
+    const int ntri = T.nep + T.np;
+    const int idx = blockIdx.x * NT + threadIdx.x;
+    if (idx >= B * ntri) return;
+    const int inst = idx / ntri, c = idx - inst * ntri;
+    if (!active[inst]) return;
+    double *zc = Ug + (size_t)inst * lp + T.n + T.eoff + 3 * c;
+    double *rs = roots + (size_t)inst * ntri + c;
+    if (c < T.nep) exp_project_dual(zc, rs); else pow_project_dual_of_entry(zc, T.pw[c - T.nep], rs);
+}
+// K4c: J (B, nep + np, 9) = D Pi of the same projection at v = y - s (row-major 3x3 per cone), for the batched-LSQR adjoint.
+__global__ void __launch_bounds__(NT)
+k_ca_triple_jac(DevT T, int B, const double *__restrict__ vg, long ldv, double *__restrict__ Jg) {
+    const int ntri = T.nep + T.np;
+    const int idx = blockIdx.x * NT + threadIdx.x;
+    if (idx >= B * ntri) return;
+    const int inst = idx / ntri, c = idx - inst * ntri;
+    const double *v = vg + (size_t)inst * ldv + T.eoff + 3 * c;
+    double w[3] = {-v[0], -v[1], -v[2]}, J[9];
+    if (c < T.nep) { exp_dproject(w, J); for (int i = 0; i < 9; i++) J[i] = ((i % 4 == 0) ? 1.0 : 0.0) - J[i]; }
+    else {
+        const double a = T.pw[c - T.nep];
+        if (a < 0) { const double vv[3] = {v[0], v[1], v[2]}; pow_dproject(vv, -a, J); }
+        else { pow_dproject(w, a, J); for (int i = 0; i < 9; i++) J[i] = ((i % 4 == 0) ? 1.0 : 0.0) - J[i]; }
+    }
+    for (int i = 0; i < 9; i++) Jg[(size_t)idx * 9 + i] = J[i];
+}
+
 // K5: the relaxed update (and renormalisation) split off k_ca_step, for templates whose PSD blocks are projected in between.
 __global__ void __launch_bounds__(NT)
 k_ca_update(int l, int lp, double *__restrict__ Wg, const double *__restrict__ UTg, const double *__restrict__ Ug,

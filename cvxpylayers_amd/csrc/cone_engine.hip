@@ -478,6 +478,24 @@ int ce_ca_psd(ce_handle h, int B, int lp, double *U, const int *active, void *st
     HIPCHK(hipGetLastError());
     return CE_OK;
 }
+int ce_ca_triples(ce_handle h, int B, int lp, double *U, double *roots, const int *active, void *stream) {
+    if (!h || B <= 0 || !U || !roots || !active) { g_err = "null argument"; return CE_E_BADARG; }
+    const int ntri = h->T.nep + h->T.np;
+    if (ntri == 0) return CE_OK;
+    HIPCHK(hipSetDevice(h->device));
+    hipLaunchKernelGGL(k_ca_triples, dim3(((size_t)B * ntri + NT - 1) / NT), dim3(NT), 0, (hipStream_t)stream, h->T, lp, B, U, roots, active);
+    HIPCHK(hipGetLastError());
+    return CE_OK;
+}
+int ce_ca_triple_jac(ce_handle h, int B, const double *v, long ld_v, double *J, void *stream) {
+    if (!h || B <= 0 || !v || !J) { g_err = "null argument"; return CE_E_BADARG; }
+    const int ntri = h->T.nep + h->T.np;
+    if (ntri == 0) return CE_OK;
+    HIPCHK(hipSetDevice(h->device));
+    hipLaunchKernelGGL(k_ca_triple_jac, dim3(((size_t)B * ntri + NT - 1) / NT), dim3(NT), 0, (hipStream_t)stream, h->T, B, v, ld_v, J);
+    HIPCHK(hipGetLastError());
+    return CE_OK;
+}
 int ce_ca_update(ce_handle h, int B, int lp, double *W, const double *UT, const double *U, const int *active, int norm_after, double alpha, void *stream) {
     if (!h || B <= 0 || !W || !UT || !U || !active) { g_err = "null argument"; return CE_E_BADARG; }
     HIPCHK(hipSetDevice(h->device));

@@ -105,12 +105,13 @@ def solve_const_a(eng, A_bm: torch.Tensor, q_eval: torch.Tensor, settings, warm=
     cone = eng.cone_dict
     z, nl, qs = int(cone.get("z", 0)), int(cone.get("l", 0)), [int(v) for v in cone.get("q", [])]
     psd = _psd_blocks(cone, dev)
+    ntri = int(cone.get("ep", 0)) + len(cone.get("p", []))       # exponential / power cone triples (after the PSD blocks)
     # ---- equilibration of the one shared matrix (25 Ruiz passes + 1 l2 pass, row scalings averaged inside SOC blocks)
     D = torch.ones(m, **f64); E = torch.ones(n, **f64)
     if settings.normalize:
         blk = torch.full((m,), -1, dtype=torch.int64, device=dev)
         off = z + nl
-        blocks = qs + [pb.d for pb in psd]          # row scalings are averaged inside SOC and PSD blocks alike
+        blocks = qs + [pb.d for pb in psd] + [3] * ntri      # row scalings are averaged inside SOC / PSD blocks and exp / power triples alike
         for k, d in enumerate(blocks):
             blk[off:off + d] = k
             off += d
@@ -187,6 +188,7 @@ def solve_const_a(eng, A_bm: torch.Tensor, q_eval: torch.Tensor, settings, warm=
         ok = (torch.isfinite(Wx).all(dim=1) & torch.isfinite(Wy).all(dim=1))[:, None]
         W[:, :n] = torch.where(ok, Wx, W[:, :n]); W[:, n:n + m] = torch.where(ok, Wy, W[:, n:n + m])
     UT = torch.zeros((B, lp), **f64); U = torch.zeros((B, lp), **f64)
+    roots = torch.zeros((B, max(ntri, 1)), **f64)        # per-cone root of the previous iteration (exp / power projections)
     active = torch.ones(B, dtype=torch.int32, device=dev)
     status = torch.zeros(B, dtype=torch.int32, device=dev)
     iters = torch.zeros(B, dtype=torch.int32, device=dev)
@@ -219,12 +221,15 @@ def solve_const_a(eng, A_bm: torch.Tensor, q_eval: torch.Tensor, settings, warm=
         norm_after = int(((it + 1) % CONVERGED_INTERVAL) == 0)
         _lib.check(L.ce_ca_step(h, Bc, lp, W.data_ptr(), UT.data_ptr(), U.data_ptr(), PX.data_ptr(), PX.stride(0), QY.data_ptr(),
                                 QY.stride(0), state["G"].data_ptr(), state["PHI"].data_ptr(), scale.data_ptr(),
-                                state["inv_den"].data_ptr(), active.data_ptr(), int(not (check or last) and not psd),
+                                state["inv_den"].data_ptr(), active.data_ptr(), int(not (check or last) and not psd and not ntri),
                                 norm_after, alpha, strm), "ce_ca_step")
-        if psd:
+        if psd or ntri:
             # PSD blocks: the step kernel leaves the cone input in U; project it in place (ce_ca_psd: workgroup-parallel Jacobi,
             # ~600x faster than batched rocSOLVER eigh at 20x20), then the relaxed update / renormalisation the kernel skipped
-            _lib.check(L.ce_ca_psd(h, Bc, lp, U.data_ptr(), active.data_ptr(), strm), "ce_ca_psd")
+            if psd:
+                _lib.check(L.ce_ca_psd(h, Bc, lp, U.data_ptr(), active.data_ptr(), strm), "ce_ca_psd")
+            if ntri:
+                _lib.check(L.ce_ca_triples(h, Bc, lp, U.data_ptr(), roots.data_ptr(), active.data_ptr(), strm), "ce_ca_triples")
             if not (check or last):
                 _lib.check(L.ce_ca_update(h, Bc, lp, W.data_ptr(), UT.data_ptr(), U.data_ptr(), active.data_ptr(), norm_after, alpha, strm), "ce_ca_update")
 
@@ -275,7 +280,7 @@ def solve_const_a(eng, A_bm: torch.Tensor, q_eval: torch.Tensor, settings, warm=
                 keep = (active != 0).nonzero().flatten()
                 write_back(done_rows)
                 rows = rows[keep]
-                W, UT, U = W[keep].contiguous(), UT[keep].contiguous(), U[keep].contiguous()
+                W, UT, U, roots = W[keep].contiguous(), UT[keep].contiguous(), U[keep].contiguous(), roots[keep].contiguous()
                 bh, ch, sigma, nrm_b0, nrm_c0 = bh[keep].contiguous(), ch[keep].contiguous(), sigma[keep].contiguous(), nrm_b0[keep].contiguous(), nrm_c0[keep].contiguous()
                 scale, sum_log, n_log, last_sc = scale[keep].contiguous(), sum_log[keep].contiguous(), n_log[keep].contiguous(), last_sc[keep].contiguous()
                 active, status, iters, resid, rescaled = active[keep].contiguous(), status[keep].contiguous(), iters[keep].contiguous(), resid[keep].contiguous(), rescaled[keep].contiguous()
@@ -295,7 +300,7 @@ def solve_const_a(eng, A_bm: torch.Tensor, q_eval: torch.Tensor, settings, warm=
 # is the same reduced system the per-instance kernels eliminate directly).  diffcp itself solves its system with LSQR
 # (mode="lsqr" is its default); here every operator application is a GEMM over the batch plus elementwise cone derivatives.
 # ======================================================================================================================
-def _dproj(v, h, z, nl, qs, psd=(), psd_eig=None):
+def _dproj(v, h, z, nl, qs, psd=(), psd_eig=None, tri=None):
     """DPi_{K*}(v) h, blockwise: zero rows (dual cone free) -> h; nonneg -> h [v > 0]; SOC -> closed form (cone_oracle.c dproj_soc)."""
     out = h.clone()
     if nl:
@@ -320,6 +325,11 @@ def _dproj(v, h, z, nl, qs, psd=(), psd_eig=None):
     for pb, (Uv, Bm) in zip(psd, psd_eig or ()):      # DPi(V)[H] = U (B o (U^T H U)) U^T
         Hm = pb.smat(h[:, pb.off:pb.off + pb.d])
         out[:, pb.off:pb.off + pb.d] = pb.svec(Uv @ (Bm * (Uv.transpose(1, 2) @ Hm @ Uv)) @ Uv.transpose(1, 2))
+    if tri is not None:       # exponential / power triples: 3x3 Jacobians J (B, ntri, 3, 3) from ce_ca_triple_jac (symmetric)
+        off0, J = tri
+        ntri = J.shape[1]
+        hb = h[:, off0:off0 + 3 * ntri].reshape(-1, ntri, 3, 1)
+        out[:, off0:off0 + 3 * ntri] = (J @ hb).reshape(-1, 3 * ntri)
     return out
 
 
@@ -354,18 +364,26 @@ def vjp_const_a(eng, A_bm, x, y, s, dx, dy, batch_minor_out=False, atol=1e-12, b
     v = y - s
     psd = _psd_blocks(cone, dev)
     peig = _psd_eig(v, psd)
+    ntri = int(cone.get("ep", 0)) + len(cone.get("p", []))
+    tri = None
+    if ntri:
+        vc = v.contiguous()
+        J = torch.empty((B, ntri, 3, 3), **f64)
+        _lib.check(_lib.lib().ce_ca_triple_jac(eng._h, B, vc.data_ptr(), vc.stride(0), J.data_ptr(),
+                                               C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "ce_ca_triple_jac")
+        tri = (m - 3 * ntri, 0.5 * (J + J.transpose(2, 3)))
 
     def N(rx, ry):          # (B,n),(B,m) -> (B,n),(B,m)
-        return -(ry @ A), _dproj(v, rx @ At - ry, z, nl, qs, psd, peig) + ry
+        return -(ry @ A), _dproj(v, rx @ At - ry, z, nl, qs, psd, peig, tri) + ry
 
     def NT(px, py):
-        q = _dproj(v, py, z, nl, qs, psd, peig)
+        q = _dproj(v, py, z, nl, qs, psd, peig, tri)
         return q @ A, -(px @ At) - q + py
 
     def nrm(a, b_):
         return torch.sqrt((a * a).sum(dim=1) + (b_ * b_).sum(dim=1))
 
-    bx, by = dx.to(torch.float64), _dproj(v, dy.to(torch.float64), z, nl, qs, psd, peig)
+    bx, by = dx.to(torch.float64), _dproj(v, dy.to(torch.float64), z, nl, qs, psd, peig, tri)
     # LSQR (Paige & Saunders), batched; rows that met a stopping test are frozen
     bnorm = nrm(bx, by)
     live = bnorm > 0

@@ -165,7 +165,7 @@ class ConeEngine:
         import os
         from cvxpylayers_amd.interfaces.const_a import is_constant_A
         env = os.environ.get("CE_CONST_A")
-        if env == "0" or A_bm.shape[0] < 2 or int(self.cone_dict.get("ep", 0)) + len(self.cone_dict.get("p", [])) > 0:     # (the batch-GEMM path has no exponential / power cone step)
+        if env == "0" or A_bm.shape[0] < 2:
             return False
         if env != "1" and self.launch_info()["fwd_mode"] not in (1, 2):
             return False

@@ -154,6 +154,12 @@ int ce_ca_check(ce_handle h, int B, int lp, int iter, const ce_settings *setting
                 double *scale, double *sum_log, int *n_log, int *last_scale_iter, int *active, int *status, int *iters,
                 double *resid, int *rescaled, void *stream);
 int ce_ca_psd(ce_handle h, int B, int lp, double *U, const int *active, void *stream);
+/* Exponential / power cone triples of the cone input U (B, lp) projected in place (after ce_ca_step, like ce_ca_psd); roots
+ * (B, nep + np) is caller-owned state: each cone's root of the previous iteration (zero-initialised). */
+int ce_ca_triples(ce_handle h, int B, int lp, double *U, double *roots, const int *active, void *stream);
+/* J (B, nep + np, 9): the 3x3 Jacobians of that projection at v = y - s (rows of v have pitch ld_v), used by the batched-LSQR
+ * adjoint of the constant-A path in place of diffcp's per-instance dpi operator (diffcp_if.py:86 -> adj_batch). */
+int ce_ca_triple_jac(ce_handle h, int B, const double *v, long ld_v, double *J, void *stream);
 /* w += alpha (u - ut) (+ renormalisation) as its own launch, for templates whose PSD blocks are projected after ce_ca_step */
 int ce_ca_update(ce_handle h, int B, int lp, double *W, const double *UT, const double *U, const int *active, int norm_after, double alpha, void *stream);
 int ce_ca_finish(ce_handle h, int B, int lp, int max_iters, const double *W, const double *UT, const double *U, const double *D,

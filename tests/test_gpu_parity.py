@@ -368,3 +368,27 @@ def test_psd_order_12_on_the_512_thread_variants():
 
 def test_exp_cones_on_the_512_thread_variants():
     run_parity(60, {"z": 4, "l": 12, "q": [4], "s": [], "ep": 28}, 4, seed=2, eps=1e-9, max_iters=200000)
+
+
+def test_constant_A_path_with_exp_and_power_cones(monkeypatch):
+    """Exponential / power triples on the batch-GEMM path: ce_ca_triples in the forward, ce_ca_triple_jac + batched LSQR in the adjoint."""
+    from oracle import oracle
+    monkeypatch.setenv("CE_CONST_A", "1")
+    n, cones, B = 10, {"z": 2, "l": 3, "q": [4], "s": [3], "ep": 2, "p": [0.4, -0.7]}, 12
+    tpl = P.dense_template(n, cones)
+    A, b, c = P.generate(n, cones, B, seed=33, batched=("b", "c"))
+    eps = 1e-9
+    ref = oracle.solve_batch(A, b, c, cones, eps=eps, max_iters=200000)
+    assert (ref["status"] == 1).all()
+    eng, A_bm, x, y, s, iters, status, resid = gpu_solve(tpl, A, b, c, eps=eps, max_iters=200000)
+    assert eng.last_path == "const_a" and (status == 1).all()
+    for got, want in ((x, ref["x"]), (y, ref["y"]), (s, ref["s"])):
+        assert np.abs(got.cpu().numpy() - want).max() < 1e-6 * (1 + np.abs(want).max())
+    assert np.abs(iters - ref["iters"]).max() <= 25
+    rng = np.random.default_rng(2)
+    dx = rng.standard_normal(ref["x"].shape); dy = rng.standard_normal(ref["y"].shape)
+    g = oracle.adjoint_batch(A, b, c, cones, ref["x"], ref["y"], ref["s"], dx, dy, mode="dense")
+    xr, yr, sr = (torch.from_numpy(ref[k]).cuda() for k in ("x", "y", "s"))
+    dA, dq, adj = eng.vjp(A_bm, xr, yr, sr, torch.from_numpy(dx).cuda(), torch.from_numpy(dy).cuda())
+    assert (adj.cpu().numpy() == 0).all()
+    assert np.abs(dq.cpu().numpy()[:n] - g["dc"].T).max() < 1e-5 * (1 + np.abs(g["dc"]).max())
