@@ -212,6 +212,95 @@ class ConeEngine:
         return dict(fwd_lds_bytes=a.value, bwd_lds_bytes=b.value, fwd_mode=c.value, bwd_mode=d.value)
 
 
+
+class QuadEpigraph:
+    """min 1/2 x^T P x + q^T x + d  s.t.  A x + s = b, s in K      ==>      min t + q^T x + d  s.t. (same), and
+           (t + 1, sqrt(2) L^T x, t - 1) in SOC(n + 2),   P = L L^T,
+    because ||(sqrt(2) L^T x, t - 1)|| <= t + 1  <=>  1/2 x^T P x <= t.  This is the reduction CVXPY itself applies when a solver has
+    no quadratic objective (what DIFFCP receives); doing it here, on device tensors under autograd, lets P be a *parameter*: the
+    Cholesky factor is computed per instance (batched, differentiable), its entries become entries of A_eval, and the gradient
+    with respect to P flows back through torch's Cholesky derivative.  One extra variable (t, last) and one extra SOC block,
+    placed after the template's own SOC blocks (SCS row order z, l, q, s, ep, p); the template's rows keep their relative order.
+
+    P_eval holds the values of P in the CSC structure `objective_structure = (indices, indptr, (n, n))`; a structure with all
+    entries on or above (or on or below) the diagonal is read as one triangle of the symmetric matrix."""
+
+    def __init__(self, objective_structure, A_structure, A_shape, cone_dict):
+        p_indices, p_indptr, (n, n2) = objective_structure
+        m, np1 = A_shape
+        assert n == n2 == np1 - 1, "P must be n x n"
+        self.n, self.m = int(n), int(m)
+        self.p_rows = np.asarray(p_indices, dtype=np.int64)
+        self.p_cols = np.repeat(np.arange(n), np.diff(np.asarray(p_indptr))).astype(np.int64)
+        self.one_triangle = bool(len(self.p_rows)) and (bool((self.p_rows <= self.p_cols).all()) or bool((self.p_rows >= self.p_cols).all()))
+        a_idx, a_ptr = np.asarray(A_structure[0], dtype=np.int64), np.asarray(A_structure[1], dtype=np.int64)
+        nnz_old = int(a_ptr[-1])
+        r0 = int(cone_dict.get("z", 0)) + int(cone_dict.get("l", 0)) + int(sum(cone_dict.get("q", [])))      # first row of the new SOC block
+        self.r0 = r0
+        d = n + 2
+        self.m_aug = m + d
+        remap = np.where(np.arange(m) < r0, np.arange(m), np.arange(m) + d)       # template row -> augmented row
+        self.dual_rows = remap
+        # entries of the augmented [A_cvx | b_cvx] (columns x_0..x_{n-1}, t, b), sorted by (column, row); source index into
+        # cat([A_eval (nnz_old), sqrt(2) * L[j, k] for the n(n+1)/2 pairs j >= k, +1, -1]) per instance
+        tri_j, tri_k = np.tril_indices(n)
+        self.tri_j, self.tri_k = tri_j, tri_k
+        ntri = len(tri_j)
+        ONE, MINUS = nnz_old + ntri, nnz_old + ntri + 1
+        a_cols = np.repeat(np.arange(np1), np.diff(a_ptr))
+        ent = []          # (col, row, source)
+        for kk in range(nnz_old):
+            c_ = int(a_cols[kk])
+            ent.append((c_ if c_ < n else n + 1, int(remap[a_idx[kk]]), kk))
+        for e in range(ntri):          # A_cvx[r0 + 1 + k, j] = sqrt(2) L[j, k]
+            ent.append((int(tri_j[e]), r0 + 1 + int(tri_k[e]), nnz_old + e))
+        ent.append((n, r0, ONE)); ent.append((n, r0 + n + 1, ONE))               # t in the first and the last row of the block
+        ent.append((n + 1, r0, ONE)); ent.append((n + 1, r0 + n + 1, MINUS))     # b = (1, 0, ..., 0, -1)
+        ent.sort()
+        self.aug_indices = np.asarray([e[1] for e in ent], dtype=np.int32)
+        counts = np.bincount(np.asarray([e[0] for e in ent]), minlength=n + 2)
+        self.aug_indptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+        self.src = np.asarray([e[2] for e in ent], dtype=np.int64)
+        self.aug_cones = {**cone_dict, "q": list(cone_dict.get("q", [])) + [d]}
+        self._dev = {}
+
+    def _idx(self, device):
+        key = str(device)
+        if key not in self._dev:
+            t = lambda a: torch.from_numpy(np.asarray(a, dtype=np.int64)).to(device)
+            self._dev[key] = dict(src=t(self.src), pr=t(self.p_rows), pc=t(self.p_cols), tj=t(self.tri_j), tk=t(self.tri_k), dual=t(self.dual_rows))
+        return self._dev[key]
+
+    def assemble(self, P_eval, q_eval, A_eval):
+        """(nnz_P, B), (n+1, B), (nnz_aug, B)  ->  q_aug (n+2, B), A_aug (nnz_aug', B); differentiable torch ops"""
+        ix = self._idx(A_eval.device)
+        n, B = self.n, A_eval.shape[1]
+        f64 = dict(dtype=torch.float64, device=A_eval.device)
+        Pd = torch.zeros((B, n * n), **f64).index_add(1, ix["pr"] * n + ix["pc"], P_eval.to(torch.float64).t()).reshape(B, n, n)
+        if self.one_triangle:
+            Pd = Pd + Pd.transpose(1, 2) - torch.diag_embed(torch.diagonal(Pd, dim1=1, dim2=2))
+        else:
+            Pd = 0.5 * (Pd + Pd.transpose(1, 2))
+        # P is positive semidefinite, possibly singular: a relative jitter keeps the factorisation defined (1e-12 of the largest
+        # diagonal entry: far below the solver tolerance)
+        jit = 1e-12 * torch.diagonal(Pd, dim1=1, dim2=2).abs().amax(dim=1).clamp_min(1e-300) + 1e-300
+        Lf, info = torch.linalg.cholesky_ex(Pd + jit[:, None, None] * torch.eye(n, **f64))
+        if bool((info != 0).any()):
+            raise SolverError("MI355 solver: the quadratic objective matrix P is not positive semidefinite "
+                              f"(Cholesky failed for {int((info != 0).sum())} of {B} instances)")
+        Lvals = (2.0 ** 0.5) * Lf[:, ix["tj"], ix["tk"]].t()                      # (n(n+1)/2, B)
+        one = torch.ones((1, B), **f64)
+        source = torch.cat([A_eval.to(torch.float64), Lvals, one, -one], dim=0)
+        A_aug = source.index_select(0, ix["src"])
+        q64 = q_eval.to(torch.float64)
+        q_aug = torch.cat([q64[:n], one, q64[n:n + 1]], dim=0)
+        return q_aug, A_aug
+
+    def split(self, primal_aug, dual_aug):
+        ix = self._idx(dual_aug.device)
+        return primal_aug[:, :self.n], dual_aug.index_select(1, ix["dual"])
+
+
 class MI355_ctx:
     """Built once per layer from CVXPY's ParamConeProg; same constructor signature as DIFFCP_ctx
     (diffcp_if.py:105-120): constraint_structure = (indices, indptr, (m, n+1)) is the CSC structure of the
@@ -227,6 +316,18 @@ class MI355_ctx:
         self.options = options or {}
         self.default_device = torch.device("cuda", 0)
         self._engines: dict[int, ConeEngine] = {}
+        # Quadratic objective 1/2 x^T P x (plugins registered in SUPPORTS_QUAD_OBJ receive P_eval, _quad_form_dpp.py:32,
+        # interfaces/__init__.py:35-42): handled as an epigraph SOC block over the Cholesky factor of P (see QuadEpigraph).
+        self.quad = QuadEpigraph(objective_structure, self.A_structure, self.A_shape, self.cone_dict) if objective_structure is not None else None
+        self._aug_ctx = None
+
+    def augmented(self) -> "MI355_ctx":
+        """the cone-program context of the epigraph form (one extra variable, one extra SOC of dimension n + 2)"""
+        if self._aug_ctx is None:
+            q = self.quad
+            self._aug_ctx = MI355_ctx(None, (q.aug_indices, q.aug_indptr, (q.m_aug, q.n + 2)), q.aug_cones, None, None, self.options)
+            self._aug_ctx.default_device = self.default_device
+        return self._aug_ctx
 
     def engine(self, device: torch.device) -> ConeEngine:
         idx = device.index or 0
@@ -257,14 +358,14 @@ def _detect_batch_size(con_values) -> tuple[int, bool]:
     return con_values.shape[1], False
 
 
-class _CvxpyLayer(torch.autograd.Function):
-    """Same calling convention as diffcp_if._CvxpyLayer (diffcp_if.py:327-403)."""
+class _ConeLayer(torch.autograd.Function):
+    """Same calling convention as diffcp_if._CvxpyLayer (diffcp_if.py:327-403); linear objective (P_eval is None)."""
 
     @staticmethod
     def forward(P_eval, q_eval, A_eval, cl_ctx, solver_args, needs_grad=True, warm_start=None):
         ctx = cl_ctx.solver_ctx if hasattr(cl_ctx, "solver_ctx") else cl_ctx
         if P_eval is not None:
-            raise NotImplementedError("MI355 solver: quadratic objectives (P) are not supported yet")
+            raise RuntimeError("internal: quadratic objectives are reduced to cone form by _CvxpyLayer.apply")
         batch_size, originally_unbatched = _detect_batch_size(A_eval)
         if originally_unbatched:
             A_eval = A_eval.unsqueeze(1)
@@ -335,3 +436,27 @@ class _CvxpyLayer(torch.autograd.Function):
             dq = dq.squeeze(1)
             dA = dA.squeeze(1)
         return None, dq, dA, None, None, None, None
+
+
+class _CvxpyLayer:
+    """What get_torch_cvxpylayer("MI355") returns: `apply(P_eval, q_eval, A_eval, cl_ctx, solver_args, needs_grad, warm_start)
+    -> (primal, dual, aux, data)` like every reference plugin (torch/cvxpylayer.py:475-483).  A linear objective goes straight to
+    the autograd Function; a quadratic objective (P_eval given, the ctx built with an objective structure) is first brought to
+    epigraph cone form by differentiable torch ops (QuadEpigraph), so gradients reach P_eval through autograd."""
+
+    @staticmethod
+    def apply(P_eval, q_eval, A_eval, cl_ctx, solver_args=None, needs_grad=True, warm_start=None):
+        if P_eval is None:
+            return _ConeLayer.apply(None, q_eval, A_eval, cl_ctx, solver_args, needs_grad, warm_start)
+        ctx = cl_ctx.solver_ctx if hasattr(cl_ctx, "solver_ctx") else cl_ctx
+        if ctx.quad is None:
+            raise ValueError("MI355 solver: P_eval was given but the context was built without an objective structure")
+        unbatched = A_eval.dim() == 1
+        if unbatched:
+            P_eval, q_eval, A_eval = P_eval.unsqueeze(1), q_eval.unsqueeze(1), A_eval.unsqueeze(1)
+        if A_eval.device.type != "cuda":
+            P_eval, q_eval, A_eval = (t.to(ctx.default_device) for t in (P_eval, q_eval, A_eval))
+        q_aug, A_aug = ctx.quad.assemble(P_eval, q_eval, A_eval)
+        primal_a, dual_a, info, data = _ConeLayer.apply(None, q_aug, A_aug, ctx.augmented(), solver_args, needs_grad, warm_start)
+        primal, dual = ctx.quad.split(primal_a, dual_a)
+        return primal, dual, info, data

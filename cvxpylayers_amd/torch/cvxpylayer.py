@@ -64,7 +64,8 @@ class CanonTemplate:
     A_structure: tuple
     cone_dims: dict
     var_recover: list
-    P_map: Any = None
+    P_map: Any = None              # (nnz_P, Ptot+1) map of the quadratic objective 1/2 x^T P x (plugins in SUPPORTS_QUAD_OBJ), or None
+    P_structure: Any = None        # (indices, indptr, (n, n)) CSC structure of P (param_prob.reduced_P.problem_data_index)
     gp: bool = False
     gp_log_mask: tuple | None = None
 
@@ -134,6 +135,21 @@ def _spmm_bm(arrs, P: torch.Tensor, out: torch.Tensor | None = None) -> torch.Te
     return out
 
 
+class _ParamMap1(torch.autograd.Function):
+    """One map (the quadratic objective's P_eval = P_map p), batch-major, transpose as backward."""
+
+    @staticmethod
+    def forward(ctx, csr: _DeviceCSR, p_bm: torch.Tensor):
+        fwd, bwd = csr.on(p_bm.device)
+        ctx.bwd = bwd
+        return _spmm_bm(fwd, p_bm.contiguous())
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        return None, _spmm_bm(ctx.bwd, g.contiguous())
+
+
 class _ParamMapApply(torch.autograd.Function):
     """Batch-major evaluation of both parameter maps, (A_bm, q_bm) = (p A_map^T, p q_map^T), with the transposed maps as backward
     accumulated into one p gradient (reference: _ScipySparseMatmul applied once per map, :12-37, and autograd's add)."""
@@ -194,9 +210,9 @@ class _ParamProbView:
         def __init__(self, pdi):
             self.problem_data_index = pdi
 
-    def __init__(self, a_structure):
+    def __init__(self, a_structure, p_structure=None):
         self.reduced_A = self._Red(a_structure)
-        self.reduced_P = None
+        self.reduced_P = self._Red(p_structure) if p_structure is not None else None
 
 
 class CvxpyLayer(torch.nn.Module):
@@ -220,7 +236,8 @@ class CvxpyLayer(torch.nn.Module):
         self.template = template
         self.solver = solver
         opts = dict(solver_args or {})
-        solver_ctx = get_solver_ctx(solver, _ParamProbView(template.A_structure), template.cone_dims, {}, opts, verbose)
+        solver_ctx = get_solver_ctx(solver, _ParamProbView(template.A_structure, template.P_structure if template.P_map is not None else None),
+                                    template.cone_dims, {}, opts, verbose)
         self.ctx = _Ctx(solver_ctx, solver)
         # The maps address parameters Fortran-flattened (the reference's p_stack); the device copies are re-indexed once to the
         # parameters' native row-major layout so flattening a batched parameter is a contiguous copy, not a strided transpose.
@@ -237,6 +254,7 @@ class CvxpyLayer(torch.nn.Module):
             return sp.csr_array(sp.csr_array(mat)[:, inv])
         self._A = _DeviceCSR(recol(template.A_map))
         self._q = _DeviceCSR(recol(template.q_map))
+        self._P = _DeviceCSR(recol(template.P_map)) if template.P_map is not None else None
         self.batch_sizes: list | None = None
 
     # ---- utils/parse_args.py:94-143
@@ -307,14 +325,16 @@ class CvxpyLayer(torch.nn.Module):
         with torch.cuda.device(params[0].device):
             p_bm = self._flatten_params(params, batch)
             A_bm, q_bm = _ParamMapApply.apply(self._A, self._q, p_bm)   # (B, nnz_aug) engine-native, (B, n+1)
+            P_eval = _ParamMap1.apply(self._P, p_bm).t() if self._P is not None else None
         A_eval, q_eval = A_bm.t(), q_bm.t()                     # the reference's (nnz_aug, B) / (n+1, B), as views
         if not batch:
             A_eval, q_eval = A_eval.squeeze(1), q_eval.squeeze(1)
+            P_eval = P_eval.squeeze(1) if P_eval is not None else None
         needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
         layer_cls = get_torch_cvxpylayer(self.solver)
         # warm_start=True: the plugin starts from this layer's previous solution when the batch size matches (the reference keeps
         # the same cache for its MOREAU plugin, torch/cvxpylayer.py:464-487)
-        primal, dual, info, _ = layer_cls.apply(None, q_eval, A_eval, self.ctx, solver_args, needs_grad, True if warm_start else None)
+        primal, dual, info, _ = layer_cls.apply(P_eval, q_eval, A_eval, self.ctx, solver_args, needs_grad, True if warm_start else None)
         self.info = info
         return self._recover_results(primal, dual, batch)
 

@@ -19,7 +19,9 @@ from cvxpylayers_amd.torch.cvxpylayer import CanonTemplate, VariableRecovery
 
 def template_from_affine_builder(builder: Callable, param_shapes: Sequence[tuple], cones: dict,
                                  var_recover: Sequence[VariableRecovery], col_order: Sequence[int] | None = None) -> CanonTemplate:
-    """builder(*param_arrays) -> (A (m,n), b (m,), c (n,)) in SOLVER form (A x + s = b), affine in the parameters.
+    """builder(*param_arrays) -> (A (m,n), b (m,), c (n,)) in SOLVER form (A x + s = b), affine in the parameters; a fourth
+    return value P (n,n) (symmetric, affine in the parameters) adds the quadratic objective 1/2 x^T P x: its upper triangle becomes
+    the template's P structure / P_map (what plugins in SUPPORTS_QUAD_OBJ receive as P_eval).
 
     Parameters are flattened in Fortran order (torch/cvxpylayer.py:40-55).  `col_order[i]` = position of user parameter i in
     the canonical parameter vector (CVXPY orders columns by parameter id, not by user order; utils/parse_args.py:330-385);
@@ -39,17 +41,21 @@ def template_from_affine_builder(builder: Callable, param_shapes: Sequence[tuple
 
     def evaluate(pvec):
         args = [pvec[offs[i]:offs[i] + sizes[i]].reshape(param_shapes[i], order="F") for i in range(npar)]
-        A, b, c = builder(*args)
-        return np.asarray(A, float), np.asarray(b, float), np.asarray(c, float)
+        out = builder(*args)
+        A, b, c = out[:3]
+        Pm = np.asarray(out[3], float) if len(out) > 3 else None
+        return np.asarray(A, float), np.asarray(b, float), np.asarray(c, float), Pm
 
-    A0, b0, c0 = evaluate(np.zeros(ptot))
+    A0, b0, c0, P0 = evaluate(np.zeros(ptot))
     m, n = A0.shape
     assert m == cone_rows(cones), "cone dims do not add up to the number of rows"
-    dA, db, dc = [], [], []
+    dA, db, dc, dP = [], [], [], []
     for k in range(ptot):
         e = np.zeros(ptot); e[k] = 1.0
-        A1, b1, c1 = evaluate(e)
+        A1, b1, c1, P1 = evaluate(e)
         dA.append(A1 - A0); db.append(b1 - b0); dc.append(c1 - c0)
+        if P0 is not None:
+            dP.append(P1 - P0)
     # structural pattern: any entry that is non-zero for some parameter value
     patA = (A0 != 0)
     patb = (b0 != 0)
@@ -85,5 +91,26 @@ def template_from_affine_builder(builder: Callable, param_shapes: Sequence[tuple
     A_map = sp.csr_array(sp.coo_array((vals_l, (rows_l, cols_l)), shape=(nnz_aug, ptot + 1)))
     q_map = sp.csr_array(sp.coo_array((qv, (qr, qc)), shape=(n + 1, ptot + 1)))
     col_offsets = [offs[i] for i in range(npar)]
+    P_map = P_structure = None
+    if P0 is not None:
+        patP = np.triu(P0 != 0)
+        for k in range(ptot):
+            patP |= np.triu(dP[k] != 0)
+        p_idx, p_ptr = [], [0]
+        for j in range(n):
+            r_ = np.nonzero(patP[:, j])[0]
+            p_idx.extend(r_.tolist()); p_ptr.append(len(p_idx))
+        p_idx = np.asarray(p_idx, dtype=np.int32); p_ptr = np.asarray(p_ptr, dtype=np.int32)
+        p_cols = np.repeat(np.arange(n), np.diff(p_ptr))
+        pr, pc, pv = [], [], []
+        v0 = P0[p_idx, p_cols]
+        nzp = np.nonzero(v0)[0]
+        pr.extend(nzp.tolist()); pc.extend([ptot] * len(nzp)); pv.extend(v0[nzp].tolist())
+        for k in range(ptot):
+            v = dP[k][p_idx, p_cols]
+            nzp = np.nonzero(v)[0]
+            pr.extend(nzp.tolist()); pc.extend([k] * len(nzp)); pv.extend(v[nzp].tolist())
+        P_map = sp.csr_array(sp.coo_array((pv, (pr, pc)), shape=(len(p_idx), ptot + 1)))
+        P_structure = (p_idx, p_ptr, (n, n))
     return CanonTemplate([tuple(s) for s in param_shapes], col_offsets, A_map, q_map,
-                         (indices, indptr, (m, n + 1)), dict(cones), list(var_recover))
+                         (indices, indptr, (m, n + 1)), dict(cones), list(var_recover), P_map=P_map, P_structure=P_structure)

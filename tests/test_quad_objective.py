@@ -1,0 +1,178 @@
+"""Quadratic objectives 1/2 x^T P x at the plugin boundary (reference: P_eval for plugins in SUPPORTS_QUAD_OBJ, _quad_form_dpp.py:32;
+tests/test_torch.py:790-1370).  The MI355 plugin reduces them to an epigraph SOC over the Cholesky factor of P with differentiable
+torch ops (QuadEpigraph).  CPU: the reduction itself, solved by the oracle, against closed forms.  GPU: the whole plugin, values
+and gradients with respect to P, q, A, b against autograd through the KKT system."""
+import numpy as np
+import pytest
+import torch
+
+from cvxpylayers_amd import problems as P
+from cvxpylayers_amd.interfaces.mi355_if import MI355_ctx, QuadEpigraph, dims_to_solver_dict
+
+
+def _upper_structure(n):
+    rows, ptr = [], [0]
+    for j in range(n):
+        rows.extend(range(j + 1)); ptr.append(len(rows))
+    return np.asarray(rows, dtype=np.int32), np.asarray(ptr, dtype=np.int32), (n, n)
+
+
+def _p_values(Pm, struct):
+    idx, ptr, _ = struct
+    cols = np.repeat(np.arange(Pm.shape[-1]), np.diff(ptr))
+    return Pm[..., idx, cols]                      # (B, nnzP)
+
+
+def _eq_qp(n, p, B, seed):
+    rng = np.random.default_rng(seed)
+    G = rng.standard_normal((B, n, n)); Pm = G @ G.transpose(0, 2, 1) / n + 0.5 * np.eye(n)
+    q = rng.standard_normal((B, n)); F = rng.standard_normal((B, p, n)); g = rng.standard_normal((B, p))
+    return Pm, q, F, g
+
+
+def _kkt_solution(Pm, q, F, g):
+    B, n = q.shape; p = g.shape[1]
+    K = np.zeros((B, n + p, n + p)); K[:, :n, :n] = Pm; K[:, :n, n:] = F.transpose(0, 2, 1); K[:, n:, :n] = F
+    sol = np.linalg.solve(K, np.concatenate([-q, g], axis=1)[:, :, None])[:, :, 0]
+    return sol[:, :n], sol[:, n:]
+
+
+def test_epigraph_reduction_solved_by_the_oracle_matches_the_kkt_solution():
+    from oracle import oracle
+    n, p, B = 6, 2, 5
+    Pm, q, F, g = _eq_qp(n, p, B, seed=0)
+    cones = {"z": p, "l": 0, "q": [], "s": []}
+    tpl = P.dense_template(n, cones)
+    A_eval, q_eval = tpl.values_from_dense(F, g, q)              # F x + s = g, s in the zero cone
+    pst = _upper_structure(n)
+    qe = QuadEpigraph(pst, (tpl.indices, tpl.indptr), (tpl.m, n + 1), dims_to_solver_dict(cones))
+    q_aug, A_aug = qe.assemble(torch.from_numpy(_p_values(Pm, pst).T.copy()), torch.from_numpy(q_eval), torch.from_numpy(A_eval))
+    aug = P.ConeTemplate(n=n + 1, m=qe.m_aug, indices=qe.aug_indices, indptr=qe.aug_indptr, cones=qe.aug_cones)
+    assert P.cone_rows(qe.aug_cones) == qe.m_aug and qe.aug_cones["q"] == [n + 2]
+    Ad, bd, cd = aug.dense_from_values(A_aug.numpy(), q_aug.numpy())
+    r = oracle.solve_batch(Ad, bd, cd, qe.aug_cones, eps=1e-10, max_iters=200000)
+    assert (r["status"] == 1).all()
+    xs, nus = _kkt_solution(Pm, q, F, g)
+    np.testing.assert_allclose(r["x"][:, :n], xs, atol=1e-6)
+    np.testing.assert_allclose(r["x"][:, n], 0.5 * np.einsum("bi,bij,bj->b", xs, Pm, xs), atol=1e-6)    # t = 1/2 x^T P x at the optimum
+    xo, yo = qe.split(torch.from_numpy(r["x"]), torch.from_numpy(r["y"]))
+    np.testing.assert_allclose(yo.numpy(), nus, atol=1e-5)       # multipliers of F x = g, rows back in template order
+
+
+def test_epigraph_keeps_the_row_order_of_later_cone_blocks():
+    # SOC block inserted after the template's own SOCs and before PSD / exponential rows (SCS order z, l, q, s, ep, p)
+    cones = {"z": 1, "l": 2, "q": [3], "s": [2], "ep": 1}
+    n = 4
+    tpl = P.dense_template(n, cones)
+    qe = QuadEpigraph(_upper_structure(n), (tpl.indices, tpl.indptr), (tpl.m, n + 1), dims_to_solver_dict(cones))
+    assert qe.r0 == 6 and qe.aug_cones["q"] == [3, n + 2] and qe.aug_cones["s"] == [2] and qe.aug_cones["ep"] == 1
+    assert list(qe.dual_rows) == [0, 1, 2, 3, 4, 5] + [6 + n + 2 + k for k in range(3 + 3)]
+    assert qe.m_aug == tpl.m + n + 2 and len(qe.aug_indptr) == n + 3
+
+
+def test_indefinite_P_is_refused():
+    n = 3
+    cones = {"z": 1, "l": 0, "q": [], "s": []}
+    tpl = P.dense_template(n, cones)
+    pst = _upper_structure(n)
+    qe = QuadEpigraph(pst, (tpl.indices, tpl.indptr), (tpl.m, n + 1), dims_to_solver_dict(cones))
+    Pm = np.diag([1.0, -1.0, 1.0])[None]
+    from cvxpylayers_amd.interfaces.mi355_if import SolverError
+    with pytest.raises(SolverError, match="not positive semidefinite"):
+        qe.assemble(torch.from_numpy(_p_values(Pm, pst).T.copy()), torch.zeros(n + 1, 1, dtype=torch.float64), torch.zeros(tpl.nnz_aug, 1, dtype=torch.float64))
+
+
+@pytest.mark.gpu
+def test_quadratic_objective_values_and_gradients_on_gpu():
+    from cvxpylayers_amd.interfaces.mi355_if import _CvxpyLayer
+    n, p, B = 6, 2, 7
+    Pm, q, F, g = _eq_qp(n, p, B, seed=1)
+    cones = {"z": p, "l": 0, "q": [], "s": []}
+    tpl = P.dense_template(n, cones)
+    pst = _upper_structure(n)
+    ctx = MI355_ctx(pst, tpl.problem_data_index, cones, options={"eps": 1e-10, "max_iters": 200000})
+    dev = torch.device("cuda", 0)
+    Pt = torch.from_numpy(Pm).to(dev).requires_grad_(); qt = torch.from_numpy(q).to(dev).requires_grad_()
+    Ft = torch.from_numpy(F).to(dev).requires_grad_(); gt = torch.from_numpy(g).to(dev).requires_grad_()
+    idx, ptr, _ = pst
+    pcols = torch.from_numpy(np.repeat(np.arange(n), np.diff(ptr))).to(dev); prow = torch.from_numpy(idx.astype(np.int64)).to(dev)
+    P_eval = Pt[:, prow, pcols].t()                                         # (nnzP, B): upper triangle, CSC order
+    cols = np.repeat(np.arange(n + 1), np.diff(tpl.indptr))
+    ar = torch.from_numpy(tpl.indices.astype(np.int64)).to(dev); ac = torch.from_numpy(cols).to(dev)
+    aug = torch.cat([Ft, gt[:, :, None]], dim=2)                            # [A_cvx | b] with A_cvx = -A = ... solver form F x + s = g  ->  A_cvx = -F
+    aug = torch.cat([-Ft, gt[:, :, None]], dim=2)
+    A_eval = aug[:, ar, ac].t()
+    q_eval = torch.cat([qt.t(), torch.zeros(1, B, dtype=torch.float64, device=dev)], dim=0)
+    primal, dual, info, _ = _CvxpyLayer.apply(P_eval, q_eval, A_eval, ctx, {}, True, None)
+    assert primal.shape == (B, n) and dual.shape == (B, p)
+    wx = torch.linspace(0.5, 1.5, n, dtype=torch.float64, device=dev)
+    (primal * wx).sum().backward()
+    grads = [t.grad.clone() for t in (Pt, qt, Ft, gt)]
+    # reference: autograd through the KKT solve
+    P2, q2, F2, g2 = (t.detach().clone().requires_grad_() for t in (Pt, qt, Ft, gt))
+    Ps = 0.5 * (P2 + P2.transpose(1, 2))
+    K = torch.cat([torch.cat([Ps, F2.transpose(1, 2)], dim=2), torch.cat([F2, torch.zeros(B, p, p, dtype=torch.float64, device=dev)], dim=2)], dim=1)
+    sol = torch.linalg.solve(K, torch.cat([-q2, g2], dim=1)[:, :, None])[:, :, 0]
+    assert torch.allclose(primal, sol[:, :n].detach(), atol=1e-6) and torch.allclose(dual, sol[:, n:].detach(), atol=1e-5)
+    (sol[:, :n] * wx).sum().backward()
+    # only the upper triangle of P reaches the solver: compare the gradient folded onto it
+    up = torch.triu(torch.ones(n, n, dtype=torch.float64, device=dev))
+    gP_ref = (P2.grad + P2.grad.transpose(1, 2)) * up - torch.diag_embed(torch.diagonal(P2.grad, dim1=1, dim2=2))
+    assert torch.allclose(grads[0] * up, gP_ref, atol=2e-5), (grads[0] * up - gP_ref).abs().max()
+    for got, want in zip(grads[1:], (q2.grad, F2.grad, g2.grad)):
+        assert torch.allclose(got, want, atol=2e-5), (got - want).abs().max()
+
+
+@pytest.mark.gpu
+def test_box_qp_with_a_native_quadratic_objective():
+    # BASELINE config 2 in its native form: min 1/2 x^T P x + q^T x, 0 <= x <= 1 with P = 2 I, q = -2 t  ->  clip(t, 0, 1)
+    from cvxpylayers_amd.interfaces.mi355_if import _CvxpyLayer
+    n, B = 8, 16
+    cones = {"z": 0, "l": 2 * n, "q": [], "s": []}
+    A = np.concatenate([-np.eye(n), np.eye(n)], axis=0)                      # x >= 0: s = x ; x <= 1: s = 1 - x
+    b = np.concatenate([np.zeros(n), np.ones(n)])
+    tpl = P.dense_template(n, cones, pattern=(A != 0), b_pattern=(b != 0))
+    rng = np.random.default_rng(0)
+    t = rng.standard_normal((B, n)) * 1.5
+    A_eval, q_eval = tpl.values_from_dense(np.broadcast_to(A, (B,) + A.shape).copy(), np.broadcast_to(b, (B, 2 * n)).copy(), -2 * t)
+    pst = (np.arange(n, dtype=np.int32), np.arange(n + 1, dtype=np.int32), (n, n))          # diagonal structure
+    ctx = MI355_ctx(pst, tpl.problem_data_index, cones, options={"eps": 1e-9, "max_iters": 100000})
+    dev = torch.device("cuda", 0)
+    P_eval = torch.full((n, B), 2.0, dtype=torch.float64, device=dev)
+    primal, dual, info, _ = _CvxpyLayer.apply(P_eval, torch.from_numpy(q_eval).to(dev), torch.from_numpy(A_eval).to(dev), ctx, {}, False, None)
+    np.testing.assert_allclose(primal.cpu().numpy(), np.clip(t, 0, 1), atol=1e-5)
+
+
+@pytest.mark.gpu
+def test_frontend_layer_with_a_parametric_quad_form():
+    """quad_form(x, P) with P a parameter (reference tests/test_torch.py:858-900, gradcheck of q and Q) through the frontend:
+    min 1/2 x^T P x + q^T x  s.t.  1^T x = 1, x >= 0 -- strictly positive optimum here, so the KKT reference has the equality only."""
+    from cvxpylayers_amd.torch import CvxpyLayer, VariableRecovery
+    from cvxpylayers_amd.torch.templates import template_from_affine_builder
+    n = 5
+
+    def builder(Pp, qp):
+        A = np.zeros((1 + n, n)); b = np.zeros(1 + n)
+        A[0] = 1.0; b[0] = 1.0                         # 1^T x = 1
+        A[1:] = -np.eye(n)                             # x >= 0
+        return A, b, qp, 0.5 * (Pp + Pp.T)
+    tpl = template_from_affine_builder(builder, [(n, n), (n,)], {"z": 1, "l": n, "q": [], "s": []}, [VariableRecovery(slice(0, n), None, (n,))])
+    assert tpl.P_map is not None and tpl.P_structure[2] == (n, n)
+    layer = CvxpyLayer(template=tpl, solver_args={"eps": 1e-10, "max_iters": 200000})
+    torch.manual_seed(3)
+    G = torch.randn(4, n, n, dtype=torch.float64, device="cuda")
+    Pt = (G @ G.transpose(1, 2) / n + torch.eye(n, dtype=torch.float64, device="cuda")).requires_grad_()
+    qt = (0.1 * torch.randn(4, n, dtype=torch.float64, device="cuda")).requires_grad_()
+    (x,) = layer(Pt, qt)
+    assert x.shape == (4, n) and bool((x > 1e-3).all())
+    wts = torch.linspace(1.0, 2.0, n, dtype=torch.float64, device="cuda")
+    (x * wts).sum().backward()
+    P2 = Pt.detach().clone().requires_grad_(); q2 = qt.detach().clone().requires_grad_()
+    Ps = 0.5 * (P2 + P2.transpose(1, 2))
+    ones = torch.ones(4, 1, n, dtype=torch.float64, device="cuda")
+    K = torch.cat([torch.cat([Ps, ones.transpose(1, 2)], dim=2), torch.cat([ones, torch.zeros(4, 1, 1, dtype=torch.float64, device="cuda")], dim=2)], dim=1)
+    sol = torch.linalg.solve(K, torch.cat([-q2, torch.ones(4, 1, dtype=torch.float64, device="cuda")], dim=1)[:, :, None])[:, :, 0]
+    assert torch.allclose(x, sol[:, :n].detach(), atol=1e-6)
+    (sol[:, :n] * wts).sum().backward()
+    assert torch.allclose(qt.grad, q2.grad, atol=2e-5)
+    assert torch.allclose(Pt.grad + Pt.grad.transpose(1, 2), P2.grad + P2.grad.transpose(1, 2), atol=4e-5)    # symmetric part is what the problem sees
