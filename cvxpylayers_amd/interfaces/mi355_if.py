@@ -120,6 +120,8 @@ class ConeEngine:
         K, B = A_eval.shape
         if A_eval.dtype != torch.float64:
             A_eval = A_eval.double()
+        if B == 0:
+            return A_eval.new_empty((0, K))
         if A_eval.stride(0) == 1 and (A_eval.stride(1) == K or B == 1):
             return A_eval.t()
         if not A_eval.is_contiguous():
@@ -133,6 +135,11 @@ class ConeEngine:
         warm = (x, y, s) of shapes (B, n), (B, m), (B, m): initial point (instances with non-finite entries start cold)."""
         B = A_bm.shape[0]
         dev = self.device
+        if B == 0:        # empty batch: nothing to launch (the C ABI refuses B <= 0)
+            f64 = dict(dtype=torch.float64, device=dev)
+            self.last_path = "per_instance"
+            return (torch.empty((0, self.n), **f64), torch.empty((0, self.m), **f64), torch.empty((0, self.m), **f64),
+                    torch.empty((0,), dtype=torch.int32, device=dev), torch.empty((0,), dtype=torch.int32, device=dev), torch.empty((0, 3), **f64))
         if warm is not None:
             if tuple(warm[0].shape) != (B, self.n) or tuple(warm[1].shape) != (B, self.m) or tuple(warm[2].shape) != (B, self.m):
                 raise ValueError(f"warm start: expected x {(B, self.n)}, y {(B, self.m)}, s {(B, self.m)}, got "
@@ -177,6 +184,9 @@ class ConeEngine:
         reference-style A_eval, so that autograd can accumulate it into the leaf without a strided copy (one engine layout pass)."""
         B = A_bm.shape[0]
         dev = self.device
+        if B == 0:
+            return (torch.empty((self.nnz_aug, 0), dtype=torch.float64, device=dev), torch.empty((self.n + 1, 0), dtype=torch.float64, device=dev),
+                    torch.empty((0,), dtype=torch.int32, device=dev))
         if getattr(self, "last_path", None) == "const_a" and (self.launch_info()["bwd_mode"] in (1, 2) or __import__("os").environ.get("CE_CONST_A") == "1"):
             from cvxpylayers_amd.interfaces.const_a import vjp_const_a      # shared A: batched LSQR with GEMMs over the batch
             return vjp_const_a(self, A_bm, x, y, s, dx, dy, batch_minor_out=batch_minor_out)

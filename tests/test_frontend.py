@@ -326,3 +326,18 @@ def test_warm_start_reuses_the_previous_solution():
     inside = ((t2 > 1e-3) & (t2 < 1 - 1e-3)).double()
     outside = ((t2 < -1e-3) | (t2 > 1 + 1e-3)).double()
     assert ((t3.grad - 1).abs() * inside).max() < 1e-3 and (t3.grad.abs() * outside).max() < 1e-3
+
+
+@pytest.mark.gpu
+def test_float32_parameters_give_float64_results():
+    """float32 parameters give float64 results (diffcp_if.py:374-375).  (An empty batch is not a concept of the reference's frontend:
+    batch size 0 is its marker for "unbatched", utils/parse_args.py:94-143; the engine itself returns empty outputs for B = 0.)"""
+    n = 6
+    layer = CvxpyLayer(template=boxqp_template(n), solver_args={"eps": 1e-8})
+    t = torch.linspace(-1, 2, 3 * n, device="cuda").reshape(3, n)           # float32
+    (x,) = layer(t)
+    assert x.dtype == torch.float64 and torch.allclose(x, torch.clamp(t.double(), 0, 1), atol=1e-5)
+    from cvxpylayers_amd.interfaces.mi355_if import make_settings
+    eng = layer.ctx.solver_ctx.engine(torch.device("cuda", 0))
+    out = eng.solve(torch.empty((0, eng.nnz_aug), dtype=torch.float64, device="cuda"), torch.empty((eng.n + 1, 0), dtype=torch.float64, device="cuda"), make_settings({}))
+    assert out[0].shape == (0, eng.n) and out[4].shape == (0,)
