@@ -368,9 +368,10 @@ static void set_ry(double *ry, int m, const oc_cones *k, double scale) {
     for (int i = 0; i < m; i++) ry[i] = (i < k->z) ? 1.0 / (ZERO_CONE_FACTOR * scale) : 1.0 / scale;
 }
 
-/* factor S = rho_x I + A^T diag(1/ry) A ; returns 0 ok */
-static int factor_kkt(const double *A, const double *ry, double rho_x, int m, int n, double *L) {
+/* factor S = rho_x I + P + A^T diag(1/ry) A  (P may be NULL); returns 0 ok */
+static int factor_kkt(const double *A, const double *Pm, const double *ry, double rho_x, int m, int n, double *L) {
     memset(L, 0, sizeof(double) * n * n);
+    if (Pm) for (int a = 0; a < n; a++) for (int b2 = 0; b2 <= a; b2++) L[a * n + b2] = 0.5 * (Pm[a * n + b2] + Pm[b2 * n + a]);
     for (int i = 0; i < m; i++) { const double *r = A + (size_t)i * n; double w = 1.0 / ry[i];
         for (int a = 0; a < n; a++) { double ra = r[a] * w; if (ra == 0) continue; for (int b2 = 0; b2 <= a; b2++) L[a * n + b2] += ra * r[b2]; } }
     for (int a = 0; a < n; a++) { L[a * n + a] += rho_x; for (int b2 = a + 1; b2 < n; b2++) L[a * n + b2] = L[b2 * n + a]; }
@@ -386,17 +387,22 @@ static void kkt_solve(const double *A, const double *L, const double *ry, int m,
     for (int i = 0; i < m; i++) y[i] = (y[i] - bb[i]) / ry[i];
 }
 
-static int solve_one(int n, int m, const double *A0, const double *b0, const double *c0, const oc_cones *K, const oc_opts *o,
+/* P0: optional quadratic objective 1/2 x^T P x (dense n x n, symmetric PSD; SCS 3's QP extension of the embedding:
+ * Q(x, y, tau) = (P x + A^T y + c tau, -A x + b tau, -(1/tau) x^T P x - c^T x - b^T y)) */
+static int solve_one(int n, int m, const double *A0, const double *b0, const double *c0, const double *P0, const oc_cones *K, const oc_opts *o,
                      double *xo, double *yo, double *so, oc_info *info) {
     int l = n + m + 1;
     size_t szA = (size_t)m * n;
-    double *buf = calloc(szA + (size_t)n * n + 16 * (size_t)l + 4 * (size_t)(m + n) + 64, sizeof(double));
+    double *buf = calloc(szA + 2 * (size_t)n * n + 16 * (size_t)l + 6 * (size_t)(m + n) + 64, sizeof(double));
     if (!buf) return OC_FAILED;
-    double *A = buf, *L = A + szA, *p = L + (size_t)n * n;
+    double *A = buf, *L = A + szA, *Pbuf = L + (size_t)n * n, *p = Pbuf + (size_t)n * n;
+    double *Pm = P0 ? Pbuf : NULL;
+    if (P0) memcpy(Pm, P0, sizeof(double) * n * n);
     double *b = p; p += m; double *c = p; p += n; double *D = p; p += m; double *E = p; p += n;
     double *ry = p; p += m; double *g = p; p += l; double *w = p; p += l; double *ut = p; p += l; double *u = p; p += l;
     double *rsk = p; p += l; double *pp = p; p += l; double *t1 = p; p += l; double *t2 = p; p += l; double *t3 = p; p += l;
     double *Dt = p; p += m; double *Et = p; p += n; double *xs = p; p += n; double *ys = p; p += m; double *ss = p; p += m;
+    double *Pg = p; p += n; double *Pv = p; p += n;
     memcpy(A, A0, sizeof(double) * szA); memcpy(b, b0, sizeof(double) * m); memcpy(c, c0, sizeof(double) * n);
     for (int i = 0; i < m; i++) D[i] = 1; for (int j = 0; j < n; j++) E[j] = 1;
     double sigma = 1.0;
@@ -407,11 +413,14 @@ static int solve_one(int n, int m, const double *A0, const double *b0, const dou
             for (int i = 0; i < m; i++) { const double *r = A + (size_t)i * n; Dt[i] = l2 ? norm2(r, n) : norm_inf(r, n); }
             for (int j = 0; j < n; j++) Et[j] = 0;
             for (int i = 0; i < m; i++) { const double *r = A + (size_t)i * n; for (int j = 0; j < n; j++) { if (l2) Et[j] += r[j] * r[j]; else { double v = fabs(r[j]); if (v > Et[j]) Et[j] = v; } } }
+            if (Pm) for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) {       /* columns of [P; A] */
+                double v = Pm[i * n + j]; if (l2) Et[j] += v * v; else if (fabs(v) > Et[j]) Et[j] = fabs(v); }
             if (l2) for (int j = 0; j < n; j++) Et[j] = sqrt(Et[j]);
             block_average(Dt, K);
             for (int i = 0; i < m; i++) Dt[i] = 1.0 / sqrt(clamp_scale(Dt[i]));
             for (int j = 0; j < n; j++) Et[j] = 1.0 / sqrt(clamp_scale(Et[j]));
             for (int i = 0; i < m; i++) { double *r = A + (size_t)i * n; for (int j = 0; j < n; j++) r[j] *= Dt[i] * Et[j]; D[i] *= Dt[i]; }
+            if (Pm) for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) Pm[i * n + j] *= Et[i] * Et[j];
             for (int j = 0; j < n; j++) E[j] *= Et[j];
         }
         for (int i = 0; i < m; i++) b[i] *= D[i];
@@ -424,11 +433,12 @@ static int solve_one(int n, int m, const double *A0, const double *b0, const dou
     double nrm_b0 = norm_inf(b0, m), nrm_c0 = norm_inf(c0, n);
     double scale = o->scale, rtau = TAU_FACTOR, rho_x = o->rho_x;
     set_ry(ry, m, K, scale);
-    if (factor_kkt(A, ry, rho_x, m, n, L)) { free(buf); info->status = OC_FAILED; return OC_FAILED; }
+    if (factor_kkt(A, Pm, ry, rho_x, m, n, L)) { free(buf); info->status = OC_FAILED; return OC_FAILED; }
     /* g = (R_z + M_zz)^{-1} h, h=(c,b):  kkt rhs (c, -b) */
     for (int i = 0; i < m; i++) t1[i] = -b[i];
     kkt_solve(A, L, ry, m, n, c, t1, g, g + n, t2);
-    double hg = dot(c, g, n) + dot(b, g + n, m);
+    double hg = dot(c, g, n) + dot(b, g + n, m), gPg = 0;
+    if (Pm) { matvec(Pm, g, Pg, n, n); gPg = dot(g, Pg, n); }
     /* cold start */
     memset(w, 0, sizeof(double) * l); w[l - 1] = 1.0;
     if (o->warm_start) {   /* the fixed point of the iteration map has w = u + R^-1 v;  x^ = sigma x / E, y^ = sigma y / D, s^ = sigma D s */
@@ -451,7 +461,12 @@ static int solve_one(int n, int m, const double *A0, const double *b0, const dou
         for (int j = 0; j < n; j++) t1[j] = rho_x * w[j];
         for (int i = 0; i < m; i++) t2[i] = -ry[i] * w[n + i];
         kkt_solve(A, L, ry, m, n, t1, t2, pp, pp + n, t3);
-        double tau_t = (rtau * w[l - 1] + dot(c, pp, n) + dot(b, pp + n, m)) / (rtau + hg);
+        double tau_t;
+        if (Pm) {   /* positive root of (r_tau + h.g - g^T P g) t^2 + (-(r_tau w_tau + h.p) + 2 p^T P g) t - p^T P p = 0 */
+            matvec(Pm, pp, Pv, n, n);
+            double qa = rtau + hg - gPg, qb = -(rtau * w[l - 1] + dot(c, pp, n) + dot(b, pp + n, m)) + 2 * dot(pp, Pg, n), qc = -dot(pp, Pv, n);
+            tau_t = (-qb + sqrt(fmax(qb * qb - 4 * qa * qc, 0.0))) / (2 * qa);
+        } else tau_t = (rtau * w[l - 1] + dot(c, pp, n) + dot(b, pp + n, m)) / (rtau + hg);
         for (int i = 0; i < l - 1; i++) ut[i] = pp[i] - tau_t * g[i];
         ut[l - 1] = tau_t;
         /* (2) cone step */
@@ -474,18 +489,24 @@ static int solve_one(int n, int m, const double *A0, const double *b0, const dou
             double rp = 0, rd = 0, naxs = 0;
             for (int i = 0; i < m; i++) { double v = t1[i] + ss[i]; if (fabs(v) > naxs) naxs = fabs(v); v -= b0[i] * tau; if (fabs(v) > rp) rp = fabs(v); }
             for (int j = 0; j < n; j++) { double v = t2[j] + c0[j] * tau; if (fabs(v) > rd) rd = fabs(v); }
-            double ctx = dot(c0, xs, n), bty = dot(b0, ys, m);
+            double ctx = dot(c0, xs, n), bty = dot(b0, ys, m), xPx = 0, nPx = 0;
+            if (P0) {   /* dual residual P x + A^T y + c tau, gap x^T P x + c^T x + b^T y  (x, y homogeneous: x / tau is the point) */
+                matvec(P0, xs, Pv, n, n);
+                xPx = dot(xs, Pv, n); nPx = norm_inf(Pv, n);
+                rd = 0; for (int j = 0; j < n; j++) { double v = Pv[j] + t2[j] + c0[j] * tau; if (fabs(v) > rd) rd = fabs(v); }
+            }
             (void)kap;
             if (tau > 0) {
-                res_pri = rp / tau; res_dual = rd / tau; gap = fabs(ctx + bty) / tau; pobj = ctx / tau; dobj = -bty / tau;
-                double prl = fmax(fmax(nrm_b0 * tau, ns), nax) / tau, drl = fmax(nrm_c0 * tau, naty) / tau, grl = fmax(fabs(ctx), fabs(bty)) / tau;
+                double xPxt = xPx / tau;
+                res_pri = rp / tau; res_dual = rd / tau; gap = fabs(xPxt + ctx + bty) / tau; pobj = (0.5 * xPxt + ctx) / tau; dobj = (-0.5 * xPxt - bty) / tau;
+                double prl = fmax(fmax(nrm_b0 * tau, ns), nax) / tau, drl = fmax(fmax(nrm_c0 * tau, naty), nPx) / tau, grl = fmax(fmax(fabs(ctx), fabs(bty)), fabs(xPxt)) / tau;
                 if (res_pri <= o->eps_abs + o->eps_rel * prl && res_dual <= o->eps_abs + o->eps_rel * drl && gap <= o->eps_abs + o->eps_rel * grl) { status = OC_SOLVED; break; }
             }
             if (bty < 0 && naty / (-bty) <= o->eps_infeas) { status = OC_INFEASIBLE; break; }
-            if (ctx < 0 && naxs / (-ctx) <= o->eps_infeas) { status = OC_UNBOUNDED; break; }
+            if (ctx < 0 && fmax(naxs, nPx) / (-ctx) <= o->eps_infeas) { status = OC_UNBOUNDED; break; }
             /* (5) adaptive scale (SCS 3 heuristic: running geometric mean of relative residual ratio) */
             if (o->adaptive_scale && iter > 0) {
-                double dp = fmax(fmax(nax, ns), nrm_b0 * tau), dd = fmax(naty, nrm_c0 * tau);
+                double dp = fmax(fmax(nax, ns), nrm_b0 * tau), dd = fmax(fmax(naty, nrm_c0 * tau), nPx);
                 double rel_p = rp / (dp > 0 ? dp : 1), rel_d = rd / (dd > 0 ? dd : 1);
                 if (rel_p > 0 && rel_d > 0 && isfinite(rel_p) && isfinite(rel_d)) {
                     sum_log += log(rel_p) - log(rel_d); n_log++;
@@ -495,10 +516,11 @@ static int solve_one(int n, int m, const double *A0, const double *b0, const dou
                         if (ns2 != scale && (factor > sqrt(10.0) || factor < 1.0 / sqrt(10.0))) {
                             sum_log = 0; n_log = 0; last_scale_iter = iter; scale = ns2; n_rescale++;
                             set_ry(ry, m, K, scale);
-                            if (factor_kkt(A, ry, rho_x, m, n, L)) { status = OC_FAILED; break; }
+                            if (factor_kkt(A, Pm, ry, rho_x, m, n, L)) { status = OC_FAILED; break; }
                             for (int i = 0; i < m; i++) t1[i] = -b[i];
                             kkt_solve(A, L, ry, m, n, c, t1, g, g + n, t2);
                             hg = dot(c, g, n) + dot(b, g + n, m);
+                            if (Pm) { matvec(Pm, g, Pg, n, n); gPg = dot(g, Pg, n); }
                             /* keep (s,kappa): R+ (w+ + u - 2ut) = rsk */
                             for (int i = 0; i < m; i++) w[n + i] = rsk[n + i] / ry[i] + 2 * ut[n + i] - u[n + i];
                         }
@@ -584,7 +606,9 @@ static void dproj_dual_cone(const double *v, const oc_cones *K, const psd_cache 
     }
 }
 
-typedef struct { int n, m; const double *A, *b, *c, *v; const oc_cones *K; const psd_cache *pcs; double *t1, *t2; } adj_op;
+/* P (optional) and Px, xPx: quadratic objective; DQ(z) = [[P, A^T, c], [-A, 0, b], [-(c + 2 P x)^T, -b^T, x^T P x]] at tau = 1 */
+typedef struct { int n, m; const double *A, *b, *c, *v; const oc_cones *K; const psd_cache *pcs; double *t1, *t2;
+                 const double *P, *Px; double xPx; double *tn; } adj_op;
 
 /* out = M^T r,  M = (Q - I) DPi(z) + I,  Q = [[0,A^T,c],[-A,0,b],[-c^T,-b^T,0]]
  *   M^T r = DPi^T ( -Q r - r ) + r                                                   */
@@ -593,13 +617,14 @@ static void apply_MT(const adj_op *op, const double *r, double *out) {
     /* x block: -A^T ry - c rt */
     matvec_t(op->A, ry, out, m, n);
     for (int j = 0; j < n; j++) out[j] = -out[j] - op->c[j] * rt;
+    if (op->P) { matvec_t(op->P, rx, op->tn, n, n); for (int j = 0; j < n; j++) out[j] += op->tn[j] - 2 * op->Px[j] * rt; }
     /* y block: D (A rx - b rt - ry) + ry */
     matvec(op->A, rx, op->t1, m, n);
     for (int i = 0; i < m; i++) op->t1[i] = op->t1[i] - op->b[i] * rt - ry[i];
     dproj_dual_cone(op->v, op->K, op->pcs, op->t1, op->t2);
     for (int i = 0; i < m; i++) out[n + i] = op->t2[i] + ry[i];
-    /* tau block (DPi = 1): c^T rx + b^T ry */
-    out[n + m] = dot(op->c, rx, n) + dot(op->b, ry, m);
+    /* tau block (DPi = 1): c^T rx + b^T ry (+ x^T P x r_tau) */
+    out[n + m] = dot(op->c, rx, n) + dot(op->b, ry, m) + (op->P ? op->xPx * rt : 0.0);
 }
 /* out = M p */
 static void apply_M(const adj_op *op, const double *p, double *out) {
@@ -610,9 +635,11 @@ static void apply_M(const adj_op *op, const double *p, double *out) {
     /* (Q - I) q + p */
     matvec_t(op->A, qy, out, m, n);
     for (int j = 0; j < n; j++) out[j] = out[j] + op->c[j] * qt - qx[j] + p[j];
+    if (op->P) { matvec(op->P, qx, op->tn, n, n); for (int j = 0; j < n; j++) out[j] += op->tn[j]; }
     matvec(op->A, qx, op->t2, m, n);
     for (int i = 0; i < m; i++) out[n + i] = -op->t2[i] + op->b[i] * qt - qy[i] + p[n + i];
     out[n + m] = -dot(op->c, qx, n) - dot(op->b, qy, m) - qt + p[n + m];
+    if (op->P) out[n + m] += -2 * dot(op->Px, qx, n) + op->xPx * qt;
 }
 
 /* LSQR (Paige & Saunders 1982), solving min || MT r - dz ||, zero start -> minimum-norm solution */
@@ -689,11 +716,11 @@ static void dense_solve_MT(const adj_op *op, const double *bvec, int N, double *
     free(Mt); free(cp);
 }
 
-static int adjoint_one(int n, int m, const double *A, const double *b, const double *c, const oc_cones *K, const oc_opts *o,
+static int adjoint_one(int n, int m, const double *A, const double *b, const double *c, const double *Pq, const oc_cones *K, const oc_opts *o,
                        const double *x, const double *y, const double *s, const double *dx, const double *dy, const double *ds,
-                       double *dA, double *db, double *dc) {
+                       double *dA, double *db, double *dc, double *dP) {
     int N = n + m + 1;
-    double *buf = calloc((size_t)12 * N + 4 * m, sizeof(double));
+    double *buf = calloc((size_t)12 * N + 4 * m + 2 * n, sizeof(double));
     double *v = buf, *dz = v + m, *r = dz + N, *t1 = r + N, *t2 = t1 + m, *t3 = t2 + m, *work = t3 + m;
     for (int i = 0; i < m; i++) v[i] = y[i] - s[i];
     psd_cache *pcs = NULL;
@@ -704,7 +731,9 @@ static int adjoint_one(int n, int m, const double *A, const double *b, const dou
             pcs[cidx].V = malloc(sizeof(double) * k * k); pcs[cidx].w = malloc(sizeof(double) * k);
             svec_to_mat(v + off, k, S); jacobi_eig(S, k, pcs[cidx].w, pcs[cidx].V); free(S); off += k * (k + 1) / 2; }
     }
-    adj_op op = { n, m, A, b, c, v, K, pcs, t1, t2 };
+    double *Pxv = buf + (size_t)12 * N + 4 * m, *tnv = Pxv + n, xPx = 0;
+    if (Pq) { matvec(Pq, x, Pxv, n, n); xPx = dot(x, Pxv, n); }
+    adj_op op = { n, m, A, b, c, v, K, pcs, t1, t2, Pq, Pxv, xPx, tnv };
     /* dz = (dx, DPi^T (dy + ds) - ds, -(x.dx + y.dy + s.ds)) */
     memcpy(dz, dx, sizeof(double) * n);
     for (int i = 0; i < m; i++) t3[i] = dy[i] + (ds ? ds[i] : 0);
@@ -721,6 +750,8 @@ static int adjoint_one(int n, int m, const double *A, const double *b, const dou
     for (int i = 0; i < m; i++) for (int j = 0; j < n; j++) dA[(size_t)i * n + j] = x[j] * ry[i] - y[i] * rx[j];
     for (int i = 0; i < m; i++) db[i] = y[i] * rt - ry[i];
     for (int j = 0; j < n; j++) dc[j] = x[j] * rt - rx[j];
+    if (Pq && dP)      /* Q_xx = P, Q_tau,x = -(c + (1/tau) P x)^T  =>  dP = sym(-r_x x^T) + r_tau x x^T */
+        for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) dP[(size_t)i * n + j] = -0.5 * (rx[i] * x[j] + rx[j] * x[i]) + rt * x[i] * x[j];
     if (pcs) { for (int cidx = 0; cidx < K->ns; cidx++) { free(pcs[cidx].V); free(pcs[cidx].w); } free(pcs); }
     free(buf);
     return itn;
@@ -736,9 +767,9 @@ int oc_num_threads(void) {
 }
 
 /* A: [B][m][n] row-major dense, b: [B][m], c: [B][n]; outputs x [B][n], y,s [B][m], iters/status [B], resid [B][3] */
-int oc_solve_batch(int B, int n, int m, const double *A, const double *b, const double *c,
-                   int z, int l, int nq, const int *q, int ns, const int *s, int nep, int np, const double *pw, const oc_opts *o,
-                   double *x, double *y, double *sv, int *iters, int *status, double *resid, int nthreads) {
+int oc_solve_batch_qp(int B, int n, int m, const double *A, const double *b, const double *c, const double *Pq,
+                      int z, int l, int nq, const int *q, int ns, const int *s, int nep, int np, const double *pw, const oc_opts *o,
+                      double *x, double *y, double *sv, int *iters, int *status, double *resid, int nthreads) {
     oc_cones K = { z, l, nq, ns, q, s, nep, np, pw };
     if (cone_rows(&K) != m) return -1;
 #ifdef _OPENMP
@@ -747,18 +778,24 @@ int oc_solve_batch(int B, int n, int m, const double *A, const double *b, const 
     #pragma omp parallel for schedule(dynamic, 1)
     for (int i = 0; i < B; i++) {
         oc_info info; memset(&info, 0, sizeof(info));
-        solve_one(n, m, A + (size_t)i * m * n, b + (size_t)i * m, c + (size_t)i * n, &K, o, x + (size_t)i * n, y + (size_t)i * m, sv + (size_t)i * m, &info);
+        solve_one(n, m, A + (size_t)i * m * n, b + (size_t)i * m, c + (size_t)i * n, Pq ? Pq + (size_t)i * n * n : NULL, &K, o, x + (size_t)i * n, y + (size_t)i * m, sv + (size_t)i * m, &info);
         iters[i] = info.iters; status[i] = info.status;
         if (resid) { resid[3 * i] = info.res_pri; resid[3 * i + 1] = info.res_dual; resid[3 * i + 2] = info.gap; }
     }
     return 0;
 }
 
-/* ds may be NULL (the layer passes ds = 0, diffcp_if.py:84).  dA: [B][m][n] dense. lsqr_iters may be NULL. */
-int oc_adjoint_batch(int B, int n, int m, const double *A, const double *b, const double *c,
-                     int z, int l, int nq, const int *q, int ns, const int *s, int nep, int np, const double *pw, const oc_opts *o,
-                     const double *x, const double *y, const double *sv, const double *dx, const double *dy, const double *ds,
-                     double *dA, double *db, double *dc, int *lsqr_iters, int nthreads) {
+int oc_solve_batch(int B, int n, int m, const double *A, const double *b, const double *c,
+                   int z, int l, int nq, const int *q, int ns, const int *s, int nep, int np, const double *pw, const oc_opts *o,
+                   double *x, double *y, double *sv, int *iters, int *status, double *resid, int nthreads) {
+    return oc_solve_batch_qp(B, n, m, A, b, c, NULL, z, l, nq, q, ns, s, nep, np, pw, o, x, y, sv, iters, status, resid, nthreads);
+}
+
+/* ds may be NULL (the layer passes ds = 0, diffcp_if.py:84).  dA: [B][m][n] dense. lsqr_iters may be NULL.  Pq / dP: [B][n][n] or NULL. */
+int oc_adjoint_batch_qp(int B, int n, int m, const double *A, const double *b, const double *c, const double *Pq,
+                        int z, int l, int nq, const int *q, int ns, const int *s, int nep, int np, const double *pw, const oc_opts *o,
+                        const double *x, const double *y, const double *sv, const double *dx, const double *dy, const double *ds,
+                        double *dA, double *db, double *dc, double *dP, int *lsqr_iters, int nthreads) {
     oc_cones K = { z, l, nq, ns, q, s, nep, np, pw };
     if (cone_rows(&K) != m) return -1;
 #ifdef _OPENMP
@@ -766,10 +803,18 @@ int oc_adjoint_batch(int B, int n, int m, const double *A, const double *b, cons
 #endif
     #pragma omp parallel for schedule(dynamic, 1)
     for (int i = 0; i < B; i++) {
-        int it = adjoint_one(n, m, A + (size_t)i * m * n, b + (size_t)i * m, c + (size_t)i * n, &K, o,
+        int it = adjoint_one(n, m, A + (size_t)i * m * n, b + (size_t)i * m, c + (size_t)i * n, Pq ? Pq + (size_t)i * n * n : NULL, &K, o,
                              x + (size_t)i * n, y + (size_t)i * m, sv + (size_t)i * m, dx + (size_t)i * n, dy + (size_t)i * m,
-                             ds ? ds + (size_t)i * m : NULL, dA + (size_t)i * m * n, db + (size_t)i * m, dc + (size_t)i * n);
+                             ds ? ds + (size_t)i * m : NULL, dA + (size_t)i * m * n, db + (size_t)i * m, dc + (size_t)i * n,
+                             dP ? dP + (size_t)i * n * n : NULL);
         if (lsqr_iters) lsqr_iters[i] = it;
     }
     return 0;
+}
+
+int oc_adjoint_batch(int B, int n, int m, const double *A, const double *b, const double *c,
+                     int z, int l, int nq, const int *q, int ns, const int *s, int nep, int np, const double *pw, const oc_opts *o,
+                     const double *x, const double *y, const double *sv, const double *dx, const double *dy, const double *ds,
+                     double *dA, double *db, double *dc, int *lsqr_iters, int nthreads) {
+    return oc_adjoint_batch_qp(B, n, m, A, b, c, NULL, z, l, nq, q, ns, s, nep, np, pw, o, x, y, sv, dx, dy, ds, dA, db, dc, NULL, lsqr_iters, nthreads);
 }

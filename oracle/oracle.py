@@ -75,8 +75,9 @@ def _cones(cones):
     return int(cones.get("z", 0)), int(cones.get("l", 0)), q, s, (int(cones.get("ep", 0)), pw)
 
 
-def solve_batch(A, b, c, cones, nthreads=0, warm=None, **opts):
-    """A (B,m,n) dense, b (B,m), c (B,n) float64.  Returns dict(x,y,s,iters,status,resid).  warm = (x, y, s): initial point."""
+def solve_batch(A, b, c, cones, nthreads=0, warm=None, P=None, **opts):
+    """A (B,m,n) dense, b (B,m), c (B,n) float64.  Returns dict(x,y,s,iters,status,resid).  warm = (x, y, s): initial point.
+    P (B,n,n): optional quadratic objective 1/2 x^T P x (symmetric PSD)."""
     A = np.ascontiguousarray(A, dtype=np.float64)
     b = np.ascontiguousarray(b, dtype=np.float64)
     c = np.ascontiguousarray(c, dtype=np.float64)
@@ -88,7 +89,10 @@ def solve_batch(A, b, c, cones, nthreads=0, warm=None, **opts):
         o.warm_start = 1
         x[...] = warm[0]; y[...] = warm[1]; sv[...] = warm[2]
     iters = np.zeros(B, dtype=np.int32); status = np.zeros(B, dtype=np.int32); resid = np.zeros((B, 3))
-    rc = lib().oc_solve_batch(B, n, m, _p(A), _p(b), _p(c), z, l, len(q), _p(q, C.c_int), len(s), _p(s, C.c_int), nep[0], len(nep[1]), _p(nep[1]),
+    Pp = None
+    if P is not None:
+        P = np.ascontiguousarray(P, dtype=np.float64); Pp = _p(P)
+    rc = lib().oc_solve_batch_qp(B, n, m, _p(A), _p(b), _p(c), Pp, z, l, len(q), _p(q, C.c_int), len(s), _p(s, C.c_int), nep[0], len(nep[1]), _p(nep[1]),
                               C.byref(o), _p(x), _p(y), _p(sv), _p(iters, C.c_int), _p(status, C.c_int), _p(resid),
                               int(nthreads))
     if rc != 0:
@@ -96,7 +100,7 @@ def solve_batch(A, b, c, cones, nthreads=0, warm=None, **opts):
     return dict(x=x, y=y, s=sv, iters=iters, status=status, resid=resid)
 
 
-def adjoint_batch(A, b, c, cones, x, y, s, dx, dy, ds=None, nthreads=0, **opts):
+def adjoint_batch(A, b, c, cones, x, y, s, dx, dy, ds=None, nthreads=0, P=None, **opts):
     """diffcp adj_batch restatement: returns dA (B,m,n) dense, db (B,m), dc (B,n), lsqr_iters (B,)."""
     A = np.ascontiguousarray(A, dtype=np.float64)
     b = np.ascontiguousarray(b, dtype=np.float64)
@@ -112,12 +116,19 @@ def adjoint_batch(A, b, c, cones, x, y, s, dx, dy, ds=None, nthreads=0, **opts):
         ds = np.ascontiguousarray(ds, dtype=np.float64)
         dsp = _p(ds)
     dA = np.empty((B, m, n)); db = np.empty((B, m)); dc = np.empty((B, n)); it = np.zeros(B, dtype=np.int32)
-    rc = lib().oc_adjoint_batch(B, n, m, _p(A), _p(b), _p(c), z, l, len(q), _p(q, C.c_int), len(sd), _p(sd, C.c_int), nep[0], len(nep[1]), _p(nep[1]),
-                                C.byref(o), _p(x), _p(y), _p(s), _p(dx), _p(dy), dsp, _p(dA), _p(db), _p(dc),
-                                _p(it, C.c_int), int(nthreads))
+    Pp = dPp = None; dP = None
+    if P is not None:
+        P = np.ascontiguousarray(P, dtype=np.float64); Pp = _p(P)
+        dP = np.empty((B, n, n)); dPp = _p(dP)
+    rc = lib().oc_adjoint_batch_qp(B, n, m, _p(A), _p(b), _p(c), Pp, z, l, len(q), _p(q, C.c_int), len(sd), _p(sd, C.c_int), nep[0], len(nep[1]), _p(nep[1]),
+                                C.byref(o), _p(x), _p(y), _p(s), _p(dx), _p(dy), dsp, _p(dA), _p(db), _p(dc), dPp,
+                                   _p(it, C.c_int), int(nthreads))
     if rc != 0:
         raise ValueError("cone dims do not match m")
-    return dict(dA=dA, db=db, dc=dc, lsqr_iters=it)
+    out = dict(dA=dA, db=db, dc=dc, lsqr_iters=it)
+    if dP is not None:
+        out["dP"] = dP
+    return out
 
 
 def proj_exp(v, dual=False):

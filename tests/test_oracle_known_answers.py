@@ -235,3 +235,66 @@ def test_geometric_mean_maximisation(alpha):
     assert st == 1
     np.testing.assert_allclose(x[:2], xs, atol=1e-6)
     np.testing.assert_allclose(x[2], xs[0] ** alpha * xs[1] ** (1 - alpha), atol=1e-6)
+
+
+# ---------------------------------------------------------------- quadratic objective 1/2 x^T P x (SCS 3's QP embedding)
+def test_qp_equality_constrained_matches_kkt_and_epigraph_form():
+    rng = np.random.default_rng(0)
+    n, p, B = 6, 2, 5
+    G = rng.standard_normal((B, n, n)); Pm = G @ G.transpose(0, 2, 1) / n + 0.5 * np.eye(n)
+    q = rng.standard_normal((B, n)); F = rng.standard_normal((B, p, n)); g = rng.standard_normal((B, p))
+    r = oracle.solve_batch(F, g, q, {"z": p, "l": 0, "q": []}, P=Pm, **TIGHT)
+    K = np.zeros((B, n + p, n + p)); K[:, :n, :n] = Pm; K[:, :n, n:] = F.transpose(0, 2, 1); K[:, n:, :n] = F
+    sol = np.linalg.solve(K, np.concatenate([-q, g], axis=1)[:, :, None])[:, :, 0]
+    assert (r["status"] == 1).all()
+    np.testing.assert_allclose(r["x"], sol[:, :n], atol=1e-8)
+    np.testing.assert_allclose(r["y"], sol[:, n:], atol=1e-8)
+
+
+def test_qp_box_native_form_agrees_with_the_soc_epigraph_form():
+    # BASELINE config 2 both ways: native P = 2 F^T F with box rows, and the epigraph form DIFFCP is handed
+    from cvxpylayers_amd import problems as P
+    nx, B = 12, 6
+    A, b, c, cones_e = P.box_qp_batch(nx, B, seed=0)
+    re = oracle.solve_batch(A, b, c, cones_e, eps=1e-10, max_iters=400000)
+    rng = np.random.default_rng(0)
+    Fm = rng.standard_normal((nx, nx)) / np.sqrt(nx); g = rng.standard_normal((B, nx))
+    lo = -0.5 - 0.5 * rng.random((B, nx)); hi = 0.5 + 0.5 * rng.random((B, nx))
+    Pn = np.broadcast_to(2 * Fm.T @ Fm, (B, nx, nx)).copy()
+    An = np.broadcast_to(np.concatenate([-np.eye(nx), np.eye(nx)], axis=0), (B, 2 * nx, nx)).copy()
+    rn = oracle.solve_batch(An, np.concatenate([-lo, hi], axis=1), -2 * g @ Fm, {"z": 0, "l": 2 * nx, "q": []}, P=Pn, eps=1e-10, max_iters=400000)
+    assert (rn["status"] == 1).all() and (re["status"] == 1).all()
+    np.testing.assert_allclose(rn["x"], re["x"][:, :nx], atol=1e-6)
+    assert rn["iters"].mean() < re["iters"].mean()          # the native form converges in fewer iterations
+
+
+def test_qp_adjoint_matches_finite_differences_including_dP():
+    from cvxpylayers_amd import problems as P
+    rng = np.random.default_rng(1)
+    cones = {"z": 2, "l": 4, "q": [4], "s": [], "ep": 1}; n = 8
+    A, b, c = P.generate(n, cones, 1, seed=3)
+    G = rng.standard_normal((1, n, n)); Pm = G @ G.transpose(0, 2, 1) / n
+    kw = dict(eps=1e-12, max_iters=400000)
+    r = oracle.solve_batch(A, b, c, cones, P=Pm, **kw)
+    assert r["status"][0] == 1
+    dx = rng.standard_normal(r["x"].shape); dy = rng.standard_normal(r["y"].shape)
+    g = oracle.adjoint_batch(A, b, c, cones, r["x"], r["y"], r["s"], dx, dy, P=Pm, mode="dense")
+
+    def f(A_, b_, c_, P_):
+        rr = oracle.solve_batch(A_, b_, c_, cones, P=P_, **kw)
+        return float((rr["x"] * dx).sum() + (rr["y"] * dy).sum())
+    h = 1e-6
+    for (i, j) in ((0, 0), (1, 3), (5, 5)):
+        Pp = Pm.copy(); Pp[0, i, j] += h; Pq = Pm.copy(); Pq[0, i, j] -= h
+        if i != j:
+            Pp[0, j, i] += h; Pq[0, j, i] -= h
+        fd = (f(A, b, c, Pp) - f(A, b, c, Pq)) / (2 * h)
+        got = g["dP"][0, i, j] + (g["dP"][0, j, i] if i != j else 0.0)
+        assert abs(fd - got) < 2e-5 * (1 + abs(fd)), (i, j, fd, got)
+    for k in (0, 4, 9):
+        bp = b.copy(); bp[0, k] += h; bm = b.copy(); bm[0, k] -= h
+        fd = (f(A, bp, c, Pm) - f(A, bm, c, Pm)) / (2 * h)
+        assert abs(fd - g["db"][0, k]) < 2e-5 * (1 + abs(fd))
+    Ap = A.copy(); Ap[0, 3, 2] += h; Am = A.copy(); Am[0, 3, 2] -= h
+    fd = (f(Ap, b, c, Pm) - f(Am, b, c, Pm)) / (2 * h)
+    assert abs(fd - g["dA"][0, 3, 2]) < 2e-5 * (1 + abs(fd))
