@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "csrc", "libcone_engine.so")
 
 # every symbol include/cone_engine.h declares
-SYMBOLS = ["ce_default_settings", "ce_create", "ce_destroy", "ce_last_error", "ce_solve", "ce_vjp",
+SYMBOLS = ["ce_default_settings", "ce_create", "ce_destroy", "ce_last_error", "ce_solve", "ce_vjp", "ce_qp_native", "ce_solve_qp", "ce_vjp_qp",
            "ce_transpose", "ce_parammap_apply", "ce_parammap_apply2", "ce_ca_step", "ce_ca_check", "ce_ca_psd", "ce_ca_triples", "ce_ca_triple_jac", "ce_ca_update", "ce_ca_finish", "ce_set_profiling", "ce_get_profile", "ce_reset_profile", "ce_get_launch_info"]
 
 
@@ -20,7 +20,8 @@ class CeTemplate(C.Structure):
     _fields_ = [("n", C.c_int), ("m", C.c_int), ("nnz_aug", C.c_int), ("indices", C.POINTER(C.c_int)),
                 ("indptr", C.POINTER(C.c_int)), ("z", C.c_int), ("l", C.c_int), ("nq", C.c_int),
                 ("q", C.POINTER(C.c_int)), ("ns", C.c_int), ("s", C.POINTER(C.c_int)), ("nep", C.c_int),
-                ("np", C.c_int), ("p", C.POINTER(C.c_double))]
+                ("np", C.c_int), ("p", C.POINTER(C.c_double)),
+                ("nnz_p", C.c_int), ("p_indices", C.POINTER(C.c_int)), ("p_indptr", C.POINTER(C.c_int))]
 
 
 class CeSettings(C.Structure):
@@ -60,6 +61,9 @@ def lib():
     L.ce_last_error.restype = C.c_char_p
     L.ce_solve.argtypes = [vp, C.c_int, dp, lg, lg, dp, lg, lg, C.POINTER(CeSettings), dp, dp, dp, ip, ip, dp, vp]
     L.ce_vjp.argtypes = [vp, C.c_int, dp, lg, lg, dp, lg, lg, dp, dp, dp, dp, dp, dp, lg, lg, dp, lg, lg, ip, vp]
+    L.ce_qp_native.argtypes = [vp]
+    L.ce_solve_qp.argtypes = [vp, C.c_int, dp, lg, lg, dp, lg, lg, dp, C.POINTER(CeSettings), dp, dp, dp, ip, ip, dp, vp]
+    L.ce_vjp_qp.argtypes = [vp, C.c_int, dp, lg, lg, dp, dp, dp, dp, dp, dp, dp, lg, lg, dp, lg, lg, dp, ip, vp]
     L.ce_transpose.argtypes = [vp, C.c_int, C.c_int, dp, dp, vp]
     L.ce_parammap_apply.argtypes = [C.c_int, C.c_int, C.c_int, ip, ip, dp, dp, lg, dp, lg, vp]
     L.ce_parammap_apply2.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, ip, ip, dp, dp, lg, dp, lg, vp]

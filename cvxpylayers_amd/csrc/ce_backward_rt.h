@@ -33,7 +33,13 @@ template <int TI, int TJ, int TH, bool PSD = false, int BGR = 16>
 __global__ void __launch_bounds__(BGR * 16, (BGR == 16 ? 3 : 2))
 k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict__ xg, const double *__restrict__ yg,
               const double *__restrict__ sg, const double *__restrict__ dxg, const double *__restrict__ dyg,
-              double *__restrict__ dAo, double *__restrict__ dqo, long sdqk, long sdqb, int *__restrict__ adj_status) {
+              double *__restrict__ dAo, double *__restrict__ dqo, long sdqk, long sdqb, int *__restrict__ adj_status,
+              const double *__restrict__ Pvals_g = nullptr, int nnzP = 0, const int *__restrict__ pmap = nullptr,
+              const int *__restrict__ prow = nullptr, const int *__restrict__ pcol = nullptr, int p_tri = 0,
+              double *__restrict__ dPo = nullptr) {
+    // Quadratic objective (Pvals_g != nullptr): the reduced adjoint system is [[H + P, -B^T], [B, 0]] (x-block of M^T r = dz gains
+    // P r_x) and dP = -sym(r_x x^T) (oracle/cone_oracle.c adjoint_one with r_tau = 0).  pmap: n x n map to the entries of the P
+    // structure (-1: structural zero); a one-triangle structure (p_tri) maps (i,j) and (j,i) to one entry, whose gradient is doubled.
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int tid = threadIdx.x, inst = blockIdx.x;
     const int n = T.n, m = T.m, lda = T.lda, nq = T.nq, z = T.z;
@@ -210,6 +216,7 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
     if (NK > NKCAP || NK > BGR * TI) {   // more active rows than the register tile holds: degenerate instance (flagged, zero gradient)
         for (int k = tid; k < T.nnz_aug; k += NTB) dAo[(size_t)inst * T.nnz_aug + k] = 0.0;
         for (int j = tid; j <= n; j += NTB) dqo[j * sdqk + inst * sdqb] = 0.0;
+        if (dPo) for (int k = tid; k < nnzP; k += NTB) dPo[(size_t)inst * nnzP + k] = 0.0;
         if (tid == 0 && adj_status) adj_status[inst] = 2;
         return;
     }
@@ -319,6 +326,16 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
 #pragma unroll
                 for (int j = 0; j < TH; j++) kt[i][j] = fma(ar[i], ac[j], kt[i][j]);
         }
+    }
+    if (Pvals_g) {   // uniform
+        const double *pv = Pvals_g + (size_t)inst * nnzP;
+#pragma unroll
+        for (int i = 0; i < TH; i++)
+#pragma unroll
+            for (int j = 0; j < TH; j++) {
+                const int r = ra + BGR * i, cc = cb + BGC * j;
+                if (r < n && cc < n) { const int ix = pmap[r * n + cc]; if (ix >= 0) kt[i][j] += pv[ix]; }
+            }
     }
     CE_STAMP(8);
     // B / -B^T blocks and the right-hand side.  The source of equality e (a row of A or a_y of a boundary cone) is resolved
@@ -536,6 +553,13 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
         dAo[(size_t)inst * T.nnz_aug + k] = val;
     }
     for (int j = tid; j <= n; j += NTB) dqo[j * sdqk + inst * sdqb] = (j < n) ? -rx[j] : 0.0;
+    if (dPo) {
+        for (int k = tid; k < nnzP; k += NTB) {
+            const int i = prow[k], j = pcol[k];
+            const double v = -0.5 * (rx[i] * xg[(size_t)inst * n + j] + rx[j] * xg[(size_t)inst * n + i]);
+            dPo[(size_t)inst * nnzP + k] = (p_tri && i != j) ? 2.0 * v : v;
+        }
+    }
     if (tid == 0 && adj_status) adj_status[inst] = misc[2];
 #ifdef CE_TIMING
     CE_STAMP(7);

@@ -211,12 +211,17 @@ __device__ __forceinline__ void psd_project(double *zsvec, int k, double *Sm, do
 #ifndef F2_WPS
 #define F2_WPS 3
 #endif
-template <int CHT, int T1, int CHA, int T2, int CHG, int TG, bool PSD = false, int NTH = 256>
+// HASP: quadratic objective 1/2 x^T P x (SCS 3's QP embedding, oracle/cone_oracle.c solve_one): P-hat = E P E joins the reduced
+// KKT matrix S = rho_x I + P-hat + A-hat^T Dy A-hat, tau-tilde becomes the positive root of a quadratic, the dual residual and
+// the gap get their P terms.  Pvals: (B, nnzP) values in the template's P structure; idx_p: gather map of the (jg, cg) tile
+// layout of G (row jg, columns TG*cg + k), -1 = structural zero (one-triangle structures map (i,j) and (j,i) to one entry).
+template <int CHT, int T1, int CHA, int T2, int CHG, int TG, bool PSD = false, int NTH = 256, bool HASP = false>
 __global__ void __launch_bounds__(NTH, (NTH == 256 ? F2_WPS : 2))
 k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__restrict__ qv, long sqk, long sqb,
        const int *__restrict__ idx_at, const int *__restrict__ idx_ar, const int *__restrict__ idx_b,
        double *__restrict__ xo, double *__restrict__ yo, double *__restrict__ so, int *__restrict__ iters_o,
-       int *__restrict__ status_o, double *__restrict__ resid_o) {
+       int *__restrict__ status_o, double *__restrict__ resid_o,
+       const double *__restrict__ Pvals_g = nullptr, int nnzP = 0, const int *__restrict__ idx_p = nullptr) {
     constexpr int NT = NTH, NW = NTH / 64;        // threads / waves per workgroup of this instantiation (shadow the file-level defaults)
     using L = F2<CHT, T1, CHA, T2, CHG, TG, NW>;
     using Co = F2Co<CHT, CHA, CHG>;
@@ -271,6 +276,13 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
         const int j1 = co.j1, c1 = co.c1, i2 = co.i2, c2 = co.c2;
         const bool own1 = (c1 == 0) && (j1 < n), own2 = (c2 == 0) && (i2 < m);
         float atf[T1], arf[T2];
+        float pf[HASP ? TG : 1];
+        if constexpr (HASP) {
+            const double *pv = Pvals_g + (size_t)blockIdx.x * nnzP;
+#pragma unroll
+            for (int k = 0; k < TG; k++) { const int ix = idx_p[k * NT + tid]; pf[k] = ix >= 0 ? (float)pv[ix] : 0.0f; }
+        }
+        float *const fPn = reinterpret_cast<float *>(sm + L::O_S3);          // column norms of P-hat (= row norms: symmetric)
 #pragma unroll
         for (int k = 0; k < T1; k++) { const int ix = idx_at[k * NT + tid]; atf[k] = ix >= 0 ? (float)(-vals[ix]) : 0.0f; }   // A = -A_cvx (diffcp_if.py:65)
 #pragma unroll
@@ -298,9 +310,27 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
                 for (int k = 0; k < T2; k += 2) { r0 = fmaxf(r0, fabsf(arf[k])); r1 = fmaxf(r1, fabsf(arf[k + 1])); }
                 cn = group_reduce_f<CHT, true>(fmaxf(c0, c1_)); rn = group_reduce_f<CHA, true>(fmaxf(r0, r1));
             }
-            if (own1) fEt[j1] = 1.0f / sqrtf(clampf(cn));
+            if constexpr (HASP) {      // columns of [P-hat; A-hat]: the column norm of A-hat is combined with that of P-hat after the barrier
+                const Co cop(wave);
+                float pn = 0;
+                if (l2) {
+#pragma unroll
+                    for (int k = 0; k < TG; k++) pn = fmaf(pf[k], pf[k], pn);
+                    pn = group_reduce_f<CHG, false>(pn);          // squared
+                } else {
+#pragma unroll
+                    for (int k = 0; k < TG; k++) pn = fmaxf(pn, fabsf(pf[k]));
+                    pn = group_reduce_f<CHG, true>(pn);
+                }
+                if (cop.cg == 0 && cop.jg < n) fPn[cop.jg] = pn;
+            } else {
+                if (own1) fEt[j1] = 1.0f / sqrtf(clampf(cn));
+            }
             if (own2) fRn[i2] = rn;          // raw row norms
             __syncthreads();
+            if constexpr (HASP) {
+                if (own1) { const float pn = fPn[j1]; fEt[j1] = 1.0f / sqrtf(clampf(l2 ? sqrtf(cn * cn + pn) : fmaxf(cn, pn))); }
+            }
             if (own2) {
                 float a = rn;
                 const int r0 = socr[i2], d = abs(socd[i2]);
@@ -323,6 +353,13 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
                 const float2 *e2 = reinterpret_cast<const float2 *>(fEt + T2 * c2);
 #pragma unroll
                 for (int k = 0; k < T2 / 2; k++) { const float2 ee = e2[k]; arf[2 * k] *= di * ee.x; arf[2 * k + 1] *= di * ee.y; }
+                if constexpr (HASP) {
+                    const Co cop(wave);
+                    const float eg = fEt[cop.jg < NP ? cop.jg : 0];
+                    const float2 *g2 = reinterpret_cast<const float2 *>(fEt + TG * cop.cg);
+#pragma unroll
+                    for (int k = 0; k < TG / 2; k++) { const float2 ee = g2[k]; pf[2 * k] *= eg * ee.x; pf[2 * k + 1] *= eg * ee.y; }
+                }
                 if (own1) sm[L::O_EV + j1] *= (double)ej;
                 if (own2) sm[L::O_DV + i2] *= (double)di;
             }
@@ -373,6 +410,21 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
             ar[2 * k] = ix0 >= 0 ? -vals[ix0] * (di * ee.x) : 0.0;
             ar[2 * k + 1] = ix1 >= 0 ? -vals[ix1] * (di * ee.y) : 0.0;
             if (k % 4 == 3) __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    // P-hat row segment of the (jg, cg) layout, re-materialised wherever it is needed (S formation, P-hat g_x, the residual check)
+    double gPg = 0;                                                  // g_x^T P-hat g_x
+    double *const PgV = Gm + n * ldg;                                // [NP] P-hat g_x   (HASP only; dynamic tail of the LDS carve)
+    auto materialize_p = [&](const Co &co, double (&pg)[TG]) {
+        const double *pv = Pvals_g + (size_t)blockIdx.x * nnzP;
+        const double ej = sm[L::O_EV + (co.jg < NP ? co.jg : 0)];
+        const double2 *e2 = reinterpret_cast<const double2 *>(sm + L::O_EV + TG * co.cg);
+#pragma unroll
+        for (int k = 0; k < TG / 2; k++) {
+            const int ix0 = idx_p[(2 * k) * NT + co.t], ix1 = idx_p[(2 * k + 1) * NT + co.t];
+            const double2 ee = e2[k];
+            pg[2 * k] = ix0 >= 0 ? pv[ix0] * (ej * ee.x) : 0.0;
+            pg[2 * k + 1] = ix1 >= 0 ? pv[ix1] * (ej * ee.y) : 0.0;
         }
     };
     // The column groups j1 == n and j1 == n + 1 (idle in the A^T product) carry phi as two extra "columns", so that the
@@ -427,6 +479,12 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
             }
 #pragma unroll
             for (int s = 0; s < TG; s++) if (jg < n && TG * cg + s == jg) sreg[s] += rho_x;
+            if constexpr (HASP) {
+                double pg[TG];
+                materialize_p(co, pg);
+#pragma unroll
+                for (int s = 0; s < TG; s++) if (jg < n) sreg[s] += pg[s];
+            }
         }
         F2_STAMP(8);
         // Gauss-Jordan inversion on the register tile; pivot order k = kk + TG*cgk (kk static).  Pivot row / column are
@@ -501,6 +559,16 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
             if (owng) { sm[L::O_GV + OX + jg] = gx; sm[L::O_PX + jg] = gk; }
         }
         __syncthreads();
+        if constexpr (HASP) {      // P-hat g_x (vector, kept) and g_x^T P-hat g_x
+            double pg[TG];
+            materialize_p(co, pg);
+            const double a = seg_dot<CHG, TG>(pg, sm + L::O_GV + OX + TG * cg);
+            if (owng) PgV[jg] = a;
+            __syncthreads();
+            double rg[1] = {tid < n ? sm[L::O_GV + OX + tid] * PgV[tid] : 0.0};
+            block_reduce_n<1, NW>(rg, 0u, red);
+            gPg = uniform_d(rg[0]);
+        }
         materialize_ar(co);
         double r[1] = {0};
         {
@@ -620,8 +688,19 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
         __syncthreads();
         // P2: q = A p_x ; tau-tilde ; u-tilde ; cone input
         {
-            const double tau_t = (rtau * sm[L::O_W + OT] + sm[L::O_WP] + sm[L::O_WP + 1]) * inv_den;
+            double tau_t = (rtau * sm[L::O_W + OT] + sm[L::O_WP] + sm[L::O_WP + 1]) * inv_den;
             const double q = seg_dot<CHA, T2>(ar, sm + L::O_PX + T2 * c2);
+            if constexpr (HASP) {
+                // positive root of (r_tau + h.g - g^T P g) t^2 + (-(r_tau w_tau + h.p) + 2 p^T P g) t - p^T P p = 0, with
+                // p^T P p = rho_x p_x.(w_x - p_x) - (A p_x).p_y  (first block row of the linear system: no extra product)
+                double r3[3] = {0, 0, 0};
+                if (own2) { const double py = sm[L::O_W + OY + i2] + dyv(i2) * q; r3[0] = q * py; }
+                if (e < n) { const double px = sm[L::O_PX + e]; r3[1] = px * (sm[L::O_W + OX + e] - px); r3[2] = px * PgV[e]; }
+                block_reduce_n<3, NW>(r3, 0u, red);
+                const double pPp = rho_x * r3[1] - r3[0];
+                const double qa = rtau + hg - gPg, qb = -(rtau * sm[L::O_W + OT] + sm[L::O_WP] + sm[L::O_WP + 1]) + 2 * r3[2];
+                tau_t = uniform_d((-qb + sqrt(fmax(qb * qb + 4 * qa * fmax(pPp, 0.0), 0.0))) / (2 * qa));
+            }
             if (own2) {
                 const int ee = OY + i2;
                 const double we = sm[L::O_W + ee];
@@ -696,10 +775,18 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
                 const double aty_raw = seg_dot<CHT, T1>(at, sm + L::O_U + OY + T1 * c1);      // A-hat^T y-hat
                 if (own1) sm[L::O_ZB + OX + j1] = aty_raw;
             }
+            if constexpr (HASP) {      // P-hat x-hat, parked in TV (free between the products of two iterations)
+                __builtin_amdgcn_sched_barrier(0);
+                double pg[TG];
+                materialize_p(co, pg);
+                const double px_raw = seg_dot<CHG, TG>(pg, sm + L::O_U + OX + TG * cg);
+                if (owng) sm[L::O_TV + jg] = px_raw;
+            }
             __syncthreads();
             const double tau = uniform_d(fabs(sm[L::O_U + OT]));
             const double isg = uniform_d(1.0 / sc[SC_SIGMA]);
             double r[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // rp, nax, ns, naxs, rd, naty (max) ; ctx, bty (sum)
+            double rP[2] = {0, 0};                    // |P x| (max) ; x^T P x (sum)
             if (e < m) {
                 const int i = e;
                 const double sc_ = isg / sm[L::O_DV + i];
@@ -714,27 +801,32 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
                 const double sc_ = isg / sm[L::O_EV + j];
                 const double aty = sm[L::O_ZB + OX + j] * sc_;
                 const double cj = sm[L::O_CV + j];
-                r[4] = fabs(aty + cj * tau * sc_); r[5] = fabs(aty);
+                double pxj = 0;
+                if constexpr (HASP) { pxj = sm[L::O_TV + j] * sc_; rP[0] = fabs(pxj); rP[1] = sm[L::O_TV + j] * sm[L::O_U + OX + j] * isg * isg; }
+                r[4] = fabs(pxj + aty + cj * tau * sc_); r[5] = fabs(aty);
                 r[6] = cj * sm[L::O_U + OX + j] * isg * isg;
             }
             block_reduce_n<8, NW>(r, 0x3Fu, red);
+            double nPx = 0, xPx = 0;
+            if constexpr (HASP) { block_reduce_n<2, NW>(rP, 0x1u, red); nPx = uniform_d(rP[0]); xPx = uniform_d(rP[1]); }
             // the reduced values are equal in every lane: move them to scalar registers so that the convergence logic below
             // is scalar code with uniform branches (and n_log / last_scale_iter / status stay scalar)
             const double rp = uniform_d(r[0]), nax = uniform_d(r[1]), ns = uniform_d(r[2]), naxs = uniform_d(r[3]), rd = uniform_d(r[4]),
                          naty = uniform_d(r[5]), ctx = uniform_d(r[6]), bty = uniform_d(r[7]);
             const double nrm_b0 = uniform_d(sc[SC_NB0]), nrm_c0 = uniform_d(sc[SC_NC0]);
             if (tau > 0) {
-                const double res_pri = rp / tau, res_dual = rd / tau, gap = fabs(ctx + bty) / tau;
+                const double xPxt = xPx / tau;            // (0 without a quadratic objective)
+                const double res_pri = rp / tau, res_dual = rd / tau, gap = fabs(xPxt + ctx + bty) / tau;
                 sc[SC_RP] = res_pri; sc[SC_RD] = res_dual; sc[SC_GAP] = gap;
-                const double prl = fmax(fmax(nrm_b0 * tau, ns), nax) / tau, drl = fmax(nrm_c0 * tau, naty) / tau;
-                const double grl = fmax(fabs(ctx), fabs(bty)) / tau;
+                const double prl = fmax(fmax(nrm_b0 * tau, ns), nax) / tau, drl = fmax(fmax(nrm_c0 * tau, naty), nPx) / tau;
+                const double grl = fmax(fmax(fabs(ctx), fabs(bty)), fabs(xPxt)) / tau;
                 if (res_pri <= S.eps_abs + S.eps_rel * prl && res_dual <= S.eps_abs + S.eps_rel * drl &&
                     gap <= S.eps_abs + S.eps_rel * grl) { status = 1; stop = true; }
             }
             if (!stop && bty < 0 && naty / (-bty) <= S.eps_infeas) { status = -2; stop = true; }
-            if (!stop && ctx < 0 && naxs / (-ctx) <= S.eps_infeas) { status = -1; stop = true; }
+            if (!stop && ctx < 0 && fmax(naxs, nPx) / (-ctx) <= S.eps_infeas) { status = -1; stop = true; }
             if (!stop && S.adaptive_scale && iter > 0) {
-                const double dp = fmax(fmax(nax, ns), nrm_b0 * tau), dd = fmax(naty, nrm_c0 * tau);
+                const double dp = fmax(fmax(nax, ns), nrm_b0 * tau), dd = fmax(fmax(naty, nrm_c0 * tau), nPx);
                 const double rel_p = rp / (dp > 0 ? dp : 1), rel_d = rd / (dd > 0 ? dd : 1);
                 if (rel_p > 0 && rel_d > 0 && isfinite(rel_p) && isfinite(rel_d)) {
                     const double sum_log = uniform_d(sc[SC_SUMLOG]) + log(rel_p) - log(rel_d); n_log++;

@@ -62,6 +62,10 @@ struct ce_engine {
     int rt_variant = -1, rt_vp = 0, rt_lda = 0;   // register-tiled forward kernel variant (-1: generic kernel)
     int f2_variant = -1; int *d_idx_at = nullptr, *d_idx_ar = nullptr, *d_idx_b = nullptr; int f2_ldg = 0;   // second-generation forward kernel
     int brt_variant = -1;                          // register-tiled backward kernel variant (-1: generic kernel)
+    // quadratic objective
+    int nnz_p = 0, p_tri = 0; bool qp_native = false;
+    std::vector<int> p_rows, p_cols;               // host copy of the P structure (entry -> (row, col))
+    int *d_idx_p = nullptr, *d_pmap = nullptr, *d_prow = nullptr, *d_pcol = nullptr;
     // profiling
     bool prof = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[3];
@@ -156,7 +160,7 @@ static int f2_pick_ldg(int v) {
     }
     return NPg;
 }
-static bool f2_fits(const DevT &T, int v, int *ldg, size_t *bytes) {
+static bool f2_fits(const DevT &T, int v, int *ldg, size_t *bytes, bool has_p = false) {
     const int *V = F2_VARIANTS[v];
     const F2Dims d = f2_dims(v);
     const int NTH = V[6];
@@ -166,7 +170,7 @@ static bool f2_fits(const DevT &T, int v, int *ldg, size_t *bytes) {
     *ldg = f2_pick_ldg(v);
     if ((size_t)T.n * *ldg < (size_t)d.NPa) return false;
     const size_t psd = (T.ns > 0 ? 2 * (size_t)T.maxs * T.maxs + 2 * (size_t)T.maxs + 8 : 0) + (size_t)(T.nep + T.np);      // Jacobi scratch: S, V, (c, s, p, q) per pair; one root per exponential cone
-    *bytes = ((size_t)d.O_G + d.MP /* SOC row info (2 int arrays) */ + (size_t)T.n * *ldg + psd) * 8;
+    *bytes = ((size_t)d.O_G + d.MP /* SOC row info (2 int arrays) */ + (size_t)T.n * *ldg + psd + (has_p ? d.NP : 0) /* P-hat g_x */) * 8;
     return *bytes <= LDS_LIMIT;
 }
 
@@ -216,6 +220,18 @@ int ce_create(const ce_template *tpl, int device, ce_handle *out) {
         T.pw = h->d_pw;
     }
     h->q.assign(tpl->q, tpl->q + tpl->nq);
+    if (tpl->nnz_p > 0) {
+        if (!tpl->p_indices || !tpl->p_indptr || tpl->p_indptr[tpl->n] != tpl->nnz_p) { delete h; g_err = "bad P structure"; return CE_E_BADARG; }
+        h->nnz_p = tpl->nnz_p; h->p_rows.resize(tpl->nnz_p); h->p_cols.resize(tpl->nnz_p);
+        bool upper = true, lower = true;
+        for (int j = 0; j < tpl->n; j++)
+            for (int k = tpl->p_indptr[j]; k < tpl->p_indptr[j + 1]; k++) {
+                const int i = tpl->p_indices[k];
+                if (i < 0 || i >= tpl->n) { delete h; g_err = "P row index out of range"; return CE_E_BADARG; }
+                h->p_rows[k] = i; h->p_cols[k] = j; upper = upper && i <= j; lower = lower && i >= j;
+            }
+        h->p_tri = (upper || lower) ? 1 : 0;
+    }
     HIPCHK(hipMalloc(&h->d_rowidx, sizeof(int) * tpl->nnz_aug));
     HIPCHK(hipMalloc(&h->d_colidx, sizeof(int) * tpl->nnz_aug));
     HIPCHK(hipMalloc(&h->d_rowcone, sizeof(int) * tpl->m));
@@ -240,9 +256,11 @@ int ce_create(const ce_template *tpl, int device, ce_handle *out) {
     }
     const char *fwd_env = getenv("CE_FWD");      // "v2" (default when it fits), "rt", "generic": A/B switch for benchmarking
     if (!getenv("CE_FORCE_GENERIC") && !(fwd_env && (!strcmp(fwd_env, "rt") || !strcmp(fwd_env, "generic")))) {
+        const bool has_p = h->nnz_p > 0 && T.ns == 0 && T.nep + T.np == 0;     // P inside the kernels: plain cones only (else: epigraph form upstream)
         for (int v = 0; v < F2_NV; v++) {
             int ldg; size_t by;
-            if (!f2_fits(T, v, &ldg, &by)) continue;
+            if (has_p && v < 2) continue;                   // the quadratic-objective kernels are instantiated for variants 2..4
+            if (!f2_fits(T, v, &ldg, &by, has_p)) continue;
             const int *V = F2_VARIANTS[v];
             const int CHT = V[0], T1 = V[1], CHA = V[2], T2 = V[3], NTH = V[6];
             std::vector<int> pos((size_t)T.m * T.n, -1), ib(T.m, -1), iat((size_t)T1 * NTH, -1), iar((size_t)T2 * NTH, -1);
@@ -258,6 +276,22 @@ int ce_create(const ce_template *tpl, int device, ce_handle *out) {
             HIPCHK(hipMemcpy(h->d_idx_ar, iar.data(), sizeof(int) * iar.size(), hipMemcpyHostToDevice));
             HIPCHK(hipMemcpy(h->d_idx_b, ib.data(), sizeof(int) * T.m, hipMemcpyHostToDevice));
             h->f2_variant = v; h->f2_ldg = ldg; h->fwd_lds = by; h->fwd_mode = 4;
+            if (has_p) {      // gather map of the (jg, cg) tile layout and the dense n x n entry map
+                const int CHG = V[4], TG = V[5];
+                std::vector<int> pmap((size_t)T.n * T.n, -1), ip((size_t)TG * NTH, -1);
+                for (int k = 0; k < h->nnz_p; k++) { pmap[(size_t)h->p_rows[k] * T.n + h->p_cols[k]] = k; if (h->p_tri) pmap[(size_t)h->p_cols[k] * T.n + h->p_rows[k]] = k; }
+                for (int t = 0; t < NTH; t++) {
+                    const int jg = t / CHG, cg = t % CHG;
+                    for (int k = 0; k < TG; k++) { const int c = TG * cg + k; if (jg < T.n && c < T.n) ip[(size_t)k * NTH + t] = pmap[(size_t)jg * T.n + c]; }
+                }
+                HIPCHK(hipMalloc(&h->d_idx_p, sizeof(int) * ip.size())); HIPCHK(hipMalloc(&h->d_pmap, sizeof(int) * pmap.size()));
+                HIPCHK(hipMalloc(&h->d_prow, sizeof(int) * h->nnz_p)); HIPCHK(hipMalloc(&h->d_pcol, sizeof(int) * h->nnz_p));
+                HIPCHK(hipMemcpy(h->d_idx_p, ip.data(), sizeof(int) * ip.size(), hipMemcpyHostToDevice));
+                HIPCHK(hipMemcpy(h->d_pmap, pmap.data(), sizeof(int) * pmap.size(), hipMemcpyHostToDevice));
+                HIPCHK(hipMemcpy(h->d_prow, h->p_rows.data(), sizeof(int) * h->nnz_p, hipMemcpyHostToDevice));
+                HIPCHK(hipMemcpy(h->d_pcol, h->p_cols.data(), sizeof(int) * h->nnz_p, hipMemcpyHostToDevice));
+                h->qp_native = true;
+            }
             break;
         }
     }
@@ -281,12 +315,14 @@ int ce_create(const ce_template *tpl, int device, ce_handle *out) {
             }
         }
     }
+    if (h->qp_native && h->bwd_mode != 3) h->qp_native = false;      // the adjoint with P lives in the register-tiled backward kernel
 #define SETATTR(kern, bytes) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)))
     SETATTR((k_forward<true, true>), LDS_LIMIT);  SETATTR((k_forward<true, false>), LDS_LIMIT);  SETATTR((k_forward<false, false>), LDS_LIMIT);
     SETATTR((k_forward_rt<8, 13, 7, 4, 13, 160, 4>), LDS_LIMIT); SETATTR((k_forward_rt<8, 16, 8, 4, 16, 208, 4>), LDS_LIMIT); SETATTR((k_forward_rt<4, 32, 32, 4, 32, 272, 2>), LDS_LIMIT);
     SETATTR((k_fwd2<16, 2, 8, 2, 16, 2, true>), LDS_LIMIT); SETATTR((k_fwd2<8, 8, 4, 8, 8, 4, true>), LDS_LIMIT); SETATTR((k_fwd2<4, 26, 2, 26, 4, 14, true>), LDS_LIMIT);
     SETATTR((k_fwd2<4, 30, 4, 26, 4, 26, false, 512>), LDS_LIMIT); SETATTR((k_fwd2<8, 20, 2, 32, 8, 8, false, 512>), LDS_LIMIT);
     SETATTR((k_fwd2<4, 30, 4, 26, 4, 26, true, 512>), LDS_LIMIT); SETATTR((k_fwd2<8, 20, 2, 32, 8, 8, true, 512>), LDS_LIMIT);
+    SETATTR((k_fwd2<4, 26, 2, 26, 4, 14, false, 256, true>), LDS_LIMIT); SETATTR((k_fwd2<8, 20, 2, 32, 8, 8, false, 512, true>), LDS_LIMIT); SETATTR((k_fwd2<4, 30, 4, 26, 4, 26, false, 512, true>), LDS_LIMIT);
     SETATTR((k_fwd2<16, 2, 8, 2, 16, 2>), LDS_LIMIT); SETATTR((k_fwd2<8, 8, 4, 8, 8, 4>), LDS_LIMIT); SETATTR((k_fwd2<4, 26, 2, 26, 4, 14>), LDS_LIMIT);
     SETATTR((k_backward_rt<4, 4, 4, true>), LDS_LIMIT); SETATTR((k_backward_rt<7, 7, 4, true>), LDS_LIMIT); SETATTR((k_backward_rt<7, 7, 7, true>), LDS_LIMIT);
     SETATTR((k_backward_rt<7, 13, 7, false, 32>), LDS_LIMIT); SETATTR((k_backward_rt<7, 13, 7, true, 32>), LDS_LIMIT);
@@ -300,7 +336,7 @@ int ce_create(const ce_template *tpl, int device, ce_handle *out) {
 int ce_destroy(ce_handle h) {
     if (!h) return CE_OK;
     hipSetDevice(h->device);
-    hipFree(h->d_rowidx); hipFree(h->d_colidx); hipFree(h->d_rowcone); hipFree(h->d_qoff); hipFree(h->d_soff); hipFree(h->d_sord); hipFree(h->d_pw);
+    hipFree(h->d_rowidx); hipFree(h->d_colidx); hipFree(h->d_rowcone); hipFree(h->d_qoff); hipFree(h->d_soff); hipFree(h->d_sord); hipFree(h->d_pw); hipFree(h->d_idx_p); hipFree(h->d_pmap); hipFree(h->d_prow); hipFree(h->d_pcol);
     hipFree(h->wsA); hipFree(h->wsdA); hipFree(h->gws); hipFree(h->d_idx_at); hipFree(h->d_idx_ar); hipFree(h->d_idx_b);
     for (auto &v : h->ev) for (auto &p : v) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
     delete h;
@@ -340,9 +376,18 @@ static int to_batch_major(ce_engine *h, int B, const double *vals, long sk, long
     return CE_OK;
 }
 
+int ce_qp_native(ce_handle h) { return (h && h->qp_native) ? 1 : 0; }
+
 int ce_solve(ce_handle h, int B, const double *A_vals, long sA_k, long sA_b, const double *q_vals, long sq_k, long sq_b,
              const ce_settings *settings, double *x, double *y, double *s, int *iters, int *status, double *resid, void *stream) {
+    return ce_solve_qp(h, B, A_vals, sA_k, sA_b, q_vals, sq_k, sq_b, nullptr, settings, x, y, s, iters, status, resid, stream);
+}
+
+int ce_solve_qp(ce_handle h, int B, const double *A_vals, long sA_k, long sA_b, const double *q_vals, long sq_k, long sq_b,
+                const double *P_vals, const ce_settings *settings, double *x, double *y, double *s, int *iters, int *status, double *resid, void *stream) {
     if (!h || B <= 0 || !A_vals || !q_vals || !x || !y || !s || !iters || !status) { g_err = "null argument"; return CE_E_BADARG; }
+    if (P_vals && !h->qp_native) { g_err = "quadratic objective: this template does not run P inside the kernels (ce_qp_native == 0); use the epigraph form"; return CE_E_UNSUPPORTED; }
+    if (!P_vals && h->qp_native) { g_err = "template created with a P structure: P_vals is required"; return CE_E_BADARG; }
     HIPCHK(hipSetDevice(h->device));
     hipStream_t st = (hipStream_t)stream;
     if (h->T.nep + h->T.np > 0 && h->fwd_mode != 4) { g_err = "exponential / power cones: the template does not fit the LDS-resident forward kernel (n <= 98, m <= 120 this round)"; return CE_E_UNSUPPORTED; }
@@ -367,8 +412,10 @@ int ce_solve(ce_handle h, int B, const double *A_vals, long sA_k, long sA_b, con
         DevT Trt = T; Trt.lda = h->rt_lda;
 #define LAUNCH_RT(...) hipLaunchKernelGGL((k_forward_rt<__VA_ARGS__>), grid, dim3(NT2), h->fwd_lds, st, Trt, S, Abm, q_vals, sq_k, sq_b, x, y, s, iters, status, resid)
         DevT Tf2 = T; Tf2.ldg = h->f2_ldg;
-#define LAUNCH_F2(...) hipLaunchKernelGGL((k_fwd2<__VA_ARGS__>), grid, dim3(F2_VARIANTS[h->f2_variant][6]), h->fwd_lds, st, Tf2, S, Abm, q_vals, sq_k, sq_b, h->d_idx_at, h->d_idx_ar, h->d_idx_b, x, y, s, iters, status, resid)
-        if (h->fwd_mode == 4 && (T.ns > 0 || T.nep + T.np > 0)) {
+#define LAUNCH_F2(...) hipLaunchKernelGGL((k_fwd2<__VA_ARGS__>), grid, dim3(F2_VARIANTS[h->f2_variant][6]), h->fwd_lds, st, Tf2, S, Abm, q_vals, sq_k, sq_b, h->d_idx_at, h->d_idx_ar, h->d_idx_b, x, y, s, iters, status, resid, P_vals, h->nnz_p, h->d_idx_p)
+        if (h->fwd_mode == 4 && P_vals) {
+            if (h->f2_variant == 2) LAUNCH_F2(4, 26, 2, 26, 4, 14, false, 256, true); else if (h->f2_variant == 3) LAUNCH_F2(8, 20, 2, 32, 8, 8, false, 512, true); else LAUNCH_F2(4, 30, 4, 26, 4, 26, false, 512, true);
+        } else if (h->fwd_mode == 4 && (T.ns > 0 || T.nep + T.np > 0)) {
             if (h->f2_variant == 0) LAUNCH_F2(16, 2, 8, 2, 16, 2, true); else if (h->f2_variant == 1) LAUNCH_F2(8, 8, 4, 8, 8, 4, true); else if (h->f2_variant == 2) LAUNCH_F2(4, 26, 2, 26, 4, 14, true); else if (h->f2_variant == 3) LAUNCH_F2(8, 20, 2, 32, 8, 8, true, 512); else LAUNCH_F2(4, 30, 4, 26, 4, 26, true, 512);
         } else if (h->fwd_mode == 4) {
             if (h->f2_variant == 0) LAUNCH_F2(16, 2, 8, 2, 16, 2); else if (h->f2_variant == 1) LAUNCH_F2(8, 8, 4, 8, 8, 4); else if (h->f2_variant == 2) LAUNCH_F2(4, 26, 2, 26, 4, 14); else if (h->f2_variant == 3) LAUNCH_F2(8, 20, 2, 32, 8, 8, false, 512); else LAUNCH_F2(4, 30, 4, 26, 4, 26, false, 512);
@@ -387,7 +434,14 @@ int ce_vjp(ce_handle h, int B, const double *A_vals, long sA_k, long sA_b, const
            const double *x, const double *y, const double *s, const double *dx, const double *dy,
            double *dA_vals, long sdA_k, long sdA_b, double *dq_vals, long sdq_k, long sdq_b, int *adj_status, void *stream) {
     (void)q_vals; (void)sq_k; (void)sq_b;   // b, c do not enter the adjoint system once r_tau is pinned
+    return ce_vjp_qp(h, B, A_vals, sA_k, sA_b, nullptr, x, y, s, dx, dy, dA_vals, sdA_k, sdA_b, dq_vals, sdq_k, sdq_b, nullptr, adj_status, stream);
+}
+
+int ce_vjp_qp(ce_handle h, int B, const double *A_vals, long sA_k, long sA_b, const double *P_vals,
+              const double *x, const double *y, const double *s, const double *dx, const double *dy,
+              double *dA_vals, long sdA_k, long sdA_b, double *dq_vals, long sdq_k, long sdq_b, double *dP_vals, int *adj_status, void *stream) {
     if (!h || B <= 0 || !x || !y || !s || !dx || !dy || !dA_vals || !dq_vals) { g_err = "null argument"; return CE_E_BADARG; }
+    if ((P_vals != nullptr) != h->qp_native || (P_vals && !dP_vals)) { g_err = "quadratic objective: P_vals / dP_vals must be given exactly when ce_qp_native(h) == 1"; return CE_E_BADARG; }
     HIPCHK(hipSetDevice(h->device));
     hipStream_t st = (hipStream_t)stream;
     const DevT &T = h->T;
@@ -413,7 +467,7 @@ int ce_vjp(ce_handle h, int B, const double *A_vals, long sA_k, long sA_b, const
         dim3 grid(B), block(NT);
 #define LAUNCH_B(AL, KL) hipLaunchKernelGGL((k_backward<AL, KL>), grid, block, h->bwd_lds, st, T, h->nkcap, h->ldk, Abm, x, y, s, dx, dy, dAbm, dq_vals, sdq_k, sdq_b, adj_status, gA, gK)
         DevT Tb = T; Tb.lda = T.n;
-#define LAUNCH_BRT(...) hipLaunchKernelGGL((k_backward_rt<__VA_ARGS__>), grid, dim3(h->brt_variant >= 0 ? BRT_VARIANTS[h->brt_variant][3] * 16 : NT), h->bwd_lds, st, Tb, Abm, x, y, s, dx, dy, dAbm, dq_vals, sdq_k, sdq_b, adj_status)
+#define LAUNCH_BRT(...) hipLaunchKernelGGL((k_backward_rt<__VA_ARGS__>), grid, dim3(h->brt_variant >= 0 ? BRT_VARIANTS[h->brt_variant][3] * 16 : NT), h->bwd_lds, st, Tb, Abm, x, y, s, dx, dy, dAbm, dq_vals, sdq_k, sdq_b, adj_status, P_vals, h->nnz_p, h->d_pmap, h->d_prow, h->d_pcol, h->p_tri, dP_vals)
         if (h->bwd_mode == 3 && (T.ns > 0 || T.nep + T.np > 0)) {
             if (h->brt_variant == 0) LAUNCH_BRT(4, 4, 4, true); else if (h->brt_variant == 1) LAUNCH_BRT(7, 7, 4, true); else if (h->brt_variant == 2) LAUNCH_BRT(7, 7, 7, true); else LAUNCH_BRT(7, 13, 7, true, 32);
         } else if (h->bwd_mode == 3) {

@@ -76,7 +76,7 @@ def make_settings(merged_args: dict) -> _lib.CeSettings:
 class ConeEngine:
     """Owns one ce_handle (one template, one device)."""
 
-    def __init__(self, indices, indptr, n, m, cone_dict, device: torch.device):
+    def __init__(self, indices, indptr, n, m, cone_dict, device: torch.device, p_structure=None):
         L = _lib.lib()
         self.device = device
         self.n, self.m = int(n), int(m)
@@ -97,12 +97,21 @@ class ConeEngine:
         self._pw = np.ascontiguousarray(cone_dict.get("p", []), dtype=np.float64)
         t.nep, t.np = int(cone_dict.get("ep", 0)), len(self._pw)
         t.p = self._pw.ctypes.data_as(C.POINTER(C.c_double))
+        self.nnz_p = 0
+        if p_structure is not None:       # quadratic objective: CSC structure of P (n x n)
+            self._p_idx = np.ascontiguousarray(p_structure[0], dtype=np.int32)
+            self._p_ptr = np.ascontiguousarray(p_structure[1], dtype=np.int32)
+            self.nnz_p = int(self._p_ptr[-1])
+            t.nnz_p = self.nnz_p
+            t.p_indices = self._p_idx.ctypes.data_as(C.POINTER(C.c_int))
+            t.p_indptr = self._p_ptr.ctypes.data_as(C.POINTER(C.c_int))
         h = C.c_void_p()
         rc = L.ce_create(C.byref(t), device.index or 0, C.byref(h))
         if rc == -2:
             raise NotImplementedError(L.ce_last_error().decode())
         _lib.check(rc, "ce_create")
         self._h = h
+        self.qp_native = bool(self.nnz_p) and bool(L.ce_qp_native(h))     # P runs inside the kernels (else: epigraph form upstream)
 
     def __del__(self):
         try:
@@ -130,7 +139,7 @@ class ConeEngine:
         _lib.check(_lib.lib().ce_transpose(self._h, K, B, A_eval.data_ptr(), out.data_ptr(), self._stream()), "ce_transpose")
         return out
 
-    def solve(self, A_bm: torch.Tensor, q_eval: torch.Tensor, settings, warm=None):
+    def solve(self, A_bm: torch.Tensor, q_eval: torch.Tensor, settings, warm=None, P_bm=None):
         """A_bm (B, nnz_aug) contiguous, q_eval (n+1, B) any strides.  Returns x, y, s, iters, status, resid.
         warm = (x, y, s) of shapes (B, n), (B, m), (B, m): initial point (instances with non-finite entries start cold)."""
         B = A_bm.shape[0]
@@ -144,7 +153,9 @@ class ConeEngine:
             if tuple(warm[0].shape) != (B, self.n) or tuple(warm[1].shape) != (B, self.m) or tuple(warm[2].shape) != (B, self.m):
                 raise ValueError(f"warm start: expected x {(B, self.n)}, y {(B, self.m)}, s {(B, self.m)}, got "
                                  f"{tuple(warm[0].shape)}, {tuple(warm[1].shape)}, {tuple(warm[2].shape)}")
-        if self._use_const_a(A_bm):
+        if P_bm is not None and not self.qp_native:
+            raise RuntimeError("quadratic objective on an engine without native P support (use the epigraph form)")
+        if P_bm is None and self._use_const_a(A_bm):
             from cvxpylayers_amd.interfaces.const_a import solve_const_a
             self.last_path = "const_a"
             return solve_const_a(self, A_bm, q_eval, settings, warm=warm)
@@ -160,9 +171,14 @@ class ConeEngine:
         iters = torch.empty((B,), dtype=torch.int32, device=dev)
         status = torch.empty((B,), dtype=torch.int32, device=dev)
         resid = torch.empty((B, 3), dtype=torch.float64, device=dev)
-        rc = _lib.lib().ce_solve(self._h, B, A_bm.data_ptr(), 1, self.nnz_aug, q_eval.data_ptr(), q_eval.stride(0),
-                                 q_eval.stride(1), C.byref(settings), x.data_ptr(), y.data_ptr(), s.data_ptr(),
-                                 iters.data_ptr(), status.data_ptr(), resid.data_ptr(), self._stream())
+        if P_bm is not None:
+            rc = _lib.lib().ce_solve_qp(self._h, B, A_bm.data_ptr(), 1, self.nnz_aug, q_eval.data_ptr(), q_eval.stride(0),
+                                        q_eval.stride(1), P_bm.data_ptr(), C.byref(settings), x.data_ptr(), y.data_ptr(), s.data_ptr(),
+                                        iters.data_ptr(), status.data_ptr(), resid.data_ptr(), self._stream())
+        else:
+            rc = _lib.lib().ce_solve(self._h, B, A_bm.data_ptr(), 1, self.nnz_aug, q_eval.data_ptr(), q_eval.stride(0),
+                                     q_eval.stride(1), C.byref(settings), x.data_ptr(), y.data_ptr(), s.data_ptr(),
+                                     iters.data_ptr(), status.data_ptr(), resid.data_ptr(), self._stream())
         _lib.check(rc, "ce_solve")
         return x, y, s, iters, status, resid
 
@@ -178,7 +194,7 @@ class ConeEngine:
             return False
         return is_constant_A(A_bm, self.nnzA)
 
-    def vjp(self, A_bm, x, y, s, dx, dy, batch_minor_out: bool = False):
+    def vjp(self, A_bm, x, y, s, dx, dy, batch_minor_out: bool = False, P_bm=None):
         """Returns dA (nnz_aug, B), dq (n+1, B), adj_status (B,).  dA is a transposed view of a batch-major buffer (the
         engine-native layout, no extra pass) unless batch_minor_out: then it is (nnz_aug, B) contiguous -- the layout of a
         reference-style A_eval, so that autograd can accumulate it into the leaf without a strided copy (one engine layout pass)."""
@@ -198,6 +214,13 @@ class ConeEngine:
         else:
             dA = torch.empty((B, self.nnz_aug), dtype=torch.float64, device=dev)
             sk, sb = 1, self.nnz_aug
+        if P_bm is not None:      # quadratic objective: also dP (B, nnz_p) batch-major
+            dP = torch.empty((B, self.nnz_p), dtype=torch.float64, device=dev)
+            rc = _lib.lib().ce_vjp_qp(self._h, B, A_bm.data_ptr(), 1, self.nnz_aug, P_bm.data_ptr(), x.data_ptr(), y.data_ptr(),
+                                      s.data_ptr(), dx.data_ptr(), dy.data_ptr(), dA.data_ptr(), sk, sb,
+                                      dq.data_ptr(), B, 1, dP.data_ptr(), adj.data_ptr(), self._stream())
+            _lib.check(rc, "ce_vjp_qp")
+            return (dA if batch_minor_out else dA.t()), dq, adj, dP
         rc = _lib.lib().ce_vjp(self._h, B, A_bm.data_ptr(), 1, self.nnz_aug, None, 0, 0, x.data_ptr(), y.data_ptr(),
                                s.data_ptr(), dx.data_ptr(), dy.data_ptr(), dA.data_ptr(), sk, sb,
                                dq.data_ptr(), B, 1, adj.data_ptr(), self._stream())
@@ -243,6 +266,15 @@ class QuadEpigraph:
         self.p_rows = np.asarray(p_indices, dtype=np.int64)
         self.p_cols = np.repeat(np.arange(n), np.diff(np.asarray(p_indptr))).astype(np.int64)
         self.one_triangle = bool(len(self.p_rows)) and (bool((self.p_rows <= self.p_cols).all()) or bool((self.p_rows >= self.p_cols).all()))
+        self.p_indices, self.p_indptr = np.asarray(p_indices, dtype=np.int32), np.asarray(p_indptr, dtype=np.int32)
+        # native (in-kernel) P needs symmetric values: for a full structure, entry (i, j) is averaged with entry (j, i); sym_perm
+        # is that pairing (identity for one-triangle structures, None when the structure is not symmetric -> epigraph form only)
+        if self.one_triangle or len(self.p_rows) == 0:
+            self.sym_perm = np.arange(len(self.p_rows))
+        else:
+            pos = {(int(r), int(c)): k for k, (r, c) in enumerate(zip(self.p_rows, self.p_cols))}
+            perm = [pos.get((int(c), int(r)), -1) for r, c in zip(self.p_rows, self.p_cols)]
+            self.sym_perm = np.asarray(perm) if min(perm) >= 0 else None
         a_idx, a_ptr = np.asarray(A_structure[0], dtype=np.int64), np.asarray(A_structure[1], dtype=np.int64)
         nnz_old = int(a_ptr[-1])
         r0 = int(cone_dict.get("z", 0)) + int(cone_dict.get("l", 0)) + int(sum(cone_dict.get("q", [])))      # first row of the new SOC block
@@ -342,8 +374,9 @@ class MI355_ctx:
     def engine(self, device: torch.device) -> ConeEngine:
         idx = device.index or 0
         if idx not in self._engines:
+            pst = (self.quad.p_indices, self.quad.p_indptr) if self.quad is not None and self.quad.sym_perm is not None else None
             self._engines[idx] = ConeEngine(self.A_structure[0], self.A_structure[1], self.A_shape[1] - 1, self.A_shape[0],
-                                            self.cone_dict, torch.device("cuda", idx))
+                                            self.cone_dict, torch.device("cuda", idx), p_structure=pst)
         return self._engines[idx]
 
 
@@ -374,8 +407,7 @@ class _ConeLayer(torch.autograd.Function):
     @staticmethod
     def forward(P_eval, q_eval, A_eval, cl_ctx, solver_args, needs_grad=True, warm_start=None):
         ctx = cl_ctx.solver_ctx if hasattr(cl_ctx, "solver_ctx") else cl_ctx
-        if P_eval is not None:
-            raise RuntimeError("internal: quadratic objectives are reduced to cone form by _CvxpyLayer.apply")
+        # P_eval given: only for engines that run the quadratic objective inside the kernels (_CvxpyLayer.apply decides)
         batch_size, originally_unbatched = _detect_batch_size(A_eval)
         if originally_unbatched:
             A_eval = A_eval.unsqueeze(1)
@@ -395,6 +427,11 @@ class _ConeLayer(torch.autograd.Function):
             q_dev = q_eval.detach().to(device=dev, dtype=torch.float64)
             batch_minor_in = A_dev.dim() == 2 and A_dev.is_contiguous() and A_dev.shape[1] > 1
             A_bm = eng.to_batch_major(A_dev)
+            P_bm = None
+            if P_eval is not None:
+                if originally_unbatched:
+                    P_eval = P_eval.unsqueeze(1)
+                P_bm = P_eval.detach().to(device=dev, dtype=torch.float64).t().contiguous()        # (B, nnz_p)
             warm = None
             if warm_start is True:                                   # re-use the previous solution of this layer (same batch size)
                 prev = getattr(eng, "_last_solution", None)
@@ -402,7 +439,7 @@ class _ConeLayer(torch.autograd.Function):
                     warm = prev
             elif warm_start not in (None, False):
                 warm = tuple(t if t.dim() == 2 else t.unsqueeze(0) for t in warm_start)     # (x, y, s) tensors
-            x, y, s, iters, status, resid = eng.solve(A_bm, q_dev, settings, warm=warm)
+            x, y, s, iters, status, resid = eng.solve(A_bm, q_dev, settings, warm=warm, P_bm=P_bm)
             eng._last_solution = (x.detach(), y.detach(), s)
             st = status.cpu()
         if bool((st < 0).any()) and merged_args.get("raise_on_error", True):
@@ -418,7 +455,7 @@ class _ConeLayer(torch.autograd.Function):
         # attaches this node to them: keeping the SAME objects on the node would form a reference cycle (node -> saved ->
         # primal -> grad_fn -> node) that only the cyclic GC breaks, i.e. 167 MB buffers pile up for many steps and the
         # caching allocator falls back to hipMalloc (3 ms each).  Detached aliases share the storage without the cycle.
-        saved = (eng, A_bm, x.detach(), y.detach(), s, batch_minor_in) if needs_grad else None
+        saved = (eng, A_bm, x.detach(), y.detach(), s, batch_minor_in, P_bm) if needs_grad else None
         return primal, dual, info, (saved, batch_size, originally_unbatched, in_device)
 
     @staticmethod
@@ -433,11 +470,16 @@ class _ConeLayer(torch.autograd.Function):
         saved, batch_size, originally_unbatched, in_device = ctx.backward_data
         if saved is None:
             raise RuntimeError("backward called on a layer evaluated with needs_grad=False")
-        eng, A_bm, x, y, s, batch_minor_in = saved
+        eng, A_bm, x, y, s, batch_minor_in, P_bm = saved
+        dP = None
         with torch.cuda.device(eng.device):
             dx = dprimal.to(device=eng.device, dtype=torch.float64).contiguous()
             dy = ddual.to(device=eng.device, dtype=torch.float64).contiguous()
-            dA, dq, adj = eng.vjp(A_bm, x, y, s, dx, dy, batch_minor_out=batch_minor_in)
+            if P_bm is not None:
+                dA, dq, adj, dP_bm = eng.vjp(A_bm, x, y, s, dx, dy, batch_minor_out=batch_minor_in, P_bm=P_bm)
+                dP = dP_bm.t().to(in_device)
+            else:
+                dA, dq, adj = eng.vjp(A_bm, x, y, s, dx, dy, batch_minor_out=batch_minor_in)
         ctx.adj_status = adj
         eng._pending_adj = (adj, batch_size)     # inspected at the next call (no host sync on the backward path)
         dA = dA.to(in_device)
@@ -445,7 +487,8 @@ class _ConeLayer(torch.autograd.Function):
         if originally_unbatched:
             dq = dq.squeeze(1)
             dA = dA.squeeze(1)
-        return None, dq, dA, None, None, None, None
+            dP = dP.squeeze(1) if dP is not None else None
+        return dP, dq, dA, None, None, None, None
 
 
 class _CvxpyLayer:
@@ -461,6 +504,14 @@ class _CvxpyLayer:
         ctx = cl_ctx.solver_ctx if hasattr(cl_ctx, "solver_ctx") else cl_ctx
         if ctx.quad is None:
             raise ValueError("MI355 solver: P_eval was given but the context was built without an objective structure")
+        import os
+        dev0 = A_eval.device if A_eval.device.type == "cuda" else ctx.default_device
+        if ctx.quad.sym_perm is not None and os.environ.get("CE_QP_EPIGRAPH") != "1" and ctx.engine(dev0).qp_native:
+            # P inside the kernels (SCS 3's QP embedding; plain cones, register-tiled sizes): symmetric values in, dP out
+            if not ctx.quad.one_triangle:
+                perm = torch.from_numpy(ctx.quad.sym_perm).to(P_eval.device)
+                P_eval = 0.5 * (P_eval + P_eval.index_select(0, perm))
+            return _ConeLayer.apply(P_eval, q_eval, A_eval, ctx, solver_args, needs_grad, warm_start)
         unbatched = A_eval.dim() == 1
         if unbatched:
             P_eval, q_eval, A_eval = P_eval.unsqueeze(1), q_eval.unsqueeze(1), A_eval.unsqueeze(1)

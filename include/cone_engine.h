@@ -58,6 +58,11 @@ typedef struct {
     int nep;               /* exponential cones ("ep"): triples (x, y, z), y exp(x/y) <= z, after the PSD blocks (SCS row order z,l,q,s,ep,p) */
     int np;                /* 3-d power cones ("p"): triples (x, y, z), x^a y^(1-a) >= |z|, after the exponential cones */
     const double *p;       /* [np] exponents a in (0, 1); a negative entry -a is the DUAL power cone of exponent a (SCS convention)  (HOST memory) */
+    /* optional quadratic objective 1/2 x^T P x (param_prob.reduced_P.problem_data_index, interfaces/__init__.py:27): CSC structure
+     * of the n x n matrix P, either one triangle or structurally symmetric; nnz_p = 0: linear objective */
+    int nnz_p;
+    const int *p_indices;  /* [nnz_p] row indices (HOST memory) */
+    const int *p_indptr;   /* [n+1] */
 } ce_template;
 
 /* Solver settings; names follow SCS / diffcp keyword arguments (diffcp maps eps -> eps_abs, eps_rel). */
@@ -117,6 +122,22 @@ int ce_vjp(ce_handle h, int B,
  * device buffers.  Used by the plugin to turn the reference's batch-minor A_eval (nnz_aug x B) into the
  * engine-native batch-major (B x nnz_aug) once, into a tensor it keeps for backward. */
 int ce_transpose(ce_handle h, int rows, int cols, const double *in, double *out, void *stream);
+
+/*
+ * Quadratic objective (templates created with nnz_p > 0): ce_solve / ce_vjp with the values of P  <- P_eval of the QP-capable
+ * plugins (moreau_if.py:399-404; _quad_form_dpp.py:32).  P_vals is BATCH-MAJOR (B, nnz_p) contiguous device memory (the P entries
+ * in the template's structure; for a structurally symmetric P the values must be symmetric).  SCS 3's QP embedding: P joins the
+ * reduced KKT matrix, tau-tilde is the positive root of a quadratic, dual residual / gap / objective include P.  ce_vjp_qp also
+ * returns dP_vals (B, nnz_p) batch-major (the gradient of a one-triangle entry is that of both matrix entries it stands for).
+ * ce_qp_native(h): 1 if this template's quadratic objective runs inside the kernels (fits the register-tiled variants, no
+ * PSD / exponential / power cones); otherwise callers reduce it to an epigraph SOC themselves (mi355_if.py QuadEpigraph).
+ */
+int ce_qp_native(ce_handle h);
+int ce_solve_qp(ce_handle h, int B, const double *A_vals, long sA_k, long sA_b, const double *q_vals, long sq_k, long sq_b,
+                const double *P_vals, const ce_settings *settings, double *x, double *y, double *s, int *iters, int *status, double *resid, void *stream);
+int ce_vjp_qp(ce_handle h, int B, const double *A_vals, long sA_k, long sA_b, const double *P_vals,
+              const double *x, const double *y, const double *s, const double *dx, const double *dy,
+              double *dA_vals, long sdA_k, long sdA_b, double *dq_vals, long sdq_k, long sdq_b, double *dP_vals, int *adj_status, void *stream);
 
 /*
  * Parameter-map evaluation on the device, batch-major  <- CvxpyLayer.forward's  A_eval = A_map @ p_stack,

@@ -83,8 +83,11 @@ def test_indefinite_P_is_refused():
 
 
 @pytest.mark.gpu
-def test_quadratic_objective_values_and_gradients_on_gpu():
+@pytest.mark.parametrize("form", ["native", "epigraph"])
+def test_quadratic_objective_values_and_gradients_on_gpu(form, monkeypatch):
     from cvxpylayers_amd.interfaces.mi355_if import _CvxpyLayer
+    if form == "epigraph":
+        monkeypatch.setenv("CE_QP_EPIGRAPH", "1")
     n, p, B = 6, 2, 7
     Pm, q, F, g = _eq_qp(n, p, B, seed=1)
     cones = {"z": p, "l": 0, "q": [], "s": []}
@@ -105,6 +108,7 @@ def test_quadratic_objective_values_and_gradients_on_gpu():
     q_eval = torch.cat([qt.t(), torch.zeros(1, B, dtype=torch.float64, device=dev)], dim=0)
     primal, dual, info, _ = _CvxpyLayer.apply(P_eval, q_eval, A_eval, ctx, {}, True, None)
     assert primal.shape == (B, n) and dual.shape == (B, p)
+    assert ctx.engine(dev).qp_native and (ctx._aug_ctx is None) == (form == "native")
     wx = torch.linspace(0.5, 1.5, n, dtype=torch.float64, device=dev)
     (primal * wx).sum().backward()
     grads = [t.grad.clone() for t in (Pt, qt, Ft, gt)]
@@ -176,3 +180,48 @@ def test_frontend_layer_with_a_parametric_quad_form():
     (sol[:, :n] * wts).sum().backward()
     assert torch.allclose(qt.grad, q2.grad, atol=2e-5)
     assert torch.allclose(Pt.grad + Pt.grad.transpose(1, 2), P2.grad + P2.grad.transpose(1, 2), atol=4e-5)    # symmetric part is what the problem sees
+
+
+@pytest.mark.gpu
+def test_native_qp_kernels_match_the_oracle_on_box_qps():
+    """BASELINE config 2 in its native form (P = 2 F^T F, 100 box rows, n = 50) through ce_solve_qp / ce_vjp_qp against the oracle's
+    QP embedding: solutions, iteration counts, dA / dq / dP."""
+    from oracle import oracle
+    from cvxpylayers_amd.interfaces.mi355_if import ConeEngine, make_settings
+    nx, B = 50, 24
+    rng = np.random.default_rng(0)
+    Fm = rng.standard_normal((nx, nx)) / np.sqrt(nx); g = rng.standard_normal((B, nx))
+    lo = -0.5 - 0.5 * rng.random((B, nx)); hi = 0.5 + 0.5 * rng.random((B, nx))
+    Pn = np.broadcast_to(2 * Fm.T @ Fm, (B, nx, nx)).copy() * (1 + 0.1 * rng.random((B, 1, 1)))       # per-instance P
+    An = np.broadcast_to(np.concatenate([-np.eye(nx), np.eye(nx)], axis=0), (B, 2 * nx, nx)).copy()
+    bn = np.concatenate([-lo, hi], axis=1); qn = -2 * g @ Fm
+    cones = {"z": 0, "l": 2 * nx, "q": [], "s": []}
+    tpl = P.dense_template(nx, cones, pattern=(An[0] != 0))
+    pst = _upper_structure(nx)
+    eng = ConeEngine(tpl.indices, tpl.indptr, tpl.n, tpl.m, cones, torch.device("cuda", 0), p_structure=pst[:2])
+    assert eng.qp_native
+    A_eval, q_eval = tpl.values_from_dense(An, bn, qn)
+    A_bm = eng.to_batch_major(torch.from_numpy(A_eval).cuda())
+    P_bm = torch.from_numpy(_p_values(Pn, pst)).cuda().contiguous()
+    for eps in (1e-4, 1e-9):
+        ref = oracle.solve_batch(An, bn, qn, cones, P=Pn, eps=eps, max_iters=100000)
+        x, y, s, iters, status, resid = eng.solve(A_bm, torch.from_numpy(q_eval).cuda(), make_settings(dict(eps=eps, max_iters=100000)), P_bm=P_bm)
+        assert (status.cpu().numpy() == 1).all() and (ref["status"] == 1).all()
+        tol = max(1e-6, 20 * eps)
+        for got, want in ((x, ref["x"]), (y, ref["y"]), (s, ref["s"])):
+            err = np.abs(got.cpu().numpy() - want).max(axis=1) / (1 + np.abs(want).max(axis=1))
+            assert err.max() < tol, err.max()
+        assert np.abs(iters.cpu().numpy() - ref["iters"]).max() <= 25, (iters.cpu().numpy(), ref["iters"])
+    dx = rng.standard_normal(ref["x"].shape); dy = rng.standard_normal(ref["y"].shape)
+    gr = oracle.adjoint_batch(An, bn, qn, cones, ref["x"], ref["y"], ref["s"], dx, dy, P=Pn, mode="dense")
+    xr, yr, sr = (torch.from_numpy(ref[k]).cuda() for k in ("x", "y", "s"))
+    dA, dq, adj, dP = eng.vjp(A_bm, xr, yr, sr, torch.from_numpy(dx).cuda(), torch.from_numpy(dy).cuda(), P_bm=P_bm)
+    assert (adj.cpu().numpy() == 0).all()
+    cols = np.repeat(np.arange(nx + 1), np.diff(tpl.indptr))
+    want = np.stack([-gr["dA"][:, i, j] if j < nx else gr["db"][:, i] for i, j in zip(tpl.indices, cols)])
+    assert np.abs(dA.cpu().numpy() - want).max() < 1e-5 * (1 + np.abs(want).max())
+    assert np.abs(dq.cpu().numpy()[:nx] - gr["dc"].T).max() < 1e-5 * (1 + np.abs(gr["dc"]).max())
+    idx, ptr, _ = pst
+    pc = np.repeat(np.arange(nx), np.diff(ptr))
+    wantP = gr["dP"][:, idx, pc] + np.where(idx != pc, gr["dP"][:, pc, idx], 0.0)        # one stored entry stands for (i,j) and (j,i)
+    assert np.abs(dP.cpu().numpy() - wantP).max() < 1e-5 * (1 + np.abs(wantP).max())
