@@ -31,15 +31,17 @@ def sdp(B, k=20, neq=20, seed=0):
     return A, b, -(y0 @ A), cones
 
 
-def run(name, tpl, cones, A_eval, q_eval, eps, reps, note):
-    ctx = MI355_ctx(None, tpl.problem_data_index, cones, options={"eps": eps, "max_iters": 20000, "raise_on_error": False})
+def run(name, tpl, cones, A_eval, q_eval, eps, reps, note, P_eval=None, p_structure=None):
+    ctx = MI355_ctx(p_structure, tpl.problem_data_index, cones, options={"eps": eps, "max_iters": 20000, "raise_on_error": False})
     A_t = torch.from_numpy(A_eval).to(dev).t().contiguous().t().requires_grad_()      # (nnz_aug, B) view of batch-major storage
     q_t = torch.from_numpy(q_eval).to(dev).requires_grad_()
+    P_t = torch.from_numpy(P_eval).to(dev).requires_grad_() if P_eval is not None else None
     B = A_eval.shape[1]
 
     def step():
         A_t.grad = None; q_t.grad = None
-        p, d, info, _ = _CvxpyLayer.apply(None, q_t, A_t, ctx, {}, True, None)
+        if P_t is not None: P_t.grad = None
+        p, d, info, _ = _CvxpyLayer.apply(P_t, q_t, A_t, ctx, {}, True, None)
         p.sum().backward()
         return info
     info = step(); torch.cuda.synchronize()
@@ -67,6 +69,30 @@ A, b, c, cones = P.box_qp_batch(50, 4096 if not ONLY else 2, seed=0)
 tpl = P.dense_template(A.shape[2], cones, pattern=(A[0] != 0))
 if not ONLY:
     res.append(run("C2Q", tpl, cones, *tpl.values_from_dense(A, b, c), 1e-4, 5, "box QP n=50 in SOC-epigraph form (BASELINE config 2 as DIFFCP sees it); F shared, g/lo/hi batched"))
+def native_box_qp(B, nx=50, seed=0):
+    """BASELINE config 2 in its native form: min 1/2 x^T (2 F^T F) x - 2 g^T F x, lo <= x <= hi; same F, g, lo, hi as box_qp_batch"""
+    rng = np.random.default_rng(seed)
+    F = rng.standard_normal((nx, nx)) / np.sqrt(nx); g = rng.standard_normal((B, nx))
+    lo = -0.5 - 0.5 * rng.random((B, nx)); hi = 0.5 + 0.5 * rng.random((B, nx))
+    An = np.concatenate([-np.eye(nx), np.eye(nx)], axis=0)
+    rows, ptr = [], [0]
+    for j in range(nx):
+        rows.extend(range(j + 1)); ptr.append(len(rows))
+    pst = (np.asarray(rows, dtype=np.int32), np.asarray(ptr, dtype=np.int32), (nx, nx))
+    Pm = 2 * F.T @ F
+    pv = Pm[pst[0], np.repeat(np.arange(nx), np.diff(pst[1]))]
+    return An, np.concatenate([-lo, hi], axis=1), -2 * g @ F, pst, np.broadcast_to(pv[:, None], (len(pv), B)).copy()
+
+
+if not ONLY or ONLY == "C2N":
+    An, bn, qn, pst, Pv = native_box_qp(4096)
+    conesN = {"z": 0, "l": 100, "q": [], "s": []}
+    tplN = P.dense_template(50, conesN, pattern=(An != 0))
+    res.append(run("C2N", tplN, conesN, *tplN.values_from_dense(np.broadcast_to(An, (4096,) + An.shape).copy(), bn, qn), 1e-4, 200 if ONLY else 5,
+                   "box QP n=50 in NATIVE form (P = 2 F^T F inside the kernels, 100 box rows): BASELINE config 2 (i)", P_eval=Pv, p_structure=pst))
+    if ONLY:
+        json.dump(res, open(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/configs_C2N.json", "w"), indent=1)
+        sys.exit(0)
 ecfg = dict(n=40, cones={"z": 0, "l": 12, "q": [4], "s": [], "ep": 24})      # the cone shape of a 12-sample, 3-feature logistic-regression layer
 tplE = P.dense_template(ecfg["n"], ecfg["cones"])
 Ae, be, ce_ = P.generate(ecfg["n"], ecfg["cones"], 4096, seed=0)
