@@ -341,3 +341,21 @@ def test_float32_parameters_give_float64_results():
     eng = layer.ctx.solver_ctx.engine(torch.device("cuda", 0))
     out = eng.solve(torch.empty((0, eng.nnz_aug), dtype=torch.float64, device="cuda"), torch.empty((eng.n + 1, 0), dtype=torch.float64, device="cuda"), make_settings({}))
     assert out[0].shape == (0, eng.n) and out[4].shape == (0,)
+
+
+def test_affine_probing_with_a_quadratic_objective_builds_the_P_map():
+    """builder returning (A, b, c, P): the upper triangle of P becomes the template's P structure and P_map @ (p, 1) its values"""
+    n = 4
+
+    def builder(Pp, qp):
+        A = np.zeros((1, n)); A[0] = 1.0
+        return A, np.ones(1), qp, 0.5 * (Pp + Pp.T) + np.eye(n)
+    tpl = template_from_affine_builder(builder, [(n, n), (n,)], {"z": 1, "l": 0, "q": [], "s": []}, [VariableRecovery(slice(0, n), None, (n,))])
+    idx, ptr, shape = tpl.P_structure
+    assert shape == (n, n) and len(idx) == n * (n + 1) // 2 and tpl.P_map.shape == (len(idx), n * n + n + 1)
+    rng = np.random.default_rng(0)
+    Pp, qp = rng.standard_normal((n, n)), rng.standard_normal(n)
+    pvec = np.concatenate([Pp.reshape(-1, order="F"), qp, [1.0]])
+    vals = tpl.P_map @ pvec
+    want = (0.5 * (Pp + Pp.T) + np.eye(n))[idx, np.repeat(np.arange(n), np.diff(ptr))]
+    np.testing.assert_allclose(vals, want, atol=1e-14)
