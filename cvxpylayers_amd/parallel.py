@@ -71,20 +71,22 @@ def allreduce_broadcast_grad(g: torch.Tensor, group=None) -> torch.Tensor:
     return g
 
 
-def sharded_apply(layer_cls, q_eval, A_eval, ctx, solver_args, needs_grad=True, total=None, gather=True, group=None):
+def sharded_apply(layer_cls, q_eval, A_eval, ctx, solver_args, needs_grad=True, total=None, gather=True, group=None, P_eval=None):
     """Solve this rank's slice of a replicated (…, B_total) batch and (optionally) all-gather primal/dual.
 
-    q_eval (n+1, B_total), A_eval (nnz_aug, B_total) replicated on every rank (or pass already-local slices with
-    total=None).  Returns primal (B_total, n), dual (B_total, m) when gather else the local rows."""
+    q_eval (n+1, B_total), A_eval (nnz_aug, B_total) (and P_eval (nnz_p, B_total) for a quadratic objective) replicated on every
+    rank (or pass already-local slices with total=None).  Returns primal (B_total, n), dual (B_total, m) when gather else the
+    local rows."""
     if dist.is_initialized() and total is not None:
         rank, world = dist.get_rank(group), dist.get_world_size(group)
         lo, hi = shard_bounds(total, rank, world)
         q_eval = q_eval[:, lo:hi]
         A_eval = A_eval[:, lo:hi]
+        P_eval = P_eval[:, lo:hi] if P_eval is not None else None
         sizes = [shard_bounds(total, r, world)[1] - shard_bounds(total, r, world)[0] for r in range(world)]
     else:
         sizes = None
-    primal, dual, info, data = layer_cls.apply(None, q_eval, A_eval, ctx, solver_args, needs_grad, None)
+    primal, dual, info, data = layer_cls.apply(P_eval, q_eval, A_eval, ctx, solver_args, needs_grad, None)
     if gather:
         primal = gather_rows(primal, sizes, group)
         dual = gather_rows(dual, sizes, group)

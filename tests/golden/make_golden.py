@@ -30,6 +30,10 @@ CASES = {
     "expcone_logreg_shape": (40, {"z": 0, "l": 12, "q": [4], "s": [], "ep": 24}, 4, 0),
     "powcone_mixed": (8, {"z": 1, "l": 3, "q": [3], "s": [], "ep": 1, "p": [0.3, -0.6, 0.5]}, 8, 3),
 }
+# quadratic-objective cases: name -> (n, cones, B, seed); P = G G^T / n + 0.1 I from the same seed (stored in the fixture)
+QP_CASES = {
+    "qp_mixed": (10, {"z": 2, "l": 6, "q": [4]}, 8, 7),
+}
 ONLY_NEW = "--only-new" in sys.argv      # keep the fixtures already committed byte-identical
 
 
@@ -50,6 +54,20 @@ def main():
                             s=np.asarray(cones.get("s", []), dtype=np.int64), ep=int(cones.get("ep", 0)),
                             p=np.asarray(cones.get("p", []), dtype=np.float64),
                             x=r["x"], y=r["y"], sl=r["s"], dx=dx, dy=dy, dA=g["dA"], db=g["db"], dc=g["dc"])
+        print(name, "iters", r["iters"].max(), "file", name + ".npz")
+    for name, (n, cones, B, seed) in QP_CASES.items():
+        if ONLY_NEW and os.path.exists(os.path.join(here, name + ".npz")):
+            continue
+        A, b, c = P.generate(n, cones, B, seed=seed)
+        rng = np.random.default_rng(seed + 200)
+        G = rng.standard_normal((B, n, n)); Pm = G @ G.transpose(0, 2, 1) / n + 0.1 * np.eye(n)
+        r = oracle.solve_batch(A, b, c, cones, P=Pm, eps=1e-10, max_iters=200000)
+        assert (r["status"] == 1).all(), (name, r["status"])
+        dx = rng.standard_normal(r["x"].shape); dy = rng.standard_normal(r["y"].shape)
+        g = oracle.adjoint_batch(A, b, c, cones, r["x"], r["y"], r["s"], dx, dy, P=Pm, mode="dense")
+        np.savez_compressed(os.path.join(here, name + ".npz"), n=n, B=B, seed=seed, z=cones.get("z", 0), l=cones.get("l", 0),
+                            q=np.asarray(cones.get("q", []), dtype=np.int64), s=np.asarray([], dtype=np.int64), ep=0, p=np.asarray([], dtype=np.float64),
+                            P=Pm, x=r["x"], y=r["y"], sl=r["s"], dx=dx, dy=dy, dA=g["dA"], db=g["db"], dc=g["dc"], dP=g["dP"])
         print(name, "iters", r["iters"].max(), "file", name + ".npz")
 
 

@@ -33,11 +33,14 @@ def relerr(got, want):
 def test_oracle_reproduces_golden(path):
     from oracle import oracle
     d, n, cones, A, b, c = load(path)
-    r = oracle.solve_batch(A, b, c, cones, eps=1e-10, max_iters=200000)
+    Pm = d["P"] if "P" in d.files else None
+    r = oracle.solve_batch(A, b, c, cones, P=Pm, eps=1e-10, max_iters=200000)
     assert (r["status"] == 1).all()
     assert relerr(r["x"], d["x"]) < 1e-9 and relerr(r["y"], d["y"]) < 1e-9 and relerr(r["s"], d["sl"]) < 1e-9
-    g = oracle.adjoint_batch(A, b, c, cones, d["x"], d["y"], d["sl"], d["dx"], d["dy"], mode="dense")
+    g = oracle.adjoint_batch(A, b, c, cones, d["x"], d["y"], d["sl"], d["dx"], d["dy"], P=Pm, mode="dense")
     assert relerr(g["dA"], d["dA"]) < 1e-8 and relerr(g["db"], d["db"]) < 1e-8 and relerr(g["dc"], d["dc"]) < 1e-8
+    if Pm is not None:
+        assert relerr(g["dP"], d["dP"]) < 1e-8
 
 
 @pytest.mark.gpu
@@ -47,19 +50,32 @@ def test_engine_matches_golden(path):
     from cvxpylayers_amd.interfaces.mi355_if import ConeEngine, make_settings
     d, n, cones, A, b, c = load(path)
     tpl = P.dense_template(n, cones)
+    pst = P_bm = None
+    if "P" in d.files:         # quadratic objective: upper-triangle structure, values batch-major
+        rows, ptr = [], [0]
+        for j in range(n):
+            rows.extend(range(j + 1)); ptr.append(len(rows))
+        pst = (np.asarray(rows, dtype=np.int32), np.asarray(ptr, dtype=np.int32))
+        pcols = np.repeat(np.arange(n), np.diff(pst[1]))
+        P_bm = torch.from_numpy(np.ascontiguousarray(d["P"][:, pst[0], pcols])).cuda()
     try:
-        eng = ConeEngine(tpl.indices, tpl.indptr, tpl.n, tpl.m, tpl.cones, torch.device("cuda", 0))
+        eng = ConeEngine(tpl.indices, tpl.indptr, tpl.n, tpl.m, tpl.cones, torch.device("cuda", 0), p_structure=pst)
     except NotImplementedError as e:       # cone type the device path rejects explicitly (CE_E_UNSUPPORTED)
         pytest.skip(str(e))
     A_eval, q_eval = tpl.values_from_dense(A, b, c)
     A_bm = eng.to_batch_major(torch.from_numpy(A_eval).cuda())
-    x, y, s, iters, status, resid = eng.solve(A_bm, torch.from_numpy(q_eval).cuda(), make_settings(dict(eps=1e-10, max_iters=200000)))
+    x, y, s, iters, status, resid = eng.solve(A_bm, torch.from_numpy(q_eval).cuda(), make_settings(dict(eps=1e-10, max_iters=200000)), P_bm=P_bm)
     assert (status.cpu().numpy() == 1).all()
     for got, want in ((x, d["x"]), (y, d["y"]), (s, d["sl"])):
         err = np.abs(got.cpu().numpy() - want).max(axis=1) / (1 + np.abs(want).max(axis=1))
         assert err.max() < 1e-6, err.max()
     xr, yr, sr, dx, dy = (torch.from_numpy(d[k]).cuda() for k in ("x", "y", "sl", "dx", "dy"))
-    dA, dq, adj = eng.vjp(A_bm, xr, yr, sr, dx, dy)
+    if P_bm is not None:
+        dA, dq, adj, dP = eng.vjp(A_bm, xr, yr, sr, dx, dy, P_bm=P_bm)
+        wantP = d["dP"][:, pst[0], pcols] + np.where(pst[0] != pcols, d["dP"][:, pcols, pst[0]], 0.0)
+        assert relerr(dP.cpu().numpy(), wantP) < 1e-5
+    else:
+        dA, dq, adj = eng.vjp(A_bm, xr, yr, sr, dx, dy)
     assert (adj.cpu().numpy() == 0).all()
     dA = dA.cpu().numpy(); dq = dq.cpu().numpy()
     cols = np.repeat(np.arange(n + 1), np.diff(tpl.indptr))
