@@ -512,6 +512,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
                 const double *rowk = sm + (buf ? L::O_S3 : L::O_S1), *colk = sm + (buf ? L::O_S4 : L::O_S2);
                 if (jg < n) {
                     const double pv = rowk[k];
+                    if constexpr (HASP) { if (jg == k && cg == 0 && !(pv > 0)) sc[7] = 1.0; }     // S not positive definite: P is not PSD
                     double pinv = __builtin_amdgcn_rcp(pv);                 // seed + two Newton steps instead of the IEEE divide
                     pinv = fma(fma(-pv, pinv, 1.0), pinv, pinv);            // expansion: it sits on the critical path of every pivot
                     pinv = fma(fma(-pv, pinv, 1.0), pinv, pinv);
@@ -538,6 +539,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
             }
         });
         F2_STAMP(9);
+        if constexpr (HASP) { if (sc[7] != 0.0) return; }      // (uniform: read after the loop's last barrier) -> status FAILED below
         // G to LDS (the panel data in that region is dead), scratch back to zero
         if (jg < n) {
             double2 *dst = reinterpret_cast<double2 *>(Gm + jg * ldg + TG * cg);
@@ -647,6 +649,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
 
     for (bool done = false; !done;) {
     refactor();
+    if constexpr (HASP) { if (sc[7] != 0.0) { status = -4; break; } }     // SCS_FAILED: the factorisation met a non-positive pivot
     F2_STAMP(3);
     if (resume) {   // relaxed update w += alpha (u - ut) owed by the iteration a rescale interrupted
         const int e = Co::thread_id(wave);
@@ -879,8 +882,8 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
     // ---------------------------------------------------------------- write back (un-normalise)
     {
         const bool solved = (status == 1 || status == 2);
-        const bool infeas = (status == -2 || status == -7);
-        const double it = solved ? 1.0 / (sigma * tau) : 1.0 / sigma;
+        const bool infeas = (status == -2 || status == -7 || status == -4);      // (failed: everything NaN)
+        const double it = solved ? 1.0 / (sigma * tau) : (status == -4 ? NAN : 1.0 / sigma);
         for (int j = tid_w; j < n; j += NT) xo[(size_t)inst * n + j] = infeas ? NAN : sm[L::O_EV + j] * sm[L::O_U + OX + j] * it;
         for (int i = tid_w; i < m; i += NT) {
             const double uy = sm[L::O_U + OY + i], di = sm[L::O_DV + i];

@@ -225,3 +225,23 @@ def test_native_qp_kernels_match_the_oracle_on_box_qps():
     pc = np.repeat(np.arange(nx), np.diff(ptr))
     wantP = gr["dP"][:, idx, pc] + np.where(idx != pc, gr["dP"][:, pc, idx], 0.0)        # one stored entry stands for (i,j) and (j,i)
     assert np.abs(dP.cpu().numpy() - wantP).max() < 1e-5 * (1 + np.abs(wantP).max())
+
+
+@pytest.mark.gpu
+def test_indefinite_P_fails_loudly_in_the_native_kernels():
+    from cvxpylayers_amd.interfaces.mi355_if import _CvxpyLayer, SolverError
+    n = 4
+    cones = {"z": 1, "l": 0, "q": [], "s": []}
+    tpl = P.dense_template(n, cones)
+    pst = _upper_structure(n)
+    ctx = MI355_ctx(pst, tpl.problem_data_index, cones, options={"eps": 1e-8})
+    dev = torch.device("cuda", 0)
+    Pm = np.stack([np.eye(n), np.diag([1.0, -1.0, 1.0, 1.0])])          # second instance indefinite
+    A_eval, q_eval = tpl.values_from_dense(np.ones((2, 1, n)), np.ones((2, 1)), np.zeros((2, n)))
+    args = (torch.from_numpy(_p_values(Pm, pst).T.copy()).to(dev), torch.from_numpy(q_eval).to(dev), torch.from_numpy(A_eval).to(dev))
+    with pytest.raises(SolverError, match="Failed"):
+        _CvxpyLayer.apply(*args, ctx, {}, False, None)
+    primal, dual, info, _ = _CvxpyLayer.apply(*args, ctx, {"raise_on_error": False}, False, None)
+    st = info["status"].cpu().numpy()
+    assert st[0] == 1 and st[1] == -4 and bool(torch.isnan(primal[1]).all())
+    np.testing.assert_allclose(primal[0].cpu().numpy(), np.full(n, 1.0 / n), atol=1e-6)       # min 1/2 |x|^2, sum x = 1
