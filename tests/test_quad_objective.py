@@ -245,3 +245,28 @@ def test_indefinite_P_fails_loudly_in_the_native_kernels():
     st = info["status"].cpu().numpy()
     assert st[0] == 1 and st[1] == -4 and bool(torch.isnan(primal[1]).all())
     np.testing.assert_allclose(primal[0].cpu().numpy(), np.full(n, 1.0 / n), atol=1e-6)       # min 1/2 |x|^2, sum x = 1
+
+
+def test_full_symmetric_structure_is_paired_and_asymmetric_structure_has_no_native_route():
+    n = 3
+    cones = {"z": 1, "l": 0, "q": [], "s": []}
+    tpl = P.dense_template(n, cones)
+    full = (np.tile(np.arange(n), n).astype(np.int32), (np.arange(n + 1) * n).astype(np.int32), (n, n))          # dense CSC, both triangles
+    qe = QuadEpigraph(full, (tpl.indices, tpl.indptr), (tpl.m, n + 1), dims_to_solver_dict(cones))
+    assert not qe.one_triangle and qe.sym_perm is not None
+    rows, cols = qe.p_rows, qe.p_cols
+    assert all((rows[qe.sym_perm[k]], cols[qe.sym_perm[k]]) == (cols[k], rows[k]) for k in range(n * n))
+    # values given on both triangles are averaged: P = [[2, 1, 0], [3, 2, 0], [0, 0, 2]] acts as its symmetric part
+    Pm = np.array([[2.0, 1.0, 0.0], [3.0, 2.0, 0.0], [0.0, 0.0, 2.0]])
+    vals = Pm[rows, cols][:, None]
+    q_aug, A_aug = qe.assemble(torch.from_numpy(vals), torch.zeros(n + 1, 1, dtype=torch.float64), torch.zeros(tpl.nnz_aug, 1, dtype=torch.float64))
+    Ls = A_aug[:, 0].numpy()[[k for k, s_ in enumerate(qe.src) if tpl.nnz_aug <= s_ < tpl.nnz_aug + n * (n + 1) // 2]]
+    Lm = np.zeros((n, n)); Lm[qe.tri_j, qe.tri_k] = 0.0
+    order = np.argsort([s_ for s_ in qe.src if tpl.nnz_aug <= s_ < tpl.nnz_aug + n * (n + 1) // 2])
+    Lm[qe.tri_j, qe.tri_k] = Ls[order] / np.sqrt(2.0)
+    np.testing.assert_allclose(Lm @ Lm.T, 0.5 * (Pm + Pm.T), atol=1e-9)
+    lop = (np.array([0, 1, 1], dtype=np.int32), np.array([0, 2, 3, 3], dtype=np.int32), (n, n))    # (0,0), (1,0), (1,1): lower triangle
+    assert QuadEpigraph(lop, (tpl.indices, tpl.indptr), (tpl.m, n + 1), dims_to_solver_dict(cones)).one_triangle
+    asym = (np.array([1, 0], dtype=np.int32), np.array([0, 1, 1, 2], dtype=np.int32), (n, n))      # (1,0) and (0,2): both triangles, no mirrors
+    qa = QuadEpigraph(asym, (tpl.indices, tpl.indptr), (tpl.m, n + 1), dims_to_solver_dict(cones))
+    assert not qa.one_triangle and qa.sym_perm is None          # -> never the in-kernel route; the epigraph form symmetrises densely
