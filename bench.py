@@ -23,7 +23,7 @@ sys.path.insert(0, ROOT)
 
 from cvxpylayers_amd import problems as P  # noqa: E402
 from cvxpylayers_amd.interfaces.mi355_if import MI355_ctx, _CvxpyLayer  # noqa: E402
-from cvxpylayers_amd.parallel import gather_rows  # noqa: E402
+from cvxpylayers_amd.parallel import gather_solution  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
 FP64_VALU_PEAK_TF = 78.6     # half the 157.3 TF fp32 vector peak
@@ -104,8 +104,7 @@ def main():
         q_t.grad = None
         primal, dual, info, _ = _CvxpyLayer.apply(None, q_t, A_t, ctx, {}, True, None)
         if world > 1:
-            primal = gather_rows(primal)
-            dual = gather_rows(dual)
+            primal, dual = gather_solution(primal, dual)      # one fused RCCL all-gather per step
         primal.sum().backward()
         return info
 

@@ -64,6 +64,17 @@ def gather_rows(x: torch.Tensor, sizes=None, group=None) -> torch.Tensor:
     return _AllGatherRows.apply(x, list(sizes), group)
 
 
+def gather_solution(primal: torch.Tensor, dual: torch.Tensor, sizes=None, group=None):
+    """primal (b, n) and dual (b, m) of every rank in ONE collective: the rows are fused into a (b, n + m) buffer, all-gathered
+    once (the messages are latency-bound: 600 KB per rank at the metric configuration) and split again.
+    Differentiable like gather_rows."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return primal, dual
+    n = primal.shape[1]
+    both = gather_rows(torch.cat([primal, dual], dim=1), sizes, group)
+    return both[:, :n], both[:, n:]
+
+
 def allreduce_broadcast_grad(g: torch.Tensor, group=None) -> torch.Tensor:
     """Sum a broadcast-parameter gradient over ranks (each rank holds the sum over its shard)."""
     if dist.is_initialized() and dist.get_world_size(group) > 1:
@@ -88,6 +99,5 @@ def sharded_apply(layer_cls, q_eval, A_eval, ctx, solver_args, needs_grad=True, 
         sizes = None
     primal, dual, info, data = layer_cls.apply(P_eval, q_eval, A_eval, ctx, solver_args, needs_grad, None)
     if gather:
-        primal = gather_rows(primal, sizes, group)
-        dual = gather_rows(dual, sizes, group)
+        primal, dual = gather_solution(primal, dual, sizes, group)
     return primal, dual, info
