@@ -64,3 +64,28 @@ def test_plugin_refuses_cpu_only_host():
     ctx = MI355_ctx(None, tpl.problem_data_index, tpl.cones)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         _CvxpyLayer.apply(None, torch.zeros(4, 2, dtype=torch.double), torch.zeros(tpl.nnz_aug, 2, dtype=torch.double), ctx, {}, False, None)
+
+
+def test_solver_args_map_to_ce_settings_like_diffcp_maps_them_to_scs():
+    """diffcp maps `eps` to eps_abs and eps_rel; SCS option names pass through; options that only steer diffcp's CPU execution are
+    accepted and ignored; anything unknown is an error (a typo must not silently run with defaults)."""
+    from cvxpylayers_amd.interfaces.mi355_if import make_settings
+    s = make_settings({"eps": 1e-7, "max_iters": 123, "alpha": 1.2, "scale": 0.5, "normalize": False, "adaptive_scale": 0,
+                       "acceleration_lookback": 10, "n_jobs_forward": 4, "mode": "lsqr", "verbose": True})
+    assert s.eps_abs == 1e-7 and s.eps_rel == 1e-7 and s.max_iters == 123 and s.alpha == 1.2 and s.scale == 0.5
+    assert s.normalize == 0 and s.adaptive_scale == 0 and s.warm_start == 0
+    s2 = make_settings({"eps_abs": 1e-5, "eps_rel": 1e-3})
+    assert s2.eps_abs == 1e-5 and s2.eps_rel == 1e-3
+    with pytest.raises(ValueError, match="unknown solver_args"):
+        make_settings({"epsilon": 1e-3})
+
+
+def test_cone_dims_objects_and_dicts_give_the_same_solver_dict():
+    """cone_dims arrives as CVXPY's ConeDims (attrs zero / nonneg / soc / exp / psd / p3d) or as an SCS-style dict (keys z or f, l, q, ep, s, p)"""
+    from types import SimpleNamespace
+    from cvxpylayers_amd.interfaces.mi355_if import dims_to_solver_dict
+    obj = SimpleNamespace(zero=2, nonneg=3, soc=[4, 5], exp=1, psd=[3], p3d=[0.5])
+    want = {"z": 2, "l": 3, "q": [4, 5], "ep": 1, "s": [3], "p": [0.5]}
+    assert dims_to_solver_dict(obj) == want
+    assert dims_to_solver_dict({"f": 2, "l": 3, "q": [4, 5], "ep": 1, "s": [3], "p": [0.5]}) == want
+    assert dims_to_solver_dict({"z": 1}) == {"z": 1, "l": 0, "q": [], "ep": 0, "s": [], "p": []}
