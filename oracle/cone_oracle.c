@@ -56,6 +56,8 @@ typedef struct {
     double lsqr_atol, lsqr_btol, lsqr_conlim;
     int lsqr_iter_lim;     /* <=0: 2*N */
     int warm_start;        /* != 0: x, y, s hold an initial point on entry (SCS warm start u = (x, y, 1), v = (0, s, 0)) */
+    int aa_mem;            /* Anderson acceleration memory (SCS acceleration_lookback; 0 = off) */
+    int aa_interval;       /* applied every aa_interval iterations (SCS acceleration_interval, default 10) */
 } oc_opts;
 
 enum { OC_SOLVED = 1, OC_SOLVED_INACCURATE = 2, OC_UNBOUNDED = -1, OC_INFEASIBLE = -2,
@@ -76,7 +78,7 @@ void oc_default_opts(oc_opts *o) {
     o->eps_abs = 1e-4; o->eps_rel = 1e-4; o->eps_infeas = 1e-7; o->alpha = 1.5;
     o->rho_x = 1e-6; o->scale = 0.1; o->max_iters = 100000; o->normalize = 1;
     o->adaptive_scale = 1; o->adj_mode = 0; o->lsqr_atol = 1e-8; o->lsqr_btol = 1e-8;
-    o->lsqr_conlim = 1e8; o->lsqr_iter_lim = -1; o->warm_start = 0;
+    o->lsqr_conlim = 1e8; o->lsqr_iter_lim = -1; o->warm_start = 0; o->aa_mem = 0; o->aa_interval = 10;
 }
 
 static int cone_rows(const oc_cones *k) {
@@ -452,11 +454,64 @@ static int solve_one(int n, int m, const double *A0, const double *b0, const dou
     }
     int status = 0, iter, last_scale_iter = 0, n_rescale = 0; double sum_log = 0; int n_log = 0;
     double res_pri = NAN, res_dual = NAN, gap = NAN, pobj = NAN, dobj = NAN;
+    /* ---- Anderson acceleration of the fixed-point map w -> F(w) (type I, as in SCS 3: Zhang, O'Donoghue, Boyd, "Globally
+     * convergent type-I Anderson acceleration for nonsmooth fixed-point iterations"): every aa_interval iterations the pair
+     * (x = input of the last iteration, f = its output) extends the secant history S = [dx], Y = [dg], D = [df], g = x - f;
+     * gamma = (S^T Y + r I)^-1 S^T g, r = 1e-8 |S|_F |Y|_F, and the iterate is replaced by f - D gamma.  Safeguard: if the residual
+     * of the map at the accelerated point exceeds the residual before, the step is undone and the history dropped.  The history
+     * is also dropped on a rescale (the map changes) and scaled with w when w is renormalised (the map is homogeneous). */
+    const int aa_mem = o->aa_mem > 0 ? o->aa_mem : 0, aa_int = o->aa_interval > 0 ? o->aa_interval : 10;
+    double *aab = aa_mem > 0 ? calloc((size_t)(3 * aa_mem + 7) * l + (size_t)aa_mem * (aa_mem + 2), sizeof(double)) : NULL;
+    double *aS = aab, *aY = aS ? aS + (size_t)aa_mem * l : NULL, *aD = aS ? aY + (size_t)aa_mem * l : NULL;
+    double *aXp = aS ? aD + (size_t)aa_mem * l : NULL, *aFp = aS ? aXp + l : NULL, *aGp = aS ? aFp + l : NULL, *wprev = aS ? aGp + l : NULL,
+           *aFsave = aS ? wprev + l : NULL, *aXsave = aS ? aFsave + l : NULL, *aG = aS ? aXsave + l : NULL, *aM = aS ? aG + l : NULL;
+    int aa_iter = 0, aa_pending = 0; double aa_normg = 0;
     for (iter = 0; iter < o->max_iters; iter++) {
         int check = (iter % CONVERGED_INTERVAL) == 0;
-        if (check && iter > 0) { /* keep the homogeneous iterate in range (iteration map is positively homogeneous) */
-            double nw = norm2(w, l); if (nw > 0) { double f = sqrt((double)l) / nw; for (int i = 0; i < l; i++) w[i] *= f; }
+        if (aa_mem > 0 && aa_pending) {      /* safeguard: residual of the map at the accelerated point */
+            double dn = 0; for (int i = 0; i < l; i++) { double d = wprev[i] - w[i]; dn += d * d; } dn = sqrt(dn);
+            if (!(dn <= aa_normg)) { memcpy(w, aFsave, sizeof(double) * l); memcpy(wprev, aXsave, sizeof(double) * l); aa_iter = 0; }
+            aa_pending = 0;
         }
+        if (aa_mem > 0 && iter > 0 && iter % aa_int == 0) {
+            for (int i = 0; i < l; i++) aG[i] = wprev[i] - w[i];          /* x = wprev, f = w */
+            if (aa_iter > 0) {
+                int idx = (aa_iter - 1) % aa_mem;
+                for (int i = 0; i < l; i++) { aS[(size_t)idx * l + i] = wprev[i] - aXp[i]; aY[(size_t)idx * l + i] = aG[i] - aGp[i]; aD[(size_t)idx * l + i] = w[i] - aFp[i]; }
+            }
+            memcpy(aXp, wprev, sizeof(double) * l); memcpy(aFp, w, sizeof(double) * l); memcpy(aGp, aG, sizeof(double) * l);
+            if (aa_iter > 0) {
+                int len = aa_iter < aa_mem ? aa_iter : aa_mem;
+                double *M = aM, *rhs = aM + (size_t)aa_mem * aa_mem, *gam = rhs + aa_mem;
+                double ns = 0, ny = 0;
+                for (int a = 0; a < len; a++) { ns += dot(aS + (size_t)a * l, aS + (size_t)a * l, l); ny += dot(aY + (size_t)a * l, aY + (size_t)a * l, l); }
+                for (int a = 0; a < len; a++) { for (int b2 = 0; b2 < len; b2++) M[a * len + b2] = dot(aS + (size_t)a * l, aY + (size_t)b2 * l, l); rhs[a] = dot(aS + (size_t)a * l, aG, l); }
+                double reg = 1e-8 * sqrt(ns) * sqrt(ny);
+                for (int a = 0; a < len; a++) M[a * len + a] += reg;
+                int ok = 1;
+                for (int c2 = 0; c2 < len && ok; c2++) {      /* Gaussian elimination, partial pivoting */
+                    int pv = c2; for (int r = c2 + 1; r < len; r++) if (fabs(M[r * len + c2]) > fabs(M[pv * len + c2])) pv = r;
+                    if (!(fabs(M[pv * len + c2]) > 1e-300)) { ok = 0; break; }
+                    if (pv != c2) { for (int j = 0; j < len; j++) { double t = M[c2 * len + j]; M[c2 * len + j] = M[pv * len + j]; M[pv * len + j] = t; } double t = rhs[c2]; rhs[c2] = rhs[pv]; rhs[pv] = t; }
+                    for (int r = c2 + 1; r < len; r++) { double f = M[r * len + c2] / M[c2 * len + c2]; for (int j = c2; j < len; j++) M[r * len + j] -= f * M[c2 * len + j]; rhs[r] -= f * rhs[c2]; }
+                }
+                double gn = 0;
+                if (ok) for (int r = len - 1; r >= 0; r--) { double v = rhs[r]; for (int j = r + 1; j < len; j++) v -= M[r * len + j] * gam[j]; gam[r] = v / M[r * len + r]; gn += gam[r] * gam[r]; }
+                if (!ok || !(sqrt(gn) < 1e10)) aa_iter = 0;
+                else {
+                    memcpy(aFsave, w, sizeof(double) * l); memcpy(aXsave, wprev, sizeof(double) * l);
+                    aa_normg = norm2(aG, l);
+                    for (int a = 0; a < len; a++) for (int i = 0; i < l; i++) w[i] -= gam[a] * aD[(size_t)a * l + i];
+                    aa_pending = 1;
+                }
+            }
+            aa_iter++;
+        }
+        if (check && iter > 0) { /* keep the homogeneous iterate in range (iteration map is positively homogeneous) */
+            double nw = norm2(w, l); if (nw > 0) { double f = sqrt((double)l) / nw; for (int i = 0; i < l; i++) w[i] *= f;
+                if (aa_mem > 0) { for (size_t i = 0; i < (size_t)(3 * aa_mem + 7) * l; i++) aab[i] *= f; aa_normg *= f; } }
+        }
+        if (aa_mem > 0) memcpy(wprev, w, sizeof(double) * l);
         /* (1) linear-system step: p = (R_z+M_zz)^{-1} R_z w_z : kkt rhs (rho_x w_x, -r_y w_y) */
         for (int j = 0; j < n; j++) t1[j] = rho_x * w[j];
         for (int i = 0; i < m; i++) t2[i] = -ry[i] * w[n + i];
@@ -514,7 +569,7 @@ static int solve_one(int n, int m, const double *A0, const double *b0, const dou
                     if (iter - last_scale_iter >= RESCALING_MIN_ITERS) {
                         double ns2 = fmin(fmax(scale * factor, MIN_SCALE_VALUE), MAX_SCALE_VALUE);
                         if (ns2 != scale && (factor > sqrt(10.0) || factor < 1.0 / sqrt(10.0))) {
-                            sum_log = 0; n_log = 0; last_scale_iter = iter; scale = ns2; n_rescale++;
+                            sum_log = 0; n_log = 0; last_scale_iter = iter; scale = ns2; n_rescale++; aa_iter = 0; aa_pending = 0;
                             set_ry(ry, m, K, scale);
                             if (factor_kkt(A, Pm, ry, rho_x, m, n, L)) { status = OC_FAILED; break; }
                             for (int i = 0; i < m; i++) t1[i] = -b[i];
@@ -548,6 +603,7 @@ static int solve_one(int n, int m, const double *A0, const double *b0, const dou
         for (int j = 0; j < n; j++) xo[j] = E[j] * u[j] / sigma;
         for (int i = 0; i < m; i++) { yo[i] = NAN; so[i] = rsk[n + i] / (D[i] * sigma); }
     }
+    free(aab);
     info->iters = iter; info->status = status; info->pobj = pobj; info->dobj = dobj; info->res_pri = res_pri;
     info->res_dual = res_dual; info->gap = gap; info->scale = scale; info->n_rescale = n_rescale;
     free(buf);

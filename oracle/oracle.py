@@ -23,7 +23,8 @@ class Opts(C.Structure):
                 ("alpha", C.c_double), ("rho_x", C.c_double), ("scale", C.c_double),
                 ("max_iters", C.c_int), ("normalize", C.c_int), ("adaptive_scale", C.c_int),
                 ("adj_mode", C.c_int), ("lsqr_atol", C.c_double), ("lsqr_btol", C.c_double),
-                ("lsqr_conlim", C.c_double), ("lsqr_iter_lim", C.c_int), ("warm_start", C.c_int)]
+                ("lsqr_conlim", C.c_double), ("lsqr_iter_lim", C.c_int), ("warm_start", C.c_int),
+                ("aa_mem", C.c_int), ("aa_interval", C.c_int)]
 
 
 def build(force: bool = False) -> str:
@@ -55,7 +56,10 @@ def make_opts(**kw) -> Opts:
     mode = kw.pop("mode", None)
     if mode is not None:
         o.adj_mode = {"lsqr": 0, "dense": 1}[mode]
-    kw.pop("acceleration_lookback", None)  # Anderson acceleration is not restated (off on both sides)
+    if "acceleration_lookback" in kw:       # SCS names: lookback = memory (0 = off, the default here), interval
+        o.aa_mem = int(kw.pop("acceleration_lookback"))
+    if "acceleration_interval" in kw:
+        o.aa_interval = int(kw.pop("acceleration_interval"))
     kw.pop("verbose", None)
     for k, v in kw.items():
         if not hasattr(o, k):

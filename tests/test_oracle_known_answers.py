@@ -298,3 +298,16 @@ def test_qp_adjoint_matches_finite_differences_including_dP():
     Ap = A.copy(); Ap[0, 3, 2] += h; Am = A.copy(); Am[0, 3, 2] -= h
     fd = (f(Ap, b, c, Pm) - f(Am, b, c, Pm)) / (2 * h)
     assert abs(fd - g["dA"][0, 3, 2]) < 2e-5 * (1 + abs(fd))
+
+
+def test_anderson_acceleration_reaches_the_same_solution_in_fewer_iterations():
+    # type-I Anderson acceleration of the iteration map (SCS acceleration_lookback / acceleration_interval), off by default
+    from cvxpylayers_amd import problems as P
+    cfg = P.CONFIGS["M"]
+    A, b, c = P.generate(cfg["n"], cfg["cones"], 32, seed=0)
+    plain = oracle.solve_batch(A, b, c, cfg["cones"], eps=1e-9, max_iters=20000)
+    for mem in (1, 5):
+        acc = oracle.solve_batch(A, b, c, cfg["cones"], eps=1e-9, max_iters=20000, acceleration_lookback=mem)
+        assert (acc["status"] == 1).all()
+        np.testing.assert_allclose(acc["x"], plain["x"], atol=1e-6)
+        assert acc["iters"].mean() < plain["iters"].mean()
