@@ -77,6 +77,9 @@ def main():
     ap.add_argument("--eps", type=float, default=1e-4, help="eps_abs=eps_rel (SCS default 1e-4)")
     ap.add_argument("--cpu-sample", type=int, default=4096)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--accel", type=int, default=1,
+                    help="acceleration_lookback: > 0 (default) = type-I Anderson acceleration, one-pair history, every 10 iterations -- SCS's "
+                         "default is acceleration on (lookback 10); 0 = plain iteration.  The CPU baseline runs with the same setting.")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -91,7 +94,7 @@ def main():
     cfg = P.CONFIGS[args.config]
     n, cones, B = cfg["n"], cfg["cones"], args.batch
     tpl = P.dense_template(n, cones)
-    solver_args = {"eps": args.eps, "max_iters": 10000, "acceleration_lookback": 0}
+    solver_args = {"eps": args.eps, "max_iters": 10000, "acceleration_lookback": args.accel}
     A, b, c = P.generate(n, cones, B, seed=rank)
     A_eval, q_eval = tpl.values_from_dense(A, b, c)
     ctx = MI355_ctx(None, tpl.problem_data_index, cones, options=solver_args)
@@ -150,8 +153,10 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"config {args.config}: n={n} m={m} cones l={cones.get('l', 0)} q={cones.get('q', [])} dense A "
                                    f"(nnzA={nnzA}), A,b,c batched, B={B} per GPU, eps_abs=eps_rel={args.eps}, max_iters=10000, "
-                                   "acceleration off; step = plugin forward (layout pass + solve + status) + backward (adjoint VJP of sum(x))",
-                       "batch_per_gpu": B, "parallelism": f"batch-shard x{world}"},
+                                   + ("Anderson acceleration type I, memory 1, interval 10 (both sides)" if args.accel > 0 else "acceleration off")
+                                   + "; step = plugin forward (layout pass + solve + status) + backward (adjoint VJP of sum(x))",
+                       "batch_per_gpu": B, "parallelism": f"batch-shard x{world}", "acceleration_lookback": int(args.accel > 0),
+                       "solved_fraction": float((info["status"] == 1).float().mean().item()), "mean_iters": float(iters.mean())},
             "roofline": {"bound": "hbm", "kernel": "forward (k_fwd2 / k_forward_rt / k_forward): the longest kernel of the step", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": fwd_bytes * B,

@@ -27,7 +27,8 @@ class CeTemplate(C.Structure):
 class CeSettings(C.Structure):
     _fields_ = [("eps_abs", C.c_double), ("eps_rel", C.c_double), ("eps_infeas", C.c_double), ("alpha", C.c_double),
                 ("rho_x", C.c_double), ("scale", C.c_double), ("max_iters", C.c_int), ("normalize", C.c_int),
-                ("adaptive_scale", C.c_int), ("warm_start", C.c_int)]
+                ("adaptive_scale", C.c_int), ("warm_start", C.c_int),
+                ("acceleration_lookback", C.c_int), ("acceleration_interval", C.c_int)]
 
 
 def build(force: bool = False) -> str:

@@ -620,6 +620,15 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
     __syncthreads();
 
     int status = 0, iter = 0, last_scale_iter = 0, n_log = 0;
+    // Anderson acceleration of the iteration map w -> F(w) (type I, one secant pair; oracle/cone_oracle.c with aa_mem = 1):
+    // every aa_int iterations, with x = input and f = output of the last iteration, g = x - f, s = x - x_prev, y = g - g_prev,
+    // d = f - f_prev:  w <- f - (s.g / (s.y + 1e-8 |s||y|)) d.   The next iteration's residual is the safeguard: if it exceeds |g| the
+    // step is undone and the history dropped.  Vectors (VP doubles each) live in the dynamic tail of the LDS carve.
+    const bool aa_on = S.acceleration_lookback > 0;
+    const int aa_int = S.acceleration_interval;
+    double *const aaWP = Gm + n * ldg + (PSD ? ((T.ns > 0 ? 2 * T.maxs * T.maxs + 2 * T.maxs + 8 : 0) + T.nep + T.np) : 0) + (HASP ? NP : 0);
+    double *const aaXP = aaWP + VP, *const aaFP = aaXP + VP, *const aaFS = aaFP + VP, *const aaXS = aaFS + VP;
+    int aa_iter = 0; bool aa_pending = false;      // (|g| before the step lives in sc[8]: no register across the loop)
     const bool big_soc = T.maxq > SOC_SMALL;
     bool resume = false;     // true: the iteration interrupted by a rescale still owes its relaxed update
 
@@ -667,14 +676,52 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
         const bool ev = e < l;
         const bool check = (iter % CONVERGED_INTERVAL) == 0;
         const bool last = iter + 1 >= S.max_iters;
+        if (aa_on) {      // (uniform)
+            if (aa_pending) {      // safeguard: residual of the map at the accelerated point against the residual before the step
+                const double dd = ev ? aaWP[ve] - sm[L::O_W + ve] : 0.0;
+                double r[1] = {dd * dd};
+                block_reduce_n<1, NW>(r, 0u, red);
+                if (!(uniform_d(sqrt(r[0])) <= sc[8])) {
+                    if (ev) { sm[L::O_W + ve] = aaFS[ve]; aaWP[ve] = aaXS[ve]; }
+                    aa_iter = 0;
+                    __syncthreads();
+                }
+                aa_pending = false;
+            }
+            if (iter > 0 && iter % aa_int == 0) {
+                const double xv = ev ? aaWP[ve] : 0.0, fv = ev ? sm[L::O_W + ve] : 0.0, gv = xv - fv;
+                if (aa_iter > 0) {
+                    const double xp = ev ? aaXP[ve] : 0.0, fp = ev ? aaFP[ve] : 0.0;
+                    const double sv = xv - xp, yv = gv - (xp - fp), dv = fv - fp;
+                    double r[5] = {sv * sv, yv * yv, sv * yv, sv * gv, gv * gv};
+                    block_reduce_n<5, NW>(r, 0u, red);
+                    const double mm = uniform_d(r[2] + 1e-8 * sqrt(r[0]) * sqrt(r[1]));
+                    const double gam = uniform_d(r[3] / mm);
+                    if (ev) { aaXP[ve] = xv; aaFP[ve] = fv; }
+                    if (fabs(mm) > 1e-300 && fabs(gam) < 1e10) {
+                        if (ev) { aaFS[ve] = fv; aaXS[ve] = xv; sm[L::O_W + ve] = fv - gam * dv; }
+                        if (threadIdx.x == 0) sc[8] = sqrt(r[4]);
+                        aa_pending = true;
+                    } else aa_iter = 0;
+                } else if (ev) { aaXP[ve] = xv; aaFP[ve] = fv; }
+                aa_iter++;
+                __syncthreads();
+            }
+        }
         if (check && iter > 0) {   // keep the homogeneous iterate in range
             const double we = ev ? sm[L::O_W + ve] : 0.0;
             double r[1] = {we * we};
             block_reduce_n<1, NW>(r, 0u, red);
             const double nw = uniform_d(sqrt(r[0]));
-            if (nw > 0 && ev) sm[L::O_W + ve] = we * (sqrt((double)l) / nw);
+            if (nw > 0 && ev) {
+                const double fsc = sqrt((double)l) / nw;
+                sm[L::O_W + ve] = we * fsc;
+                if (aa_on) { aaXP[ve] *= fsc; aaFP[ve] *= fsc; aaFS[ve] *= fsc; aaXS[ve] *= fsc; }     // the map is positively homogeneous
+            }
+            if (aa_on && nw > 0 && threadIdx.x == 0) sc[8] *= sqrt((double)l) / nw;
             __syncthreads();
         }
+        if (aa_on && ev) aaWP[ve] = sm[L::O_W + ve];      // input of this iteration (read again at the top of the next one, after barriers)
         // P1a: t = rho_x w_x - A^T w_y   (+ phi . w from the two spare column groups)
         {
             const double *wvec = sm + L::O_W + ((j1 == n + 1 && T1 * c1 < n) ? OX : OY) + T1 * c1;
@@ -846,7 +893,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
                                 const double d0 = ue + sm[L::O_W + ve] - 2 * ute;
                                 sm[L::O_W + ve] = d0 * dy_ratio + 2 * ute - ue;
                             }
-                            n_log = 0; last_scale_iter = iter; scale = uniform_d(ns2);
+                            n_log = 0; last_scale_iter = iter; scale = uniform_d(ns2); aa_iter = 0; aa_pending = false;
                             __syncthreads();
                             sc[SC_SUMLOG] = 0.0;
                             rescale = true;

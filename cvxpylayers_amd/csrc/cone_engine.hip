@@ -64,6 +64,7 @@ struct ce_engine {
     int brt_variant = -1;                          // register-tiled backward kernel variant (-1: generic kernel)
     // quadratic objective
     int nnz_p = 0, p_tri = 0; bool qp_native = false;
+    bool aa_ok = false;                            // the forward launch carries the LDS for the Anderson-acceleration vectors
     std::vector<int> p_rows, p_cols;               // host copy of the P structure (entry -> (row, col))
     int *d_idx_p = nullptr, *d_pmap = nullptr, *d_prow = nullptr, *d_pcol = nullptr;
     // profiling
@@ -180,7 +181,7 @@ const char *ce_last_error(void) { return g_err.c_str(); }
 
 void ce_default_settings(ce_settings *s) {
     s->eps_abs = 1e-4; s->eps_rel = 1e-4; s->eps_infeas = 1e-7; s->alpha = 1.5; s->rho_x = 1e-6; s->scale = 0.1;
-    s->max_iters = 100000; s->normalize = 1; s->adaptive_scale = 1; s->warm_start = 0;
+    s->max_iters = 100000; s->normalize = 1; s->adaptive_scale = 1; s->warm_start = 0; s->acceleration_lookback = 0; s->acceleration_interval = 10;
 }
 
 int ce_create(const ce_template *tpl, int device, ce_handle *out) {
@@ -276,6 +277,11 @@ int ce_create(const ce_template *tpl, int device, ce_handle *out) {
             HIPCHK(hipMemcpy(h->d_idx_ar, iar.data(), sizeof(int) * iar.size(), hipMemcpyHostToDevice));
             HIPCHK(hipMemcpy(h->d_idx_b, ib.data(), sizeof(int) * T.m, hipMemcpyHostToDevice));
             h->f2_variant = v; h->f2_ldg = ldg; h->fwd_lds = by; h->fwd_mode = 4;
+            {   // five more vectors (w_prev, x_prev, f_prev, f_save, x_save) when they fit: Anderson acceleration available
+                const F2Dims dd = f2_dims(v);
+                const size_t by_aa = by + 5 * (size_t)dd.VP * 8;
+                if (by_aa <= LDS_LIMIT) { h->fwd_lds = by_aa; h->aa_ok = true; }
+            }
             if (has_p) {      // gather map of the (jg, cg) tile layout and the dense n x n entry map
                 const int CHG = V[4], TG = V[5];
                 std::vector<int> pmap((size_t)T.n * T.n, -1), ip((size_t)TG * NTH, -1);
@@ -393,6 +399,8 @@ int ce_solve_qp(ce_handle h, int B, const double *A_vals, long sA_k, long sA_b, 
     if (h->T.nep + h->T.np > 0 && h->fwd_mode != 4) { g_err = "exponential / power cones: the template does not fit the LDS-resident forward kernel (n <= 98, m <= 120 this round)"; return CE_E_UNSUPPORTED; }
     if (h->T.ns > 0 && h->fwd_mode != 4) { g_err = "PSD cones: per-instance A does not fit the LDS-resident forward kernel (n <= 98, m <= 120 this round); only batch-invariant A is supported at this size (constant-A path)"; return CE_E_UNSUPPORTED; }
     ce_settings S; if (settings) S = *settings; else ce_default_settings(&S);
+    if (!(h->fwd_mode == 4 && h->aa_ok)) S.acceleration_lookback = 0;       // only k_fwd2 implements it (and only when its vectors fit LDS)
+    if (S.acceleration_interval <= 0) S.acceleration_interval = 10;
     const double *Abm = nullptr;
     int rc = to_batch_major(h, B, A_vals, sA_k, sA_b, st, &Abm);
     if (rc) return rc;

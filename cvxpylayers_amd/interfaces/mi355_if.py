@@ -66,10 +66,12 @@ def make_settings(merged_args: dict) -> _lib.CeSettings:
     for k in ("max_iters", "normalize", "adaptive_scale"):
         if k in a:
             setattr(s, k, int(a[k]))
-    if a.get("acceleration_lookback", 0) not in (0, None):
-        # Anderson acceleration is not implemented on the device path; the iteration converges to the same
-        # optimum without it (README.md:233-236 recommends acceleration_lookback=0 for robustness).
-        pass
+    # Anderson acceleration (SCS acceleration_lookback / acceleration_interval): off unless asked for; the second-generation
+    # forward kernel keeps a one-pair history whatever the lookback, other paths iterate without it.
+    if a.get("acceleration_lookback") not in (0, None):
+        s.acceleration_lookback = int(a["acceleration_lookback"])
+    if a.get("acceleration_interval") not in (0, None):
+        s.acceleration_interval = int(a["acceleration_interval"])
     return s
 
 

@@ -77,6 +77,10 @@ typedef struct {
     int warm_start;       /* != 0: x, y, s hold an initial primal / dual / slack point on entry (SCS warm start: u = (x, y, 1), v = (0, s, 0));
                              instances whose point is not finite start cold.  The reference's DIFFCP plugin exposes this as
                              diffcp's `warm_starts` solve argument; MOREAU as `warm_start` (torch/cvxpylayer.py:464-487) */
+    int acceleration_lookback;   /* SCS name.  0 (default here): plain iteration.  > 0: type-I Anderson acceleration of the iteration map
+                                    with a one-pair secant history (the engine keeps memory 1 whatever the value; honoured by the
+                                    second-generation forward kernel, ignored elsewhere) */
+    int acceleration_interval;   /* applied every this many iterations (SCS default 10) */
 } ce_settings;
 
 void ce_default_settings(ce_settings *s);

@@ -392,3 +392,29 @@ def test_constant_A_path_with_exp_and_power_cones(monkeypatch):
     dA, dq, adj = eng.vjp(A_bm, xr, yr, sr, torch.from_numpy(dx).cuda(), torch.from_numpy(dy).cuda())
     assert (adj.cpu().numpy() == 0).all()
     assert np.abs(dq.cpu().numpy()[:n] - g["dc"].T).max() < 1e-5 * (1 + np.abs(g["dc"]).max())
+
+
+def test_anderson_acceleration_matches_the_oracle_with_memory_one():
+    """acceleration_lookback > 0: k_fwd2 applies type-I Anderson acceleration with a one-pair history every acceleration_interval
+    iterations; the oracle with aa_mem = 1 is the same algorithm (iteration counts within one check interval, same solutions,
+    fewer iterations than the plain iteration)."""
+    from oracle import oracle
+    from cvxpylayers_amd.interfaces.mi355_if import make_settings
+    cfg = P.CONFIGS["M"]; n, cones, B = cfg["n"], cfg["cones"], 64
+    tpl = P.dense_template(n, cones)
+    A, b, c = P.generate(n, cones, B, seed=0)
+    eng = _engine_for(tpl)
+    A_eval, q_eval = tpl.values_from_dense(A, b, c)
+    A_bm = eng.to_batch_major(torch.from_numpy(A_eval).cuda()); q_t = torch.from_numpy(q_eval).cuda()
+    for eps in (1e-4, 1e-8):
+        ref = oracle.solve_batch(A, b, c, cones, eps=eps, max_iters=20000, acceleration_lookback=1)
+        plain = oracle.solve_batch(A, b, c, cones, eps=eps, max_iters=20000)
+        x, y, s, iters, status, resid = eng.solve(A_bm, q_t, make_settings(dict(eps=eps, max_iters=20000, acceleration_lookback=1)))
+        assert (status.cpu().numpy() == 1).all() and (ref["status"] == 1).all()
+        tol = max(1e-6, 20 * eps)
+        for got, want in ((x, ref["x"]), (y, ref["y"]), (s, ref["s"])):
+            err = np.abs(got.cpu().numpy() - want).max(axis=1) / (1 + np.abs(want).max(axis=1))
+            assert err.max() < tol, err.max()
+        it = iters.cpu().numpy()
+        assert np.mean(np.abs(it - ref["iters"]) <= 25) > 0.9, (it, ref["iters"])       # a borderline safeguard decision may shift an instance
+        assert it.mean() < plain["iters"].mean()
