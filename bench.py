@@ -77,9 +77,10 @@ def main():
     ap.add_argument("--eps", type=float, default=1e-4, help="eps_abs=eps_rel (SCS default 1e-4)")
     ap.add_argument("--cpu-sample", type=int, default=4096)
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--accel", type=int, default=1,
-                    help="acceleration_lookback: > 0 (default) = type-I Anderson acceleration, one-pair history, every 10 iterations -- SCS's "
-                         "default is acceleration on (lookback 10); 0 = plain iteration.  The CPU baseline runs with the same setting.")
+    ap.add_argument("--accel", type=int, default=0,
+                    help="acceleration_lookback: 0 (default, the configuration the committed rocprofv3 summaries were taken with) = plain "
+                         "iteration; > 0 = type-I Anderson acceleration, one-pair history, every 10 iterations (SCS's own default is "
+                         "acceleration on).  The CPU baseline runs with the same setting.")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
