@@ -16,6 +16,10 @@ echo "== bench" | tee -a "$OUT/summary.txt"
 timeout 300 python bench.py 2>"$OUT/bench.err" | tee "$OUT/bench.json" | cut -c1-600 | tee -a "$OUT/summary.txt"
 echo "== bench eps=1e-8" | tee -a "$OUT/summary.txt"
 timeout 300 python bench.py --eps 1e-8 --no-cpu 2>>"$OUT/bench.err" | tee "$OUT/bench_eps8.json" | cut -c1-300 | tee -a "$OUT/summary.txt"
+echo "== bench --accel 1 (Anderson acceleration on both sides)" | tee -a "$OUT/summary.txt"
+timeout 300 python bench.py --accel 1 2>>"$OUT/bench.err" | tee "$OUT/bench_accel1.json" | cut -c1-300 | tee -a "$OUT/summary.txt"
+(cd /tmp && timeout 240 rocprofv3 --kernel-trace --stats -d "$OUT/prof_accel1" -o trace --output-format csv -- python "$OLDPWD/bench.py" --no-cpu --accel 1 > "$OUT/prof_accel1.log" 2>&1)
+find "$OUT/prof_accel1" -name "*kernel_stats.csv" | head -1 | xargs -r head -4 | tee -a "$OUT/summary.txt"
 echo "== rocprofv3 kernel-trace stats" | tee -a "$OUT/summary.txt"
 (cd /tmp && timeout 240 rocprofv3 --kernel-trace --stats -d "$OUT/prof" -o trace --output-format csv -- python "$OLDPWD/bench.py" --no-cpu > "$OUT/prof.log" 2>&1)
 find "$OUT/prof" -name "*kernel_stats.csv" | head -1 | xargs -r head -12 | tee -a "$OUT/summary.txt"
