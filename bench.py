@@ -6,7 +6,11 @@ One "step" = one pass of the hot path over one batch: the plugin boundary call
 on B=4096 synthetic instances of the metric config (n=50, m=100: 20 nonneg rows + 8 SOC(10), dense A; A, b, c all
 batched) with q_eval / A_eval already resident in HBM in the reference's batch-minor layout.  The layout pass,
 the solve, the status read-back and the adjoint are all inside the timed region.
-N>1: each rank holds its own 4096 instances (weak scaling); the step includes the all-gather of primal/dual.
+N>1: each rank holds its own 4096 instances (weak scaling); the step includes the all-gather of primal/dual (every rank
+evaluates the same loss on the gathered tensor: parallel.py's loss="replicated" contract, no collective in the backward).
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment launches the N ranks itself (re-exec under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`); under an external launcher
+(the driver's torchrun line) RANK / LOCAL_RANK / WORLD_SIZE are read from the environment.
 """
 import argparse
 import json
@@ -70,8 +74,8 @@ def pmc_traffic(kernel_short):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200, help="timed steps (default 200: ~0.7 s, long enough to be past the clock ramp)")
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=4096)
     ap.add_argument("--config", default="M")
     ap.add_argument("--eps", type=float, default=1e-4, help="eps_abs=eps_rel (SCS default 1e-4)")
@@ -83,7 +87,19 @@ def main():
                          "acceleration on).  The CPU baseline runs with the same setting.")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # launched bare: create the N ranks (one process per GPU) and let rank 0 of that job print the JSON line
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        os.execv(sys.executable, cmd)
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: reporting n_gpus={world}", file=sys.stderr)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
@@ -135,6 +151,18 @@ def main():
     bwd_ms, nb = eng.profile(1)
     lay_ms, nl = eng.profile(2)
     eng.set_profiling(False)
+    allgather_ms = None
+    if world > 1:         # the exchange step on its own: one fused RCCL all-gather of (B, n + m) rows per step (HIP events on this stream)
+        with torch.no_grad():
+            pr = torch.zeros((B, n), dtype=torch.float64, device=dev); du = torch.zeros((B, tpl.m), dtype=torch.float64, device=dev)
+            for _ in range(5):
+                gather_solution(pr, du)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(50):
+                gather_solution(pr, du)
+            e1.record(); e1.synchronize()
+            allgather_ms = e0.elapsed_time(e1) / 50
 
     if rank == 0:
         ms_per_step = 1e3 * dt / args.steps
@@ -149,7 +177,8 @@ def main():
         # algorithmic fp64 flops of the forward kernel: setup m n^2 + n^3/3, per iteration 4 nnzA + 2 n^2 + 10(n+m)
         flops = B * (m * n * n + n ** 3 / 3.0) + float(iters.sum()) * (4 * nnzA + 2 * n * n + 10 * (n + m))
         out = {
-            "metric": "forward+backward problems/sec, batch=4096 n=50 m=100 SOC", "value": value, "unit": "problems/s",
+            "metric": ("forward+backward problems/sec, batch=4096 n=50 m=100 SOC" if (args.config == "M" and B == 4096) else
+                       f"forward+backward problems/sec, batch={B} n={n} m={m} config {args.config}"), "value": value, "unit": "problems/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"config {args.config}: n={n} m={m} cones l={cones.get('l', 0)} q={cones.get('q', [])} dense A "
@@ -169,6 +198,9 @@ def main():
             "iters": {"mean": float(iters.mean()), "max": float(iters.max())},
             "launch": eng.launch_info(),
         }
+        if allgather_ms is not None:
+            out["allgather_ms"] = allgather_ms
+            out["allgather_bytes_per_rank"] = 8 * B * (n + m)
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(n, cones, solver_args, args.cpu_sample, seed=0)
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]

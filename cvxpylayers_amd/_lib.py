@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "csrc", "libcone_engine.so")
 
 # every symbol include/cone_engine.h declares
-SYMBOLS = ["ce_default_settings", "ce_create", "ce_destroy", "ce_last_error", "ce_solve", "ce_vjp", "ce_qp_native", "ce_solve_qp", "ce_vjp_qp",
+SYMBOLS = ["ce_abi_version", "ce_struct_size", "ce_default_settings", "ce_create", "ce_destroy", "ce_last_error", "ce_solve", "ce_vjp", "ce_qp_native", "ce_solve_qp", "ce_vjp_qp",
            "ce_transpose", "ce_parammap_apply", "ce_parammap_apply2", "ce_ca_step", "ce_ca_check", "ce_ca_psd", "ce_ca_triples", "ce_ca_triple_jac", "ce_ca_update", "ce_ca_finish", "ce_set_profiling", "ce_get_profile", "ce_reset_profile", "ce_get_launch_info"]
 
 
@@ -31,13 +31,15 @@ class CeSettings(C.Structure):
                 ("acceleration_lookback", C.c_int), ("acceleration_interval", C.c_int)]
 
 
+ABI_VERSION = 3          # include/cone_engine.h CE_ABI_VERSION this binding was written against
+
+
 def build(force: bool = False) -> str:
-    src = os.path.join(_HERE, "csrc", "cone_engine.hip")
-    hdr = os.path.join(_HERE, "..", "include", "cone_engine.h")
-    stale = (not os.path.exists(SO_PATH) or os.path.getmtime(SO_PATH) < os.path.getmtime(src)
-             or os.path.getmtime(SO_PATH) < os.path.getmtime(hdr))
-    if force or stale:
-        subprocess.check_call([os.path.join(_HERE, "csrc", "build.sh")])
+    """csrc/Makefile decides what is stale (every kernel header is a dependency of the objects that include it); force = rebuild all."""
+    csrc = os.path.join(_HERE, "csrc")
+    if force:
+        subprocess.check_call(["make", "-C", csrc, "clean"], stdout=subprocess.DEVNULL)
+    subprocess.check_call([os.path.join(csrc, "build.sh")], stdout=subprocess.DEVNULL)
     return SO_PATH
 
 
@@ -54,6 +56,14 @@ def lib():
             f"{SO_PATH} is missing: the HIP engine is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(cvxpylayers_amd has no CPU fallback).")
     L = C.CDLL(SO_PATH)
+    # ABI guard: a stale .so (or a stale binding) must be rejected, not read out of bounds
+    try:
+        ver, st, ss = L.ce_abi_version(), L.ce_struct_size(0), L.ce_struct_size(1)
+    except AttributeError as e:
+        raise RuntimeError(f"{SO_PATH} predates the ABI guard (no ce_abi_version): rebuild it") from e
+    if ver != ABI_VERSION or st != C.sizeof(CeTemplate) or ss != C.sizeof(CeSettings):
+        raise RuntimeError(f"{SO_PATH}: ABI mismatch (library version {ver}, ce_template {st} B, ce_settings {ss} B; binding version "
+                           f"{ABI_VERSION}, {C.sizeof(CeTemplate)} B, {C.sizeof(CeSettings)} B): rebuild the library")
     vp, dp, ip, lg = C.c_void_p, C.c_void_p, C.c_void_p, C.c_long
     L.ce_default_settings.argtypes = [C.POINTER(CeSettings)]
     L.ce_default_settings.restype = None

@@ -1,7 +1,6 @@
 #!/bin/bash
-# Builds the C-ABI shared library for gfx950 (cross-compiles without a GPU).
+# Builds the C-ABI shared library for gfx950 (cross-compiles without a GPU): csrc/Makefile, kernel families in parallel.
+# Extra compiler flags: EXTRA="-DCE_TIMING" ./build.sh   (forces a full rebuild when EXTRA changes: run `make clean` first)
 set -e
 cd "$(dirname "$0")"
-HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-$HIPCC --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-value \
-    -I../../include cone_engine.hip -o libcone_engine.so "$@"
+make -j"${CE_BUILD_JOBS:-8}" "$@"

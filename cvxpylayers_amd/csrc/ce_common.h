@@ -12,19 +12,7 @@ constexpr double MIN_SCALE = 1e-4, MAX_SCALE = 1e4;
 constexpr double MIN_SCALE_VALUE = 1e-6, MAX_SCALE_VALUE = 1e6;
 constexpr double TAU_FACTOR = 10.0, ZERO_CONE_FACTOR = 1000.0;
 
-struct DevT {
-    int n, m, nnz_aug, nnzA, z, l, nq, lda, ldg, maxq;
-    const int *rowidx;    // [nnz_aug] row of structural entry k
-    const int *colidx;    // [nnz_aug] column (n == the b column)
-    const int *rowcone;   // [m] -1 for zero / nonneg rows, else SOC index
-    const int *qoff;      // [nq+1] first row of SOC c
-    int ns, maxs;         // PSD cones, largest order
-    const int *soff;      // [ns+1] first row of PSD cone c (svec blocks follow the SOCs, SCS row order z,l,q,s)
-    const int *sord;      // [ns] order k of PSD cone c
-    int nep, eoff;        // exponential cones (3 rows each) and their first row (after the PSD blocks: SCS row order z,l,q,s,ep,p)
-    int np;               // 3-d power cones, after the exponential cones
-    const double *pw;     // [np] exponent a of x^a y^(1-a) >= |z|; a < 0: the dual cone of exponent |a| (SCS convention)
-};
+// DevT (the device-side template description) lives in ce_types.h, shared by all translation units
 
 thread_local std::string g_err;
 

@@ -1,0 +1,57 @@
+// ce_types.h -- types shared by the translation units of libcone_engine.so and the launcher entry points each kernel
+// translation unit exports to the host dispatch (cone_engine.hip).  The kernels are split over several .hip files so that
+// they compile in parallel and a change to one kernel family rebuilds one object (csrc/Makefile).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "cone_engine.h"
+
+struct DevT {
+    int n, m, nnz_aug, nnzA, z, l, nq, lda, ldg, maxq;
+    const int *rowidx;    // [nnz_aug] row of structural entry k
+    const int *colidx;    // [nnz_aug] column (n == the b column)
+    const int *rowcone;   // [m] -1 for zero / nonneg rows, else SOC index
+    const int *qoff;      // [nq+1] first row of SOC c
+    int ns, maxs;         // PSD cones, largest order
+    const int *soff;      // [ns+1] first row of PSD cone c (svec blocks follow the SOCs, SCS row order z,l,q,s)
+    const int *sord;      // [ns] order k of PSD cone c
+    int nep, eoff;        // exponential cones (3 rows each) and their first row (after the PSD blocks: SCS row order z,l,q,s,ep,p)
+    int np;               // 3-d power cones, after the exponential cones
+    const double *pw;     // [np] exponent a of x^a y^(1-a) >= |z|; a < 0: the dual cone of exponent |a| (SCS convention)
+};
+
+// arguments of one forward launch (all kernels of the forward family take a subset)
+struct CeFwdArgs {
+    DevT T; ce_settings S;
+    const double *Abm; const double *q; long sqk, sqb;
+    const int *idx_at, *idx_ar, *idx_b;
+    double *x, *y, *s; int *iters, *status; double *resid;
+    const double *P; int nnz_p; const int *idx_p;
+    double *gA, *gG;            // global residency workspaces of the size-generic kernel
+};
+struct CeBwdArgs {
+    DevT T; int nkcap, ldk;
+    const double *Abm, *x, *y, *s, *dx, *dy;
+    double *dA, *dq; long sdqk, sdqb; int *adj;
+    const double *P; int nnz_p; const int *pmap, *prow, *pcol; int p_tri; double *dP;
+    double *gA, *gK;
+};
+
+// launchers (one per kernel object file): 0 on success, -1 unknown variant
+int ce_launch_fwd2_plain(int variant, int B, size_t lds, hipStream_t st, const CeFwdArgs &a);   // zero / nonneg / SOC
+int ce_launch_fwd2_psd(int variant, int B, size_t lds, hipStream_t st, const CeFwdArgs &a);     // + PSD / exponential / power cones
+int ce_launch_fwd2_qp(int variant, int B, size_t lds, hipStream_t st, const CeFwdArgs &a);      // quadratic objective inside the kernel
+int ce_launch_fwd_rt(int variant, int B, size_t lds, hipStream_t st, const CeFwdArgs &a);
+int ce_launch_fwd_generic(int mode, int B, size_t lds, hipStream_t st, const CeFwdArgs &a);
+int ce_launch_bwd_rt_plain(int variant, int B, size_t lds, hipStream_t st, const CeBwdArgs &a);
+int ce_launch_bwd_rt_psd(int variant, int B, size_t lds, hipStream_t st, const CeBwdArgs &a);
+int ce_launch_bwd_generic(int mode, int B, size_t lds, hipStream_t st, const CeBwdArgs &a);
+// raise the dynamic-LDS limit of every kernel of the family
+hipError_t ce_setattr_fwd2_plain(int bytes);
+hipError_t ce_setattr_fwd2_psd(int bytes);
+hipError_t ce_setattr_fwd2_qp(int bytes);
+hipError_t ce_setattr_fwd_rt(int bytes);
+hipError_t ce_setattr_fwd_generic(int bytes);
+hipError_t ce_setattr_bwd_rt_plain(int bytes);
+hipError_t ce_setattr_bwd_rt_psd(int bytes);
+hipError_t ce_setattr_bwd_generic(int bytes);

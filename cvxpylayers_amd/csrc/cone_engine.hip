@@ -31,15 +31,15 @@
 #include <vector>
 
 #include "cone_engine.h"
+#include "ce_types.h"
 
 namespace {
 #include "ce_common.h"
 #include "ce_expcone.h"
-#include "ce_forward_generic.h"
-#include "ce_forward_rt.h"
-#include "ce_forward_v2.h"
-#include "ce_backward.h"
-#include "ce_backward_rt.h"
+#include "ce_forward_rt.h"     // NT2, SOC_SMALL, RT_NVEC / RT_EXTRA (launch planning); its kernels are instantiated in ce_tu_fwd_other.hip
+#include "ce_forward_v2.h"     // psd_project (used by k_ca_psd); k_fwd2 itself is instantiated in ce_tu_fwd2.hip
+#include "ce_backward.h"       // k_transpose, k_parammap*  (k_backward is instantiated in ce_tu_bwd_generic.hip)
+#include "ce_backward_rt.h"    // bwd_rt_union_doubles, BGC (launch planning); kernels in ce_tu_bwd_rt.hip
 #include "ce_const_a.h"
 }  // namespace
 
@@ -178,6 +178,8 @@ static bool f2_fits(const DevT &T, int v, int *ldg, size_t *bytes, bool has_p = 
 extern "C" {
 
 const char *ce_last_error(void) { return g_err.c_str(); }
+int ce_abi_version(void) { return CE_ABI_VERSION; }
+int ce_struct_size(int which) { return which == 0 ? (int)sizeof(ce_template) : which == 1 ? (int)sizeof(ce_settings) : -1; }
 
 void ce_default_settings(ce_settings *s) {
     s->eps_abs = 1e-4; s->eps_rel = 1e-4; s->eps_infeas = 1e-7; s->alpha = 1.5; s->rho_x = 1e-6; s->scale = 0.1;
@@ -322,19 +324,9 @@ int ce_create(const ce_template *tpl, int device, ce_handle *out) {
         }
     }
     if (h->qp_native && h->bwd_mode != 3) h->qp_native = false;      // the adjoint with P lives in the register-tiled backward kernel
-#define SETATTR(kern, bytes) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)))
-    SETATTR((k_forward<true, true>), LDS_LIMIT);  SETATTR((k_forward<true, false>), LDS_LIMIT);  SETATTR((k_forward<false, false>), LDS_LIMIT);
-    SETATTR((k_forward_rt<8, 13, 7, 4, 13, 160, 4>), LDS_LIMIT); SETATTR((k_forward_rt<8, 16, 8, 4, 16, 208, 4>), LDS_LIMIT); SETATTR((k_forward_rt<4, 32, 32, 4, 32, 272, 2>), LDS_LIMIT);
-    SETATTR((k_fwd2<16, 2, 8, 2, 16, 2, true>), LDS_LIMIT); SETATTR((k_fwd2<8, 8, 4, 8, 8, 4, true>), LDS_LIMIT); SETATTR((k_fwd2<4, 26, 2, 26, 4, 14, true>), LDS_LIMIT);
-    SETATTR((k_fwd2<4, 30, 4, 26, 4, 26, false, 512>), LDS_LIMIT); SETATTR((k_fwd2<8, 20, 2, 32, 8, 8, false, 512>), LDS_LIMIT);
-    SETATTR((k_fwd2<4, 30, 4, 26, 4, 26, true, 512>), LDS_LIMIT); SETATTR((k_fwd2<8, 20, 2, 32, 8, 8, true, 512>), LDS_LIMIT);
-    SETATTR((k_fwd2<4, 26, 2, 26, 4, 14, false, 256, true>), LDS_LIMIT); SETATTR((k_fwd2<8, 20, 2, 32, 8, 8, false, 512, true>), LDS_LIMIT); SETATTR((k_fwd2<4, 30, 4, 26, 4, 26, false, 512, true>), LDS_LIMIT);
-    SETATTR((k_fwd2<16, 2, 8, 2, 16, 2>), LDS_LIMIT); SETATTR((k_fwd2<8, 8, 4, 8, 8, 4>), LDS_LIMIT); SETATTR((k_fwd2<4, 26, 2, 26, 4, 14>), LDS_LIMIT);
-    SETATTR((k_backward_rt<4, 4, 4, true>), LDS_LIMIT); SETATTR((k_backward_rt<7, 7, 4, true>), LDS_LIMIT); SETATTR((k_backward_rt<7, 7, 7, true>), LDS_LIMIT);
-    SETATTR((k_backward_rt<7, 13, 7, false, 32>), LDS_LIMIT); SETATTR((k_backward_rt<7, 13, 7, true, 32>), LDS_LIMIT);
-    SETATTR((k_backward_rt<4, 4, 4>), LDS_LIMIT); SETATTR((k_backward_rt<7, 7, 4>), LDS_LIMIT); SETATTR((k_backward_rt<7, 7, 7>), LDS_LIMIT);
-    SETATTR((k_backward<true, true>), LDS_LIMIT); SETATTR((k_backward<true, false>), LDS_LIMIT); SETATTR((k_backward<false, false>), LDS_LIMIT);
-#undef SETATTR
+    HIPCHK(ce_setattr_fwd_generic((int)LDS_LIMIT)); HIPCHK(ce_setattr_fwd_rt((int)LDS_LIMIT));
+    HIPCHK(ce_setattr_fwd2_plain((int)LDS_LIMIT)); HIPCHK(ce_setattr_fwd2_psd((int)LDS_LIMIT)); HIPCHK(ce_setattr_fwd2_qp((int)LDS_LIMIT));
+    HIPCHK(ce_setattr_bwd_rt_plain((int)LDS_LIMIT)); HIPCHK(ce_setattr_bwd_rt_psd((int)LDS_LIMIT)); HIPCHK(ce_setattr_bwd_generic((int)LDS_LIMIT));
     *out = h;
     return CE_OK;
 }
@@ -415,24 +407,20 @@ int ce_solve_qp(ce_handle h, int B, const double *A_vals, long sA_k, long sA_b, 
     }
     {
         ProfScope ps(h, 0, st);
-        dim3 grid(B), block(NT);
-#define LAUNCH_F(AL, GL) hipLaunchKernelGGL((k_forward<AL, GL>), grid, block, h->fwd_lds, st, T, S, Abm, q_vals, sq_k, sq_b, x, y, s, iters, status, resid, gA, gG)
-        DevT Trt = T; Trt.lda = h->rt_lda;
-#define LAUNCH_RT(...) hipLaunchKernelGGL((k_forward_rt<__VA_ARGS__>), grid, dim3(NT2), h->fwd_lds, st, Trt, S, Abm, q_vals, sq_k, sq_b, x, y, s, iters, status, resid)
-        DevT Tf2 = T; Tf2.ldg = h->f2_ldg;
-#define LAUNCH_F2(...) hipLaunchKernelGGL((k_fwd2<__VA_ARGS__>), grid, dim3(F2_VARIANTS[h->f2_variant][6]), h->fwd_lds, st, Tf2, S, Abm, q_vals, sq_k, sq_b, h->d_idx_at, h->d_idx_ar, h->d_idx_b, x, y, s, iters, status, resid, P_vals, h->nnz_p, h->d_idx_p)
-        if (h->fwd_mode == 4 && P_vals) {
-            if (h->f2_variant == 2) LAUNCH_F2(4, 26, 2, 26, 4, 14, false, 256, true); else if (h->f2_variant == 3) LAUNCH_F2(8, 20, 2, 32, 8, 8, false, 512, true); else LAUNCH_F2(4, 30, 4, 26, 4, 26, false, 512, true);
-        } else if (h->fwd_mode == 4 && (T.ns > 0 || T.nep + T.np > 0)) {
-            if (h->f2_variant == 0) LAUNCH_F2(16, 2, 8, 2, 16, 2, true); else if (h->f2_variant == 1) LAUNCH_F2(8, 8, 4, 8, 8, 4, true); else if (h->f2_variant == 2) LAUNCH_F2(4, 26, 2, 26, 4, 14, true); else if (h->f2_variant == 3) LAUNCH_F2(8, 20, 2, 32, 8, 8, true, 512); else LAUNCH_F2(4, 30, 4, 26, 4, 26, true, 512);
-        } else if (h->fwd_mode == 4) {
-            if (h->f2_variant == 0) LAUNCH_F2(16, 2, 8, 2, 16, 2); else if (h->f2_variant == 1) LAUNCH_F2(8, 8, 4, 8, 8, 4); else if (h->f2_variant == 2) LAUNCH_F2(4, 26, 2, 26, 4, 14); else if (h->f2_variant == 3) LAUNCH_F2(8, 20, 2, 32, 8, 8, false, 512); else LAUNCH_F2(4, 30, 4, 26, 4, 26, false, 512);
+        CeFwdArgs fa{};
+        fa.T = T; fa.S = S; fa.Abm = Abm; fa.q = q_vals; fa.sqk = sq_k; fa.sqb = sq_b; fa.idx_at = h->d_idx_at; fa.idx_ar = h->d_idx_ar; fa.idx_b = h->d_idx_b;
+        fa.x = x; fa.y = y; fa.s = s; fa.iters = iters; fa.status = status; fa.resid = resid; fa.P = P_vals; fa.nnz_p = h->nnz_p; fa.idx_p = h->d_idx_p; fa.gA = gA; fa.gG = gG;
+        int lrc;
+        if (h->fwd_mode == 4) {
+            fa.T.ldg = h->f2_ldg;
+            if (P_vals) lrc = ce_launch_fwd2_qp(h->f2_variant, B, h->fwd_lds, st, fa);
+            else if (T.ns > 0 || T.nep + T.np > 0) lrc = ce_launch_fwd2_psd(h->f2_variant, B, h->fwd_lds, st, fa);
+            else lrc = ce_launch_fwd2_plain(h->f2_variant, B, h->fwd_lds, st, fa);
         } else if (h->fwd_mode == 3) {
-            if (h->rt_variant == 0) LAUNCH_RT(8, 13, 7, 4, 13, 160, 4); else if (h->rt_variant == 1) LAUNCH_RT(8, 16, 8, 4, 16, 208, 4); else LAUNCH_RT(4, 32, 32, 4, 32, 272, 2);
-        } else if (h->fwd_mode == 0) LAUNCH_F(true, true); else if (h->fwd_mode == 1) LAUNCH_F(true, false); else LAUNCH_F(false, false);
-#undef LAUNCH_RT
-#undef LAUNCH_F2
-#undef LAUNCH_F
+            fa.T.lda = h->rt_lda;
+            lrc = ce_launch_fwd_rt(h->rt_variant, B, h->fwd_lds, st, fa);
+        } else lrc = ce_launch_fwd_generic(h->fwd_mode, B, h->fwd_lds, st, fa);
+        if (lrc) { g_err = "internal: no forward kernel for the planned variant"; return CE_E_BADARG; }
     }
     HIPCHK(hipGetLastError());
     return CE_OK;
@@ -472,17 +460,16 @@ int ce_vjp_qp(ce_handle h, int B, const double *A_vals, long sA_k, long sA_b, co
     }
     {
         ProfScope ps(h, 1, st);
-        dim3 grid(B), block(NT);
-#define LAUNCH_B(AL, KL) hipLaunchKernelGGL((k_backward<AL, KL>), grid, block, h->bwd_lds, st, T, h->nkcap, h->ldk, Abm, x, y, s, dx, dy, dAbm, dq_vals, sdq_k, sdq_b, adj_status, gA, gK)
-        DevT Tb = T; Tb.lda = T.n;
-#define LAUNCH_BRT(...) hipLaunchKernelGGL((k_backward_rt<__VA_ARGS__>), grid, dim3(h->brt_variant >= 0 ? BRT_VARIANTS[h->brt_variant][3] * 16 : NT), h->bwd_lds, st, Tb, Abm, x, y, s, dx, dy, dAbm, dq_vals, sdq_k, sdq_b, adj_status, P_vals, h->nnz_p, h->d_pmap, h->d_prow, h->d_pcol, h->p_tri, dP_vals)
-        if (h->bwd_mode == 3 && (T.ns > 0 || T.nep + T.np > 0)) {
-            if (h->brt_variant == 0) LAUNCH_BRT(4, 4, 4, true); else if (h->brt_variant == 1) LAUNCH_BRT(7, 7, 4, true); else if (h->brt_variant == 2) LAUNCH_BRT(7, 7, 7, true); else LAUNCH_BRT(7, 13, 7, true, 32);
-        } else if (h->bwd_mode == 3) {
-            if (h->brt_variant == 0) LAUNCH_BRT(4, 4, 4); else if (h->brt_variant == 1) LAUNCH_BRT(7, 7, 4); else if (h->brt_variant == 2) LAUNCH_BRT(7, 7, 7); else LAUNCH_BRT(7, 13, 7, false, 32);
-        } else if (h->bwd_mode == 0) LAUNCH_B(true, true); else if (h->bwd_mode == 1) LAUNCH_B(true, false); else LAUNCH_B(false, false);
-#undef LAUNCH_BRT
-#undef LAUNCH_B
+        CeBwdArgs ba{};
+        ba.T = T; ba.nkcap = h->nkcap; ba.ldk = h->ldk; ba.Abm = Abm; ba.x = x; ba.y = y; ba.s = s; ba.dx = dx; ba.dy = dy; ba.dA = dAbm; ba.dq = dq_vals;
+        ba.sdqk = sdq_k; ba.sdqb = sdq_b; ba.adj = adj_status; ba.P = P_vals; ba.nnz_p = h->nnz_p; ba.pmap = h->d_pmap; ba.prow = h->d_prow; ba.pcol = h->d_pcol;
+        ba.p_tri = h->p_tri; ba.dP = dP_vals; ba.gA = gA; ba.gK = gK;
+        int lrc;
+        if (h->bwd_mode == 3) {
+            ba.T.lda = T.n;
+            lrc = (T.ns > 0 || T.nep + T.np > 0) ? ce_launch_bwd_rt_psd(h->brt_variant, B, h->bwd_lds, st, ba) : ce_launch_bwd_rt_plain(h->brt_variant, B, h->bwd_lds, st, ba);
+        } else lrc = ce_launch_bwd_generic(h->bwd_mode, B, h->bwd_lds, st, ba);
+        if (lrc) { g_err = "internal: no backward kernel for the planned variant"; return CE_E_BADARG; }
     }
     if (need_tr) {
         ProfScope ps(h, 2, st);

@@ -196,16 +196,21 @@ class ConeEngine:
             return False
         return is_constant_A(A_bm, self.nnzA)
 
-    def vjp(self, A_bm, x, y, s, dx, dy, batch_minor_out: bool = False, P_bm=None):
+    def vjp(self, A_bm, x, y, s, dx, dy, batch_minor_out: bool = False, P_bm=None, path: str | None = None):
         """Returns dA (nnz_aug, B), dq (n+1, B), adj_status (B,).  dA is a transposed view of a batch-major buffer (the
         engine-native layout, no extra pass) unless batch_minor_out: then it is (nnz_aug, B) contiguous -- the layout of a
-        reference-style A_eval, so that autograd can accumulate it into the leaf without a strided copy (one engine layout pass)."""
+        reference-style A_eval, so that autograd can accumulate it into the leaf without a strided copy (one engine layout pass).
+        path: the path ("per_instance" / "const_a") of the forward call being differentiated, as recorded by the caller right
+        after solve() -- the autograd node keeps it, so interleaved forward calls of one layer cannot redirect a pending backward.
+        None (direct engine users with one solve in flight): the path of the most recent solve()."""
         B = A_bm.shape[0]
         dev = self.device
         if B == 0:
             return (torch.empty((self.nnz_aug, 0), dtype=torch.float64, device=dev), torch.empty((self.n + 1, 0), dtype=torch.float64, device=dev),
                     torch.empty((0,), dtype=torch.int32, device=dev))
-        if getattr(self, "last_path", None) == "const_a" and (self.launch_info()["bwd_mode"] in (1, 2) or __import__("os").environ.get("CE_CONST_A") == "1"):
+        if path is None:
+            path = getattr(self, "last_path", None)
+        if path == "const_a" and (self.launch_info()["bwd_mode"] in (1, 2) or __import__("os").environ.get("CE_CONST_A") == "1"):
             from cvxpylayers_amd.interfaces.const_a import vjp_const_a      # shared A: batched LSQR with GEMMs over the batch
             return vjp_const_a(self, A_bm, x, y, s, dx, dy, batch_minor_out=batch_minor_out)
         dq = torch.empty((self.n + 1, B), dtype=torch.float64, device=dev)
@@ -386,10 +391,8 @@ def _warn_flagged_adjoint(eng):
     """Deferred check of the previous backward's per-instance flags (degenerate active set: more active rows than the direct
     solve holds / singular pivot, or LSQR iteration limit): their gradients are zero or inexact.  Done at the next call so that
     the backward path itself never synchronises the host."""
-    pend = getattr(eng, "_pending_adj", None)
-    if pend is not None:
-        eng._pending_adj = None
-        adj, bs = pend
+    pend, eng._pending_adj = getattr(eng, "_pending_adj", None) or [], []
+    for adj, bs in pend:
         nbad = int((adj != 0).sum())
         if nbad:
             warnings.warn(f"MI355 adjoint: {nbad} of {bs} instances of the previous backward pass were flagged (degenerate active "
@@ -424,6 +427,12 @@ class _ConeLayer(torch.autograd.Function):
         if solver_args:
             merged_args.update(solver_args)
         settings = make_settings(merged_args)
+        if warm_start is None and merged_args.get("warm_starts") is not None:
+            # diffcp's solve argument (diffcp_if.py:365-367 forwards it): one (x, y, s) triple per instance
+            ws = merged_args["warm_starts"]
+            if len(ws) != batch_size:
+                raise ValueError(f"warm_starts: expected one (x, y, s) triple per instance ({batch_size}), got {len(ws)}")
+            warm_start = tuple(torch.stack([torch.as_tensor(np.asarray(t[k]), dtype=torch.float64) for t in ws]) for k in range(3))
         with torch.cuda.device(dev):
             A_dev = A_eval.detach().to(device=dev, dtype=torch.float64)
             q_dev = q_eval.detach().to(device=dev, dtype=torch.float64)
@@ -442,6 +451,7 @@ class _ConeLayer(torch.autograd.Function):
             elif warm_start not in (None, False):
                 warm = tuple(t if t.dim() == 2 else t.unsqueeze(0) for t in warm_start)     # (x, y, s) tensors
             x, y, s, iters, status, resid = eng.solve(A_bm, q_dev, settings, warm=warm, P_bm=P_bm)
+            path = eng.last_path          # recorded per call: the backward of THIS node must not follow a later solve's path
             eng._last_solution = (x.detach(), y.detach(), s)
             st = status.cpu()
         if bool((st < 0).any()) and merged_args.get("raise_on_error", True):
@@ -457,7 +467,7 @@ class _ConeLayer(torch.autograd.Function):
         # attaches this node to them: keeping the SAME objects on the node would form a reference cycle (node -> saved ->
         # primal -> grad_fn -> node) that only the cyclic GC breaks, i.e. 167 MB buffers pile up for many steps and the
         # caching allocator falls back to hipMalloc (3 ms each).  Detached aliases share the storage without the cycle.
-        saved = (eng, A_bm, x.detach(), y.detach(), s, batch_minor_in, P_bm) if needs_grad else None
+        saved = (eng, A_bm, x.detach(), y.detach(), s, batch_minor_in, P_bm, path) if needs_grad else None
         return primal, dual, info, (saved, batch_size, originally_unbatched, in_device)
 
     @staticmethod
@@ -472,18 +482,19 @@ class _ConeLayer(torch.autograd.Function):
         saved, batch_size, originally_unbatched, in_device = ctx.backward_data
         if saved is None:
             raise RuntimeError("backward called on a layer evaluated with needs_grad=False")
-        eng, A_bm, x, y, s, batch_minor_in, P_bm = saved
+        eng, A_bm, x, y, s, batch_minor_in, P_bm, path = saved
         dP = None
         with torch.cuda.device(eng.device):
             dx = dprimal.to(device=eng.device, dtype=torch.float64).contiguous()
             dy = ddual.to(device=eng.device, dtype=torch.float64).contiguous()
             if P_bm is not None:
-                dA, dq, adj, dP_bm = eng.vjp(A_bm, x, y, s, dx, dy, batch_minor_out=batch_minor_in, P_bm=P_bm)
+                dA, dq, adj, dP_bm = eng.vjp(A_bm, x, y, s, dx, dy, batch_minor_out=batch_minor_in, P_bm=P_bm, path=path)
                 dP = dP_bm.t().to(in_device)
             else:
-                dA, dq, adj = eng.vjp(A_bm, x, y, s, dx, dy, batch_minor_out=batch_minor_in)
+                dA, dq, adj = eng.vjp(A_bm, x, y, s, dx, dy, batch_minor_out=batch_minor_in, path=path)
         ctx.adj_status = adj
-        eng._pending_adj = (adj, batch_size)     # inspected at the next call (no host sync on the backward path)
+        pend = getattr(eng, "_pending_adj", None) or []
+        eng._pending_adj = (pend + [(adj, batch_size)])[-8:]     # inspected at the next forward call (no host sync on the backward path)
         dA = dA.to(in_device)
         dq = dq.to(in_device)
         if originally_unbatched:

@@ -85,6 +85,15 @@ typedef struct {
 
 void ce_default_settings(ce_settings *s);
 
+/* ABI guard.  The structs above carry no size field, so a binding compiled / written against an older header would hand the
+ * library short structs.  Bindings must check  ce_abi_version() == CE_ABI_VERSION  and  ce_struct_size(which) == sizeof(their
+ * struct)  (which: 0 ce_template, 1 ce_settings) once at load time and refuse to continue otherwise (cvxpylayers_amd/_lib.py
+ * does; tests/test_cabi.py checks the stub printed in INTEGRATION.md the same way).  CE_ABI_VERSION is bumped whenever a struct
+ * layout or an entry point's signature changes. */
+#define CE_ABI_VERSION 3
+int ce_abi_version(void);
+int ce_struct_size(int which);
+
 int ce_create(const ce_template *tpl, int device, ce_handle *out);
 int ce_destroy(ce_handle h);
 const char *ce_last_error(void);

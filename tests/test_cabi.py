@@ -28,6 +28,35 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, sym), sym
 
 
+def test_struct_layouts_agree_between_library_binding_and_the_documented_stub():
+    """ce_template / ce_settings carry no size field: the library reports sizeof() of its own structs (ce_struct_size) and both the
+    binding (_lib.py) and the stub a maintainer would copy out of INTEGRATION.md section 2 must match it field by field."""
+    L = _lib.lib()
+    hdr = open(os.path.join(ROOT, "include", "cone_engine.h")).read()
+    assert int(re.search(r"#define CE_ABI_VERSION (\d+)", hdr).group(1)) == L.ce_abi_version() == _lib.ABI_VERSION
+    assert L.ce_struct_size(0) == C.sizeof(_lib.CeTemplate) and L.ce_struct_size(1) == C.sizeof(_lib.CeSettings)
+    assert L.ce_struct_size(2) == -1
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    classes = re.findall(r"^class (\w+)\(C\.Structure\):.*\n((?:    .*\n)+)", doc, flags=re.M)
+    ns = {"C": C}
+    for name, body in classes:
+        exec(f"class {name}(C.Structure):\n{body}", ns)
+    for stub, mine in (("ce_template", _lib.CeTemplate), ("ce_settings", _lib.CeSettings)):
+        assert stub in ns, f"INTEGRATION.md no longer documents {stub}"
+        assert [(f, t) for f, t in ns[stub]._fields_] == [(f, t) for f, t in mine._fields_], stub
+        assert C.sizeof(ns[stub]) == C.sizeof(mine)
+    # every field of the header's structs, in order (catches a field added to the header but to neither python struct)
+    for cname, mine in (("ce_template", _lib.CeTemplate), ("ce_settings", _lib.CeSettings)):
+        body = re.search(r"typedef struct \{([^{}]*)\} " + cname + ";", re.sub(r"/\*.*?\*/", "", hdr, flags=re.S), flags=re.S).group(1)
+        names = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if decl:
+                names += [re.sub(r"[\s\*]", "", part).split(" ")[-1] for part in re.sub(r"^(const\s+)?(int|double)\s+", "", decl).split(",")]
+        assert names == [f for f, _ in mine._fields_], (cname, names)
+    assert f"ce_abi_version() == {_lib.ABI_VERSION}" in doc
+
+
 def test_default_settings_are_scs_defaults():
     s = _lib.CeSettings()
     _lib.lib().ce_default_settings(C.byref(s))

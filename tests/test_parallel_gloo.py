@@ -48,19 +48,31 @@ def _worker(rank, world, port, ragged):
     total = 7 if ragged else 8
     A = torch.randn(5, total, dtype=torch.double, requires_grad=True)
     q = torch.randn(3, total, dtype=torch.double, requires_grad=True)
+    wts = torch.arange(1, total + 1, dtype=torch.double)[:, None]
+    lo, hi = shard_bounds(total, rank, world)
+    want = torch.zeros_like(A)
+    want[:, lo:hi] = 2.0 * wts[lo:hi, 0][None, :]              # d/dA of sum(primal * wts) restricted to this rank's shard
+    # (1) loss="replicated" (default): every rank evaluates the same loss on the gathered tensor; each rank's shard gradient is
+    #     the true gradient, no factor, no collective in the backward
     primal, dual, info = sharded_apply(_FakeLayer, q, A, None, {}, True, total=total)
     assert primal.shape == (total, 5) and dual.shape == (total, 3)
     assert torch.allclose(primal, 2.0 * A.detach().t()) and torch.allclose(dual, 3.0 * q.detach().t())
-    wts = torch.arange(1, total + 1, dtype=torch.double)[:, None]
     (primal * wts).sum().backward()
-    # every rank used the same loss on the gathered tensor: the reduce-scatter sums world copies of the gradient
-    lo, hi = shard_bounds(total, rank, world)
-    want = torch.zeros_like(A)
-    want[:, lo:hi] = world * 2.0 * wts[lo:hi, 0][None, :]
+    assert torch.allclose(A.grad, want), (A.grad, want)
+    # (2) loss="partial": the loss lives on rank 0 only (the other ranks contribute a zero term); same gradients
+    A.grad = None
+    primal, dual, info = sharded_apply(_FakeLayer, q, A, None, {}, True, total=total, loss="partial")
+    ((primal * wts).sum() * (1.0 if rank == 0 else 0.0)).backward()
+    assert torch.allclose(A.grad, want), (A.grad, want)
+    # (3) loss="partial" with every rank scoring its own half of the rows: L = sum_r L_r
+    A.grad = None
+    primal, dual, info = sharded_apply(_FakeLayer, q, A, None, {}, True, total=total, loss="partial")
+    mine = torch.zeros(total, 1, dtype=torch.double); mine[rank::world] = 1.0
+    (primal * wts * mine).sum().backward()
     assert torch.allclose(A.grad, want), (A.grad, want)
     # broadcast-parameter gradient: sum over the batch = sum over ranks of shard sums
     g = allreduce_broadcast_grad(A.grad.sum(dim=1))
-    assert torch.allclose(g, world * 2.0 * wts.sum() * torch.ones(5, dtype=torch.double))
+    assert torch.allclose(g, 2.0 * wts.sum() * torch.ones(5, dtype=torch.double))
     # plain gather of local rows
     loc = torch.full((hi - lo, 2), float(rank), dtype=torch.double)
     sizes = [shard_bounds(total, r, world)[1] - shard_bounds(total, r, world)[0] for r in range(world)]
