@@ -9,7 +9,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(_HERE, "csrc", "libcone_engine.so")
+SO_PATH = os.environ.get("CE_ENGINE_SO") or os.path.join(_HERE, "csrc", "libcone_engine.so")     # CE_ENGINE_SO: a debug build (csrc: make timing)
 
 # every symbol include/cone_engine.h declares
 SYMBOLS = ["ce_abi_version", "ce_struct_size", "ce_default_settings", "ce_create", "ce_destroy", "ce_last_error", "ce_solve", "ce_vjp", "ce_qp_native", "ce_solve_qp", "ce_vjp_qp",

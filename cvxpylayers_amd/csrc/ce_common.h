@@ -95,6 +95,8 @@ __device__ __forceinline__ void mv_rows_partial(const double *Mat, int ld, int r
     }
 }
 
+#include "ce_math.h"
+
 __device__ __forceinline__ double clamp_scale(double v) { return v < MIN_SCALE ? 1.0 : (v > MAX_SCALE ? MAX_SCALE : v); }
 
 // scatter one instance's boundary values (batch-major row of [A_cvx | b_cvx] values) into dense solver form

@@ -32,7 +32,7 @@ struct F2 {
     static constexpr int O_W = 0, O_UT = VP, O_U = 2 * VP, O_ZB = 3 * VP, O_GV = 4 * VP, O_PHI = 5 * VP;
     static constexpr int O_BV = 6 * VP, O_DV = O_BV + MP, O_CV = O_DV + MP, O_EV = O_CV + NP, O_TV = O_EV + NP, O_PX = O_TV + NP,
                          O_S1 = O_PX + NP, O_S2 = O_S1 + NP, O_S3 = O_S2 + NP, O_S4 = O_S3 + NP,
-                         O_RED = O_S4 + NP, O_WP = O_RED + NWARP * 8, O_SC = O_WP + NWARP, O_G = O_SC + 16;
+                         O_RED = O_S4 + NP, O_WP = O_RED + NWARP * 8, O_SC = O_WP + NWARP, O_MT = O_SC + 16, O_G = O_MT + 20;      // O_MT: ce_math.h coefficient table
     static_assert(T1 % 2 == 0 && T2 % 2 == 0 && TG % 2 == 0, "segments must be even for 16-byte LDS reads");
     static_assert(CHT <= 16 && CHA <= 16 && CHG <= 16, "DPP butterflies stay inside a row of 16 lanes");
 };
@@ -92,6 +92,27 @@ __device__ __forceinline__ double seg_dot_lds(const double *row, const double *v
         a1 = fma(r.y, v.y, a1);
     }
     return group_reduce<CH, false>(a0 + a1);
+}
+
+// Gather maps (template entry of every tile slot, -1 = structural zero) are THREAD-MAJOR: entry (t, k) at base[t * idx_stride<TT> + k],
+// rows padded to a multiple of 4 ints (16-byte aligned), so that a thread fetches its row with dwordx4 loads off ONE base address
+// (immediate offsets).  The slot-major layout of round 1 (base[k * NT + t]) needed one 64-bit address per slot beyond the
+// 12-bit immediate range: 2 x 22 address VGPRs computed, spilled and reloaded in every refactor().
+template <int TT> constexpr int idx_stride = (TT + 3) & ~3;
+// tile[k] = f(k, map entry) for k < TT, CHUNK loads of 4 entries in flight at a time
+template <int TT, class F>
+__device__ __forceinline__ void for_each_idx(const int *__restrict__ base, int t, F &&f) {
+    // scalar base + unsigned 32-bit byte offset: the loads take the (SGPR base, VGPR offset) addressing form, no 64-bit vector address
+    const int4 *ip = reinterpret_cast<const int4 *>(reinterpret_cast<const char *>(base) + (unsigned)t * (unsigned)(idx_stride<TT> * sizeof(int)));
+#pragma unroll
+    for (int c4 = 0; c4 < idx_stride<TT> / 4; c4++) {
+        const int4 ix = ip[c4];
+        if (4 * c4 + 0 < TT) f(std::integral_constant<int, 0>{}, 4 * c4 + 0, ix.x);
+        if (4 * c4 + 1 < TT) f(std::integral_constant<int, 1>{}, 4 * c4 + 1, ix.y);
+        if (4 * c4 + 2 < TT) f(std::integral_constant<int, 2>{}, 4 * c4 + 2, ix.z);
+        if (4 * c4 + 3 < TT) f(std::integral_constant<int, 3>{}, 4 * c4 + 3, ix.w);
+        if (c4 % 2 == 1) __builtin_amdgcn_sched_barrier(0);       // bounded number of loads in flight (register peak)
+    }
 }
 
 // thread coordinates, re-derived from an opaque copy of the thread id wherever they are needed: they then are short-lived
@@ -245,6 +266,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
 #endif
     F2_STAMP(0);
     for (int i = tid; i < L::O_G; i += NT) sm[i] = 0.0;
+    const double *const mtab = sm + L::O_MT;
     for (int i = tid; i < MP; i += NT) {
         int r0 = -1, d = 0;
         if (i < m) { const int c = T.rowcone[i]; if (c >= 0) { r0 = T.qoff[c]; d = T.qoff[c + 1] - r0; } }
@@ -255,6 +277,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
         socr[i] = r0; socd[i] = d;
     }
     __syncthreads();
+    ce_math_table_init(sm + L::O_MT, tid);
     for (int i = tid; i < m; i += NT) { const int ix = idx_b[i]; sm[L::O_BV + i] = ix >= 0 ? vals[ix] : 0.0; sm[L::O_DV + i] = 1.0; }
     for (int j = tid; j < n; j += NT) { sm[L::O_CV + j] = qv[j * sqk + inst * sqb]; sm[L::O_EV + j] = 1.0; }
     __syncthreads();
@@ -280,13 +303,11 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
         if constexpr (HASP) {
             const double *pv = Pvals_g + (size_t)blockIdx.x * nnzP;
 #pragma unroll
-            for (int k = 0; k < TG; k++) { const int ix = idx_p[k * NT + tid]; pf[k] = ix >= 0 ? (float)pv[ix] : 0.0f; }
+            for (int k = 0; k < TG; k++) { const int ix = idx_p[tid * idx_stride<TG> + k]; pf[k] = ix >= 0 ? (float)pv[ix] : 0.0f; }
         }
         float *const fPn = reinterpret_cast<float *>(sm + L::O_S3);          // column norms of P-hat (= row norms: symmetric)
-#pragma unroll
-        for (int k = 0; k < T1; k++) { const int ix = idx_at[k * NT + tid]; atf[k] = ix >= 0 ? (float)(-vals[ix]) : 0.0f; }   // A = -A_cvx (diffcp_if.py:65)
-#pragma unroll
-        for (int k = 0; k < T2; k++) { const int ix = idx_ar[k * NT + tid]; arf[k] = ix >= 0 ? (float)(-vals[ix]) : 0.0f; }
+        for_each_idx<T1>(idx_at, tid, [&](auto, int k, int ix) { atf[k] = ix >= 0 ? (float)(-vals[ix]) : 0.0f; });   // A = -A_cvx (diffcp_if.py:65)
+        for_each_idx<T2>(idx_ar, tid, [&](auto, int k, int ix) { arf[k] = ix >= 0 ? (float)(-vals[ix]) : 0.0f; });
         float *const fEt0 = reinterpret_cast<float *>(sm + L::O_S1), *const fEt1 = reinterpret_cast<float *>(sm + L::O_S2);
         float *const fDt0 = reinterpret_cast<float *>(sm + L::O_U + OY), *const fDt1 = reinterpret_cast<float *>(sm + L::O_UT + OY);
         float *const fRn = reinterpret_cast<float *>(sm + L::O_ZB + OY);
@@ -390,27 +411,13 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
     double at[T1], ar[T2];
     auto materialize_at = [&](const Co &co) {
         const double ej = sm[L::O_EV + (co.j1 < NP ? co.j1 : 0)];
-        const double2 *d2 = reinterpret_cast<const double2 *>(sm + L::O_DV + T1 * co.c1);
-#pragma unroll
-        for (int k = 0; k < T1 / 2; k++) {
-            const int ix0 = idx_at[(2 * k) * NT + co.t], ix1 = idx_at[(2 * k + 1) * NT + co.t];
-            const double2 d = d2[k];
-            at[2 * k] = ix0 >= 0 ? -vals[ix0] * (d.x * ej) : 0.0;
-            at[2 * k + 1] = ix1 >= 0 ? -vals[ix1] * (d.y * ej) : 0.0;
-            if (k % 4 == 3) __builtin_amdgcn_sched_barrier(0);       // bounded number of loads in flight (register peak)
-        }
+        const double *dv = sm + L::O_DV + T1 * co.c1;
+        for_each_idx<T1>(idx_at, co.t, [&](auto, int k, int ix) { at[k] = ix >= 0 ? -vals[ix] * (dv[k] * ej) : 0.0; });
     };
     auto materialize_ar = [&](const Co &co) {
         const double di = sm[L::O_DV + (co.i2 < MP ? co.i2 : 0)];
-        const double2 *e2 = reinterpret_cast<const double2 *>(sm + L::O_EV + T2 * co.c2);
-#pragma unroll
-        for (int k = 0; k < T2 / 2; k++) {
-            const int ix0 = idx_ar[(2 * k) * NT + co.t], ix1 = idx_ar[(2 * k + 1) * NT + co.t];
-            const double2 ee = e2[k];
-            ar[2 * k] = ix0 >= 0 ? -vals[ix0] * (di * ee.x) : 0.0;
-            ar[2 * k + 1] = ix1 >= 0 ? -vals[ix1] * (di * ee.y) : 0.0;
-            if (k % 4 == 3) __builtin_amdgcn_sched_barrier(0);
-        }
+        const double *evs = sm + L::O_EV + T2 * co.c2;
+        for_each_idx<T2>(idx_ar, co.t, [&](auto, int k, int ix) { ar[k] = ix >= 0 ? -vals[ix] * (di * evs[k]) : 0.0; });
     };
     // P-hat row segment of the (jg, cg) layout, re-materialised wherever it is needed (S formation, P-hat g_x, the residual check)
     double gPg = 0;                                                  // g_x^T P-hat g_x
@@ -418,14 +425,8 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
     auto materialize_p = [&](const Co &co, double (&pg)[TG]) {
         const double *pv = Pvals_g + (size_t)blockIdx.x * nnzP;
         const double ej = sm[L::O_EV + (co.jg < NP ? co.jg : 0)];
-        const double2 *e2 = reinterpret_cast<const double2 *>(sm + L::O_EV + TG * co.cg);
-#pragma unroll
-        for (int k = 0; k < TG / 2; k++) {
-            const int ix0 = idx_p[(2 * k) * NT + co.t], ix1 = idx_p[(2 * k + 1) * NT + co.t];
-            const double2 ee = e2[k];
-            pg[2 * k] = ix0 >= 0 ? pv[ix0] * (ej * ee.x) : 0.0;
-            pg[2 * k + 1] = ix1 >= 0 ? pv[ix1] * (ej * ee.y) : 0.0;
-        }
+        const double *evs = sm + L::O_EV + TG * co.cg;
+        for_each_idx<TG>(idx_p, co.t, [&](auto, int k, int ix) { pg[k] = ix >= 0 ? pv[ix] * (ej * evs[k]) : 0.0; });
     };
     // The column groups j1 == n and j1 == n + 1 (idle in the A^T product) carry phi as two extra "columns", so that the
     // A^T w_y phase also yields phi_y . w_y and phi_x . w_x (the numerator of tau-tilde) without a separate reduction.
@@ -698,7 +699,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
                     const double mm = uniform_d(r[2] + 1e-8 * sqrt(r[0]) * sqrt(r[1]));
                     const double gam = uniform_d(r[3] / mm);
                     if (ev) { aaXP[ve] = xv; aaFP[ve] = fv; }
-                    if (fabs(mm) > 1e-300 && fabs(gam) < 1e10) {
+                    if ((__double2hiint(mm) & 0x7fffffff) > 0x01b00000 /* |mm| > ~1e-300, without an fp64 literal */ && fabs(gam) < 1e10) {
                         if (ev) { aaFS[ve] = fv; aaXS[ve] = xv; sm[L::O_W + ve] = fv - gam * dv; }
                         if (threadIdx.x == 0) sc[8] = sqrt(r[4]);
                         aa_pending = true;
@@ -879,10 +880,10 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
                 const double dp = fmax(fmax(nax, ns), nrm_b0 * tau), dd = fmax(fmax(naty, nrm_c0 * tau), nPx);
                 const double rel_p = rp / (dp > 0 ? dp : 1), rel_d = rd / (dd > 0 ? dd : 1);
                 if (rel_p > 0 && rel_d > 0 && isfinite(rel_p) && isfinite(rel_d)) {
-                    const double sum_log = uniform_d(sc[SC_SUMLOG]) + log(rel_p) - log(rel_d); n_log++;
+                    const double sum_log = uniform_d(sc[SC_SUMLOG]) + ce_log(rel_p, mtab) - ce_log(rel_d, mtab); n_log++;
                     __syncthreads();                 // everyone has read SC_SUMLOG before it is rewritten
                     sc[SC_SUMLOG] = sum_log;
-                    const double factor = sqrt(exp(sum_log / n_log));
+                    const double factor = ce_exp(0.5 * sum_log / n_log, mtab);          // sqrt(exp(sum_log / n_log))
                     if (iter - last_scale_iter >= RESCALING_MIN_ITERS) {
                         const double ns2 = fmin(fmax(scale * factor, MIN_SCALE_VALUE), MAX_SCALE_VALUE);
                         if (ns2 != scale && (factor > sqrt(10.0) || factor < 1.0 / sqrt(10.0))) {

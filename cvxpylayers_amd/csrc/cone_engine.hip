@@ -143,7 +143,7 @@ static F2Dims f2_dims(int v) {
     const int *V = F2_VARIANTS[v];
     F2Dims d; d.MP = V[0] * V[1]; d.NPa = V[2] * V[3]; d.NPg = V[4] * V[5]; d.NP = std::max(d.NPa, d.NPg); d.VP = d.MP + d.NP + 2;
     const int nw = V[6] / 64;
-    d.O_G = 6 * d.VP + 2 * d.MP + 8 * d.NP + nw * 8 + nw + 16;
+    d.O_G = 6 * d.VP + 2 * d.MP + 8 * d.NP + nw * 8 + nw + 16 + 20;      // (+20: the ce_math.h table, F2::O_MT)
     return d;
 }
 // leading dimension of G in LDS: smallest even ld >= NPg for which the 16 lanes of an LDS group (CHG segments x 16/CHG rows)
@@ -266,13 +266,14 @@ int ce_create(const ce_template *tpl, int device, ce_handle *out) {
             if (!f2_fits(T, v, &ldg, &by, has_p)) continue;
             const int *V = F2_VARIANTS[v];
             const int CHT = V[0], T1 = V[1], CHA = V[2], T2 = V[3], NTH = V[6];
-            std::vector<int> pos((size_t)T.m * T.n, -1), ib(T.m, -1), iat((size_t)T1 * NTH, -1), iar((size_t)T2 * NTH, -1);
+            const int S1 = (T1 + 3) & ~3, S2 = (T2 + 3) & ~3;       // thread-major gather maps, rows padded to 16 bytes (ce_forward_v2.h idx_stride)
+            std::vector<int> pos((size_t)T.m * T.n, -1), ib(T.m, -1), iat((size_t)S1 * NTH, -1), iar((size_t)S2 * NTH, -1);
             for (int j = 0; j <= T.n; j++)
                 for (int k = tpl->indptr[j]; k < tpl->indptr[j + 1]; k++) { if (j < T.n) pos[(size_t)tpl->indices[k] * T.n + j] = k; else ib[tpl->indices[k]] = k; }
             for (int t = 0; t < NTH; t++) {
                 const int j1 = t / CHT, c1 = t % CHT, i2 = t / CHA, c2 = t % CHA;
-                for (int k = 0; k < T1; k++) { const int r = T1 * c1 + k; if (j1 < T.n && r < T.m) iat[(size_t)k * NTH + t] = pos[(size_t)r * T.n + j1]; }
-                for (int k = 0; k < T2; k++) { const int c = T2 * c2 + k; if (i2 < T.m && c < T.n) iar[(size_t)k * NTH + t] = pos[(size_t)i2 * T.n + c]; }
+                for (int k = 0; k < T1; k++) { const int r = T1 * c1 + k; if (j1 < T.n && r < T.m) iat[(size_t)t * S1 + k] = pos[(size_t)r * T.n + j1]; }
+                for (int k = 0; k < T2; k++) { const int c = T2 * c2 + k; if (i2 < T.m && c < T.n) iar[(size_t)t * S2 + k] = pos[(size_t)i2 * T.n + c]; }
             }
             HIPCHK(hipMalloc(&h->d_idx_at, sizeof(int) * iat.size())); HIPCHK(hipMalloc(&h->d_idx_ar, sizeof(int) * iar.size())); HIPCHK(hipMalloc(&h->d_idx_b, sizeof(int) * T.m));
             HIPCHK(hipMemcpy(h->d_idx_at, iat.data(), sizeof(int) * iat.size(), hipMemcpyHostToDevice));
@@ -286,11 +287,12 @@ int ce_create(const ce_template *tpl, int device, ce_handle *out) {
             }
             if (has_p) {      // gather map of the (jg, cg) tile layout and the dense n x n entry map
                 const int CHG = V[4], TG = V[5];
-                std::vector<int> pmap((size_t)T.n * T.n, -1), ip((size_t)TG * NTH, -1);
+                const int SG = (TG + 3) & ~3;
+                std::vector<int> pmap((size_t)T.n * T.n, -1), ip((size_t)SG * NTH, -1);
                 for (int k = 0; k < h->nnz_p; k++) { pmap[(size_t)h->p_rows[k] * T.n + h->p_cols[k]] = k; if (h->p_tri) pmap[(size_t)h->p_cols[k] * T.n + h->p_rows[k]] = k; }
                 for (int t = 0; t < NTH; t++) {
                     const int jg = t / CHG, cg = t % CHG;
-                    for (int k = 0; k < TG; k++) { const int c = TG * cg + k; if (jg < T.n && c < T.n) ip[(size_t)k * NTH + t] = pmap[(size_t)jg * T.n + c]; }
+                    for (int k = 0; k < TG; k++) { const int c = TG * cg + k; if (jg < T.n && c < T.n) ip[(size_t)t * SG + k] = pmap[(size_t)jg * T.n + c]; }
                 }
                 HIPCHK(hipMalloc(&h->d_idx_p, sizeof(int) * ip.size())); HIPCHK(hipMalloc(&h->d_pmap, sizeof(int) * pmap.size()));
                 HIPCHK(hipMalloc(&h->d_prow, sizeof(int) * h->nnz_p)); HIPCHK(hipMalloc(&h->d_pcol, sizeof(int) * h->nnz_p));

@@ -93,3 +93,45 @@ def test_device_power_cone_routines_match_oracle(host):
         host.h_peig(_p(v.copy()), a, _p(W), _p(th))
         Sd = oracle.dproj_pow(v, a, dual=True); Sd = (Sd + Sd.T) / 2
         assert np.abs(W @ np.diag(th) @ W.T - Sd).max() < 1e-6 and np.abs(W.T @ W - np.eye(3)).max() < 1e-12, (v, a)
+
+
+MATH_SRC = r'''
+#include <cmath>
+#include <cstring>
+#define __device__
+#define __forceinline__ inline
+#define CE_MATH_HOST
+static inline int ce_fexp(double x) { int e; std::frexp(x, &e); return e; }
+static inline double ce_fmant(double x) { int e; return std::frexp(x, &e); }
+static inline double ce_bits(unsigned long long b) { double d; std::memcpy(&d, &b, 8); return d; }
+#define CE_FREXP_EXP(x) ce_fexp(x)
+#define CE_FREXP_MANT(x) ce_fmant(x)
+#define CE_BITS_TO_DOUBLE(b) ce_bits(b)
+using std::rint; using std::ldexp;
+#include "ce_math.h"
+extern "C" {
+void h_logexp(const double *x, int n, double *lg, double *ex) {
+    double tab[CE_MATH_TAB];
+    for (int t = 0; t < CE_MATH_TAB; t++) ce_math_table_init(tab, t);
+    for (int i = 0; i < n; i++) { lg[i] = x[i] > 0 ? ce_log(x[i], tab) : 0.0; ex[i] = std::fabs(x[i]) < 700 ? ce_exp(x[i], tab) : 0.0; }
+}
+}
+'''
+
+
+def test_table_log_exp_match_libm(tmp_path):
+    """ce_math.h (the adaptive-scale update's log / exp with coefficients in an LDS table): within 1 ulp-class error of libm over
+    the ranges the solver feeds them (ratios of residuals, 1e-300 .. 1e300; exponents of a few tens)."""
+    (tmp_path / "m.cpp").write_text(MATH_SRC)
+    so = str(tmp_path / "libm_host.so")
+    subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-shared", "-fPIC", "-I", os.path.join(ROOT, "cvxpylayers_amd", "csrc"), "-o", so, str(tmp_path / "m.cpp")])
+    L = C.CDLL(so)
+    rng = np.random.default_rng(0)
+    x = np.concatenate([10.0 ** rng.uniform(-300, 300, 20000), rng.uniform(0.4, 2.5, 20000), [5e-324, 1e-310, 1.0, 2.0, 0.5]])
+    lg = np.zeros_like(x); ex = np.zeros_like(x)
+    L.h_logexp(_p(x), len(x), _p(lg), _p(ex))
+    assert np.abs(lg - np.log(x)).max() <= 4e-16 * np.abs(np.log(x)).max() and np.abs((lg - np.log(x))[-3:]).max() <= 1.2e-16
+    y = np.concatenate([rng.uniform(-60, 60, 20000), rng.uniform(-1e-3, 1e-3, 1000), [0.0]])
+    lg = np.zeros_like(y); ex = np.zeros_like(y)
+    L.h_logexp(_p(y), len(y), _p(lg), _p(ex))
+    assert (np.abs(ex - np.exp(y)) / np.exp(y)).max() <= 4e-16

