@@ -33,6 +33,11 @@ struct F2 {
     static constexpr int O_BV = 6 * VP, O_DV = O_BV + MP, O_CV = O_DV + MP, O_EV = O_CV + NP, O_TV = O_EV + NP, O_PX = O_TV + NP,
                          O_S1 = O_PX + NP, O_S2 = O_S1 + NP, O_S3 = O_S2 + NP, O_S4 = O_S3 + NP,
                          O_RED = O_S4 + NP, O_WP = O_RED + NWARP * 8, O_SC = O_WP + NWARP, O_MT = O_SC + 16, O_G = O_MT + 20;      // O_MT: ce_math.h coefficient table
+    // S = A^T Dy A on the matrix cores: NTILE column tiles of 16, row panels of A-hat staged with pitch LDP (= 16 mod 32 doubles: the
+    // two row groups of a 32-lane LDS pass fall 128 bytes apart).  The G region holds at least one panel of 4 rows.
+    static constexpr int NTILE = (NPg + 15) / 16;
+    static constexpr int LDP = (16 * NTILE) % 32 == 16 ? 16 * NTILE : 16 * NTILE + 16;
+    static_assert(NTILE <= NWARP && LDP >= NPa, "one 16-row strip of S per wave; a panel row holds a whole row tile");
     static_assert(T1 % 2 == 0 && T2 % 2 == 0 && TG % 2 == 0, "segments must be even for 16-byte LDS reads");
     static_assert(CHT <= 16 && CHA <= 16 && CHG <= 16, "DPP butterflies stay inside a row of 16 lanes");
 };
@@ -258,6 +263,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
     const int tid = threadIdx.x, inst = blockIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = T.n, m = T.m, l = n + m + 1, ldg = T.ldg, nq = T.nq, z = T.z;
+    const int gsz = max(n * ldg, 4 * L::LDP);                      // doubles of the G region (cone_engine.hip f2_fits sizes it the same way)
     const double *const vals = Avals + (size_t)inst * T.nnz_aug;
 
 #ifdef CE_TIMING
@@ -421,7 +427,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
     };
     // P-hat row segment of the (jg, cg) layout, re-materialised wherever it is needed (S formation, P-hat g_x, the residual check)
     double gPg = 0;                                                  // g_x^T P-hat g_x
-    double *const PgV = Gm + n * ldg;                                // [NP] P-hat g_x   (HASP only; dynamic tail of the LDS carve)
+    double *const PgV = Gm + gsz;                                // [NP] P-hat g_x   (HASP only; dynamic tail of the LDS carve)
     auto materialize_p = [&](const Co &co, double (&pg)[TG]) {
         const double *pv = Pvals_g + (size_t)blockIdx.x * nnzP;
         const double ej = sm[L::O_EV + (co.jg < NP ? co.jg : 0)];
@@ -451,35 +457,59 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
         double sreg[TG];
 #pragma unroll
         for (int s = 0; s < TG; s++) sreg[s] = 0.0;
-        // S = A^T Dy A from row panels staged through the G region (row pitch NP)
+        // S = A-hat^T Dy A-hat on the matrix cores (v_mfma_f64_16x16x4_f64).  Row panels of A-hat are staged through the (not yet used)
+        // G region with pitch LDP; wave w accumulates the 16-row strip S[16w .. 16w+15][:] as NTILE tiles of 16 x 16:
+        //     D[M][N] += sum_K A[M][K] B[K][N],   A[M][K] = A-hat[i0 + K][16w + M] dy(i0 + K),   B[K][N] = A-hat[i0 + K][16J + N],
+        // four panel rows per instruction; lane l supplies A[l & 15][l >> 4] and B[l >> 4][l & 15], i.e. BOTH operands are the panel
+        // entry (row i0 + (l >> 4), column 16 * tile + (l & 15)): one ds_read_b64 per operand, 16 contiguous doubles per row group and
+        // (LDP = 16 mod 32 doubles) the two row groups of a 32-lane LDS pass 128 bytes apart: conflict-free.  Accumulator layout
+        // (MI355X guide, f64 MFMA): register r of lane l holds D[(l >> 4) + 4 r][l & 15].
         {
-            constexpr int LDP = NP;
-            const int PR = min(m, (n * ldg) / LDP);            // rows per panel
-            if constexpr (L::NPa < NP) {   // panel columns the row tiles do not cover stay zero
-                for (int i = tid; i < PR * (NP - L::NPa); i += NT) Gm[(i / (NP - L::NPa)) * LDP + L::NPa + i % (NP - L::NPa)] = 0.0;
-            }
+            constexpr int NTILE = L::NTILE, LDP = L::LDP;
+            typedef double v4d __attribute__((ext_vector_type(4)));
+            v4d acc[NTILE];
+#pragma unroll
+            for (int J = 0; J < NTILE; J++) acc[J] = v4d{0.0, 0.0, 0.0, 0.0};
+            const int PR = (gsz / LDP) & ~3;                   // rows per panel (a multiple of the MFMA depth 4)
+            const int lane = tid & 63, lg = lane >> 4, lc = lane & 15;
             for (int p0 = 0; p0 < m; p0 += PR) {
-                const int p1 = min(m, p0 + PR);
+                const int p1 = min(m, p0 + PR), rows4 = (p1 - p0 + 3) & ~3;
                 if (i2 >= p0 && i2 < p1) {
                     double2 *dst = reinterpret_cast<double2 *>(Gm + (i2 - p0) * LDP + T2 * c2);
 #pragma unroll
                     for (int k = 0; k < T2 / 2; k++) dst[k] = make_double2(ar[2 * k], ar[2 * k + 1]);
                 }
+                // columns the row tiles do not cover, and the rows that pad the panel to a multiple of 4, are zero
+                for (int i = tid; i < (p1 - p0) * (LDP - L::NPa); i += NT) Gm[(i / (LDP - L::NPa)) * LDP + L::NPa + i % (LDP - L::NPa)] = 0.0;
+                for (int i = tid; i < (rows4 - (p1 - p0)) * LDP; i += NT) Gm[(p1 - p0) * LDP + i] = 0.0;
                 __syncthreads();
-                if (jg < n) {
-                    const double *r = Gm;
-#pragma unroll 2
-                    for (int i = p0; i < p1; i++, r += LDP) {
-                        const double aj = r[jg] * dyv(i);
-                        const double2 *r2 = reinterpret_cast<const double2 *>(r + TG * cg);
+                if (wave < NTILE) {
+                    const double *prow = Gm + lg * LDP + lc;
+                    for (int i0 = 0; i0 < rows4; i0 += 4, prow += 4 * LDP) {
+                        const double a = prow[16 * wave] * dyv(p0 + i0 + lg);
 #pragma unroll
-                        for (int s = 0; s < TG / 2; s++) { const double2 v = r2[s]; sreg[2 * s] = fma(v.x, aj, sreg[2 * s]); sreg[2 * s + 1] = fma(v.y, aj, sreg[2 * s + 1]); }
+                        for (int J = 0; J < NTILE; J++) acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, prow[16 * J], acc[J], 0, 0, 0);
                     }
                 }
                 __syncthreads();
             }
+            // S (rows and columns < n) to LDS, row-major with pitch ldg, then into the (jg, cg) register tile of the inversion
+            if (wave < NTILE) {
 #pragma unroll
-            for (int s = 0; s < TG; s++) if (jg < n && TG * cg + s == jg) sreg[s] += rho_x;
+                for (int J = 0; J < NTILE; J++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int row = 16 * wave + lg + 4 * r, col = 16 * J + lc;
+                        if (row < n && col < L::NPg) Gm[row * ldg + col] = acc[J][r] + (row == col ? rho_x : 0.0);
+                    }
+            }
+            __syncthreads();
+            if (jg < n) {
+                const double2 *src = reinterpret_cast<const double2 *>(Gm + jg * ldg + TG * cg);
+#pragma unroll
+                for (int s = 0; s < TG / 2; s++) { const double2 v = src[s]; sreg[2 * s] = v.x; sreg[2 * s + 1] = v.y; }
+            }
+            __syncthreads();
             if constexpr (HASP) {
                 double pg[TG];
                 materialize_p(co, pg);
@@ -627,7 +657,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
     // step is undone and the history dropped.  Vectors (VP doubles each) live in the dynamic tail of the LDS carve.
     const bool aa_on = S.acceleration_lookback > 0;
     const int aa_int = S.acceleration_interval;
-    double *const aaWP = Gm + n * ldg + (PSD ? ((T.ns > 0 ? 2 * T.maxs * T.maxs + 2 * T.maxs + 8 : 0) + T.nep + T.np) : 0) + (HASP ? NP : 0);
+    double *const aaWP = Gm + gsz + (PSD ? ((T.ns > 0 ? 2 * T.maxs * T.maxs + 2 * T.maxs + 8 : 0) + T.nep + T.np) : 0) + (HASP ? NP : 0);
     double *const aaXP = aaWP + VP, *const aaFP = aaXP + VP, *const aaFS = aaFP + VP, *const aaXS = aaFS + VP;
     int aa_iter = 0; bool aa_pending = false;      // (|g| before the step lives in sc[8]: no register across the loop)
     const bool big_soc = T.maxq > SOC_SMALL;
@@ -787,10 +817,10 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
             __syncthreads();
         }
         if constexpr (PSD) {   // PSD blocks of the cone input are projected in place (all threads, one cone after the other)
-            double *psdS = Gm + n * ldg, *psdV = psdS + T.maxs * T.maxs, *psdC = psdV + T.maxs * T.maxs;
+            double *psdS = Gm + gsz, *psdV = psdS + T.maxs * T.maxs, *psdC = psdV + T.maxs * T.maxs;
             for (int c = 0; c < T.ns; c++) psd_project<NTH>(sm + L::O_ZB + OY + T.soff[c], T.sord[c], psdS, psdV, psdC, red);
             if (T.nep + T.np > 0) {   // exponential / power cones: one thread per cone, root warm-started from the previous iteration (ce_expcone.h)
-                double *expR = Gm + n * ldg + (T.ns > 0 ? 2 * T.maxs * T.maxs + 2 * T.maxs + 8 : 0);
+                double *expR = Gm + gsz + (T.ns > 0 ? 2 * T.maxs * T.maxs + 2 * T.maxs + 8 : 0);
                 for (int c = threadIdx.x; c < T.nep + T.np; c += NTH) {
                     double *zc = sm + L::O_ZB + OY + T.eoff + 3 * c;
                     if (c < T.nep) exp_project_dual(zc, expR + c); else pow_project_dual_of_entry(zc, T.pw[c - T.nep], expR + c);
