@@ -263,7 +263,8 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
     const int tid = threadIdx.x, inst = blockIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = T.n, m = T.m, l = n + m + 1, ldg = T.ldg, nq = T.nq, z = T.z;
-    const int gsz = max(n * ldg, 4 * L::LDP);                      // doubles of the G region (cone_engine.hip f2_fits sizes it the same way)
+    const int gsz = max(max(n * ldg, 4 * L::LDP), 16 * NP);        // doubles of the G region: G itself, one 4-row panel of the S formation, the exchange
+                                                                   // buffers of the blocked inversion (cone_engine.hip f2_fits sizes it the same way)
     const double *const vals = Avals + (size_t)inst * T.nnz_aug;
 
 #ifdef CE_TIMING
@@ -518,53 +519,98 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
             }
         }
         F2_STAMP(8);
-        // Gauss-Jordan inversion on the register tile; pivot order k = kk + TG*cgk (kk static).  Pivot row / column are
-        // published through LDS, double buffered: row -> S1/S3, column -> S2/S4.
-        auto publish = [&](auto slot_c, int cgn, int bufn) {
-            constexpr int slot = decltype(slot_c)::value;
-            const int kn = TG * cgn + slot;
-            double *rowk = sm + (bufn ? L::O_S3 : L::O_S1), *colk = sm + (bufn ? L::O_S4 : L::O_S2);
-            if (jg < n && cg == cgn) colk[jg] = sreg[slot];
-            if (jg == kn) {
-                double2 *dst = reinterpret_cast<double2 *>(rowk + TG * cg);
+        // BLOCKED Gauss-Jordan inversion on the register tile: four pivots per workgroup barrier.  Block order: slots kk0 = 0, 4, 8, ...
+        // (static), inside a slot block the lane groups cgk = 0, 1, ... that still hold a pivot < n; block K = columns / rows
+        // k0 .. k0 + 3, k0 = TG cgk + kk0.  With C = S[:, K], R = S[K, :] (published through LDS, double buffered in the idle G
+        // region) and P = S[K, K]^-1 (4 x 4, every thread inverts it itself: no second barrier):
+        //     rows outside K :  S[i, :] += w R,  w = -C[i, :] P,   S[i, K] = w        rows in K :  S[q, :] = P[q, :] R,  S[q, K] = P[q, :]
+        // A block that runs past n (or past the slot count TG) is padded with the identity.  One barrier per block instead of one
+        // per pivot (round 1: 50 barriers, 72 k cycles of a 183 k cycle refactor at the metric configuration).
+        constexpr int NBLK = (TG + 3) / 4;
+        auto rbuf = [&](int b) -> double * { return Gm + b * (8 * NP); };              // 4 rows of NP
+        auto cbuf = [&](int b) -> double * { return Gm + b * (8 * NP) + 4 * NP; };     // NP rows of 4
+        auto publish = [&](auto blk_c, int cgn, int bufn) {
+            constexpr int kk0 = 4 * decltype(blk_c)::value;
+            const int k0 = TG * cgn + kk0;
+            if (jg < n && cg == cgn) {           // (TG is even: a block has 4 or 2 slots; the missing pair is treated as zero by the reader)
+                double2 *dst = reinterpret_cast<double2 *>(cbuf(bufn) + 4 * jg);
+                dst[0] = make_double2(sreg[kk0], sreg[kk0 + 1]);
+                if constexpr (kk0 + 3 < TG) dst[1] = make_double2(sreg[kk0 + 2], sreg[kk0 + 3]);
+            }
+            if (jg >= k0 && jg < k0 + (TG - kk0 < 4 ? TG - kk0 : 4) && jg < n) {
+                double2 *dst = reinterpret_cast<double2 *>(rbuf(bufn) + (jg - k0) * NP + TG * cg);
 #pragma unroll
                 for (int s = 0; s < TG / 2; s++) dst[s] = make_double2(sreg[2 * s], sreg[2 * s + 1]);
             }
         };
+        for (int i = tid; i < 16 * NP; i += NT) Gm[i] = 0.0;          // stale panel data out of the exchange buffers (padding rows are read)
+        __syncthreads();
         int cnt = 0;
         publish(std::integral_constant<int, 0>{}, 0, 0);
         __syncthreads();
-        static_for<TG>([&](auto kkc) {
-            constexpr int kk = decltype(kkc)::value;
-            const int nv = (kk < n) ? (n - 1 - kk) / TG + 1 : 0;        // pivots of this slot: cgk = 0 .. nv-1
-            const int nvn = (kk + 1 < TG && kk + 1 < n) ? 1 : 0;        // does the next slot have a pivot?
+        static_for<NBLK>([&](auto blk_c) {
+            constexpr int blk = decltype(blk_c)::value, kk0 = 4 * blk;
+            constexpr int NBS = (TG - kk0) < 4 ? (TG - kk0) : 4;                         // slots of this block that exist
+            const int nv = (kk0 < n) ? (n - 1 - kk0) / TG + 1 : 0;                       // lane groups with a pivot in this block
+            const int nvn = (kk0 + 4 < TG && kk0 + 4 < n) ? 1 : 0;                       // does the next block have one?
             for (int cgk = 0; cgk < nv; cgk++) {
-                const int k = TG * cgk + kk, buf = cnt & 1;
-                const double *rowk = sm + (buf ? L::O_S3 : L::O_S1), *colk = sm + (buf ? L::O_S4 : L::O_S2);
+                const int k0 = TG * cgk + kk0, buf = cnt & 1;
+                const int nbv = min(NBS, n - k0);                                        // pivots of this block (the rest: identity)
+                const double *rb = rbuf(buf), *cb = cbuf(buf);
                 if (jg < n) {
-                    const double pv = rowk[k];
-                    if constexpr (HASP) { if (jg == k && cg == 0 && !(pv > 0)) sc[7] = 1.0; }     // S not positive definite: P is not PSD
-                    double pinv = __builtin_amdgcn_rcp(pv);                 // seed + two Newton steps instead of the IEEE divide
-                    pinv = fma(fma(-pv, pinv, 1.0), pinv, pinv);            // expansion: it sits on the critical path of every pivot
-                    pinv = fma(fma(-pv, pinv, 1.0), pinv, pinv);
-                    const bool prow_thread = (jg == k);
-                    const double cj0 = colk[jg] * pinv;
-                    const double2 *r2 = reinterpret_cast<const double2 *>(rowk + TG * cg);
-                    if (prow_thread) {      // divergent only in the one wave that holds the pivot row
+                    double a[4][4];
 #pragma unroll
-                        for (int s2 = 0; s2 < TG / 2; s2++) { const double2 rv = r2[s2]; sreg[2 * s2] = rv.x * pinv; sreg[2 * s2 + 1] = rv.y * pinv; }
-                    } else {
+                    for (int q = 0; q < 4; q++)
 #pragma unroll
-                        for (int s2 = 0; s2 < TG / 2; s2++) {
-                            const double2 rv = r2[s2];
-                            sreg[2 * s2] = fma(-cj0, rv.x, sreg[2 * s2]);
-                            sreg[2 * s2 + 1] = fma(-cj0, rv.y, sreg[2 * s2 + 1]);
+                        for (int q2 = 0; q2 < 4; q2++) a[q][q2] = (q < nbv && q2 < nbv) ? rb[q * NP + k0 + q2] : (q == q2 ? 1.0 : 0.0);
+                    bool bad = false;
+#pragma unroll
+                    for (int p = 0; p < 4; p++) {      // in-place inverse of the 4 x 4 block (no pivoting: S is positive definite)
+                        const double pv = a[p][p];
+                        bad = bad || !(pv > 0);
+                        double pinv = __builtin_amdgcn_rcp(pv);                 // seed + two Newton steps instead of the IEEE divide
+                        pinv = fma(fma(-pv, pinv, 1.0), pinv, pinv);
+                        pinv = fma(fma(-pv, pinv, 1.0), pinv, pinv);
+#pragma unroll
+                        for (int j = 0; j < 4; j++) if (j != p) a[p][j] *= pinv;
+#pragma unroll
+                        for (int i = 0; i < 4; i++) if (i != p) {
+                            const double f = a[i][p];
+#pragma unroll
+                            for (int j = 0; j < 4; j++) if (j != p) a[i][j] = fma(-f, a[p][j], a[i][j]);
+                            a[i][p] = -f * pinv;
                         }
+                        a[p][p] = pinv;
                     }
-                    if (cg == cgk) sreg[kk] = prow_thread ? pinv : -cj0;       // the pivot column itself
+                    if constexpr (HASP) { if (bad && jg == k0 && cg == 0) sc[7] = 1.0; }     // S not positive definite: P is not PSD
+                    const double2 c01 = reinterpret_cast<const double2 *>(cb + 4 * jg)[0];
+                    double2 c23 = make_double2(0.0, 0.0);
+                    if constexpr (NBS > 2) c23 = reinterpret_cast<const double2 *>(cb + 4 * jg)[1];
+                    const int qrow = jg - k0;
+                    const bool prow_thread = (qrow >= 0 && qrow < NBS);
+                    double w[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const double wc = -(c01.x * a[0][q] + c01.y * a[1][q] + c23.x * a[2][q] + c23.y * a[3][q]);
+                        const double wp = qrow == 0 ? a[0][q] : (qrow == 1 ? a[1][q] : (qrow == 2 ? a[2][q] : a[3][q]));
+                        w[q] = prow_thread ? wp : wc;
+                    }
+                    const double2 *r0 = reinterpret_cast<const double2 *>(rb + TG * cg), *r1 = reinterpret_cast<const double2 *>(rb + NP + TG * cg),
+                                  *r2 = reinterpret_cast<const double2 *>(rb + 2 * NP + TG * cg), *r3 = reinterpret_cast<const double2 *>(rb + 3 * NP + TG * cg);
+#pragma unroll
+                    for (int s2 = 0; s2 < TG / 2; s2++) {
+                        const double2 v0 = r0[s2], v1 = r1[s2], v2 = r2[s2], v3 = r3[s2];
+                        const double bx = prow_thread ? 0.0 : sreg[2 * s2], by = prow_thread ? 0.0 : sreg[2 * s2 + 1];
+                        sreg[2 * s2] = fma(w[3], v3.x, fma(w[2], v2.x, fma(w[1], v1.x, fma(w[0], v0.x, bx))));
+                        sreg[2 * s2 + 1] = fma(w[3], v3.y, fma(w[2], v2.y, fma(w[1], v1.y, fma(w[0], v0.y, by))));
+                    }
+                    if (cg == cgk) {
+#pragma unroll
+                        for (int q = 0; q < NBS; q++) sreg[kk0 + q] = w[q];       // the block columns themselves
+                    }
                 }
-                if (cgk + 1 < nv) publish(std::integral_constant<int, kk>{}, cgk + 1, buf ^ 1);
-                else if (nvn) publish(std::integral_constant<int, (kk + 1 < TG ? kk + 1 : kk)>{}, 0, buf ^ 1);
+                if (cgk + 1 < nv) publish(std::integral_constant<int, blk>{}, cgk + 1, buf ^ 1);
+                else if (nvn) publish(std::integral_constant<int, (blk + 1 < NBLK ? blk + 1 : blk)>{}, 0, buf ^ 1);
                 cnt++;
                 __syncthreads();
             }

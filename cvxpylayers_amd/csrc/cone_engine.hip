@@ -172,7 +172,7 @@ static bool f2_fits(const DevT &T, int v, int *ldg, size_t *bytes, bool has_p = 
     if ((size_t)T.n * *ldg < (size_t)d.NPa) return false;
     const size_t psd = (T.ns > 0 ? 2 * (size_t)T.maxs * T.maxs + 2 * (size_t)T.maxs + 8 : 0) + (size_t)(T.nep + T.np);      // Jacobi scratch: S, V, (c, s, p, q) per pair; one root per exponential cone
     const int ntile = (d.NPg + 15) / 16, ldp = (16 * ntile) % 32 == 16 ? 16 * ntile : 16 * ntile + 16;      // F2::NTILE, F2::LDP
-    const size_t gsz = std::max((size_t)T.n * *ldg, (size_t)4 * ldp);                                        // G region: also one 4-row panel of the S formation
+    const size_t gsz = std::max(std::max((size_t)T.n * *ldg, (size_t)4 * ldp), (size_t)16 * d.NP);                                        // G region: also one 4-row panel of the S formation
     *bytes = ((size_t)d.O_G + d.MP /* SOC row info (2 int arrays) */ + gsz + psd + (has_p ? d.NP : 0) /* P-hat g_x */) * 8;
     return *bytes <= LDS_LIMIT;
 }
