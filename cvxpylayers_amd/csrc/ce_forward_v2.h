@@ -120,6 +120,15 @@ __device__ __forceinline__ void for_each_idx(const int *__restrict__ base, int t
     }
 }
 
+// Orders LDS writes of this wave before LDS reads of this wave (other lanes' data).  LDS instructions of one wave execute in order,
+// so no hardware wait is needed beyond what the compiler inserts for the data dependence; the fences keep the COMPILER from moving
+// the reads above the writes.
+__device__ __forceinline__ void wave_lds_exchange() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // thread coordinates, re-derived from an opaque copy of the thread id wherever they are needed: they then are short-lived
 // values (a handful of VALU ops) instead of kernel-lived registers competing with the tiles
 template <int CHT, int CHA, int CHG>
@@ -241,13 +250,20 @@ __device__ __forceinline__ void psd_project(double *zsvec, int k, double *Sm, do
 // KKT matrix S = rho_x I + P-hat + A-hat^T Dy A-hat, tau-tilde becomes the positive root of a quadratic, the dual residual and
 // the gap get their P terms.  Pvals: (B, nnzP) values in the template's P structure; idx_p: gather map of the (jg, cg) tile
 // layout of G (row jg, columns TG*cg + k), -1 = structural zero (one-triangle structures map (i,j) and (j,i) to one entry).
-template <int CHT, int T1, int CHA, int T2, int CHG, int TG, bool PSD = false, int NTH = 256, bool HASP = false>
+// WL ("wave-local cones"): the host has ordered the rows so that no cone block straddles the rows of two waves in the (i2, c2) row
+// layout (cone_engine.hip pack_rows; nonnegative rows are the filler and count as cones of dimension 1; row_perm maps kernel rows
+// back to the template's rows).  A row thread then exchanges its cone's values with lanes of ITS OWN wave only -- LDS is in
+// order per wave, no workgroup barrier -- which removes one of the two barriers of every equilibration pass and fuses the cone
+// projection + relaxed update into the A p_x phase: 3 barriers per iteration instead of 4.
+template <int CHT, int T1, int CHA, int T2, int CHG, int TG, bool PSD = false, int NTH = 256, bool HASP = false, bool WL = false>
 __global__ void __launch_bounds__(NTH, (NTH == 256 ? F2_WPS : 2))
 k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__restrict__ qv, long sqk, long sqb,
        const int *__restrict__ idx_at, const int *__restrict__ idx_ar, const int *__restrict__ idx_b,
        double *__restrict__ xo, double *__restrict__ yo, double *__restrict__ so, int *__restrict__ iters_o,
        int *__restrict__ status_o, double *__restrict__ resid_o,
-       const double *__restrict__ Pvals_g = nullptr, int nnzP = 0, const int *__restrict__ idx_p = nullptr) {
+       const double *__restrict__ Pvals_g = nullptr, int nnzP = 0, const int *__restrict__ idx_p = nullptr,
+       const int *__restrict__ row_perm = nullptr) {
+    static_assert(!(WL && (PSD || HASP)), "wave-local cone exchange: plain cones only");
     constexpr int NT = NTH, NW = NTH / 64;        // threads / waves per workgroup of this instantiation (shadow the file-level defaults)
     using L = F2<CHT, T1, CHA, T2, CHG, TG, NW>;
     using Co = F2Co<CHT, CHA, CHG>;
@@ -355,7 +371,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
                 if (own1) fEt[j1] = 1.0f / sqrtf(clampf(cn));
             }
             if (own2) fRn[i2] = rn;          // raw row norms
-            __syncthreads();
+            if constexpr (WL) wave_lds_exchange(); else __syncthreads();
             if constexpr (HASP) {
                 if (own1) { const float pn = fPn[j1]; fEt[j1] = 1.0f / sqrtf(clampf(l2 ? sqrtf(cn * cn + pn) : fmaxf(cn, pn))); }
             }
@@ -681,7 +697,8 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
         if (e < n) { wx = sg * xo[(size_t)inst_ * n + e] / sm[L::O_EV + e]; bad = !(fabs(wx) < 1e300); }
         for (int i = e; i < m; i += NT) {
             const double dvi = sm[L::O_DV + i];
-            const double v = sg * yo[(size_t)inst_ * m + i] / dvi + sg * dvi * so[(size_t)inst_ * m + i] * dyv(i);
+            const int io = WL ? row_perm[i] : i;                 // kernel row -> template row
+            const double v = sg * yo[(size_t)inst_ * m + io] / dvi + sg * dvi * so[(size_t)inst_ * m + io] * dyv(i);
             bad = bad || !(fabs(v) < 1e300);
         }
         double rb[1] = {bad ? 1.0 : 0.0};
@@ -690,7 +707,8 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
             if (e < n) sm[L::O_W + OX + e] = wx;
             for (int i = e; i < m; i += NT) {
                 const double dvi = sm[L::O_DV + i];
-                sm[L::O_W + OY + i] = sg * yo[(size_t)inst_ * m + i] / dvi + sg * dvi * so[(size_t)inst_ * m + i] * dyv(i);
+                const int io = WL ? row_perm[i] : i;
+                sm[L::O_W + OY + i] = sg * yo[(size_t)inst_ * m + io] / dvi + sg * dvi * so[(size_t)inst_ * m + io] * dyv(i);
             }
         }
     }
@@ -813,6 +831,62 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
             if (owng) sm[L::O_PX + jg] = a;
         }
         __syncthreads();
+        if constexpr (WL) {
+            // P2 + P3 fused: q = A p_x ; tau-tilde ; u-tilde ; cone projection ; relaxed update.  The cone blocks of y are wave-local.
+            const double tau_t = (rtau * sm[L::O_W + OT] + sm[L::O_WP] + sm[L::O_WP + 1]) * inv_den;
+            const double q = seg_dot<CHA, T2>(ar, sm + L::O_PX + T2 * c2);
+            const bool upd = !check && !last;          // fast path: the relaxed update happens here (else after the convergence check)
+            const int ee = OY + i2;
+            double we = 0, ute = 0, ze = 0;
+            int cd = 0;
+            if (own2) {
+                we = sm[L::O_W + ee];
+                const double py = we + dyv(i2) * q;
+                ute = py - tau_t * sm[L::O_GV + ee];
+                ze = 2 * ute - we;
+                cd = socd[i2];                          // 0: zero-cone row (dual free), 1: nonnegative row, > 1: row of an SOC
+                if (cd == 1 && ze < 0) ze = 0;
+                sm[L::O_UT + ee] = ute; sm[L::O_ZB + ee] = ze;
+            }
+            wave_lds_exchange();
+            if (own2) {
+                double ue = ze;
+                if (cd > 1) {
+                    const int soc_r0 = socr[i2];
+                    const double *zc = sm + L::O_ZB + OY + soc_r0;
+                    const double t0 = zc[0];
+                    double q0 = 0, q1 = 0;
+                    for (int k = 1; k < cd; k += 4) {
+                        const double z0 = zc[k], z1 = (k + 1 < cd) ? zc[k + 1] : 0.0, z2 = (k + 2 < cd) ? zc[k + 2] : 0.0, z3 = (k + 3 < cd) ? zc[k + 3] : 0.0;
+                        q0 = fma(z0, z0, q0); q1 = fma(z1, z1, q1); q0 = fma(z2, z2, q0); q1 = fma(z3, z3, q1);
+                    }
+                    const double qq = q0 + q1;
+                    double nz = 0, rinv = 0;
+                    if (qq > 0) sqrt_rsqrt(qq, nz, rinv);
+                    if (nz <= t0) { /* inside */ }
+                    else if (nz <= -t0) ue = 0.0;
+                    else { const double c0 = 0.5 * (t0 + nz); ue = (i2 == soc_r0) ? c0 : ue * (c0 * rinv); }
+                }
+                sm[L::O_U + ee] = ue;
+                if (upd) sm[L::O_W + ee] = we + alpha * (ue - ute);
+            }
+            if (e < n) {
+                const int ex = OX + e;
+                const double wx = sm[L::O_W + ex];
+                const double utx = sm[L::O_PX + e] - tau_t * sm[L::O_GV + ex];
+                const double ux = 2 * utx - wx;
+                sm[L::O_UT + ex] = utx; sm[L::O_U + ex] = ux;
+                if (upd) sm[L::O_W + ex] = wx + alpha * (ux - utx);
+            }
+            if (e == NT - 1) {
+                const double wt = sm[L::O_W + OT];
+                const double ut = fmax(0.0, 2 * tau_t - wt);
+                sm[L::O_UT + OT] = tau_t; sm[L::O_U + OT] = ut;
+                if (upd) sm[L::O_W + OT] = wt + alpha * (ut - tau_t);
+            }
+            __syncthreads();
+            if (upd) { iter++; continue; }
+        } else {
         // P2: q = A p_x ; tau-tilde ; u-tilde ; cone input
         {
             double tau_t = (rtau * sm[L::O_W + OT] + sm[L::O_WP] + sm[L::O_WP + 1]) * inv_den;
@@ -888,6 +962,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
         // ---- slow path (every CONVERGED_INTERVAL iterations, and the last one)
         if (ev) sm[L::O_U + ve] = project_e(e, ve);
         __syncthreads();
+        }      // (!WL)
         bool stop = false, rescale = false;
         if (check) {
             // The two products of the residual test are parked in LDS (ZB is free here) and the residuals are evaluated in a
@@ -1012,8 +1087,9 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
         for (int i = tid_w; i < m; i += NT) {
             const double uy = sm[L::O_U + OY + i], di = sm[L::O_DV + i];
             const double sh = (uy + sm[L::O_W + OY + i] - 2 * sm[L::O_UT + OY + i]) / dyv(i);
-            yo[(size_t)inst * m + i] = (solved || infeas) ? di * uy * it : NAN;
-            so[(size_t)inst * m + i] = infeas ? NAN : sh / di * it;
+            const int io = WL ? row_perm[i] : i;                 // kernel row -> template row
+            yo[(size_t)inst * m + io] = (solved || infeas) ? di * uy * it : NAN;
+            so[(size_t)inst * m + io] = infeas ? NAN : sh / di * it;
         }
         if (tid_w == 0) {
             iters_o[inst] = iter; status_o[inst] = status;

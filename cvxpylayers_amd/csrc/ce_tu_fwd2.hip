@@ -12,12 +12,23 @@ namespace {
 #error "compile with -DCE_F2_KIND=0|1|2"
 #endif
 
-#define F2_ARGS a.T, a.S, a.Abm, a.q, a.sqk, a.sqb, a.idx_at, a.idx_ar, a.idx_b, a.x, a.y, a.s, a.iters, a.status, a.resid, a.P, a.nnz_p, a.idx_p
+#define F2_ARGS a.T, a.S, a.Abm, a.q, a.sqk, a.sqb, a.idx_at, a.idx_ar, a.idx_b, a.x, a.y, a.s, a.iters, a.status, a.resid, a.P, a.nnz_p, a.idx_p, a.row_perm
 #define LAUNCH_F2(NTHREADS, ...) hipLaunchKernelGGL((k_fwd2<__VA_ARGS__>), dim3(B), dim3(NTHREADS), lds, st, F2_ARGS)
 #define SETATTR(...) do { hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fwd2<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes); if (e_ != hipSuccess) return e_; } while (0)
 
 #if CE_F2_KIND == 0
 int ce_launch_fwd2_plain(int variant, int B, size_t lds, hipStream_t st, const CeFwdArgs &a) {
+    if (a.row_perm) {      // rows packed so that every cone is wave-local (WL instantiations)
+        switch (variant) {
+        case 0: LAUNCH_F2(256, 16, 2, 8, 2, 16, 2, false, 256, false, true); break;
+        case 1: LAUNCH_F2(256, 8, 8, 4, 8, 8, 4, false, 256, false, true); break;
+        case 2: LAUNCH_F2(256, 4, 26, 2, 26, 4, 14, false, 256, false, true); break;
+        case 3: LAUNCH_F2(512, 8, 20, 2, 32, 8, 8, false, 512, false, true); break;
+        case 4: LAUNCH_F2(512, 4, 30, 4, 26, 4, 26, false, 512, false, true); break;
+        default: return -1;
+        }
+        return 0;
+    }
     switch (variant) {
     case 0: LAUNCH_F2(256, 16, 2, 8, 2, 16, 2); break;
     case 1: LAUNCH_F2(256, 8, 8, 4, 8, 8, 4); break;
@@ -31,6 +42,8 @@ int ce_launch_fwd2_plain(int variant, int B, size_t lds, hipStream_t st, const C
 hipError_t ce_setattr_fwd2_plain(int bytes) {
     SETATTR(16, 2, 8, 2, 16, 2); SETATTR(8, 8, 4, 8, 8, 4); SETATTR(4, 26, 2, 26, 4, 14);
     SETATTR(8, 20, 2, 32, 8, 8, false, 512); SETATTR(4, 30, 4, 26, 4, 26, false, 512);
+    SETATTR(16, 2, 8, 2, 16, 2, false, 256, false, true); SETATTR(8, 8, 4, 8, 8, 4, false, 256, false, true); SETATTR(4, 26, 2, 26, 4, 14, false, 256, false, true);
+    SETATTR(8, 20, 2, 32, 8, 8, false, 512, false, true); SETATTR(4, 30, 4, 26, 4, 26, false, 512, false, true);
     return hipSuccess;
 }
 #elif CE_F2_KIND == 1

@@ -27,6 +27,7 @@ struct CeFwdArgs {
     const int *idx_at, *idx_ar, *idx_b;
     double *x, *y, *s; int *iters, *status; double *resid;
     const double *P; int nnz_p; const int *idx_p;
+    const int *row_perm;        // k_fwd2 WL variants: kernel row -> template row (NULL: rows in template order)
     double *gA, *gG;            // global residency workspaces of the size-generic kernel
 };
 struct CeBwdArgs {

@@ -61,6 +61,7 @@ struct ce_engine {
     int fwd_mode = 0, bwd_mode = 0; size_t fwd_lds = 0, bwd_lds = 0; int nkcap = 0, ldk = 0;
     int rt_variant = -1, rt_vp = 0, rt_lda = 0;   // register-tiled forward kernel variant (-1: generic kernel)
     int f2_variant = -1; int *d_idx_at = nullptr, *d_idx_ar = nullptr, *d_idx_b = nullptr; int f2_ldg = 0;   // second-generation forward kernel
+    bool wl = false; int wl_nq = 0; int *d_row_perm = nullptr, *d_k_rowcone = nullptr, *d_k_qoff = nullptr;   // rows packed so that cones are wave-local (k_fwd2 WL)
     int brt_variant = -1;                          // register-tiled backward kernel variant (-1: generic kernel)
     // quadratic objective
     int nnz_p = 0, p_tri = 0; bool qp_native = false;
@@ -177,6 +178,35 @@ static bool f2_fits(const DevT &T, int v, int *ldg, size_t *bytes, bool has_p = 
     return *bytes <= LDS_LIMIT;
 }
 
+// Row order for k_fwd2's wave-local cone exchange (ce_forward_v2.h, WL): the rows of one wave in the (i2, c2) row layout form a
+// window of W = 64 / CHA rows, and no cone may straddle two windows.  Zero-cone rows stay first (the kernel tells them by i < z);
+// then the SOC blocks in template order, each pushed to the next window when it would straddle, the gap filled with nonnegative
+// rows (which are interchangeable: they count as cones of dimension 1); the remaining nonnegative rows go last.  Exact fit only
+// (no padding rows: they would change the size of the embedding and with it the iterates); returns false when that fails.
+static bool pack_rows(const ce_template *tpl, int W, std::vector<int> &korig, std::vector<int> &k_rowcone, std::vector<int> &k_qoff) {
+    const int z = tpl->z, l = tpl->l, m = tpl->m;
+    if (tpl->ns > 0 || tpl->nep + tpl->np > 0) return false;
+    for (int c = 0; c < tpl->nq; c++) if (tpl->q[c] > W) return false;
+    korig.clear(); k_rowcone.assign(m, -1); k_qoff.clear();
+    for (int i = 0; i < z; i++) korig.push_back(i);
+    int next_single = z, singles_left = l, orig = z + l;
+    auto place_single = [&]() { k_rowcone[korig.size()] = (int)k_qoff.size(); k_qoff.push_back((int)korig.size()); korig.push_back(next_single++); singles_left--; };
+    for (int c = 0; c < tpl->nq; c++) {
+        const int d = tpl->q[c];
+        const int used = (int)korig.size() % W;
+        if (used + d > W) {
+            const int need = W - used;
+            if (singles_left < need) return false;
+            for (int k = 0; k < need; k++) place_single();
+        }
+        k_qoff.push_back((int)korig.size());
+        for (int k = 0; k < d; k++) { k_rowcone[korig.size()] = (int)k_qoff.size() - 1; korig.push_back(orig++); }
+    }
+    while (singles_left > 0) place_single();
+    k_qoff.push_back((int)korig.size());
+    return (int)korig.size() == m;
+}
+
 extern "C" {
 
 const char *ce_last_error(void) { return g_err.c_str(); }
@@ -269,13 +299,28 @@ int ce_create(const ce_template *tpl, int device, ce_handle *out) {
             const int *V = F2_VARIANTS[v];
             const int CHT = V[0], T1 = V[1], CHA = V[2], T2 = V[3], NTH = V[6];
             const int S1 = (T1 + 3) & ~3, S2 = (T2 + 3) & ~3;       // thread-major gather maps, rows padded to 16 bytes (ce_forward_v2.h idx_stride)
-            std::vector<int> pos((size_t)T.m * T.n, -1), ib(T.m, -1), iat((size_t)S1 * NTH, -1), iar((size_t)S2 * NTH, -1);
+            std::vector<int> pos((size_t)T.m * T.n, -1), ib0(T.m, -1), ib(T.m, -1), iat((size_t)S1 * NTH, -1), iar((size_t)S2 * NTH, -1);
             for (int j = 0; j <= T.n; j++)
-                for (int k = tpl->indptr[j]; k < tpl->indptr[j + 1]; k++) { if (j < T.n) pos[(size_t)tpl->indices[k] * T.n + j] = k; else ib[tpl->indices[k]] = k; }
+                for (int k = tpl->indptr[j]; k < tpl->indptr[j + 1]; k++) { if (j < T.n) pos[(size_t)tpl->indices[k] * T.n + j] = k; else ib0[tpl->indices[k]] = k; }
+            // kernel row order: packed for the wave-local cone exchange when the template allows it (plain cones, linear objective)
+            std::vector<int> korig(T.m), k_rowcone, k_qoff;
+            for (int i = 0; i < T.m; i++) korig[i] = i;
+            {
+                std::vector<int> ko, krc, kq;
+                const char *wl_env = getenv("CE_WL");                  // "0": keep the template's row order (A/B switch for benchmarking)
+                if (!has_p && !(wl_env && !strcmp(wl_env, "0")) && pack_rows(tpl, 64 / CHA, ko, krc, kq)) { korig = ko; k_rowcone = krc; k_qoff = kq; h->wl = true; h->wl_nq = (int)kq.size() - 1; }
+            }
+            for (int r = 0; r < T.m; r++) ib[r] = ib0[korig[r]];
             for (int t = 0; t < NTH; t++) {
                 const int j1 = t / CHT, c1 = t % CHT, i2 = t / CHA, c2 = t % CHA;
-                for (int k = 0; k < T1; k++) { const int r = T1 * c1 + k; if (j1 < T.n && r < T.m) iat[(size_t)t * S1 + k] = pos[(size_t)r * T.n + j1]; }
-                for (int k = 0; k < T2; k++) { const int c = T2 * c2 + k; if (i2 < T.m && c < T.n) iar[(size_t)t * S2 + k] = pos[(size_t)i2 * T.n + c]; }
+                for (int k = 0; k < T1; k++) { const int r = T1 * c1 + k; if (j1 < T.n && r < T.m) iat[(size_t)t * S1 + k] = pos[(size_t)korig[r] * T.n + j1]; }
+                for (int k = 0; k < T2; k++) { const int c = T2 * c2 + k; if (i2 < T.m && c < T.n) iar[(size_t)t * S2 + k] = pos[(size_t)korig[i2] * T.n + c]; }
+            }
+            if (h->wl) {
+                HIPCHK(hipMalloc(&h->d_row_perm, sizeof(int) * T.m)); HIPCHK(hipMalloc(&h->d_k_rowcone, sizeof(int) * T.m)); HIPCHK(hipMalloc(&h->d_k_qoff, sizeof(int) * k_qoff.size()));
+                HIPCHK(hipMemcpy(h->d_row_perm, korig.data(), sizeof(int) * T.m, hipMemcpyHostToDevice));
+                HIPCHK(hipMemcpy(h->d_k_rowcone, k_rowcone.data(), sizeof(int) * T.m, hipMemcpyHostToDevice));
+                HIPCHK(hipMemcpy(h->d_k_qoff, k_qoff.data(), sizeof(int) * k_qoff.size(), hipMemcpyHostToDevice));
             }
             HIPCHK(hipMalloc(&h->d_idx_at, sizeof(int) * iat.size())); HIPCHK(hipMalloc(&h->d_idx_ar, sizeof(int) * iar.size())); HIPCHK(hipMalloc(&h->d_idx_b, sizeof(int) * T.m));
             HIPCHK(hipMemcpy(h->d_idx_at, iat.data(), sizeof(int) * iat.size(), hipMemcpyHostToDevice));
@@ -339,7 +384,7 @@ int ce_destroy(ce_handle h) {
     if (!h) return CE_OK;
     hipSetDevice(h->device);
     hipFree(h->d_rowidx); hipFree(h->d_colidx); hipFree(h->d_rowcone); hipFree(h->d_qoff); hipFree(h->d_soff); hipFree(h->d_sord); hipFree(h->d_pw); hipFree(h->d_idx_p); hipFree(h->d_pmap); hipFree(h->d_prow); hipFree(h->d_pcol);
-    hipFree(h->wsA); hipFree(h->wsdA); hipFree(h->gws); hipFree(h->d_idx_at); hipFree(h->d_idx_ar); hipFree(h->d_idx_b);
+    hipFree(h->wsA); hipFree(h->wsdA); hipFree(h->gws); hipFree(h->d_idx_at); hipFree(h->d_idx_ar); hipFree(h->d_idx_b); hipFree(h->d_row_perm); hipFree(h->d_k_rowcone); hipFree(h->d_k_qoff);
     for (auto &v : h->ev) for (auto &p : v) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
     delete h;
     return CE_OK;
@@ -417,6 +462,9 @@ int ce_solve_qp(ce_handle h, int B, const double *A_vals, long sA_k, long sA_b, 
         int lrc;
         if (h->fwd_mode == 4) {
             fa.T.ldg = h->f2_ldg;
+            if (h->wl) {      // rows packed for the wave-local cone exchange: the kernel sees the cone layout in ITS row order
+                fa.row_perm = h->d_row_perm; fa.T.rowcone = h->d_k_rowcone; fa.T.qoff = h->d_k_qoff; fa.T.nq = h->wl_nq; fa.T.l = 0;
+            }
             if (P_vals) lrc = ce_launch_fwd2_qp(h->f2_variant, B, h->fwd_lds, st, fa);
             else if (T.ns > 0 || T.nep + T.np > 0) lrc = ce_launch_fwd2_psd(h->f2_variant, B, h->fwd_lds, st, fa);
             else lrc = ce_launch_fwd2_plain(h->f2_variant, B, h->fwd_lds, st, fa);
