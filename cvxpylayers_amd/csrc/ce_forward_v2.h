@@ -321,7 +321,11 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
         const Co co(wave);
         const int j1 = co.j1, c1 = co.c1, i2 = co.i2, c2 = co.c2;
         const bool own1 = (c1 == 0) && (j1 < n), own2 = (c2 == 0) && (i2 < m);
-        float atf[T1], arf[T2];
+        // tiles as packed pairs: the scaling of a pass is one v_pk_mul_f32 per pair and factor (gfx950 packed fp32 runs at twice the
+        // scalar fp32 rate), the inf-norms are v_max3_f32 chains, 1/sqrt is the hardware v_rsq_f32 (D, E are preconditioners:
+        // any positive scaling is valid, 1 ulp of single precision is more than enough)
+        typedef float f2v __attribute__((ext_vector_type(2)));
+        f2v atv[T1 / 2], arv[T2 / 2];
         float pf[HASP ? TG : 1];
         if constexpr (HASP) {
             const double *pv = Pvals_g + (size_t)blockIdx.x * nnzP;
@@ -329,12 +333,13 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
             for (int k = 0; k < TG; k++) { const int ix = idx_p[tid * idx_stride<TG> + k]; pf[k] = ix >= 0 ? (float)pv[ix] : 0.0f; }
         }
         float *const fPn = reinterpret_cast<float *>(sm + L::O_S3);          // column norms of P-hat (= row norms: symmetric)
-        for_each_idx<T1>(idx_at, tid, [&](auto, int k, int ix) { atf[k] = ix >= 0 ? (float)(-vals[ix]) : 0.0f; });   // A = -A_cvx (diffcp_if.py:65)
-        for_each_idx<T2>(idx_ar, tid, [&](auto, int k, int ix) { arf[k] = ix >= 0 ? (float)(-vals[ix]) : 0.0f; });
+        for_each_idx<T1>(idx_at, tid, [&](auto, int k, int ix) { atv[k >> 1][k & 1] = ix >= 0 ? (float)(-vals[ix]) : 0.0f; });   // A = -A_cvx (diffcp_if.py:65)
+        for_each_idx<T2>(idx_ar, tid, [&](auto, int k, int ix) { arv[k >> 1][k & 1] = ix >= 0 ? (float)(-vals[ix]) : 0.0f; });
         float *const fEt0 = reinterpret_cast<float *>(sm + L::O_S1), *const fEt1 = reinterpret_cast<float *>(sm + L::O_S2);
         float *const fDt0 = reinterpret_cast<float *>(sm + L::O_U + OY), *const fDt1 = reinterpret_cast<float *>(sm + L::O_UT + OY);
         float *const fRn = reinterpret_cast<float *>(sm + L::O_ZB + OY);
         auto clampf = [](float v) -> float { return v < (float)MIN_SCALE ? 1.0f : (v > (float)MAX_SCALE ? (float)MAX_SCALE : v); };
+        double Eacc = 1.0, Dacc = 1.0;        // accumulated scalings of this thread's column / row (owners write them once, after the passes)
         for (int pass = 0; pass < NUM_RUIZ_PASSES + NUM_L2_PASSES; pass++) {
             const bool l2 = pass >= NUM_RUIZ_PASSES;
             float *const fEt = (pass & 1) ? fEt1 : fEt0;                  // column scaling of this pass (x-indexed)
@@ -342,16 +347,16 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
             float cn = 0, rn = 0;
             if (l2) {
 #pragma unroll
-                for (int k = 0; k < T1; k++) cn = fmaf(atf[k], atf[k], cn);
+                for (int k = 0; k < T1 / 2; k++) { cn = fmaf(atv[k].x, atv[k].x, cn); cn = fmaf(atv[k].y, atv[k].y, cn); }
 #pragma unroll
-                for (int k = 0; k < T2; k++) rn = fmaf(arf[k], arf[k], rn);
+                for (int k = 0; k < T2 / 2; k++) { rn = fmaf(arv[k].x, arv[k].x, rn); rn = fmaf(arv[k].y, arv[k].y, rn); }
                 cn = sqrtf(group_reduce_f<CHT, false>(cn)); rn = sqrtf(group_reduce_f<CHA, false>(rn));
             } else {
                 float c0 = 0, c1_ = 0, r0 = 0, r1 = 0;
 #pragma unroll
-                for (int k = 0; k < T1; k += 2) { c0 = fmaxf(c0, fabsf(atf[k])); c1_ = fmaxf(c1_, fabsf(atf[k + 1])); }
+                for (int k = 0; k < T1 / 2; k += 2) { c0 = fmaxf(fmaxf(c0, fabsf(atv[k].x)), fabsf(atv[k].y)); if (k + 1 < T1 / 2) c1_ = fmaxf(fmaxf(c1_, fabsf(atv[k + 1].x)), fabsf(atv[k + 1].y)); }
 #pragma unroll
-                for (int k = 0; k < T2; k += 2) { r0 = fmaxf(r0, fabsf(arf[k])); r1 = fmaxf(r1, fabsf(arf[k + 1])); }
+                for (int k = 0; k < T2 / 2; k += 2) { r0 = fmaxf(fmaxf(r0, fabsf(arv[k].x)), fabsf(arv[k].y)); if (k + 1 < T2 / 2) r1 = fmaxf(fmaxf(r1, fabsf(arv[k + 1].x)), fabsf(arv[k + 1].y)); }
                 cn = group_reduce_f<CHT, true>(fmaxf(c0, c1_)); rn = group_reduce_f<CHA, true>(fmaxf(r0, r1));
             }
             if constexpr (HASP) {      // columns of [P-hat; A-hat]: the column norm of A-hat is combined with that of P-hat after the barrier
@@ -368,35 +373,37 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
                 }
                 if (cop.cg == 0 && cop.jg < n) fPn[cop.jg] = pn;
             } else {
-                if (own1) fEt[j1] = 1.0f / sqrtf(clampf(cn));
+                if (own1) fEt[j1] = __builtin_amdgcn_rsqf(clampf(cn));
             }
             if (own2) fRn[i2] = rn;          // raw row norms
             if constexpr (WL) wave_lds_exchange(); else __syncthreads();
             if constexpr (HASP) {
-                if (own1) { const float pn = fPn[j1]; fEt[j1] = 1.0f / sqrtf(clampf(l2 ? sqrtf(cn * cn + pn) : fmaxf(cn, pn))); }
+                if (own1) { const float pn = fPn[j1]; fEt[j1] = __builtin_amdgcn_rsqf(clampf(l2 ? sqrtf(cn * cn + pn) : fmaxf(cn, pn))); }
             }
             if (own2) {
                 float a = rn;
                 const int r0 = socr[i2], d = abs(socd[i2]);
-                if (d > 0) {   // block-average inside the SOC / PSD block so the scaled cone is still the cone
+                if (d > 1) {   // block-average inside the SOC / PSD block so the scaled cone is still the cone
                     float s0 = 0, s1 = 0;
                     int i = 0;
                     for (; i + 1 < d; i += 2) { s0 += fRn[r0 + i]; s1 += fRn[r0 + i + 1]; }
                     if (i < d) s0 += fRn[r0 + i];
-                    a = (s0 + s1) / (float)d;
+                    a = (s0 + s1) * __builtin_amdgcn_rcpf((float)d);
                 }
-                fDt[i2] = 1.0f / sqrtf(clampf(a));
+                fDt[i2] = __builtin_amdgcn_rsqf(clampf(a));
             }
             __syncthreads();
             {
                 const float ej = fEt[j1 < NP ? j1 : 0];            // pad entries are 0
-                const float2 *d2 = reinterpret_cast<const float2 *>(fDt + T1 * c1);
+                const f2v ej2 = {ej, ej};
+                const f2v *d2 = reinterpret_cast<const f2v *>(fDt + T1 * c1);
 #pragma unroll
-                for (int k = 0; k < T1 / 2; k++) { const float2 d = d2[k]; atf[2 * k] *= d.x * ej; atf[2 * k + 1] *= d.y * ej; }
+                for (int k = 0; k < T1 / 2; k++) atv[k] *= d2[k] * ej2;
                 const float di = fDt[i2 < MP ? i2 : 0];
-                const float2 *e2 = reinterpret_cast<const float2 *>(fEt + T2 * c2);
+                const f2v di2 = {di, di};
+                const f2v *e2 = reinterpret_cast<const f2v *>(fEt + T2 * c2);
 #pragma unroll
-                for (int k = 0; k < T2 / 2; k++) { const float2 ee = e2[k]; arf[2 * k] *= di * ee.x; arf[2 * k + 1] *= di * ee.y; }
+                for (int k = 0; k < T2 / 2; k++) arv[k] *= e2[k] * di2;
                 if constexpr (HASP) {
                     const Co cop(wave);
                     const float eg = fEt[cop.jg < NP ? cop.jg : 0];
@@ -404,11 +411,12 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
 #pragma unroll
                     for (int k = 0; k < TG / 2; k++) { const float2 ee = g2[k]; pf[2 * k] *= eg * ee.x; pf[2 * k + 1] *= eg * ee.y; }
                 }
-                if (own1) sm[L::O_EV + j1] *= (double)ej;
-                if (own2) sm[L::O_DV + i2] *= (double)di;
+                Eacc *= (double)ej; Dacc *= (double)di;
             }
             // no barrier: the next pass writes the other ping-pong buffers (and the row norms, last read before the barrier above)
         }
+        if (own1) sm[L::O_EV + j1] = Eacc;
+        if (own2) sm[L::O_DV + i2] = Dacc;
         __syncthreads();
         double r[2] = {0, 0};
         for (int i = tid; i < m; i += NT) { const double v = sm[L::O_BV + i] * sm[L::O_DV + i]; sm[L::O_BV + i] = v; r[0] = fmax(r[0], fabs(v)); }
