@@ -25,8 +25,10 @@ constexpr int RT_EXTRA = NW2 * 8 + NW2 + 16;   // red, wpart, scalars
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    // every lane has a valid source for these controls (quad_perm, row_mirror, row_half_mirror) and all rows / banks are enabled:
+    // with bound_ctrl the "old" operand is dead, which spares the v_mov that would otherwise initialise the destination
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
     return __hiloint2double(hi, lo);
 }
 // all-reduce inside aligned groups of CH consecutive lanes (CH in 1,2,4,8,16); every lane of the wave must be active

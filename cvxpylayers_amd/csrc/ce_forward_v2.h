@@ -52,7 +52,7 @@ __device__ __forceinline__ double uniform_d(double v) {
 template <int CH, bool MAX>
 __device__ __forceinline__ float group_reduce_f(float v) {
     auto op = [](float a, float b) { return MAX ? fmaxf(a, b) : a + b; };
-    auto mov = [](float x, auto ctrl) { constexpr int CTRL = decltype(ctrl)::value; return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), CTRL, 0xF, 0xF, false)); };
+    auto mov = [](float x, auto ctrl) { constexpr int CTRL = decltype(ctrl)::value; return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true)); };
     if constexpr (CH >= 2) v = op(v, mov(v, std::integral_constant<int, 0xB1>{}));
     if constexpr (CH >= 4) v = op(v, mov(v, std::integral_constant<int, 0x4E>{}));
     if constexpr (CH >= 8) v = op(v, mov(v, std::integral_constant<int, 0x141>{}));
@@ -76,7 +76,7 @@ __device__ __forceinline__ void sqrt_rsqrt(double q, double &s, double &rinv) {
 template <int CH, int TT>
 __device__ __forceinline__ double seg_dot(const double (&tile)[TT], const double *vec) {
     const double2 *v2 = reinterpret_cast<const double2 *>(vec);
-    double a0 = 0, a1 = 0;
+    double a0 = 0, a1 = 0;       // (four chains were tried: the two extra accumulators push the iteration loop into scratch spills)
 #pragma unroll
     for (int k = 0; k < TT / 2; k++) {
         const double2 v = v2[k];
