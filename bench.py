@@ -81,10 +81,10 @@ def main():
     ap.add_argument("--eps", type=float, default=1e-4, help="eps_abs=eps_rel (SCS default 1e-4)")
     ap.add_argument("--cpu-sample", type=int, default=4096)
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--accel", type=int, default=0,
-                    help="acceleration_lookback: 0 (default, the configuration the committed rocprofv3 summaries were taken with) = plain "
-                         "iteration; > 0 = type-I Anderson acceleration, one-pair history, every 10 iterations (SCS's own default is "
-                         "acceleration on).  The CPU baseline runs with the same setting.")
+    ap.add_argument("--accel", type=int, default=10,
+                    help="acceleration_lookback handed to both sides.  10 (default) = SCS's own default, which diffcp forwards: type-I Anderson "
+                         "acceleration every 10 iterations (the engine keeps a one-pair history, the CPU oracle the full lookback: same iteration "
+                         "counts within 2.5 %%, profiles/r02/aa_memory.json); 0 = plain iteration.")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -183,9 +183,9 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"config {args.config}: n={n} m={m} cones l={cones.get('l', 0)} q={cones.get('q', [])} dense A "
                                    f"(nnzA={nnzA}), A,b,c batched, B={B} per GPU, eps_abs=eps_rel={args.eps}, max_iters=10000, "
-                                   + ("Anderson acceleration type I, memory 1, interval 10 (both sides)" if args.accel > 0 else "acceleration off")
+                                   + (f"Anderson acceleration (SCS default: acceleration_lookback={args.accel}, interval 10; engine: one-pair history)" if args.accel > 0 else "acceleration off")
                                    + "; step = plugin forward (layout pass + solve + status) + backward (adjoint VJP of sum(x))",
-                       "batch_per_gpu": B, "parallelism": f"batch-shard x{world}", "acceleration_lookback": int(args.accel > 0),
+                       "batch_per_gpu": B, "parallelism": f"batch-shard x{world}", "acceleration_lookback": int(args.accel),
                        "solved_fraction": float((info["status"] == 1).float().mean().item()), "mean_iters": float(iters.mean())},
             "roofline": {"bound": "hbm", "kernel": "forward (k_fwd2 / k_forward_rt / k_forward): the longest kernel of the step", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,

@@ -13,7 +13,7 @@ SO_PATH = os.environ.get("CE_ENGINE_SO") or os.path.join(_HERE, "csrc", "libcone
 
 # every symbol include/cone_engine.h declares
 SYMBOLS = ["ce_abi_version", "ce_struct_size", "ce_default_settings", "ce_create", "ce_destroy", "ce_last_error", "ce_solve", "ce_vjp", "ce_qp_native", "ce_solve_qp", "ce_vjp_qp",
-           "ce_transpose", "ce_parammap_apply", "ce_parammap_apply2", "ce_ca_step", "ce_ca_check", "ce_ca_psd", "ce_ca_triples", "ce_ca_triple_jac", "ce_ca_update", "ce_ca_finish", "ce_set_profiling", "ce_get_profile", "ce_reset_profile", "ce_get_launch_info"]
+           "ce_transpose", "ce_parammap_apply", "ce_parammap_apply2", "ce_ca_step", "ce_ca_check", "ce_ca_psd", "ce_ca_psd_mfma", "ce_ca_triples", "ce_ca_triple_jac", "ce_ca_update", "ce_ca_finish", "ce_set_profiling", "ce_get_profile", "ce_reset_profile", "ce_get_launch_info"]
 
 
 class CeTemplate(C.Structure):
@@ -31,7 +31,7 @@ class CeSettings(C.Structure):
                 ("acceleration_lookback", C.c_int), ("acceleration_interval", C.c_int)]
 
 
-ABI_VERSION = 3          # include/cone_engine.h CE_ABI_VERSION this binding was written against
+ABI_VERSION = 4          # include/cone_engine.h CE_ABI_VERSION this binding was written against
 
 
 def build(force: bool = False) -> str:
@@ -82,6 +82,7 @@ def lib():
     L.ce_ca_check.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(CeSettings), dp, dp, dp, dp, lg, dp, lg, dp, dp, dp, dp, dp, dp, dp,
                               dp, dp, ip, ip, ip, ip, ip, dp, ip, vp]
     L.ce_ca_psd.argtypes = [vp, C.c_int, C.c_int, dp, ip, vp]
+    L.ce_ca_psd_mfma.argtypes = [vp, C.c_int, C.c_int, dp, dp, C.c_int, ip, vp]
     L.ce_ca_triples.argtypes = [vp, C.c_int, C.c_int, dp, dp, ip, vp]
     L.ce_ca_triple_jac.argtypes = [vp, C.c_int, dp, lg, dp, vp]
     L.ce_ca_update.argtypes = [vp, C.c_int, C.c_int, dp, dp, dp, ip, C.c_int, C.c_double, vp]

@@ -213,6 +213,20 @@ k_ca_psd(DevT T, int lp, double *__restrict__ Ug, const int *__restrict__ active
     psd_project<NT>(Ug + (size_t)inst * lp + T.n + T.soff[c], k, Sm, Vm, cs, red);
 }
 
+// K4': the same projection with the contractions on the matrix cores and a warm-started Jacobi (ce_psd_mfma.h).  Vstate (B, ns,
+// maxs * maxs): eigenvectors of every block from the previous call; warm = 0 restarts them from the identity.
+__global__ void __launch_bounds__(NT)
+k_ca_psd_mfma(DevT T, int lp, double *__restrict__ Ug, double *__restrict__ Vstate, int warm, const int *__restrict__ active) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int inst = blockIdx.x, c = blockIdx.y;
+    if (!active[inst]) return;
+    const int k = T.sord[c];
+    const int KPm = psd_mfma_kp(T.maxs), PM = KPm * (KPm + 1);
+    double *Sm = sm, *Vm = Sm + PM, *Tm = Vm + PM, *cs = Tm + PM, *red = cs + 2 * KPm + 8;
+    psd_project_mfma<NT>(Ug + (size_t)inst * lp + T.n + T.soff[c], k, Sm, Vm, Tm, cs, red,
+                         Vstate + ((size_t)inst * T.ns + c) * T.maxs * T.maxs, warm);
+}
+
 // K4b: exponential / power cone triples of the cone input (B, lp) projected in place, one thread per (instance, cone); `roots`
 // (B, nep + np) keeps each cone's root between iterations (the warm start of the bracketed Newton iteration, ce_expcone.h).
 __global__ void __launch_bounds__(NT)

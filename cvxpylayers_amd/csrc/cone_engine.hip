@@ -40,6 +40,7 @@ namespace {
 #include "ce_forward_v2.h"     // psd_project (used by k_ca_psd); k_fwd2 itself is instantiated in ce_tu_fwd2.hip
 #include "ce_backward.h"       // k_transpose, k_parammap*  (k_backward is instantiated in ce_tu_bwd_generic.hip)
 #include "ce_backward_rt.h"    // bwd_rt_union_doubles, BGC (launch planning); kernels in ce_tu_bwd_rt.hip
+#include "ce_psd_mfma.h"
 #include "ce_const_a.h"
 }  // namespace
 
@@ -576,6 +577,17 @@ int ce_ca_psd(ce_handle h, int B, int lp, double *U, const int *active, void *st
     const size_t lds = (2 * (size_t)h->T.maxs * h->T.maxs + 2 * h->T.maxs + 8 + NW * 8) * 8;
     if (lds > 64 * 1024) { g_err = "PSD order too large for the LDS-resident Jacobi projection"; return CE_E_TOO_LARGE; }
     hipLaunchKernelGGL(k_ca_psd, dim3(B, h->T.ns), dim3(NT), lds, (hipStream_t)stream, h->T, lp, U, active);
+    HIPCHK(hipGetLastError());
+    return CE_OK;
+}
+int ce_ca_psd_mfma(ce_handle h, int B, int lp, double *U, double *Vstate, int warm, const int *active, void *stream) {
+    if (!h || B <= 0 || !U || !Vstate || !active) { g_err = "null argument"; return CE_E_BADARG; }
+    if (h->T.ns == 0) return CE_OK;
+    HIPCHK(hipSetDevice(h->device));
+    const int kp = psd_mfma_kp(h->T.maxs);
+    const size_t lds = (3 * (size_t)kp * (kp + 1) + 2 * kp + 8 + NW * 8) * 8;
+    if (lds > 64 * 1024) { g_err = "PSD order too large for the LDS-resident MFMA projection (order <= 48)"; return CE_E_TOO_LARGE; }
+    hipLaunchKernelGGL(k_ca_psd_mfma, dim3(B, h->T.ns), dim3(NT), lds, (hipStream_t)stream, h->T, lp, U, Vstate, warm, active);
     HIPCHK(hipGetLastError());
     return CE_OK;
 }

@@ -160,8 +160,10 @@ class ConeEngine:
         if P_bm is None and self._use_const_a(A_bm):
             from cvxpylayers_amd.interfaces.const_a import solve_const_a
             self.last_path = "const_a"
+            self._note_acceleration(settings, honoured=False, path="constant-A (batch GEMM) path")
             return solve_const_a(self, A_bm, q_eval, settings, warm=warm)
         self.last_path = "per_instance"
+        self._note_acceleration(settings, honoured=self.launch_info()["fwd_mode"] == 4, path="size-generic forward kernels")
         if warm is not None:       # the engine reads the initial point from the output buffers (ce_settings.warm_start)
             x, y, s = (t.detach().to(device=dev, dtype=torch.float64).clone().contiguous() for t in warm)
             settings.warm_start = 1
@@ -183,6 +185,14 @@ class ConeEngine:
                                      iters.data_ptr(), status.data_ptr(), resid.data_ptr(), self._stream())
         _lib.check(rc, "ce_solve")
         return x, y, s, iters, status, resid
+
+    def _note_acceleration(self, settings, honoured: bool, path: str):
+        """An explicit acceleration request that the selected path cannot honour is reported once per engine (not silently dropped);
+        the plugin's own default (SCS's lookback 10) is not an explicit request."""
+        if settings.acceleration_lookback > 0 and not honoured and getattr(settings, "_explicit_aa", False) and not getattr(self, "_aa_warned", False):
+            self._aa_warned = True
+            warnings.warn(f"MI355 solver: acceleration_lookback={settings.acceleration_lookback} is not implemented on the {path}; "
+                          "iterating without Anderson acceleration")
 
     def _use_const_a(self, A_bm) -> bool:
         """The batch-GEMM path pays off when the instance is too large for the register / LDS-resident kernels (those are
@@ -426,7 +436,14 @@ class _ConeLayer(torch.autograd.Function):
         merged_args = {**ctx.options}
         if solver_args:
             merged_args.update(solver_args)
+        # SCS runs with Anderson acceleration by default (acceleration_lookback = 10, acceleration_interval = 10) and diffcp forwards
+        # SCS's defaults (diffcp_if.py:356-367), so identical solver_args mean acceleration ON here as well.  The engine keeps a
+        # one-pair history whatever the lookback: on every BASELINE configuration that gives the iteration counts of lookback 10
+        # within 2.5 % (profiles/r02/aa_memory.json, scripts/aa_memory_study.py).  acceleration_lookback=0 switches it off.
+        explicit_aa = "acceleration_lookback" in merged_args
+        merged_args.setdefault("acceleration_lookback", 10)
         settings = make_settings(merged_args)
+        settings._explicit_aa = bool(explicit_aa and merged_args.get("acceleration_lookback"))
         if warm_start is None and merged_args.get("warm_starts") is not None:
             # diffcp's solve argument (diffcp_if.py:365-367 forwards it): one (x, y, s) triple per instance
             ws = merged_args["warm_starts"]

@@ -90,7 +90,7 @@ void ce_default_settings(ce_settings *s);
  * struct)  (which: 0 ce_template, 1 ce_settings) once at load time and refuse to continue otherwise (cvxpylayers_amd/_lib.py
  * does; tests/test_cabi.py checks the stub printed in INTEGRATION.md the same way).  CE_ABI_VERSION is bumped whenever a struct
  * layout or an entry point's signature changes. */
-#define CE_ABI_VERSION 3
+#define CE_ABI_VERSION 4
 int ce_abi_version(void);
 int ce_struct_size(int which);
 
@@ -188,6 +188,10 @@ int ce_ca_check(ce_handle h, int B, int lp, int iter, const ce_settings *setting
                 double *scale, double *sum_log, int *n_log, int *last_scale_iter, int *active, int *status, int *iters,
                 double *resid, int *rescaled, void *stream);
 int ce_ca_psd(ce_handle h, int B, int lp, double *U, const int *active, void *stream);
+/* The same projection with its dense contractions on the matrix cores (v_mfma_f64_16x16x4_f64: S' = V^T S V, X = V diag(w+) V^T) and
+ * a Jacobi eigensolver warm-started from the eigenvectors of the previous call: Vstate (B, ns, maxs * maxs) is caller-owned state,
+ * warm = 0 restarts from the identity (callers do so once per check interval to bound the loss of orthogonality).  PSD orders <= 48. */
+int ce_ca_psd_mfma(ce_handle h, int B, int lp, double *U, double *Vstate, int warm, const int *active, void *stream);
 /* Exponential / power cone triples of the cone input U (B, lp) projected in place (after ce_ca_step, like ce_ca_psd); roots
  * (B, nep + np) is caller-owned state: each cone's root of the previous iteration (zero-initialised). */
 int ce_ca_triples(ce_handle h, int B, int lp, double *U, double *roots, const int *active, void *stream);
