@@ -93,13 +93,25 @@ def test_C5_portfolio_n501_at_size():
     assert np.abs(w.sum(axis=1) - 1).max() < 1e-5 and w.min() > -1e-5
     assert (np.linalg.norm(w @ (-A[502:, :500].T), axis=1) - t).max() < 1e-5
     assert np.abs((c * x).sum(axis=1) + (bb * y).sum(axis=1)).max() < 1e-4
-    # adjoint of dx = 1 at the oracle's own solution, so that only the adjoint solves are compared (LSQR on both sides)
-    from cvxpylayers_amd.interfaces.mi355_if import make_settings  # noqa: F401
+    # adjoint of dx = 1 at the oracle's own solution (so that only the adjoint solves are compared), against the oracle's DENSE
+    # elimination of M^T r = dz.  (diffcp's default LSQR mode, restated in the oracle with diffcp's tolerances, is itself only good to
+    # 3e-4 .. 3e-3 on this ill-conditioned program -- scripts/c5_adjoint_diag.py --, so it is not the comparator here.)
     A_eval, _ = tpl.values_from_dense(Ab, bb, c)
     A_bm = torch.from_numpy(A_eval).cuda().t().contiguous()
     xo, yo, so = (torch.from_numpy(ref[k]).cuda() for k in ("x", "y", "s"))
     dA2, dq2, adj2 = eng.vjp(A_bm, xo, yo, so, torch.ones_like(xo), torch.zeros_like(yo), path="const_a")
-    g = oracle.adjoint_batch(Ab, bb, c, cones, ref["x"], ref["y"], ref["s"], np.ones_like(ref["x"]), np.zeros_like(ref["y"]), mode="lsqr")
-    err = _rel(dq2.cpu().numpy()[:tpl.n].T, g["dc"])
-    print("C5 adjoint: rel |dc - dc_oracle(lsqr)| =", err, "flagged", int((adj2 != 0).sum().item()))
-    assert err < 1e-4, err
+    g = oracle.adjoint_batch(Ab, bb, c, cones, ref["x"], ref["y"], ref["s"], np.ones_like(ref["x"]), np.zeros_like(ref["y"]), mode="dense")
+    assert int((adj2 != 0).sum().item()) == 0
+    # Per instance: at a vertex of the feasible set (as many active rows as variables) the solution is locally constant and both
+    # sides return dc = 0; a few instances sit on a degenerate face (one active row fewer: the reduced system [[0, -B^T], [B, 0]] is
+    # singular, the solution map is not differentiable there) where a minimum-norm least-squares solve (LSQR: diffcp, this path)
+    # and an elimination with pivoting (the oracle's dense mode) legitimately return different elements.  Those are excluded.
+    dc_gpu = dq2.cpu().numpy()[:tpl.n].T
+    db_gpu = _db_from_dA(tpl, dA2.cpu().numpy(), B)
+    brows = tpl.b_idx                                                 # the boundary carries db only for the structural entries of b
+    err = np.maximum(np.abs(dc_gpu - g["dc"]).max(axis=1) / (1 + np.abs(g["dc"]).max(axis=1)),
+                     np.abs(db_gpu[:, brows] - g["db"][:, brows]).max(axis=1) / (1 + np.abs(g["db"]).max(axis=1)))
+    v = ref["y"] - ref["s"]
+    n_act = (v[:, 1:501] > 0).sum(axis=1) + 1 + 51                  # active bounds + budget row + the SOC rows (dual in the interior)
+    regular = n_act >= tpl.n
+    assert regular.mean() > 0.8 and err[regular].max() < 1e-5, (regular.mean(), err[regular].max(), err[~regular])
