@@ -42,6 +42,7 @@ namespace {
 #include "ce_backward_rt.h"    // bwd_rt_union_doubles, BGC (launch planning); kernels in ce_tu_bwd_rt.hip
 #include "ce_psd_mfma.h"
 #include "ce_const_a.h"
+#include "ce_shared_a.h"
 }  // namespace
 
 // ================================================================================================
@@ -62,6 +63,7 @@ struct ce_engine {
     int fwd_mode = 0, bwd_mode = 0; size_t fwd_lds = 0, bwd_lds = 0; int nkcap = 0, ldk = 0;
     int rt_variant = -1, rt_vp = 0, rt_lda = 0;   // register-tiled forward kernel variant (-1: generic kernel)
     int f2_variant = -1; int *d_idx_at = nullptr, *d_idx_ar = nullptr, *d_idx_b = nullptr; int f2_ldg = 0;   // second-generation forward kernel
+    int *d_csc_ptr = nullptr, *d_csr_ptr = nullptr, *d_csr_col = nullptr, *d_csr_src = nullptr;   // sparse structure of the A part (shared-A kernels)
     bool wl = false; int wl_nq = 0; int *d_row_perm = nullptr, *d_k_rowcone = nullptr, *d_k_qoff = nullptr;   // rows packed so that cones are wave-local (k_fwd2 WL)
     int brt_variant = -1;                          // register-tiled backward kernel variant (-1: generic kernel)
     // quadratic objective
@@ -276,6 +278,21 @@ int ce_create(const ce_template *tpl, int device, ce_handle *out) {
     HIPCHK(hipMemcpy(h->d_colidx, colidx.data(), sizeof(int) * tpl->nnz_aug, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->d_rowcone, rowcone.data(), sizeof(int) * tpl->m, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->d_qoff, qoff.data(), sizeof(int) * (tpl->nq + 1), hipMemcpyHostToDevice));
+    {   // CSR of the A part (entry positions refer to the boundary's value order) + its CSC column starts, for the shared-A kernels
+        const int nnzA = tpl->indptr[tpl->n];
+        std::vector<int> rptr(tpl->m + 1, 0), rcol(std::max(nnzA, 1)), rsrc(std::max(nnzA, 1));
+        for (int k = 0; k < nnzA; k++) rptr[tpl->indices[k] + 1]++;
+        for (int i = 0; i < tpl->m; i++) rptr[i + 1] += rptr[i];
+        std::vector<int> fill(rptr.begin(), rptr.end() - 1);
+        for (int j = 0; j < tpl->n; j++)
+            for (int k = tpl->indptr[j]; k < tpl->indptr[j + 1]; k++) { const int pos = fill[tpl->indices[k]]++; rcol[pos] = j; rsrc[pos] = k; }
+        HIPCHK(hipMalloc(&h->d_csc_ptr, sizeof(int) * (tpl->n + 1))); HIPCHK(hipMalloc(&h->d_csr_ptr, sizeof(int) * (tpl->m + 1)));
+        HIPCHK(hipMalloc(&h->d_csr_col, sizeof(int) * rcol.size())); HIPCHK(hipMalloc(&h->d_csr_src, sizeof(int) * rsrc.size()));
+        HIPCHK(hipMemcpy(h->d_csc_ptr, tpl->indptr, sizeof(int) * (tpl->n + 1), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->d_csr_ptr, rptr.data(), sizeof(int) * (tpl->m + 1), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->d_csr_col, rcol.data(), sizeof(int) * rcol.size(), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(h->d_csr_src, rsrc.data(), sizeof(int) * rsrc.size(), hipMemcpyHostToDevice));
+    }
     HIPCHK(hipMalloc(&h->d_soff, sizeof(int) * (tpl->ns + 1))); HIPCHK(hipMalloc(&h->d_sord, sizeof(int) * std::max(tpl->ns, 1)));
     HIPCHK(hipMemcpy(h->d_soff, soff.data(), sizeof(int) * (tpl->ns + 1), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->d_sord, sord.data(), sizeof(int) * std::max(tpl->ns, 1), hipMemcpyHostToDevice));
@@ -385,7 +402,7 @@ int ce_destroy(ce_handle h) {
     if (!h) return CE_OK;
     hipSetDevice(h->device);
     hipFree(h->d_rowidx); hipFree(h->d_colidx); hipFree(h->d_rowcone); hipFree(h->d_qoff); hipFree(h->d_soff); hipFree(h->d_sord); hipFree(h->d_pw); hipFree(h->d_idx_p); hipFree(h->d_pmap); hipFree(h->d_prow); hipFree(h->d_pcol);
-    hipFree(h->wsA); hipFree(h->wsdA); hipFree(h->gws); hipFree(h->d_idx_at); hipFree(h->d_idx_ar); hipFree(h->d_idx_b); hipFree(h->d_row_perm); hipFree(h->d_k_rowcone); hipFree(h->d_k_qoff);
+    hipFree(h->wsA); hipFree(h->wsdA); hipFree(h->gws); hipFree(h->d_idx_at); hipFree(h->d_idx_ar); hipFree(h->d_idx_b); hipFree(h->d_row_perm); hipFree(h->d_k_rowcone); hipFree(h->d_k_qoff); hipFree(h->d_csc_ptr); hipFree(h->d_csr_ptr); hipFree(h->d_csr_col); hipFree(h->d_csr_src);
     for (auto &v : h->ev) for (auto &p : v) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
     delete h;
     return CE_OK;
@@ -588,6 +605,25 @@ int ce_ca_psd_mfma(ce_handle h, int B, int lp, double *U, double *Vstate, int wa
     const size_t lds = (3 * (size_t)kp * (kp + 1) + 2 * kp + 8 + NW * 8) * 8;
     if (lds > 64 * 1024) { g_err = "PSD order too large for the LDS-resident MFMA projection (order <= 48)"; return CE_E_TOO_LARGE; }
     hipLaunchKernelGGL(k_ca_psd_mfma, dim3(B, h->T.ns), dim3(NT), lds, (hipStream_t)stream, h->T, lp, U, Vstate, warm, active);
+    HIPCHK(hipGetLastError());
+    return CE_OK;
+}
+int ce_vjp_shared_a(ce_handle h, int B, const double *A_vals0, const double *x, const double *y, const double *s, const double *dx, const double *dy,
+                    double *dA_bm, double *dq_vals, long sdq_k, long sdq_b, int *adj_status, int *lsqr_iters, double atol, double btol, int iter_lim, void *stream) {
+    if (!h || B <= 0 || !A_vals0 || !x || !y || !s || !dx || !dy || !dA_bm || !dq_vals) { g_err = "null argument"; return CE_E_BADARG; }
+    const DevT &T = h->T;
+    if (T.nep + T.np > 0) { g_err = "shared-A adjoint kernel: exponential / power cones are not implemented"; return CE_E_UNSUPPORTED; }
+    const size_t lds = sa_lsqr_lds_doubles(T.n, T.m, T.nq, T.ns, T.maxs) * 8;
+    if (lds > LDS_LIMIT) { g_err = "shared-A adjoint kernel: the LSQR vectors of one instance do not fit LDS"; return CE_E_TOO_LARGE; }
+    HIPCHK(hipSetDevice(h->device));
+    static bool attr_done = false;
+    if (!attr_done) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sa_lsqr), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT)); attr_done = true; }
+    SaStruct S{h->d_csc_ptr, h->d_rowidx, h->d_csr_ptr, h->d_csr_col, h->d_csr_src, T.nnzA};
+    {
+        ProfScope ps(h, 1, (hipStream_t)stream);
+        hipLaunchKernelGGL(k_sa_lsqr, dim3(B), dim3(NT), lds, (hipStream_t)stream, T, S, A_vals0, x, y, s, dx, dy, dA_bm, dq_vals, sdq_k, sdq_b, adj_status, lsqr_iters,
+                           atol, btol, iter_lim > 0 ? iter_lim : 4 * (T.n + T.m));
+    }
     HIPCHK(hipGetLastError());
     return CE_OK;
 }

@@ -357,6 +357,22 @@ def vjp_const_a(eng, A_bm, x, y, s, dx, dy, batch_minor_out=False, atol=1e-12, b
     """Returns dA (nnz_aug, B), dq (n+1, B), adj_status (B,) in the boundary convention (diffcp_if.py:91-92)."""
     dev = A_bm.device
     n, m, B = eng.n, eng.m, A_bm.shape[0]
+    import os as _os
+    if _os.environ.get("CE_SA_KERNEL", "1") != "0":
+        # one kernel, one workgroup per instance (ce_shared_a.h); falls through to the batched torch implementation when the template
+        # has exponential / power cones or the LSQR vectors of an instance do not fit LDS
+        f64_ = dict(dtype=torch.float64, device=dev)
+        dA_bm = torch.empty((B, eng.nnz_aug), **f64_); dq = torch.empty((n + 1, B), **f64_)
+        adj = torch.empty((B,), dtype=torch.int32, device=dev); its = torch.empty((B,), dtype=torch.int32, device=dev)
+        xc, yc, sc_, dxc, dyc = (t.to(torch.float64).contiguous() for t in (x, y, s, dx, dy))
+        rc = _lib.lib().ce_vjp_shared_a(eng._h, B, A_bm.data_ptr(), xc.data_ptr(), yc.data_ptr(), sc_.data_ptr(), dxc.data_ptr(), dyc.data_ptr(),
+                                        dA_bm.data_ptr(), dq.data_ptr(), B, 1, adj.data_ptr(), its.data_ptr(), atol, btol, iter_factor * (n + m),
+                                        C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+        if rc == 0:
+            eng.last_lsqr_iters = its
+            return (dA_bm.t().contiguous() if batch_minor_out else dA_bm.t()), dq, adj
+        if rc not in (-2, -3):
+            _lib.check(rc, "ce_vjp_shared_a")
     indices, indptr = eng._indices, eng._indptr
     nnzA = eng.nnzA
     cols_np = np.repeat(np.arange(n + 1), np.diff(indptr))

@@ -204,6 +204,18 @@ int ce_ca_finish(ce_handle h, int B, int lp, int max_iters, const double *W, con
                  const double *E, const double *b_hat, const double *c_hat, const double *sigma, const double *scale,
                  const int *active, int *status, int *iters, double *x, double *y, double *s, void *stream);
 
+/*
+ * Shared-A adjoint  <- _compute_gradients -> adj_batch (diffcp_if.py:73-96, 385-403) for templates whose A does not depend on the
+ * parameters: diffcp's adjoint system (r_tau = 0) solved by LSQR -- diffcp's own default mode -- entirely inside one kernel, one
+ * workgroup per instance, A applied from its sparse structure, the PSD cone's derivative on the matrix cores.  A_vals0: the nnz_aug
+ * boundary values of ONE instance (the A part is shared); x, y, s, dx, dy as ce_vjp; dA_bm (B, nnz_aug) batch-major; dq at
+ * [k * sdq_k + i * sdq_b]; adj_status[i] = 1 when LSQR hit iter_lim (0: 4 (n + m)); lsqr_iters (B) or NULL; atol / btol: LSQR stopping
+ * tolerances.  Cones: zero / nonnegative / second-order / PSD; CE_E_UNSUPPORTED / CE_E_TOO_LARGE otherwise (callers fall back to the
+ * batched path of const_a.py).
+ */
+int ce_vjp_shared_a(ce_handle h, int B, const double *A_vals0, const double *x, const double *y, const double *s, const double *dx, const double *dy,
+                    double *dA_bm, double *dq_vals, long sdq_k, long sdq_b, int *adj_status, int *lsqr_iters, double atol, double btol, int iter_lim, void *stream);
+
 /* Introspection used by bench.py / tests: per-kernel HIP-event timing on the launch stream. */
 int ce_set_profiling(ce_handle h, int enable);
 /* which: 0 forward kernel, 1 backward kernel, 2 layout (transpose) kernels.  Returns the mean ms per launch
