@@ -358,7 +358,11 @@ def vjp_const_a(eng, A_bm, x, y, s, dx, dy, batch_minor_out=False, atol=1e-12, b
     dev = A_bm.device
     n, m, B = eng.n, eng.m, A_bm.shape[0]
     import os as _os
-    if _os.environ.get("CE_SA_KERNEL", "1") != "0":
+    # The one-kernel LSQR (ce_shared_a.h) wins whenever the batched implementation below is launch-bound (small / medium batches) or A is
+    # very sparse; at very large batch x nnz its row-parallel sparse products lose to the batch GEMMs with the dense A (measured at
+    # BASELINE config 5: B = 16384, nnzA = 26 k: 1.05 s against 0.77 s), hence the work threshold.  CE_SA_KERNEL=1 / 0 forces / disables.
+    _sa = _os.environ.get("CE_SA_KERNEL")
+    if _sa != "0" and (_sa == "1" or B * max(eng.nnzA, 1) <= (1 << 26)):
         # one kernel, one workgroup per instance (ce_shared_a.h); falls through to the batched torch implementation when the template
         # has exponential / power cones or the LSQR vectors of an instance do not fit LDS
         f64_ = dict(dtype=torch.float64, device=dev)

@@ -31,7 +31,7 @@ def sdp(B, k=20, neq=20, seed=0):
     return A, b, -(y0 @ A), cones
 
 
-def run(name, tpl, cones, A_eval, q_eval, eps, reps, note, P_eval=None, p_structure=None):
+def run(name, tpl, cones, A_eval, q_eval, eps, reps, note, P_eval=None, p_structure=None, min_seconds=1.0):
     ctx = MI355_ctx(p_structure, tpl.problem_data_index, cones, options={"eps": eps, "max_iters": 20000, "raise_on_error": False})
     A_t = torch.from_numpy(A_eval).to(dev).t().contiguous().t().requires_grad_()      # (nnz_aug, B) view of batch-major storage
     q_t = torch.from_numpy(q_eval).to(dev).requires_grad_()
@@ -44,31 +44,24 @@ def run(name, tpl, cones, A_eval, q_eval, eps, reps, note, P_eval=None, p_struct
         p, d, info, _ = _CvxpyLayer.apply(P_t, q_t, A_t, ctx, {}, True, None)
         p.sum().backward()
         return info
-    info = step(); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        info = step()
+    info = step(); info = step(); torch.cuda.synchronize()          # warm-up (kernel loading, allocator, clock ramp)
+    t0 = time.perf_counter(); done = 0
+    while done < reps or time.perf_counter() - t0 < min_seconds:      # at least `reps` steps AND `min_seconds` of wall time (short timings right
+        info = step(); done += 1                                     # after start-up see the clock ramp: profiles/r01/e_configs.json M row)
+        if done >= 2000: break
+        if done >= reps and done % 4 == 0: torch.cuda.synchronize()
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / reps
+    dt = (time.perf_counter() - t0) / done
+    reps = done
     it = info["iters"].float()
     out = dict(config=name, B=B, n=tpl.n, m=tpl.m, cones={k: (v if not isinstance(v, list) else (f"{len(v)}x{v[0]}" if v else "-")) for k, v in cones.items()},
                eps=eps, ms_per_step=dt * 1e3, problems_per_s=B / dt, iters_mean=float(it.mean()), iters_max=float(it.max()),
-               solved=float((info["status"] == 1).float().mean()), path=ctx.engine(dev).last_path, note=note)
+               solved=float((info["status"] == 1).float().mean()), path=ctx.engine(dev).last_path, reps=reps,
+               acceleration="plugin default (SCS acceleration_lookback 10; engine: one-pair history where the kernel implements it)", note=note)
     print(json.dumps(out), flush=True)
     return out
 
 
-ONLY = os.environ.get("CONFIGS_ONLY")          # e.g. CONFIGS_ONLY=E runs just the exponential-cone row
-res = []
-for key, B, note in () if ONLY else (("M", 4096, "metric configuration"), ("C2", 4096, "nonneg cone only (random LP)"), ("C3", 4096, "SOCP n=100, 10 SOC(11)")):
-    cfg = P.CONFIGS[key]
-    tpl = P.dense_template(cfg["n"], cfg["cones"])
-    A, b, c = P.generate(cfg["n"], cfg["cones"], B, seed=0)
-    res.append(run(key, tpl, cfg["cones"], *tpl.values_from_dense(A, b, c), 1e-4, 5 if key != "C2" else 2, note))
-A, b, c, cones = P.box_qp_batch(50, 4096 if not ONLY else 2, seed=0)
-tpl = P.dense_template(A.shape[2], cones, pattern=(A[0] != 0))
-if not ONLY:
-    res.append(run("C2Q", tpl, cones, *tpl.values_from_dense(A, b, c), 1e-4, 5, "box QP n=50 in SOC-epigraph form (BASELINE config 2 as DIFFCP sees it); F shared, g/lo/hi batched"))
 def native_box_qp(B, nx=50, seed=0):
     """BASELINE config 2 in its native form: min 1/2 x^T (2 F^T F) x - 2 g^T F x, lo <= x <= hi; same F, g, lo, hi as box_qp_batch"""
     rng = np.random.default_rng(seed)
@@ -84,29 +77,39 @@ def native_box_qp(B, nx=50, seed=0):
     return An, np.concatenate([-lo, hi], axis=1), -2 * g @ F, pst, np.broadcast_to(pv[:, None], (len(pv), B)).copy()
 
 
-if not ONLY or ONLY == "C2N":
+
+
+WANT = [k for k in os.environ.get("CONFIGS", "M,C2,C2Q,C2N,C3,C4,C5,E").split(",") if k]
+res = []
+for key, note in (("M", "metric configuration"), ("C2", "nonneg cone only (random LP)"), ("C3", "SOCP n=100, 10 SOC(11)")):
+    if key not in WANT: continue
+    cfg = P.CONFIGS[key]
+    tpl = P.dense_template(cfg["n"], cfg["cones"])
+    A, b, c = P.generate(cfg["n"], cfg["cones"], 4096, seed=0)
+    res.append(run(key, tpl, cfg["cones"], *tpl.values_from_dense(A, b, c), 1e-4, 20 if key != "C2" else 3, note))
+if "C2Q" in WANT:
+    A, b, c, cones = P.box_qp_batch(50, 4096, seed=0)
+    tpl = P.dense_template(A.shape[2], cones, pattern=(A[0] != 0))
+    res.append(run("C2Q", tpl, cones, *tpl.values_from_dense(A, b, c), 1e-4, 10, "box QP n=50 in SOC-epigraph form (BASELINE config 2 as DIFFCP sees it); F shared, g/lo/hi batched"))
+if "C2N" in WANT:
     An, bn, qn, pst, Pv = native_box_qp(4096)
     conesN = {"z": 0, "l": 100, "q": [], "s": []}
     tplN = P.dense_template(50, conesN, pattern=(An != 0))
-    res.append(run("C2N", tplN, conesN, *tplN.values_from_dense(np.broadcast_to(An, (4096,) + An.shape).copy(), bn, qn), 1e-4, 200 if ONLY else 5,
+    res.append(run("C2N", tplN, conesN, *tplN.values_from_dense(np.broadcast_to(An, (4096,) + An.shape).copy(), bn, qn), 1e-4, 20,
                    "box QP n=50 in NATIVE form (P = 2 F^T F inside the kernels, 100 box rows): BASELINE config 2 (i)", P_eval=Pv, p_structure=pst))
-    if ONLY:
-        json.dump(res, open(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/configs_C2N.json", "w"), indent=1)
-        sys.exit(0)
-ecfg = dict(n=40, cones={"z": 0, "l": 12, "q": [4], "s": [], "ep": 24})      # the cone shape of a 12-sample, 3-feature logistic-regression layer
-tplE = P.dense_template(ecfg["n"], ecfg["cones"])
-Ae, be, ce_ = P.generate(ecfg["n"], ecfg["cones"], 4096, seed=0)
-res.append(run("E", tplE, ecfg["cones"], *tplE.values_from_dense(Ae, be, ce_), 1e-4, 30 if ONLY else 5, "24 exponential cones + nonneg + SOC(4), n=40, m=88 (logistic-regression layer shape), dense random A"))
-if ONLY:
-    json.dump(res, open(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/configs_E.json", "w"), indent=1)
-    sys.exit(0)
-A, b, c, cones = sdp(1024)
-tpl = P.dense_template(A.shape[1], cones, pattern=(A != 0), b_pattern=np.ones(A.shape[0], bool))
-res.append(run("C4", tpl, cones, *tpl.values_from_dense(np.broadcast_to(A, (1024,) + A.shape).copy(), b, c), 1e-4, 3, "SDP, one 20x20 PSD cone, A shared (BASELINE config 4)"))
-Bp = int(os.environ.get("C5_BATCH", "16384"))
-A, b, c, cones = portfolio(Bp)
-tpl = P.dense_template(A.shape[1], cones, pattern=(A != 0), b_pattern=(b[0] != 0))
-res.append(run("C5", tpl, cones, *tpl.values_from_dense(np.broadcast_to(A, (Bp,) + A.shape).copy(), b, c), 1e-4, 1, "portfolio n=501, A shared, returns batched (BASELINE config 5), 1 GPU"))
+if "E" in WANT:
+    ecfg = dict(n=40, cones={"z": 0, "l": 12, "q": [4], "s": [], "ep": 24})      # the cone shape of a 12-sample, 3-feature logistic-regression layer
+    tplE = P.dense_template(ecfg["n"], ecfg["cones"])
+    Ae, be, ce_ = P.generate(ecfg["n"], ecfg["cones"], 4096, seed=0)
+    res.append(run("E", tplE, ecfg["cones"], *tplE.values_from_dense(Ae, be, ce_), 1e-4, 10, "24 exponential cones + nonneg + SOC(4), n=40, m=88 (logistic-regression layer shape), dense random A"))
+if "C4" in WANT:
+    A, b, c, cones, tpl = P.sdp_c4_batch(1024, seed=0)
+    res.append(run("C4", tpl, cones, *tpl.values_from_dense(np.broadcast_to(A, (1024,) + A.shape).copy(), b, c), 1e-4, 5, "SDP, one 20x20 PSD cone, A shared (BASELINE config 4)"))
+if "C5" in WANT:
+    Bp = int(os.environ.get("C5_BATCH", "16384"))
+    A, b, c, cones, tpl = P.portfolio_c5_batch(Bp, seed=0)
+    res.append(run("C5", tpl, cones, *tpl.values_from_dense(np.broadcast_to(A, (Bp,) + A.shape).copy(), np.broadcast_to(b, (Bp,) + b.shape).copy(), c), 1e-4, 2,
+                   "portfolio n=501, A shared, returns batched (BASELINE config 5), 1 GPU", min_seconds=0.0))
 out = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/configs.json"
-os.makedirs(os.path.dirname(out), exist_ok=True)
+os.makedirs(os.path.dirname(out) or ".", exist_ok=True)
 json.dump(res, open(out, "w"), indent=1)
