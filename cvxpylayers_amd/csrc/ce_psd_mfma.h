@@ -15,6 +15,28 @@
 
 typedef double psd_v4d __attribute__((ext_vector_type(4)));
 
+// idx / d for 0 <= idx < 65536, 1 <= d <= 64 without the ~40-instruction integer division expansion (rcp = 1.0f / d, computed once):
+// (idx + 0.5) / d stays at least 0.5 / d away from every integer, far more than the rounding error of the float product.
+__device__ __forceinline__ int psd_fdiv(int idx, float rcp) { return (int)(((float)idx + 0.5f) * rcp); }
+
+// Jacobi rotation (c, s) annihilating the (p, q) entry:  theta = (a_qq - a_pp) / (2 a_pq),  t = sign(theta) / (|theta| + sqrt(theta^2 + 1)),
+// c = 1 / sqrt(t^2 + 1), s = t c  -- with hardware reciprocal / reciprocal-square-root seeds and Newton / Goldschmidt refinement instead of
+// the IEEE divide and square-root expansions (four of them, ~200 dependent instructions, sat on the critical path of EVERY round of
+// every sweep: one lane per pair computes this while the rest of the workgroup waits).  c^2 + s^2 = 1 to rounding, which is what keeps V
+// orthogonal; the angle itself only needs to be approximately optimal for the sweeps to converge.
+__device__ __forceinline__ double psd_rcp(double v) { double r = __builtin_amdgcn_rcp(v); r = fma(fma(-v, r, 1.0), r, r); return fma(fma(-v, r, 1.0), r, r); }
+__device__ __forceinline__ void psd_rotation(double app, double aqq, double apq, double &c, double &sn) {
+    c = 1.0; sn = 0.0;
+    if (apq == 0.0) return;
+    const double theta = (aqq - app) * psd_rcp(2 * apq), at = fabs(theta);
+    double t;
+    if (at > 1e100) t = 0.5 * psd_rcp(theta);
+    else { double sq, ri; sqrt_rsqrt(fma(theta, theta, 1.0), sq, ri); t = (theta >= 0 ? 1.0 : -1.0) * psd_rcp(at + sq); }
+    double sq2, ri2;
+    sqrt_rsqrt(fma(t, t, 1.0), sq2, ri2);
+    c = ri2; sn = t * ri2;
+}
+
 // D = A B on KT x KT tiles of 16 x 16; fa(M, K), fb(K, N): operand elements, out(M, N, v): result sink.  All waves of the workgroup call it.
 template <int NTH, class FA, class FB, class FO>
 __device__ __forceinline__ void psd_mfma_gemm(int KT, FA &&fa, FB &&fb, FO &&out) {
@@ -36,11 +58,13 @@ __device__ __forceinline__ void psd_sweeps(double *Sm, double *Vm, int k, int P,
     constexpr int NT = NTH, NW = NTH / 64;
     const int tid = threadIdx.x;
     const int K = (k + 1) & ~1;
+    double prev_off = 0;
     for (int sweep = 0; sweep < 40; sweep++) {
         double r[2] = {0, 0};
         for (int idx = tid; idx < k * k; idx += NT) { const int i = idx / k, j = idx - i * k; const double v = Sm[i * P + j]; if (i == j) r[1] = fma(v, v, r[1]); else r[0] = fma(v, v, r[0]); }
         block_reduce_n<2, NW>(r, 0u, red);
-        if (r[0] <= 1e-30 * (r[0] + r[1]) || r[0] == 0.0) break;          // uniform
+        if (r[0] <= 1e-30 * (r[0] + r[1]) || r[0] == 0.0 || (r[0] <= 1e-24 * (r[0] + r[1]) && r[0] > 0.25 * prev_off)) break;          // uniform (see psd_sweeps_wave)
+        prev_off = r[0];
         for (int rd = 0; rd < K - 1; rd++) {
             if (tid < K / 2) {
                 int p = (tid == 0) ? K - 1 : (rd + tid) % (K - 1);
@@ -48,12 +72,7 @@ __device__ __forceinline__ void psd_sweeps(double *Sm, double *Vm, int k, int P,
                 if (p > q) { const int t_ = p; p = q; q = t_; }
                 double c = 1.0, sn = 0.0;
                 if (q < k) {
-                    const double apq = Sm[p * P + q];
-                    if (apq != 0.0) {
-                        const double theta = (Sm[q * P + q] - Sm[p * P + p]) / (2 * apq);
-                        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1));
-                        c = 1 / sqrt(t * t + 1); sn = t * c;
-                    }
+                    psd_rotation(Sm[p * P + p], Sm[q * P + q], Sm[p * P + q], c, sn);
                 } else { p = -1; }
                 cs[4 * tid] = c; cs[4 * tid + 1] = sn; cs[4 * tid + 2] = (double)p; cs[4 * tid + 3] = (double)q;
             }
@@ -82,26 +101,90 @@ __device__ __forceinline__ void psd_sweeps(double *Sm, double *Vm, int k, int P,
     }
 }
 
+// The same sweeps executed by ONE wave (lanes of wave 0), without workgroup barriers: a k <= 64 Jacobi round is two short phases
+// of independent work -- (A) K/2 rotation parameters, (B) the two-sided update S <- J^T S J done on the (K/2)^2 disjoint 2 x 2 blocks
+// {p_a, q_a} x {p_b, q_b} together with the column rotations V <- V J -- and an s_barrier between phases costs more than the phase
+// (~700 cycles against ~150 when the wave just orders its own LDS accesses).  All waves call it; ends with a workgroup barrier.
+template <int NTH>
+__device__ __forceinline__ void psd_sweeps_wave(double *Sm, double *Vm, int k, int P, double *cs, double *red) {
+    (void)red;
+    const int tid = threadIdx.x;
+    const int K = (k + 1) & ~1, H = K / 2;
+    const float rk = 1.0f / (float)k, rH = 1.0f / (float)H;
+    if (tid < 64) {
+        const int lane = tid;
+        double prev_off = 0;
+        for (int sweep = 0; sweep < 40; sweep++) {
+            double r0 = 0, r1 = 0;
+            for (int idx = lane; idx < k * k; idx += 64) { const int i = psd_fdiv(idx, rk), j = idx - i * k; const double v = Sm[i * P + j]; if (i == j) r1 = fma(v, v, r1); else r0 = fma(v, v, r0); }
+            r0 = wave_reduce_dpp<false>(r0); r1 = wave_reduce_dpp<false>(r1);
+            // converged: off-diagonal mass below 1e-15 of the total, or -- the warm-started matrix S' = V^T S V carries rounding noise of a
+            // few 1e-16 |S| per entry, so that target can sit below the floor -- already tiny (1e-12) and no longer decreasing
+            if (r0 <= 1e-30 * (r0 + r1) || r0 == 0.0 || (r0 <= 1e-24 * (r0 + r1) && r0 > 0.25 * prev_off)) break;          // wave-uniform
+            prev_off = r0;
+            for (int rd = 0; rd < K - 1; rd++) {
+                for (int t = lane; t < H; t += 64) {
+                    int p = rd + t; if (p >= K - 1) p -= K - 1;                    // (rd + t) % (K - 1), both terms < K - 1
+                    if (t == 0) p = K - 1;
+                    int q = rd + K - 1 - t; if (q >= K - 1) q -= K - 1;
+                    if (p > q) { const int t_ = p; p = q; q = t_; }
+                    double c = 1.0, sn = 0.0;
+                    if (q < k) {
+                        psd_rotation(Sm[p * P + p], Sm[q * P + q], Sm[p * P + q], c, sn);
+                    } else { q = -1; }                                 // the dummy player of an odd order: p is left alone this round
+                    cs[4 * t] = c; cs[4 * t + 1] = sn; cs[4 * t + 2] = (double)p; cs[4 * t + 3] = (double)q;
+                }
+                wave_lds_exchange();
+                for (int blk = lane; blk < H * H; blk += 64) {         // S <- J^T S J on the 2 x 2 block (pair a) x (pair b)
+                    const int a = psd_fdiv(blk, rH), b = blk - a * H;
+                    const double ca = cs[4 * a], sa = cs[4 * a + 1], cb = cs[4 * b], sb = cs[4 * b + 1];
+                    const int pa = (int)cs[4 * a + 2], qa = (int)cs[4 * a + 3], pb = (int)cs[4 * b + 2], qb = (int)cs[4 * b + 3];
+                    const double s00 = Sm[pa * P + pb], s01 = qb >= 0 ? Sm[pa * P + qb] : 0.0, s10 = qa >= 0 ? Sm[qa * P + pb] : 0.0, s11 = (qa >= 0 && qb >= 0) ? Sm[qa * P + qb] : 0.0;
+                    // columns:  (x_p, x_q) <- (c x_p - s x_q, s x_p + c x_q)   then rows likewise
+                    const double t00 = cb * s00 - sb * s01, t01 = sb * s00 + cb * s01, t10 = cb * s10 - sb * s11, t11 = sb * s10 + cb * s11;
+                    Sm[pa * P + pb] = ca * t00 - sa * t10;
+                    if (qb >= 0) Sm[pa * P + qb] = ca * t01 - sa * t11;
+                    if (qa >= 0) Sm[qa * P + pb] = sa * t00 + ca * t10;
+                    if (qa >= 0 && qb >= 0) Sm[qa * P + qb] = sa * t01 + ca * t11;
+                }
+                for (int it = lane; it < k * H; it += 64) {            // V <- V J
+                    const int row = psd_fdiv(it, rH), b = it - row * H;
+                    const int pb = (int)cs[4 * b + 2], qb = (int)cs[4 * b + 3];
+                    if (qb < 0) continue;
+                    const double cb = cs[4 * b], sb = cs[4 * b + 1];
+                    const double x = Vm[row * P + pb], y = Vm[row * P + qb];
+                    Vm[row * P + pb] = cb * x - sb * y; Vm[row * P + qb] = sb * x + cb * y;
+                }
+                wave_lds_exchange();
+            }
+        }
+    }
+    __syncthreads();
+}
+
 // LDS doubles needed: 3 * KP * (KP + 1) + 2 * k + 8  (+ the reduction scratch of block_reduce_n)
 __host__ __device__ inline int psd_mfma_kp(int k) { return 16 * ((k + 15) / 16); }
 
 // zsvec (svec of S, lower triangle column-major, sqrt(2) off-diagonals) is replaced by svec(Pi_PSD(S)).
 // Vstate: k * k doubles of global memory, the eigenvectors of the previous call (row-major), or NULL; warm != 0: start from them.
-template <int NTH>
+// VM_IS_STATE: the eigenvectors of the previous call are still in Vm (a persistent kernel keeps them in LDS): warm != 0 starts from them.
+template <int NTH, bool VM_IS_STATE = false>
 __device__ __forceinline__ void psd_project_mfma(double *zsvec, int k, double *Sm, double *Vm, double *Tm, double *cs, double *red,
                                                  double *Vstate, int warm) {
     constexpr int NT = NTH;
     const int tid = threadIdx.x;
     const int KP = psd_mfma_kp(k), P = KP + 1, KT = KP / 16;
-    const bool use_prev = warm && Vstate != nullptr;
+    const bool use_prev = warm && (VM_IS_STATE || Vstate != nullptr);
+    const float rKP = 1.0f / (float)KP, rk = 1.0f / (float)k;
     for (int idx = tid; idx < KP * KP; idx += NT) {
-        const int i = idx / KP, j = idx - i * KP;
+        const int i = psd_fdiv(idx, rKP), j = idx - i * KP;
         double sv = 0.0, vv = 0.0;
         if (i < k && j < k) {
             const int a = i >= j ? i : j, b = i >= j ? j : i;                 // lower-triangle entry (a, b), column-major packed
             const double v = zsvec[b * k - (b * (b - 1)) / 2 + (a - b)];
             sv = (a == b) ? v : v * M_SQRT1_2;
-            vv = use_prev ? Vstate[i * k + j] : (i == j ? 1.0 : 0.0);
+            if constexpr (VM_IS_STATE) vv = use_prev ? Vm[i * P + j] : (i == j ? 1.0 : 0.0);
+            else vv = use_prev ? Vstate[i * k + j] : (i == j ? 1.0 : 0.0);
         }
         Sm[i * P + j] = sv; Vm[i * P + j] = vv;
     }
@@ -115,26 +198,31 @@ __device__ __forceinline__ void psd_project_mfma(double *zsvec, int k, double *S
                            [&](int M, int N, double v) { Sm[M * P + N] = v; });
         __syncthreads();
         for (int idx = tid; idx < k * k; idx += NT) {      // exact symmetry for the rotations (each pair handled by its lower-triangle thread)
-            const int i = idx / k, j = idx - i * k;
+            const int i = psd_fdiv(idx, rk), j = idx - i * k;
             if (i > j) { const double a = 0.5 * (Sm[i * P + j] + Sm[j * P + i]); Sm[i * P + j] = a; Sm[j * P + i] = a; }
         }
         __syncthreads();
     }
-    psd_sweeps<NTH>(Sm, Vm, k, P, cs, red);
+    psd_sweeps_wave<NTH>(Sm, Vm, k, P, cs, red);
     for (int i = tid; i < KP; i += NT) cs[i] = i < k ? fmax(Sm[i * P + i], 0.0) : 0.0;
     __syncthreads();
     // X = (V diag(w+)) V^T
     psd_mfma_gemm<NTH>(KT, [&](int M, int K) { return Vm[M * P + K] * cs[K]; }, [&](int K, int N) { return Vm[N * P + K]; },
                        [&](int M, int N, double v) { Tm[M * P + N] = v; });
     __syncthreads();
-    for (int pos = tid; pos < k * (k + 1) / 2; pos += NT) {
-        int b = 0, rem = pos;
-        while (rem >= k - b) { rem -= k - b; b++; }
-        const int a = b + rem;
+    for (int idx = tid; idx < k * k; idx += NT) {          // lower triangle (a >= b) -> svec position b k - b (b - 1) / 2 + (a - b)
+        const int a = psd_fdiv(idx, rk), b = idx - a * k;
+        if (a < b) continue;
         const double v = 0.5 * (Tm[a * P + b] + Tm[b * P + a]);
-        zsvec[pos] = (a == b) ? v : v * M_SQRT2;
+        zsvec[b * k - (b * (b - 1)) / 2 + (a - b)] = (a == b) ? v : v * M_SQRT2;
     }
     if (Vstate != nullptr)
-        for (int idx = tid; idx < k * k; idx += NT) { const int i = idx / k, j = idx - i * k; Vstate[idx] = Vm[i * P + j]; }
+        for (int idx = tid; idx < k * k; idx += NT) { const int i = psd_fdiv(idx, rk), j = idx - i * k; Vstate[idx] = Vm[i * P + j]; }
     __syncthreads();
+}
+
+// the same with the eigenvector state resident in LDS (Vm keeps its content between calls)
+template <int NTH>
+__device__ __forceinline__ void psd_project_mfma_lds(double *zsvec, int k, double *Sm, double *Vm, double *Tm, double *cs, double *red, int warm) {
+    psd_project_mfma<NTH, true>(zsvec, k, Sm, Vm, Tm, cs, red, nullptr, warm);
 }

@@ -89,7 +89,7 @@ k_sa_lsqr(DevT T, SaStruct S, const double *__restrict__ Avals0, const double *_
             Hm[i * P + j] = sv; U[i * P + j] = (i == j && i < k) ? 1.0 : 0.0;
         }
         __syncthreads();
-        psd_sweeps<NT>(Hm, U, k, P, cs, red);
+        psd_sweeps_wave<NT>(Hm, U, k, P, cs, red);
         for (int idx = tid; idx < KP * KP; idx += NT) {
             const int i = idx / KP, j = idx - i * KP;
             double bv = 0.0;

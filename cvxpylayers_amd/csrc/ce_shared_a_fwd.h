@@ -1,0 +1,359 @@
+// ce_shared_a_fwd.h -- SHARED-A forward: the whole SCS-style solve of one instance inside ONE persistent kernel (one workgroup per instance).
+//
+// Templates whose A does not depend on the parameters (only b, c vary: BASELINE configurations 4 and 5) and whose A consists of a few
+// "dense" rows plus rows with a single entry (bounds, identity blocks of PSD / SOC embeddings):   A-hat = [ A_s (singleton rows) ; A_d (r rows) ].
+// Then the reduced KKT matrix is diagonal plus rank r,
+//        S = rho_x I + A-hat^T Dy A-hat = Dg + A_d^T Dd A_d ,      Dg_j = rho_x + scale * gs_j ,
+// and its inverse is applied by the Woodbury identity with ONE r x r matrix per instance,
+//        S^-1 t = u - Dg^-1 A_d^T K^-1 A_d u ,   u = Dg^-1 t ,   K = Dd^-1 + A_d Dg^-1 A_d^T ,
+// instead of round 1's dense n x n eigenvector products (two rocBLAS GEMMs over the batch per iteration, ~10 launches and a host
+// synchronisation per check interval).  K is formed on the matrix cores (v_mfma_f64_16x16x4_f64) from the transposed dense rows
+// A_d^T (n x RP, row-major, shared by all instances: coalesced reads that hit L2) and inverted in LDS; all iterates of the instance
+// live in LDS; termination, certificates and the adaptive scale run in the kernel (no host round trip); the PSD cone is projected by
+// the warm-started MFMA routine of ce_psd_mfma.h with the eigenvectors kept in LDS between iterations.
+// Algorithm, constants and order of operations: oracle/cone_oracle.c (SCS 3 restated) / cvxpylayers_amd/interfaces/const_a.py.
+// Cones: zero / nonnegative / second-order / PSD.
+#pragma once
+
+struct SaFwd {
+    int r, RP;                   // dense rows, padded to a multiple of 16
+    const double *AdT;           // [n][RP]  equilibrated dense rows, transposed (solver sign), zero padded
+    const int *drow;             // [r]      row index of dense row a
+    const int *srow_col;         // [m]      column of a singleton row, -1 otherwise
+    const double *srow_val;      // [m]      its (equilibrated, solver-sign) value
+    const int *scol_ptr;         // [n + 1]  singleton rows of every column
+    const int *scol_row;         // [#singleton entries]
+    const double *gs;            // [n]      sum over the singleton rows of column j of d0_i a_i^2
+    const double *Dv, *Ev;       // [m], [n] equilibration
+};
+
+// LDS doubles (see the carve in the kernel)
+__host__ __device__ inline size_t sa_fwd_lds_doubles(int n, int m, int nq, int ns, int maxs, int RP) {
+    const int l = n + m + 1, lp = l + (l & 1);
+    const int kp = ns > 0 ? psd_mfma_kp(maxs) : 0;
+    return 6 * (size_t)lp + 3 * (size_t)n + 2 * (size_t)m + (size_t)RP * (RP + 1) + 4 * (size_t)RP + 2 * (size_t)(nq > 0 ? nq : 1) +
+           (size_t)(ns > 0 ? (ns + 2) * kp * (kp + 1) + 2 * kp + 8 : 0) + NT + NW * 8 + 32;
+}
+
+template <int RP>
+__global__ void __launch_bounds__(NT, 2)
+k_sa_fwd(DevT T, SaFwd F, ce_settings S, const double *__restrict__ BHg, const double *__restrict__ CHg, const double *__restrict__ sigma_g,
+         const double *__restrict__ nb0_g, const double *__restrict__ nc0_g, const double *__restrict__ warm_x, const double *__restrict__ warm_y,
+         const double *__restrict__ warm_s, double *__restrict__ xo, double *__restrict__ yo, double *__restrict__ so,
+         int *__restrict__ iters_o, int *__restrict__ status_o, double *__restrict__ resid_o) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    const int tid = threadIdx.x, inst = blockIdx.x;
+    const int n = T.n, m = T.m, l = n + m + 1, lp = l + (l & 1), z = T.z, nl = T.l, nq = T.nq, ns = T.ns;
+    const int r = F.r, LK = RP + 1;
+    double *p = sm;
+    double *W = p; p += lp; double *UT = p; p += lp; double *U = p; p += lp; double *G = p; p += lp; double *PHI = p; p += lp; double *zb = p; p += lp;
+    double *tv = p; p += n; double *px = p; p += n; double *dgi = p; p += n;
+    double *qy = p; p += m; double *bh = p; p += m;
+    double *Kinv = p; p += (size_t)RP * LK;
+    double *vd = p; p += RP; double *zd = p; p += RP; double *wyd = p; p += RP; double *dyd = p; p += RP;
+    double *socc = p; p += 2 * (nq > 0 ? nq : 1);
+    const int KP = ns > 0 ? psd_mfma_kp(T.maxs) : 0, PM = KP * (KP + 1);
+    double *Vst = p; p += (size_t)ns * PM;                 // eigenvectors of every PSD block, kept between iterations
+    double *Sm = p; p += PM; double *Tm = p; p += PM;      // PSD scratch
+    double *cs = p; p += (ns > 0 ? 2 * KP + 8 : 0);
+    double *part = p; p += NT;                              // partial sums of the dense-row products
+    double *red = p; p += NW * 8;
+    double *sc = p; p += 32;
+    const double *ch = CHg + (size_t)inst * n;              // c-hat stays in global memory (read in refresh / checks only)
+    const double rho_x = S.rho_x, rtau = TAU_FACTOR, alpha = S.alpha;
+    const double sigma = sigma_g[inst], isg = 1.0 / sigma;
+    double scale = S.scale;
+    auto dyv = [&](int i) -> double { return (i < z) ? ZERO_CONE_FACTOR * scale : scale; };
+
+    for (int i = tid; i < m; i += NT) bh[i] = BHg[(size_t)inst * m + i];
+    for (int e = tid; e < lp; e += NT) { W[e] = 0.0; UT[e] = 0.0; U[e] = 0.0; }
+    ce_math_table_init(sc + 12, tid);                       // sc[12 ..]: ce_math.h coefficient table (CE_MATH_TAB = 18 <= 20)
+    __syncthreads();
+    const double *mtab = sc + 12;
+
+    // ---------------- products with the shared matrix
+    // dense rows:  out_a = sum_j AdT[j][a] xin[j]   (a < RP; every thread (a, group) sums a stride of j, partials through LDS)
+    auto dense_times = [&](const double *xin, double *out) {
+        constexpr int ng = NT / RP;
+        const int a = tid % RP, g = tid / RP;
+        double acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
+        int j = g;
+        for (; j + 3 * ng < n; j += 4 * ng) {        // four loads in flight (the matrix streams from L2: latency, not bandwidth, is the cost)
+            const double m0 = F.AdT[(size_t)j * RP + a], m1 = F.AdT[(size_t)(j + ng) * RP + a], m2 = F.AdT[(size_t)(j + 2 * ng) * RP + a], m3 = F.AdT[(size_t)(j + 3 * ng) * RP + a];
+            acc0 = fma(m0, xin[j], acc0); acc1 = fma(m1, xin[j + ng], acc1); acc2 = fma(m2, xin[j + 2 * ng], acc2); acc3 = fma(m3, xin[j + 3 * ng], acc3);
+        }
+        for (; j < n; j += ng) acc0 = fma(F.AdT[(size_t)j * RP + a], xin[j], acc0);
+        part[tid] = (acc0 + acc1) + (acc2 + acc3);
+        __syncthreads();
+        if (tid < RP) { double s_ = 0; for (int gg = 0; gg < ng; gg++) s_ += part[gg * RP + tid]; out[tid] = s_; }
+        __syncthreads();
+    };
+    // sum_a AdT[j][a] w[a] for one row j: the row is contiguous (RP doubles, 16-byte aligned), fetched with wide loads all in flight
+    auto row_dot = [&](int j, const double *w) -> double {
+        const double2 *row = reinterpret_cast<const double2 *>(F.AdT + (size_t)j * RP);
+        double2 rv[RP / 2];
+#pragma unroll
+        for (int a2 = 0; a2 < RP / 2; a2++) rv[a2] = row[a2];
+        double a0 = 0, a1 = 0;
+#pragma unroll
+        for (int a2 = 0; a2 < RP / 2; a2++) { a0 = fma(rv[a2].x, w[2 * a2], a0); a1 = fma(rv[a2].y, w[2 * a2 + 1], a1); }
+        return a0 + a1;
+    };
+    // y = A-hat x :  singleton rows elementwise, dense rows through dense_times.   out(i, value)
+    auto A_times = [&](const double *xin, auto &&out) {
+        dense_times(xin, vd);
+        for (int i = tid; i < m; i += NT) { const int c = F.srow_col[i]; if (c >= 0) out(i, F.srow_val[i] * xin[c]); }
+        for (int a = tid; a < r; a += NT) out(F.drow[a], vd[a]);
+        __syncthreads();
+    };
+    // x = A-hat^T y :  out(j, value)
+    auto AT_times = [&](const double *yin, auto &&out) {
+        for (int a = tid; a < RP; a += NT) wyd[a] = a < r ? yin[F.drow[a]] : 0.0;
+        __syncthreads();
+        for (int j = tid; j < n; j += NT) {
+            double acc = row_dot(j, wyd);
+            for (int k = F.scol_ptr[j]; k < F.scol_ptr[j + 1]; k++) { const int i = F.scol_row[k]; acc = fma(F.srow_val[i], yin[i], acc); }
+            out(j, acc);
+        }
+        __syncthreads();
+    };
+    // pout = S^-1 tin  (Woodbury).  tin / pout may alias.
+    auto wood = [&](const double *tin, double *pout) {
+        for (int j = tid; j < n; j += NT) pout[j] = tin[j] * dgi[j];
+        __syncthreads();
+        dense_times(pout, vd);
+        if (tid < RP) { double s_ = 0; const double *kr = Kinv + tid * LK; for (int b = 0; b < r; b++) s_ = fma(kr[b], vd[b], s_); zd[tid] = tid < r ? s_ : 0.0; }
+        __syncthreads();
+        for (int j = tid; j < n; j += NT) {
+            pout[j] -= dgi[j] * row_dot(j, zd);
+        }
+        __syncthreads();
+    };
+
+    // ---------------- (re)factor for the current scale: Dg^-1, K^-1 (MFMA + Gauss-Jordan in LDS), then g, h.g, phi
+    double hg = 0, inv_den = 0;
+    auto refresh = [&]() {
+        for (int j = tid; j < n; j += NT) dgi[j] = 1.0 / (rho_x + scale * F.gs[j]);
+        for (int a = tid; a < RP; a += NT) dyd[a] = a < r ? dyv(F.drow[a]) : 1.0;
+        __syncthreads();
+        {   // K = Dd^-1 + A_d Dg^-1 A_d^T : tiles of 16 x 16 over the waves, operands straight from the shared A_d^T (coalesced, L2)
+            typedef double v4d __attribute__((ext_vector_type(4)));
+            const int KT = RP / 16, wave = tid >> 6, lane = tid & 63, lg = lane >> 4, lc = lane & 15;
+            for (int t = wave; t < KT * KT; t += NW) {
+                const int ti = t / KT, tj = t - ti * KT;
+                v4d acc = {0.0, 0.0, 0.0, 0.0};
+                for (int j0 = 0; j0 < n; j0 += 4) {
+                    const int j = j0 + lg;
+                    double a = 0.0, b = 0.0;
+                    if (j < n) { const double *row = F.AdT + (size_t)j * RP; a = row[16 * ti + lc] * dgi[j]; b = row[16 * tj + lc]; }
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int row = 16 * ti + lg + 4 * q, col = 16 * tj + lc;
+                    Kinv[row * LK + col] = acc[q] + (row == col ? (row < r ? 1.0 / dyd[row] : 1.0) : 0.0);
+                }
+            }
+        }
+        __syncthreads();
+        for (int k = 0; k < r; k++) {       // in-place Gauss-Jordan inverse (K is symmetric positive definite: no pivoting)
+            const double pinv = 1.0 / Kinv[k * LK + k];
+            __syncthreads();
+            for (int idx = tid; idx < r * r; idx += NT) {
+                const int i = idx / r, j = idx - i * r;
+                if (i != k && j != k) Kinv[i * LK + j] = fma(-Kinv[i * LK + k] * pinv, Kinv[k * LK + j], Kinv[i * LK + j]);
+            }
+            __syncthreads();
+            for (int i = tid; i < r; i += NT) {
+                if (i != k) { const double ck = Kinv[i * LK + k], rk = Kinv[k * LK + i]; Kinv[i * LK + k] = -ck * pinv; Kinv[k * LK + i] = rk * pinv; }
+                else Kinv[k * LK + k] = pinv;
+            }
+            __syncthreads();
+        }
+        // a = A^T (Dy b) ;  gx = S^-1 (c - a) ;  pk = S^-1 (c + a) ;  gy = Dy (A gx + b) ;  hg = c.gx + b.gy ;  phi = (rho pk ; b - A pk)
+        for (int i = tid; i < m; i += NT) qy[i] = dyv(i) * bh[i];
+        __syncthreads();
+        AT_times(qy, [&](int j, double a) { const double cj = ch[j]; tv[j] = cj - a; px[j] = cj + a; });
+        wood(tv, tv);                   // gx
+        wood(px, px);                   // pk
+        A_times(tv, [&](int i, double a) { G[n + i] = dyv(i) * (a + bh[i]); });
+        A_times(px, [&](int i, double a) { PHI[n + i] = bh[i] - a; });
+        double rr[1] = {0};
+        for (int j = tid; j < n; j += NT) { G[j] = tv[j]; PHI[j] = rho_x * px[j]; rr[0] = fma(ch[j], tv[j], rr[0]); }
+        for (int i = tid; i < m; i += NT) rr[0] = fma(bh[i], G[n + i], rr[0]);
+        block_reduce<1>(rr, 0u, red);
+        hg = rr[0]; inv_den = 1.0 / (rtau + hg);
+        if (tid == 0) { G[l - 1] = 0.0; PHI[l - 1] = 0.0; }
+        __syncthreads();
+    };
+
+    if (tid == 0) W[l - 1] = 1.0;       // cold start w = (0, 0, 1)
+    __syncthreads();
+    if (S.warm_start && warm_x) {       // SCS warm start u = (x^, y^, 1), v = (0, s^, 0): w = u + R^-1 v in the equilibrated space
+        double bad[1] = {0};
+        for (int j = tid; j < n; j += NT) { const double v = sigma * warm_x[(size_t)inst * n + j] / F.Ev[j]; tv[j] = v; if (!(fabs(v) < 1e300)) bad[0] = 1.0; }
+        for (int i = tid; i < m; i += NT) {
+            const double dvi = F.Dv[i];
+            const double v = sigma * warm_y[(size_t)inst * m + i] / dvi + sigma * dvi * warm_s[(size_t)inst * m + i] * dyv(i);
+            qy[i] = v; if (!(fabs(v) < 1e300)) bad[0] = 1.0;
+        }
+        block_reduce<1>(bad, 1u, red);
+        if (bad[0] == 0.0) { for (int j = tid; j < n; j += NT) W[j] = tv[j]; for (int i = tid; i < m; i += NT) W[n + i] = qy[i]; }
+        __syncthreads();
+    }
+
+    int status = 0, iter = 0, last_scale_iter = 0, n_log = 0;
+    double sum_log = 0;
+    bool done = false, resume = false;
+    double res3[3] = {NAN, NAN, NAN};
+    while (!done) {
+        refresh();
+        if (resume) {      // relaxed update owed by the iteration a rescale interrupted
+            for (int e = tid; e < l; e += NT) W[e] += alpha * (U[e] - UT[e]);
+            __syncthreads();
+            resume = false; iter++;
+        }
+        for (;;) {
+            if (iter >= S.max_iters) { done = true; break; }
+            const bool check = (iter % CONVERGED_INTERVAL) == 0, last = iter + 1 >= S.max_iters;
+            if (check && iter > 0) {       // keep the homogeneous iterate in range
+                double rn[1] = {0};
+                for (int e = tid; e < l; e += NT) rn[0] = fma(W[e], W[e], rn[0]);
+                block_reduce<1>(rn, 0u, red);
+                const double nw = sqrt(rn[0]);
+                if (nw > 0) { const double f = sqrt((double)l) / nw; for (int e = tid; e < l; e += NT) W[e] *= f; }
+                __syncthreads();
+            }
+            // t = rho w_x - A^T w_y ;  p_x = S^-1 t ;  q = A p_x
+            AT_times(W + n, [&](int j, double a) { tv[j] = rho_x * W[j] - a; });
+            wood(tv, px);
+            A_times(px, [&](int i, double a) { qy[i] = a; });
+            // tau-tilde, u-tilde, cone input
+            double rt[1] = {0};
+            for (int e = tid; e < l - 1; e += NT) rt[0] = fma(PHI[e], W[e], rt[0]);
+            block_reduce<1>(rt, 0u, red);
+            const double tau_t = (rtau * W[l - 1] + rt[0]) * inv_den;
+            for (int e = tid; e < l; e += NT) {
+                double ute, ze;
+                const double we = W[e];
+                if (e < n) { ute = px[e] - tau_t * G[e]; ze = 2 * ute - we; }
+                else if (e < l - 1) {
+                    const int i = e - n;
+                    ute = we + dyv(i) * qy[i] - tau_t * G[e]; ze = 2 * ute - we;
+                    if (i >= z && i < z + nl && ze < 0) ze = 0;
+                } else { ute = tau_t; ze = fmax(0.0, 2 * tau_t - we); }
+                UT[e] = ute; zb[e] = ze;
+            }
+            __syncthreads();
+            if (nq > 0) {
+                for (int c = tid; c < nq; c += NT) {
+                    const int r0 = n + T.qoff[c], r1 = n + T.qoff[c + 1];
+                    const double t0 = zb[r0]; double nz = 0;
+                    for (int k = r0 + 1; k < r1; k++) nz = fma(zb[k], zb[k], nz);
+                    nz = sqrt(nz);
+                    double c0, f;
+                    if (r1 - r0 == 1) { c0 = fmax(t0, 0.0); f = 0.0; }
+                    else if (nz <= t0) { c0 = t0; f = 1.0; }
+                    else if (nz <= -t0) { c0 = 0.0; f = 0.0; }
+                    else { c0 = 0.5 * (t0 + nz); f = c0 / nz; }
+                    socc[2 * c] = c0; socc[2 * c + 1] = f;
+                }
+                __syncthreads();
+                for (int i = tid + z + nl; i < m; i += NT) { const int c = T.rowcone[i]; if (c >= 0) zb[n + i] = (i == T.qoff[c]) ? socc[2 * c] : socc[2 * c + 1] * zb[n + i]; }
+                __syncthreads();
+            }
+#ifndef SA_SKIP_PSD        // (debug builds time the kernel without the projection)
+            for (int c = 0; c < ns; c++)       // PSD blocks: MFMA sandwich + warm-started Jacobi, eigenvectors stay in LDS (restart at check iterations)
+                psd_project_mfma_lds<NT>(zb + n + T.soff[c], T.sord[c], Sm, Vst + (size_t)c * PM, Tm, cs, red, (!check && iter > 0) ? 1 : 0);
+#endif
+            for (int e = tid; e < l; e += NT) U[e] = zb[e];
+            __syncthreads();
+            if (!check && !last) {
+                for (int e = tid; e < l; e += NT) W[e] += alpha * (U[e] - UT[e]);
+                __syncthreads();
+                iter++;
+                continue;
+            }
+            // ---- check iteration: residuals, termination, certificates, adaptive scale
+            bool stop = false, rescale = false;
+            if (check) {
+                A_times(U, [&](int i, double a) { qy[i] = a; });                      // A x-hat
+                AT_times(U + n, [&](int j, double a) { tv[j] = a; });                 // A^T y-hat
+                const double tau = fabs(U[l - 1]);
+                double rr[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // rp, nax, ns, naxs, rd, naty (max) ; ctx, bty (sum)
+                for (int i = tid; i < m; i += NT) {
+                    const double sc_ = isg / F.Dv[i];
+                    const double ax = qy[i] * sc_, uy = U[n + i];
+                    const double sh = (uy + W[n + i] - 2 * UT[n + i]) / dyv(i) * sc_;
+                    const double bt = bh[i] * tau * sc_;
+                    rr[0] = fmax(rr[0], fabs(ax + sh - bt)); rr[1] = fmax(rr[1], fabs(ax)); rr[2] = fmax(rr[2], fabs(sh)); rr[3] = fmax(rr[3], fabs(ax + sh));
+                    rr[7] += bh[i] * uy * isg * isg;
+                }
+                for (int j = tid; j < n; j += NT) {
+                    const double sc_ = isg / F.Ev[j];
+                    const double aty = tv[j] * sc_, cj = ch[j];
+                    rr[4] = fmax(rr[4], fabs(aty + cj * tau * sc_)); rr[5] = fmax(rr[5], fabs(aty));
+                    rr[6] += cj * U[j] * isg * isg;
+                }
+                block_reduce<8>(rr, 0x3Fu, red);
+                const double rp = rr[0], nax = rr[1], nsn = rr[2], naxs = rr[3], rd = rr[4], naty = rr[5], ctx = rr[6], bty = rr[7];
+                const double nrm_b0 = nb0_g[inst], nrm_c0 = nc0_g[inst];
+                if (tau > 0) {
+                    const double res_pri = rp / tau, res_dual = rd / tau, gap = fabs(ctx + bty) / tau;
+                    res3[0] = res_pri; res3[1] = res_dual; res3[2] = gap;
+                    const double prl = fmax(fmax(nrm_b0 * tau, nsn), nax) / tau, drl = fmax(nrm_c0 * tau, naty) / tau;
+                    const double grl = fmax(fabs(ctx), fabs(bty)) / tau;
+                    if (res_pri <= S.eps_abs + S.eps_rel * prl && res_dual <= S.eps_abs + S.eps_rel * drl && gap <= S.eps_abs + S.eps_rel * grl) { status = 1; stop = true; }
+                }
+                if (!stop && bty < 0 && naty / (-bty) <= S.eps_infeas) { status = -2; stop = true; }
+                if (!stop && ctx < 0 && naxs / (-ctx) <= S.eps_infeas) { status = -1; stop = true; }
+                if (!stop && S.adaptive_scale && iter > 0) {
+                    const double dp = fmax(fmax(nax, nsn), nrm_b0 * tau), dd = fmax(naty, nrm_c0 * tau);
+                    const double rel_p = rp / (dp > 0 ? dp : 1), rel_d = rd / (dd > 0 ? dd : 1);
+                    if (rel_p > 0 && rel_d > 0 && isfinite(rel_p) && isfinite(rel_d)) {
+                        sum_log += ce_log(rel_p, mtab) - ce_log(rel_d, mtab); n_log++;
+                        const double factor = ce_exp(0.5 * sum_log / n_log, mtab);
+                        if (iter - last_scale_iter >= RESCALING_MIN_ITERS) {
+                            const double ns2 = fmin(fmax(scale * factor, MIN_SCALE_VALUE), MAX_SCALE_VALUE);
+                            if (ns2 != scale && (factor > sqrt(10.0) || factor < 1.0 / sqrt(10.0))) {
+                                const double dy_ratio = ns2 / scale;       // keep (s, kappa):  w_y+ = rsk_y / r_y+ + 2 ut_y - u_y
+                                for (int e = tid + n; e < l - 1; e += NT) { const double ue = U[e], ute = UT[e]; W[e] = (ue + W[e] - 2 * ute) * dy_ratio + 2 * ute - ue; }
+                                n_log = 0; sum_log = 0; last_scale_iter = iter; scale = ns2; rescale = true;
+                                __syncthreads();
+                            }
+                        }
+                    }
+                }
+            }
+            if (stop) { done = true; break; }
+            if (last) { iter++; done = true; break; }
+            if (rescale) { resume = true; break; }
+            for (int e = tid; e < l; e += NT) W[e] += alpha * (U[e] - UT[e]);
+            __syncthreads();
+            iter++;
+        }
+    }
+    __syncthreads();
+    const double tau = fabs(U[l - 1]);
+    if (status == 0) {   // ran out of iterations (SCS set_unfinished)
+        const double kap = fabs(rtau * (U[l - 1] + W[l - 1] - 2 * UT[l - 1]));
+        double rr[2] = {0, 0};
+        for (int j = tid; j < n; j += NT) rr[0] += ch[j] * U[j] * isg * isg;
+        for (int i = tid; i < m; i += NT) rr[1] += bh[i] * U[n + i] * isg * isg;
+        block_reduce<2>(rr, 0u, red);
+        if (tau > kap) status = 2; else if (rr[1] < rr[0]) status = -7; else status = -6;
+    }
+    const bool solved = (status == 1 || status == 2), infeas = (status == -2 || status == -7);
+    const double it = solved ? 1.0 / (sigma * tau) : 1.0 / sigma;
+    for (int j = tid; j < n; j += NT) xo[(size_t)inst * n + j] = infeas ? NAN : F.Ev[j] * U[j] * it;
+    for (int i = tid; i < m; i += NT) {
+        const double uy = U[n + i], di = F.Dv[i];
+        const double sh = (uy + W[n + i] - 2 * UT[n + i]) / dyv(i);
+        yo[(size_t)inst * m + i] = (solved || infeas) ? di * uy * it : NAN;
+        so[(size_t)inst * m + i] = infeas ? NAN : sh / di * it;
+    }
+    if (tid == 0) {
+        iters_o[inst] = iter; status_o[inst] = status;
+        if (resid_o) { resid_o[3 * inst] = res3[0]; resid_o[3 * inst + 1] = res3[1]; resid_o[3 * inst + 2] = res3[2]; }
+    }
+}

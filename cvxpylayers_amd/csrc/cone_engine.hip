@@ -43,6 +43,7 @@ namespace {
 #include "ce_psd_mfma.h"
 #include "ce_const_a.h"
 #include "ce_shared_a.h"
+#include "ce_shared_a_fwd.h"
 }  // namespace
 
 // ================================================================================================
@@ -605,6 +606,36 @@ int ce_ca_psd_mfma(ce_handle h, int B, int lp, double *U, double *Vstate, int wa
     const size_t lds = (3 * (size_t)kp * (kp + 1) + 2 * kp + 8 + NW * 8) * 8;
     if (lds > 64 * 1024) { g_err = "PSD order too large for the LDS-resident MFMA projection (order <= 48)"; return CE_E_TOO_LARGE; }
     hipLaunchKernelGGL(k_ca_psd_mfma, dim3(B, h->T.ns), dim3(NT), lds, (hipStream_t)stream, h->T, lp, U, Vstate, warm, active);
+    HIPCHK(hipGetLastError());
+    return CE_OK;
+}
+int ce_solve_shared_a(ce_handle h, int B, int r, int RP, const double *AdT, const int *drow, const int *srow_col, const double *srow_val,
+                      const int *scol_ptr, const int *scol_row, const double *gs, const double *Dv, const double *Ev, const double *b_hat,
+                      const double *c_hat, const double *sigma, const double *nrm_b0, const double *nrm_c0, const ce_settings *settings,
+                      const double *warm_x, const double *warm_y, const double *warm_s,
+                      double *x, double *y, double *s, int *iters, int *status, double *resid, void *stream) {
+    if (!h || B <= 0 || !AdT || !drow || !srow_col || !srow_val || !scol_ptr || !scol_row || !gs || !Dv || !Ev || !b_hat || !c_hat || !sigma || !nrm_b0 || !nrm_c0 ||
+        !settings || !x || !y || !s || !iters || !status) { g_err = "null argument"; return CE_E_BADARG; }
+    const DevT &T = h->T;
+    if (T.nep + T.np > 0) { g_err = "shared-A forward kernel: exponential / power cones are not implemented"; return CE_E_UNSUPPORTED; }
+    if (r < 0 || r > RP || (RP != 16 && RP != 32 && RP != 64)) { g_err = "shared-A forward kernel: at most 64 dense rows (RP in 16, 32, 64)"; return CE_E_UNSUPPORTED; }
+    const size_t lds = sa_fwd_lds_doubles(T.n, T.m, T.nq, T.ns, T.maxs, RP) * 8;
+    if (lds > LDS_LIMIT) { g_err = "shared-A forward kernel: the iterates of one instance do not fit LDS"; return CE_E_TOO_LARGE; }
+    HIPCHK(hipSetDevice(h->device));
+    static bool attr_done = false;
+    if (!attr_done) {
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sa_fwd<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sa_fwd<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
+        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sa_fwd<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
+        attr_done = true;
+    }
+    SaFwd F{r, RP, AdT, drow, srow_col, srow_val, scol_ptr, scol_row, gs, Dv, Ev};
+    {
+        ProfScope ps(h, 0, (hipStream_t)stream);
+#define LAUNCH_SA(RPV) hipLaunchKernelGGL(k_sa_fwd<RPV>, dim3(B), dim3(NT), lds, (hipStream_t)stream, T, F, *settings, b_hat, c_hat, sigma, nrm_b0, nrm_c0, warm_x, warm_y, warm_s, x, y, s, iters, status, resid)
+        if (RP == 16) LAUNCH_SA(16); else if (RP == 32) LAUNCH_SA(32); else LAUNCH_SA(64);
+#undef LAUNCH_SA
+    }
     HIPCHK(hipGetLastError());
     return CE_OK;
 }

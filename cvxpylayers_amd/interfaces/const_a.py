@@ -138,6 +138,61 @@ def solve_const_a(eng, A_bm: torch.Tensor, q_eval: torch.Tensor, settings, warm=
     else:
         sigma = torch.ones(B, **f64)
     bh = (bh * sigma[:, None]).contiguous(); ch = (ch * sigma[:, None]).contiguous()
+    # ---- persistent one-kernel path (ce_shared_a_fwd.h): A = (rows with one entry) + (r <= 64 rows with several): the reduced KKT matrix
+    #      is diagonal + rank r and is applied by the Woodbury identity; every iterate of an instance stays in LDS, no host round trips.
+    #      Per-instance streaming of the shared dense rows from L2 limits it at very large batch x size (BASELINE config 5 at
+    #      B = 16384 stays on the batch-GEMM path below); CE_SA_FWD=1 / 0 forces / disables.
+    _saf = os.environ.get("CE_SA_FWD")
+    if _saf != "0" and not ntri:
+        row_nnz = np.bincount(indices[:nnzA], minlength=m)
+        drows_np = np.nonzero(row_nnz >= 2)[0].astype(np.int32)
+        r_d = int(len(drows_np))
+        RP = 16 if r_d <= 16 else (32 if r_d <= 32 else 64)
+        stable = False
+        if r_d <= 64 and (_saf == "1" or B * n * RP <= (1 << 28)):
+            srow = (row_nnz == 1)
+            ent_rows = indices[:nnzA].astype(np.int64); ent_cols = cols[:nnzA].astype(np.int64)
+            sing = srow[ent_rows]                                          # structural entries that sit in single-entry rows
+            srow_col_np = np.full(m, -1, dtype=np.int32); srow_col_np[ent_rows[sing]] = ent_cols[sing]
+            order = np.argsort(ent_cols[sing], kind="stable")
+            scol_row_np = ent_rows[sing][order].astype(np.int32)
+            scol_ptr_np = np.concatenate([[0], np.cumsum(np.bincount(ent_cols[sing], minlength=n))]).astype(np.int32)
+            ti32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.int32)).to(dev)
+            drow_t, srow_col_t, scol_ptr_t, scol_row_t = ti32(drows_np if r_d else np.zeros(1)), ti32(srow_col_np), ti32(scol_ptr_np), ti32(scol_row_np if len(scol_row_np) else np.zeros(1))
+            srow_val = torch.zeros(m, **f64)
+            if sing.any():
+                rs_t = torch.from_numpy(ent_rows[sing]).to(dev); cs_t = torch.from_numpy(ent_cols[sing]).to(dev)
+                srow_val[rs_t] = A[rs_t, cs_t]
+            AdT = torch.zeros((n, RP), **f64)
+            if r_d:
+                AdT[:, :r_d] = A[torch.from_numpy(drows_np.astype(np.int64)).to(dev), :].t()
+            d0s = torch.ones(m, **f64); d0s[:z] = ZERO_CONE_FACTOR
+            gs = torch.zeros(n, **f64)
+            if sing.any():
+                gs.index_add_(0, cs_t, d0s[rs_t] * srow_val[rs_t] ** 2)
+            # Woodbury is only stable when the diagonal part carries weight in EVERY column (each variable sits in some single-entry row:
+            # bounds, identity blocks); a column without one has Dg_j = rho_x = 1e-6 and the formula cancels catastrophically
+            stable = bool((gs.min() >= 1e-2).item()) if n else False
+        if r_d <= 64 and (_saf == "1" or B * n * RP <= (1 << 28)) and stable:
+            xo = torch.empty((B, n), **f64); yo = torch.empty((B, m), **f64); so = torch.empty((B, m), **f64)
+            it_o = torch.empty(B, dtype=torch.int32, device=dev); st_o = torch.empty(B, dtype=torch.int32, device=dev); rs_o = torch.empty((B, 3), **f64)
+            wx = wy = ws = None
+            settings.warm_start = 0
+            if warm is not None:
+                wx, wy, ws = (t.detach().to(device=dev, dtype=torch.float64).contiguous() for t in warm)
+                settings.warm_start = 1
+            ptr = lambda t: t.data_ptr() if t is not None else None
+            rc = L.ce_solve_shared_a(eng._h, B, r_d, RP, AdT.data_ptr(), drow_t.data_ptr(), srow_col_t.data_ptr(), srow_val.data_ptr(), scol_ptr_t.data_ptr(),
+                                     scol_row_t.data_ptr(), gs.data_ptr(), D.data_ptr(), E.data_ptr(), bh.data_ptr(), ch.data_ptr(), sigma.data_ptr(),
+                                     nrm_b0.data_ptr(), nrm_c0.data_ptr(), C.byref(settings), ptr(wx), ptr(wy), ptr(ws), xo.data_ptr(), yo.data_ptr(),
+                                     so.data_ptr(), it_o.data_ptr(), st_o.data_ptr(), rs_o.data_ptr(), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+            if rc == 0:
+                eng.last_const_a_kernel = "k_sa_fwd"
+                _tick("k_sa_fwd (enqueued)")
+                return xo, yo, so, it_o, st_o, rs_o
+            if rc not in (-2, -3):
+                _lib.check(rc, "ce_solve_shared_a")
+    eng.last_const_a_kernel = "batch GEMM"
     # ---- one eigendecomposition serves every instance and every rescale:  A^T D0 A = Q Lam Q^T
     d0 = torch.ones(m, **f64); d0[:z] = ZERO_CONE_FACTOR
     lam, Q = torch.linalg.eigh(At @ (d0[:, None] * A))

@@ -205,6 +205,25 @@ int ce_ca_finish(ce_handle h, int B, int lp, int max_iters, const double *W, con
                  const int *active, int *status, int *iters, double *x, double *y, double *s, void *stream);
 
 /*
+ * Shared-A forward  <- _build_diffcp_matrices + diffcp.solve_and_derivative_batch (diffcp_if.py:46-70, 365-372) for templates whose A does
+ * not depend on the parameters and consists of r <= 64 rows with several entries plus rows with a single entry: the whole solve of an
+ * instance in one persistent kernel (iterates in LDS, reduced KKT matrix = diagonal + rank r applied by the Woodbury identity, its
+ * r x r core formed on the matrix cores, termination / adaptive scale in the kernel, PSD projection with MFMA contractions).
+ * The caller equilibrates the ONE shared matrix (cvxpylayers_amd/interfaces/const_a.py) and passes, all device memory:
+ *   AdT (n, RP) row-major: the equilibrated dense rows transposed (solver sign A = -A_cvx), zero padded to RP in {16, 32, 64};
+ *   drow (r): their row indices; srow_col / srow_val (m): column (-1: none) and value of every single-entry row;
+ *   scol_ptr (n + 1) / scol_row: the single-entry rows of every column; gs (n): sum over them of d0_i a_i^2 (d0 = 1000 on zero-cone rows);
+ *   Dv (m), Ev (n): the equilibration; b_hat (B, m), c_hat (B, n), sigma / nrm_b0 / nrm_c0 (B): normalised data as in ce_ca_check;
+ *   warm_x / warm_y / warm_s: (B, .) initial point used when settings->warm_start != 0, else NULL.
+ * Outputs as ce_solve.  CE_E_UNSUPPORTED / CE_E_TOO_LARGE: callers use the batch-GEMM path of const_a.py instead.
+ */
+int ce_solve_shared_a(ce_handle h, int B, int r, int RP, const double *AdT, const int *drow, const int *srow_col, const double *srow_val,
+                      const int *scol_ptr, const int *scol_row, const double *gs, const double *Dv, const double *Ev, const double *b_hat,
+                      const double *c_hat, const double *sigma, const double *nrm_b0, const double *nrm_c0, const ce_settings *settings,
+                      const double *warm_x, const double *warm_y, const double *warm_s,
+                      double *x, double *y, double *s, int *iters, int *status, double *resid, void *stream);
+
+/*
  * Shared-A adjoint  <- _compute_gradients -> adj_batch (diffcp_if.py:73-96, 385-403) for templates whose A does not depend on the
  * parameters: diffcp's adjoint system (r_tau = 0) solved by LSQR -- diffcp's own default mode -- entirely inside one kernel, one
  * workgroup per instance, A applied from its sparse structure, the PSD cone's derivative on the matrix cores.  A_vals0: the nnz_aug
