@@ -162,6 +162,58 @@ __device__ __forceinline__ void psd_sweeps_wave(double *Sm, double *Vm, int k, i
     __syncthreads();
 }
 
+// Workgroup version of the same two-phase rounds (rotation parameters | 2 x 2 block updates + V columns), two barriers per round.
+template <int NTH>
+__device__ __forceinline__ void psd_sweeps_wg(double *Sm, double *Vm, int k, int P, double *cs, double *red) {
+    constexpr int NT = NTH, NW = NTH / 64;
+    const int tid = threadIdx.x;
+    const int K = (k + 1) & ~1, H = K / 2;
+    const float rk = 1.0f / (float)k, rH = 1.0f / (float)H;
+    double prev_off = 0;
+    for (int sweep = 0; sweep < 40; sweep++) {
+        double r[2] = {0, 0};
+        for (int idx = tid; idx < k * k; idx += NT) { const int i = psd_fdiv(idx, rk), j = idx - i * k; const double v = Sm[i * P + j]; if (i == j) r[1] = fma(v, v, r[1]); else r[0] = fma(v, v, r[0]); }
+        block_reduce_n<2, NW>(r, 0u, red);
+        if (r[0] <= 1e-30 * (r[0] + r[1]) || r[0] == 0.0 || (r[0] <= 1e-24 * (r[0] + r[1]) && r[0] > 0.25 * prev_off)) break;          // uniform (see psd_sweeps_wave)
+        prev_off = r[0];
+        for (int rd = 0; rd < K - 1; rd++) {
+            if (tid < H) {
+                const int t = tid;
+                int p = rd + t; if (p >= K - 1) p -= K - 1;
+                if (t == 0) p = K - 1;
+                int q = rd + K - 1 - t; if (q >= K - 1) q -= K - 1;
+                if (p > q) { const int t_ = p; p = q; q = t_; }
+                double c = 1.0, sn = 0.0;
+                if (q < k) psd_rotation(Sm[p * P + p], Sm[q * P + q], Sm[p * P + q], c, sn); else q = -1;
+                cs[4 * t] = c; cs[4 * t + 1] = sn; cs[4 * t + 2] = (double)p; cs[4 * t + 3] = (double)q;
+            }
+            __syncthreads();
+            for (int w = tid; w < H * H + k * H; w += NT) {
+                if (w < H * H) {                                       // S <- J^T S J on the 2 x 2 block (pair a) x (pair b)
+                    const int a = psd_fdiv(w, rH), b = w - a * H;
+                    const double ca = cs[4 * a], sa = cs[4 * a + 1], cb = cs[4 * b], sb = cs[4 * b + 1];
+                    const int pa = (int)cs[4 * a + 2], qa = (int)cs[4 * a + 3], pb = (int)cs[4 * b + 2], qb = (int)cs[4 * b + 3];
+                    const double s00 = Sm[pa * P + pb], s01 = qb >= 0 ? Sm[pa * P + qb] : 0.0, s10 = qa >= 0 ? Sm[qa * P + pb] : 0.0, s11 = (qa >= 0 && qb >= 0) ? Sm[qa * P + qb] : 0.0;
+                    const double t00 = cb * s00 - sb * s01, t01 = sb * s00 + cb * s01, t10 = cb * s10 - sb * s11, t11 = sb * s10 + cb * s11;
+                    Sm[pa * P + pb] = ca * t00 - sa * t10;
+                    if (qb >= 0) Sm[pa * P + qb] = ca * t01 - sa * t11;
+                    if (qa >= 0) Sm[qa * P + pb] = sa * t00 + ca * t10;
+                    if (qa >= 0 && qb >= 0) Sm[qa * P + qb] = sa * t01 + ca * t11;
+                } else {                                               // V <- V J
+                    const int it = w - H * H, row = psd_fdiv(it, rH), b = it - row * H;
+                    const int pb = (int)cs[4 * b + 2], qb = (int)cs[4 * b + 3];
+                    if (qb >= 0) {
+                        const double cb = cs[4 * b], sb = cs[4 * b + 1];
+                        const double x = Vm[row * P + pb], y = Vm[row * P + qb];
+                        Vm[row * P + pb] = cb * x - sb * y; Vm[row * P + qb] = sb * x + cb * y;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
 // LDS doubles needed: 3 * KP * (KP + 1) + 2 * k + 8  (+ the reduction scratch of block_reduce_n)
 __host__ __device__ inline int psd_mfma_kp(int k) { return 16 * ((k + 15) / 16); }
 
@@ -203,7 +255,7 @@ __device__ __forceinline__ void psd_project_mfma(double *zsvec, int k, double *S
         }
         __syncthreads();
     }
-    psd_sweeps_wave<NTH>(Sm, Vm, k, P, cs, red);
+    psd_sweeps_wg<NTH>(Sm, Vm, k, P, cs, red);
     for (int i = tid; i < KP; i += NT) cs[i] = i < k ? fmax(Sm[i * P + i], 0.0) : 0.0;
     __syncthreads();
     // X = (V diag(w+)) V^T

@@ -60,6 +60,7 @@ k_sa_lsqr(DevT T, SaStruct S, const double *__restrict__ Avals0, const double *_
     double *ux = p; p += n; double *vx = p; p += n; double *wx = p; p += n; double *rx = p; p += n; double *tx = p; p += n;
     double *socs = p; p += 4 * (nq > 0 ? nq : 1);          // per cone: t, |z|, case, z.h
     const int KP = ns > 0 ? psd_mfma_kp(T.maxs) : 0, P = KP + 1, PM = KP * P;
+    const float rKP = KP > 0 ? 1.0f / (float)KP : 1.0f;
     double *Um = p; p += (size_t)ns * PM;                    // eigenvectors of smat(v_c), per cone
     double *Bm = p; p += (size_t)ns * PM;                    // divided differences, per cone
     double *Hm = p; p += PM; double *Ym = p; p += PM;        // scratch
@@ -83,15 +84,15 @@ k_sa_lsqr(DevT T, SaStruct S, const double *__restrict__ Avals0, const double *_
         double *U = Um + (size_t)c * PM, *Bc = Bm + (size_t)c * PM;
         const double *zs = vv + T.soff[c];
         for (int idx = tid; idx < KP * KP; idx += NT) {
-            const int i = idx / KP, j = idx - i * KP;
+            const int i = psd_fdiv(idx, rKP), j = idx - i * KP;
             double sv = 0.0;
             if (i < k && j < k) { const int a = i >= j ? i : j, b = i >= j ? j : i; const double v0 = zs[b * k - (b * (b - 1)) / 2 + (a - b)]; sv = (a == b) ? v0 : v0 * M_SQRT1_2; }
             Hm[i * P + j] = sv; U[i * P + j] = (i == j && i < k) ? 1.0 : 0.0;
         }
         __syncthreads();
-        psd_sweeps_wave<NT>(Hm, U, k, P, cs, red);
+        psd_sweeps_wg<NT>(Hm, U, k, P, cs, red);
         for (int idx = tid; idx < KP * KP; idx += NT) {
-            const int i = idx / KP, j = idx - i * KP;
+            const int i = psd_fdiv(idx, rKP), j = idx - i * KP;
             double bv = 0.0;
             if (i < k && j < k) {
                 const double wi = Hm[i * P + i], wj = Hm[j * P + j];
@@ -137,7 +138,7 @@ k_sa_lsqr(DevT T, SaStruct S, const double *__restrict__ Avals0, const double *_
             const int k = T.sord[c], off = T.soff[c], KT = KP / 16;
             const double *U = Um + (size_t)c * PM, *Bc = Bm + (size_t)c * PM;
             for (int idx = tid; idx < KP * KP; idx += NT) {
-                const int i = idx / KP, j = idx - i * KP;
+                const int i = psd_fdiv(idx, rKP), j = idx - i * KP;
                 double sv = 0.0;
                 if (i < k && j < k) { const int a = i >= j ? i : j, b = i >= j ? j : i; const double v0 = h[off + b * k - (b * (b - 1)) / 2 + (a - b)]; sv = (a == b) ? v0 : v0 * M_SQRT1_2; }
                 Hm[i * P + j] = sv;
@@ -151,12 +152,11 @@ k_sa_lsqr(DevT T, SaStruct S, const double *__restrict__ Avals0, const double *_
             __syncthreads();
             psd_mfma_gemm<NT>(KT, [&](int M, int K) { return Ym[M * P + K]; }, [&](int K, int N) { return U[N * P + K]; }, [&](int M, int N, double v) { Hm[M * P + N] = v; });   // (U Y) U^T
             __syncthreads();
-            for (int pos = tid; pos < k * (k + 1) / 2; pos += NT) {
-                int b = 0, rem = pos;
-                while (rem >= k - b) { rem -= k - b; b++; }
-                const int a = b + rem;
+            for (int idx = tid; idx < k * k; idx += NT) {          // lower triangle (a >= b) -> svec position
+                const int a = psd_fdiv(idx, 1.0f / (float)k), b = idx - a * k;
+                if (a < b) continue;
                 const double v0 = 0.5 * (Hm[a * P + b] + Hm[b * P + a]);
-                tmp[off + pos] = (a == b) ? v0 : v0 * M_SQRT2;
+                tmp[off + b * k - (b * (b - 1)) / 2 + (a - b)] = (a == b) ? v0 : v0 * M_SQRT2;
             }
             __syncthreads();
         }

@@ -33,7 +33,7 @@ print("path", eng.last_path, "B", B, "eps", eps, "fwd %.1f ms  iters mean %.0f m
 dx = torch.ones_like(x); dy = torch.zeros_like(y)
 eng.vjp(A_bm, x, y, s, dx, dy); torch.cuda.synchronize()
 t0 = time.perf_counter(); dA, dq, adj = eng.vjp(A_bm, x, y, s, dx, dy); torch.cuda.synchronize(); t1 = time.perf_counter()
-print("bwd %.1f ms, LSQR not converged for %d" % ((t1 - t0) * 1e3, int((adj != 0).sum())))
+print("bwd %.1f ms, LSQR not converged for %d" % ((t1 - t0) * 1e3, int((adj != 0).sum())), "LSQR iterations mean", float(getattr(eng, "last_lsqr_iters", torch.zeros(1)).float().mean()))
 nb = min(B, 8)
 t0 = time.perf_counter(); ref = oracle.solve_batch(Ab[:nb], b[:nb], c[:nb], cones, eps=eps, max_iters=20000); t1 = time.perf_counter()
 print("oracle %d instances %.2f s (%d threads), iters %s" % (nb, t1 - t0, oracle.num_threads(), ref["iters"][:4]), "max |x - x_ref|", np.abs(x.cpu().numpy()[:nb] - ref["x"]).max())
