@@ -45,3 +45,33 @@ if has configs; then
 fi
 find "$OUT" -name "*.db" -delete
 du -sh "$OUT" | tee -a "$OUT/summary.txt"
+if has c4prof; then
+  echo "== C4 (SDP 20x20, shared A): kernel trace + MFMA counters" | tee -a "$OUT/summary.txt"
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/c4_prof" -o trace --output-format csv -- python "$OLDPWD/scripts/sdp_c4_probe.py" 1024 1e-4 > "$OUT/c4_prof.log" 2>&1)
+  find "$OUT/c4_prof" -name "*kernel_stats.csv" | head -1 | xargs -r head -8 | tee -a "$OUT/summary.txt"
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_MFMA SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d "$OUT/c4_mfma" -o p --output-format csv -- python "$OLDPWD/scripts/sdp_c4_probe.py" 1024 1e-4 > "$OUT/c4_mfma.log" 2>&1)
+  python - "$OUT" <<'PY' | tee -a "$OUT/summary.txt"
+import csv, glob, collections, json, os, sys
+out = sys.argv[1]
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(os.path.join(out, "c4_mfma", "**", "*counter_collection.csv"), recursive=True):
+    per = collections.defaultdict(lambda: collections.defaultdict(float)); names = {}
+    for r in csv.DictReader(open(f)):
+        per[r["Dispatch_Id"]][r["Counter_Name"]] += float(r["Counter_Value"]); names[r["Dispatch_Id"]] = r["Kernel_Name"].split("(")[0].split("<")[0][-40:]
+    for d, cs in per.items():
+        for c, v in cs.items(): agg[names[d]][c].append(v)
+res = {}
+for k, cs in agg.items():
+    if not any(t in k for t in ("k_sa_", "k_ca_", "k_fwd2", "k_backward")): continue
+    s = {c: sum(v) / len(v) for c, v in cs.items()}
+    s["launches"] = max(len(v) for v in cs.values())
+    # SQ_VALU_MFMA_BUSY_CYCLES counts cycles per SIMD summed over the sampled SIMDs; the same sampling applies to SQ_BUSY_CYCLES (per SQ = per CU group);
+    # the ratio MFMA-busy / (4 SIMDs x CU-busy) is the share of SIMD time with the matrix pipe busy
+    if s.get("SQ_BUSY_CYCLES"): s["mfma_busy_share_of_simd_time"] = s.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (4.0 * s["SQ_BUSY_CYCLES"])
+    if s.get("SQ_WAVE_CYCLES"): s["valu_busy_share_of_wave_time"] = s.get("SQ_ACTIVE_INST_VALU", 0.0) / s["SQ_WAVE_CYCLES"]
+    res[k] = s
+print(json.dumps(res, indent=1))
+json.dump(res, open(os.path.join(out, "c4_mfma_summary.json"), "w"), indent=1)
+PY
+fi
+find "$OUT" -name "*.db" -delete
