@@ -256,7 +256,7 @@ __device__ __forceinline__ void psd_project(double *zsvec, int k, double *Sm, do
 // order per wave, no workgroup barrier -- which removes one of the two barriers of every equilibration pass and fuses the cone
 // projection + relaxed update into the A p_x phase: 3 barriers per iteration instead of 4.
 template <int CHT, int T1, int CHA, int T2, int CHG, int TG, bool PSD = false, int NTH = 256, bool HASP = false, bool WL = false>
-__global__ void __launch_bounds__(NTH, (NTH == 256 ? F2_WPS : 2))
+__global__ void __launch_bounds__(NTH, (NTH == 256 ? ((HASP || PSD) ? 2 : F2_WPS) : 2))       // quadratic-objective / PSD variants: 2 workgroups per CU (256 VGPRs), their extra live values push the tiles of the 3-per-CU build into scratch
 k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__restrict__ qv, long sqk, long sqb,
        const int *__restrict__ idx_at, const int *__restrict__ idx_ar, const int *__restrict__ idx_b,
        double *__restrict__ xo, double *__restrict__ yo, double *__restrict__ so, int *__restrict__ iters_o,

@@ -32,7 +32,7 @@ def sdp(B, k=20, neq=20, seed=0):
 
 
 def run(name, tpl, cones, A_eval, q_eval, eps, reps, note, P_eval=None, p_structure=None, min_seconds=1.0):
-    ctx = MI355_ctx(p_structure, tpl.problem_data_index, cones, options={"eps": eps, "max_iters": 20000, "raise_on_error": False})
+    ctx = MI355_ctx(p_structure, tpl.problem_data_index, cones, options={"eps": eps, "max_iters": 20000, "raise_on_error": False, **({"acceleration_lookback": int(os.environ["CONFIGS_ACCEL"])} if "CONFIGS_ACCEL" in os.environ else {})})
     A_t = torch.from_numpy(A_eval).to(dev).t().contiguous().t().requires_grad_()      # (nnz_aug, B) view of batch-major storage
     q_t = torch.from_numpy(q_eval).to(dev).requires_grad_()
     P_t = torch.from_numpy(P_eval).to(dev).requires_grad_() if P_eval is not None else None
