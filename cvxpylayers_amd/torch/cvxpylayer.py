@@ -25,6 +25,7 @@ What is different (MI355X-first):
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass, field
 from typing import Any, Sequence
 
@@ -195,6 +196,75 @@ def _unpack_svec(svec, k, batch):
     return _svec_to_symmetric(svec, k, batch, rows, cols, np.where(rows == cols, 1.0, 1.0 / np.sqrt(2.0)))
 
 
+def _recovery_map(var_recover, n_src: int, source: str):
+    """The variable recovery of one source (primal or dual) as a sparse map R (sum of output sizes x n_src): output element t of a
+    variable, in the row-major order of its final shape, is scale * src[index].  Slices + Fortran reshapes give one entry per row;
+    svec unpacking gives the 1 (primal) or 1/sqrt(2) off-diagonal (PSD dual) weights of torch/cvxpylayer.py:183-222.  Returns
+    (csr, [(variable position, row offset, size)])."""
+    rows, cols, vals, layout, off = [], [], [], [], 0
+    for pos, var in enumerate(var_recover):
+        if var.source != source:
+            continue
+        sl = var.primal if source == "primal" else var.dual
+        src = np.arange(n_src)[sl]
+        shape = tuple(var.shape)
+        size = int(np.prod(shape)) if len(shape) else 1
+        if var.unpack_fn == "reshape":
+            # out.reshape(-1)[t] = data[f(t)] with data Fortran-ordered over `shape`
+            idx = np.arange(size).reshape(shape, order="F").reshape(-1) if len(shape) > 1 else np.arange(size)
+            rows.append(off + np.arange(size)); cols.append(src[idx]); vals.append(np.ones(size))
+        elif var.unpack_fn in ("svec_primal", "svec_dual"):
+            k = shape[0]
+            if var.unpack_fn == "svec_primal":
+                rr, cc = np.triu_indices(k)
+                w = np.ones(rr.size)
+            else:
+                r0, c0 = np.tril_indices(k)
+                order = np.lexsort((r0, c0))
+                rr, cc = r0[order], c0[order]
+                w = np.where(rr == cc, 1.0, 1.0 / np.sqrt(2.0))
+            rows.append(off + rr * k + cc); cols.append(src); vals.append(w)
+            offd = rr != cc
+            rows.append(off + cc[offd] * k + rr[offd]); cols.append(src[offd]); vals.append(w[offd])
+        else:
+            raise ValueError(f"Unknown variable recovery type: {var.unpack_fn}")
+        layout.append((pos, off, size))
+        off += size
+    if not layout:
+        return None, []
+    mat = sp.csr_array((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(off, n_src))
+    return mat, layout
+
+
+class _RecoverMap(torch.autograd.Function):
+    """Variable recovery of one source as ONE launch of the sparse-map kernel (ce_parammap_apply2) writing every requested variable
+    in its final layout, and its transpose as the backward (gradients of all variables gathered into d primal / d dual in one
+    launch).  Replaces the per-variable slice / permute / index_put chain of _recover_results_torch, which stays as the checker."""
+
+    @staticmethod
+    def forward(ctx, csr: _DeviceCSR, layout, shapes, src: torch.Tensor):
+        fwd, bwd = csr.on(src.device)
+        ctx.bwd, ctx.layout, ctx.total, ctx.src_shape = bwd, layout, fwd[3], src.shape
+        src2 = src.reshape(-1, src.shape[-1]).contiguous()
+        with torch.cuda.device(src.device):
+            rec = _spmm_bm(fwd, src2)
+        lead = tuple(src.shape[:-1])
+        return tuple(rec[:, off:off + size].reshape(lead + tuple(shape)) if len(layout) > 1 else rec.reshape(lead + tuple(shape))
+                     for (_, off, size), shape in zip(layout, shapes))
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, *grads):
+        B = int(np.prod(ctx.src_shape[:-1])) if len(ctx.src_shape) > 1 else 1
+        ref = next(g for g in grads if g is not None)
+        parts = [g.reshape(B, size) if g is not None else torch.zeros((B, size), dtype=ref.dtype, device=ref.device)
+                 for g, (_, _, size) in zip(grads, ctx.layout)]
+        g_rec = parts[0].contiguous() if len(parts) == 1 else torch.cat(parts, dim=1)
+        with torch.cuda.device(ref.device):
+            d_src = _spmm_bm(ctx.bwd, g_rec)
+        return None, None, None, d_src.reshape(ctx.src_shape)
+
+
 class _Ctx:
     """The object handed to the plugin as cl_ctx (the plugin only needs .solver_ctx)."""
 
@@ -256,6 +326,16 @@ class CvxpyLayer(torch.nn.Module):
         self._q = _DeviceCSR(recol(template.q_map))
         self._P = _DeviceCSR(recol(template.P_map)) if template.P_map is not None else None
         self.batch_sizes: list | None = None
+        # variable recovery as one sparse-map launch per source (and its transpose in backward); CE_FUSED_RECOVERY=0 keeps the
+        # per-variable torch chain (the checker of tests/test_gpu_recovery.py)
+        n_primal = int(template.q_map.shape[0]) - 1
+        n_dual = int(template.A_structure[2][0])
+        self._rec = {}
+        for source, n_src in (("primal", n_primal), ("dual", n_dual)):
+            mat, layout = _recovery_map(template.var_recover, n_src, source)
+            if mat is not None:
+                self._rec[source] = (_DeviceCSR(mat), layout)
+        self.fused_recovery = os.environ.get("CE_FUSED_RECOVERY", "1") != "0"
 
     # ---- utils/parse_args.py:94-143
     def validate_params(self, values: list) -> tuple:
@@ -336,10 +416,28 @@ class CvxpyLayer(torch.nn.Module):
         # the same cache for its MOREAU plugin, torch/cvxpylayer.py:464-487)
         primal, dual, info, _ = layer_cls.apply(P_eval, q_eval, A_eval, self.ctx, solver_args, needs_grad, True if warm_start else None)
         self.info = info
-        return self._recover_results(primal, dual, batch)
+        if self.fused_recovery:
+            return self._recover_results(primal, dual, batch)
+        return self._recover_results_torch(primal, dual, batch)
 
-    # ---- torch/cvxpylayer.py:225-282
     def _recover_results(self, primal, dual, batch):
+        """torch/cvxpylayer.py:225-282 as one map launch per source (see _RecoverMap)."""
+        out = [None] * len(self.template.var_recover)
+        for source, src in (("primal", primal), ("dual", dual)):
+            if source not in self._rec:
+                continue
+            csr, layout = self._rec[source]
+            shapes = [tuple(self.template.var_recover[pos].shape) for pos, _, _ in layout]
+            res = _RecoverMap.apply(csr, layout, shapes, src)
+            for (pos, _, _), r in zip(layout, res):
+                r = r.reshape(batch + tuple(self.template.var_recover[pos].shape))
+                if self.template.gp and source == "primal":
+                    r = torch.exp(r)
+                out[pos] = r
+        return tuple(out)
+
+    # ---- torch/cvxpylayer.py:225-282, per variable with torch ops (checker of the fused path)
+    def _recover_results_torch(self, primal, dual, batch):
         internal = tuple(primal.shape[:-1])
         out = []
         for var in self.template.var_recover:
