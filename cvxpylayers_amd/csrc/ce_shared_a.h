@@ -12,6 +12,7 @@
 //
 // Cones: zero / nonnegative / second-order / PSD (exponential and power cones take the batched torch path of const_a.py).
 #pragma once
+#include "ce_shared_a_ops.h"
 
 struct SaStruct {            // sparse structure of the template's A part (device arrays, built once per engine)
     const int *csc_ptr;      // [n + 1]   column starts in the value order of the boundary (CSC of [A_cvx | b_cvx], first nnzA entries)
@@ -41,20 +42,26 @@ __device__ __forceinline__ void sa_spmv(const int *__restrict__ ptr, const int *
     }
 }
 
-// LDS doubles: 8 m + 5 n + 2 nq + ns (4 KP (KP + 1) + 2 KP + 8) + NW * 8 + 16
-__host__ __device__ inline size_t sa_lsqr_lds_doubles(int n, int m, int nq, int ns, int maxs) {
+// LDS doubles: [split products: 2 RP + 2 NT] + 8 m + 5 n + 4 nq + ns (4 KP (KP + 1) + 2 KP + 8) + NW * 8 + 16
+__host__ __device__ inline size_t sa_lsqr_lds_doubles(int n, int m, int nq, int ns, int maxs, int RP) {
     const int kp = ns > 0 ? psd_mfma_kp(maxs) : 0;
-    return 8 * (size_t)m + 5 * (size_t)n + 4 * (size_t)(nq > 0 ? nq : 1) + (size_t)(ns > 0 ? (2 * ns + 2) * kp * (kp + 1) + 2 * kp + 8 : 0) + NW * 8 + 16;
+    return (size_t)(RP > 0 ? 2 * RP + 2 * NT : 0) + 8 * (size_t)m + 5 * (size_t)n + 4 * (size_t)(nq > 0 ? nq : 1) +
+           (size_t)(ns > 0 ? (2 * ns + 2) * kp * (kp + 1) + 2 * kp + 8 : 0) + NW * 8 + 16;
 }
 
+// RP > 0: A is applied through its split into singleton rows and r <= RP dense rows (ce_shared_a_ops.h: balanced, wide loads); RP == 0: through
+// the CSR / CSC structure (any sparsity pattern, but rows of very different lengths serialise on the longest).
+template <int RP>
 __global__ void __launch_bounds__(NT)
-k_sa_lsqr(DevT T, SaStruct S, const double *__restrict__ Avals0, const double *__restrict__ xg, const double *__restrict__ yg,
+k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, const double *__restrict__ xg, const double *__restrict__ yg,
           const double *__restrict__ sg, const double *__restrict__ dxg, const double *__restrict__ dyg, double *__restrict__ dAo,
           double *__restrict__ dqo, long sdqk, long sdqb, int *__restrict__ adj_status, int *__restrict__ iters_o, double atol, double btol, int itn_lim) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int tid = threadIdx.x, inst = blockIdx.x;
     const int n = T.n, m = T.m, z = T.z, nl = T.l, nq = T.nq, ns = T.ns;
     double *p = sm;
+    double *wyd = p, *vd = p, *part = p;                     // split products: 16-byte aligned at the start of the carve
+    if constexpr (RP > 0) { wyd = p; p += RP; vd = p; p += RP; part = p; p += 2 * NT; }
     double *vv = p; p += m;            // v = y - s
     double *uy = p; p += m; double *vy = p; p += m; double *wy = p; p += m; double *ry = p; p += m; double *ty = p; p += m; double *qv = p; p += m; double *tmp = p; p += m;
     double *ux = p; p += n; double *vx = p; p += n; double *wx = p; p += n; double *rx = p; p += n; double *tx = p; p += n;
@@ -71,13 +78,15 @@ k_sa_lsqr(DevT T, SaStruct S, const double *__restrict__ Avals0, const double *_
     for (int i = tid; i < m; i += NT) vv[i] = y[i] - s[i];
     __syncthreads();
     // ---- per-cone data of DPi
-    for (int c = tid; c < nq; c += NT) {
+    for (int c = tid >> 6; c < nq; c += NW) {            // one wave per cone
         const int r0 = T.qoff[c], r1 = T.qoff[c + 1];
         const double t = vv[r0]; double nz = 0;
-        for (int k = r0 + 1; k < r1; k++) nz = fma(vv[k], vv[k], nz);
-        nz = sqrt(nz);
-        socs[4 * c] = t; socs[4 * c + 1] = nz;
-        socs[4 * c + 2] = (r1 - r0 == 1) ? (t >= 0 ? 0.0 : 1.0) : (nz <= t ? 0.0 : (nz <= -t ? 1.0 : 2.0));     // 0 identity, 1 zero, 2 boundary
+        for (int k = r0 + 1 + (tid & 63); k < r1; k += 64) nz = fma(vv[k], vv[k], nz);
+        nz = sqrt(wave_reduce_dpp<false>(nz));
+        if ((tid & 63) == 0) {
+            socs[4 * c] = t; socs[4 * c + 1] = nz;
+            socs[4 * c + 2] = (r1 - r0 == 1) ? (t >= 0 ? 0.0 : 1.0) : (nz <= t ? 0.0 : (nz <= -t ? 1.0 : 2.0));     // 0 identity, 1 zero, 2 boundary
+        }
     }
     for (int c = 0; c < ns; c++) {      // eigenvectors and divided differences of every PSD block (cold Jacobi, once)
         const int k = T.sord[c];
@@ -109,9 +118,12 @@ k_sa_lsqr(DevT T, SaStruct S, const double *__restrict__ Avals0, const double *_
     // q <- DPi(h), in place safe (h may alias q).  All threads call it; ends synchronised.
     auto dproj = [&](const double *h, double *q) {
         if (nq > 0) {
-            for (int i = tid; i < m; i += NT) { const int c = T.rowcone[i]; tmp[i] = (c >= 0 && i > T.qoff[c]) ? vv[i] * h[i] : 0.0; }
-            __syncthreads();
-            for (int c = tid; c < nq; c += NT) { double a = 0; for (int k = T.qoff[c] + 1; k < T.qoff[c + 1]; k++) a += tmp[k]; socs[4 * c + 3] = a; }
+            for (int c = tid >> 6; c < nq; c += NW) {       // z.h per cone: one wave per cone
+                double a = 0;
+                for (int k = T.qoff[c] + 1 + (tid & 63); k < T.qoff[c + 1]; k += 64) a = fma(vv[k], h[k], a);
+                a = wave_reduce_dpp<false>(a);
+                if ((tid & 63) == 0) socs[4 * c + 3] = a;
+            }
             __syncthreads();
         }
         for (int i = tid; i < m; i += NT) {
@@ -164,8 +176,14 @@ k_sa_lsqr(DevT T, SaStruct S, const double *__restrict__ Avals0, const double *_
         __syncthreads();
     };
     // solver-form A = -A_cvx: the stored values carry the boundary's sign
-    auto A_times = [&](const double *xin, auto &&out) { sa_spmv(S.csr_ptr, S.csr_col, S.csr_src, Avals0, m, [&](int j) { return xin[j]; }, [&](int i, double a) { out(i, -a); }); };
-    auto AT_times = [&](const double *yin, auto &&out) { sa_spmv(S.csc_ptr, S.csc_row, (const int *)nullptr, Avals0, n, [&](int i) { return yin[i]; }, [&](int j, double a) { out(j, -a); }); };
+    auto A_times = [&](const double *xin, auto &&out) {
+        if constexpr (RP > 0) sa_A_times<NT, RP>(F, n, m, xin, part, vd, out);
+        else sa_spmv(S.csr_ptr, S.csr_col, S.csr_src, Avals0, m, [&](int j) { return xin[j]; }, [&](int i, double a) { out(i, -a); });
+    };
+    auto AT_times = [&](const double *yin, auto &&out) {
+        if constexpr (RP > 0) sa_AT_times<NT, RP>(F, n, yin, wyd, out);
+        else sa_spmv(S.csc_ptr, S.csc_row, (const int *)nullptr, Avals0, n, [&](int i) { return yin[i]; }, [&](int j, double a) { out(j, -a); });
+    };
     auto nrm2 = [&](const double *a, const double *b) -> double {
         double r[1] = {0};
         for (int j = tid; j < n; j += NT) r[0] = fma(a[j], a[j], r[0]);

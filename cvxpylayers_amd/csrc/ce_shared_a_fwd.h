@@ -14,6 +14,7 @@
 // Algorithm, constants and order of operations: oracle/cone_oracle.c (SCS 3 restated) / cvxpylayers_amd/interfaces/const_a.py.
 // Cones: zero / nonnegative / second-order / PSD.
 #pragma once
+#include "ce_shared_a_ops.h"
 
 struct SaFwd {
     int r, RP;                   // dense rows, padded to a multiple of 16
@@ -28,15 +29,17 @@ struct SaFwd {
 };
 
 // LDS doubles (see the carve in the kernel)
-__host__ __device__ inline size_t sa_fwd_lds_doubles(int n, int m, int nq, int ns, int maxs, int RP) {
-    const int l = n + m + 1, lp = l + (l & 1);
+__host__ __device__ inline size_t sa_fwd_lds_doubles(int n, int m, int nq, int ns, int maxs, int RP, int nth) {
+    const int l = n + m + 1, lp = l + (l & 1), ne = n + (n & 1), me = m + (m & 1);
     const int kp = ns > 0 ? psd_mfma_kp(maxs) : 0;
-    return 6 * (size_t)lp + 3 * (size_t)n + 2 * (size_t)m + (size_t)RP * (RP + 1) + 4 * (size_t)RP + 2 * (size_t)(nq > 0 ? nq : 1) +
-           (size_t)(ns > 0 ? (ns + 2) * kp * (kp + 1) + 2 * kp + 8 : 0) + NT + NW * 8 + 32;
+    return 6 * (size_t)lp + 3 * (size_t)ne + 2 * (size_t)me + (size_t)RP * (RP + 1) + 4 * (size_t)RP + 2 * (size_t)(nq > 0 ? nq : 1) +
+           (size_t)(ns > 0 ? (ns + 2) * kp * (kp + 1) + 2 * kp + 8 : 0) + 2 * nth + (nth / 64) * 8 + 32;
 }
 
-template <int RP>
-__global__ void __launch_bounds__(NT, 2)
+// NTH threads per instance: 256 (two instances per CU when the iterates allow it) or 512 (templates whose iterates fill most of a CU's LDS
+// anyway: eight waves keep more loads of the shared matrix in flight and shorten every elementwise pass).
+template <int RP, int NTH>
+__global__ void __launch_bounds__(NTH, NTH == 256 ? 2 : 1)
 k_sa_fwd(DevT T, SaFwd F, ce_settings S, const double *__restrict__ BHg, const double *__restrict__ CHg, const double *__restrict__ sigma_g,
          const double *__restrict__ nb0_g, const double *__restrict__ nc0_g, const double *__restrict__ warm_x, const double *__restrict__ warm_y,
          const double *__restrict__ warm_s, double *__restrict__ xo, double *__restrict__ yo, double *__restrict__ so,
@@ -45,10 +48,12 @@ k_sa_fwd(DevT T, SaFwd F, ce_settings S, const double *__restrict__ BHg, const d
     const int tid = threadIdx.x, inst = blockIdx.x;
     const int n = T.n, m = T.m, l = n + m + 1, lp = l + (l & 1), z = T.z, nl = T.l, nq = T.nq, ns = T.ns;
     const int r = F.r, LK = RP + 1;
+    constexpr int NT = NTH, NW = NTH / 64;                  // (shadow the engine-wide 256-thread constants)
+    const int ne = n + (n & 1), me = m + (m & 1);           // even strides: every LDS vector below starts 16-byte aligned
     double *p = sm;
     double *W = p; p += lp; double *UT = p; p += lp; double *U = p; p += lp; double *G = p; p += lp; double *PHI = p; p += lp; double *zb = p; p += lp;
-    double *tv = p; p += n; double *px = p; p += n; double *dgi = p; p += n;
-    double *qy = p; p += m; double *bh = p; p += m;
+    double *tv = p; p += ne; double *px = p; p += ne; double *dgi = p; p += ne;
+    double *qy = p; p += me; double *bh = p; p += me;
     double *Kinv = p; p += (size_t)RP * LK;
     double *vd = p; p += RP; double *zd = p; p += RP; double *wyd = p; p += RP; double *dyd = p; p += RP;
     double *socc = p; p += 2 * (nq > 0 ? nq : 1);
@@ -56,7 +61,7 @@ k_sa_fwd(DevT T, SaFwd F, ce_settings S, const double *__restrict__ BHg, const d
     double *Vst = p; p += (size_t)ns * PM;                 // eigenvectors of every PSD block, kept between iterations
     double *Sm = p; p += PM; double *Tm = p; p += PM;      // PSD scratch
     double *cs = p; p += (ns > 0 ? 2 * KP + 8 : 0);
-    double *part = p; p += NT;                              // partial sums of the dense-row products
+    double *part = p; p += 2 * NT;                              // partial sums of the dense-row products
     double *red = p; p += NW * 8;
     double *sc = p; p += 32;
     const double *ch = CHg + (size_t)inst * n;              // c-hat stays in global memory (read in refresh / checks only)
@@ -71,63 +76,29 @@ k_sa_fwd(DevT T, SaFwd F, ce_settings S, const double *__restrict__ BHg, const d
     __syncthreads();
     const double *mtab = sc + 12;
 
-    // ---------------- products with the shared matrix
-    // dense rows:  out_a = sum_j AdT[j][a] xin[j]   (a < RP; every thread (a, group) sums a stride of j, partials through LDS)
-    auto dense_times = [&](const double *xin, double *out) {
-        constexpr int ng = NT / RP;
-        const int a = tid % RP, g = tid / RP;
-        double acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
-        int j = g;
-        for (; j + 3 * ng < n; j += 4 * ng) {        // four loads in flight (the matrix streams from L2: latency, not bandwidth, is the cost)
-            const double m0 = F.AdT[(size_t)j * RP + a], m1 = F.AdT[(size_t)(j + ng) * RP + a], m2 = F.AdT[(size_t)(j + 2 * ng) * RP + a], m3 = F.AdT[(size_t)(j + 3 * ng) * RP + a];
-            acc0 = fma(m0, xin[j], acc0); acc1 = fma(m1, xin[j + ng], acc1); acc2 = fma(m2, xin[j + 2 * ng], acc2); acc3 = fma(m3, xin[j + 3 * ng], acc3);
-        }
-        for (; j < n; j += ng) acc0 = fma(F.AdT[(size_t)j * RP + a], xin[j], acc0);
-        part[tid] = (acc0 + acc1) + (acc2 + acc3);
-        __syncthreads();
-        if (tid < RP) { double s_ = 0; for (int gg = 0; gg < ng; gg++) s_ += part[gg * RP + tid]; out[tid] = s_; }
-        __syncthreads();
-    };
-    // sum_a AdT[j][a] w[a] for one row j: the row is contiguous (RP doubles, 16-byte aligned), fetched with wide loads all in flight
-    auto row_dot = [&](int j, const double *w) -> double {
-        const double2 *row = reinterpret_cast<const double2 *>(F.AdT + (size_t)j * RP);
-        double2 rv[RP / 2];
-#pragma unroll
-        for (int a2 = 0; a2 < RP / 2; a2++) rv[a2] = row[a2];
-        double a0 = 0, a1 = 0;
-#pragma unroll
-        for (int a2 = 0; a2 < RP / 2; a2++) { a0 = fma(rv[a2].x, w[2 * a2], a0); a1 = fma(rv[a2].y, w[2 * a2 + 1], a1); }
-        return a0 + a1;
-    };
-    // y = A-hat x :  singleton rows elementwise, dense rows through dense_times.   out(i, value)
-    auto A_times = [&](const double *xin, auto &&out) {
-        dense_times(xin, vd);
-        for (int i = tid; i < m; i += NT) { const int c = F.srow_col[i]; if (c >= 0) out(i, F.srow_val[i] * xin[c]); }
-        for (int a = tid; a < r; a += NT) out(F.drow[a], vd[a]);
-        __syncthreads();
-    };
-    // x = A-hat^T y :  out(j, value)
-    auto AT_times = [&](const double *yin, auto &&out) {
-        for (int a = tid; a < RP; a += NT) wyd[a] = a < r ? yin[F.drow[a]] : 0.0;
-        __syncthreads();
-        for (int j = tid; j < n; j += NT) {
-            double acc = row_dot(j, wyd);
-            for (int k = F.scol_ptr[j]; k < F.scol_ptr[j + 1]; k++) { const int i = F.scol_row[k]; acc = fma(F.srow_val[i], yin[i], acc); }
-            out(j, acc);
+    // ---------------- products with the shared matrix (ce_shared_a_ops.h)
+    auto dense_times = [&](const double *xin, double *out) { sa_dense_times<NT, RP>(F.AdT, n, xin, part, out); };
+    auto A_times = [&](const double *xin, auto &&out) { sa_A_times<NT, RP>(F, n, m, xin, part, vd, out); };
+    auto AT_times = [&](const double *yin, auto &&out) { sa_AT_times<NT, RP>(F, n, yin, wyd, out); };
+    // pout <- S^-1 t  for pout = u = Dg^-1 t on entry (Woodbury);  zd = K^-1 A_d u is left behind
+    auto wood_u = [&](double *pout) {
+        dense_times(pout, vd);
+        for (int a = tid >> 3; a < RP; a += NT / 8) {       // zd = K^-1 vd : eight lanes per row
+            const double *kr = Kinv + a * LK;
+            double s_ = 0;
+            for (int b = tid & 7; b < r; b += 8) s_ = fma(kr[b], vd[b], s_);
+            s_ = group_reduce<8, false>(s_);
+            if ((tid & 7) == 0) zd[a] = a < r ? s_ : 0.0;
         }
         __syncthreads();
+        sa_rows_dot<NT, RP>(F.AdT, n, zd, [&](int, int) { return 0.0; }, [&](int j, double a) { pout[j] -= dgi[j] * a; });
+        __syncthreads();
     };
-    // pout = S^-1 tin  (Woodbury).  tin / pout may alias.
+    // pout = S^-1 tin.  tin / pout may alias.
     auto wood = [&](const double *tin, double *pout) {
         for (int j = tid; j < n; j += NT) pout[j] = tin[j] * dgi[j];
         __syncthreads();
-        dense_times(pout, vd);
-        if (tid < RP) { double s_ = 0; const double *kr = Kinv + tid * LK; for (int b = 0; b < r; b++) s_ = fma(kr[b], vd[b], s_); zd[tid] = tid < r ? s_ : 0.0; }
-        __syncthreads();
-        for (int j = tid; j < n; j += NT) {
-            pout[j] -= dgi[j] * row_dot(j, zd);
-        }
-        __syncthreads();
+        wood_u(pout);
     };
 
     // ---------------- (re)factor for the current scale: Dg^-1, K^-1 (MFMA + Gauss-Jordan in LDS), then g, h.g, phi
@@ -181,7 +152,7 @@ k_sa_fwd(DevT T, SaFwd F, ce_settings S, const double *__restrict__ BHg, const d
         double rr[1] = {0};
         for (int j = tid; j < n; j += NT) { G[j] = tv[j]; PHI[j] = rho_x * px[j]; rr[0] = fma(ch[j], tv[j], rr[0]); }
         for (int i = tid; i < m; i += NT) rr[0] = fma(bh[i], G[n + i], rr[0]);
-        block_reduce<1>(rr, 0u, red);
+        block_reduce_n<1, NW>(rr, 0u, red);
         hg = rr[0]; inv_den = 1.0 / (rtau + hg);
         if (tid == 0) { G[l - 1] = 0.0; PHI[l - 1] = 0.0; }
         __syncthreads();
@@ -197,7 +168,7 @@ k_sa_fwd(DevT T, SaFwd F, ce_settings S, const double *__restrict__ BHg, const d
             const double v = sigma * warm_y[(size_t)inst * m + i] / dvi + sigma * dvi * warm_s[(size_t)inst * m + i] * dyv(i);
             qy[i] = v; if (!(fabs(v) < 1e300)) bad[0] = 1.0;
         }
-        block_reduce<1>(bad, 1u, red);
+        block_reduce_n<1, NW>(bad, 1u, red);
         if (bad[0] == 0.0) { for (int j = tid; j < n; j += NT) W[j] = tv[j]; for (int i = tid; i < m; i += NT) W[n + i] = qy[i]; }
         __syncthreads();
     }
@@ -219,61 +190,71 @@ k_sa_fwd(DevT T, SaFwd F, ce_settings S, const double *__restrict__ BHg, const d
             if (check && iter > 0) {       // keep the homogeneous iterate in range
                 double rn[1] = {0};
                 for (int e = tid; e < l; e += NT) rn[0] = fma(W[e], W[e], rn[0]);
-                block_reduce<1>(rn, 0u, red);
+                block_reduce_n<1, NW>(rn, 0u, red);
                 const double nw = sqrt(rn[0]);
                 if (nw > 0) { const double f = sqrt((double)l) / nw; for (int e = tid; e < l; e += NT) W[e] *= f; }
                 __syncthreads();
             }
-            // t = rho w_x - A^T w_y ;  p_x = S^-1 t ;  q = A p_x
-            AT_times(W + n, [&](int j, double a) { tv[j] = rho_x * W[j] - a; });
-            wood(tv, px);
-            A_times(px, [&](int i, double a) { qy[i] = a; });
-            // tau-tilde, u-tilde, cone input
-            double rt[1] = {0};
-            for (int e = tid; e < l - 1; e += NT) rt[0] = fma(PHI[e], W[e], rt[0]);
-            block_reduce<1>(rt, 0u, red);
-            const double tau_t = (rtau * W[l - 1] + rt[0]) * inv_den;
+            // tau-tilde needs phi.w: the partial sums ride on the barriers of the products below
+            {
+                double rt = 0;
+                for (int e = tid; e < l - 1; e += NT) rt = fma(PHI[e], W[e], rt);
+                rt = wave_reduce_dpp<false>(rt);
+                if ((tid & 63) == 0) red[tid >> 6] = rt;
+            }
+            // t = rho w_x - A^T w_y ;  u = Dg^-1 t ;  p_x = S^-1 t
+            AT_times(W + n, [&](int j, double a) { px[j] = (rho_x * W[j] - a) * dgi[j]; });
+            // q = A p_x :  the dense rows are Dd^-1 zd  (A_d p_x = A_d u - A_d Dg^-1 A_d^T zd = K zd - (K - Dd^-1) zd); singleton rows: a gather below
+            wood_u(px);
+            for (int a = tid; a < r; a += NT) qy[F.drow[a]] = zd[a] / dyd[a];
+            double rts = 0;
+#pragma unroll
+            for (int w = 0; w < NW; w++) rts += red[w];
+            const double tau_t = (rtau * W[l - 1] + rts) * inv_den;
+            __syncthreads();
             for (int e = tid; e < l; e += NT) {
                 double ute, ze;
                 const double we = W[e];
                 if (e < n) { ute = px[e] - tau_t * G[e]; ze = 2 * ute - we; }
                 else if (e < l - 1) {
-                    const int i = e - n;
-                    ute = we + dyv(i) * qy[i] - tau_t * G[e]; ze = 2 * ute - we;
+                    const int i = e - n, c = F.srow_col[i];           // >= 0: singleton row, -2: dense row, -1: empty row
+                    const double qi = c >= 0 ? F.srow_val[i] * px[c] : (c == -2 ? qy[i] : 0.0);
+                    ute = we + dyv(i) * qi - tau_t * G[e]; ze = 2 * ute - we;
                     if (i >= z && i < z + nl && ze < 0) ze = 0;
                 } else { ute = tau_t; ze = fmax(0.0, 2 * tau_t - we); }
                 UT[e] = ute; zb[e] = ze;
             }
             __syncthreads();
             if (nq > 0) {
-                for (int c = tid; c < nq; c += NT) {
+                for (int c = tid >> 6; c < nq; c += NW) {         // one wave per cone
                     const int r0 = n + T.qoff[c], r1 = n + T.qoff[c + 1];
                     const double t0 = zb[r0]; double nz = 0;
-                    for (int k = r0 + 1; k < r1; k++) nz = fma(zb[k], zb[k], nz);
-                    nz = sqrt(nz);
+                    for (int k = r0 + 1 + (tid & 63); k < r1; k += 64) nz = fma(zb[k], zb[k], nz);
+                    nz = sqrt(wave_reduce_dpp<false>(nz));
                     double c0, f;
                     if (r1 - r0 == 1) { c0 = fmax(t0, 0.0); f = 0.0; }
                     else if (nz <= t0) { c0 = t0; f = 1.0; }
                     else if (nz <= -t0) { c0 = 0.0; f = 0.0; }
                     else { c0 = 0.5 * (t0 + nz); f = c0 / nz; }
-                    socc[2 * c] = c0; socc[2 * c + 1] = f;
+                    if ((tid & 63) == 0) { socc[2 * c] = c0; socc[2 * c + 1] = f; }
                 }
                 __syncthreads();
                 for (int i = tid + z + nl; i < m; i += NT) { const int c = T.rowcone[i]; if (c >= 0) zb[n + i] = (i == T.qoff[c]) ? socc[2 * c] : socc[2 * c + 1] * zb[n + i]; }
                 __syncthreads();
             }
 #ifndef SA_SKIP_PSD        // (debug builds time the kernel without the projection)
+            if constexpr (NTH == 256)          // (templates with PSD blocks always run the 256-thread instantiation)
             for (int c = 0; c < ns; c++)       // PSD blocks: MFMA sandwich + warm-started Jacobi, eigenvectors stay in LDS (restart at check iterations)
                 psd_project_mfma_lds<NT>(zb + n + T.soff[c], T.sord[c], Sm, Vst + (size_t)c * PM, Tm, cs, red, (!check && iter > 0) ? 1 : 0);
 #endif
-            for (int e = tid; e < l; e += NT) U[e] = zb[e];
-            __syncthreads();
             if (!check && !last) {
-                for (int e = tid; e < l; e += NT) W[e] += alpha * (U[e] - UT[e]);
+                for (int e = tid; e < l; e += NT) { const double ue = zb[e]; U[e] = ue; W[e] += alpha * (ue - UT[e]); }
                 __syncthreads();
                 iter++;
                 continue;
             }
+            for (int e = tid; e < l; e += NT) U[e] = zb[e];
+            __syncthreads();
             // ---- check iteration: residuals, termination, certificates, adaptive scale
             bool stop = false, rescale = false;
             if (check) {
@@ -295,7 +276,7 @@ k_sa_fwd(DevT T, SaFwd F, ce_settings S, const double *__restrict__ BHg, const d
                     rr[4] = fmax(rr[4], fabs(aty + cj * tau * sc_)); rr[5] = fmax(rr[5], fabs(aty));
                     rr[6] += cj * U[j] * isg * isg;
                 }
-                block_reduce<8>(rr, 0x3Fu, red);
+                block_reduce_n<8, NW>(rr, 0x3Fu, red);
                 const double rp = rr[0], nax = rr[1], nsn = rr[2], naxs = rr[3], rd = rr[4], naty = rr[5], ctx = rr[6], bty = rr[7];
                 const double nrm_b0 = nb0_g[inst], nrm_c0 = nc0_g[inst];
                 if (tau > 0) {
@@ -340,7 +321,7 @@ k_sa_fwd(DevT T, SaFwd F, ce_settings S, const double *__restrict__ BHg, const d
         double rr[2] = {0, 0};
         for (int j = tid; j < n; j += NT) rr[0] += ch[j] * U[j] * isg * isg;
         for (int i = tid; i < m; i += NT) rr[1] += bh[i] * U[n + i] * isg * isg;
-        block_reduce<2>(rr, 0u, red);
+        block_reduce_n<2, NW>(rr, 0u, red);
         if (tau > kap) status = 2; else if (rr[1] < rr[0]) status = -7; else status = -6;
     }
     const bool solved = (status == 1 || status == 2), infeas = (status == -2 || status == -7);

@@ -65,6 +65,10 @@ struct ce_engine {
     int rt_variant = -1, rt_vp = 0, rt_lda = 0;   // register-tiled forward kernel variant (-1: generic kernel)
     int f2_variant = -1; int *d_idx_at = nullptr, *d_idx_ar = nullptr, *d_idx_b = nullptr; int f2_ldg = 0;   // second-generation forward kernel
     int *d_csc_ptr = nullptr, *d_csr_ptr = nullptr, *d_csr_col = nullptr, *d_csr_src = nullptr;   // sparse structure of the A part (shared-A kernels)
+    // split of the A part into singleton rows and sp_r <= 64 dense rows (ce_shared_a_ops.h); sp_RP == 0: more than 64 rows with several entries
+    int sp_r = 0, sp_RP = 0;
+    int *d_sp_drow = nullptr, *d_sp_srow_col = nullptr, *d_sp_scol_ptr = nullptr, *d_sp_scol_row = nullptr, *d_sp_rowslot = nullptr;
+    double *d_sp_AdT = nullptr, *d_sp_sval = nullptr;
     bool wl = false; int wl_nq = 0; int *d_row_perm = nullptr, *d_k_rowcone = nullptr, *d_k_qoff = nullptr;   // rows packed so that cones are wave-local (k_fwd2 WL)
     int brt_variant = -1;                          // register-tiled backward kernel variant (-1: generic kernel)
     // quadratic objective
@@ -293,6 +297,28 @@ int ce_create(const ce_template *tpl, int device, ce_handle *out) {
         HIPCHK(hipMemcpy(h->d_csr_ptr, rptr.data(), sizeof(int) * (tpl->m + 1), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(h->d_csr_col, rcol.data(), sizeof(int) * rcol.size(), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(h->d_csr_src, rsrc.data(), sizeof(int) * rsrc.size(), hipMemcpyHostToDevice));
+        // split: rows with one entry / rows with several
+        std::vector<int> drow, rowslot(tpl->m, -1), srow_col(tpl->m, -1);
+        for (int i = 0; i < tpl->m; i++) {
+            const int cnt = rptr[i + 1] - rptr[i];
+            if (cnt >= 2) { rowslot[i] = (int)drow.size(); drow.push_back(i); }
+            else if (cnt == 1) srow_col[i] = rcol[rptr[i]];
+        }
+        if ((int)drow.size() <= 64) {
+            h->sp_r = (int)drow.size();
+            h->sp_RP = h->sp_r <= 16 ? 16 : (h->sp_r <= 32 ? 32 : 64);
+            std::vector<int> scol_ptr(tpl->n + 1, 0), scol_row;
+            for (int i = 0; i < tpl->m; i++) if (srow_col[i] >= 0) scol_ptr[srow_col[i] + 1]++;
+            for (int j = 0; j < tpl->n; j++) scol_ptr[j + 1] += scol_ptr[j];
+            scol_row.resize(std::max(scol_ptr[tpl->n], 1));
+            std::vector<int> sfill(scol_ptr.begin(), scol_ptr.end() - 1);
+            for (int i = 0; i < tpl->m; i++) if (srow_col[i] >= 0) scol_row[sfill[srow_col[i]]++] = i;
+            if (drow.empty()) drow.push_back(0);
+            auto up = [&](int **dst, const std::vector<int> &v) -> int { HIPCHK(hipMalloc(dst, sizeof(int) * v.size())); HIPCHK(hipMemcpy(*dst, v.data(), sizeof(int) * v.size(), hipMemcpyHostToDevice)); return 0; };
+            if (up(&h->d_sp_drow, drow) || up(&h->d_sp_srow_col, srow_col) || up(&h->d_sp_scol_ptr, scol_ptr) || up(&h->d_sp_scol_row, scol_row) || up(&h->d_sp_rowslot, rowslot)) return CE_E_HIP;
+            HIPCHK(hipMalloc(&h->d_sp_AdT, sizeof(double) * (size_t)std::max(tpl->n, 1) * h->sp_RP));
+            HIPCHK(hipMalloc(&h->d_sp_sval, sizeof(double) * std::max(tpl->m, 1)));
+        }
     }
     HIPCHK(hipMalloc(&h->d_soff, sizeof(int) * (tpl->ns + 1))); HIPCHK(hipMalloc(&h->d_sord, sizeof(int) * std::max(tpl->ns, 1)));
     HIPCHK(hipMemcpy(h->d_soff, soff.data(), sizeof(int) * (tpl->ns + 1), hipMemcpyHostToDevice));
@@ -404,6 +430,7 @@ int ce_destroy(ce_handle h) {
     hipSetDevice(h->device);
     hipFree(h->d_rowidx); hipFree(h->d_colidx); hipFree(h->d_rowcone); hipFree(h->d_qoff); hipFree(h->d_soff); hipFree(h->d_sord); hipFree(h->d_pw); hipFree(h->d_idx_p); hipFree(h->d_pmap); hipFree(h->d_prow); hipFree(h->d_pcol);
     hipFree(h->wsA); hipFree(h->wsdA); hipFree(h->gws); hipFree(h->d_idx_at); hipFree(h->d_idx_ar); hipFree(h->d_idx_b); hipFree(h->d_row_perm); hipFree(h->d_k_rowcone); hipFree(h->d_k_qoff); hipFree(h->d_csc_ptr); hipFree(h->d_csr_ptr); hipFree(h->d_csr_col); hipFree(h->d_csr_src);
+    hipFree(h->d_sp_drow); hipFree(h->d_sp_srow_col); hipFree(h->d_sp_scol_ptr); hipFree(h->d_sp_scol_row); hipFree(h->d_sp_rowslot); hipFree(h->d_sp_AdT); hipFree(h->d_sp_sval);
     for (auto &v : h->ev) for (auto &p : v) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
     delete h;
     return CE_OK;
@@ -619,21 +646,28 @@ int ce_solve_shared_a(ce_handle h, int B, int r, int RP, const double *AdT, cons
     const DevT &T = h->T;
     if (T.nep + T.np > 0) { g_err = "shared-A forward kernel: exponential / power cones are not implemented"; return CE_E_UNSUPPORTED; }
     if (r < 0 || r > RP || (RP != 16 && RP != 32 && RP != 64)) { g_err = "shared-A forward kernel: at most 64 dense rows (RP in 16, 32, 64)"; return CE_E_UNSUPPORTED; }
-    const size_t lds = sa_fwd_lds_doubles(T.n, T.m, T.nq, T.ns, T.maxs, RP) * 8;
+    // 512 threads per instance when the iterates of one instance leave room for a single workgroup per CU anyway (CE_SA_NT=256 / 512 / 1024 forces;
+    // the 1024-thread instantiation is capped at 128 VGPRs and spills: kept for experiments only)
+    int nth = 256;
+    if (T.ns == 0 && sa_fwd_lds_doubles(T.n, T.m, T.nq, T.ns, T.maxs, RP, 256) * 8 > LDS_LIMIT / 2) nth = 512;
+    if (const char *e = getenv("CE_SA_NT")) { const int v = atoi(e); if (v == 256 || ((v == 512 || (v == 1024 && RP == 64)) && T.ns == 0)) nth = v; }
+    const size_t lds = sa_fwd_lds_doubles(T.n, T.m, T.nq, T.ns, T.maxs, RP, nth) * 8;
     if (lds > LDS_LIMIT) { g_err = "shared-A forward kernel: the iterates of one instance do not fit LDS"; return CE_E_TOO_LARGE; }
     HIPCHK(hipSetDevice(h->device));
     static bool attr_done = false;
     if (!attr_done) {
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sa_fwd<16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sa_fwd<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
-        HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sa_fwd<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT));
+#define SA_ATTR(RPV, NTV) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sa_fwd<RPV, NTV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT))
+        SA_ATTR(16, 256); SA_ATTR(32, 256); SA_ATTR(64, 256); SA_ATTR(16, 512); SA_ATTR(32, 512); SA_ATTR(64, 512); SA_ATTR(64, 1024);
+#undef SA_ATTR
         attr_done = true;
     }
     SaFwd F{r, RP, AdT, drow, srow_col, srow_val, scol_ptr, scol_row, gs, Dv, Ev};
     {
         ProfScope ps(h, 0, (hipStream_t)stream);
-#define LAUNCH_SA(RPV) hipLaunchKernelGGL(k_sa_fwd<RPV>, dim3(B), dim3(NT), lds, (hipStream_t)stream, T, F, *settings, b_hat, c_hat, sigma, nrm_b0, nrm_c0, warm_x, warm_y, warm_s, x, y, s, iters, status, resid)
-        if (RP == 16) LAUNCH_SA(16); else if (RP == 32) LAUNCH_SA(32); else LAUNCH_SA(64);
+#define LAUNCH_SA(RPV, NTV) hipLaunchKernelGGL((k_sa_fwd<RPV, NTV>), dim3(B), dim3(NTV), lds, (hipStream_t)stream, T, F, *settings, b_hat, c_hat, sigma, nrm_b0, nrm_c0, warm_x, warm_y, warm_s, x, y, s, iters, status, resid)
+        if (nth == 256) { if (RP == 16) LAUNCH_SA(16, 256); else if (RP == 32) LAUNCH_SA(32, 256); else LAUNCH_SA(64, 256); }
+        else if (nth == 512) { if (RP == 16) LAUNCH_SA(16, 512); else if (RP == 32) LAUNCH_SA(32, 512); else LAUNCH_SA(64, 512); }
+        else LAUNCH_SA(64, 1024);
 #undef LAUNCH_SA
     }
     HIPCHK(hipGetLastError());
@@ -644,16 +678,32 @@ int ce_vjp_shared_a(ce_handle h, int B, const double *A_vals0, const double *x, 
     if (!h || B <= 0 || !A_vals0 || !x || !y || !s || !dx || !dy || !dA_bm || !dq_vals) { g_err = "null argument"; return CE_E_BADARG; }
     const DevT &T = h->T;
     if (T.nep + T.np > 0) { g_err = "shared-A adjoint kernel: exponential / power cones are not implemented"; return CE_E_UNSUPPORTED; }
-    const size_t lds = sa_lsqr_lds_doubles(T.n, T.m, T.nq, T.ns, T.maxs) * 8;
+    // products through the singleton / dense-row split when the template has one (CE_SA_SPLIT=0: CSR / CSC products)
+    int RP = h->sp_RP;
+    if (const char *e = getenv("CE_SA_SPLIT")) { if (atoi(e) == 0) RP = 0; }
+    if (RP > 0 && sa_lsqr_lds_doubles(T.n, T.m, T.nq, T.ns, T.maxs, RP) * 8 > LDS_LIMIT) RP = 0;
+    const size_t lds = sa_lsqr_lds_doubles(T.n, T.m, T.nq, T.ns, T.maxs, RP) * 8;
     if (lds > LDS_LIMIT) { g_err = "shared-A adjoint kernel: the LSQR vectors of one instance do not fit LDS"; return CE_E_TOO_LARGE; }
     HIPCHK(hipSetDevice(h->device));
     static bool attr_done = false;
-    if (!attr_done) { HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sa_lsqr), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT)); attr_done = true; }
+    if (!attr_done) {
+#define SA_ATTR(RPV) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sa_lsqr<RPV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT))
+        SA_ATTR(0); SA_ATTR(16); SA_ATTR(32); SA_ATTR(64);
+#undef SA_ATTR
+        attr_done = true;
+    }
     SaStruct S{h->d_csc_ptr, h->d_rowidx, h->d_csr_ptr, h->d_csr_col, h->d_csr_src, T.nnzA};
+    SaSplit F{h->sp_r, RP, h->d_sp_AdT, h->d_sp_drow, h->d_sp_srow_col, h->d_sp_sval, h->d_sp_scol_ptr, h->d_sp_scol_row};
+    if (RP > 0) {      // the values may differ between calls: refill A_d^T / singleton values from this call's A (n RP + m doubles)
+        HIPCHK(hipMemsetAsync(h->d_sp_AdT, 0, sizeof(double) * (size_t)T.n * RP, (hipStream_t)stream));
+        HIPCHK(hipMemsetAsync(h->d_sp_sval, 0, sizeof(double) * T.m, (hipStream_t)stream));
+        if (T.nnzA > 0) hipLaunchKernelGGL(k_sa_fill_split, dim3((T.nnzA + 255) / 256), dim3(256), 0, (hipStream_t)stream, T.nnzA, RP, h->d_rowidx, h->d_colidx, h->d_sp_rowslot, A_vals0, h->d_sp_AdT, h->d_sp_sval);
+    }
     {
         ProfScope ps(h, 1, (hipStream_t)stream);
-        hipLaunchKernelGGL(k_sa_lsqr, dim3(B), dim3(NT), lds, (hipStream_t)stream, T, S, A_vals0, x, y, s, dx, dy, dA_bm, dq_vals, sdq_k, sdq_b, adj_status, lsqr_iters,
-                           atol, btol, iter_lim > 0 ? iter_lim : 4 * (T.n + T.m));
+#define LAUNCH_SAL(RPV) hipLaunchKernelGGL(k_sa_lsqr<RPV>, dim3(B), dim3(NT), lds, (hipStream_t)stream, T, S, F, A_vals0, x, y, s, dx, dy, dA_bm, dq_vals, sdq_k, sdq_b, adj_status, lsqr_iters, atol, btol, iter_lim > 0 ? iter_lim : 4 * (T.n + T.m))
+        if (RP == 0) LAUNCH_SAL(0); else if (RP == 16) LAUNCH_SAL(16); else if (RP == 32) LAUNCH_SAL(32); else LAUNCH_SAL(64);
+#undef LAUNCH_SAL
     }
     HIPCHK(hipGetLastError());
     return CE_OK;

@@ -140,8 +140,8 @@ def solve_const_a(eng, A_bm: torch.Tensor, q_eval: torch.Tensor, settings, warm=
     bh = (bh * sigma[:, None]).contiguous(); ch = (ch * sigma[:, None]).contiguous()
     # ---- persistent one-kernel path (ce_shared_a_fwd.h): A = (rows with one entry) + (r <= 64 rows with several): the reduced KKT matrix
     #      is diagonal + rank r and is applied by the Woodbury identity; every iterate of an instance stays in LDS, no host round trips.
-    #      Per-instance streaming of the shared dense rows from L2 limits it at very large batch x size (BASELINE config 5 at
-    #      B = 16384 stays on the batch-GEMM path below); CE_SA_FWD=1 / 0 forces / disables.
+    #      Taken whenever the template has that shape, the Woodbury form is stable and the iterates fit LDS (measured against the batch-GEMM
+    #      path below: 28 vs 40 ms at BASELINE config 4, 420 vs 480 ms at config 5 with B = 16384); CE_SA_FWD=0 disables.
     _saf = os.environ.get("CE_SA_FWD")
     if _saf != "0" and not ntri:
         row_nnz = np.bincount(indices[:nnzA], minlength=m)
@@ -149,11 +149,11 @@ def solve_const_a(eng, A_bm: torch.Tensor, q_eval: torch.Tensor, settings, warm=
         r_d = int(len(drows_np))
         RP = 16 if r_d <= 16 else (32 if r_d <= 32 else 64)
         stable = False
-        if r_d <= 64 and (_saf == "1" or B * n * RP <= (1 << 28)):
+        if r_d <= 64:
             srow = (row_nnz == 1)
             ent_rows = indices[:nnzA].astype(np.int64); ent_cols = cols[:nnzA].astype(np.int64)
             sing = srow[ent_rows]                                          # structural entries that sit in single-entry rows
-            srow_col_np = np.full(m, -1, dtype=np.int32); srow_col_np[ent_rows[sing]] = ent_cols[sing]
+            srow_col_np = np.full(m, -1, dtype=np.int32); srow_col_np[drows_np] = -2; srow_col_np[ent_rows[sing]] = ent_cols[sing]      # >= 0 column of a singleton row, -2 dense row, -1 empty row
             order = np.argsort(ent_cols[sing], kind="stable")
             scol_row_np = ent_rows[sing][order].astype(np.int32)
             scol_ptr_np = np.concatenate([[0], np.cumsum(np.bincount(ent_cols[sing], minlength=n))]).astype(np.int32)
@@ -173,7 +173,7 @@ def solve_const_a(eng, A_bm: torch.Tensor, q_eval: torch.Tensor, settings, warm=
             # Woodbury is only stable when the diagonal part carries weight in EVERY column (each variable sits in some single-entry row:
             # bounds, identity blocks); a column without one has Dg_j = rho_x = 1e-6 and the formula cancels catastrophically
             stable = bool((gs.min() >= 1e-2).item()) if n else False
-        if r_d <= 64 and (_saf == "1" or B * n * RP <= (1 << 28)) and stable:
+        if r_d <= 64 and stable:
             xo = torch.empty((B, n), **f64); yo = torch.empty((B, m), **f64); so = torch.empty((B, m), **f64)
             it_o = torch.empty(B, dtype=torch.int32, device=dev); st_o = torch.empty(B, dtype=torch.int32, device=dev); rs_o = torch.empty((B, 3), **f64)
             wx = wy = ws = None
@@ -413,11 +413,14 @@ def vjp_const_a(eng, A_bm, x, y, s, dx, dy, batch_minor_out=False, atol=1e-12, b
     dev = A_bm.device
     n, m, B = eng.n, eng.m, A_bm.shape[0]
     import os as _os
-    # The one-kernel LSQR (ce_shared_a.h) wins whenever the batched implementation below is launch-bound (small / medium batches) or A is
-    # very sparse; at very large batch x nnz its row-parallel sparse products lose to the batch GEMMs with the dense A (measured at
-    # BASELINE config 5: B = 16384, nnzA = 26 k: 1.05 s against 0.77 s), hence the work threshold.  CE_SA_KERNEL=1 / 0 forces / disables.
+    # The one-kernel LSQR (ce_shared_a.h).  With the singleton / dense-row split of A (at most 64 rows with several entries) its products are
+    # balanced and it beats the batched implementation below at every size measured (BASELINE config 5, B = 16384: 0.26 s against 0.73 s);
+    # without the split its CSR / CSC products serialise on the longest row and lose at very large batch x nnz (1.05 s there), hence the
+    # work threshold for that case only.  CE_SA_KERNEL=1 / 0 forces / disables.
     _sa = _os.environ.get("CE_SA_KERNEL")
-    if _sa != "0" and (_sa == "1" or B * max(eng.nnzA, 1) <= (1 << 26)):
+    _row_nnz = np.bincount(eng._indices[:eng.nnzA], minlength=m) if eng.nnzA else np.zeros(m, dtype=np.int64)
+    _has_split = int((_row_nnz >= 2).sum()) <= 64
+    if _sa != "0" and (_sa == "1" or _has_split or B * max(eng.nnzA, 1) <= (1 << 26)):
         # one kernel, one workgroup per instance (ce_shared_a.h); falls through to the batched torch implementation when the template
         # has exponential / power cones or the LSQR vectors of an instance do not fit LDS
         f64_ = dict(dtype=torch.float64, device=dev)

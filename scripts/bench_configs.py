@@ -108,7 +108,8 @@ if "C4" in WANT:
 if "C5" in WANT:
     Bp = int(os.environ.get("C5_BATCH", "16384"))
     A, b, c, cones, tpl = P.portfolio_c5_batch(Bp, seed=0)
-    res.append(run("C5", tpl, cones, *tpl.values_from_dense(np.broadcast_to(A, (Bp,) + A.shape).copy(), np.broadcast_to(b, (Bp,) + b.shape).copy(), c), 1e-4, 2,
+    A1, _ = tpl.values_from_dense(A[None], b[None], c[:1])          # A, b shared: tile one instance's values (the dense (B, m, n) array would be 36 GB)
+    res.append(run("C5", tpl, cones, np.repeat(A1, Bp, axis=1), np.concatenate([c.T, np.zeros((1, Bp))], axis=0), 1e-4, 2,
                    "portfolio n=501, A shared, returns batched (BASELINE config 5), 1 GPU", min_seconds=0.0))
 out = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/configs.json"
 os.makedirs(os.path.dirname(out) or ".", exist_ok=True)

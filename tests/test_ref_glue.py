@@ -141,10 +141,19 @@ def test_variable_recovery_agrees_with_the_reference(ns, name):
         B = batch[0] if batch else 1
         primal = torch.tensor(rng.standard_normal((B, n))); dual = torch.tensor(rng.standard_normal((B, m)))
         want = ns.cvxpylayer._recover_results(primal, dual, rl.ctx, batch)
-        got = mine._recover_results(primal, dual, batch)
+        got = mine._recover_results_torch(primal, dual, batch)       # the per-variable chain (checker of the one-launch device path)
         assert len(want) == len(got)
         for a, b in zip(want, got):
             assert a.shape == b.shape and torch.equal(a, b)
+        # the sparse recovery map the device path launches (ce_parammap_apply2), applied here with scipy: same numbers, same layout
+        for source, src in (("primal", primal), ("dual", dual)):
+            if source not in mine._rec:
+                continue
+            csr, layout = mine._rec[source]
+            rec = (csr.mat @ src.numpy().T).T
+            for pos, off, size in layout:
+                w = want[pos].numpy()
+                assert np.array_equal(rec[:, off:off + size].reshape(w.shape), w)
 
 
 def test_validate_params_messages_are_the_references(ns):
