@@ -42,10 +42,10 @@ __device__ __forceinline__ void sa_spmv(const int *__restrict__ ptr, const int *
     }
 }
 
-// LDS doubles: [split products: 2 RP + 2 NT] + 8 m + 5 n + 4 nq + ns (4 KP (KP + 1) + 2 KP + 8) + NW * 8 + 16
+// LDS doubles: [split products: 2 RP + 2 NT] + 7 m + 5 n + 5 nq + ns (4 KP (KP + 1) + 2 KP + 8) + NW * 8 + 16
 __host__ __device__ inline size_t sa_lsqr_lds_doubles(int n, int m, int nq, int ns, int maxs, int RP) {
     const int kp = ns > 0 ? psd_mfma_kp(maxs) : 0;
-    return (size_t)(RP > 0 ? 2 * RP + 2 * NT : 0) + 8 * (size_t)m + 5 * (size_t)n + 4 * (size_t)(nq > 0 ? nq : 1) +
+    return (size_t)(RP > 0 ? 2 * RP + 2 * NT : 0) + 7 * (size_t)m + 5 * (size_t)n + 5 * (size_t)(nq > 0 ? nq : 1) + 1 +
            (size_t)(ns > 0 ? (2 * ns + 2) * kp * (kp + 1) + 2 * kp + 8 : 0) + NW * 8 + 16;
 }
 
@@ -63,9 +63,9 @@ k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, cons
     double *wyd = p, *vd = p, *part = p;                     // split products: 16-byte aligned at the start of the carve
     if constexpr (RP > 0) { wyd = p; p += RP; vd = p; p += RP; part = p; p += 2 * NT; }
     double *vv = p; p += m;            // v = y - s
-    double *uy = p; p += m; double *vy = p; p += m; double *wy = p; p += m; double *ry = p; p += m; double *ty = p; p += m; double *qv = p; p += m; double *tmp = p; p += m;
+    double *uy = p; p += m; double *vy = p; p += m; double *wy = p; p += m; double *ry = p; p += m; double *ty = p; p += m; double *qv = p; p += m;
     double *ux = p; p += n; double *vx = p; p += n; double *wx = p; p += n; double *rx = p; p += n; double *tx = p; p += n;
-    double *socs = p; p += 4 * (nq > 0 ? nq : 1);          // per cone: t, |z|, case, z.h
+    double *socs = p; p += 5 * (nq > 0 ? nq : 1);          // per cone: t, |z|, case, z.h ; then h_0 per cone
     const int KP = ns > 0 ? psd_mfma_kp(T.maxs) : 0, P = KP + 1, PM = KP * P;
     const float rKP = KP > 0 ? 1.0f / (float)KP : 1.0f;
     double *Um = p; p += (size_t)ns * PM;                    // eigenvectors of smat(v_c), per cone
@@ -115,19 +115,22 @@ k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, cons
     }
     __syncthreads();
 
-    // q <- DPi(h), in place safe (h may alias q).  All threads call it; ends synchronised.
-    auto dproj = [&](const double *h, double *q) {
+    // sink(i, DPi(hs * h)_i) for every row i.  h must be complete (synchronised) on entry; every thread calls it.  The value of row i depends on
+    // h_i, on per-cone sums taken in a first phase (one barrier) and, for PSD blocks, on the whole block (copied to a matrix before any sink of
+    // the block runs): sinks may therefore overwrite h_i.  No trailing barrier.
+    auto dproj = [&](const double *h, double hs, auto &&sink) {
         if (nq > 0) {
-            for (int c = tid >> 6; c < nq; c += NW) {       // z.h per cone: one wave per cone
+            for (int c = tid >> 6; c < nq; c += NW) {       // z.h and h_0 per cone: one wave per cone
                 double a = 0;
                 for (int k = T.qoff[c] + 1 + (tid & 63); k < T.qoff[c + 1]; k += 64) a = fma(vv[k], h[k], a);
                 a = wave_reduce_dpp<false>(a);
-                if ((tid & 63) == 0) socs[4 * c + 3] = a;
+                if ((tid & 63) == 0) { socs[4 * c + 3] = a * hs; socs[4 * nq + c] = h[T.qoff[c]] * hs; }
             }
             __syncthreads();
         }
-        for (int i = tid; i < m; i += NT) {
-            double o = h[i];
+        const int psd0 = ns > 0 ? T.soff[0] : m;
+        for (int i = tid; i < psd0; i += NT) {
+            double o = h[i] * hs;
             if (i >= z && i < z + nl) o = (vv[i] > 0) ? o : 0.0;
             else {
                 const int c = (i >= z + nl && nq > 0) ? T.rowcone[i] : -1;
@@ -136,23 +139,22 @@ k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, cons
                     if (kase == 1.0) o = 0.0;
                     else if (kase == 2.0) {
                         const int r0 = T.qoff[c];
-                        const double t = socs[4 * c], nz = socs[4 * c + 1], zh = socs[4 * c + 3], h0 = h[r0];
+                        const double t = socs[4 * c], nz = socs[4 * c + 1], zh = socs[4 * c + 3], h0 = socs[4 * nq + c];
                         const double nzs = fmax(nz, 1e-300);
                         if (i == r0) o = (nz * h0 + zh) / (2 * nzs);
-                        else o = (vv[i] * h0 + (t + nz) * h[i] - t * vv[i] * zh / (nzs * nzs)) / (2 * nzs);
+                        else o = (vv[i] * h0 + (t + nz) * o - t * vv[i] * zh / (nzs * nzs)) / (2 * nzs);
                     }
                 }
             }
-            tmp[i] = o;
+            sink(i, o);
         }
-        __syncthreads();
         for (int c = 0; c < ns; c++) {      // PSD block: Z = U (B o (U^T H U)) U^T on the matrix cores
             const int k = T.sord[c], off = T.soff[c], KT = KP / 16;
             const double *U = Um + (size_t)c * PM, *Bc = Bm + (size_t)c * PM;
             for (int idx = tid; idx < KP * KP; idx += NT) {
                 const int i = psd_fdiv(idx, rKP), j = idx - i * KP;
                 double sv = 0.0;
-                if (i < k && j < k) { const int a = i >= j ? i : j, b = i >= j ? j : i; const double v0 = h[off + b * k - (b * (b - 1)) / 2 + (a - b)]; sv = (a == b) ? v0 : v0 * M_SQRT1_2; }
+                if (i < k && j < k) { const int a = i >= j ? i : j, b = i >= j ? j : i; const double v0 = h[off + b * k - (b * (b - 1)) / 2 + (a - b)] * hs; sv = (a == b) ? v0 : v0 * M_SQRT1_2; }
                 Hm[i * P + j] = sv;
             }
             __syncthreads();
@@ -168,86 +170,95 @@ k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, cons
                 const int a = psd_fdiv(idx, 1.0f / (float)k), b = idx - a * k;
                 if (a < b) continue;
                 const double v0 = 0.5 * (Hm[a * P + b] + Hm[b * P + a]);
-                tmp[off + b * k - (b * (b - 1)) / 2 + (a - b)] = (a == b) ? v0 : v0 * M_SQRT2;
+                sink(off + b * k - (b * (b - 1)) / 2 + (a - b), (a == b) ? v0 : v0 * M_SQRT2);
+            }
+            if (c + 1 < ns) __syncthreads();                       // (Hm is reused by the next block)
+        }
+    };
+    // the two products of one operator application share their barriers.  On return (synchronised): fx(j, (A^T yin)_j) was called for every
+    // column and fy(i, (A xin)_i) for every row (solver-form A = -A_cvx: the stored values carry the boundary's sign).
+    auto both_products = [&](const double *yin, const double *xin, auto &&fx, auto &&fy) {
+        if constexpr (RP > 0) {
+            for (int a = tid; a < RP; a += NT) wyd[a] = a < F.r ? yin[F.drow[a]] : 0.0;
+            __syncthreads();
+            sa_rows_dot<NT, RP>(F.AdT, n, wyd,
+                                [&](int j, int k8) { double acc = 0; for (int k = F.scol_ptr[j] + k8; k < F.scol_ptr[j + 1]; k += 8) { const int i = F.scol_row[k]; acc = fma(F.srow_val[i], yin[i], acc); } return acc; },
+                                fx);
+            sa_dense_partials<NT, RP>(F.AdT, n, xin, part);
+            __syncthreads();
+            for (int i = tid; i < m; i += NT) {
+                const int c = F.srow_col[i];
+                if (c >= 0) fy(i, F.srow_val[i] * xin[c]);
+                else {
+                    const int a = F.rowslot[i];                  // slot of a dense row, -1: empty row
+                    double s_ = 0;
+                    if (a >= 0) { constexpr int ng = 2 * NT / RP; for (int gg = 0; gg < ng; gg++) s_ += part[gg * RP + a]; }
+                    fy(i, s_);
+                }
             }
             __syncthreads();
+        } else {
+            sa_spmv(S.csc_ptr, S.csc_row, (const int *)nullptr, Avals0, n, [&](int i) { return yin[i]; }, [&](int j, double a) { fx(j, -a); });
+            sa_spmv(S.csr_ptr, S.csr_col, S.csr_src, Avals0, m, [&](int j) { return xin[j]; }, [&](int i, double a) { fy(i, -a); });
+            __syncthreads();
         }
-        for (int i = tid; i < m; i += NT) q[i] = tmp[i];
-        __syncthreads();
-    };
-    // solver-form A = -A_cvx: the stored values carry the boundary's sign
-    auto A_times = [&](const double *xin, auto &&out) {
-        if constexpr (RP > 0) sa_A_times<NT, RP>(F, n, m, xin, part, vd, out);
-        else sa_spmv(S.csr_ptr, S.csr_col, S.csr_src, Avals0, m, [&](int j) { return xin[j]; }, [&](int i, double a) { out(i, -a); });
-    };
-    auto AT_times = [&](const double *yin, auto &&out) {
-        if constexpr (RP > 0) sa_AT_times<NT, RP>(F, n, yin, wyd, out);
-        else sa_spmv(S.csc_ptr, S.csc_row, (const int *)nullptr, Avals0, n, [&](int i) { return yin[i]; }, [&](int j, double a) { out(j, -a); });
-    };
-    auto nrm2 = [&](const double *a, const double *b) -> double {
-        double r[1] = {0};
-        for (int j = tid; j < n; j += NT) r[0] = fma(a[j], a[j], r[0]);
-        for (int i = tid; i < m; i += NT) r[0] = fma(b[i], b[i], r[0]);
-        block_reduce<1>(r, 0u, red);
-        return sqrt(r[0]);
     };
     auto safe = [](double t) -> double { return t > 0 ? t : 1.0; };
+    auto sum_all = [&](double v) -> double { double r[1] = {v}; block_reduce<1>(r, 0u, red); return r[0]; };
 
     // ---- LSQR (Paige & Saunders) on N r = (dx, DPi dy)
-    for (int j = tid; j < n; j += NT) { ux[j] = dxg[(size_t)inst * n + j]; rx[j] = 0.0; }
+    //      N (r_x, r_y) = (-A^T r_y, DPi(A r_x - r_y) + r_y),     N^T (p_x, p_y) = (A^T q, -A p_x - q + p_y),  q = DPi(p_y)
+    double acc = 0;
+    for (int j = tid; j < n; j += NT) { const double v = dxg[(size_t)inst * n + j]; ux[j] = v; rx[j] = 0.0; acc = fma(v, v, acc); }
     for (int i = tid; i < m; i += NT) { ty[i] = dyg[(size_t)inst * m + i]; ry[i] = 0.0; }
     __syncthreads();
-    dproj(ty, uy);
-    const double bnorm = nrm2(ux, uy);
-    double beta = bnorm;
-    for (int j = tid; j < n; j += NT) ux[j] /= safe(beta);
-    for (int i = tid; i < m; i += NT) uy[i] /= safe(beta);
+    dproj(ty, 1.0, [&](int i, double o) { uy[i] = o; acc = fma(o, o, acc); });
+    const double bnorm = sqrt(sum_all(acc));
+    double beta = bnorm, ib = 1.0 / safe(beta);
+    // u <- u / beta ;  q = DPi(uy) ;  (vx, vy) = N^T u
+    for (int j = tid; j < n; j += NT) ux[j] *= ib;
+    dproj(uy, ib, [&](int i, double o) { qv[i] = o; });
+    for (int i = tid; i < m; i += NT) uy[i] *= ib;       // (every read of uy by dproj is behind one of its barriers, or by the row's own thread)
     __syncthreads();
-    // (vx, vy) = N^T u :  q = DPi(uy);  vx = A^T q;  vy = -A ux - q + uy
-    dproj(uy, qv);
-    AT_times(qv, [&](int j, double a) { vx[j] = a; });
-    A_times(ux, [&](int i, double a) { vy[i] = -a - qv[i] + uy[i]; });
+    acc = 0;
+    both_products(qv, ux, [&](int j, double a) { vx[j] = a; acc = fma(a, a, acc); },
+                  [&](int i, double a) { const double v = -a - qv[i] + uy[i]; vy[i] = v; acc = fma(v, v, acc); });
+    double alfa = sqrt(sum_all(acc));
+    {
+        const double ia = 1.0 / safe(alfa);
+        for (int j = tid; j < n; j += NT) { const double v = vx[j] * ia; vx[j] = v; wx[j] = v; }
+        for (int i = tid; i < m; i += NT) { const double v = vy[i] * ia; vy[i] = v; wy[i] = v; }
+    }
     __syncthreads();
-    double alfa = nrm2(vx, vy);
-    for (int j = tid; j < n; j += NT) { vx[j] /= safe(alfa); wx[j] = vx[j]; }
-    for (int i = tid; i < m; i += NT) { vy[i] /= safe(alfa); wy[i] = vy[i]; }
-    __syncthreads();
-    double rhobar = alfa, phibar = beta, anorm = 0, ddnorm = 0, xxnorm = 0, zz = 0, cs2 = -1, sn2 = 0;
+    double rhobar = alfa, phibar = beta, anorm = 0, xxnorm = 0, zz = 0, cs2 = -1, sn2 = 0;
     bool live = bnorm > 0 && alfa * beta > 0;
     int itn = 0;
     while (live && itn < itn_lim) {
         itn++;
-        // (tx, ty) = N v :  tx = -A^T vy ;  ty = DPi(A vx - vy) + vy
-        AT_times(vy, [&](int j, double a) { tx[j] = -a; });
-        A_times(vx, [&](int i, double a) { ty[i] = a - vy[i]; });
-        __syncthreads();
-        dproj(ty, ty);
-        for (int j = tid; j < n; j += NT) ux[j] = tx[j] - alfa * ux[j];
-        for (int i = tid; i < m; i += NT) uy[i] = ty[i] + vy[i] - alfa * uy[i];
-        __syncthreads();
-        beta = nrm2(ux, uy);
-        for (int j = tid; j < n; j += NT) ux[j] /= safe(beta);
-        for (int i = tid; i < m; i += NT) uy[i] /= safe(beta);
-        __syncthreads();
+        // (tx, ty) = N v :  tx = -A^T vy ;  ty = DPi(A vx - vy) + vy ;   u-hat = t - alfa u
+        acc = 0;
+        both_products(vy, vx, [&](int j, double a) { const double v = -a - alfa * ux[j]; ux[j] = v; acc = fma(v, v, acc); },
+                      [&](int i, double a) { ty[i] = a - vy[i]; });
+        dproj(ty, 1.0, [&](int i, double o) { const double v = o + vy[i] - alfa * uy[i]; uy[i] = v; acc = fma(v, v, acc); });
+        beta = sqrt(sum_all(acc));
+        ib = 1.0 / safe(beta);
         anorm = sqrt(anorm * anorm + alfa * alfa + beta * beta);
-        // (tx, ty) = N^T u
-        dproj(uy, qv);
-        AT_times(qv, [&](int j, double a) { tx[j] = a; });
-        A_times(ux, [&](int i, double a) { ty[i] = -a - qv[i] + uy[i]; });
+        // u = u-hat / beta ;  q = DPi(uy) ;  (tx, ty) = N^T u ;  v-hat = t - beta v
+        for (int j = tid; j < n; j += NT) ux[j] *= ib;
+        dproj(uy, ib, [&](int i, double o) { qv[i] = o; });
+        for (int i = tid; i < m; i += NT) uy[i] *= ib;
         __syncthreads();
-        for (int j = tid; j < n; j += NT) vx[j] = tx[j] - beta * vx[j];
-        for (int i = tid; i < m; i += NT) vy[i] = ty[i] - beta * vy[i];
-        __syncthreads();
-        alfa = nrm2(vx, vy);
+        acc = 0;
+        both_products(qv, ux, [&](int j, double a) { const double v = a - beta * vx[j]; vx[j] = v; acc = fma(v, v, acc); },
+                      [&](int i, double a) { const double v = -a - qv[i] + uy[i] - beta * vy[i]; vy[i] = v; acc = fma(v, v, acc); });
+        alfa = sqrt(sum_all(acc));
         const double rho = sqrt(rhobar * rhobar + beta * beta);
         const double cs_ = rhobar / safe(rho), sn = beta / safe(rho);
         const double theta = sn * alfa; rhobar = -cs_ * alfa; const double phi = cs_ * phibar; phibar = sn * phibar; const double tau = sn * phi;
-        const double t1 = phi / safe(rho), t2 = -theta / safe(rho);
-        double rw[1] = {0};
-        for (int j = tid; j < n; j += NT) { vx[j] /= safe(alfa); const double w = wx[j]; rw[0] = fma(w, w, rw[0]); rx[j] += t1 * w; wx[j] = vx[j] + t2 * w; }
-        for (int i = tid; i < m; i += NT) { vy[i] /= safe(alfa); const double w = wy[i]; rw[0] = fma(w, w, rw[0]); ry[i] += t1 * w; wy[i] = vy[i] + t2 * w; }
-        block_reduce<1>(rw, 0u, red);
-        ddnorm += rw[0] / safe(rho * rho);
+        const double t1 = phi / safe(rho), t2 = -theta / safe(rho), ia = 1.0 / safe(alfa);
+        for (int j = tid; j < n; j += NT) { const double v = vx[j] * ia, w = wx[j]; vx[j] = v; rx[j] += t1 * w; wx[j] = v + t2 * w; }
+        for (int i = tid; i < m; i += NT) { const double v = vy[i] * ia, w = wy[i]; vy[i] = v; ry[i] += t1 * w; wy[i] = v + t2 * w; }
+        __syncthreads();
         const double delta = sn2 * rho, gambar = -cs2 * rho, rhs = phi - delta * zz, zbar = rhs / safe(fabs(gambar)) * (gambar > 0 ? 1.0 : (gambar < 0 ? -1.0 : 0.0));
         const double xnorm = sqrt(xxnorm + zbar * zbar);
         const double gamma = sqrt(gambar * gambar + theta * theta);

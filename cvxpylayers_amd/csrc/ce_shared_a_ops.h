@@ -12,12 +12,13 @@ struct SaSplit {
     const int *drow, *srow_col;
     const double *srow_val;
     const int *scol_ptr, *scol_row;
+    const int *rowslot;          // [m] slot a of a dense row, -1 otherwise
 };
 
 // out[a] = sum_j AdT[j][a] xin[j]  (a < RP).  Thread (a-pair, g) sums rows j = g, g + ng, ... with eight 16-byte loads in flight (RP / 2 lanes
 // cover a row: a wave reads whole rows, 1 KB per instruction); partials through `part` (2 NTH doubles of LDS).  Ends synchronised.
 template <int NTH, int RP>
-__device__ __forceinline__ void sa_dense_times(const double *__restrict__ AdT, int n, const double *xin, double *part, double *out) {
+__device__ __forceinline__ void sa_dense_partials(const double *__restrict__ AdT, int n, const double *xin, double *part) {
     constexpr int HP = RP / 2, ng = NTH / HP;
     const int tid = threadIdx.x, a2 = tid % HP, g = tid / HP;
     const double2 *base = reinterpret_cast<const double2 *>(AdT) + a2;
@@ -29,9 +30,14 @@ __device__ __forceinline__ void sa_dense_times(const double *__restrict__ AdT, i
 #pragma unroll
         for (int u = 0; u < 8; u++) { acc[u & 1].x = fma(mv[u].x, xv[u], acc[u & 1].x); acc[u & 1].y = fma(mv[u].y, xv[u], acc[u & 1].y); }
     }
-    reinterpret_cast<double2 *>(part)[tid] = double2{acc[0].x + acc[1].x, acc[0].y + acc[1].y};      // part[g][a]: g * RP + 2 a2 (+1)
+    reinterpret_cast<double2 *>(part)[tid] = double2{acc[0].x + acc[1].x, acc[0].y + acc[1].y};      // part[g][a]: g * RP + 2 a2 (+1), g < 2 NTH / RP
+}
+template <int NTH, int RP>
+__device__ __forceinline__ void sa_dense_times(const double *__restrict__ AdT, int n, const double *xin, double *part, double *out) {
+    constexpr int ng = 2 * NTH / RP;
+    sa_dense_partials<NTH, RP>(AdT, n, xin, part);
     __syncthreads();
-    if (tid < RP) { double s_ = 0; for (int gg = 0; gg < ng; gg++) s_ += part[gg * RP + tid]; out[tid] = s_; }
+    if (threadIdx.x < RP) { double s_ = 0; for (int gg = 0; gg < ng; gg++) s_ += part[gg * RP + threadIdx.x]; out[threadIdx.x] = s_; }
     __syncthreads();
 }
 

@@ -693,7 +693,7 @@ int ce_vjp_shared_a(ce_handle h, int B, const double *A_vals0, const double *x, 
         attr_done = true;
     }
     SaStruct S{h->d_csc_ptr, h->d_rowidx, h->d_csr_ptr, h->d_csr_col, h->d_csr_src, T.nnzA};
-    SaSplit F{h->sp_r, RP, h->d_sp_AdT, h->d_sp_drow, h->d_sp_srow_col, h->d_sp_sval, h->d_sp_scol_ptr, h->d_sp_scol_row};
+    SaSplit F{h->sp_r, RP, h->d_sp_AdT, h->d_sp_drow, h->d_sp_srow_col, h->d_sp_sval, h->d_sp_scol_ptr, h->d_sp_scol_row, h->d_sp_rowslot};
     if (RP > 0) {      // the values may differ between calls: refill A_d^T / singleton values from this call's A (n RP + m doubles)
         HIPCHK(hipMemsetAsync(h->d_sp_AdT, 0, sizeof(double) * (size_t)T.n * RP, (hipStream_t)stream));
         HIPCHK(hipMemsetAsync(h->d_sp_sval, 0, sizeof(double) * T.m, (hipStream_t)stream));

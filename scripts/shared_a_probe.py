@@ -54,10 +54,11 @@ for name in (want or ["torch", "k512", "k256", "default"]):
     eng = ctx.engine(dev)
     out = dict(variant=name, cfg=cfg, B=B, fwd_ms=tf * 1e3, bwd_ms=tb * 1e3, iters_mean=float(info["iters"].float().mean()), solved=float((info["status"] == 1).float().mean()),
                fwd_kernel=getattr(eng, "last_const_a_kernel", None), lsqr_iters=(float(eng.last_lsqr_iters.float().mean()) if getattr(eng, "last_lsqr_iters", None) is not None else None))
-    x = p.detach(); g = q_t.grad.detach()
-    if ref is None: ref = (x.clone(), g.clone())
+    x = p.detach(); g = q_t.grad.detach(); gA = A_t.grad.detach()
+    out["gq_max"] = float(g.abs().max()); out["gA_max"] = float(gA.abs().max())
+    if ref is None: ref = (x.clone(), g.clone(), gA.clone())
     else:
-        out["dx_max"] = float((x - ref[0]).abs().max()); out["dgrad_rel"] = float((g - ref[1]).abs().max() / (1 + ref[1].abs().max()))
+        out["dx_max"] = float((x - ref[0]).abs().max()); out["dgq_rel"] = float((g - ref[1]).abs().max() / (1e-300 + ref[1].abs().max())); out["dgA_rel"] = float((gA - ref[2]).abs().max() / (1e-300 + ref[2].abs().max()))
     eng.last_lsqr_iters = None
     print(json.dumps(out), flush=True); res.append(out)
 os.makedirs("gpurun_out/sap", exist_ok=True)
