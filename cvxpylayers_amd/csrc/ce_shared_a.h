@@ -42,40 +42,43 @@ __device__ __forceinline__ void sa_spmv(const int *__restrict__ ptr, const int *
     }
 }
 
-// LDS doubles: [split products: 2 RP + 2 NT] + 7 m + 5 n + 5 nq + ns (4 KP (KP + 1) + 2 KP + 8) + NW * 8 + 16
-__host__ __device__ inline size_t sa_lsqr_lds_doubles(int n, int m, int nq, int ns, int maxs, int RP) {
+// LDS doubles.  nvv: rows in front of the first PSD block (v = y - s is kept for those only; PSD blocks read y - s once, at the start).
+// The partial sums of the dense-row products (2 NT doubles) share the PSD scratch matrices when the template has PSD blocks.
+__host__ __device__ inline size_t sa_lsqr_lds_doubles(int n, int m, int nq, int ns, int maxs, int RP, int nvv) {
     const int kp = ns > 0 ? psd_mfma_kp(maxs) : 0;
-    return (size_t)(RP > 0 ? 2 * RP + 2 * NT : 0) + 7 * (size_t)m + 5 * (size_t)n + 5 * (size_t)(nq > 0 ? nq : 1) + 1 +
-           (size_t)(ns > 0 ? (2 * ns + 2) * kp * (kp + 1) + 2 * kp + 8 : 0) + NW * 8 + 16;
+    return (size_t)(RP > 0 ? 2 * RP + (ns > 0 ? 0 : 2 * NT) : 0) + (size_t)(ns > 0 ? (2 * ns + 2) * kp * (kp + 1) + 2 * kp + 8 : 0) + NW * 8 +
+           (size_t)(nvv + (nvv & 1)) + 6 * (size_t)m + 4 * (size_t)n + 5 * (size_t)(nq > 0 ? nq : 1) + 16;
 }
 
 // RP > 0: A is applied through its split into singleton rows and r <= RP dense rows (ce_shared_a_ops.h: balanced, wide loads); RP == 0: through
 // the CSR / CSC structure (any sparsity pattern, but rows of very different lengths serialise on the longest).
 template <int RP>
-__global__ void __launch_bounds__(NT)
+__global__ void __launch_bounds__(NT, 3)
 k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, const double *__restrict__ xg, const double *__restrict__ yg,
           const double *__restrict__ sg, const double *__restrict__ dxg, const double *__restrict__ dyg, double *__restrict__ dAo,
           double *__restrict__ dqo, long sdqk, long sdqb, int *__restrict__ adj_status, int *__restrict__ iters_o, double atol, double btol, int itn_lim) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int tid = threadIdx.x, inst = blockIdx.x;
     const int n = T.n, m = T.m, z = T.z, nl = T.l, nq = T.nq, ns = T.ns;
-    double *p = sm;
-    double *wyd = p, *vd = p, *part = p;                     // split products: 16-byte aligned at the start of the carve
-    if constexpr (RP > 0) { wyd = p; p += RP; vd = p; p += RP; part = p; p += 2 * NT; }
-    double *vv = p; p += m;            // v = y - s
-    double *uy = p; p += m; double *vy = p; p += m; double *wy = p; p += m; double *ry = p; p += m; double *ty = p; p += m; double *qv = p; p += m;
-    double *ux = p; p += n; double *vx = p; p += n; double *wx = p; p += n; double *rx = p; p += n; double *tx = p; p += n;
-    double *socs = p; p += 5 * (nq > 0 ? nq : 1);          // per cone: t, |z|, case, z.h ; then h_0 per cone
     const int KP = ns > 0 ? psd_mfma_kp(T.maxs) : 0, P = KP + 1, PM = KP * P;
     const float rKP = KP > 0 ? 1.0f / (float)KP : 1.0f;
+    const int psd_first = ns > 0 ? T.soff[0] : m, nvv = psd_first + (psd_first & 1);
+    double *p = sm;                                          // (everything read with 16-byte accesses sits at the start: even sizes only)
+    double *wyd = p, *vd = p, *part = p;
+    if constexpr (RP > 0) { wyd = p; p += RP; vd = p; p += RP; if (ns == 0) { part = p; p += 2 * NT; } }
+    double *Hm = p; p += PM; double *Ym = p; p += PM;        // PSD scratch
+    if (RP > 0 && ns > 0) part = Hm;                         // partial sums of the dense-row products: 2 NT <= 2 PM doubles, used between dproj calls only
     double *Um = p; p += (size_t)ns * PM;                    // eigenvectors of smat(v_c), per cone
     double *Bm = p; p += (size_t)ns * PM;                    // divided differences, per cone
-    double *Hm = p; p += PM; double *Ym = p; p += PM;        // scratch
     double *cs = p; p += (ns > 0 ? 2 * KP + 8 : 0);
     double *red = p; p += NW * 8;
+    double *vv = p; p += nvv;          // v = y - s, rows in front of the PSD blocks
+    double *uy = p; p += m; double *vy = p; p += m; double *wy = p; p += m; double *ry = p; p += m; double *ty = p; p += m; double *qv = p; p += m;
+    double *ux = p; p += n; double *vx = p; p += n; double *wx = p; p += n; double *rx = p; p += n;
+    double *socs = p; p += 5 * (nq > 0 ? nq : 1);          // per cone: t, |z|, case, z.h ; then h_0 per cone
     const double *x = xg + (size_t)inst * n, *y = yg + (size_t)inst * m, *s = sg + (size_t)inst * m;
 
-    for (int i = tid; i < m; i += NT) vv[i] = y[i] - s[i];
+    for (int i = tid; i < psd_first; i += NT) vv[i] = y[i] - s[i];
     __syncthreads();
     // ---- per-cone data of DPi
     for (int c = tid >> 6; c < nq; c += NW) {            // one wave per cone
@@ -91,11 +94,11 @@ k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, cons
     for (int c = 0; c < ns; c++) {      // eigenvectors and divided differences of every PSD block (cold Jacobi, once)
         const int k = T.sord[c];
         double *U = Um + (size_t)c * PM, *Bc = Bm + (size_t)c * PM;
-        const double *zs = vv + T.soff[c];
+        const double *ys = y + T.soff[c], *ss = s + T.soff[c];
         for (int idx = tid; idx < KP * KP; idx += NT) {
             const int i = psd_fdiv(idx, rKP), j = idx - i * KP;
             double sv = 0.0;
-            if (i < k && j < k) { const int a = i >= j ? i : j, b = i >= j ? j : i; const double v0 = zs[b * k - (b * (b - 1)) / 2 + (a - b)]; sv = (a == b) ? v0 : v0 * M_SQRT1_2; }
+            if (i < k && j < k) { const int a = i >= j ? i : j, b = i >= j ? j : i; const int e = b * k - (b * (b - 1)) / 2 + (a - b); const double v0 = ys[e] - ss[e]; sv = (a == b) ? v0 : v0 * M_SQRT1_2; }
             Hm[i * P + j] = sv; U[i * P + j] = (i == j && i < k) ? 1.0 : 0.0;
         }
         __syncthreads();
@@ -128,8 +131,7 @@ k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, cons
             }
             __syncthreads();
         }
-        const int psd0 = ns > 0 ? T.soff[0] : m;
-        for (int i = tid; i < psd0; i += NT) {
+        for (int i = tid; i < psd_first; i += NT) {
             double o = h[i] * hs;
             if (i >= z && i < z + nl) o = (vv[i] > 0) ? o : 0.0;
             else {

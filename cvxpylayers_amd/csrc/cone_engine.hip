@@ -67,6 +67,7 @@ struct ce_engine {
     int *d_csc_ptr = nullptr, *d_csr_ptr = nullptr, *d_csr_col = nullptr, *d_csr_src = nullptr;   // sparse structure of the A part (shared-A kernels)
     // split of the A part into singleton rows and sp_r <= 64 dense rows (ce_shared_a_ops.h); sp_RP == 0: more than 64 rows with several entries
     int sp_r = 0, sp_RP = 0;
+    int psd_first = 0;           // first row of the first PSD block (m when the template has none)
     int *d_sp_drow = nullptr, *d_sp_srow_col = nullptr, *d_sp_scol_ptr = nullptr, *d_sp_scol_row = nullptr, *d_sp_rowslot = nullptr;
     double *d_sp_AdT = nullptr, *d_sp_sval = nullptr;
     bool wl = false; int wl_nq = 0; int *d_row_perm = nullptr, *d_k_rowcone = nullptr, *d_k_qoff = nullptr;   // rows packed so that cones are wave-local (k_fwd2 WL)
@@ -256,6 +257,7 @@ int ce_create(const ce_template *tpl, int device, ce_handle *out) {
     T.ns = tpl->ns; T.maxs = 0;
     for (int c = 0; c < tpl->ns; c++) { soff[c] = r; sord[c] = tpl->s[c]; T.maxs = std::max(T.maxs, tpl->s[c]); r += tpl->s[c] * (tpl->s[c] + 1) / 2; }
     soff[tpl->ns] = r;
+    h->psd_first = tpl->ns > 0 ? soff[0] : tpl->m;
     T.nep = tpl->nep; T.eoff = r; T.np = tpl->np; T.pw = nullptr;
     if (tpl->np > 0) {
         HIPCHK(hipMalloc(&h->d_pw, sizeof(double) * tpl->np));
@@ -681,8 +683,8 @@ int ce_vjp_shared_a(ce_handle h, int B, const double *A_vals0, const double *x, 
     // products through the singleton / dense-row split when the template has one (CE_SA_SPLIT=0: CSR / CSC products)
     int RP = h->sp_RP;
     if (const char *e = getenv("CE_SA_SPLIT")) { if (atoi(e) == 0) RP = 0; }
-    if (RP > 0 && sa_lsqr_lds_doubles(T.n, T.m, T.nq, T.ns, T.maxs, RP) * 8 > LDS_LIMIT) RP = 0;
-    const size_t lds = sa_lsqr_lds_doubles(T.n, T.m, T.nq, T.ns, T.maxs, RP) * 8;
+    if (RP > 0 && sa_lsqr_lds_doubles(T.n, T.m, T.nq, T.ns, T.maxs, RP, h->psd_first) * 8 > LDS_LIMIT) RP = 0;
+    const size_t lds = sa_lsqr_lds_doubles(T.n, T.m, T.nq, T.ns, T.maxs, RP, h->psd_first) * 8;
     if (lds > LDS_LIMIT) { g_err = "shared-A adjoint kernel: the LSQR vectors of one instance do not fit LDS"; return CE_E_TOO_LARGE; }
     HIPCHK(hipSetDevice(h->device));
     static bool attr_done = false;
