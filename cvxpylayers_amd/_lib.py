@@ -31,7 +31,7 @@ class CeSettings(C.Structure):
                 ("acceleration_lookback", C.c_int), ("acceleration_interval", C.c_int)]
 
 
-ABI_VERSION = 4          # include/cone_engine.h CE_ABI_VERSION this binding was written against
+ABI_VERSION = 5          # include/cone_engine.h CE_ABI_VERSION this binding was written against
 
 
 def build(force: bool = False) -> str:

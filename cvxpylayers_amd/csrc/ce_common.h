@@ -5,6 +5,7 @@
 constexpr int NT = 256;            // threads per workgroup
 constexpr int NW = NT / 64;        // waves per workgroup
 constexpr int CONVERGED_INTERVAL = 25;
+constexpr int AA_MAX_REJECT = 10;     // safeguard rejections after which Anderson acceleration is switched off for the instance (oracle/cone_oracle.c)
 constexpr int RESCALING_MIN_ITERS = 100;
 constexpr int NUM_RUIZ_PASSES = 25;
 constexpr int NUM_L2_PASSES = 1;

@@ -727,7 +727,8 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
     // every aa_int iterations, with x = input and f = output of the last iteration, g = x - f, s = x - x_prev, y = g - g_prev,
     // d = f - f_prev:  w <- f - (s.g / (s.y + 1e-8 |s||y|)) d.   The next iteration's residual is the safeguard: if it exceeds |g| the
     // step is undone and the history dropped.  Vectors (VP doubles each) live in the dynamic tail of the LDS carve.
-    const bool aa_on = S.acceleration_lookback > 0;
+    bool aa_on = S.acceleration_lookback > 0;      // cleared after AA_MAX_REJECT safeguard rejections (robustness rule, see the oracle)
+    int aa_rej = 0;
     const int aa_int = S.acceleration_interval;
     double *const aaWP = Gm + gsz + (PSD ? ((T.ns > 0 ? 2 * T.maxs * T.maxs + 2 * T.maxs + 8 : 0) + T.nep + T.np) : 0) + (HASP ? NP : 0);
     double *const aaXP = aaWP + VP, *const aaFP = aaXP + VP, *const aaFS = aaFP + VP, *const aaXS = aaFS + VP;
@@ -787,11 +788,12 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
                 if (!(uniform_d(sqrt(r[0])) <= sc[8])) {
                     if (ev) { sm[L::O_W + ve] = aaFS[ve]; aaWP[ve] = aaXS[ve]; }
                     aa_iter = 0;
+                    if (++aa_rej >= AA_MAX_REJECT) aa_on = false;
                     __syncthreads();
                 }
                 aa_pending = false;
             }
-            if (iter > 0 && iter % aa_int == 0) {
+            if (aa_on && iter > 0 && iter % aa_int == 0) {
                 const double xv = ev ? aaWP[ve] : 0.0, fv = ev ? sm[L::O_W + ve] : 0.0, gv = xv - fv;
                 if (aa_iter > 0) {
                     const double xp = ev ? aaXP[ve] : 0.0, fp = ev ? aaFP[ve] : 0.0;

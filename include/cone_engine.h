@@ -89,8 +89,8 @@ void ce_default_settings(ce_settings *s);
  * library short structs.  Bindings must check  ce_abi_version() == CE_ABI_VERSION  and  ce_struct_size(which) == sizeof(their
  * struct)  (which: 0 ce_template, 1 ce_settings) once at load time and refuse to continue otherwise (cvxpylayers_amd/_lib.py
  * does; tests/test_cabi.py checks the stub printed in INTEGRATION.md the same way).  CE_ABI_VERSION is bumped whenever a struct
- * layout or an entry point's signature changes. */
-#define CE_ABI_VERSION 4
+ * layout, an entry point's signature or the meaning of an argument changes (5: srow_col of ce_solve_shared_a marks dense rows with -2). */
+#define CE_ABI_VERSION 5
 int ce_abi_version(void);
 int ce_struct_size(int which);
 

@@ -69,6 +69,7 @@ enum { OC_SOLVED = 1, OC_SOLVED_INACCURATE = 2, OC_UNBOUNDED = -1, OC_INFEASIBLE
 #define NUM_L2_PASSES 1
 #define TAU_FACTOR 10.0
 #define CONVERGED_INTERVAL 25
+#define AA_MAX_REJECT 10      /* safeguard rejections after which Anderson acceleration is switched off for the instance */
 #define RESCALING_MIN_ITERS 100
 #define MIN_SCALE_VALUE 1e-6
 #define MAX_SCALE_VALUE 1e6
@@ -459,21 +460,24 @@ static int solve_one(int n, int m, const double *A0, const double *b0, const dou
      * (x = input of the last iteration, f = its output) extends the secant history S = [dx], Y = [dg], D = [df], g = x - f;
      * gamma = (S^T Y + r I)^-1 S^T g, r = 1e-8 |S|_F |Y|_F, and the iterate is replaced by f - D gamma.  Safeguard: if the residual
      * of the map at the accelerated point exceeds the residual before, the step is undone and the history dropped.  The history
-     * is also dropped on a rescale (the map changes) and scaled with w when w is renormalised (the map is homogeneous). */
+     * is also dropped on a rescale (the map changes) and scaled with w when w is renormalised (the map is homogeneous).
+     * Robustness rule (not in SCS): after AA_MAX_REJECT safeguard rejections the acceleration is switched off for the instance -- on slowly
+     * converging LPs most steps of a short history are rejected and the accepted ones do harm (random LP n=50 m=100: 1716 iterations plain,
+     * 5496 and 12 % unsolved at 20000 with memory 1 and no cap, 1805 with the cap; configurations where AA helps never reach the cap). */
     const int aa_mem = o->aa_mem > 0 ? o->aa_mem : 0, aa_int = o->aa_interval > 0 ? o->aa_interval : 10;
     double *aab = aa_mem > 0 ? calloc((size_t)(3 * aa_mem + 7) * l + (size_t)aa_mem * (aa_mem + 2), sizeof(double)) : NULL;
     double *aS = aab, *aY = aS ? aS + (size_t)aa_mem * l : NULL, *aD = aS ? aY + (size_t)aa_mem * l : NULL;
     double *aXp = aS ? aD + (size_t)aa_mem * l : NULL, *aFp = aS ? aXp + l : NULL, *aGp = aS ? aFp + l : NULL, *wprev = aS ? aGp + l : NULL,
            *aFsave = aS ? wprev + l : NULL, *aXsave = aS ? aFsave + l : NULL, *aG = aS ? aXsave + l : NULL, *aM = aS ? aG + l : NULL;
-    int aa_iter = 0, aa_pending = 0; double aa_normg = 0;
+    int aa_iter = 0, aa_pending = 0, aa_rej = 0, aa_live = 1; double aa_normg = 0;
     for (iter = 0; iter < o->max_iters; iter++) {
         int check = (iter % CONVERGED_INTERVAL) == 0;
         if (aa_mem > 0 && aa_pending) {      /* safeguard: residual of the map at the accelerated point */
             double dn = 0; for (int i = 0; i < l; i++) { double d = wprev[i] - w[i]; dn += d * d; } dn = sqrt(dn);
-            if (!(dn <= aa_normg)) { memcpy(w, aFsave, sizeof(double) * l); memcpy(wprev, aXsave, sizeof(double) * l); aa_iter = 0; }
+            if (!(dn <= aa_normg)) { memcpy(w, aFsave, sizeof(double) * l); memcpy(wprev, aXsave, sizeof(double) * l); aa_iter = 0; if (++aa_rej >= AA_MAX_REJECT) aa_live = 0; }
             aa_pending = 0;
         }
-        if (aa_mem > 0 && iter > 0 && iter % aa_int == 0) {
+        if (aa_mem > 0 && aa_live && iter > 0 && iter % aa_int == 0) {
             for (int i = 0; i < l; i++) aG[i] = wprev[i] - w[i];          /* x = wprev, f = w */
             if (aa_iter > 0) {
                 int idx = (aa_iter - 1) % aa_mem;

@@ -43,6 +43,16 @@ if has configs; then
   echo "== BASELINE configs" | tee -a "$OUT/summary.txt"
   timeout 900 python scripts/bench_configs.py "$OUT/configs.json" 2>&1 | grep -v amdgpu.ids | tail -12 | tee -a "$OUT/summary.txt"
 fi
+if has frontend; then
+  echo "== whole layer (frontend: parameter maps + plugin + one-launch recovery)" | tee -a "$OUT/summary.txt"
+  timeout 300 python scripts/bench_frontend.py "$OUT/frontend_layer.json" 2>&1 | grep -v amdgpu.ids | tail -4 | tee -a "$OUT/summary.txt"
+fi
+if has c5prof; then
+  echo "== C5 (portfolio n=501, shared A, B=16384): kernel trace" | tee -a "$OUT/summary.txt"
+  (cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d "$OUT/c5_prof" -o trace --output-format csv -- python "$OLDPWD/scripts/shared_a_probe.py" C5 16384 default > "$OUT/c5_prof.log" 2>&1)
+  find "$OUT/c5_prof" -name "*kernel_stats.csv" | head -1 | xargs -r head -6 | cut -c1-260 | tee -a "$OUT/summary.txt"
+  grep variant "$OUT/c5_prof.log" | tee -a "$OUT/summary.txt"
+fi
 find "$OUT" -name "*.db" -delete
 du -sh "$OUT" | tee -a "$OUT/summary.txt"
 if has c4prof; then
@@ -51,13 +61,13 @@ if has c4prof; then
   find "$OUT/c4_prof" -name "*kernel_stats.csv" | head -1 | xargs -r head -8 | tee -a "$OUT/summary.txt"
   (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_MFMA SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -d "$OUT/c4_mfma" -o p --output-format csv -- python "$OLDPWD/scripts/sdp_c4_probe.py" 1024 1e-4 > "$OUT/c4_mfma.log" 2>&1)
   python - "$OUT" <<'PY' | tee -a "$OUT/summary.txt"
-import csv, glob, collections, json, os, sys
+import csv, glob, collections, json, os, re, sys
 out = sys.argv[1]
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(out, "c4_mfma", "**", "*counter_collection.csv"), recursive=True):
     per = collections.defaultdict(lambda: collections.defaultdict(float)); names = {}
     for r in csv.DictReader(open(f)):
-        per[r["Dispatch_Id"]][r["Counter_Name"]] += float(r["Counter_Value"]); names[r["Dispatch_Id"]] = r["Kernel_Name"].split("(")[0].split("<")[0][-40:]
+        per[r["Dispatch_Id"]][r["Counter_Name"]] += float(r["Counter_Value"]); mm = re.search(r"\bk_\w+", r["Kernel_Name"]); names[r["Dispatch_Id"]] = mm.group(0) if mm else r["Kernel_Name"][:40]
     for d, cs in per.items():
         for c, v in cs.items(): agg[names[d]][c].append(v)
 res = {}
