@@ -75,9 +75,10 @@ for k, cs in agg.items():
     if not any(t in k for t in ("k_sa_", "k_ca_", "k_fwd2", "k_backward")): continue
     s = {c: sum(v) / len(v) for c, v in cs.items()}
     s["launches"] = max(len(v) for v in cs.values())
-    # SQ_VALU_MFMA_BUSY_CYCLES counts cycles per SIMD summed over the sampled SIMDs; the same sampling applies to SQ_BUSY_CYCLES (per SQ = per CU group);
-    # the ratio MFMA-busy / (4 SIMDs x CU-busy) is the share of SIMD time with the matrix pipe busy
-    if s.get("SQ_BUSY_CYCLES"): s["mfma_busy_share_of_simd_time"] = s.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (4.0 * s["SQ_BUSY_CYCLES"])
+    # GRBM_GUI_ACTIVE is summed over the 8 XCDs, SQ_VALU_MFMA_BUSY_CYCLES over the 1024 SIMDs of the device: busy share of one SIMD =
+    # MFMA-busy / (1024 x kernel cycles); flops: SQ_INSTS_MFMA x 2048 (v_mfma_f64_16x16x4_f64)
+    if s.get("GRBM_GUI_ACTIVE"): s["kernel_cycles"] = s["GRBM_GUI_ACTIVE"] / 8; s["mfma_util_per_simd"] = s.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024 * s["kernel_cycles"])
+    s["mfma_f64_flops_per_launch"] = s.get("SQ_INSTS_MFMA", 0.0) * 2048
     if s.get("SQ_WAVE_CYCLES"): s["valu_busy_share_of_wave_time"] = s.get("SQ_ACTIVE_INST_VALU", 0.0) / s["SQ_WAVE_CYCLES"]
     res[k] = s
 print(json.dumps(res, indent=1))
