@@ -50,6 +50,7 @@ def cpu_baseline(n, cones, solver_args, sample, seed, budget_s=12.0):
         if dt >= budget_s or passes >= 200:
             break
     return dict(value=done / dt, unit="problems/s", cores=threads, kind="port",
+                note="own port, untuned: this repository's plain-C + OpenMP restatement of the SCS / diffcp algorithms (oracle/), not SCS / diffcp themselves",
                 sample=f"{passes} passes over {sample} instances of the same workload (forward + LSQR adjoint, diffcp's default mode), {dt:.1f} s of wall time",
                 mean_iters=float(r["iters"].mean()), mean_lsqr_iters=float(g["lsqr_iters"].mean()))
 
