@@ -32,7 +32,7 @@ struct SaFwd {
 __host__ __device__ inline size_t sa_fwd_lds_doubles(int n, int m, int nq, int ns, int maxs, int RP, int nth) {
     const int l = n + m + 1, lp = l + (l & 1), ne = n + (n & 1), me = m + (m & 1);
     const int kp = ns > 0 ? psd_mfma_kp(maxs) : 0;
-    return 6 * (size_t)lp + 3 * (size_t)ne + 2 * (size_t)me + (size_t)RP * (RP + 1) + 4 * (size_t)RP + 2 * (size_t)(nq > 0 ? nq : 1) +
+    return 6 * (size_t)lp + 3 * (size_t)ne + 2 * (size_t)me + 2 * (size_t)RP * (RP + 1) + 5 * (size_t)RP + 2 * (size_t)(nq > 0 ? nq : 1) +
            (size_t)(ns > 0 ? (ns + 2) * kp * (kp + 1) + 2 * kp + 8 : 0) + 2 * nth + (nth / 64) * 8 + 32;
 }
 
@@ -55,7 +55,8 @@ k_sa_fwd(DevT T, SaFwd F, ce_settings S, const double *__restrict__ BHg, const d
     double *tv = p; p += ne; double *px = p; p += ne; double *dgi = p; p += ne;
     double *qy = p; p += me; double *bh = p; p += me;
     double *Kinv = p; p += (size_t)RP * LK;
-    double *vd = p; p += RP; double *zd = p; p += RP; double *wyd = p; p += RP; double *dyd = p; p += RP;
+    double *K0 = p; p += (size_t)RP * LK;                   // A_d Dg^-1 A_d^T (kept next to its regularised inverse: see the iteration)
+    double *vd = p; p += RP; double *zd = p; p += RP; double *wyd = p; p += RP; double *dyd = p; p += 2 * RP;      // dyd[RP ..]: w_d + z of the iteration
     double *socc = p; p += 2 * (nq > 0 ? nq : 1);
     const int KP = ns > 0 ? psd_mfma_kp(T.maxs) : 0, PM = KP * (KP + 1);
     double *Vst = p; p += (size_t)ns * PM;                 // eigenvectors of every PSD block, kept between iterations
@@ -122,6 +123,7 @@ k_sa_fwd(DevT T, SaFwd F, ce_settings S, const double *__restrict__ BHg, const d
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     const int row = 16 * ti + lg + 4 * q, col = 16 * tj + lc;
+                    K0[row * LK + col] = acc[q];
                     Kinv[row * LK + col] = acc[q] + (row == col ? (row < r ? 1.0 / dyd[row] : 1.0) : 0.0);
                 }
             }
@@ -202,10 +204,38 @@ k_sa_fwd(DevT T, SaFwd F, ce_settings S, const double *__restrict__ BHg, const d
                 rt = wave_reduce_dpp<false>(rt);
                 if ((tid & 63) == 0) red[tid >> 6] = rt;
             }
-            // t = rho w_x - A^T w_y ;  u = Dg^-1 t ;  p_x = S^-1 t
-            AT_times(W + n, [&](int j, double a) { px[j] = (rho_x * W[j] - a) * dgi[j]; });
-            // q = A p_x :  the dense rows are Dd^-1 zd  (A_d p_x = A_d u - A_d Dg^-1 A_d^T zd = K zd - (K - Dd^-1) zd); singleton rows: a gather below
-            wood_u(px);
+            // p_x = S^-1 t,  t = rho w_x - A^T w_y,  with TWO passes over the shared dense rows instead of three.  Split t by the two row classes:
+            //   t' = Dg^-1 (rho w_x - A_s^T w_y)  (singleton rows: a gather),   u = Dg^-1 t = t' - Dg^-1 A_d^T w_d,   w_d = the dense rows of w_y.
+            //   A_d u = A_d t' - K0 w_d,  K0 = A_d Dg^-1 A_d^T (r x r, in LDS since the factorisation)        -> one pass  (A_d t')
+            //   z = K^-1 A_d u ;   p_x = u - Dg^-1 A_d^T z = t' - Dg^-1 A_d^T (w_d + z)                        -> one pass  (A_d^T (w_d + z))
+            for (int a = tid; a < RP; a += NT) wyd[a] = a < r ? W[n + F.drow[a]] : 0.0;
+            for (int j = tid; j < n; j += NT) {
+                double acc = rho_x * W[j];
+                for (int k = F.scol_ptr[j]; k < F.scol_ptr[j + 1]; k++) { const int i = F.scol_row[k]; acc = fma(-F.srow_val[i], W[n + i], acc); }
+                px[j] = acc * dgi[j];
+            }
+            __syncthreads();
+            sa_dense_partials<NT, RP>(F.AdT, n, px, part);
+            for (int a = tid >> 3; a < RP; a += NT / 8) {       // K0 w_d : eight lanes per row
+                const double *kr = K0 + a * LK;
+                double s_ = 0;
+                for (int b = tid & 7; b < r; b += 8) s_ = fma(kr[b], wyd[b], s_);
+                s_ = group_reduce<8, false>(s_);
+                if ((tid & 7) == 0) zd[a] = s_;
+            }
+            __syncthreads();
+            if (tid < RP) { constexpr int ng = 2 * NT / RP; double s_ = -zd[tid]; for (int gg = 0; gg < ng; gg++) s_ += part[gg * RP + tid]; vd[tid] = s_; }      // A_d u
+            __syncthreads();
+            for (int a = tid >> 3; a < RP; a += NT / 8) {       // z = K^-1 (A_d u)
+                const double *kr = Kinv + a * LK;
+                double s_ = 0;
+                for (int b = tid & 7; b < r; b += 8) s_ = fma(kr[b], vd[b], s_);
+                s_ = group_reduce<8, false>(s_);
+                if ((tid & 7) == 0) { const double zv = a < r ? s_ : 0.0; zd[a] = zv; dyd[RP + a] = wyd[a] + zv; }
+            }
+            __syncthreads();
+            sa_rows_dot<NT, RP>(F.AdT, n, dyd + RP, [&](int, int) { return 0.0; }, [&](int j, double a) { px[j] -= dgi[j] * a; });
+            __syncthreads();
             for (int a = tid; a < r; a += NT) qy[F.drow[a]] = zd[a] / dyd[a];
             double rts = 0;
 #pragma unroll
