@@ -183,10 +183,9 @@ k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, cons
         if constexpr (RP > 0) {
             for (int a = tid; a < RP; a += NT) wyd[a] = a < F.r ? yin[F.drow[a]] : 0.0;
             __syncthreads();
-            sa_rows_dot<NT, RP>(F.AdT, n, wyd,
-                                [&](int j, int k8) { double acc = 0; for (int k = F.scol_ptr[j] + k8; k < F.scol_ptr[j + 1]; k += 8) { const int i = F.scol_row[k]; acc = fma(F.srow_val[i], yin[i], acc); } return acc; },
-                                fx);
-            sa_dense_partials<NT, RP>(F.AdT, n, xin, part);
+            sa_fused_pass<NT, RP>(F.AdT, n, wyd, xin,
+                                  [&](int j, int k8) { double acc = 0; for (int k = F.scol_ptr[j] + k8; k < F.scol_ptr[j + 1]; k += 8) { const int i = F.scol_row[k]; acc = fma(F.srow_val[i], yin[i], acc); } return acc; },
+                                  fx, part);
             __syncthreads();
             for (int i = tid; i < m; i += NT) {
                 const int c = F.srow_col[i];
@@ -194,7 +193,10 @@ k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, cons
                 else {
                     const int a = F.rowslot[i];                  // slot of a dense row, -1: empty row
                     double s_ = 0;
-                    if (a >= 0) { constexpr int ng = 2 * NT / RP; for (int gg = 0; gg < ng; gg++) s_ += part[gg * RP + a]; }
+                    if (a >= 0) {
+#pragma unroll
+                        for (int w = 0; w < NW; w++) s_ += part[w * RP + a];
+                    }
                     fy(i, s_);
                 }
             }

@@ -71,6 +71,53 @@ __device__ __forceinline__ void sa_rows_dot(const double *__restrict__ AdT, int 
     }
 }
 
+// Both directions from ONE stream over A_d^T:  out(j, sum_a AdT[j][a] w[a] + extra) for every j  AND  the partial sums of
+// v[a] = sum_j AdT[j][a] xin[j]:  part[wave * RP + a], to be summed over the NTH / 64 waves by the caller after a barrier.  Lane layout of
+// sa_rows_dot (eight lanes per row, lane k holds a = 16 i + 2 k, 16 i + 2 k + 1); every lane accumulates its 2 RP / 16 entries of v over the
+// rows it visits, the eight row groups of a wave are folded with three shuffles per entry.  No trailing barrier.
+template <int NTH, int RP, class FE, class FO>
+__device__ __forceinline__ void sa_fused_pass(const double *__restrict__ AdT, int n, const double *w, const double *xin, FE &&extra, FO &&out, double *part) {
+    constexpr int NL = RP / 16, RS = NTH / 8, UR = RP == 64 ? 2 : 4;      // rows in flight per lane (RP = 64: two, the accumulators need the registers)
+    const int tid = threadIdx.x, k8 = tid & 7;
+    const double2 *w2 = reinterpret_cast<const double2 *>(w) + k8;
+    double2 vacc[NL];
+#pragma unroll
+    for (int i = 0; i < NL; i++) vacc[i] = double2{0.0, 0.0};
+    for (int j0 = tid >> 3; j0 < n; j0 += UR * RS) {
+        double2 rv[UR][NL];
+#pragma unroll
+        for (int u = 0; u < UR; u++) {
+            const int j = j0 + u * RS, jc = j < n ? j : n - 1;
+            const double2 *row = reinterpret_cast<const double2 *>(AdT + (size_t)jc * RP) + k8;
+#pragma unroll
+            for (int i = 0; i < NL; i++) rv[u][i] = row[8 * i];
+        }
+#pragma unroll
+        for (int u = 0; u < UR; u++) {
+            const int j = j0 + u * RS;
+            const bool ok = j < n;
+            const double xv = ok ? xin[j] : 0.0;
+            double a0 = ok ? extra(j, k8) : 0.0, a1 = 0;
+#pragma unroll
+            for (int i = 0; i < NL; i++) {
+                const double2 wv = w2[8 * i];
+                a0 = fma(rv[u][i].x, wv.x, a0); a1 = fma(rv[u][i].y, wv.y, a1);
+                vacc[i].x = fma(rv[u][i].x, xv, vacc[i].x); vacc[i].y = fma(rv[u][i].y, xv, vacc[i].y);
+            }
+            const double acc = group_reduce<8, false>(a0 + a1);
+            if (ok && k8 == 0) out(j, acc);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NL; i++) {
+        double vx = vacc[i].x, vy = vacc[i].y;
+        vx += __shfl_xor(vx, 8); vy += __shfl_xor(vy, 8);
+        vx += __shfl_xor(vx, 16); vy += __shfl_xor(vy, 16);
+        vx += __shfl_xor(vx, 32); vy += __shfl_xor(vy, 32);
+        if ((tid & 63) < 8) reinterpret_cast<double2 *>(part + (tid >> 6) * RP)[8 * i + k8] = double2{vx, vy};
+    }
+}
+
 // y = A x :  out(i, value) for every row i.  vd: RP doubles, part: 2 NTH doubles of LDS.  Ends synchronised.
 template <int NTH, int RP, class ST, class FO>
 __device__ __forceinline__ void sa_A_times(const ST &F, int n, int m, const double *xin, double *part, double *vd, FO &&out) {
