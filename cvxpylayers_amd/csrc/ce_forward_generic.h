@@ -1,5 +1,71 @@
 // ce_forward_generic.h -- size-generic LDS/L2-resident forward kernel (fallback path)
 #pragma once
+// ------------------------------------------------------------------------------------------------
+// Products with a matrix that lives in GLOBAL memory (L2 / HBM workspace; residency modes 1 and 2).  The LDS versions of
+// ce_common.h walk a row per thread (conflict-free in LDS, but 64 different cache lines per load instruction in global memory) with two
+// loads in flight; here lanes walk along rows (whole 128-byte lines per 16-lane group), UNR loads are in flight per lane, and the
+// partial-sum layout stays the one sum_parts() reads.
+// out indexed by COLUMN:  part[ch][j] = sum_{i in chunk ch} Mat[i][j] v[i]
+template <int UNR = 16>
+__device__ __forceinline__ void mv_cols_g(const double *__restrict__ Mat, int ld, int rows, int cols, const double *v, double *part) {
+    const int CH = chunks_for(cols);
+    const int len = (rows + CH - 1) / CH;
+    for (int idx = threadIdx.x; idx < cols * CH; idx += NT) {
+        const int j = idx % cols, ch = idx / cols;
+        const int i0 = ch * len, i1 = min(rows, i0 + len);
+        double a0 = 0, a1 = 0;
+        for (int i = i0; i < i1; i += UNR) {
+            double mv[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; u++) { const int ii = i + u < i1 ? i + u : i1 - 1; mv[u] = Mat[(size_t)ii * ld + j]; }
+#pragma unroll
+            for (int u = 0; u < UNR; u++) { const double x = i + u < i1 ? v[i + u] : 0.0; if (u & 1) a1 = fma(mv[u], x, a1); else a0 = fma(mv[u], x, a0); }
+        }
+        part[ch * cols + j] = a0 + a1;
+    }
+}
+// out indexed by ROW:  part[0][i] = sum_j Mat[i][j] v[j]  (sixteen lanes per row, DPP reduction; the other chunks of sum_parts() are zeroed)
+template <int UNR = 8>
+__device__ __forceinline__ void mv_rows_g(const double *__restrict__ Mat, int ld, int rows, int cols, const double *v, double *part) {
+    const int c16 = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    for (int i0 = 0; i0 < rows; i0 += NT / 16) {            // uniform trip count (the DPP reduction needs whole rows of lanes)
+        const int i = i0 + rg;
+        const bool ok = i < rows;
+        const double *r = Mat + (size_t)(ok ? i : rows - 1) * ld;
+        double a0 = 0, a1 = 0;
+        for (int j = c16; j < cols; j += 16 * UNR) {
+            double mv[UNR];
+#pragma unroll
+            for (int u = 0; u < UNR; u++) { const int jj = j + 16 * u; mv[u] = r[jj < cols ? jj : cols - 1]; }
+#pragma unroll
+            for (int u = 0; u < UNR; u++) { const int jj = j + 16 * u; const double x = jj < cols ? v[jj] : 0.0; if (u & 1) a1 = fma(mv[u], x, a1); else a0 = fma(mv[u], x, a0); }
+        }
+        const double a = group_reduce<16, false>(a0 + a1);
+        if (ok && c16 == 0) part[i] = a;
+    }
+    const int CH = chunks_for(rows);
+    for (int idx = threadIdx.x + rows; idx < CH * rows; idx += NT) part[idx] = 0.0;
+}
+// row norms of a global-memory matrix (max |.| or sum of squares), same lane layout: part[i], other chunks untouched (callers read part[i] only)
+__device__ __forceinline__ void row_norms_g(const double *__restrict__ Mat, int ld, int rows, int cols, bool l2, double *part) {
+    const int c16 = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    for (int i0 = 0; i0 < rows; i0 += NT / 16) {
+        const int i = i0 + rg;
+        const bool ok = i < rows;
+        const double *r = Mat + (size_t)(ok ? i : rows - 1) * ld;
+        double a = 0;
+        for (int j = c16; j < cols; j += 16 * 8) {
+            double mv[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const int jj = j + 16 * u; mv[u] = jj < cols ? r[jj] : 0.0; }
+#pragma unroll
+            for (int u = 0; u < 8; u++) a = l2 ? fma(mv[u], mv[u], a) : fmax(a, fabs(mv[u]));
+        }
+        a = l2 ? group_reduce<16, false>(a) : group_reduce<16, true>(a);
+        if (ok && c16 == 0) part[i] = a;
+    }
+}
+
 // ================================================================================================
 // FORWARD
 // ================================================================================================
@@ -34,6 +100,11 @@ k_forward(DevT T, ce_settings S, const double *__restrict__ Avals, const double 
     double *wpart = p; p += NW;  // per-wave partials of phi . w
     double *sc = p; p += 2 * n;  // refactor() right-hand sides (keeps u / ut intact across a rescale)
 
+    // products with A / G: LDS-resident -> ce_common.h, global-memory-resident -> the coalesced versions above
+    auto AT_times = [&](const double *v, double *out) { if constexpr (A_LDS) mv_cols_partial(A, lda, m, n, v, out); else mv_cols_g(A, lda, m, n, v, out); };
+    auto A_times = [&](const double *v, double *out) { if constexpr (A_LDS) mv_rows_partial(A, lda, m, n, v, out); else mv_rows_g(A, lda, m, n, v, out); };
+    auto G_times = [&](const double *v, double *out) { if constexpr (G_LDS) mv_cols_partial(G, ldg, n, n, v, out); else mv_cols_g(G, ldg, n, n, v, out); };
+
     // ---------------------------------------------------------------- load
     load_instance(T, Avals + (size_t)inst * T.nnz_aug, A, bv);
     for (int j = tid; j < n; j += NT) { cv[j] = qv[j * sqk + inst * sqb]; Ev[j] = 1.0; }
@@ -52,6 +123,23 @@ k_forward(DevT T, ce_settings S, const double *__restrict__ Avals, const double 
     if (S.normalize) {
         for (int pass = 0; pass < NUM_RUIZ_PASSES + NUM_L2_PASSES; pass++) {
             const bool l2 = pass >= NUM_RUIZ_PASSES;
+            if constexpr (!A_LDS) {   // A in global memory: lanes along the rows, several loads in flight (see mv_rows_g / mv_cols_g)
+                row_norms_g(A, lda, m, n, l2, part);
+                { const int CH = chunks_for(m); for (int idx = tid + m; idx < CH * m; idx += NT) part[idx] = 0.0; }
+                const int CH2 = chunks_for(n), len2 = (m + CH2 - 1) / CH2;
+                for (int idx = tid; idx < n * CH2; idx += NT) {
+                    const int j = idx % n, ch = idx / n, i0 = ch * len2, i1 = min(m, i0 + len2);
+                    double a = 0;
+                    for (int i = i0; i < i1; i += 8) {
+                        double mv[8];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) mv[u] = i + u < i1 ? A[(size_t)(i + u) * lda + j] : 0.0;
+#pragma unroll
+                        for (int u = 0; u < 8; u++) a = l2 ? fma(mv[u], mv[u], a) : fmax(a, fabs(mv[u]));
+                    }
+                    part2[ch * n + j] = a;
+                }
+            } else
             {   // row norms -> part (indexed by row), column norms -> part2 (indexed by column)
                 const int CH = chunks_for(m), len = (n + CH - 1) / CH;
                 for (int idx = tid; idx < m * CH; idx += NT) {
@@ -112,6 +200,42 @@ k_forward(DevT T, ce_settings S, const double *__restrict__ Avals, const double 
 
     // ---- (re)factor: G = (rho_x I + A^T Dy A)^{-1}, g, h.g, phi    (uniform control flow; ends synchronised)
     auto refactor = [&]() {
+        if constexpr (!A_LDS) {
+            // S = rho_x I + A-hat^T Dy A-hat on the matrix cores, operands straight from the global-memory A (coalesced: sixteen lanes read one
+            // 128-byte line of a row, four rows per instruction, eight loads in flight): the upper-triangular 16 x 16 tiles over the waves.
+            //   D[M][N] += sum_K a[M][K] b[K][N],  a = A-hat[i0 + K][16 ti + M] dy(i0 + K),  b = A-hat[i0 + K][16 tj + N];  lane l supplies
+            //   a[l & 15][l >> 4], b[l >> 4][l & 15] and holds D[(l >> 4) + 4 q][l & 15] in register q (MI355X guide, f64 MFMA).
+            typedef double v4d __attribute__((ext_vector_type(4)));
+            const int KT = (n + 15) / 16, wave = tid >> 6, lane = tid & 63, lg = lane >> 4, lc = lane & 15;
+            for (int t = wave; t < KT * (KT + 1) / 2; t += NW) {
+                int ti = 0, rem = t;
+                while (rem >= KT - ti) { rem -= KT - ti; ti++; }
+                const int tj = ti + rem, ca = 16 * ti + lc, cb = 16 * tj + lc;
+                const bool va = ca < n, vb = cb < n;
+                v4d acc = {0.0, 0.0, 0.0, 0.0};
+                for (int i0 = 0; i0 < m; i0 += 16) {
+                    double av[4], bv4[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int i = i0 + 4 * u + lg;
+                        const bool ok = i < m;
+                        const double *row = A + (size_t)(ok ? i : 0) * lda;
+                        av[u] = (ok && va) ? row[ca] * dyv(i) : 0.0;
+                        bv4[u] = (ok && vb) ? row[cb] : 0.0;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv4[u], acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int row = 16 * ti + lg + 4 * q, col = 16 * tj + lc;
+                    if (row < n && col < n) {
+                        G[row * ldg + col] = acc[q] + (row == col ? rho_x : 0.0);
+                        if (ti != tj) G[col * ldg + row] = acc[q];
+                    }
+                }
+            }
+        } else
         for (int idx = tid; idx < n * n; idx += NT) {
             const int a = idx / n, b2 = idx % n;
             double acc0 = 0, acc1 = 0; int i = 0;
@@ -142,18 +266,18 @@ k_forward(DevT T, ce_settings S, const double *__restrict__ Avals, const double 
         // tv = Dy*b  (m) ;  part = A^T tv partials
         for (int i = tid; i < m; i += NT) tv[i] = dyv(i) * bv[i];
         __syncthreads();
-        mv_cols_partial(A, lda, m, n, tv, part);
+        AT_times(tv, part);
         __syncthreads();
         // sc[0:n] = c - A^T Dy b   (rhs for g_x) ;  sc[n:2n] = c + A^T Dy b  (k, for phi)
         for (int j = tid; j < n; j += NT) { const double a = sum_parts(part, n, j); sc[j] = cv[j] - a; sc[n + j] = cv[j] + a; }
         __syncthreads();
-        mv_cols_partial(G, ldg, n, n, sc, part);      // G symmetric: column form == row form
-        mv_cols_partial(G, ldg, n, n, sc + n, part2);
+        G_times(sc, part);      // G symmetric: column form == row form
+        G_times(sc + n, part2);
         __syncthreads();
         for (int j = tid; j < n; j += NT) { g[j] = sum_parts(part, n, j); tv[j] = sum_parts(part2, n, j); }   // tv[0:n] = G k
         __syncthreads();
-        mv_rows_partial(A, lda, m, n, g, part);      // A g_x
-        mv_rows_partial(A, lda, m, n, tv, part2);    // A G k
+        A_times(g, part);      // A g_x
+        A_times(tv, part2);    // A G k
         __syncthreads();
         double r[1] = {0};
         for (int i = tid; i < m; i += NT) {
@@ -209,19 +333,19 @@ k_forward(DevT T, ce_settings S, const double *__restrict__ Avals, const double 
             __syncthreads();
         }
         // S1: A^T w_y
-        mv_cols_partial(A, lda, m, n, w + n, part);
+        AT_times(w + n, part);
         __syncthreads();
         // S2: t = rho_x w_x - A^T w_y
         for (int j = tid; j < n; j += NT) tv[j] = rho_x * w[j] - sum_parts(part, n, j);
         __syncthreads();
         // S3: G t
-        mv_cols_partial(G, ldg, n, n, tv, part);
+        G_times(tv, part);
         __syncthreads();
         // S4: p_x
         for (int j = tid; j < n; j += NT) ut[j] = sum_parts(part, n, j);
         __syncthreads();
         // S5: A p_x
-        mv_rows_partial(A, lda, m, n, ut, part);
+        A_times(ut, part);
         __syncthreads();
         // S6/S7: tau-tilde, u-tilde, cone input
         double numer = rtau * w[l - 1];
@@ -264,8 +388,8 @@ k_forward(DevT T, ce_settings S, const double *__restrict__ Avals, const double 
         // ---- termination test / adaptive scale (uniform branch)
         bool stop = false;
         if (check) {
-            mv_rows_partial(A, lda, m, n, u, part);          // A-hat x-hat
-            mv_cols_partial(A, lda, m, n, u + n, part2);     // A-hat^T y-hat
+            A_times(u, part);          // A-hat x-hat
+            AT_times(u + n, part2);     // A-hat^T y-hat
             __syncthreads();
             tau = fabs(u[l - 1]);
             kap = fabs(rtau * (u[l - 1] + w[l - 1] - 2 * ut[l - 1]));

@@ -3,8 +3,8 @@
 namespace {
 #include "ce_common.h"
 #include "ce_expcone.h"
+#include "ce_forward_rt.h"        // (first: group_reduce / DPP helpers used by the size-generic kernel's global-memory products)
 #include "ce_forward_generic.h"
-#include "ce_forward_rt.h"
 }  // namespace
 
 int ce_launch_fwd_rt(int variant, int B, size_t lds, hipStream_t st, const CeFwdArgs &a) {
