@@ -29,16 +29,21 @@ struct SaFwd {
 };
 
 // LDS doubles (see the carve in the kernel)
+__host__ __device__ inline size_t sa_fwd_cidx_doubles(int n, int m, int nq, int r, int nsing) {
+    return 2 * (size_t)m + ((size_t)(n + 1 + (nsing > 0 ? nsing : 1)) + 1) / 2 + ((size_t)(nq + 1 + (r > 0 ? r : 1)) + 1) / 2 + 2;
+}
 __host__ __device__ inline size_t sa_fwd_lds_doubles(int n, int m, int nq, int ns, int maxs, int RP, int nth) {
     const int l = n + m + 1, lp = l + (l & 1), ne = n + (n & 1), me = m + (m & 1);
     const int kp = ns > 0 ? psd_mfma_kp(maxs) : 0;
-    return 6 * (size_t)lp + 3 * (size_t)ne + 2 * (size_t)me + 2 * (size_t)RP * (RP + 1) + 5 * (size_t)RP + 2 * (size_t)(nq > 0 ? nq : 1) +
+    return 6 * (size_t)lp + 2 * (size_t)ne + 2 * (size_t)me + 2 * (size_t)RP * (RP + 1) + 5 * (size_t)RP + 2 * (size_t)(nq > 0 ? nq : 1) +
            (size_t)(ns > 0 ? (ns + 2) * kp * (kp + 1) + 2 * kp + 8 : 0) + 2 * nth + (nth / 64) * 8 + 32;
 }
 
 // NTH threads per instance: 256 (two instances per CU when the iterates allow it) or 512 (templates whose iterates fill most of a CU's LDS
 // anyway: eight waves keep more loads of the shared matrix in flight and shorten every elementwise pass).
-template <int RP, int NTH>
+// CIDX: the template's small index arrays (singleton structure, cone offsets) are copied to LDS once -- every iteration reads them, and from global
+// memory each dependent lookup is an exposed L2 round trip when a single workgroup owns the CU.
+template <int RP, int NTH, bool CIDX = false>
 __global__ void __launch_bounds__(NTH, NTH == 256 ? 2 : 1)
 k_sa_fwd(DevT T, SaFwd F, ce_settings S, const double *__restrict__ BHg, const double *__restrict__ CHg, const double *__restrict__ sigma_g,
          const double *__restrict__ nb0_g, const double *__restrict__ nc0_g, const double *__restrict__ warm_x, const double *__restrict__ warm_y,
@@ -52,7 +57,8 @@ k_sa_fwd(DevT T, SaFwd F, ce_settings S, const double *__restrict__ BHg, const d
     const int ne = n + (n & 1), me = m + (m & 1);           // even strides: every LDS vector below starts 16-byte aligned
     double *p = sm;
     double *W = p; p += lp; double *UT = p; p += lp; double *U = p; p += lp; double *G = p; p += lp; double *PHI = p; p += lp; double *zb = p; p += lp;
-    double *tv = p; p += ne; double *px = p; p += ne; double *dgi = p; p += ne;
+    double *tv = zb;                                        // refresh / check scratch: the cone-input vector is free there
+    double *px = p; p += ne; double *dgi = p; p += ne;
     double *qy = p; p += me; double *bh = p; p += me;
     double *Kinv = p; p += (size_t)RP * LK;
     double *K0 = p; p += (size_t)RP * LK;                   // A_d Dg^-1 A_d^T (kept next to its regularised inverse: see the iteration)
@@ -65,6 +71,20 @@ k_sa_fwd(DevT T, SaFwd F, ce_settings S, const double *__restrict__ BHg, const d
     double *part = p; p += 2 * NT;                              // partial sums of the dense-row products
     double *red = p; p += NW * 8;
     double *sc = p; p += 32;
+    const int *c_srow_col = F.srow_col, *c_rowcone = T.rowcone, *c_scol_ptr = F.scol_ptr, *c_scol_row = F.scol_row, *c_qoff = T.qoff, *c_drow = F.drow;
+    const double *c_srow_val = F.srow_val;
+    if constexpr (CIDX) {
+        const int nsing = F.scol_ptr[n];
+        double *sv = p; p += m;
+        int *ip = reinterpret_cast<int *>(p);
+        int *i_col = ip; ip += m; int *i_cone = ip; ip += m; int *i_ptr = ip; ip += n + 1; int *i_row = ip; ip += (nsing > 0 ? nsing : 1); int *i_qoff = ip; ip += nq + 1; int *i_drow = ip;
+        for (int i = tid; i < m; i += NT) { sv[i] = F.srow_val[i]; i_col[i] = F.srow_col[i]; i_cone[i] = T.rowcone[i]; }
+        for (int j = tid; j <= n; j += NT) i_ptr[j] = F.scol_ptr[j];
+        for (int k = tid; k < nsing; k += NT) i_row[k] = F.scol_row[k];
+        for (int c = tid; c <= nq; c += NT) i_qoff[c] = T.qoff[c];
+        for (int a = tid; a < r; a += NT) i_drow[a] = F.drow[a];
+        c_srow_val = sv; c_srow_col = i_col; c_rowcone = i_cone; c_scol_ptr = i_ptr; c_scol_row = i_row; c_qoff = i_qoff; c_drow = i_drow;
+    }
     const double *ch = CHg + (size_t)inst * n;              // c-hat stays in global memory (read in refresh / checks only)
     const double rho_x = S.rho_x, rtau = TAU_FACTOR, alpha = S.alpha;
     const double sigma = sigma_g[inst], isg = 1.0 / sigma;
@@ -208,10 +228,10 @@ k_sa_fwd(DevT T, SaFwd F, ce_settings S, const double *__restrict__ BHg, const d
             //   t' = Dg^-1 (rho w_x - A_s^T w_y)  (singleton rows: a gather),   u = Dg^-1 t = t' - Dg^-1 A_d^T w_d,   w_d = the dense rows of w_y.
             //   A_d u = A_d t' - K0 w_d,  K0 = A_d Dg^-1 A_d^T (r x r, in LDS since the factorisation)        -> one pass  (A_d t')
             //   z = K^-1 A_d u ;   p_x = u - Dg^-1 A_d^T z = t' - Dg^-1 A_d^T (w_d + z)                        -> one pass  (A_d^T (w_d + z))
-            for (int a = tid; a < RP; a += NT) wyd[a] = a < r ? W[n + F.drow[a]] : 0.0;
+            for (int a = tid; a < RP; a += NT) wyd[a] = a < r ? W[n + c_drow[a]] : 0.0;
             for (int j = tid; j < n; j += NT) {
                 double acc = rho_x * W[j];
-                for (int k = F.scol_ptr[j]; k < F.scol_ptr[j + 1]; k++) { const int i = F.scol_row[k]; acc = fma(-F.srow_val[i], W[n + i], acc); }
+                for (int k = c_scol_ptr[j]; k < c_scol_ptr[j + 1]; k++) { const int i = c_scol_row[k]; acc = fma(-c_srow_val[i], W[n + i], acc); }
                 px[j] = acc * dgi[j];
             }
             __syncthreads();
@@ -236,7 +256,7 @@ k_sa_fwd(DevT T, SaFwd F, ce_settings S, const double *__restrict__ BHg, const d
             __syncthreads();
             sa_rows_dot<NT, RP>(F.AdT, n, dyd + RP, [&](int, int) { return 0.0; }, [&](int j, double a) { px[j] -= dgi[j] * a; });
             __syncthreads();
-            for (int a = tid; a < r; a += NT) qy[F.drow[a]] = zd[a] / dyd[a];
+            for (int a = tid; a < r; a += NT) qy[c_drow[a]] = zd[a] / dyd[a];
             double rts = 0;
 #pragma unroll
             for (int w = 0; w < NW; w++) rts += red[w];
@@ -247,8 +267,8 @@ k_sa_fwd(DevT T, SaFwd F, ce_settings S, const double *__restrict__ BHg, const d
                 const double we = W[e];
                 if (e < n) { ute = px[e] - tau_t * G[e]; ze = 2 * ute - we; }
                 else if (e < l - 1) {
-                    const int i = e - n, c = F.srow_col[i];           // >= 0: singleton row, -2: dense row, -1: empty row
-                    const double qi = c >= 0 ? F.srow_val[i] * px[c] : (c == -2 ? qy[i] : 0.0);
+                    const int i = e - n, c = c_srow_col[i];           // >= 0: singleton row, -2: dense row, -1: empty row
+                    const double qi = c >= 0 ? c_srow_val[i] * px[c] : (c == -2 ? qy[i] : 0.0);
                     ute = we + dyv(i) * qi - tau_t * G[e]; ze = 2 * ute - we;
                     if (i >= z && i < z + nl && ze < 0) ze = 0;
                 } else { ute = tau_t; ze = fmax(0.0, 2 * tau_t - we); }
@@ -257,7 +277,7 @@ k_sa_fwd(DevT T, SaFwd F, ce_settings S, const double *__restrict__ BHg, const d
             __syncthreads();
             if (nq > 0) {
                 for (int c = tid >> 6; c < nq; c += NW) {         // one wave per cone
-                    const int r0 = n + T.qoff[c], r1 = n + T.qoff[c + 1];
+                    const int r0 = n + c_qoff[c], r1 = n + c_qoff[c + 1];
                     const double t0 = zb[r0]; double nz = 0;
                     for (int k = r0 + 1 + (tid & 63); k < r1; k += 64) nz = fma(zb[k], zb[k], nz);
                     nz = sqrt(wave_reduce_dpp<false>(nz));
@@ -269,7 +289,7 @@ k_sa_fwd(DevT T, SaFwd F, ce_settings S, const double *__restrict__ BHg, const d
                     if ((tid & 63) == 0) { socc[2 * c] = c0; socc[2 * c + 1] = f; }
                 }
                 __syncthreads();
-                for (int i = tid + z + nl; i < m; i += NT) { const int c = T.rowcone[i]; if (c >= 0) zb[n + i] = (i == T.qoff[c]) ? socc[2 * c] : socc[2 * c + 1] * zb[n + i]; }
+                for (int i = tid + z + nl; i < m; i += NT) { const int c = c_rowcone[i]; if (c >= 0) zb[n + i] = (i == c_qoff[c]) ? socc[2 * c] : socc[2 * c + 1] * zb[n + i]; }
                 __syncthreads();
             }
 #ifndef SA_SKIP_PSD        // (debug builds time the kernel without the projection)

@@ -648,28 +648,34 @@ int ce_solve_shared_a(ce_handle h, int B, int r, int RP, const double *AdT, cons
     const DevT &T = h->T;
     if (T.nep + T.np > 0) { g_err = "shared-A forward kernel: exponential / power cones are not implemented"; return CE_E_UNSUPPORTED; }
     if (r < 0 || r > RP || (RP != 16 && RP != 32 && RP != 64)) { g_err = "shared-A forward kernel: at most 64 dense rows (RP in 16, 32, 64)"; return CE_E_UNSUPPORTED; }
-    // 512 threads per instance when the iterates of one instance leave room for a single workgroup per CU anyway (CE_SA_NT=256 / 512 / 1024 forces;
-    // the 1024-thread instantiation is capped at 128 VGPRs and spills: kept for experiments only)
+    // 512 threads per instance when the iterates of one instance leave room for a single workgroup per CU anyway (CE_SA_NT=256 / 512 forces);
+    // that instantiation also keeps the template's index arrays in LDS when they fit (CE_SA_CIDX=0 disables)
     int nth = 256;
     if (T.ns == 0 && sa_fwd_lds_doubles(T.n, T.m, T.nq, T.ns, T.maxs, RP, 256) * 8 > LDS_LIMIT / 2) nth = 512;
-    if (const char *e = getenv("CE_SA_NT")) { const int v = atoi(e); if (v == 256 || ((v == 512 || (v == 1024 && RP == 64)) && T.ns == 0)) nth = v; }
-    const size_t lds = sa_fwd_lds_doubles(T.n, T.m, T.nq, T.ns, T.maxs, RP, nth) * 8;
+    if (const char *e = getenv("CE_SA_NT")) { const int v = atoi(e); if (v == 256 || (v == 512 && T.ns == 0)) nth = v; }
+    size_t lds = sa_fwd_lds_doubles(T.n, T.m, T.nq, T.ns, T.maxs, RP, nth) * 8;
     if (lds > LDS_LIMIT) { g_err = "shared-A forward kernel: the iterates of one instance do not fit LDS"; return CE_E_TOO_LARGE; }
+    bool cidx = false;
+    if (nth == 512) {
+        const size_t with = lds + sa_fwd_cidx_doubles(T.n, T.m, T.nq, r, T.m) * 8;      // (at most m single-entry rows)
+        const char *e = getenv("CE_SA_CIDX");
+        if (with <= LDS_LIMIT && !(e && atoi(e) == 0)) { cidx = true; lds = with; }
+    }
     HIPCHK(hipSetDevice(h->device));
     static bool attr_done = false;
     if (!attr_done) {
-#define SA_ATTR(RPV, NTV) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sa_fwd<RPV, NTV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT))
-        SA_ATTR(16, 256); SA_ATTR(32, 256); SA_ATTR(64, 256); SA_ATTR(16, 512); SA_ATTR(32, 512); SA_ATTR(64, 512); SA_ATTR(64, 1024);
+#define SA_ATTR(...) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sa_fwd<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT))
+        SA_ATTR(16, 256); SA_ATTR(32, 256); SA_ATTR(64, 256); SA_ATTR(16, 512); SA_ATTR(32, 512); SA_ATTR(64, 512); SA_ATTR(16, 512, true); SA_ATTR(32, 512, true); SA_ATTR(64, 512, true);
 #undef SA_ATTR
         attr_done = true;
     }
     SaFwd F{r, RP, AdT, drow, srow_col, srow_val, scol_ptr, scol_row, gs, Dv, Ev};
     {
         ProfScope ps(h, 0, (hipStream_t)stream);
-#define LAUNCH_SA(RPV, NTV) hipLaunchKernelGGL((k_sa_fwd<RPV, NTV>), dim3(B), dim3(NTV), lds, (hipStream_t)stream, T, F, *settings, b_hat, c_hat, sigma, nrm_b0, nrm_c0, warm_x, warm_y, warm_s, x, y, s, iters, status, resid)
-        if (nth == 256) { if (RP == 16) LAUNCH_SA(16, 256); else if (RP == 32) LAUNCH_SA(32, 256); else LAUNCH_SA(64, 256); }
-        else if (nth == 512) { if (RP == 16) LAUNCH_SA(16, 512); else if (RP == 32) LAUNCH_SA(32, 512); else LAUNCH_SA(64, 512); }
-        else LAUNCH_SA(64, 1024);
+#define LAUNCH_SA(NTV, ...) hipLaunchKernelGGL((k_sa_fwd<__VA_ARGS__>), dim3(B), dim3(NTV), lds, (hipStream_t)stream, T, F, *settings, b_hat, c_hat, sigma, nrm_b0, nrm_c0, warm_x, warm_y, warm_s, x, y, s, iters, status, resid)
+        if (nth == 256) { if (RP == 16) LAUNCH_SA(256, 16, 256); else if (RP == 32) LAUNCH_SA(256, 32, 256); else LAUNCH_SA(256, 64, 256); }
+        else if (!cidx) { if (RP == 16) LAUNCH_SA(512, 16, 512); else if (RP == 32) LAUNCH_SA(512, 32, 512); else LAUNCH_SA(512, 64, 512); }
+        else { if (RP == 16) LAUNCH_SA(512, 16, 512, true); else if (RP == 32) LAUNCH_SA(512, 32, 512, true); else LAUNCH_SA(512, 64, 512, true); }
 #undef LAUNCH_SA
     }
     HIPCHK(hipGetLastError());
