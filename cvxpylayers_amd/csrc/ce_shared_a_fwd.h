@@ -256,19 +256,17 @@ k_sa_fwd(DevT T, SaFwd F, ce_settings S, const double *__restrict__ BHg, const d
             __syncthreads();
             sa_rows_dot<NT, RP>(F.AdT, n, dyd + RP, [&](int, int) { return 0.0; }, [&](int j, double a) { px[j] -= dgi[j] * a; });
             __syncthreads();
-            for (int a = tid; a < r; a += NT) qy[c_drow[a]] = zd[a] / dyd[a];
             double rts = 0;
 #pragma unroll
             for (int w = 0; w < NW; w++) rts += red[w];
             const double tau_t = (rtau * W[l - 1] + rts) * inv_den;
-            __syncthreads();
             for (int e = tid; e < l; e += NT) {
                 double ute, ze;
                 const double we = W[e];
                 if (e < n) { ute = px[e] - tau_t * G[e]; ze = 2 * ute - we; }
                 else if (e < l - 1) {
-                    const int i = e - n, c = c_srow_col[i];           // >= 0: singleton row, -2: dense row, -1: empty row
-                    const double qi = c >= 0 ? c_srow_val[i] * px[c] : (c == -2 ? qy[i] : 0.0);
+                    const int i = e - n, c = c_srow_col[i];           // >= 0: column of a singleton row, -2 - a: dense row in slot a, -1: empty row
+                    const double qi = c >= 0 ? c_srow_val[i] * px[c] : (c <= -2 ? zd[-2 - c] / dyd[-2 - c] : 0.0);      // dense rows: Dd^-1 z
                     ute = we + dyv(i) * qi - tau_t * G[e]; ze = 2 * ute - we;
                     if (i >= z && i < z + nl && ze < 0) ze = 0;
                 } else { ute = tau_t; ze = fmax(0.0, 2 * tau_t - we); }
@@ -289,21 +287,29 @@ k_sa_fwd(DevT T, SaFwd F, ce_settings S, const double *__restrict__ BHg, const d
                     if ((tid & 63) == 0) { socc[2 * c] = c0; socc[2 * c + 1] = f; }
                 }
                 __syncthreads();
-                for (int i = tid + z + nl; i < m; i += NT) { const int c = c_rowcone[i]; if (c >= 0) zb[n + i] = (i == c_qoff[c]) ? socc[2 * c] : socc[2 * c + 1] * zb[n + i]; }
-                __syncthreads();
+                if (ns > 0) {      // the PSD projection below works on zb in place: finish the second-order cones first
+                    for (int i = tid + z + nl; i < m; i += NT) { const int c = c_rowcone[i]; if (c >= 0) zb[n + i] = (i == c_qoff[c]) ? socc[2 * c] : socc[2 * c + 1] * zb[n + i]; }
+                    __syncthreads();
+                }
             }
+            // the projected value of element e (second-order cone rows are scaled here when there is no PSD block, saving a pass and a barrier)
+            auto proj_e = [&](int e) -> double {
+                double ue = zb[e];
+                if (nq > 0 && ns == 0 && e >= n + z + nl && e < l - 1) { const int i = e - n, c = c_rowcone[i]; if (c >= 0) ue = (i == c_qoff[c]) ? socc[2 * c] : socc[2 * c + 1] * ue; }
+                return ue;
+            };
 #ifndef SA_SKIP_PSD        // (debug builds time the kernel without the projection)
             if constexpr (NTH == 256)          // (templates with PSD blocks always run the 256-thread instantiation)
             for (int c = 0; c < ns; c++)       // PSD blocks: MFMA sandwich + warm-started Jacobi, eigenvectors stay in LDS (restart at check iterations)
                 psd_project_mfma_lds<NT>(zb + n + T.soff[c], T.sord[c], Sm, Vst + (size_t)c * PM, Tm, cs, red, (!check && iter > 0) ? 1 : 0);
 #endif
             if (!check && !last) {
-                for (int e = tid; e < l; e += NT) { const double ue = zb[e]; U[e] = ue; W[e] += alpha * (ue - UT[e]); }
+                for (int e = tid; e < l; e += NT) { const double ue = proj_e(e); U[e] = ue; W[e] += alpha * (ue - UT[e]); }
                 __syncthreads();
                 iter++;
                 continue;
             }
-            for (int e = tid; e < l; e += NT) U[e] = zb[e];
+            for (int e = tid; e < l; e += NT) U[e] = proj_e(e);
             __syncthreads();
             // ---- check iteration: residuals, termination, certificates, adaptive scale
             bool stop = false, rescale = false;

@@ -164,7 +164,7 @@ def solve_const_a(eng, A_bm: torch.Tensor, q_eval: torch.Tensor, settings, warm=
                 srow = (row_nnz == 1)
                 ent_rows = indices[:nnzA].astype(np.int64); ent_cols = cols[:nnzA].astype(np.int64)
                 sing = srow[ent_rows]                                          # structural entries that sit in single-entry rows
-                srow_col_np = np.full(m, -1, dtype=np.int32); srow_col_np[drows_np] = -2; srow_col_np[ent_rows[sing]] = ent_cols[sing]      # >= 0 column of a singleton row, -2 dense row, -1 empty row
+                srow_col_np = np.full(m, -1, dtype=np.int32); srow_col_np[drows_np] = -2 - np.arange(r_d, dtype=np.int32); srow_col_np[ent_rows[sing]] = ent_cols[sing]      # >= 0 column of a singleton row, -2 - a: dense row in slot a, -1 empty row
                 order = np.argsort(ent_cols[sing], kind="stable")
                 scol_row_np = ent_rows[sing][order].astype(np.int32)
                 scol_ptr_np = np.concatenate([[0], np.cumsum(np.bincount(ent_cols[sing], minlength=n))]).astype(np.int32)

@@ -89,7 +89,7 @@ void ce_default_settings(ce_settings *s);
  * library short structs.  Bindings must check  ce_abi_version() == CE_ABI_VERSION  and  ce_struct_size(which) == sizeof(their
  * struct)  (which: 0 ce_template, 1 ce_settings) once at load time and refuse to continue otherwise (cvxpylayers_amd/_lib.py
  * does; tests/test_cabi.py checks the stub printed in INTEGRATION.md the same way).  CE_ABI_VERSION is bumped whenever a struct
- * layout, an entry point's signature or the meaning of an argument changes (5: srow_col of ce_solve_shared_a marks dense rows with -2). */
+ * layout, an entry point's signature or the meaning of an argument changes (5: srow_col of ce_solve_shared_a marks the dense row of slot a with -2 - a). */
 #define CE_ABI_VERSION 5
 int ce_abi_version(void);
 int ce_struct_size(int which);
@@ -211,7 +211,7 @@ int ce_ca_finish(ce_handle h, int B, int lp, int max_iters, const double *W, con
  * r x r core formed on the matrix cores, termination / adaptive scale in the kernel, PSD projection with MFMA contractions).
  * The caller equilibrates the ONE shared matrix (cvxpylayers_amd/interfaces/const_a.py) and passes, all device memory:
  *   AdT (n, RP) row-major: the equilibrated dense rows transposed (solver sign A = -A_cvx), zero padded to RP in {16, 32, 64};
- *   drow (r): their row indices; srow_col / srow_val (m): column (-2: one of the dense rows, -1: empty row) and value of every single-entry row;
+ *   drow (r): their row indices; srow_col / srow_val (m): column (-2 - a: the dense row in slot a, -1: empty row) and value of every single-entry row;
  *   scol_ptr (n + 1) / scol_row: the single-entry rows of every column; gs (n): sum over them of d0_i a_i^2 (d0 = 1000 on zero-cone rows);
  *   Dv (m), Ev (n): the equilibration; b_hat (B, m), c_hat (B, n), sigma / nrm_b0 / nrm_c0 (B): normalised data as in ce_ca_check;
  *   warm_x / warm_y / warm_s: (B, .) initial point used when settings->warm_start != 0, else NULL.
