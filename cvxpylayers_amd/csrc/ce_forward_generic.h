@@ -99,6 +99,8 @@ k_forward(DevT T, ce_settings S, const double *__restrict__ Avals, const double 
     double *socc = p; p += 2 * (nq > 0 ? nq : 1);
     double *wpart = p; p += NW;  // per-wave partials of phi . w
     double *sc = p; p += 2 * n;  // refactor() right-hand sides (keeps u / ut intact across a rescale)
+    p += (size_t)(p - sm) & 1;   // (16-byte alignment of what follows)
+    double *pan = p;             // !G_LDS: panels of the blocked inversion (generic_gj_panel_doubles(n))
 
     // products with A / G: LDS-resident -> ce_common.h, global-memory-resident -> the coalesced versions above
     auto AT_times = [&](const double *v, double *out) { if constexpr (A_LDS) mv_cols_partial(A, lda, m, n, v, out); else mv_cols_g(A, lda, m, n, v, out); };
@@ -247,6 +249,78 @@ k_forward(DevT T, ce_settings S, const double *__restrict__ Avals, const double 
             G[a * ldg + b2] = acc0 + acc1 + (a == b2 ? rho_x : 0.0);
         }
         __syncthreads();
+        if constexpr (!G_LDS) {
+            // BLOCKED Gauss-Jordan inversion of the global-memory S, sixteen pivots per step, every product on the matrix cores.  For the pivot
+            // block K (rows / columns k0 .. k0 + 15):  P = S[K,K]^-1 ;  C = S[:,K], R = S[K,:] (panels in LDS) ;  W = -C P for rows outside K, W[K] = P ;
+            //     S[i, j] <- (i outside K ? S[i, j] : 0) + W[i,:] R[:, j]   for columns j outside K ;      S[:, K] <- W
+            // (the 4-pivot register version of ce_forward_v2.h, one level up).  The scalar version read and wrote the whole matrix once per
+            // pivot (n = 200: 128 MB of L2 traffic per inversion); this one once per sixteen.  S is symmetric positive definite: no pivoting.
+            typedef double v4d __attribute__((ext_vector_type(4)));
+            const int KT = (n + 15) / 16, NP16 = 16 * KT;
+            double *Cp = pan, *Pb = Cp + (size_t)NP16 * 17;
+            const int wave = tid >> 6, lane = tid & 63, lg = lane >> 4, lc = lane & 15;
+            for (int kb = 0; kb < KT; kb++) {
+                const int k0 = 16 * kb, nb = min(16, n - k0);
+                // column panel C[i][q] = S[i][k0 + q] (zero beyond n) and the pivot block with an identity tail; the row panel R = S[K,:] is read from
+                // global memory by the tiles themselves (rows outside K first: they do not write R; then the rows of K, each tile from its own old entries)
+                for (int idx = tid; idx < NP16 * 16; idx += NT) { const int i = idx >> 4, q = idx & 15; Cp[i * 17 + q] = (i < n && q < nb) ? G[(size_t)i * ldg + k0 + q] : 0.0; }
+                __syncthreads();
+                for (int idx = tid; idx < 256; idx += NT) { const int a = idx >> 4, b = idx & 15; Pb[a * 17 + b] = (a < nb && b < nb) ? Cp[(k0 + a) * 17 + b] : (a == b ? 1.0 : 0.0); }
+                __syncthreads();
+                for (int k = 0; k < 16; k++) {          // 16 x 16 inverse in LDS (all threads: 256 entries)
+                    const double pinv = 1.0 / Pb[k * 17 + k];
+                    const int a = tid >> 4, b = tid & 15;
+                    double v = 0;
+                    if (tid < 256) {
+                        const double ck = Pb[a * 17 + k], rk = Pb[k * 17 + b];
+                        if (a == k) v = (b == k) ? pinv : rk * pinv;
+                        else if (b == k) v = -ck * pinv;
+                        else v = fma(-ck * pinv, rk, Pb[a * 17 + b]);
+                    }
+                    __syncthreads();
+                    if (tid < 256) Pb[a * 17 + b] = v;
+                    __syncthreads();
+                }
+                // W = -C P (rows outside K), W[K] = P : one 16 x 16 tile per wave and pass, written over C
+                for (int ti = wave; ti < KT; ti += NW) {
+                    v4d acc = {0.0, 0.0, 0.0, 0.0};
+                    if (ti != kb) {
+#pragma unroll
+                        for (int s4 = 0; s4 < 4; s4++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Cp[(16 * ti + lc) * 17 + 4 * s4 + lg], Pb[(4 * s4 + lg) * 17 + lc], acc, 0, 0, 0);
+                    }
+                    // (a wave reads only its own tile's rows of C before overwriting them: no hazard between waves)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) { const int row = lg + 4 * q; Cp[(16 * ti + row) * 17 + lc] = (ti != kb) ? -acc[q] : Pb[row * 17 + lc]; }
+                }
+                __syncthreads();
+                // update of every tile (ti, tj): columns outside K get W R (+ the old entry for rows outside K), the block column becomes W
+                for (int phase = 0; phase < 2; phase++) {
+                    const int ntile = phase == 0 ? (KT - 1) * KT : KT;
+                    for (int t = wave; t < ntile; t += NW) {
+                        int ti, tj;
+                        if (phase == 0) { ti = t / KT; tj = t - ti * KT; if (ti >= kb) ti++; } else { ti = kb; tj = t; }
+                        v4d acc = {0.0, 0.0, 0.0, 0.0};
+                        if (tj != kb) {
+                            double bop[4];
+#pragma unroll
+                            for (int s4 = 0; s4 < 4; s4++) { const int q = 4 * s4 + lg, col = 16 * tj + lc; bop[s4] = (q < nb && col < n) ? G[(size_t)(k0 + q) * ldg + col] : 0.0; }      // R[q][col]
+                            if (ti != kb) {
+#pragma unroll
+                                for (int q = 0; q < 4; q++) { const int row = 16 * ti + lg + 4 * q, col = 16 * tj + lc; acc[q] = (row < n && col < n) ? G[(size_t)row * ldg + col] : 0.0; }
+                            }
+#pragma unroll
+                            for (int s4 = 0; s4 < 4; s4++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Cp[(16 * ti + lc) * 17 + 4 * s4 + lg], bop[s4], acc, 0, 0, 0);
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < 4; q++) acc[q] = Cp[(16 * ti + lg + 4 * q) * 17 + lc];
+                        }
+#pragma unroll
+                        for (int q = 0; q < 4; q++) { const int row = 16 * ti + lg + 4 * q, col = 16 * tj + lc; if (row < n && col < n) G[(size_t)row * ldg + col] = acc[q]; }
+                    }
+                    __syncthreads();
+                }
+            }
+        } else {
         // in-place Gauss-Jordan inversion (SPD: no pivoting needed)
         double *colk = part, *rowk = part2;
         for (int k = 0; k < n; k++) {
@@ -262,6 +336,7 @@ k_forward(DevT T, ce_settings S, const double *__restrict__ Avals, const double 
                 G[i * ldg + j] = v;
             }
             __syncthreads();
+        }
         }
         // tv = Dy*b  (m) ;  part = A^T tv partials
         for (int i = tid; i < m; i += NT) tv[i] = dyv(i) * bv[i];

@@ -103,6 +103,7 @@ static size_t fwd_lds_bytes(const DevT &T, bool a_lds, bool g_lds) {
     if (a_lds) d += (size_t)m * T.lda;
     if (g_lds) d += (size_t)n * T.ldg;
     d += 2 * (size_t)m + 2 * (size_t)n + 5 * (size_t)l + std::max(n, m) + 2 * (size_t)PB + NW * 8 + 2 * std::max(T.nq, 1) + NW + 2 * (size_t)n;
+    if (!g_lds) d += generic_gj_panel_doubles(n) + 2;      // panels of the blocked inversion of the global-memory G
     return d * 8 + 16;
 }
 // register-tiled forward variants: {CH1, T1, TG, CH2, T2}
