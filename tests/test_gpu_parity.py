@@ -70,6 +70,7 @@ def run_parity(n, cones, B, seed, eps, pattern=None, max_iters=20000):
     assert np.abs(dA - want).max() < gtol * scale, np.abs(dA - want).max() / scale
     assert np.abs(dq[:n] - g["dc"].T).max() < gtol * (1 + np.abs(g["dc"]).max())
     assert np.abs(dq[n]).max() == 0
+    return eng
 
 
 @pytest.mark.parametrize("eps", [1e-4, 1e-8])
@@ -100,6 +101,16 @@ def test_sparse_pattern_and_ragged_soc():
 def test_socp_c3_global_residency():
     cfg = P.CONFIGS["C3"]
     run_parity(cfg["n"], cfg["cones"], 8, seed=2, eps=1e-8)
+
+
+def test_large_per_instance_template_all_global_residency():
+    """n = 120, m = 186 with per-instance A: neither A nor G fits LDS (size-generic kernels, residency mode 2): the coalesced
+    global-memory products, the MFMA formation of S from the global A and the blocked Gauss-Jordan, against the oracle (solution
+    and adjoint)."""
+    cones = {"z": 0, "l": 60, "q": [21] * 6}
+    eng = run_parity(120, cones, 6, seed=7, eps=1e-8)
+    info = eng.launch_info()
+    assert info["fwd_mode"] == 2 and info["bwd_mode"] == 2, info
 
 
 def test_layouts_agree():
