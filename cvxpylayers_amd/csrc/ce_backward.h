@@ -186,13 +186,26 @@ k_backward(DevT T, int nkcap, int ldk, const double *__restrict__ Avals, const d
         const double pinv = 1.0 / piv;
         // rank-1 update of columns k+1 .. NK: a 16 x 16 thread grid walks rows / columns (no integer division in the loop)
         {
+            // (K may live in global memory: the pivot row's entries of a column chunk stay in registers for all rows, and every row chunk is
+            //  eight independent loads -- the plain loop had one dependent load / store pair in flight per lane)
             const int ty = tid >> 4, tx = tid & 15;
             const double *prow = K + pk * ldk;
-            for (int i = ty; i < NK; i += 16) {
-                if (i == k) continue;
-                double *row = K + perm[i] * ldk;
-                const double f = row[k] * pinv;
-                if (f != 0.0) for (int j = k + 1 + tx; j <= NK; j += 16) row[j] = fma(-f, prow[j], row[j]);
+            for (int j0 = k + 1 + tx; j0 <= NK; j0 += 128) {
+                double pr[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) { const int jj = j0 + 16 * u; pr[u] = jj <= NK ? prow[jj] : 0.0; }
+                for (int i = ty; i < NK; i += 16) {
+                    if (i == k) continue;
+                    double *row = K + perm[i] * ldk;
+                    const double f = row[k] * pinv;          // (column k itself is not touched by this step)
+                    if (f != 0.0) {
+                        double rv[8];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) { const int jj = j0 + 16 * u; rv[u] = jj <= NK ? row[jj] : 0.0; }
+#pragma unroll
+                        for (int u = 0; u < 8; u++) { const int jj = j0 + 16 * u; if (jj <= NK) row[jj] = fma(-f, pr[u], rv[u]); }
+                    }
+                }
             }
         }
         __syncthreads();
