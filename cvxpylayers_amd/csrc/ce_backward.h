@@ -34,6 +34,7 @@ k_backward(DevT T, int nkcap, int ldk, const double *__restrict__ Avals, const d
     double *cinfo = p; p += 6 * nqs; // per cone: lambda, nz, e_y.d, e_s.d, (spare)
     double *part = p; p += PB;
     double *red = p; p += NW * 8;
+    double *pan = p; if constexpr (!K_LDS) p += generic_lu_panel_doubles(nkcap);      // panels of the blocked elimination (K in global memory)
     int *ip = (int *)p;
     int *rkind = ip; ip += m;        // row kind
     int *eqrow = ip; ip += m;        // equality index of row (RK_EQ) or -1
@@ -112,11 +113,34 @@ k_backward(DevT T, int nkcap, int ldk, const double *__restrict__ Avals, const d
         as[c * n + j] = (A[r0 * lda + j] - a) * M_SQRT1_2;
     }
     __syncthreads();
+    // ---- f = dx + sum_FREE a_i d_i + sum_B [ a_s (e_s.d) + A_c^T P d / (1-lam) ],  A_c^T P d = A_c^T d - a_y (e_y.d) - a_s (e_s.d):
+    //      one product A^T w with w_i = d_i (free rows, cones in -K), d_i / (1 - lam_c) (boundary cones), 0 (equality rows), plus the per-cone
+    //      a_y / a_s terms.  (Was a serial loop over all rows inside the single thread that owned each right-hand-side entry.)  f lands in rx.
+    for (int i = tid; i < m; i += NT) {
+        double w = 0;
+        if (i < z + T.l) w = (rkind[i] == RK_FREE) ? dv[i] : 0.0;
+        else { const int c = T.rowcone[i]; if (c >= 0) { if (ckind[c] == 1) w = dv[i]; else if (ckind[c] == 2) w = dv[i] / (1 - cinfo[6 * c]); } }
+        qv2[i] = w;
+    }
+    __syncthreads();
+    if constexpr (A_LDS) mv_cols_partial(A, lda, m, n, qv2, part); else mv_cols_g(A, lda, m, n, qv2, part);
+    __syncthreads();
+    for (int r = tid; r < n; r += NT) {
+        double val = dxg[(size_t)inst * n + r] + sum_parts(part, n, r);
+        for (int c = 0; c < nq; c++) {
+            if (ckind[c] != 2) continue;
+            const double il = 1.0 / (1 - cinfo[6 * c]), eyd = cinfo[6 * c + 2], esd = cinfo[6 * c + 3];
+            val += as[c * n + r] * esd * (1 - il) - ay[c * n + r] * eyd * il;
+        }
+        rx[r] = val;
+    }
+    __syncthreads();
     // ---- assemble K = [[H, -B^T],[B, 0]] | rhs
     for (int idx = tid; idx < NK * (NK + 1); idx += NT) {
         const int r = idx / (NK + 1), cidx = idx % (NK + 1);
         double val = 0;
         if (r < n && cidx < n) {            // H[a][b] = sum_c theta_c (A_c^T A_c - a_y a_y^T - a_s a_s^T)
+            if constexpr (!A_LDS) continue;                    // (global-memory A: formed on the matrix cores below)
             for (int c = 0; c < nq; c++) {
                 if (ckind[c] != 2) continue;
                 const double lam = cinfo[6 * c], th = lam / (1 - lam);
@@ -125,23 +149,60 @@ k_backward(DevT T, int nkcap, int ldk, const double *__restrict__ Avals, const d
                 a -= ay[c * n + r] * ay[c * n + cidx] + as[c * n + r] * as[c * n + cidx];
                 val = fma(th, a, val);
             }
-        } else if (r < n && cidx == NK) {   // f = dx + sum_FREE a_i d_i + sum_B [ a_s (e_s.d) + A_c^T P d / (1-lam) ]
-            val = dxg[(size_t)inst * n + r];
-            for (int i = 0; i < z + T.l; i++) if (rkind[i] == RK_FREE) val = fma(A[i * lda + r], dv[i], val);
-            for (int c = 0; c < nq; c++) {
-                const int r0 = T.qoff[c], r1 = T.qoff[c + 1];
-                if (ckind[c] == 1) { for (int i = r0; i < r1; i++) val = fma(A[i * lda + r], dv[i], val); }
-                else if (ckind[c] == 2) {
-                    const double lam = cinfo[6 * c], eyd = cinfo[6 * c + 2], esd = cinfo[6 * c + 3];
-                    double a = 0; for (int i = r0; i < r1; i++) a = fma(A[i * lda + r], dv[i], a);
-                    a -= ay[c * n + r] * eyd + as[c * n + r] * esd;      // A_c^T P d
-                    val += as[c * n + r] * esd + a / (1 - lam);
-                }
-            }
+        } else if (r < n && cidx == NK) {   // f (computed above as one product with A^T)
+            val = rx[r];
         } else if (r >= n && cidx == NK) {  // d_B  (filled below by the owning row / cone)
             val = 0;
         } else val = 0;
         K[r * ldk + cidx] = val;
+    }
+    if constexpr (!A_LDS) {
+        // H = X^T W X on the matrix cores: X = the rows of the boundary cones (weight theta_c), then a_y and a_s of every boundary cone as two more
+        // rows with weight -theta_c; operands straight from the global-memory A (sixteen lanes read one 128-byte line, four rows per
+        // instruction), upper-triangular 16 x 16 tiles over the waves, mirrored on store.  (Was n^2 scalar dot products over the cone rows.)
+        typedef double v4d __attribute__((ext_vector_type(4)));
+        double *wrow = qv2;                                    // per-row weight (free again: f has been formed)
+        for (int i = tid; i < m; i += NT) { const int c = (i >= z + T.l) ? T.rowcone[i] : -1; wrow[i] = (c >= 0 && ckind[c] == 2) ? cinfo[6 * c] / (1 - cinfo[6 * c]) : 0.0; }
+        __syncthreads();
+        const int KT = (n + 15) / 16, wave = tid >> 6, lane = tid & 63, lg = lane >> 4, lc = lane & 15;
+        const int i_first = z + T.l;                            // cone rows only
+        for (int t = wave; t < KT * (KT + 1) / 2; t += NW) {
+            int ti = 0, rem = t;
+            while (rem >= KT - ti) { rem -= KT - ti; ti++; }
+            const int tj = ti + rem, ca = 16 * ti + lc, cb = 16 * tj + lc;
+            const bool va = ca < n, vb = cb < n;
+            v4d acc = {0.0, 0.0, 0.0, 0.0};
+            for (int i0 = i_first; i0 < m; i0 += 16) {
+                double av[4], bv4[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int i = i0 + 4 * u + lg;
+                    const bool ok = i < m;
+                    const double *row = A + (size_t)(ok ? i : 0) * lda;
+                    const double w = ok ? wrow[i] : 0.0;
+                    av[u] = (ok && va && w != 0.0) ? row[ca] * w : 0.0;
+                    bv4[u] = (ok && vb && w != 0.0) ? row[cb] : 0.0;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv4[u], acc, 0, 0, 0);
+            }
+            for (int c0 = 0; c0 < 2 * nq; c0 += 4) {           // a_y (even) / a_s (odd) of cone c0 / 2 ...
+                const int e = c0 + lg, c = e >> 1;
+                double a = 0.0, b = 0.0;
+                if (e < 2 * nq && ckind[c] == 2) {
+                    const double th = cinfo[6 * c] / (1 - cinfo[6 * c]);
+                    const double *vec = ((e & 1) ? as : ay) + c * n;
+                    if (va) a = -th * vec[ca];
+                    if (vb) b = vec[cb];
+                }
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int row = 16 * ti + lg + 4 * q, col = 16 * tj + lc;
+                if (row < n && col < n) { K[(size_t)row * ldk + col] = acc[q]; if (ti != tj) K[(size_t)col * ldk + row] = acc[q]; }
+            }
+        }
     }
     __syncthreads();
     for (int idx = tid; idx < m * n; idx += NT) {   // B rows of plain equality rows
@@ -165,6 +226,106 @@ k_backward(DevT T, int nkcap, int ldk, const double *__restrict__ Avals, const d
         kmax = r[0];
     }
     const double ptol = 1e-13 * (kmax > 0 ? kmax : 1.0);
+    if constexpr (!K_LDS) {
+        // BLOCKED Gauss-Jordan with partial pivoting, sixteen pivots per pass over the global-memory matrix (the unblocked loop below streams the
+        // whole [K | rhs] once per pivot: at n = 200 that is 0.98 MB x NK steps per instance, HBM-bound).  Per block of columns k0 .. k0 + nb - 1:
+        //   1. the column panel (all rows) goes to LDS and the nb pivot steps run on it alone: pivot search, multipliers L[i][kk] for every other row;
+        //   2. with Lp = the multipliers at the block's pivot rows, T = I + strict_lower(Lp):  U~ = T^-1 Kp  are the pivot rows as they were when
+        //      they were used (Kp: their trailing entries), the pivot rows end as (I - strict_upper(Lp)) U~, every other row as K_i - L_i U~;
+        //   3. one wave per strip of sixteen trailing columns (the right-hand side included) does that with MFMA products: U~ stays in the
+        //      accumulator layout, which is the B-operand layout of the next product (row lg + 4 q of lane l = K index 4 s + lg for q = s).
+        typedef double v4d __attribute__((ext_vector_type(4)));
+        double *Pn = pan, *Tm = Pn + (size_t)nkcap * 17, *M2 = Tm + 16 * 17, *pivv = M2 + 16 * 17;
+        const int wave = tid >> 6, lane = tid & 63, lg = lane >> 4, lc = lane & 15;
+        for (int k0 = 0; k0 < NK; k0 += 16) {
+            const int nb = min(16, NK - k0), kb = k0 >> 4;
+            for (int idx = tid; idx < NK * 16; idx += NT) { const int pr = idx >> 4, q = idx & 15; Pn[pr * 17 + q] = (q < nb) ? K[(size_t)pr * ldk + k0 + q] : 0.0; }
+            __syncthreads();
+            for (int kk = 0; kk < nb; kk++) {
+                const int k = k0 + kk;
+                if (tid < 64) {   // pivot search by wave 0 over logical rows k..NK-1
+                    double best = -1; int bi = k;
+                    for (int i = k + tid; i < NK; i += 64) { const double v = fabs(Pn[perm[i] * 17 + kk]); if (v > best) { best = v; bi = i; } }
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) {
+                        const double ob = __shfl_xor(best, o); const int oi = __shfl_xor(bi, o);
+                        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+                    }
+                    if (tid == 0) {
+                        const int t = perm[k]; perm[k] = perm[bi]; perm[bi] = t;
+                        if (best < ptol) { misc[2] = 1; }
+                    }
+                }
+                __syncthreads();
+                const int pk = perm[k];
+                double piv = Pn[pk * 17 + kk];
+                if (fabs(piv) < ptol) piv = (piv < 0 ? -ptol : ptol);
+                const double pinv = 1.0 / piv;
+                if (tid == 0) pivv[k] = piv;
+                for (int i = tid; i < NK; i += NT) {
+                    if (i == k) continue;
+                    double *row = Pn + perm[i] * 17;
+                    const double f = row[kk] * pinv;
+                    row[kk] = f;
+                    if (f != 0.0) for (int c = kk + 1; c < nb; c++) row[c] = fma(-f, Pn[pk * 17 + c], row[c]);
+                }
+                __syncthreads();
+            }
+            auto Lp = [&](int t, int u) -> double { return (t < nb && u < nb) ? Pn[perm[k0 + t] * 17 + u] : 0.0; };     // multiplier of pivot row t at step u (t != u)
+            if (tid < 16) {   // T^-1 by forward substitution, one column per thread
+                const int c = tid;
+                double x[16];
+#pragma unroll
+                for (int t = 0; t < 16; t++) {
+                    double v = (t == c) ? 1.0 : 0.0;
+#pragma unroll
+                    for (int u = 0; u < 16; u++) if (u < t) v = fma(-Lp(t, u), x[u], v);
+                    x[t] = v;
+                }
+#pragma unroll
+                for (int t = 0; t < 16; t++) Tm[t * 17 + c] = x[t];
+            }
+            for (int idx = tid; idx < 256; idx += NT) { const int t = idx >> 4, u = idx & 15; M2[t * 17 + u] = (t == u) ? 1.0 : (u > t ? -Lp(t, u) : 0.0); }
+            __syncthreads();
+            const int jt = k0 + nb;                         // first trailing column; the right-hand side is column NK
+            for (int ct = wave; jt + 16 * ct <= NK; ct += NW) {
+                const int col = jt + 16 * ct + lc; const bool cok = col <= NK;
+                v4d ut = {0.0, 0.0, 0.0, 0.0}, pf = {0.0, 0.0, 0.0, 0.0};
+                {
+                    double kp[4];
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; s4++) { const int t = 4 * s4 + lg; kp[s4] = (t < nb && cok) ? K[(size_t)perm[k0 + t] * ldk + col] : 0.0; }
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; s4++) ut = __builtin_amdgcn_mfma_f64_16x16x4f64(Tm[lc * 17 + 4 * s4 + lg], kp[s4], ut, 0, 0, 0);
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; s4++) pf = __builtin_amdgcn_mfma_f64_16x16x4f64(M2[lc * 17 + 4 * s4 + lg], ut[s4], pf, 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < 4; q++) { const int t = lg + 4 * q; if (t < nb && cok) K[(size_t)perm[k0 + t] * ldk + col] = pf[q]; }
+                }
+                for (int ti = 0; 16 * ti < NK; ti++) {
+                    if (ti == kb) continue;
+                    v4d acc; int prw[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) { const int i = 16 * ti + lg + 4 * q; prw[q] = i < NK ? perm[i] : -1; acc[q] = (prw[q] >= 0 && cok) ? K[(size_t)prw[q] * ldk + col] : 0.0; }
+                    const int ia = 16 * ti + lc;
+                    const double *lrow = Pn + (ia < NK ? perm[ia] : 0) * 17;
+#pragma unroll
+                    for (int s4 = 0; s4 < 4; s4++) {
+                        const double a = (ia < NK && 4 * s4 + lg < nb) ? -lrow[4 * s4 + lg] : 0.0;
+                        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, ut[s4], acc, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; q++) if (prw[q] >= 0 && cok) K[(size_t)prw[q] * ldk + col] = acc[q];
+                }
+            }
+            __syncthreads();
+        }
+        for (int k = tid; k < NK; k += NT) {
+            const double sol = K[(size_t)perm[k] * ldk + NK] / pivv[k];
+            if (k < n) rx[k] = sol; else bv[k - n] = sol;
+        }
+        __syncthreads();
+    } else {
     for (int k = 0; k < NK; k++) {
         if (tid < 64) {   // pivot search by wave 0 over logical rows k..NK-1
             double best = -1; int bi = k;
@@ -219,6 +380,7 @@ k_backward(DevT T, int nkcap, int ldk, const double *__restrict__ Avals, const d
         if (k < n) rx[k] = sol; else bv[k - n] = sol;
     }
     __syncthreads();
+    }
     // ---- q = A r_x ; r_y
     mv_rows_partial(A, lda, m, n, rx, part);
     __syncthreads();

@@ -99,6 +99,9 @@ __device__ __forceinline__ void mv_rows_partial(const double *Mat, int ld, int r
 // LDS doubles of the blocked Gauss-Jordan panels (G in global memory): column panel NP16 x 17, pivot block 16 x 17
 __host__ __device__ inline size_t generic_gj_panel_doubles(int n) { const int np16 = 16 * ((n + 15) / 16); return (size_t)np16 * 17 + 16 * 17 + 2; }
 
+// LDS doubles of the blocked pivoted elimination (generic backward kernel, K in global memory): column panel nkcap x 17, two 16 x 17 blocks, pivots
+__host__ __device__ inline size_t generic_lu_panel_doubles(int nkcap) { return (size_t)nkcap * 17 + 2 * 16 * 17 + (size_t)nkcap + 2; }
+
 #include "ce_math.h"
 
 __device__ __forceinline__ double clamp_scale(double v) { return v < MIN_SCALE ? 1.0 : (v > MAX_SCALE ? MAX_SCALE : v); }

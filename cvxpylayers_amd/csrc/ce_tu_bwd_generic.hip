@@ -3,6 +3,8 @@
 namespace {
 #include "ce_common.h"
 #include "ce_expcone.h"
+#include "ce_forward_rt.h"        // group_reduce / DPP helpers
+#include "ce_global_mv.h"
 #include "ce_backward.h"
 }  // namespace
 

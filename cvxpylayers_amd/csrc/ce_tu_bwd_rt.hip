@@ -6,6 +6,7 @@ namespace {
 #include "ce_expcone.h"
 #include "ce_forward_rt.h"
 #include "ce_forward_v2.h"
+#include "ce_global_mv.h"
 #include "ce_backward.h"
 #include "ce_backward_rt.h"
 }  // namespace

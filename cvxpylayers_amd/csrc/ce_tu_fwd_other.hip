@@ -4,6 +4,7 @@ namespace {
 #include "ce_common.h"
 #include "ce_expcone.h"
 #include "ce_forward_rt.h"        // (first: group_reduce / DPP helpers used by the size-generic kernel's global-memory products)
+#include "ce_global_mv.h"
 #include "ce_forward_generic.h"
 }  // namespace
 

@@ -38,6 +38,7 @@ namespace {
 #include "ce_expcone.h"
 #include "ce_forward_rt.h"     // NT2, SOC_SMALL, RT_NVEC / RT_EXTRA (launch planning); its kernels are instantiated in ce_tu_fwd_other.hip
 #include "ce_forward_v2.h"     // psd_project (used by k_ca_psd); k_fwd2 itself is instantiated in ce_tu_fwd2.hip
+#include "ce_global_mv.h"
 #include "ce_backward.h"       // k_transpose, k_parammap*  (k_backward is instantiated in ce_tu_bwd_generic.hip)
 #include "ce_backward_rt.h"    // bwd_rt_union_doubles, BGC (launch planning); kernels in ce_tu_bwd_rt.hip
 #include "ce_psd_mfma.h"
@@ -126,6 +127,7 @@ static size_t bwd_lds_bytes(const DevT &T, bool a_lds, bool k_lds, int nkcap, in
     if (a_lds) d += (size_t)m * T.lda;
     if (k_lds) d += (size_t)nkcap * ldk;
     d += 5 * (size_t)m + 2 * (size_t)n + 2 * (size_t)nqs * n + 6 * nqs + PB + NW * 8;
+    if (!k_lds) d += generic_lu_panel_doubles(nkcap);
     size_t ints = 2 * (size_t)m + 2 * nqs + nkcap + 4;
     return d * 8 + ints * 4 + 16;
 }
