@@ -34,7 +34,7 @@ k_backward(DevT T, int nkcap, int ldk, const double *__restrict__ Avals, const d
     double *cinfo = p; p += 6 * nqs; // per cone: lambda, nz, e_y.d, e_s.d, (spare)
     double *part = p; p += PB;
     double *red = p; p += NW * 8;
-    double *pan = p; if constexpr (!K_LDS) p += generic_lu_panel_doubles(nkcap);      // panels of the blocked elimination (K in global memory)
+    double *pan = p; if (!K_LDS && T.gen_blocked_b) p += generic_lu_panel_doubles(nkcap);      // panels of the blocked elimination (K in global memory)
     int *ip = (int *)p;
     int *rkind = ip; ip += m;        // row kind
     int *eqrow = ip; ip += m;        // equality index of row (RK_EQ) or -1
@@ -226,7 +226,7 @@ k_backward(DevT T, int nkcap, int ldk, const double *__restrict__ Avals, const d
         kmax = r[0];
     }
     const double ptol = 1e-13 * (kmax > 0 ? kmax : 1.0);
-    if constexpr (!K_LDS) {
+    if (!K_LDS && T.gen_blocked_b) {
         // BLOCKED Gauss-Jordan with partial pivoting, sixteen pivots per pass over the global-memory matrix (the unblocked loop below streams the
         // whole [K | rhs] once per pivot: at n = 200 that is 0.98 MB x NK steps per instance, HBM-bound).  Per block of columns k0 .. k0 + nb - 1:
         //   1. the column panel (all rows) goes to LDS and the nb pivot steps run on it alone: pivot search, multipliers L[i][kk] for every other row;

@@ -183,7 +183,7 @@ k_forward(DevT T, ce_settings S, const double *__restrict__ Avals, const double 
             G[a * ldg + b2] = acc0 + acc1 + (a == b2 ? rho_x : 0.0);
         }
         __syncthreads();
-        if constexpr (!G_LDS) {
+        if (!G_LDS && T.gen_blocked_f) {
             // BLOCKED Gauss-Jordan inversion of the global-memory S, sixteen pivots per step, every product on the matrix cores.  For the pivot
             // block K (rows / columns k0 .. k0 + 15):  P = S[K,K]^-1 ;  C = S[:,K], R = S[K,:] (panels in LDS) ;  W = -C P for rows outside K, W[K] = P ;
             //     S[i, j] <- (i outside K ? S[i, j] : 0) + W[i,:] R[:, j]   for columns j outside K ;      S[:, K] <- W

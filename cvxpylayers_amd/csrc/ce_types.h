@@ -18,6 +18,7 @@ struct DevT {
     int nep, eoff;        // exponential cones (3 rows each) and their first row (after the PSD blocks: SCS row order z,l,q,s,ep,p)
     int np;               // 3-d power cones, after the exponential cones
     const double *pw;     // [np] exponent a of x^a y^(1-a) >= |z|; a < 0: the dual cone of exponent |a| (SCS convention)
+    int gen_blocked_f, gen_blocked_b;   // size-generic kernels with G / K in global memory: LDS holds the panels of the blocked eliminations (else: unblocked)
 };
 
 // arguments of one forward launch (all kernels of the forward family take a subset)

@@ -98,13 +98,13 @@ static constexpr size_t LDS_LIMIT = 160 * 1024 - 512;   // debug build: room for
 static constexpr size_t LDS_LIMIT = 160 * 1024;
 #endif
 
-static size_t fwd_lds_bytes(const DevT &T, bool a_lds, bool g_lds) {
+static size_t fwd_lds_bytes(const DevT &T, bool a_lds, bool g_lds, bool panel = false) {
     const int n = T.n, m = T.m, l = n + m + 1, PB = std::max(NT, std::max(n, m));
     size_t d = 0;
     if (a_lds) d += (size_t)m * T.lda;
     if (g_lds) d += (size_t)n * T.ldg;
     d += 2 * (size_t)m + 2 * (size_t)n + 5 * (size_t)l + std::max(n, m) + 2 * (size_t)PB + NW * 8 + 2 * std::max(T.nq, 1) + NW + 2 * (size_t)n;
-    if (!g_lds) d += generic_gj_panel_doubles(n) + 2;      // panels of the blocked inversion of the global-memory G
+    if (!g_lds && panel) d += generic_gj_panel_doubles(n) + 2;      // panels of the blocked inversion of the global-memory G
     return d * 8 + 16;
 }
 // register-tiled forward variants: {CH1, T1, TG, CH2, T2}
@@ -121,13 +121,13 @@ static bool rt_fits(const DevT &T, int v, int *vp, size_t *bytes, int *lda_out) 
     *bytes = ((size_t)RT_NVEC * VP + RT_EXTRA + (size_t)T.m * lda) * 8;
     return *bytes <= LDS_LIMIT;
 }
-static size_t bwd_lds_bytes(const DevT &T, bool a_lds, bool k_lds, int nkcap, int ldk) {
+static size_t bwd_lds_bytes(const DevT &T, bool a_lds, bool k_lds, int nkcap, int ldk, bool panel = false) {
     const int n = T.n, m = T.m, PB = std::max(NT, std::max(n, m)), nqs = std::max(T.nq, 1);
     size_t d = 0;
     if (a_lds) d += (size_t)m * T.lda;
     if (k_lds) d += (size_t)nkcap * ldk;
     d += 5 * (size_t)m + 2 * (size_t)n + 2 * (size_t)nqs * n + 6 * nqs + PB + NW * 8;
-    if (!k_lds) d += generic_lu_panel_doubles(nkcap);
+    if (!k_lds && panel) d += generic_lu_panel_doubles(nkcap);
     size_t ints = 2 * (size_t)m + 2 * nqs + nkcap + 4;
     return d * 8 + ints * 4 + 16;
 }
@@ -335,7 +335,9 @@ int ce_create(const ce_template *tpl, int device, ce_handle *out) {
     else if (fwd_lds_bytes(T, true, false) <= LDS_LIMIT) h->fwd_mode = 1;
     else if (fwd_lds_bytes(T, false, false) <= LDS_LIMIT) h->fwd_mode = 2;
     else { ce_destroy(h); g_err = "instance vectors do not fit LDS"; return CE_E_TOO_LARGE; }
-    h->fwd_lds = fwd_lds_bytes(T, h->fwd_mode <= 1, h->fwd_mode == 0);
+    // (modes 1, 2: the blocked inversion needs its column panel in LDS; templates where that does not fit keep the unblocked loop)
+    T.gen_blocked_f = (h->fwd_mode >= 1 && fwd_lds_bytes(T, h->fwd_mode <= 1, false, true) <= LDS_LIMIT) ? 1 : 0;
+    h->fwd_lds = fwd_lds_bytes(T, h->fwd_mode <= 1, h->fwd_mode == 0, T.gen_blocked_f != 0);
     if (!getenv("CE_FORCE_GENERIC")) {
         for (int v = 0; v < 3; v++) { int vp, ld; size_t by; if (rt_fits(T, v, &vp, &by, &ld)) { h->rt_variant = v; h->rt_vp = vp; h->fwd_lds = by; h->fwd_mode = 3; h->rt_lda = ld; break; } }
     }
@@ -405,7 +407,8 @@ int ce_create(const ce_template *tpl, int device, ce_handle *out) {
     if (fwd_env && !strcmp(fwd_env, "generic") && h->fwd_mode == 3) {   // forced generic kernel
         h->rt_variant = -1;
         if (fwd_lds_bytes(T, true, true) <= LDS_LIMIT) h->fwd_mode = 0; else if (fwd_lds_bytes(T, true, false) <= LDS_LIMIT) h->fwd_mode = 1; else h->fwd_mode = 2;
-        h->fwd_lds = fwd_lds_bytes(T, h->fwd_mode <= 1, h->fwd_mode == 0);
+        T.gen_blocked_f = (h->fwd_mode >= 1 && fwd_lds_bytes(T, h->fwd_mode <= 1, false, true) <= LDS_LIMIT) ? 1 : 0;
+        h->fwd_lds = fwd_lds_bytes(T, h->fwd_mode <= 1, h->fwd_mode == 0, T.gen_blocked_f != 0);
     }
     h->nkcap = T.n + std::min(T.m, T.n);
     h->ldk = (h->nkcap + 1) | 1;
@@ -413,7 +416,8 @@ int ce_create(const ce_template *tpl, int device, ce_handle *out) {
     else if (bwd_lds_bytes(T, true, false, h->nkcap, h->ldk) <= LDS_LIMIT) h->bwd_mode = 1;
     else if (bwd_lds_bytes(T, false, false, h->nkcap, h->ldk) <= LDS_LIMIT) h->bwd_mode = 2;
     else { ce_destroy(h); g_err = "instance vectors do not fit LDS"; return CE_E_TOO_LARGE; }
-    h->bwd_lds = bwd_lds_bytes(T, h->bwd_mode <= 1, h->bwd_mode == 0, h->nkcap, h->ldk);
+    T.gen_blocked_b = (h->bwd_mode >= 1 && bwd_lds_bytes(T, h->bwd_mode <= 1, false, h->nkcap, h->ldk, true) <= LDS_LIMIT) ? 1 : 0;
+    h->bwd_lds = bwd_lds_bytes(T, h->bwd_mode <= 1, h->bwd_mode == 0, h->nkcap, h->ldk, T.gen_blocked_b != 0);
     if (!getenv("CE_FORCE_GENERIC")) {
         for (int v = 0; v < BRT_NV; v++) {
             const int TI = BRT_VARIANTS[v][0], TJ = BRT_VARIANTS[v][1], TH = BRT_VARIANTS[v][2], BGR = BRT_VARIANTS[v][3];
