@@ -405,6 +405,27 @@ def test_constant_A_path_with_exp_and_power_cones(monkeypatch):
     assert np.abs(dq.cpu().numpy()[:n] - g["dc"].T).max() < 1e-5 * (1 + np.abs(g["dc"]).max())
 
 
+def test_anderson_acceleration_gives_up_like_the_oracle_on_linear_programs():
+    """The give-up rule (AA_MAX_REJECT safeguard rejections) in k_fwd2 and in the oracle: on slowly converging random LPs both switch the
+    acceleration off for the same instances, so iteration counts stay within a check interval or two and nobody runs into the limit."""
+    from oracle import oracle
+    from cvxpylayers_amd.interfaces.mi355_if import make_settings
+    cfg = P.CONFIGS["C2"]; n, cones, B = cfg["n"], cfg["cones"], 32
+    tpl = P.dense_template(n, cones)
+    A, b, c = P.generate(n, cones, B, seed=0)
+    eng = _engine_for(tpl)
+    A_eval, q_eval = tpl.values_from_dense(A, b, c)
+    A_bm = eng.to_batch_major(torch.from_numpy(A_eval).cuda()); q_t = torch.from_numpy(q_eval).cuda()
+    ref = oracle.solve_batch(A, b, c, cones, eps=1e-4, max_iters=20000, acceleration_lookback=1)
+    plain = oracle.solve_batch(A, b, c, cones, eps=1e-4, max_iters=20000)
+    x, y, s, iters, status, resid = eng.solve(A_bm, q_t, make_settings(dict(eps=1e-4, max_iters=20000, acceleration_lookback=1)))
+    it = iters.cpu().numpy()
+    assert (status.cpu().numpy() == 1).all() and (ref["status"] == 1).all()
+    assert it.mean() < 1.25 * plain["iters"].mean(), (it.mean(), plain["iters"].mean())
+    # (after the acceleration is off both sides run the plain iteration from slightly different points: counts agree loosely)
+    assert np.median(np.abs(it - ref["iters"]) / ref["iters"]) < 0.2, (it, ref["iters"])
+
+
 def test_anderson_acceleration_matches_the_oracle_with_memory_one():
     """acceleration_lookback > 0: k_fwd2 applies type-I Anderson acceleration with a one-pair history every acceleration_interval
     iterations; the oracle with aa_mem = 1 is the same algorithm (iteration counts within one check interval, same solutions,

@@ -300,6 +300,22 @@ def test_qp_adjoint_matches_finite_differences_including_dP():
     assert abs(fd - g["dA"][0, 3, 2]) < 2e-5 * (1 + abs(fd))
 
 
+def test_anderson_acceleration_gives_up_on_slow_linear_programs():
+    """Random LPs (nonnegative cone only) converge slowly under splitting and most accelerated steps of a short history are rejected by the
+    safeguard; after AA_MAX_REJECT rejections the acceleration is switched off for the instance, so the accelerated run stays close to
+    the plain iteration (without the rule: 3x the iterations and instances that do not finish in 20000)."""
+    from cvxpylayers_amd import problems as P
+    cfg = P.CONFIGS["C2"]
+    A, b, c = P.generate(cfg["n"], cfg["cones"], 24, seed=0)
+    plain = oracle.solve_batch(A, b, c, cfg["cones"], eps=1e-4, max_iters=20000)
+    acc = oracle.solve_batch(A, b, c, cfg["cones"], eps=1e-4, max_iters=20000, acceleration_lookback=1)
+    assert (plain["status"] == 1).all() and (acc["status"] == 1).all()
+    assert acc["iters"].mean() < 1.25 * plain["iters"].mean(), (acc["iters"].mean(), plain["iters"].mean())
+    # (LP optima at eps 1e-4 are flat: compare objective values, not minimisers)
+    fa, fp = (c * acc["x"]).sum(axis=1), (c * plain["x"]).sum(axis=1)
+    np.testing.assert_allclose(fa, fp, rtol=2e-3, atol=2e-3)
+
+
 def test_anderson_acceleration_reaches_the_same_solution_in_fewer_iterations():
     # type-I Anderson acceleration of the iteration map (SCS acceleration_lookback / acceleration_interval), off by default
     from cvxpylayers_amd import problems as P
