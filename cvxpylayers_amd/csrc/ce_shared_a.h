@@ -10,7 +10,7 @@
 // dense contractions of the PSD cone's derivative   DPi(V)[H] = U (B o (U^T H U)) U^T   run on the matrix cores (ce_psd_mfma.h).
 // diffcp itself solves M^T r = dz with LSQR (its default mode); stopping rule and recurrences are Paige & Saunders', as in the oracle.
 //
-// Cones: zero / nonnegative / second-order / PSD (exponential and power cones take the batched torch path of const_a.py).
+// Cones: zero / nonnegative / second-order / PSD / exponential / 3-d power.
 #pragma once
 #include "ce_shared_a_ops.h"
 
@@ -44,10 +44,10 @@ __device__ __forceinline__ void sa_spmv(const int *__restrict__ ptr, const int *
 
 // LDS doubles.  nvv: rows in front of the first PSD block (v = y - s is kept for those only; PSD blocks read y - s once, at the start).
 // The partial sums of the dense-row products (2 NT doubles) share the PSD scratch matrices when the template has PSD blocks.
-__host__ __device__ inline size_t sa_lsqr_lds_doubles(int n, int m, int nq, int ns, int maxs, int RP, int nvv) {
+__host__ __device__ inline size_t sa_lsqr_lds_doubles(int n, int m, int nq, int ns, int maxs, int RP, int nvv, int ntri = 0) {
     const int kp = ns > 0 ? psd_mfma_kp(maxs) : 0;
     return (size_t)(RP > 0 ? 2 * RP + (ns > 0 ? 0 : 2 * NT) : 0) + (size_t)(ns > 0 ? (2 * ns + 2) * kp * (kp + 1) + 2 * kp + 8 : 0) + NW * 8 +
-           (size_t)(nvv + (nvv & 1)) + 6 * (size_t)m + 4 * (size_t)n + 5 * (size_t)(nq > 0 ? nq : 1) + 16;
+           (size_t)(nvv + (nvv & 1)) + 6 * (size_t)m + 4 * (size_t)n + 5 * (size_t)(nq > 0 ? nq : 1) + 16 + 9 * (size_t)ntri + (ntri & 1);
 }
 
 // RP > 0: A is applied through its split into singleton rows and r <= RP dense rows (ce_shared_a_ops.h: balanced, wide loads); RP == 0: through
@@ -62,7 +62,8 @@ k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, cons
     const int n = T.n, m = T.m, z = T.z, nl = T.l, nq = T.nq, ns = T.ns;
     const int KP = ns > 0 ? psd_mfma_kp(T.maxs) : 0, P = KP + 1, PM = KP * P;
     const float rKP = KP > 0 ? 1.0f / (float)KP : 1.0f;
-    const int psd_first = ns > 0 ? T.soff[0] : m, nvv = psd_first + (psd_first & 1);
+    const int ntri = T.nep + T.np;
+    const int psd_first = ns > 0 ? T.soff[0] : T.eoff, nvv = psd_first + (psd_first & 1);      // rows in front of the PSD blocks / the triples
     double *p = sm;                                          // (everything read with 16-byte accesses sits at the start: even sizes only)
     double *wyd = p, *vd = p, *part = p;
     if constexpr (RP > 0) { wyd = p; p += RP; vd = p; p += RP; if (ns == 0) { part = p; p += 2 * NT; } }
@@ -76,6 +77,8 @@ k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, cons
     double *uy = p; p += m; double *vy = p; p += m; double *wy = p; p += m; double *ry = p; p += m; double *ty = p; p += m; double *qv = p; p += m;
     double *ux = p; p += n; double *vx = p; p += n; double *wx = p; p += n; double *rx = p; p += n;
     double *socs = p; p += 5 * (nq > 0 ? nq : 1);          // per cone: t, |z|, case, z.h ; then h_0 per cone
+    p += (size_t)(p - sm) & 1;
+    double *Jt = p; p += 9 * (size_t)ntri;                    // exponential / power triples: symmetrised 3 x 3 derivative of the dual-cone projection
     const double *x = xg + (size_t)inst * n, *y = yg + (size_t)inst * m, *s = sg + (size_t)inst * m;
 
     for (int i = tid; i < psd_first; i += NT) vv[i] = y[i] - s[i];
@@ -90,6 +93,18 @@ k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, cons
             socs[4 * c] = t; socs[4 * c + 1] = nz;
             socs[4 * c + 2] = (r1 - r0 == 1) ? (t >= 0 ? 0.0 : 1.0) : (nz <= t ? 0.0 : (nz <= -t ? 1.0 : 2.0));     // 0 identity, 1 zero, 2 boundary
         }
+    }
+    for (int c = tid; c < ntri; c += NT) {   // D Pi_K*(v) of every triple (k_ca_triple_jac; symmetrised like the batched path does)
+        const int e0 = T.eoff + 3 * c;
+        const double v3[3] = {y[e0] - s[e0], y[e0 + 1] - s[e0 + 1], y[e0 + 2] - s[e0 + 2]};
+        double w3[3] = {-v3[0], -v3[1], -v3[2]}, J[9];
+        if (c < T.nep) { exp_dproject(w3, J); for (int i = 0; i < 9; i++) J[i] = ((i % 4 == 0) ? 1.0 : 0.0) - J[i]; }
+        else {
+            const double a = T.pw[c - T.nep];
+            if (a < 0) pow_dproject(v3, -a, J);
+            else { pow_dproject(w3, a, J); for (int i = 0; i < 9; i++) J[i] = ((i % 4 == 0) ? 1.0 : 0.0) - J[i]; }
+        }
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Jt[9 * c + 3 * i + j] = 0.5 * (J[3 * i + j] + J[3 * j + i]);
     }
     for (int c = 0; c < ns; c++) {      // eigenvectors and divided differences of every PSD block (cold Jacobi, once)
         const int k = T.sord[c];
@@ -175,6 +190,12 @@ k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, cons
                 sink(off + b * k - (b * (b - 1)) / 2 + (a - b), (a == b) ? v0 : v0 * M_SQRT2);
             }
             if (c + 1 < ns) __syncthreads();                       // (Hm is reused by the next block)
+        }
+        for (int c = tid; c < ntri; c += NT) {     // triples: o = J h (the thread reads its three entries before it sinks them)
+            const int e0 = T.eoff + 3 * c;
+            const double h0 = h[e0] * hs, h1 = h[e0 + 1] * hs, h2 = h[e0 + 2] * hs;
+            const double *J = Jt + 9 * c;
+            sink(e0, J[0] * h0 + J[1] * h1 + J[2] * h2); sink(e0 + 1, J[3] * h0 + J[4] * h1 + J[5] * h2); sink(e0 + 2, J[6] * h0 + J[7] * h1 + J[8] * h2);
         }
     };
     // the two products of one operator application share their barriers.  On return (synchronised): fx(j, (A^T yin)_j) was called for every

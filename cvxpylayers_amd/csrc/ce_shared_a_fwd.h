@@ -12,7 +12,7 @@
 // live in LDS; termination, certificates and the adaptive scale run in the kernel (no host round trip); the PSD cone is projected by
 // the warm-started MFMA routine of ce_psd_mfma.h with the eigenvectors kept in LDS between iterations.
 // Algorithm, constants and order of operations: oracle/cone_oracle.c (SCS 3 restated) / cvxpylayers_amd/interfaces/const_a.py.
-// Cones: zero / nonnegative / second-order / PSD.
+// Cones: zero / nonnegative / second-order / PSD / exponential / 3-d power.
 #pragma once
 #include "ce_shared_a_ops.h"
 
@@ -32,11 +32,11 @@ struct SaFwd {
 __host__ __device__ inline size_t sa_fwd_cidx_doubles(int n, int m, int nq, int r, int nsing) {
     return 2 * (size_t)m + ((size_t)(n + 1 + (nsing > 0 ? nsing : 1)) + 1) / 2 + ((size_t)(nq + 1 + (r > 0 ? r : 1)) + 1) / 2 + 2;
 }
-__host__ __device__ inline size_t sa_fwd_lds_doubles(int n, int m, int nq, int ns, int maxs, int RP, int nth) {
+__host__ __device__ inline size_t sa_fwd_lds_doubles(int n, int m, int nq, int ns, int maxs, int RP, int nth, int ntri = 0) {
     const int l = n + m + 1, lp = l + (l & 1), ne = n + (n & 1), me = m + (m & 1);
     const int kp = ns > 0 ? psd_mfma_kp(maxs) : 0;
     return 6 * (size_t)lp + 2 * (size_t)ne + 2 * (size_t)me + 2 * (size_t)RP * (RP + 1) + 5 * (size_t)RP + 2 * (size_t)(nq > 0 ? nq : 1) +
-           (size_t)(ns > 0 ? (ns + 2) * kp * (kp + 1) + 2 * kp + 8 : 0) + 2 * nth + (nth / 64) * 8 + 32;
+           (size_t)(ns > 0 ? (ns + 2) * kp * (kp + 1) + 2 * kp + 8 : 0) + 2 * nth + (nth / 64) * 8 + 32 + (size_t)(ntri + (ntri & 1));
 }
 
 // NTH threads per instance: 256 (two instances per CU when the iterates allow it) or 512 (templates whose iterates fill most of a CU's LDS
@@ -71,6 +71,8 @@ k_sa_fwd(DevT T, SaFwd F, ce_settings S, const double *__restrict__ BHg, const d
     double *part = p; p += 2 * NT;                              // partial sums of the dense-row products
     double *red = p; p += NW * 8;
     double *sc = p; p += 32;
+    const int ntri = T.nep + T.np;
+    double *troot = p; p += ntri + (ntri & 1);              // exponential / power triples: root of the previous projection (warm start of the Newton iteration)
     const int *c_srow_col = F.srow_col, *c_rowcone = T.rowcone, *c_scol_ptr = F.scol_ptr, *c_scol_row = F.scol_row, *c_qoff = T.qoff, *c_drow = F.drow;
     const double *c_srow_val = F.srow_val;
     if constexpr (CIDX) {
@@ -93,6 +95,7 @@ k_sa_fwd(DevT T, SaFwd F, ce_settings S, const double *__restrict__ BHg, const d
 
     for (int i = tid; i < m; i += NT) bh[i] = BHg[(size_t)inst * m + i];
     for (int e = tid; e < lp; e += NT) { W[e] = 0.0; UT[e] = 0.0; U[e] = 0.0; }
+    for (int c = tid; c < ntri; c += NT) troot[c] = 0.0;
     ce_math_table_init(sc + 12, tid);                       // sc[12 ..]: ce_math.h coefficient table (CE_MATH_TAB = 18 <= 20)
     __syncthreads();
     const double *mtab = sc + 12;
@@ -291,6 +294,13 @@ k_sa_fwd(DevT T, SaFwd F, ce_settings S, const double *__restrict__ BHg, const d
                     for (int i = tid + z + nl; i < m; i += NT) { const int c = c_rowcone[i]; if (c >= 0) zb[n + i] = (i == c_qoff[c]) ? socc[2 * c] : socc[2 * c + 1] * zb[n + i]; }
                     __syncthreads();
                 }
+            }
+            if (ntri > 0) {    // exponential / power cone triples (after the PSD blocks): one thread per cone, in place (ce_expcone.h)
+                for (int c = tid; c < ntri; c += NT) {
+                    double *zc = zb + n + T.eoff + 3 * c;
+                    if (c < T.nep) exp_project_dual(zc, troot + c); else pow_project_dual_of_entry(zc, T.pw[c - T.nep], troot + c);
+                }
+                __syncthreads();
             }
             // the projected value of element e (second-order cone rows are scaled here when there is no PSD block, saving a pass and a barrier)
             auto proj_e = [&](int e) -> double {

@@ -118,11 +118,11 @@ __device__ __forceinline__ void sa_fused_pass(const double *__restrict__ AdT, in
     }
 }
 
-// y = A x :  out(i, value) for every row i.  vd: RP doubles, part: 2 NTH doubles of LDS.  Ends synchronised.
+// y = A x :  out(i, value) for every row i  (srow_col: >= 0 column of a single-entry row, -1 empty row, <= -2 dense row).  vd: RP doubles, part: 2 NTH doubles of LDS.  Ends synchronised.
 template <int NTH, int RP, class ST, class FO>
 __device__ __forceinline__ void sa_A_times(const ST &F, int n, int m, const double *xin, double *part, double *vd, FO &&out) {
     sa_dense_times<NTH, RP>(F.AdT, n, xin, part, vd);
-    for (int i = threadIdx.x; i < m; i += NTH) { const int c = F.srow_col[i]; if (c >= 0) out(i, F.srow_val[i] * xin[c]); }
+    for (int i = threadIdx.x; i < m; i += NTH) { const int c = F.srow_col[i]; if (c >= 0) out(i, F.srow_val[i] * xin[c]); else if (c == -1) out(i, 0.0); }      // (-1: a row without entries; dense rows carry -2 - slot here)
     for (int a = threadIdx.x; a < F.r; a += NTH) out(F.drow[a], vd[a]);
     __syncthreads();
 }

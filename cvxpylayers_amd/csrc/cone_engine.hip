@@ -260,7 +260,7 @@ int ce_create(const ce_template *tpl, int device, ce_handle *out) {
     T.ns = tpl->ns; T.maxs = 0;
     for (int c = 0; c < tpl->ns; c++) { soff[c] = r; sord[c] = tpl->s[c]; T.maxs = std::max(T.maxs, tpl->s[c]); r += tpl->s[c] * (tpl->s[c] + 1) / 2; }
     soff[tpl->ns] = r;
-    h->psd_first = tpl->ns > 0 ? soff[0] : tpl->m;
+    h->psd_first = soff[0];      // (= first row after the second-order cones: PSD blocks, then exponential / power triples, follow)
     T.nep = tpl->nep; T.eoff = r; T.np = tpl->np; T.pw = nullptr;
     if (tpl->np > 0) {
         HIPCHK(hipMalloc(&h->d_pw, sizeof(double) * tpl->np));
@@ -653,14 +653,13 @@ int ce_solve_shared_a(ce_handle h, int B, int r, int RP, const double *AdT, cons
     if (!h || B <= 0 || !AdT || !drow || !srow_col || !srow_val || !scol_ptr || !scol_row || !gs || !Dv || !Ev || !b_hat || !c_hat || !sigma || !nrm_b0 || !nrm_c0 ||
         !settings || !x || !y || !s || !iters || !status) { g_err = "null argument"; return CE_E_BADARG; }
     const DevT &T = h->T;
-    if (T.nep + T.np > 0) { g_err = "shared-A forward kernel: exponential / power cones are not implemented"; return CE_E_UNSUPPORTED; }
     if (r < 0 || r > RP || (RP != 16 && RP != 32 && RP != 64)) { g_err = "shared-A forward kernel: at most 64 dense rows (RP in 16, 32, 64)"; return CE_E_UNSUPPORTED; }
     // 512 threads per instance when the iterates of one instance leave room for a single workgroup per CU anyway (CE_SA_NT=256 / 512 forces);
     // that instantiation also keeps the template's index arrays in LDS when they fit (CE_SA_CIDX=0 disables)
     int nth = 256;
-    if (T.ns == 0 && sa_fwd_lds_doubles(T.n, T.m, T.nq, T.ns, T.maxs, RP, 256) * 8 > LDS_LIMIT / 2) nth = 512;
+    if (T.ns == 0 && sa_fwd_lds_doubles(T.n, T.m, T.nq, T.ns, T.maxs, RP, 256, T.nep + T.np) * 8 > LDS_LIMIT / 2) nth = 512;
     if (const char *e = getenv("CE_SA_NT")) { const int v = atoi(e); if (v == 256 || (v == 512 && T.ns == 0)) nth = v; }
-    size_t lds = sa_fwd_lds_doubles(T.n, T.m, T.nq, T.ns, T.maxs, RP, nth) * 8;
+    size_t lds = sa_fwd_lds_doubles(T.n, T.m, T.nq, T.ns, T.maxs, RP, nth, T.nep + T.np) * 8;
     if (lds > LDS_LIMIT) { g_err = "shared-A forward kernel: the iterates of one instance do not fit LDS"; return CE_E_TOO_LARGE; }
     bool cidx = false;
     if (nth == 512) {
@@ -692,12 +691,11 @@ int ce_vjp_shared_a(ce_handle h, int B, const double *A_vals0, const double *x, 
                     double *dA_bm, double *dq_vals, long sdq_k, long sdq_b, int *adj_status, int *lsqr_iters, double atol, double btol, int iter_lim, void *stream) {
     if (!h || B <= 0 || !A_vals0 || !x || !y || !s || !dx || !dy || !dA_bm || !dq_vals) { g_err = "null argument"; return CE_E_BADARG; }
     const DevT &T = h->T;
-    if (T.nep + T.np > 0) { g_err = "shared-A adjoint kernel: exponential / power cones are not implemented"; return CE_E_UNSUPPORTED; }
     // products through the singleton / dense-row split when the template has one (CE_SA_SPLIT=0: CSR / CSC products)
     int RP = h->sp_RP;
     if (const char *e = getenv("CE_SA_SPLIT")) { if (atoi(e) == 0) RP = 0; }
-    if (RP > 0 && sa_lsqr_lds_doubles(T.n, T.m, T.nq, T.ns, T.maxs, RP, h->psd_first) * 8 > LDS_LIMIT) RP = 0;
-    const size_t lds = sa_lsqr_lds_doubles(T.n, T.m, T.nq, T.ns, T.maxs, RP, h->psd_first) * 8;
+    if (RP > 0 && sa_lsqr_lds_doubles(T.n, T.m, T.nq, T.ns, T.maxs, RP, h->psd_first, T.nep + T.np) * 8 > LDS_LIMIT) RP = 0;
+    const size_t lds = sa_lsqr_lds_doubles(T.n, T.m, T.nq, T.ns, T.maxs, RP, h->psd_first, T.nep + T.np) * 8;
     if (lds > LDS_LIMIT) { g_err = "shared-A adjoint kernel: the LSQR vectors of one instance do not fit LDS"; return CE_E_TOO_LARGE; }
     HIPCHK(hipSetDevice(h->device));
     static bool attr_done = false;

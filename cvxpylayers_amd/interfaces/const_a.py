@@ -152,7 +152,7 @@ def solve_const_a(eng, A_bm: torch.Tensor, q_eval: torch.Tensor, settings, warm=
     #      Taken whenever the template has that shape, the Woodbury form is stable and the iterates fit LDS (measured against the batch-GEMM
     #      path below: 28 vs 40 ms at BASELINE config 4, 420 vs 480 ms at config 5 with B = 16384); CE_SA_FWD=0 disables.
     _saf = os.environ.get("CE_SA_FWD")
-    if _saf != "0" and not ntri:
+    if _saf != "0":
         split = eng._ca_cache.get("split")
         if split is None:
             row_nnz = np.bincount(indices[:nnzA], minlength=m)

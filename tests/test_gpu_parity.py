@@ -405,6 +405,57 @@ def test_constant_A_path_with_exp_and_power_cones(monkeypatch):
     assert np.abs(dq.cpu().numpy()[:n] - g["dc"].T).max() < 1e-5 * (1 + np.abs(g["dc"]).max())
 
 
+def test_shared_A_kernels_with_exp_and_power_cones(monkeypatch):
+    """Exponential / power triples inside the persistent shared-A kernels (k_sa_fwd: in-place projection with the previous root as warm
+    start; k_sa_lsqr: symmetrised 3 x 3 derivative per triple).  Template in the shape canonicalisation produces: bounds on every variable
+    (single-entry rows), a dense equality row, triples made of a dense row, an EMPTY row (constant 1) and a single-entry row."""
+    from oracle import oracle
+    monkeypatch.setenv("CE_CONST_A", "1")
+    n = 9
+    cones = {"z": 1, "l": n, "q": [3], "s": [], "ep": 2, "p": [0.35]}
+    m = P.cone_rows(cones)
+    rng = np.random.default_rng(5)
+    A = np.zeros((m, n)); r = 0
+    A[r, :6] = rng.standard_normal(6); r += 1                          # equality: dense row
+    A[r:r + n, :] = -np.eye(n); r += n                                  # x >= lo
+    A[r, 6] = -1.0; A[r + 1, 0] = -1.0; A[r + 2, 1] = -1.0; r += 3      # SOC(3) of single-entry rows
+    for t in range(3):                                                  # two exponential triples, one power triple
+        A[r, :6] = -rng.standard_normal(6) * 0.5                        # (x.w, 1, z)-style: dense row, empty row, epigraph variable
+        A[r + 2, 6 + (t % 3)] = -1.0
+        r += 3
+    assert r == m
+    B = 10
+    x0 = rng.standard_normal((B, n)) * 0.3
+    s0 = np.zeros((B, m)); s0[:, 1:1 + n] = 1.0 + rng.random((B, n)); s0[:, 1 + n] = 2.0
+    for t in range(2): s0[:, 4 + n + 3 * t:7 + n + 3 * t] = np.array([-0.3, 1.0, 1.5])       # interior of the exponential cone: y exp(x / y) < z
+    s0[:, 10 + n:13 + n] = np.array([1.2, 1.1, 0.4])                                        # interior of the power cone
+    b = x0 @ A.T + s0
+    # a strictly feasible dual point per instance makes the program solvable: c = -A^T y0, y0 in the interior of K*
+    y0 = np.zeros((B, m)); y0[:, 0] = rng.standard_normal(B); y0[:, 1:1 + n] = 0.5 + rng.random((B, n)); y0[:, 1 + n:4 + n] = np.array([2.0, 0.5, -0.5])
+    for t in range(2): y0[:, 4 + n + 3 * t:7 + n + 3 * t] = np.array([-1.0, 0.5, 1.0])       # -u exp(v / u) = exp(-0.5) <= e w
+    y0[:, 10 + n:13 + n] = np.array([1.0, 1.0, 0.3])
+    y0 *= (0.5 + rng.random((B, 1)))
+    c = -(y0 @ A)
+    tpl = P.dense_template(n, cones, pattern=(A != 0))
+    Ab = np.broadcast_to(A, (B,) + A.shape).copy()
+    ref = oracle.solve_batch(Ab, b, c, cones, eps=1e-9, max_iters=200000)
+    ok = ref["status"] == 1
+    assert ok.mean() > 0.5, ref["status"]
+    eng, A_bm, x, y, s, iters, status, resid = gpu_solve(tpl, Ab, b, c, eps=1e-9, max_iters=200000)
+    assert eng.last_path == "const_a" and eng.last_const_a_kernel == "k_sa_fwd"
+    assert (status[ok] == 1).all(), status
+    for got, want in ((x, ref["x"]), (y, ref["y"]), (s, ref["s"])):
+        assert np.abs(got.cpu().numpy()[ok] - want[ok]).max() < 1e-6 * (1 + np.abs(want[ok]).max())
+    dx = rng.standard_normal(ref["x"].shape); dy = rng.standard_normal(ref["y"].shape)
+    g = oracle.adjoint_batch(Ab, b, c, cones, ref["x"], ref["y"], ref["s"], dx, dy, mode="dense")
+    xr, yr, sr = (torch.from_numpy(ref[k]).cuda() for k in ("x", "y", "s"))
+    dA, dq, adj = eng.vjp(A_bm, xr, yr, sr, torch.from_numpy(dx).cuda(), torch.from_numpy(dy).cuda())
+    assert eng.last_lsqr_iters is not None
+    good = ok & (adj.cpu().numpy() == 0)
+    assert good.mean() > 0.5
+    assert np.abs(dq.cpu().numpy()[:n].T[good] - g["dc"][good]).max() < 1e-5 * (1 + np.abs(g["dc"][good]).max())
+
+
 def test_anderson_acceleration_gives_up_like_the_oracle_on_linear_programs():
     """The give-up rule (AA_MAX_REJECT safeguard rejections) in k_fwd2 and in the oracle: on slowly converging random LPs both switch the
     acceleration off for the same instances, so iteration counts stay within a check interval or two and nobody runs into the limit."""
