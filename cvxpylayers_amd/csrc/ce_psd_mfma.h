@@ -51,118 +51,13 @@ __device__ __forceinline__ void psd_mfma_gemm(int KT, FA &&fa, FB &&fb, FO &&out
     }
 }
 
-// cyclic Jacobi sweeps on S (k x k, pitch P), rotations accumulated into the columns of V (pitch P); same tournament order and
-// rotation formulas as psd_jacobi.  On return diag(S) holds the eigenvalues and the columns of V the eigenvectors.
-template <int NTH>
-__device__ __forceinline__ void psd_sweeps(double *Sm, double *Vm, int k, int P, double *cs, double *red) {
-    constexpr int NT = NTH, NW = NTH / 64;
-    const int tid = threadIdx.x;
-    const int K = (k + 1) & ~1;
-    double prev_off = 0;
-    for (int sweep = 0; sweep < 40; sweep++) {
-        double r[2] = {0, 0};
-        for (int idx = tid; idx < k * k; idx += NT) { const int i = idx / k, j = idx - i * k; const double v = Sm[i * P + j]; if (i == j) r[1] = fma(v, v, r[1]); else r[0] = fma(v, v, r[0]); }
-        block_reduce_n<2, NW>(r, 0u, red);
-        if (r[0] <= 1e-30 * (r[0] + r[1]) || r[0] == 0.0 || (r[0] <= 1e-24 * (r[0] + r[1]) && r[0] > 0.25 * prev_off)) break;          // uniform (see psd_sweeps_wave)
-        prev_off = r[0];
-        for (int rd = 0; rd < K - 1; rd++) {
-            if (tid < K / 2) {
-                int p = (tid == 0) ? K - 1 : (rd + tid) % (K - 1);
-                int q = (rd + K - 1 - tid) % (K - 1);
-                if (p > q) { const int t_ = p; p = q; q = t_; }
-                double c = 1.0, sn = 0.0;
-                if (q < k) {
-                    psd_rotation(Sm[p * P + p], Sm[q * P + q], Sm[p * P + q], c, sn);
-                } else { p = -1; }
-                cs[4 * tid] = c; cs[4 * tid + 1] = sn; cs[4 * tid + 2] = (double)p; cs[4 * tid + 3] = (double)q;
-            }
-            __syncthreads();
-            for (int idx = tid; idx < (K / 2) * k * 2; idx += NT) {          // column pass on S and V
-                const int which = idx / ((K / 2) * k), rem = idx - which * (K / 2) * k;
-                const int pi = rem / k, row = rem - pi * k;
-                const int p = (int)cs[4 * pi + 2], q = (int)cs[4 * pi + 3];
-                if (p < 0) continue;
-                const double c = cs[4 * pi], sn = cs[4 * pi + 1];
-                double *M = which ? Vm : Sm;
-                const double a = M[row * P + p], b = M[row * P + q];
-                M[row * P + p] = c * a - sn * b; M[row * P + q] = sn * a + c * b;
-            }
-            __syncthreads();
-            for (int idx = tid; idx < (K / 2) * k; idx += NT) {              // row pass on S
-                const int pi = idx / k, col = idx - pi * k;
-                const int p = (int)cs[4 * pi + 2], q = (int)cs[4 * pi + 3];
-                if (p < 0) continue;
-                const double c = cs[4 * pi], sn = cs[4 * pi + 1];
-                const double a = Sm[p * P + col], b = Sm[q * P + col];
-                Sm[p * P + col] = c * a - sn * b; Sm[q * P + col] = sn * a + c * b;
-            }
-            __syncthreads();
-        }
-    }
-}
-
-// The same sweeps executed by ONE wave (lanes of wave 0), without workgroup barriers: a k <= 64 Jacobi round is two short phases
-// of independent work -- (A) K/2 rotation parameters, (B) the two-sided update S <- J^T S J done on the (K/2)^2 disjoint 2 x 2 blocks
-// {p_a, q_a} x {p_b, q_b} together with the column rotations V <- V J -- and an s_barrier between phases costs more than the phase
-// (~700 cycles against ~150 when the wave just orders its own LDS accesses).  All waves call it; ends with a workgroup barrier.
-template <int NTH>
-__device__ __forceinline__ void psd_sweeps_wave(double *Sm, double *Vm, int k, int P, double *cs, double *red) {
-    (void)red;
-    const int tid = threadIdx.x;
-    const int K = (k + 1) & ~1, H = K / 2;
-    const float rk = 1.0f / (float)k, rH = 1.0f / (float)H;
-    if (tid < 64) {
-        const int lane = tid;
-        double prev_off = 0;
-        for (int sweep = 0; sweep < 40; sweep++) {
-            double r0 = 0, r1 = 0;
-            for (int idx = lane; idx < k * k; idx += 64) { const int i = psd_fdiv(idx, rk), j = idx - i * k; const double v = Sm[i * P + j]; if (i == j) r1 = fma(v, v, r1); else r0 = fma(v, v, r0); }
-            r0 = wave_reduce_dpp<false>(r0); r1 = wave_reduce_dpp<false>(r1);
-            // converged: off-diagonal mass below 1e-15 of the total, or -- the warm-started matrix S' = V^T S V carries rounding noise of a
-            // few 1e-16 |S| per entry, so that target can sit below the floor -- already tiny (1e-12) and no longer decreasing
-            if (r0 <= 1e-30 * (r0 + r1) || r0 == 0.0 || (r0 <= 1e-24 * (r0 + r1) && r0 > 0.25 * prev_off)) break;          // wave-uniform
-            prev_off = r0;
-            for (int rd = 0; rd < K - 1; rd++) {
-                for (int t = lane; t < H; t += 64) {
-                    int p = rd + t; if (p >= K - 1) p -= K - 1;                    // (rd + t) % (K - 1), both terms < K - 1
-                    if (t == 0) p = K - 1;
-                    int q = rd + K - 1 - t; if (q >= K - 1) q -= K - 1;
-                    if (p > q) { const int t_ = p; p = q; q = t_; }
-                    double c = 1.0, sn = 0.0;
-                    if (q < k) {
-                        psd_rotation(Sm[p * P + p], Sm[q * P + q], Sm[p * P + q], c, sn);
-                    } else { q = -1; }                                 // the dummy player of an odd order: p is left alone this round
-                    cs[4 * t] = c; cs[4 * t + 1] = sn; cs[4 * t + 2] = (double)p; cs[4 * t + 3] = (double)q;
-                }
-                wave_lds_exchange();
-                for (int blk = lane; blk < H * H; blk += 64) {         // S <- J^T S J on the 2 x 2 block (pair a) x (pair b)
-                    const int a = psd_fdiv(blk, rH), b = blk - a * H;
-                    const double ca = cs[4 * a], sa = cs[4 * a + 1], cb = cs[4 * b], sb = cs[4 * b + 1];
-                    const int pa = (int)cs[4 * a + 2], qa = (int)cs[4 * a + 3], pb = (int)cs[4 * b + 2], qb = (int)cs[4 * b + 3];
-                    const double s00 = Sm[pa * P + pb], s01 = qb >= 0 ? Sm[pa * P + qb] : 0.0, s10 = qa >= 0 ? Sm[qa * P + pb] : 0.0, s11 = (qa >= 0 && qb >= 0) ? Sm[qa * P + qb] : 0.0;
-                    // columns:  (x_p, x_q) <- (c x_p - s x_q, s x_p + c x_q)   then rows likewise
-                    const double t00 = cb * s00 - sb * s01, t01 = sb * s00 + cb * s01, t10 = cb * s10 - sb * s11, t11 = sb * s10 + cb * s11;
-                    Sm[pa * P + pb] = ca * t00 - sa * t10;
-                    if (qb >= 0) Sm[pa * P + qb] = ca * t01 - sa * t11;
-                    if (qa >= 0) Sm[qa * P + pb] = sa * t00 + ca * t10;
-                    if (qa >= 0 && qb >= 0) Sm[qa * P + qb] = sa * t01 + ca * t11;
-                }
-                for (int it = lane; it < k * H; it += 64) {            // V <- V J
-                    const int row = psd_fdiv(it, rH), b = it - row * H;
-                    const int pb = (int)cs[4 * b + 2], qb = (int)cs[4 * b + 3];
-                    if (qb < 0) continue;
-                    const double cb = cs[4 * b], sb = cs[4 * b + 1];
-                    const double x = Vm[row * P + pb], y = Vm[row * P + qb];
-                    Vm[row * P + pb] = cb * x - sb * y; Vm[row * P + qb] = sb * x + cb * y;
-                }
-                wave_lds_exchange();
-            }
-        }
-    }
-    __syncthreads();
-}
-
-// Workgroup version of the same two-phase rounds (rotation parameters | 2 x 2 block updates + V columns), two barriers per round.
+// Cyclic Jacobi sweeps on S (k x k, pitch P), rotations accumulated into the columns of V (pitch P); same tournament order and rotation
+// formulas as psd_jacobi (ce_forward_v2.h).  On return diag(S) holds the eigenvalues and the columns of V the eigenvectors.  A round is two
+// barrier-separated phases: (A) the K / 2 rotation parameters, one lane per pair; (B) the two-sided update S <- J^T S J on the (K / 2)^2
+// disjoint 2 x 2 blocks {p_a, q_a} x {p_b, q_b} together with the column rotations V <- V J.  Stop rule: off-diagonal mass below 1e-15 of the
+// total, or -- the warm-started matrix S' = V^T S V carries rounding noise of a few 1e-16 |S| per entry, so that target can sit below the
+// floor -- already tiny (1e-12) and no longer decreasing.  (Variants that were measured and dropped: one wave doing the whole sweep without
+// workgroup barriers; one barrier per round with recomputed or pipelined rotations -- ROUND_NOTES.md.)
 template <int NTH>
 __device__ __forceinline__ void psd_sweeps_wg(double *Sm, double *Vm, int k, int P, double *cs, double *red) {
     constexpr int NT = NTH, NW = NTH / 64;
@@ -174,7 +69,7 @@ __device__ __forceinline__ void psd_sweeps_wg(double *Sm, double *Vm, int k, int
         double r[2] = {0, 0};
         for (int idx = tid; idx < k * k; idx += NT) { const int i = psd_fdiv(idx, rk), j = idx - i * k; const double v = Sm[i * P + j]; if (i == j) r[1] = fma(v, v, r[1]); else r[0] = fma(v, v, r[0]); }
         block_reduce_n<2, NW>(r, 0u, red);
-        if (r[0] <= 1e-30 * (r[0] + r[1]) || r[0] == 0.0 || (r[0] <= 1e-24 * (r[0] + r[1]) && r[0] > 0.25 * prev_off)) break;          // uniform (see psd_sweeps_wave)
+        if (r[0] <= 1e-30 * (r[0] + r[1]) || r[0] == 0.0 || (r[0] <= 1e-24 * (r[0] + r[1]) && r[0] > 0.25 * prev_off)) break;          // uniform
         prev_off = r[0];
         for (int rd = 0; rd < K - 1; rd++) {
             if (tid < H) {
