@@ -1,6 +1,8 @@
 """GPU parity tests proper: the HIP engine (through the C ABI, via the plugin's ConeEngine) against the CPU
 oracle on the same seeded inputs.  Tolerances (fp64): solutions within 1e-6*(1+|x|_inf) at eps=1e-8
 (BASELINE.md parity gate); gradients within 1e-5 relative to the oracle's dense adjoint."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -442,7 +444,9 @@ def test_shared_A_kernels_with_exp_and_power_cones(monkeypatch):
     ok = ref["status"] == 1
     assert ok.mean() > 0.5, ref["status"]
     eng, A_bm, x, y, s, iters, status, resid = gpu_solve(tpl, Ab, b, c, eps=1e-9, max_iters=200000)
-    assert eng.last_path == "const_a" and eng.last_const_a_kernel == "k_sa_fwd"
+    assert eng.last_path == "const_a"
+    if os.environ.get("CE_SA_FWD") != "0":          # (the toggle exists for A/B runs of the batch-GEMM path)
+        assert eng.last_const_a_kernel == "k_sa_fwd"
     assert (status[ok] == 1).all(), status
     for got, want in ((x, ref["x"]), (y, ref["y"]), (s, ref["s"])):
         assert np.abs(got.cpu().numpy()[ok] - want[ok]).max() < 1e-6 * (1 + np.abs(want[ok]).max())
@@ -450,7 +454,8 @@ def test_shared_A_kernels_with_exp_and_power_cones(monkeypatch):
     g = oracle.adjoint_batch(Ab, b, c, cones, ref["x"], ref["y"], ref["s"], dx, dy, mode="dense")
     xr, yr, sr = (torch.from_numpy(ref[k]).cuda() for k in ("x", "y", "s"))
     dA, dq, adj = eng.vjp(A_bm, xr, yr, sr, torch.from_numpy(dx).cuda(), torch.from_numpy(dy).cuda())
-    assert eng.last_lsqr_iters is not None
+    if os.environ.get("CE_SA_KERNEL") != "0":
+        assert eng.last_lsqr_iters is not None
     good = ok & (adj.cpu().numpy() == 0)
     assert good.mean() > 0.5
     assert np.abs(dq.cpu().numpy()[:n].T[good] - g["dc"][good]).max() < 1e-5 * (1 + np.abs(g["dc"][good]).max())
