@@ -839,11 +839,12 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
         {
             const double a = seg_dot_lds<CHG, TG>(Gm + (jg < n ? jg : 0) * ldg + TG * cg, sm + L::O_TV + TG * cg);
             if (owng) sm[L::O_PX + jg] = a;
+            if (WL && threadIdx.x == 0) sm[L::O_WP + 2] = sm[L::O_W + OT];   // snapshot of w_tau: the fused phase below rewrites it while other waves still need it
         }
         __syncthreads();
         if constexpr (WL) {
             // P2 + P3 fused: q = A p_x ; tau-tilde ; u-tilde ; cone projection ; relaxed update.  The cone blocks of y are wave-local.
-            const double tau_t = (rtau * sm[L::O_W + OT] + sm[L::O_WP] + sm[L::O_WP + 1]) * inv_den;
+            const double tau_t = (rtau * sm[L::O_WP + 2] + sm[L::O_WP] + sm[L::O_WP + 1]) * inv_den;
             const double q = seg_dot<CHA, T2>(ar, sm + L::O_PX + T2 * c2);
             const bool upd = !check && !last;          // fast path: the relaxed update happens here (else after the convergence check)
             const int ee = OY + i2;

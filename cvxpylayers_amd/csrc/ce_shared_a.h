@@ -243,7 +243,8 @@ k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, cons
     // u <- u / beta ;  q = DPi(uy) ;  (vx, vy) = N^T u
     for (int j = tid; j < n; j += NT) ux[j] *= ib;
     dproj(uy, ib, [&](int i, double o) { qv[i] = o; });
-    for (int i = tid; i < m; i += NT) uy[i] *= ib;       // (every read of uy by dproj is behind one of its barriers, or by the row's own thread)
+    if (ntri > 0) __syncthreads();                       // a triple's thread reads three rows of uy that other threads rescale below
+    for (int i = tid; i < m; i += NT) uy[i] *= ib;       // (every other read of uy by dproj is behind one of its barriers, or by the row's own thread)
     __syncthreads();
     acc = 0;
     both_products(qv, ux, [&](int j, double a) { vx[j] = a; acc = fma(a, a, acc); },
@@ -271,6 +272,7 @@ k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, cons
         // u = u-hat / beta ;  q = DPi(uy) ;  (tx, ty) = N^T u ;  v-hat = t - beta v
         for (int j = tid; j < n; j += NT) ux[j] *= ib;
         dproj(uy, ib, [&](int i, double o) { qv[i] = o; });
+        if (ntri > 0) __syncthreads();
         for (int i = tid; i < m; i += NT) uy[i] *= ib;
         __syncthreads();
         acc = 0;

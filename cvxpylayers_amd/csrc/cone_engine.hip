@@ -28,6 +28,7 @@
 #include <string>
 #include <type_traits>
 #include <utility>
+#include <atomic>
 #include <vector>
 
 #include "cone_engine.h"
@@ -68,6 +69,7 @@ struct ce_engine {
     int *d_csc_ptr = nullptr, *d_csr_ptr = nullptr, *d_csr_col = nullptr, *d_csr_src = nullptr;   // sparse structure of the A part (shared-A kernels)
     // split of the A part into singleton rows and sp_r <= 64 dense rows (ce_shared_a_ops.h); sp_RP == 0: more than 64 rows with several entries
     int sp_r = 0, sp_RP = 0;
+    bool sa_fwd_attr = false, sa_lsqr_attr = false;   // MaxDynamicSharedMemorySize is per device: set once per engine (an engine is bound to one device, one caller thread)
     int psd_first = 0;           // first row of the first PSD block (m when the template has none)
     int *d_sp_drow = nullptr, *d_sp_srow_col = nullptr, *d_sp_scol_ptr = nullptr, *d_sp_scol_row = nullptr, *d_sp_rowslot = nullptr;
     double *d_sp_AdT = nullptr, *d_sp_sval = nullptr;
@@ -223,11 +225,12 @@ extern "C" {
 
 const char *ce_last_error(void) { return g_err.c_str(); }
 int ce_abi_version(void) { return CE_ABI_VERSION; }
+int ce_acceleration_available(ce_handle h) { return (h && h->fwd_mode == 4 && h->aa_ok) ? 1 : 0; }
 int ce_struct_size(int which) { return which == 0 ? (int)sizeof(ce_template) : which == 1 ? (int)sizeof(ce_settings) : -1; }
 
 void ce_default_settings(ce_settings *s) {
     s->eps_abs = 1e-4; s->eps_rel = 1e-4; s->eps_infeas = 1e-7; s->alpha = 1.5; s->rho_x = 1e-6; s->scale = 0.1;
-    s->max_iters = 100000; s->normalize = 1; s->adaptive_scale = 1; s->warm_start = 0; s->acceleration_lookback = 0; s->acceleration_interval = 10;
+    s->max_iters = 100000; s->normalize = 1; s->adaptive_scale = 1; s->warm_start = 0; s->acceleration_lookback = 10; s->acceleration_interval = 10;   // SCS 3 defaults, which diffcp forwards (diffcp_if.py:356-367)
 }
 
 int ce_create(const ce_template *tpl, int device, ce_handle *out) {
@@ -668,12 +671,11 @@ int ce_solve_shared_a(ce_handle h, int B, int r, int RP, const double *AdT, cons
         if (with <= LDS_LIMIT && !(e && atoi(e) == 0)) { cidx = true; lds = with; }
     }
     HIPCHK(hipSetDevice(h->device));
-    static bool attr_done = false;
-    if (!attr_done) {
+    if (!h->sa_fwd_attr) {
 #define SA_ATTR(...) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sa_fwd<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT))
         SA_ATTR(16, 256); SA_ATTR(32, 256); SA_ATTR(64, 256); SA_ATTR(16, 512); SA_ATTR(32, 512); SA_ATTR(64, 512); SA_ATTR(16, 512, true); SA_ATTR(32, 512, true); SA_ATTR(64, 512, true);
 #undef SA_ATTR
-        attr_done = true;
+        h->sa_fwd_attr = true;
     }
     SaFwd F{r, RP, AdT, drow, srow_col, srow_val, scol_ptr, scol_row, gs, Dv, Ev};
     {
@@ -698,12 +700,11 @@ int ce_vjp_shared_a(ce_handle h, int B, const double *A_vals0, const double *x, 
     const size_t lds = sa_lsqr_lds_doubles(T.n, T.m, T.nq, T.ns, T.maxs, RP, h->psd_first, T.nep + T.np) * 8;
     if (lds > LDS_LIMIT) { g_err = "shared-A adjoint kernel: the LSQR vectors of one instance do not fit LDS"; return CE_E_TOO_LARGE; }
     HIPCHK(hipSetDevice(h->device));
-    static bool attr_done = false;
-    if (!attr_done) {
+    if (!h->sa_lsqr_attr) {
 #define SA_ATTR(RPV) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sa_lsqr<RPV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT))
         SA_ATTR(0); SA_ATTR(16); SA_ATTR(32); SA_ATTR(64);
 #undef SA_ATTR
-        attr_done = true;
+        h->sa_lsqr_attr = true;
     }
     SaStruct S{h->d_csc_ptr, h->d_rowidx, h->d_csr_ptr, h->d_csr_col, h->d_csr_src, T.nnzA};
     SaSplit F{h->sp_r, RP, h->d_sp_AdT, h->d_sp_drow, h->d_sp_srow_col, h->d_sp_sval, h->d_sp_scol_ptr, h->d_sp_scol_row, h->d_sp_rowslot};
@@ -765,8 +766,12 @@ static int parammap_launch(int device, int B, int rows, int cols, const int *ind
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = (size_t)cols * sizeof(double);
     if (cols > 0 && lds <= 64 * 1024 && B >= 256) {          // source row fits LDS (2+ workgroups per CU) and the batch fills the chip
-        static bool attr_done[2] = {false, false};
-        if (!attr_done[ACC]) { HIPCHK(hipFuncSetAttribute((const void *)k_parammap_lds<ACC>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); attr_done[ACC] = true; }
+        static std::atomic<bool> attr_done[2][64];                 // per device (the attribute is per device); re-setting it is harmless, so a benign race at most repeats the call
+        const int dslot = device & 63;
+        if (!attr_done[ACC][dslot].load(std::memory_order_acquire)) {
+            HIPCHK(hipFuncSetAttribute((const void *)k_parammap_lds<ACC>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+            attr_done[ACC][dslot].store(true, std::memory_order_release);
+        }
         hipLaunchKernelGGL(k_parammap_lds<ACC>, dim3(B), dim3(512), lds, st, rows, cols, indptr, indices, vals, P, ld_p, out, ld_out);
     } else if (B >= 1024) {
         dim3 grid((rows + 255) / 256, (B + 3) / 4);

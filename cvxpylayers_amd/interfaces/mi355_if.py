@@ -66,10 +66,10 @@ def make_settings(merged_args: dict) -> _lib.CeSettings:
     for k in ("max_iters", "normalize", "adaptive_scale"):
         if k in a:
             setattr(s, k, int(a[k]))
-    # Anderson acceleration (SCS acceleration_lookback / acceleration_interval): off unless asked for; the second-generation
-    # forward kernel keeps a one-pair history whatever the lookback, other paths iterate without it.
-    if a.get("acceleration_lookback") not in (0, None):
-        s.acceleration_lookback = int(a["acceleration_lookback"])
+    # Anderson acceleration: ce_default_settings carries SCS's defaults (lookback 10, interval 10; diffcp forwards them,
+    # diffcp_if.py:356-367); acceleration_lookback=0 switches it off.  The kernels keep a one-pair history whatever the lookback.
+    if a.get("acceleration_lookback") is not None:
+        s.acceleration_lookback = max(int(a["acceleration_lookback"]), 0)
     if a.get("acceleration_interval") not in (0, None):
         s.acceleration_interval = int(a["acceleration_interval"])
     return s
@@ -163,7 +163,7 @@ class ConeEngine:
             self._note_acceleration(settings, honoured=False, path="constant-A (batch GEMM) path")
             return solve_const_a(self, A_bm, q_eval, settings, warm=warm)
         self.last_path = "per_instance"
-        self._note_acceleration(settings, honoured=self.launch_info()["fwd_mode"] == 4, path="size-generic forward kernels")
+        self._note_acceleration(settings, honoured=bool(_lib.lib().ce_acceleration_available(self._h)), path="size-generic forward kernels")
         if warm is not None:       # the engine reads the initial point from the output buffers (ce_settings.warm_start)
             x, y, s = (t.detach().to(device=dev, dtype=torch.float64).clone().contiguous() for t in warm)
             settings.warm_start = 1
@@ -187,12 +187,13 @@ class ConeEngine:
         return x, y, s, iters, status, resid
 
     def _note_acceleration(self, settings, honoured: bool, path: str):
-        """An explicit acceleration request that the selected path cannot honour is reported once per engine (not silently dropped);
-        the plugin's own default (SCS's lookback 10) is not an explicit request."""
-        if settings.acceleration_lookback > 0 and not honoured and getattr(settings, "_explicit_aa", False) and not getattr(self, "_aa_warned", False):
+        """Records whether this solve ran with Anderson acceleration (`last_acceleration`, surfaced as info["acceleration"]) and warns
+        ONCE per engine when a positive acceleration_lookback -- explicit or the SCS default -- is not honoured by the selected path."""
+        self.last_acceleration = bool(settings.acceleration_lookback > 0 and honoured)
+        if settings.acceleration_lookback > 0 and not honoured and not getattr(self, "_aa_warned", False):
             self._aa_warned = True
             warnings.warn(f"MI355 solver: acceleration_lookback={settings.acceleration_lookback} is not implemented on the {path}; "
-                          "iterating without Anderson acceleration")
+                          "iterating without Anderson acceleration (pass acceleration_lookback=0 to silence this)")
 
     def _use_const_a(self, A_bm) -> bool:
         """The batch-GEMM path pays off when the instance is too large for the register / LDS-resident kernels (those are
@@ -437,13 +438,10 @@ class _ConeLayer(torch.autograd.Function):
         if solver_args:
             merged_args.update(solver_args)
         # SCS runs with Anderson acceleration by default (acceleration_lookback = 10, acceleration_interval = 10) and diffcp forwards
-        # SCS's defaults (diffcp_if.py:356-367), so identical solver_args mean acceleration ON here as well.  The engine keeps a
-        # one-pair history whatever the lookback: on every BASELINE configuration that gives the iteration counts of lookback 10
-        # within 2.5 % (profiles/r02/aa_memory.json, scripts/aa_memory_study.py).  acceleration_lookback=0 switches it off.
-        explicit_aa = "acceleration_lookback" in merged_args
-        merged_args.setdefault("acceleration_lookback", 10)
+        # SCS's defaults (diffcp_if.py:356-367); ce_default_settings carries the same defaults, so identical solver_args mean the same
+        # algorithm here, at the C ABI and in the reference.  The engine keeps a one-pair history whatever the lookback (iteration
+        # counts within 2.5 % of lookback 10 on every BASELINE configuration, profiles/r02/aa_memory.json).
         settings = make_settings(merged_args)
-        settings._explicit_aa = bool(explicit_aa and merged_args.get("acceleration_lookback"))
         if warm_start is None and merged_args.get("warm_starts") is not None:
             # diffcp's solve argument (diffcp_if.py:365-367 forwards it): one (x, y, s) triple per instance
             ws = merged_args["warm_starts"]
@@ -477,14 +475,22 @@ class _ConeLayer(torch.autograd.Function):
                               f"for instance {bad} ({int((st < 0).sum())} of {batch_size} instances failed)")
         if bool((st == 2).any()):
             warnings.warn("Solved/Inaccurate.")
+        failed = None
+        if bool((st < 0).any()):
+            # raise_on_error=False: per-instance failure masking.  Rows of failed instances (infeasible / unbounded /
+            # failed) come back as NaN -- never a half-converged iterate -- and their parameter gradients as zero (backward), so that one
+            # bad instance of a training batch neither poisons nor silently steers the others.  info["status"] says which.
+            failed = (status < 0)
+            x = torch.where(failed[:, None], torch.full_like(x, float("nan")), x)
+            y = torch.where(failed[:, None], torch.full_like(y, float("nan")), y)
         primal = x.to(in_device)
         dual = y.to(in_device)
-        info = dict(iters=iters, status=status, resid=resid)
+        info = dict(iters=iters, status=status, resid=resid, acceleration=getattr(eng, "last_acceleration", False))
         # x / y are handed back as `primal` / `dual` (same objects when the input lives on the engine's device), and autograd
         # attaches this node to them: keeping the SAME objects on the node would form a reference cycle (node -> saved ->
         # primal -> grad_fn -> node) that only the cyclic GC breaks, i.e. 167 MB buffers pile up for many steps and the
         # caching allocator falls back to hipMalloc (3 ms each).  Detached aliases share the storage without the cycle.
-        saved = (eng, A_bm, x.detach(), y.detach(), s, batch_minor_in, P_bm, path) if needs_grad else None
+        saved = (eng, A_bm, x.detach(), y.detach(), s, batch_minor_in, P_bm, path, failed) if needs_grad else None
         return primal, dual, info, (saved, batch_size, originally_unbatched, in_device)
 
     @staticmethod
@@ -499,16 +505,24 @@ class _ConeLayer(torch.autograd.Function):
         saved, batch_size, originally_unbatched, in_device = ctx.backward_data
         if saved is None:
             raise RuntimeError("backward called on a layer evaluated with needs_grad=False")
-        eng, A_bm, x, y, s, batch_minor_in, P_bm, path = saved
+        eng, A_bm, x, y, s, batch_minor_in, P_bm, path, failed = saved
         dP = None
         with torch.cuda.device(eng.device):
             dx = dprimal.to(device=eng.device, dtype=torch.float64).contiguous()
             dy = ddual.to(device=eng.device, dtype=torch.float64).contiguous()
+            if failed is not None:          # masked instances: NaN outputs upstream produce NaN cotangents; they contribute nothing
+                keep = ~failed[:, None]
+                dx = torch.where(keep, dx, torch.zeros_like(dx)); dy = torch.where(keep, dy, torch.zeros_like(dy))
+                x = torch.where(keep, x, torch.zeros_like(x)); y = torch.where(keep, y, torch.zeros_like(y)); s = torch.where(keep, s, torch.zeros_like(s))
             if P_bm is not None:
                 dA, dq, adj, dP_bm = eng.vjp(A_bm, x, y, s, dx, dy, batch_minor_out=batch_minor_in, P_bm=P_bm, path=path)
                 dP = dP_bm.t().to(in_device)
             else:
                 dA, dq, adj = eng.vjp(A_bm, x, y, s, dx, dy, batch_minor_out=batch_minor_in, path=path)
+        if failed is not None:
+            dA = torch.where(failed[None, :], torch.zeros_like(dA), dA); dq = torch.where(failed[None, :], torch.zeros_like(dq), dq)
+            if P_bm is not None:
+                dP = torch.where(failed[None, :].to(dP.device), torch.zeros_like(dP), dP)
         ctx.adj_status = adj
         pend = getattr(eng, "_pending_adj", None) or []
         eng._pending_adj = (pend + [(adj, batch_size)])[-8:]     # inspected at the next forward call (no host sync on the backward path)

@@ -36,7 +36,7 @@ typedef struct ce_engine *ce_handle;
 enum {
     CE_OK = 0,
     CE_E_BADARG = -1,        /* inconsistent template / null pointer */
-    CE_E_UNSUPPORTED = -2,   /* cone type not implemented on the device path (exp / power / PSD in this round) */
+    CE_E_UNSUPPORTED = -2,   /* template / argument combination not implemented on the selected device path (ce_last_error says which) */
     CE_E_TOO_LARGE = -3,     /* instance does not fit the implemented residency modes */
     CE_E_HIP = -4,           /* a HIP runtime call failed (ce_last_error has the string) */
     CE_E_STATE = -5          /* ce_vjp called without the retained forward state it was asked to reuse */
@@ -77,9 +77,11 @@ typedef struct {
     int warm_start;       /* != 0: x, y, s hold an initial primal / dual / slack point on entry (SCS warm start: u = (x, y, 1), v = (0, s, 0));
                              instances whose point is not finite start cold.  The reference's DIFFCP plugin exposes this as
                              diffcp's `warm_starts` solve argument; MOREAU as `warm_start` (torch/cvxpylayer.py:464-487) */
-    int acceleration_lookback;   /* SCS name.  0 (default here): plain iteration.  > 0: type-I Anderson acceleration of the iteration map
-                                    with a one-pair secant history (the engine keeps memory 1 whatever the value; honoured by the
-                                    second-generation forward kernel, ignored elsewhere) */
+    int acceleration_lookback;   /* SCS name; default 10 like SCS (diffcp forwards SCS's defaults, diffcp_if.py:356-367).  0: plain iteration.
+                                    > 0: type-I Anderson acceleration of the iteration map with a ONE-pair secant history whatever the
+                                    value (profiles/r02/aa_memory.json: iteration counts within 2.5 % of lookback 10 on the BASELINE
+                                    configurations) and SCS's residual safeguard.  Honoured where ce_acceleration_available() /
+                                    the shared-A kernels implement it; other paths iterate plainly (the Python plugin warns once). */
     int acceleration_interval;   /* applied every this many iterations (SCS default 10) */
 } ce_settings;
 
@@ -89,10 +91,13 @@ void ce_default_settings(ce_settings *s);
  * library short structs.  Bindings must check  ce_abi_version() == CE_ABI_VERSION  and  ce_struct_size(which) == sizeof(their
  * struct)  (which: 0 ce_template, 1 ce_settings) once at load time and refuse to continue otherwise (cvxpylayers_amd/_lib.py
  * does; tests/test_cabi.py checks the stub printed in INTEGRATION.md the same way).  CE_ABI_VERSION is bumped whenever a struct
- * layout, an entry point's signature or the meaning of an argument changes (5: srow_col of ce_solve_shared_a marks the dense row of slot a with -2 - a). */
-#define CE_ABI_VERSION 5
+ * layout, an entry point's signature or the meaning of an argument changes (6: ce_default_settings = SCS defaults incl. acceleration_lookback 10; ce_acceleration_available added). */
+#define CE_ABI_VERSION 6
 int ce_abi_version(void);
 int ce_struct_size(int which);
+/* 1 when ce_solve / ce_solve_qp on this engine honour ce_settings.acceleration_lookback > 0 (second-generation forward kernel with
+ * room for its five extra vectors in LDS), else 0: the request is ignored on that engine (plain iteration). */
+int ce_acceleration_available(ce_handle h);
 
 int ce_create(const ce_template *tpl, int device, ce_handle *out);
 int ce_destroy(ce_handle h);
@@ -229,8 +234,9 @@ int ce_solve_shared_a(ce_handle h, int B, int r, int RP, const double *AdT, cons
  * workgroup per instance, A applied from its sparse structure, the PSD cone's derivative on the matrix cores.  A_vals0: the nnz_aug
  * boundary values of ONE instance (the A part is shared); x, y, s, dx, dy as ce_vjp; dA_bm (B, nnz_aug) batch-major; dq at
  * [k * sdq_k + i * sdq_b]; adj_status[i] = 1 when LSQR hit iter_lim (0: 4 (n + m)); lsqr_iters (B) or NULL; atol / btol: LSQR stopping
- * tolerances.  Cones: zero / nonnegative / second-order / PSD; CE_E_UNSUPPORTED / CE_E_TOO_LARGE otherwise (callers fall back to the
- * batched path of const_a.py).
+ * tolerances.  All cone types (zero / nonnegative / second-order / PSD / exponential / power: the triples' derivative is a symmetrised
+ * 3 x 3 block computed once per call); CE_E_TOO_LARGE when the LSQR vectors of one instance exceed LDS (callers fall back to the batched
+ * path of const_a.py).
  */
 int ce_vjp_shared_a(ce_handle h, int B, const double *A_vals0, const double *x, const double *y, const double *s, const double *dx, const double *dy,
                     double *dA_bm, double *dq_vals, long sdq_k, long sdq_b, int *adj_status, int *lsqr_iters, double atol, double btol, int iter_lim, void *stream);

@@ -1,0 +1,116 @@
+"""Generates tests/golden/ref_notebook_*.npz  --  run from the repo root (build container only: reads /root/reference):
+    python tests/golden/make_notebook_golden.py
+
+These fixtures ARE outputs of the reference: numbers that the real cvxpylayers -> diffcp -> SCS stack printed into the example
+notebooks the reference ships (/root/reference/examples/torch/*.ipynb, stored cell outputs).  This script only PARSES them out of the
+notebook JSON (nothing is solved here) and stores them next to the notebooks' inputs, which it regenerates at full precision with the
+notebooks' own seeds (torch / numpy generators reproduce the printed 4-digit inputs; asserted below).  The layers themselves are
+restated cvxpy-free in tests/notebook_cases.py; tests/test_notebook_golden.py replays the fixtures through the oracle (CPU) and the
+HIP engine (GPU).
+
+  ref_notebook_ot.npz        optimal_transport.ipynb cells 6-14: entropic optimal transport (9 exponential cones); stored: x, y (printed
+                             inputs, cells 9-10), P (cell 11: forward), x.grad, y.grad of P[2,2] (cells 13-14: diffcp's adjoint)
+  ref_notebook_lqr.npz       lqr.ipynb cells 2-4: the LQR value-function SDP (PSD cones of order 6 and 4) solved by SCS through CVXPY;
+                             stored: optimal value (17 digits), P_lqr (8 decimals)
+  ref_notebook_tutorial.npz  tutorial.ipynb cells 16-17: fit_lr(Xtrain, ytrain, 0, 0) -> (a, b) (SOC program)
+  ref_notebook_supply.npz    supply_chain.ipynb cell 9: closed-loop cost of the baseline policy (17 digits: 20 sequential forward solves) and
+                             the validation costs after each of the first SGD epochs (5 digits: each one forward + diffcp backward through
+                             20 time steps x batch 5, so they pin the gradients as well)
+"""
+import json
+import os
+import re
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+NB = "/root/reference/examples/torch"
+_NUM = r"[-+]?(?:\d+\.\d*|\.\d+|\d+)(?:[eE][-+]?\d+)?"
+
+
+def cells(name):
+    return json.load(open(os.path.join(NB, name)))["cells"]
+
+
+def out_text(cell):
+    s = ""
+    for o in cell.get("outputs", []):
+        if "text" in o:
+            s += "".join(o["text"])
+        elif "data" in o and "text/plain" in o["data"]:
+            s += "".join(o["data"]["text/plain"])
+    return s
+
+
+def numbers(s):
+    s = re.sub(r"(grad_fn|dtype|requires_grad)=[^,)]*", "", s)
+    return np.array([float(v) for v in re.findall(_NUM, s)])
+
+
+def find_cell(cs, needle):
+    hits = [c for c in cs if c["cell_type"] == "code" and needle in "".join(c["source"])]
+    assert len(hits) == 1, (needle, len(hits))
+    return hits[0]
+
+
+def ot():
+    cs = cells("optimal_transport.ipynb")
+    x_p = numbers(out_text([c for c in cs if "".join(c["source"]).strip() == "x"][0]))
+    y_p = numbers(out_text([c for c in cs if "".join(c["source"]).strip() == "y"][0]))
+    P_p = numbers(out_text(find_cell(cs, "print(P)"))).reshape(3, 3)
+    xg = numbers(out_text(find_cell(cs, "x.grad")))
+    yg = numbers(out_text(find_cell(cs, "y.grad")))
+    assert "torch.manual_seed(6)" in "".join(find_cell(cs, "torch.manual_seed").get("source"))
+    torch.set_default_dtype(torch.double)
+    torch.manual_seed(6)                                          # cell 6
+    x = torch.randn(3); y = torch.randn(3)
+    torch.set_default_dtype(torch.float32)
+    assert np.abs(x.numpy() - x_p).max() < 5.1e-5 and np.abs(y.numpy() - y_p).max() < 5.1e-5, "seeded inputs != printed inputs"
+    np.savez(os.path.join(HERE, "ref_notebook_ot.npz"), x=x.numpy(), y=y.numpy(), x_printed=x_p, y_printed=y_p, a=np.full(3, 1 / 3), b=np.full(3, 1 / 3),
+             eps=np.array([1.0]), P=P_p, x_grad=xg, y_grad=yg)
+    print("ot", P_p, xg, yg)
+
+
+def lqr():
+    cs = cells("lqr.ipynb")
+    val = numbers(out_text(find_cell(cs, "print(result)")))
+    P = numbers(out_text([c for c in cs if "".join(c["source"]).strip() == "P_lqr"][0])).reshape(4, 4)
+    assert "np.random.seed(0)" in "".join(find_cell(cs, "np.random.seed").get("source"))
+    np.random.seed(0)                                             # cell 2
+    n, m = 4, 2
+    A = np.random.randn(n, n)
+    A /= np.max(np.abs(np.linalg.eig(A)[0]))
+    B = np.random.randn(n, m)
+    np.savez(os.path.join(HERE, "ref_notebook_lqr.npz"), A=A, B=B, Q0=np.eye(n), R0=np.eye(m), W=0.25 * np.eye(n), value=val, P_lqr=P)
+    print("lqr", val, P)
+
+
+def tutorial():
+    from sklearn.model_selection import train_test_split
+    cs = cells("tutorial.ipynb")
+    ab = numbers(out_text(find_cell(cs, "fit_lr(Xtrain, ytrain, torch.zeros(1), torch.zeros(1))")))
+    assert ab.shape == (2,)
+    torch.manual_seed(0); np.random.seed(0)                       # cell 16, second half
+    n, N = 1, 60
+    X = np.random.randn(N, n)
+    theta = np.random.randn(n)
+    y = X @ theta + .5 * np.random.randn(N)
+    Xtrain, Xtest, ytrain, ytest = train_test_split(X, y, test_size=.5)
+    np.savez(os.path.join(HERE, "ref_notebook_tutorial.npz"), Xtrain=Xtrain, ytrain=ytrain, a=ab[:1], b=ab[1:])
+    print("tutorial", ab)
+
+
+def supply():
+    cs = cells("supply_chain.ipynb")
+    txt = out_text(find_cell(cs, "Baseline cost"))
+    base = float(re.search(r"Baseline cost:\s*(" + _NUM + ")", txt).group(1))
+    valid = [float(v) for v in re.findall(r"epoch \d+, valid (" + _NUM + ")", txt)]
+    np.savez(os.path.join(HERE, "ref_notebook_supply.npz"), baseline=np.array(base), valid=np.array(valid[:8]),
+             time_horizon=20, batch_size=5, lr=0.05)
+    print("supply", base, valid[:8])
+
+
+if __name__ == "__main__":
+    ot(); lqr(); tutorial(); supply()

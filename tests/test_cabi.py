@@ -103,8 +103,12 @@ def test_solver_args_map_to_ce_settings_like_diffcp_maps_them_to_scs():
                        "acceleration_lookback": 10, "n_jobs_forward": 4, "mode": "lsqr", "verbose": True})
     assert s.eps_abs == 1e-7 and s.eps_rel == 1e-7 and s.max_iters == 123 and s.alpha == 1.2 and s.scale == 0.5
     assert s.normalize == 0 and s.adaptive_scale == 0 and s.warm_start == 0
+    assert s.acceleration_lookback == 10 and s.acceleration_interval == 10
     s2 = make_settings({"eps_abs": 1e-5, "eps_rel": 1e-3})
     assert s2.eps_abs == 1e-5 and s2.eps_rel == 1e-3
+    # one contract at every layer: ce_default_settings = SCS 3 defaults (which diffcp forwards, diffcp_if.py:356-367), acceleration included
+    assert s2.acceleration_lookback == 10 and s2.acceleration_interval == 10 and s2.alpha == 1.5 and s2.rho_x == 1e-6 and s2.scale == 0.1 and s2.eps_infeas == 1e-7
+    assert make_settings({"acceleration_lookback": 0}).acceleration_lookback == 0
     with pytest.raises(ValueError, match="unknown solver_args"):
         make_settings({"epsilon": 1e-3})
 

@@ -10,7 +10,7 @@ import pytest
 from cvxpylayers_amd import problems as P
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-FILES = sorted(f for f in glob.glob(os.path.join(HERE, "golden", "*.npz")) if not os.path.basename(f).startswith("refglue_"))   # refglue_*: tests/test_ref_glue.py, tests/test_gpu_refglue.py
+FILES = sorted(f for f in glob.glob(os.path.join(HERE, "golden", "*.npz")) if not os.path.basename(f).startswith(("refglue_", "ref_notebook_")))   # refglue_*: tests/test_ref_glue.py, tests/test_gpu_refglue.py; ref_notebook_*: tests/test_notebook_golden.py
 
 
 def load(path):
@@ -64,7 +64,7 @@ def test_engine_matches_golden(path):
         pytest.skip(str(e))
     A_eval, q_eval = tpl.values_from_dense(A, b, c)
     A_bm = eng.to_batch_major(torch.from_numpy(A_eval).cuda())
-    x, y, s, iters, status, resid = eng.solve(A_bm, torch.from_numpy(q_eval).cuda(), make_settings(dict(eps=1e-10, max_iters=200000)), P_bm=P_bm)
+    x, y, s, iters, status, resid = eng.solve(A_bm, torch.from_numpy(q_eval).cuda(), make_settings(dict(acceleration_lookback=0, eps=1e-10, max_iters=200000)), P_bm=P_bm)
     assert (status.cpu().numpy() == 1).all()
     for got, want in ((x, d["x"]), (y, d["y"]), (s, d["sl"])):
         err = np.abs(got.cpu().numpy() - want).max(axis=1) / (1 + np.abs(want).max(axis=1))

@@ -23,7 +23,7 @@ def _solve_and_vjp(tpl, cones, A, b, c, eps, max_iters, dx=None):
     A_eval, q_eval = tpl.values_from_dense(A, b, c)
     eng = ConeEngine(tpl.indices, tpl.indptr, n, m, cones, torch.device("cuda", 0))
     A_bm = torch.from_numpy(A_eval).cuda().t().contiguous(); q_t = torch.from_numpy(q_eval).cuda()
-    x, y, s, it, status, res = eng.solve(A_bm, q_t, make_settings(dict(eps=eps, max_iters=max_iters)))
+    x, y, s, it, status, res = eng.solve(A_bm, q_t, make_settings(dict(acceleration_lookback=0, eps=eps, max_iters=max_iters)))
     path = eng.last_path
     dxt = torch.ones_like(x) if dx is None else torch.from_numpy(dx).cuda()
     dA, dq, adj = eng.vjp(A_bm, x, y, s, dxt, torch.zeros_like(y), path=path)

@@ -39,7 +39,7 @@ def test_metric_config_full_batch_kkt_and_subset_parity():
     cfg = P.CONFIGS["M"]; n, cones, B = cfg["n"], cfg["cones"], 4096
     tpl, eng, A, b, c, A_bm, q_t = _setup(n, cones, B, seed=0)
     eps = 1e-8
-    x, y, s, iters, status, resid = eng.solve(A_bm, q_t, make_settings(dict(eps=eps, max_iters=20000)))
+    x, y, s, iters, status, resid = eng.solve(A_bm, q_t, make_settings(dict(acceleration_lookback=0, eps=eps, max_iters=20000)))
     assert (status.cpu().numpy() == 1).all()
     x, y, s = x.cpu().numpy(), y.cpu().numpy(), s.cpu().numpy()
     # KKT: A x + s = b, A^T y + c = 0, c^T x + b^T y = 0, s in K, y in K*, s . y = 0
@@ -63,7 +63,7 @@ def test_adjoint_is_the_derivative_of_the_gpu_solution_map():
     from cvxpylayers_amd.interfaces.mi355_if import make_settings
     cfg = P.CONFIGS["M"]; n, cones, B = cfg["n"], cfg["cones"], 64
     tpl, eng, A, b, c, A_bm, q_t = _setup(n, cones, B, seed=7)
-    st = make_settings(dict(eps=1e-11, max_iters=100000))
+    st = make_settings(dict(acceleration_lookback=0, eps=1e-11, max_iters=100000))
     x, y, s, *_ = eng.solve(A_bm, q_t, st)
     rng = np.random.default_rng(3)
     dx = torch.from_numpy(rng.standard_normal((B, n))).cuda()
@@ -89,7 +89,7 @@ def test_vjp_is_linear_and_batch_order_invariant():
     from cvxpylayers_amd.interfaces.mi355_if import make_settings
     cfg = P.CONFIGS["M"]; n, cones, B = cfg["n"], cfg["cones"], 37          # deliberately not a multiple of anything
     tpl, eng, A, b, c, A_bm, q_t = _setup(n, cones, B, seed=9)
-    x, y, s, iters, status, resid = eng.solve(A_bm, q_t, make_settings(dict(eps=1e-9)))
+    x, y, s, iters, status, resid = eng.solve(A_bm, q_t, make_settings(dict(acceleration_lookback=0, eps=1e-9)))
     rng = np.random.default_rng(0)
     d1 = [torch.from_numpy(rng.standard_normal(t.shape)).cuda() for t in (x, y)]
     d2 = [torch.from_numpy(rng.standard_normal(t.shape)).cuda() for t in (x, y)]
@@ -98,7 +98,7 @@ def test_vjp_is_linear_and_batch_order_invariant():
     assert torch.allclose(g12[0], 2.0 * g1[0] - 3.0 * g2[0], rtol=1e-9, atol=1e-9)
     assert torch.allclose(g12[1], 2.0 * g1[1] - 3.0 * g2[1], rtol=1e-9, atol=1e-9)
     perm = torch.randperm(B, device="cuda")
-    xp, yp, sp, itp, stp, _ = eng.solve(A_bm[perm].contiguous(), q_t[:, perm].contiguous(), make_settings(dict(eps=1e-9)))
+    xp, yp, sp, itp, stp, _ = eng.solve(A_bm[perm].contiguous(), q_t[:, perm].contiguous(), make_settings(dict(acceleration_lookback=0, eps=1e-9)))
     assert torch.equal(xp, x[perm]) and torch.equal(yp, y[perm]) and torch.equal(itp, iters[perm])
 
 

@@ -27,6 +27,7 @@ def gpu_solve(tpl, A, b, c, batch_minor=True, **args):
     if not batch_minor:
         A_t = A_t.t().contiguous().t()
     A_bm = eng.to_batch_major(A_t)
+    args.setdefault("acceleration_lookback", 0)      # the oracle's default: plain iteration (the accelerated runs pass lookback 1 to both)
     x, y, s, iters, status, resid = eng.solve(A_bm, q_t, make_settings(args))
     torch.cuda.synchronize()
     return eng, A_bm, x, y, s, iters.cpu().numpy(), status.cpu().numpy(), resid.cpu().numpy()
@@ -201,7 +202,7 @@ def test_constant_A_gemm_path_matches_oracle(monkeypatch):
         eng = _engine_for(tpl)
         A_eval, q_eval = tpl.values_from_dense(A, b, c)
         A_bm = eng.to_batch_major(torch.from_numpy(A_eval).cuda())
-        x, y, s, iters, status, resid = eng.solve(A_bm, torch.from_numpy(q_eval).cuda(), make_settings(dict(eps=eps, max_iters=100000)))
+        x, y, s, iters, status, resid = eng.solve(A_bm, torch.from_numpy(q_eval).cuda(), make_settings(dict(acceleration_lookback=0, eps=eps, max_iters=100000)))
         assert eng.last_path == "const_a"
         assert (status.cpu().numpy() == ref["status"]).all() and (ref["status"] == 1).all()
         tol = max(1e-6, 20 * eps)
@@ -351,7 +352,7 @@ def test_warm_start_matches_oracle_warm_start():
     A_eval, q_eval = tpl.values_from_dense(A, b2, c2)
     A_bm = eng.to_batch_major(torch.from_numpy(A_eval).cuda())
     wt = tuple(torch.from_numpy(w).cuda() for w in warm)
-    x, y, s, iters, status, resid = eng.solve(A_bm, torch.from_numpy(q_eval).cuda(), make_settings(dict(eps=1e-6, max_iters=20000)), warm=wt)
+    x, y, s, iters, status, resid = eng.solve(A_bm, torch.from_numpy(q_eval).cuda(), make_settings(dict(acceleration_lookback=0, eps=1e-6, max_iters=20000)), warm=wt)
     assert (status.cpu().numpy() == 1).all()
     assert np.abs(iters.cpu().numpy() - rw["iters"]).max() <= 25, (iters.cpu().numpy(), rw["iters"])
     for got, want in ((x, rw["x"]), (y, rw["y"]), (s, rw["s"])):

@@ -93,7 +93,7 @@ def test_engine_solutions_carry_an_optimality_certificate(name):
     dev = torch.device("cuda", 0)
     eng = ConeEngine(tpl.indices, tpl.indptr, tpl.n, tpl.m, cones, dev)
     A_bm = eng.to_batch_major(torch.from_numpy(A_eval).to(dev)); q_t = torch.from_numpy(q_eval).to(dev)
-    x, y, s, iters, status, resid = eng.solve(A_bm, q_t, make_settings(dict(eps=1e-10, max_iters=400000)))
+    x, y, s, iters, status, resid = eng.solve(A_bm, q_t, make_settings(dict(acceleration_lookback=0, eps=1e-10, max_iters=400000)))
     assert (status.cpu().numpy() == 1).all()
     res = certificate(A, b, c, cones, x.cpu().numpy(), y.cpu().numpy(), s.cpu().numpy())
     assert res.max() < 5e-8, res

@@ -205,7 +205,7 @@ def test_native_qp_kernels_match_the_oracle_on_box_qps():
     P_bm = torch.from_numpy(_p_values(Pn, pst)).cuda().contiguous()
     for eps in (1e-4, 1e-9):
         ref = oracle.solve_batch(An, bn, qn, cones, P=Pn, eps=eps, max_iters=100000)
-        x, y, s, iters, status, resid = eng.solve(A_bm, torch.from_numpy(q_eval).cuda(), make_settings(dict(eps=eps, max_iters=100000)), P_bm=P_bm)
+        x, y, s, iters, status, resid = eng.solve(A_bm, torch.from_numpy(q_eval).cuda(), make_settings(dict(acceleration_lookback=0, eps=eps, max_iters=100000)), P_bm=P_bm)
         assert (status.cpu().numpy() == 1).all() and (ref["status"] == 1).all()
         tol = max(1e-6, 20 * eps)
         for got, want in ((x, ref["x"]), (y, ref["y"]), (s, ref["s"])):
