@@ -380,10 +380,16 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
 #pragma unroll
             for (int j = 0; j < TJ; j++) if (cb + BGC * j < NK) r[0] = fmax(r[0], fabs(kt[i][j]));
         block_reduce_n<1, NWB>(r, 1u, red);
-        ptol = 1e-13 * (r[0] > 0 ? r[0] : 1.0);
+        ptol = 1e-11 * (r[0] > 0 ? r[0] : 1.0);     // rank tolerance of the oracle's dense elimination (oracle/cone_oracle.c dense_solve_MT)
     }
     __syncthreads();                 // a_y / a_s are dead: the union region becomes colbuf / rowbuf
     for (int i = tid; i < 2 * BGR * TI; i += NTB) colbuf[i] = 0.0;
+    // rank-deficient systems (redundant equality rows, degenerate active sets: the reference's LSQR returns a solution of the consistent
+    // system there, diffcp_if.py:73-96): a column without an acceptable pivot is a FREE variable, set to zero and skipped; rows that never
+    // serve as pivot keep colof = -1
+    for (int i = tid; i < BGR * TI; i += NTB) colof[i] = -1;
+    for (int j = tid; j < n; j += NTB) rx[j] = 0.0;
+    for (int j = tid; j < NK - n; j += NTB) bv[j] = 0.0;
     __syncthreads();
     // ---- Gauss-Jordan with partial pivoting on the register tiles.  One workgroup barrier per pivot:
     //   (1) the 16 lanes owning column k (one DPP row) find the pivot with a DPP butterfly and publish the column
@@ -419,19 +425,20 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
                 best = fmax(best, dpp_mov<0x140>(best));    // row_mirror
                 if constexpr (BGR == 32) best = fmax(best, __shfl_xor(best, 16));      // the column's owners span two DPP rows
                 const int bi = 255 - (__double2loint(best) & 0xFF);
+                const bool tiny = best < ptol;               // no acceptable pivot in this column (best == 0: no candidate row left, bi is meaningless)
 #pragma unroll
                 for (int i = 0; i < TI; i++) {
                     const int r = ra + BGR * i;
                     const double v = kt[i][jk];
-                    if (r == bi) { pinfo[buf] = v; cbuf[r] = 0.0; } else cbuf[r] = v;
+                    if (r == bi) { pinfo[buf] = tiny ? 0.0 : v; cbuf[r] = 0.0; } else cbuf[r] = v;
                 }
-                if (ra == 0) { misc[4 + buf] = bi; if (best < ptol) misc[2] = 1; }
+                if (ra == 0) { misc[4 + buf] = bi; if (tiny) { misc[2] |= 4; pinfo[buf] = 0.0; } }
             }
             __syncthreads();
             const int prow = __builtin_amdgcn_readfirstlane(misc[4 + buf]);
             const int ipv = prow / BGR;
-            double piv = pinfo[buf];
-            if (fabs(piv) < ptol) piv = (piv < 0 ? -ptol : ptol);
+            const double piv = pinfo[buf];
+            if (fabs(piv) < ptol) continue;                    // uniform: free variable (see above); no row is consumed
             double pinv = __builtin_amdgcn_rcp(piv);           // hardware seed + two Newton steps (the IEEE divide expansion is
             pinv = fma(fma(-piv, pinv, 1.0), pinv, pinv);      // three times as long and sits on the critical path of every pivot)
             pinv = fma(fma(-piv, pinv, 1.0), pinv, pinv);
@@ -474,6 +481,7 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
             const int r = ra + BGR * i;
             if (r < NK) {
                 const int k = colof[r];
+                if (k < 0) continue;                           // row never served as pivot (rank-deficient system)
                 const double sol = kt[i][j] / pivrow[r];
                 if (k < n) rx[k] = sol; else bv[k - n] = sol;
             }

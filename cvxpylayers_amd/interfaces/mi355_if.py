@@ -404,7 +404,7 @@ def _warn_flagged_adjoint(eng):
     the backward path itself never synchronises the host."""
     pend, eng._pending_adj = getattr(eng, "_pending_adj", None) or [], []
     for adj, bs in pend:
-        nbad = int((adj != 0).sum())
+        nbad = int(((adj & 3) != 0).sum())       # bit 2 (4): rank-deficient system, basic solution returned like the reference's LSQR does -- not a failure
         if nbad:
             warnings.warn(f"MI355 adjoint: {nbad} of {bs} instances of the previous backward pass were flagged (degenerate active "
                           "set or iteration limit); their gradients are unreliable")
