@@ -213,18 +213,21 @@ k_ca_psd(DevT T, int lp, double *__restrict__ Ug, const int *__restrict__ active
     psd_project<NT>(Ug + (size_t)inst * lp + T.n + T.soff[c], k, Sm, Vm, cs, red);
 }
 
-// K4': the same projection with the contractions on the matrix cores and a warm-started Jacobi (ce_psd_mfma.h).  Vstate (B, ns,
-// maxs * maxs): eigenvectors of every block from the previous call; warm = 0 restarts them from the identity.
+// K4': the same projection by warm-started eigen-refinement on the matrix cores (ce_psd_mfma.h, psd_project_refine; Jacobi sweeps as the
+// fall-back).  Vstate (B, ns, maxs * maxs): eigenvectors of every block from the previous call (row-major k x k); warm = 0: none yet.
 __global__ void __launch_bounds__(NT)
 k_ca_psd_mfma(DevT T, int lp, double *__restrict__ Ug, double *__restrict__ Vstate, int warm, const int *__restrict__ active) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int inst = blockIdx.x, c = blockIdx.y;
     if (!active[inst]) return;
-    const int k = T.sord[c];
-    const int KPm = psd_mfma_kp(T.maxs), PM = KPm * (KPm + 1);
-    double *Sm = sm, *Vm = Sm + PM, *Tm = Vm + PM, *cs = Tm + PM, *red = cs + 2 * KPm + 8;
-    psd_project_mfma<NT>(Ug + (size_t)inst * lp + T.n + T.soff[c], k, Sm, Vm, Tm, cs, red,
-                         Vstate + ((size_t)inst * T.ns + c) * T.maxs * T.maxs, warm);
+    const int k = T.sord[c], P = psd_refine_pitch(k);
+    const int PM = T.maxs * psd_refine_pitch(T.maxs);
+    double *Vl = sm, *Sm = Vl + PM, *Tm = Sm + PM, *Dm = Tm + PM, *Rm = Dm + PM, *cs = Rm + PM, *red = cs + 3 * T.maxs + 16;
+    double *Vg = Vstate + ((size_t)inst * T.ns + c) * T.maxs * T.maxs;
+    if (warm) for (int idx = threadIdx.x; idx < k * k; idx += NT) { const int i = idx / k, j = idx - i * k; Vl[i * P + j] = Vg[idx]; }
+    __syncthreads();
+    psd_project_refine<NT>(Ug + (size_t)inst * lp + T.n + T.soff[c], k, Vl, Sm, Tm, Dm, Rm, cs, red, warm, nullptr, (warm & 2) ? 0 : 1);      // (warm & 2: debug, Jacobi sweeps only)
+    for (int idx = threadIdx.x; idx < k * k; idx += NT) { const int i = idx / k, j = idx - i * k; Vg[idx] = Vl[i * P + j]; }
 }
 
 // K4b: exponential / power cone triples of the cone input (B, lp) projected in place, one thread per (instance, cone); `roots`

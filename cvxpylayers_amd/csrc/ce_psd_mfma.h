@@ -109,6 +109,137 @@ __device__ __forceinline__ void psd_sweeps_wg(double *Sm, double *Vm, int k, int
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------------
+// Warm-started eigen-REFINEMENT on the matrix cores (round 3).  The Jacobi sweeps above cost ~1.4 k cycles per round (two barrier-separated
+// phases of dependent work), 19 rounds per sweep, 2-3 sweeps per warm-started projection: ~90 us per ADMM iteration for one 20 x 20 block,
+// 92 % of k_sa_fwd at BASELINE config 4 with the matrix cores idle 98.6 % of the time.  Once consecutive ADMM iterates differ by less than
+// about 1 % (after ~20 of ~100 iterations at config 4) the previous eigenvectors V are an excellent approximate eigenbasis of the new S,
+// and the decomposition can be REFINED instead of recomputed (Ogita & Aishima, "Iterative refinement for symmetric eigenvalue decomposition",
+// 2018): with  R = I - V^T V,  D = V^T S V,  lam_i = D_ii / (1 - R_ii),
+//        E_ij = (D_ij + lam_j R_ij) / (lam_j - lam_i)   (i != j),      E_ii = R_ii / 2,            V <- V + V E
+// converges quadratically (off-diagonal mass 1e-3 -> 1e-6 -> 1e-12) and corrects the loss of orthogonality of V as it goes (no periodic restart
+// from the identity any more).  Everything except the k^2 divisions is k x k x k products: four MFMA products per step, one workgroup barrier
+// each.  A step is only taken when every |E_ij| <= 1/2 (first-order perturbation theory is valid for all pairs); otherwise -- early iterations,
+// eigenvalue pairs closer than the perturbation -- the routine falls back to the warm-started Jacobi sweeps on D (or to a cold start when V
+// has drifted from orthogonality or a refinement step was already taken).
+// Storage: COMPACT k x k row-major matrices with pitch P >= k (no zero padding; the MFMA operand reads are guarded), the contraction runs
+// over ceil(k / 4) steps of 4 instead of the padded KP / 4 (k = 20: 5 steps, not 8).
+template <int NTH, class FA, class FB, class FO>
+__device__ __forceinline__ void psd_gemm_kk(int k, FA &&fa, FB &&fb, FO &&out) {
+    const int KT = (k + 15) >> 4, KS = (k + 3) >> 2;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lg = lane >> 4, lc = lane & 15;
+    for (int t = wave; t < KT * KT; t += NTH / 64) {
+        const int ti = t / KT, tj = t - ti * KT;
+        const int am = 16 * ti + lc, bn = 16 * tj + lc;
+        psd_v4d acc = {0.0, 0.0, 0.0, 0.0};
+        for (int s = 0; s < KS; s++) {
+            const int kk = 4 * s + lg;
+            const double a = (am < k && kk < k) ? fa(am, kk) : 0.0, b = (bn < k && kk < k) ? fb(kk, bn) : 0.0;
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) { const int M = 16 * ti + lg + 4 * r; if (M < k && bn < k) out(M, bn, acc[r]); }
+    }
+}
+
+__host__ __device__ inline int psd_refine_pitch(int k) { return k | 1; }                 // odd pitch: the strided operand reads spread over the banks
+// LDS doubles of the scratch shared by all blocks of an instance (S, T, D, R + rotation parameters + eigenvalues); every block keeps k P more (V)
+__host__ __device__ inline int psd_refine_scratch_doubles(int kmax) { return 4 * kmax * psd_refine_pitch(kmax) + 3 * kmax + 16; }
+
+// zsvec (svec of S) is replaced by svec(Pi_PSD(S)).  Vst: k x k (pitch P) eigenvectors of the previous call of THIS block, kept by the caller between
+// calls (LDS); warm == 0: no previous call.  Sm, Tm, Dm, Rm: k x P scratch each; cs: 3 k + 16 doubles; red: block_reduce scratch.
+// stats (debug builds, may be null): [0] projections, [1] refinement steps, [2] warm Jacobi fall-backs, [3] cold starts.
+template <int NTH>
+__device__ __forceinline__ void psd_project_refine(double *zsvec, int k, double *Vst, double *Sm, double *Tm, double *Dm, double *Rm, double *cs,
+                                                   double *red, int warm, unsigned long long *stats = nullptr, int refine = 1) {
+    constexpr int NT = NTH, NW = NTH / 64, MAXL = 6;
+    const int tid = threadIdx.x, P = psd_refine_pitch(k);
+    const float rk = 1.0f / (float)k;
+    double *ev = cs + 2 * (k + 2);                                  // eigenvalues (cs[0 ..]: rotation parameters of the Jacobi sweeps)
+    for (int idx = tid; idx < k * k; idx += NT) {
+        const int i = psd_fdiv(idx, rk), j = idx - i * k;
+        const int a = i >= j ? i : j, b = i >= j ? j : i;           // lower-triangle entry (a, b), column-major packed
+        const double v = zsvec[b * k - (b * (b - 1)) / 2 + (a - b)];
+        Sm[i * P + j] = (a == b) ? v : v * M_SQRT1_2;
+    }
+    __syncthreads();
+    double *Va = Vst, *Vb = Rm;
+    int mode = warm ? 0 : 2;                                        // 0: refined (done), 1: warm Jacobi on (Dm, Vst), 2: cold start
+    if (warm) {
+        double prev_off = 0;
+        mode = 2;
+        for (int it = 0; it < MAXL; it++) {
+            // T = S Va ;  R = I - Va^T Va  (both only read Va: one phase)
+            psd_gemm_kk<NTH>(k, [&](int M, int K) { return Sm[M * P + K]; }, [&](int K, int N) { return Va[K * P + N]; }, [&](int M, int N, double v) { Tm[M * P + N] = v; });
+            psd_gemm_kk<NTH>(k, [&](int M, int K) { return Va[K * P + M]; }, [&](int K, int N) { return Va[K * P + N]; }, [&](int M, int N, double v) { Vb[M * P + N] = (M == N ? 1.0 : 0.0) - v; });
+            __syncthreads();
+            psd_gemm_kk<NTH>(k, [&](int M, int K) { return Va[K * P + M]; }, [&](int K, int N) { return Tm[K * P + N]; }, [&](int M, int N, double v) { Dm[M * P + N] = v; });
+            __syncthreads();
+            double r[5] = {0, 0, 0, 0, 0};                          // off^2, diag^2 (sums) ; clipped, max |R|, max |E_ij| (max)
+            for (int idx = tid; idx < k * k; idx += NT) {
+                const int i = psd_fdiv(idx, rk), j = idx - i * k;
+                const double dii = Dm[i * P + i], rii = Vb[i * P + i];
+                double e;
+                if (i == j) { e = 0.5 * rii; r[1] = fma(dii, dii, r[1]); r[3] = fmax(r[3], fabs(rii)); r[4] = fmax(r[4], fabs(e)); ev[i] = dii * psd_rcp(1.0 - rii); }      // Rayleigh quotient of a column of norm^2 1 - r_ii
+                else {
+                    const double sv = 0.5 * (Dm[i * P + j] + Dm[j * P + i]), rv = 0.5 * (Vb[i * P + j] + Vb[j * P + i]);
+                    const double djj = Dm[j * P + j], rjj = Vb[j * P + j];
+                    const double li = dii * psd_rcp(1.0 - rii), lj = djj * psd_rcp(1.0 - rjj);
+                    const double den = lj - li, num = fma(lj, rv, sv);
+                    if (!(fabs(num) <= 0.5 * fabs(den)) || den == 0.0) { e = 0.5 * rv; if (num != 0.0) r[2] = 1.0; }
+                    else { e = num * psd_rcp(den); r[4] = fmax(r[4], fabs(e)); }
+                    r[0] = fma(sv, sv, r[0]); r[3] = fmax(r[3], fabs(rv));
+                }
+                Tm[i * P + j] = e;
+            }
+            block_reduce_n<5, NW>(r, 0x1Cu, red);
+            const double off2 = r[0], tot = r[0] + r[1];
+            if (it == 0 && r[3] > 1e-6) { mode = 2; break; }        // the stored V drifted from orthogonality (never after a converged call): start over
+                                                                    // (after a step, R = O(|E|^2) is expected and removed by the next one)
+            if (off2 <= 1e-28 * tot && r[3] <= 1e-14) { mode = 0; break; }      // converged, nothing left to correct.  (Both tests: D_ij = (lam_i + lam_j) delta_ij
+                                                                    // does not see a loss of orthogonality between two columns with lam_i = -lam_j, R does)
+            if (r[2] != 0.0 || !refine || (it > 0 && !(off2 <= 0.25 * prev_off))) { mode = (it == 0 && r[3] <= 1e-10) ? 1 : 2; break; }      // (refine == 0: A/B switch, warm Jacobi only)
+            prev_off = off2;
+            // V' = Va + Va E  (into Vb: R is dead)
+            psd_gemm_kk<NTH>(k, [&](int M, int K) { return Va[M * P + K]; }, [&](int K, int N) { return Tm[K * P + N]; }, [&](int M, int N, double v) { Vb[M * P + N] = Va[M * P + N] + v; });
+            __syncthreads();
+            { double *t_ = Va; Va = Vb; Vb = t_; }
+            if (stats && tid == 0) atomicAdd(&stats[1], 1ull);
+            if (r[4] <= 1e-7) { mode = 0; break; }                  // quadratic convergence: the step leaves corrections (and a loss of orthogonality) of order |E|^2 <= 1e-14
+                                                                    // (E_ii = R_ii / 2 counts: the norm inflation |E|^2 / 2 of the previous step is removed by this one).
+                                                                    // (|E|, not the off-diagonal mass, decides: a pair with a tiny gap rotates by off / gap)
+        }
+    }
+    if (mode != 0) {
+        if (mode == 2) {                                            // cold start: V = I, D = S
+            for (int idx = tid; idx < k * k; idx += NT) { const int i = psd_fdiv(idx, rk), j = idx - i * k; Vst[i * P + j] = (i == j) ? 1.0 : 0.0; Dm[i * P + j] = Sm[i * P + j]; }
+        } else {                                                    // warm Jacobi: D = V^T S V, exactly symmetric for the rotations
+            for (int idx = tid; idx < k * k; idx += NT) {
+                const int i = psd_fdiv(idx, rk), j = idx - i * k;
+                if (i > j) { const double a = 0.5 * (Dm[i * P + j] + Dm[j * P + i]); Dm[i * P + j] = a; Dm[j * P + i] = a; }
+            }
+        }
+        if (stats && tid == 0) atomicAdd(&stats[mode == 2 ? 3 : 2], 1ull);
+        __syncthreads();
+        Va = Vst;
+        psd_sweeps_wg<NTH>(Dm, Vst, k, P, cs, red);
+        for (int i = tid; i < k; i += NT) ev[i] = Dm[i * P + i];
+        __syncthreads();
+    }
+    if (stats && tid == 0) atomicAdd(&stats[0], 1ull);
+    // X = (Va diag(w+)) Va^T ;  the refined eigenvectors return to the block's own buffer in the same phase
+    psd_gemm_kk<NTH>(k, [&](int M, int K) { return Va[M * P + K] * fmax(ev[K], 0.0); }, [&](int K, int N) { return Va[N * P + K]; }, [&](int M, int N, double v) { Tm[M * P + N] = v; });
+    if (Va != Vst) for (int idx = tid; idx < k * k; idx += NT) { const int i = psd_fdiv(idx, rk), j = idx - i * k; Vst[i * P + j] = Va[i * P + j]; }
+    __syncthreads();
+    for (int idx = tid; idx < k * k; idx += NT) {          // lower triangle (a >= b) -> svec position b k - b (b - 1) / 2 + (a - b)
+        const int a = psd_fdiv(idx, rk), b = idx - a * k;
+        if (a < b) continue;
+        const double v = 0.5 * (Tm[a * P + b] + Tm[b * P + a]);
+        zsvec[b * k - (b * (b - 1)) / 2 + (a - b)] = (a == b) ? v : v * M_SQRT2;
+    }
+    __syncthreads();
+}
+
 // LDS doubles needed: 3 * KP * (KP + 1) + 2 * k + 8  (+ the reduction scratch of block_reduce_n)
 __host__ __device__ inline int psd_mfma_kp(int k) { return 16 * ((k + 15) / 16); }
 

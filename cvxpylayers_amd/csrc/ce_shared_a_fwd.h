@@ -26,6 +26,8 @@ struct SaFwd {
     const int *scol_row;         // [#singleton entries]
     const double *gs;            // [n]      sum over the singleton rows of column j of d0_i a_i^2
     const double *Dv, *Ev;       // [m], [n] equilibration
+    unsigned long long *psd_stats;   // debug (CE_PSD_STATS=1): projections / refinement steps / warm Jacobi fall-backs / cold starts, or null
+    int psd_refine;                  // 1: eigen-refinement on the matrix cores (default); 0 (CE_PSD_REFINE=0): warm-started Jacobi sweeps only, restart at check iterations (round 2)
 };
 
 // LDS doubles (see the carve in the kernel)
@@ -34,9 +36,9 @@ __host__ __device__ inline size_t sa_fwd_cidx_doubles(int n, int m, int nq, int 
 }
 __host__ __device__ inline size_t sa_fwd_lds_doubles(int n, int m, int nq, int ns, int maxs, int RP, int nth, int ntri = 0) {
     const int l = n + m + 1, lp = l + (l & 1), ne = n + (n & 1), me = m + (m & 1);
-    const int kp = ns > 0 ? psd_mfma_kp(maxs) : 0;
+    const size_t psd = ns > 0 ? (size_t)ns * maxs * psd_refine_pitch(maxs) + psd_refine_scratch_doubles(maxs) : 0;      // V per block + shared scratch (ce_psd_mfma.h)
     return 6 * (size_t)lp + 2 * (size_t)ne + 2 * (size_t)me + 2 * (size_t)RP * (RP + 1) + 5 * (size_t)RP + 2 * (size_t)(nq > 0 ? nq : 1) +
-           (size_t)(ns > 0 ? (ns + 2) * kp * (kp + 1) + 2 * kp + 8 : 0) + 2 * nth + (nth / 64) * 8 + 32 + (size_t)(ntri + (ntri & 1));
+           psd + (psd & 1) + 2 * nth + (nth / 64) * 8 + 32 + (size_t)(ntri + (ntri & 1));
 }
 
 // NTH threads per instance: 256 (two instances per CU when the iterates allow it) or 512 (templates whose iterates fill most of a CU's LDS
@@ -64,10 +66,11 @@ k_sa_fwd(DevT T, SaFwd F, ce_settings S, const double *__restrict__ BHg, const d
     double *K0 = p; p += (size_t)RP * LK;                   // A_d Dg^-1 A_d^T (kept next to its regularised inverse: see the iteration)
     double *vd = p; p += RP; double *zd = p; p += RP; double *wyd = p; p += RP; double *dyd = p; p += 2 * RP;      // dyd[RP ..]: w_d + z of the iteration
     double *socc = p; p += 2 * (nq > 0 ? nq : 1);
-    const int KP = ns > 0 ? psd_mfma_kp(T.maxs) : 0, PM = KP * (KP + 1);
+    const int PM = ns > 0 ? T.maxs * psd_refine_pitch(T.maxs) : 0;     // compact k x k storage (ce_psd_mfma.h, psd_project_refine)
     double *Vst = p; p += (size_t)ns * PM;                 // eigenvectors of every PSD block, kept between iterations
-    double *Sm = p; p += PM; double *Tm = p; p += PM;      // PSD scratch
-    double *cs = p; p += (ns > 0 ? 2 * KP + 8 : 0);
+    double *Sm = p; p += PM; double *Tm = p; p += PM; double *Dm = p; p += PM; double *Rm = p; p += PM;      // PSD scratch: S, T / E, V^T S V, I - V^T V
+    double *cs = p; p += (ns > 0 ? 3 * T.maxs + 16 : 0);
+    { const size_t used = ns > 0 ? (size_t)ns * PM + psd_refine_scratch_doubles(T.maxs) : 0; p += used & 1; }       // keep the vectors below 16-byte aligned
     double *part = p; p += 2 * NT;                              // partial sums of the dense-row products
     double *red = p; p += NW * 8;
     double *sc = p; p += 32;
@@ -310,8 +313,8 @@ k_sa_fwd(DevT T, SaFwd F, ce_settings S, const double *__restrict__ BHg, const d
             };
 #ifndef SA_SKIP_PSD        // (debug builds time the kernel without the projection)
             if constexpr (NTH == 256)          // (templates with PSD blocks always run the 256-thread instantiation)
-            for (int c = 0; c < ns; c++)       // PSD blocks: MFMA sandwich + warm-started Jacobi, eigenvectors stay in LDS (restart at check iterations)
-                psd_project_mfma_lds<NT>(zb + n + T.soff[c], T.sord[c], Sm, Vst + (size_t)c * PM, Tm, cs, red, (!check && iter > 0) ? 1 : 0);
+            for (int c = 0; c < ns; c++)       // PSD blocks: warm-started eigen-refinement on the matrix cores (Jacobi sweeps as the fall-back), eigenvectors stay in LDS
+                psd_project_refine<NT>(zb + n + T.soff[c], T.sord[c], Vst + (size_t)c * PM, Sm, Tm, Dm, Rm, cs, red, (iter > 0 && (F.psd_refine || !check)) ? 1 : 0, F.psd_stats, F.psd_refine);
 #endif
             if (!check && !last) {
                 for (int e = tid; e < l; e += NT) { const double ue = proj_e(e); U[e] = ue; W[e] += alpha * (ue - UT[e]); }

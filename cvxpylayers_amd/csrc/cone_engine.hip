@@ -69,7 +69,8 @@ struct ce_engine {
     int *d_csc_ptr = nullptr, *d_csr_ptr = nullptr, *d_csr_col = nullptr, *d_csr_src = nullptr;   // sparse structure of the A part (shared-A kernels)
     // split of the A part into singleton rows and sp_r <= 64 dense rows (ce_shared_a_ops.h); sp_RP == 0: more than 64 rows with several entries
     int sp_r = 0, sp_RP = 0;
-    bool sa_fwd_attr = false, sa_lsqr_attr = false;   // MaxDynamicSharedMemorySize is per device: set once per engine (an engine is bound to one device, one caller thread)
+    bool sa_fwd_attr = false, sa_lsqr_attr = false;
+    unsigned long long *d_psd_stats = nullptr;     // CE_PSD_STATS=1: counters of the PSD projection (printed to stderr by ce_destroy)   // MaxDynamicSharedMemorySize is per device: set once per engine (an engine is bound to one device, one caller thread)
     int psd_first = 0;           // first row of the first PSD block (m when the template has none)
     int *d_sp_drow = nullptr, *d_sp_srow_col = nullptr, *d_sp_scol_ptr = nullptr, *d_sp_scol_row = nullptr, *d_sp_rowslot = nullptr;
     double *d_sp_AdT = nullptr, *d_sp_sval = nullptr;
@@ -444,6 +445,13 @@ int ce_destroy(ce_handle h) {
     hipFree(h->wsA); hipFree(h->wsdA); hipFree(h->gws); hipFree(h->d_idx_at); hipFree(h->d_idx_ar); hipFree(h->d_idx_b); hipFree(h->d_row_perm); hipFree(h->d_k_rowcone); hipFree(h->d_k_qoff); hipFree(h->d_csc_ptr); hipFree(h->d_csr_ptr); hipFree(h->d_csr_col); hipFree(h->d_csr_src);
     hipFree(h->d_sp_drow); hipFree(h->d_sp_srow_col); hipFree(h->d_sp_scol_ptr); hipFree(h->d_sp_scol_row); hipFree(h->d_sp_rowslot); hipFree(h->d_sp_AdT); hipFree(h->d_sp_sval);
     for (auto &v : h->ev) for (auto &p : v) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+    if (h->d_psd_stats) {
+        unsigned long long c[4] = {0, 0, 0, 0};
+        if (hipDeviceSynchronize() == hipSuccess && hipMemcpy(c, h->d_psd_stats, sizeof(c), hipMemcpyDeviceToHost) == hipSuccess)
+            fprintf(stderr, "[cone_engine] PSD projections %llu: refinement steps %llu (%.2f per projection), warm Jacobi fall-backs %llu, cold starts %llu\n",
+                    c[0], c[1], c[0] ? (double)c[1] / (double)c[0] : 0.0, c[2], c[3]);
+        hipFree(h->d_psd_stats);
+    }
     delete h;
     return CE_OK;
 }
@@ -641,9 +649,8 @@ int ce_ca_psd_mfma(ce_handle h, int B, int lp, double *U, double *Vstate, int wa
     if (!h || B <= 0 || !U || !Vstate || !active) { g_err = "null argument"; return CE_E_BADARG; }
     if (h->T.ns == 0) return CE_OK;
     HIPCHK(hipSetDevice(h->device));
-    const int kp = psd_mfma_kp(h->T.maxs);
-    const size_t lds = (3 * (size_t)kp * (kp + 1) + 2 * kp + 8 + NW * 8) * 8;
-    if (lds > 64 * 1024) { g_err = "PSD order too large for the LDS-resident MFMA projection (order <= 48)"; return CE_E_TOO_LARGE; }
+    const size_t lds = ((size_t)h->T.maxs * psd_refine_pitch(h->T.maxs) + psd_refine_scratch_doubles(h->T.maxs) + NW * 8) * 8;
+    if (lds > 64 * 1024) { g_err = "PSD order too large for the LDS-resident MFMA projection (order <= 39)"; return CE_E_TOO_LARGE; }
     hipLaunchKernelGGL(k_ca_psd_mfma, dim3(B, h->T.ns), dim3(NT), lds, (hipStream_t)stream, h->T, lp, U, Vstate, warm, active);
     HIPCHK(hipGetLastError());
     return CE_OK;
@@ -677,7 +684,9 @@ int ce_solve_shared_a(ce_handle h, int B, int r, int RP, const double *AdT, cons
 #undef SA_ATTR
         h->sa_fwd_attr = true;
     }
-    SaFwd F{r, RP, AdT, drow, srow_col, srow_val, scol_ptr, scol_row, gs, Dv, Ev};
+    if (!h->d_psd_stats && T.ns > 0) { const char *e = getenv("CE_PSD_STATS"); if (e && atoi(e) != 0) { HIPCHK(hipMalloc(&h->d_psd_stats, 4 * sizeof(unsigned long long))); HIPCHK(hipMemset(h->d_psd_stats, 0, 4 * sizeof(unsigned long long))); } }
+    int psd_refine = 1; if (const char *e = getenv("CE_PSD_REFINE")) psd_refine = atoi(e) != 0;
+    SaFwd F{r, RP, AdT, drow, srow_col, srow_val, scol_ptr, scol_row, gs, Dv, Ev, h->d_psd_stats, psd_refine};
     {
         ProfScope ps(h, 0, (hipStream_t)stream);
 #define LAUNCH_SA(NTV, ...) hipLaunchKernelGGL((k_sa_fwd<__VA_ARGS__>), dim3(B), dim3(NTV), lds, (hipStream_t)stream, T, F, *settings, b_hat, c_hat, sigma, nrm_b0, nrm_c0, warm_x, warm_y, warm_s, x, y, s, iters, status, resid)

@@ -261,7 +261,7 @@ def solve_const_a(eng, A_bm: torch.Tensor, q_eval: torch.Tensor, settings, warm=
     UT = torch.zeros((B, lp), **f64); U = torch.zeros((B, lp), **f64)
     roots = torch.zeros((B, max(ntri, 1)), **f64)        # per-cone root of the previous iteration (exp / power projections)
     maxs = max([pb.k for pb in psd], default=0)
-    use_mfma_psd = bool(psd) and maxs <= 48 and os.environ.get("CE_PSD_MFMA", "1") != "0"
+    use_mfma_psd = bool(psd) and maxs <= 39 and os.environ.get("CE_PSD_MFMA", "1") != "0"
     psdV = torch.zeros((B, max(len(psd), 1), max(maxs * maxs, 1)), **f64)        # eigenvectors of every PSD block (state of ce_ca_psd_mfma)
     active = torch.ones(B, dtype=torch.int32, device=dev)
     status = torch.zeros(B, dtype=torch.int32, device=dev)
@@ -301,9 +301,9 @@ def solve_const_a(eng, A_bm: torch.Tensor, q_eval: torch.Tensor, settings, warm=
             # PSD blocks: the step kernel leaves the cone input in U; project it in place (ce_ca_psd: workgroup-parallel Jacobi,
             # ~600x faster than batched rocSOLVER eigh at 20x20), then the relaxed update / renormalisation the kernel skipped
             if psd:
-                if use_mfma_psd:      # contractions on the matrix cores, Jacobi warm-started from the previous iteration's eigenvectors;
-                    #                   restarted from the identity at every check iteration (bounds the drift of the accumulated rotations)
-                    _lib.check(L.ce_ca_psd_mfma(h, Bc, lp, U.data_ptr(), psdV.data_ptr(), int(not check and it > 0), active.data_ptr(), strm), "ce_ca_psd_mfma")
+                if use_mfma_psd:      # matrix cores: eigen-refinement warm-started from the previous iteration's eigenvectors (self-correcting
+                    #                   orthogonality: no restart at check iterations any more)
+                    _lib.check(L.ce_ca_psd_mfma(h, Bc, lp, U.data_ptr(), psdV.data_ptr(), int(it > 0), active.data_ptr(), strm), "ce_ca_psd_mfma")
                 else:
                     _lib.check(L.ce_ca_psd(h, Bc, lp, U.data_ptr(), active.data_ptr(), strm), "ce_ca_psd")
             if ntri:

@@ -193,9 +193,10 @@ int ce_ca_check(ce_handle h, int B, int lp, int iter, const ce_settings *setting
                 double *scale, double *sum_log, int *n_log, int *last_scale_iter, int *active, int *status, int *iters,
                 double *resid, int *rescaled, void *stream);
 int ce_ca_psd(ce_handle h, int B, int lp, double *U, const int *active, void *stream);
-/* The same projection with its dense contractions on the matrix cores (v_mfma_f64_16x16x4_f64: S' = V^T S V, X = V diag(w+) V^T) and
- * a Jacobi eigensolver warm-started from the eigenvectors of the previous call: Vstate (B, ns, maxs * maxs) is caller-owned state,
- * warm = 0 restarts from the identity (callers do so once per check interval to bound the loss of orthogonality).  PSD orders <= 48. */
+/* The same projection on the matrix cores (v_mfma_f64_16x16x4_f64), warm-started from the eigenvectors of the previous call: Vstate
+ * (B, ns, maxs * maxs; row-major k x k per block) is caller-owned state, warm = 0: no previous call.  Warm calls REFINE the previous
+ * decomposition (R = I - V^T V, D = V^T S V, first-order correction V <- V + V E, quadratically convergent, orthogonality self-correcting:
+ * no periodic restart needed) and fall back to Jacobi sweeps when a correction would exceed 1/2 for some pair.  PSD orders <= 39. */
 int ce_ca_psd_mfma(ce_handle h, int B, int lp, double *U, double *Vstate, int warm, const int *active, void *stream);
 /* Exponential / power cone triples of the cone input U (B, lp) projected in place (after ce_ca_step, like ce_ca_psd); roots
  * (B, nep + np) is caller-owned state: each cone's root of the previous iteration (zero-initialised). */
