@@ -222,7 +222,7 @@ k_ca_psd_mfma(DevT T, int lp, double *__restrict__ Ug, double *__restrict__ Vsta
     if (!active[inst]) return;
     const int k = T.sord[c], P = psd_refine_pitch(k);
     const int PM = T.maxs * psd_refine_pitch(T.maxs);
-    double *Vl = sm, *Sm = Vl + PM, *Tm = Sm + PM, *Dm = Tm + PM, *Rm = Dm + PM, *cs = Rm + PM, *red = cs + 3 * T.maxs + 16;
+    double *Vl = sm, *Sm = Vl + PM, *Tm = Sm + PM, *Dm = Tm + PM, *Rm = Dm + PM, *cs = Rm + PM, *red = cs + 4 * T.maxs + 16;
     double *Vg = Vstate + ((size_t)inst * T.ns + c) * T.maxs * T.maxs;
     if (warm) for (int idx = threadIdx.x; idx < k * k; idx += NT) { const int i = idx / k, j = idx - i * k; Vl[i * P + j] = Vg[idx]; }
     __syncthreads();

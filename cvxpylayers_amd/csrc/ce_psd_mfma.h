@@ -59,7 +59,7 @@ __device__ __forceinline__ void psd_mfma_gemm(int KT, FA &&fa, FB &&fb, FO &&out
 // floor -- already tiny (1e-12) and no longer decreasing.  (Variants that were measured and dropped: one wave doing the whole sweep without
 // workgroup barriers; one barrier per round with recomputed or pipelined rotations -- ROUND_NOTES.md.)
 template <int NTH>
-__device__ __forceinline__ void psd_sweeps_wg(double *Sm, double *Vm, int k, int P, double *cs, double *red) {
+__device__ __forceinline__ void psd_sweeps_wg(double *Sm, double *Vm, int k, int P, double *cs, double *red, double stop_rel = 0.0) {      // stop_rel > 0: stop as soon as off^2 <= stop_rel * total (a refinement polishes)
     constexpr int NT = NTH, NW = NTH / 64;
     const int tid = threadIdx.x;
     const int K = (k + 1) & ~1, H = K / 2;
@@ -69,7 +69,7 @@ __device__ __forceinline__ void psd_sweeps_wg(double *Sm, double *Vm, int k, int
         double r[2] = {0, 0};
         for (int idx = tid; idx < k * k; idx += NT) { const int i = psd_fdiv(idx, rk), j = idx - i * k; const double v = Sm[i * P + j]; if (i == j) r[1] = fma(v, v, r[1]); else r[0] = fma(v, v, r[0]); }
         block_reduce_n<2, NW>(r, 0u, red);
-        if (r[0] <= 1e-30 * (r[0] + r[1]) || r[0] == 0.0 || (r[0] <= 1e-24 * (r[0] + r[1]) && r[0] > 0.25 * prev_off)) break;          // uniform
+        if (r[0] <= 1e-30 * (r[0] + r[1]) || r[0] == 0.0 || (r[0] <= 1e-24 * (r[0] + r[1]) && r[0] > 0.25 * prev_off) || r[0] <= stop_rel * (r[0] + r[1])) break;          // uniform
         prev_off = r[0];
         for (int rd = 0; rd < K - 1; rd++) {
             if (tid < H) {
@@ -83,7 +83,8 @@ __device__ __forceinline__ void psd_sweeps_wg(double *Sm, double *Vm, int k, int
                 cs[4 * t] = c; cs[4 * t + 1] = sn; cs[4 * t + 2] = (double)p; cs[4 * t + 3] = (double)q;
             }
             __syncthreads();
-            for (int w = tid; w < H * H + k * H; w += NT) {
+            const int kh = (k + 1) >> 1;                               // V <- V J: two rows per work item (k = 20: 100 + 100 items, one pass of 256 threads)
+            for (int w = tid; w < H * H + kh * H; w += NT) {
                 if (w < H * H) {                                       // S <- J^T S J on the 2 x 2 block (pair a) x (pair b)
                     const int a = psd_fdiv(w, rH), b = w - a * H;
                     const double ca = cs[4 * a], sa = cs[4 * a + 1], cb = cs[4 * b], sb = cs[4 * b + 1];
@@ -95,12 +96,17 @@ __device__ __forceinline__ void psd_sweeps_wg(double *Sm, double *Vm, int k, int
                     if (qa >= 0) Sm[qa * P + pb] = sa * t00 + ca * t10;
                     if (qa >= 0 && qb >= 0) Sm[qa * P + qb] = sa * t01 + ca * t11;
                 } else {                                               // V <- V J
-                    const int it = w - H * H, row = psd_fdiv(it, rH), b = it - row * H;
+                    const int it = w - H * H, rp = psd_fdiv(it, rH), b = it - rp * H;
                     const int pb = (int)cs[4 * b + 2], qb = (int)cs[4 * b + 3];
                     if (qb >= 0) {
                         const double cb = cs[4 * b], sb = cs[4 * b + 1];
+                        const int row = 2 * rp;
                         const double x = Vm[row * P + pb], y = Vm[row * P + qb];
                         Vm[row * P + pb] = cb * x - sb * y; Vm[row * P + qb] = sb * x + cb * y;
+                        if (row + 1 < k) {
+                            const double x1 = Vm[(row + 1) * P + pb], y1 = Vm[(row + 1) * P + qb];
+                            Vm[(row + 1) * P + pb] = cb * x1 - sb * y1; Vm[(row + 1) * P + qb] = sb * x1 + cb * y1;
+                        }
                     }
                 }
             }
@@ -124,18 +130,36 @@ __device__ __forceinline__ void psd_sweeps_wg(double *Sm, double *Vm, int k, int
 // has drifted from orthogonality or a refinement step was already taken).
 // Storage: COMPACT k x k row-major matrices with pitch P >= k (no zero padding; the MFMA operand reads are guarded), the contraction runs
 // over ceil(k / 4) steps of 4 instead of the padded KP / 4 (k = 20: 5 steps, not 8).
-template <int NTH, class FA, class FB, class FO>
-__device__ __forceinline__ void psd_gemm_kk(int k, FA &&fa, FB &&fb, FO &&out) {
+// out(M, N, sum_K A(M, K) B(K, N)) for M, N < k, with A(M, K) = pA[M * sAm + K * sAk] (* wK[K] when wK != null) and B(K, N) = pB[K * sBk + N * sBn].
+// Address arithmetic is what this costs (the products themselves are five MFMA instructions per tile at k = 20): row / column indices beyond k
+// are CLAMPED instead of guarded (their results are never stored), each lane keeps one base pointer per operand and steps it by a uniform
+// stride, the operands of up to five contraction steps are loaded before their products are issued; only a contraction index beyond k
+// (last step of a k that is not a multiple of 4) is masked to zero.
+template <int NTH, class FO>
+__device__ __forceinline__ void psd_gemm_kk(int k, const double *pA, int sAm, int sAk, const double *pB, int sBk, int sBn, const double *wK, FO &&out) {
     const int KT = (k + 15) >> 4, KS = (k + 3) >> 2;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lg = lane >> 4, lc = lane & 15;
     for (int t = wave; t < KT * KT; t += NTH / 64) {
         const int ti = t / KT, tj = t - ti * KT;
         const int am = 16 * ti + lc, bn = 16 * tj + lc;
+        const double *qa = pA + min(am, k - 1) * sAm + lg * sAk, *qb = pB + lg * sBk + min(bn, k - 1) * sBn;
+        const double *qw = wK ? wK + lg : nullptr;
         psd_v4d acc = {0.0, 0.0, 0.0, 0.0};
-        for (int s = 0; s < KS; s++) {
-            const int kk = 4 * s + lg;
-            const double a = (am < k && kk < k) ? fa(am, kk) : 0.0, b = (bn < k && kk < k) ? fb(kk, bn) : 0.0;
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+        constexpr int CH = 5;
+        for (int s0 = 0; s0 < KS; s0 += CH) {
+            double a[CH], b[CH];
+#pragma unroll
+            for (int u = 0; u < CH; u++) {
+                const int st = s0 + u, kk = 4 * st + lg;
+                if (st < KS) {                                     // uniform
+                    const int kc = (kk < k) ? 4 * st : (k - 1 - lg);       // clamped contraction index (relative to the lane's lg)
+                    a[u] = qa[kc * sAk]; b[u] = qb[kc * sBk];
+                    if (qw) a[u] *= qw[kc];
+                    if (kk >= k) a[u] = 0.0;
+                } else { a[u] = 0.0; b[u] = 0.0; }
+            }
+#pragma unroll
+            for (int u = 0; u < CH; u++) if (s0 + u < KS) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
         }
 #pragma unroll
         for (int r = 0; r < 4; r++) { const int M = 16 * ti + lg + 4 * r; if (M < k && bn < k) out(M, bn, acc[r]); }
@@ -143,19 +167,187 @@ __device__ __forceinline__ void psd_gemm_kk(int k, FA &&fa, FB &&fb, FO &&out) {
 }
 
 __host__ __device__ inline int psd_refine_pitch(int k) { return k | 1; }                 // odd pitch: the strided operand reads spread over the banks
-// LDS doubles of the scratch shared by all blocks of an instance (S, T, D, R + rotation parameters + eigenvalues); every block keeps k P more (V)
-__host__ __device__ inline int psd_refine_scratch_doubles(int kmax) { return 4 * kmax * psd_refine_pitch(kmax) + 3 * kmax + 16; }
+// LDS doubles of the scratch shared by all blocks of an instance (S, T / E, D, R + rotation parameters + eigenvalues + lam); every block keeps k P more (V)
+__host__ __device__ inline int psd_refine_scratch_doubles(int kmax) { return 4 * kmax * psd_refine_pitch(kmax) + 4 * kmax + 16; }
+
+// phase timing (debug, stats != null): ticks are accumulated in registers and flushed once per projection -- a global atomic per phase would stall
+// the instrumented wave for longer than the phase itself
+#define PSD_TICK(slot) do { if (stats) { const long long t_ = clock64(); tk[(slot) - 8] += t_ - tph; tph = t_; } } while (0)
+
+// One refinement loop.  Returns 0: converged (Va: eigenvectors, ev: eigenvalues);  1: the very first step would leave the basin of the first-order
+// correction and Va is still the caller's orthonormal V: D = Va^T S Va was written to Dm (not symmetrised) for Jacobi sweeps;  2: start over (cold).
+// FUSED version (k <= 32, one 16 x 16 tile of D and R per wave, kept in the MFMA accumulators): THREE barriers per step instead of six, and neither
+// T = S V nor D, R ever go through LDS --
+//   A. every wave forms the column block T(:, tj) = S V(:, tj) of its own tile in registers (the accumulator layout of a tile IS the B-operand
+//      layout of the next product: row lg + 4 q of lane l = contraction index 4 s + lg for q = s), then D(ti, tj) = V(:, ti)^T T(:, tj) and
+//      (V^T V)(ti, tj) with the same A operand; the diagonal lanes publish lam_i = D_ii (1 + R_ii)                                          | barrier
+//   B. E for the lane's own four entries straight from the accumulators (D_ij is used as it is: the two triangles differ by rounding only),
+//      E -> LDS, the step's statistics as one DPP reduction per wave                                                                        | barrier
+//   C. every thread combines the four partial statistics, decides, V' = V + V E                                                            | barrier
+template <int NTH>
+__device__ __forceinline__ int psd_refine_loop_fused(int k, int P, const double *Sm, double *&Va, double *&Vb, double *Tm, double *Dm, double *lam, double *ev,
+                                                      double *red, unsigned long long *stats, int refine, int maxl, long long (&tk)[6]) {
+    constexpr int NW = NTH / 64, KSM = 5;                      // k <= 20: five contraction steps (the caller routes larger blocks to the LDS loop)
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lg = lane >> 4, lc = lane & 15;
+    const int KT = (k + 15) >> 4, KS = (k + 3) >> 2;
+    const bool has_tile = wave < KT * KT;
+    const int ti = (KT == 2) ? (wave >> 1) : 0, tj = (KT == 2) ? (wave & 1) : 0;
+    const int am = 16 * ti + lc, bn = 16 * tj + lc, amc = min(am, k - 1), bnc = min(bn, k - 1);
+    long long tph = stats ? clock64() : 0;
+    double prev_off = 0;
+    for (int it = 0; it < maxl; it++) {
+        psd_v4d aD = {0.0, 0.0, 0.0, 0.0}, aG = {0.0, 0.0, 0.0, 0.0};         // D tile, (V^T V) tile
+        if (has_tile) {
+            // contraction index of step u for this lane: 4 u + lg, clamped to k - 1; steps beyond k contribute zero through the A operand
+            double bv[KSM];
+#pragma unroll
+            for (int u = 0; u < KSM; u++) if (u < KS) bv[u] = Va[min(4 * u + lg, k - 1) * P + bnc];
+            psd_v4d aT0 = {0.0, 0.0, 0.0, 0.0}, aT1 = {0.0, 0.0, 0.0, 0.0};
+            {
+                const double *srow = Sm + min(lc, k - 1) * P;
+#pragma unroll
+                for (int u = 0; u < KSM; u++) if (u < KS) { const int kk = 4 * u + lg; const double a = (kk < k) ? srow[min(kk, k - 1)] : 0.0; aT0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv[u], aT0, 0, 0, 0); }
+                if (KT == 2) {
+                    const double *srow1 = Sm + min(16 + lc, k - 1) * P;
+#pragma unroll
+                    for (int u = 0; u < KSM; u++) if (u < KS) { const int kk = 4 * u + lg; const double a = (kk < k) ? srow1[min(kk, k - 1)] : 0.0; aT1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv[u], aT1, 0, 0, 0); }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < KSM; u++) if (u < KS) {
+                const int kk = 4 * u + lg;
+                const double av = (kk < k) ? Va[min(kk, k - 1) * P + amc] : 0.0;
+                const double tb = (u < 4) ? aT0[u & 3] : aT1[u & 3];
+                aD = __builtin_amdgcn_mfma_f64_16x16x4f64(av, tb, aD, 0, 0, 0);
+                aG = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[u], aG, 0, 0, 0);
+            }
+            if (ti == tj) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int M = 16 * ti + lg + 4 * r;
+                    if (M == bn && M < k) { const double rii = 1.0 - aG[r]; lam[M] = fma(aD[r], rii, aD[r]); ev[M] = aD[r] * psd_rcp(1.0 - rii); }
+                }
+            }
+        }
+        __syncthreads();
+        PSD_TICK(8);
+        double r[4] = {0, 0, 0, 0};                                   // off^2, diag^2 (sums) ; max |R|, max |E| (1e300: a pair outside the basin) (max)
+        if (has_tile && bn < k) {
+            const double lj = lam[bn];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int M = 16 * ti + lg + 4 * q;
+                if (M >= k) continue;
+                const double d = aD[q], rr = (M == bn ? 1.0 : 0.0) - aG[q];
+                double e;
+                if (M == bn) { e = 0.5 * rr; r[1] = fma(d, d, r[1]); r[3] = fmax(r[3], fabs(e)); }
+                else {
+                    const double den = lj - lam[M], num = fma(lj, rr, d);
+                    if (!(fabs(num) <= 0.8 * fabs(den)) || den == 0.0) { e = 0.5 * rr; if (num != 0.0) r[3] = 1e300; }
+                    else { e = num * psd_rcp(den); r[3] = fmax(r[3], fabs(e)); }
+                    r[0] = fma(d, d, r[0]);
+                }
+                r[2] = fmax(r[2], fabs(rr));
+                Tm[M * P + bn] = e;
+            }
+        }
+        r[0] = wave_reduce_dpp<false>(r[0]); r[1] = wave_reduce_dpp<false>(r[1]); r[2] = wave_reduce_dpp<true>(r[2]); r[3] = wave_reduce_dpp<true>(r[3]);
+        if (lane == 0) { red[4 * wave] = r[0]; red[4 * wave + 1] = r[1]; red[4 * wave + 2] = r[2]; red[4 * wave + 3] = r[3]; }
+        __syncthreads();
+        PSD_TICK(9);
+        double off2 = 0, dg2 = 0, rmax = 0, emax = 0;
+#pragma unroll
+        for (int w = 0; w < NW; w++) { off2 += red[4 * w]; dg2 += red[4 * w + 1]; rmax = fmax(rmax, red[4 * w + 2]); emax = fmax(emax, red[4 * w + 3]); }
+        const double tot = off2 + dg2;
+        if (it == 0 && rmax > 1e-6) return 2;                         // the stored V drifted from orthogonality (never after a converged call)
+        if (off2 <= 1e-28 * tot && rmax <= 1e-14) return 0;           // converged, nothing left to correct (both tests: D_ij = (lam_i + lam_j) delta_ij does not
+                                                                      // see a loss of orthogonality between two columns with lam_i = -lam_j, R does)
+        if (emax >= 1e300 || !refine || (it > 0 && !(off2 <= 0.25 * prev_off))) {
+            if (it > 0 || rmax > 1e-10) return 2;
+            if (has_tile && bn < k) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) { const int M = 16 * ti + lg + 4 * q; if (M < k) Dm[M * P + bn] = aD[q]; }
+            }
+            __syncthreads();
+            return 1;
+        }
+        prev_off = off2;
+        psd_gemm_kk<NTH>(k, Va, P, 1, Tm, P, 1, nullptr, [&](int M, int N, double v) { Vb[M * P + N] = Va[M * P + N] + v; });      // V' = Va + Va E
+        __syncthreads();
+        { double *t_ = Va; Va = Vb; Vb = t_; }
+        PSD_TICK(10);
+        if (stats && tid == 0) atomicAdd(&stats[1], 1ull);
+        if (emax <= 1e-7) return 0;                                   // quadratic convergence: this step leaves corrections (and a loss of orthogonality) of order |E|^2 <= 1e-14.
+                                                                      // E_ii = R_ii / 2 counts (the norm inflation |E|^2 / 2 of the previous step is removed by this one); |E|, not the
+                                                                      // off-diagonal mass, decides (a pair with a tiny gap rotates by off / gap)
+    }
+    return 2;
+}
+
+// The same loop with T, D, R materialised in LDS (any k; six barriers per step): used for k > 32 only.
+template <int NTH>
+__device__ __forceinline__ int psd_refine_loop_lds(int k, int P, const double *Sm, double *&Va, double *&Vb, double *Tm, double *Dm, double *ev,
+                                                    double *red, unsigned long long *stats, int refine, int maxl) {
+    constexpr int NT = NTH, NW = NTH / 64;
+    const int tid = threadIdx.x;
+    const float rk = 1.0f / (float)k;
+    double prev_off = 0;
+    for (int it = 0; it < maxl; it++) {
+        psd_gemm_kk<NTH>(k, Sm, P, 1, Va, P, 1, nullptr, [&](int M, int N, double v) { Tm[M * P + N] = v; });                                  // T = S Va
+        psd_gemm_kk<NTH>(k, Va, 1, P, Va, P, 1, nullptr, [&](int M, int N, double v) { Vb[M * P + N] = (M == N ? 1.0 : 0.0) - v; });           // R = I - Va^T Va
+        __syncthreads();
+        psd_gemm_kk<NTH>(k, Va, 1, P, Tm, P, 1, nullptr, [&](int M, int N, double v) { Dm[M * P + N] = v; });                                  // D = Va^T T
+        __syncthreads();
+        double r[5] = {0, 0, 0, 0, 0};                          // off^2, diag^2 (sums) ; clipped, max |R|, max |E| (max)
+        for (int i = tid; i < k; i += NT) {
+            const double dii = Dm[i * P + i], rii = Vb[i * P + i], e = 0.5 * rii;
+            Tm[i * P + i] = e; ev[i] = dii * psd_rcp(1.0 - rii);
+            r[1] = fma(dii, dii, r[1]); r[3] = fmax(r[3], fabs(rii)); r[4] = fmax(r[4], fabs(e));
+        }
+        const int hr = (k + 1) >> 1;                            // pairs i < j, one work item each: rows i and k - 1 - i folded into one row of k items
+        for (int idx = tid; idx < hr * k; idx += NT) {
+            const int i0 = psd_fdiv(idx, rk), j0 = idx - i0 * k;
+            int i, j;
+            if (j0 > i0) { i = i0; j = j0; } else if (j0 < i0 && 2 * i0 != k - 1) { i = k - 1 - i0; j = k - 1 - j0; } else continue;
+            const double sv = 0.5 * (Dm[i * P + j] + Dm[j * P + i]), rv = 0.5 * (Vb[i * P + j] + Vb[j * P + i]);
+            const double dii = Dm[i * P + i], djj = Dm[j * P + j], rii = Vb[i * P + i], rjj = Vb[j * P + j];
+            const double li = fma(dii, rii, dii), lj = fma(djj, rjj, djj);
+            const double den = lj - li, nij = fma(lj, rv, sv), nji = fma(li, rv, sv), lim = 0.8 * fabs(den);
+            double eij, eji;
+            if (!(fabs(nij) <= lim) || !(fabs(nji) <= lim) || den == 0.0) { eij = eji = 0.5 * rv; if (nij != 0.0 || nji != 0.0) r[2] = 1.0; }
+            else { const double inv = psd_rcp(den); eij = nij * inv; eji = -nji * inv; r[4] = fmax(r[4], fmax(fabs(eij), fabs(eji))); }
+            Tm[i * P + j] = eij; Tm[j * P + i] = eji;
+            r[0] = fma(2.0 * sv, sv, r[0]); r[3] = fmax(r[3], fabs(rv));
+        }
+        block_reduce_n<5, NW>(r, 0x1Cu, red);
+        const double off2 = r[0], tot = r[0] + r[1];
+        if (it == 0 && r[3] > 1e-6) return 2;
+        if (off2 <= 1e-28 * tot && r[3] <= 1e-14) return 0;
+        if (r[2] != 0.0 || !refine || (it > 0 && !(off2 <= 0.25 * prev_off))) return (it == 0 && r[3] <= 1e-10) ? 1 : 2;
+        prev_off = off2;
+        psd_gemm_kk<NTH>(k, Va, P, 1, Tm, P, 1, nullptr, [&](int M, int N, double v) { Vb[M * P + N] = Va[M * P + N] + v; });
+        __syncthreads();
+        { double *t_ = Va; Va = Vb; Vb = t_; }
+        if (stats && tid == 0) atomicAdd(&stats[1], 1ull);
+        if (r[4] <= 1e-7) return 0;
+    }
+    return 2;
+}
 
 // zsvec (svec of S) is replaced by svec(Pi_PSD(S)).  Vst: k x k (pitch P) eigenvectors of the previous call of THIS block, kept by the caller between
-// calls (LDS); warm == 0: no previous call.  Sm, Tm, Dm, Rm: k x P scratch each; cs: 3 k + 16 doubles; red: block_reduce scratch.
-// stats (debug builds, may be null): [0] projections, [1] refinement steps, [2] warm Jacobi fall-backs, [3] cold starts.
+// calls (LDS); warm == 0: no previous call.  Sm, Tm, Dm, Rm: k x P scratch each; cs: 4 k + 16 doubles; red: block_reduce scratch.
+// Strategy: refine the previous decomposition; when that is not possible (first call, a step outside the basin) run Jacobi sweeps only until the
+// off-diagonal mass is 1e-3 of the total and let the refinement polish (quadratic, ~1 k cycles per step against ~27 k per sweep); if even that
+// leaves the basin (clustered eigenvalues), sweep to full accuracy.
+// stats (debug, may be null): [0] projections, [1] refinement steps, [2] warm Jacobi fall-backs, [3] cold starts, [6] ticks in the sweeps, [8..] ticks per phase.
 template <int NTH>
 __device__ __forceinline__ void psd_project_refine(double *zsvec, int k, double *Vst, double *Sm, double *Tm, double *Dm, double *Rm, double *cs,
                                                    double *red, int warm, unsigned long long *stats = nullptr, int refine = 1) {
-    constexpr int NT = NTH, NW = NTH / 64, MAXL = 6;
+    constexpr int NT = NTH, NW = NTH / 64, MAXL = 8;
     const int tid = threadIdx.x, P = psd_refine_pitch(k);
     const float rk = 1.0f / (float)k;
-    double *ev = cs + 2 * (k + 2);                                  // eigenvalues (cs[0 ..]: rotation parameters of the Jacobi sweeps)
+    double *ev = cs + 2 * (k + 2), *lam = ev + k;                   // eigenvalues, lam of the fused loop (cs[0 ..]: rotation parameters of the Jacobi sweeps)
+    const bool fused = k <= 20 && NW >= ((k + 15) >> 4) * ((k + 15) >> 4);
     for (int idx = tid; idx < k * k; idx += NT) {
         const int i = psd_fdiv(idx, rk), j = idx - i * k;
         const int a = i >= j ? i : j, b = i >= j ? j : i;           // lower-triangle entry (a, b), column-major packed
@@ -164,54 +356,16 @@ __device__ __forceinline__ void psd_project_refine(double *zsvec, int k, double 
     }
     __syncthreads();
     double *Va = Vst, *Vb = Rm;
-    int mode = warm ? 0 : 2;                                        // 0: refined (done), 1: warm Jacobi on (Dm, Vst), 2: cold start
-    if (warm) {
-        double prev_off = 0;
-        mode = 2;
-        for (int it = 0; it < MAXL; it++) {
-            // T = S Va ;  R = I - Va^T Va  (both only read Va: one phase)
-            psd_gemm_kk<NTH>(k, [&](int M, int K) { return Sm[M * P + K]; }, [&](int K, int N) { return Va[K * P + N]; }, [&](int M, int N, double v) { Tm[M * P + N] = v; });
-            psd_gemm_kk<NTH>(k, [&](int M, int K) { return Va[K * P + M]; }, [&](int K, int N) { return Va[K * P + N]; }, [&](int M, int N, double v) { Vb[M * P + N] = (M == N ? 1.0 : 0.0) - v; });
-            __syncthreads();
-            psd_gemm_kk<NTH>(k, [&](int M, int K) { return Va[K * P + M]; }, [&](int K, int N) { return Tm[K * P + N]; }, [&](int M, int N, double v) { Dm[M * P + N] = v; });
-            __syncthreads();
-            double r[5] = {0, 0, 0, 0, 0};                          // off^2, diag^2 (sums) ; clipped, max |R|, max |E_ij| (max)
-            for (int idx = tid; idx < k * k; idx += NT) {
-                const int i = psd_fdiv(idx, rk), j = idx - i * k;
-                const double dii = Dm[i * P + i], rii = Vb[i * P + i];
-                double e;
-                if (i == j) { e = 0.5 * rii; r[1] = fma(dii, dii, r[1]); r[3] = fmax(r[3], fabs(rii)); r[4] = fmax(r[4], fabs(e)); ev[i] = dii * psd_rcp(1.0 - rii); }      // Rayleigh quotient of a column of norm^2 1 - r_ii
-                else {
-                    const double sv = 0.5 * (Dm[i * P + j] + Dm[j * P + i]), rv = 0.5 * (Vb[i * P + j] + Vb[j * P + i]);
-                    const double djj = Dm[j * P + j], rjj = Vb[j * P + j];
-                    const double li = dii * psd_rcp(1.0 - rii), lj = djj * psd_rcp(1.0 - rjj);
-                    const double den = lj - li, num = fma(lj, rv, sv);
-                    if (!(fabs(num) <= 0.5 * fabs(den)) || den == 0.0) { e = 0.5 * rv; if (num != 0.0) r[2] = 1.0; }
-                    else { e = num * psd_rcp(den); r[4] = fmax(r[4], fabs(e)); }
-                    r[0] = fma(sv, sv, r[0]); r[3] = fmax(r[3], fabs(rv));
-                }
-                Tm[i * P + j] = e;
-            }
-            block_reduce_n<5, NW>(r, 0x1Cu, red);
-            const double off2 = r[0], tot = r[0] + r[1];
-            if (it == 0 && r[3] > 1e-6) { mode = 2; break; }        // the stored V drifted from orthogonality (never after a converged call): start over
-                                                                    // (after a step, R = O(|E|^2) is expected and removed by the next one)
-            if (off2 <= 1e-28 * tot && r[3] <= 1e-14) { mode = 0; break; }      // converged, nothing left to correct.  (Both tests: D_ij = (lam_i + lam_j) delta_ij
-                                                                    // does not see a loss of orthogonality between two columns with lam_i = -lam_j, R does)
-            if (r[2] != 0.0 || !refine || (it > 0 && !(off2 <= 0.25 * prev_off))) { mode = (it == 0 && r[3] <= 1e-10) ? 1 : 2; break; }      // (refine == 0: A/B switch, warm Jacobi only)
-            prev_off = off2;
-            // V' = Va + Va E  (into Vb: R is dead)
-            psd_gemm_kk<NTH>(k, [&](int M, int K) { return Va[M * P + K]; }, [&](int K, int N) { return Tm[K * P + N]; }, [&](int M, int N, double v) { Vb[M * P + N] = Va[M * P + N] + v; });
-            __syncthreads();
-            { double *t_ = Va; Va = Vb; Vb = t_; }
-            if (stats && tid == 0) atomicAdd(&stats[1], 1ull);
-            if (r[4] <= 1e-7) { mode = 0; break; }                  // quadratic convergence: the step leaves corrections (and a loss of orthogonality) of order |E|^2 <= 1e-14
-                                                                    // (E_ii = R_ii / 2 counts: the norm inflation |E|^2 / 2 of the previous step is removed by this one).
-                                                                    // (|E|, not the off-diagonal mass, decides: a pair with a tiny gap rotates by off / gap)
+    long long tk[6] = {0, 0, 0, 0, 0, 0};
+    int res = warm ? -1 : 2;                                        // -1: try to refine the caller's V
+    for (int attempt = 0;; attempt++) {
+        if (res < 0 || (res == 3 && refine)) {
+            Va = Vst; Vb = Rm;
+            res = fused ? psd_refine_loop_fused<NTH>(k, P, Sm, Va, Vb, Tm, Dm, lam, ev, red, stats, refine, MAXL, tk)
+                        : psd_refine_loop_lds<NTH>(k, P, Sm, Va, Vb, Tm, Dm, ev, red, stats, refine, MAXL);
+            if (res == 0) break;
         }
-    }
-    if (mode != 0) {
-        if (mode == 2) {                                            // cold start: V = I, D = S
+        if (res == 2) {                                             // cold start: V = I, D = S
             for (int idx = tid; idx < k * k; idx += NT) { const int i = psd_fdiv(idx, rk), j = idx - i * k; Vst[i * P + j] = (i == j) ? 1.0 : 0.0; Dm[i * P + j] = Sm[i * P + j]; }
         } else {                                                    // warm Jacobi: D = V^T S V, exactly symmetric for the rotations
             for (int idx = tid; idx < k * k; idx += NT) {
@@ -219,16 +373,24 @@ __device__ __forceinline__ void psd_project_refine(double *zsvec, int k, double 
                 if (i > j) { const double a = 0.5 * (Dm[i * P + j] + Dm[j * P + i]); Dm[i * P + j] = a; Dm[j * P + i] = a; }
             }
         }
-        if (stats && tid == 0) atomicAdd(&stats[mode == 2 ? 3 : 2], 1ull);
+        if (stats && tid == 0) atomicAdd(&stats[res == 2 ? 3 : 2], 1ull);
         __syncthreads();
         Va = Vst;
-        psd_sweeps_wg<NTH>(Dm, Vst, k, P, cs, red);
+        const bool coarse = refine && attempt == 0;                 // first fall-back: sweep into the basin of the refinement only
+        const long long tj0 = stats ? clock64() : 0;
+        psd_sweeps_wg<NTH>(Dm, Vst, k, P, cs, red, coarse ? 1e-6 : 0.0);
+        if (stats && tid == 0) atomicAdd(&stats[6], (unsigned long long)(clock64() - tj0));
+        if (coarse) { res = 3; continue; }                          // (the sweeps end with the barriers of their last reduction)
         for (int i = tid; i < k; i += NT) ev[i] = Dm[i * P + i];
         __syncthreads();
+        break;
     }
     if (stats && tid == 0) atomicAdd(&stats[0], 1ull);
+    long long tph = stats ? clock64() : 0;
+    for (int i = tid; i < k; i += NT) ev[i] = fmax(ev[i], 0.0);
+    __syncthreads();
     // X = (Va diag(w+)) Va^T ;  the refined eigenvectors return to the block's own buffer in the same phase
-    psd_gemm_kk<NTH>(k, [&](int M, int K) { return Va[M * P + K] * fmax(ev[K], 0.0); }, [&](int K, int N) { return Va[N * P + K]; }, [&](int M, int N, double v) { Tm[M * P + N] = v; });
+    psd_gemm_kk<NTH>(k, Va, P, 1, Va, 1, P, ev, [&](int M, int N, double v) { Tm[M * P + N] = v; });
     if (Va != Vst) for (int idx = tid; idx < k * k; idx += NT) { const int i = psd_fdiv(idx, rk), j = idx - i * k; Vst[i * P + j] = Va[i * P + j]; }
     __syncthreads();
     for (int idx = tid; idx < k * k; idx += NT) {          // lower triangle (a >= b) -> svec position b k - b (b - 1) / 2 + (a - b)
@@ -238,6 +400,8 @@ __device__ __forceinline__ void psd_project_refine(double *zsvec, int k, double 
         zsvec[b * k - (b * (b - 1)) / 2 + (a - b)] = (a == b) ? v : v * M_SQRT2;
     }
     __syncthreads();
+    PSD_TICK(13);
+    if (stats && tid == 0) for (int q = 0; q < 6; q++) atomicAdd(&stats[8 + q], (unsigned long long)tk[q]);
 }
 
 // LDS doubles needed: 3 * KP * (KP + 1) + 2 * k + 8  (+ the reduction scratch of block_reduce_n)

@@ -69,7 +69,7 @@ k_sa_fwd(DevT T, SaFwd F, ce_settings S, const double *__restrict__ BHg, const d
     const int PM = ns > 0 ? T.maxs * psd_refine_pitch(T.maxs) : 0;     // compact k x k storage (ce_psd_mfma.h, psd_project_refine)
     double *Vst = p; p += (size_t)ns * PM;                 // eigenvectors of every PSD block, kept between iterations
     double *Sm = p; p += PM; double *Tm = p; p += PM; double *Dm = p; p += PM; double *Rm = p; p += PM;      // PSD scratch: S, T / E, V^T S V, I - V^T V
-    double *cs = p; p += (ns > 0 ? 3 * T.maxs + 16 : 0);
+    double *cs = p; p += (ns > 0 ? 4 * T.maxs + 16 : 0);
     { const size_t used = ns > 0 ? (size_t)ns * PM + psd_refine_scratch_doubles(T.maxs) : 0; p += used & 1; }       // keep the vectors below 16-byte aligned
     double *part = p; p += 2 * NT;                              // partial sums of the dense-row products
     double *red = p; p += NW * 8;
@@ -215,6 +215,7 @@ k_sa_fwd(DevT T, SaFwd F, ce_settings S, const double *__restrict__ BHg, const d
         for (;;) {
             if (iter >= S.max_iters) { done = true; break; }
             const bool check = (iter % CONVERGED_INTERVAL) == 0, last = iter + 1 >= S.max_iters;
+            const long long t_iter0 = F.psd_stats ? clock64() : 0;
             if (check && iter > 0) {       // keep the homogeneous iterate in range
                 double rn[1] = {0};
                 for (int e = tid; e < l; e += NT) rn[0] = fma(W[e], W[e], rn[0]);
@@ -312,9 +313,12 @@ k_sa_fwd(DevT T, SaFwd F, ce_settings S, const double *__restrict__ BHg, const d
                 return ue;
             };
 #ifndef SA_SKIP_PSD        // (debug builds time the kernel without the projection)
-            if constexpr (NTH == 256)          // (templates with PSD blocks always run the 256-thread instantiation)
-            for (int c = 0; c < ns; c++)       // PSD blocks: warm-started eigen-refinement on the matrix cores (Jacobi sweeps as the fall-back), eigenvectors stay in LDS
-                psd_project_refine<NT>(zb + n + T.soff[c], T.sord[c], Vst + (size_t)c * PM, Sm, Tm, Dm, Rm, cs, red, (iter > 0 && (F.psd_refine || !check)) ? 1 : 0, F.psd_stats, F.psd_refine);
+            if constexpr (NTH == 256) {        // (templates with PSD blocks always run the 256-thread instantiation)
+                const long long tp0 = (F.psd_stats && ns > 0) ? clock64() : 0;
+                for (int c = 0; c < ns; c++)   // PSD blocks: warm-started eigen-refinement on the matrix cores (Jacobi sweeps as the fall-back), eigenvectors stay in LDS
+                    psd_project_refine<NT>(zb + n + T.soff[c], T.sord[c], Vst + (size_t)c * PM, Sm, Tm, Dm, Rm, cs, red, (iter > 0 && (F.psd_refine || !check)) ? 1 : 0, F.psd_stats, F.psd_refine);
+                if (F.psd_stats && ns > 0 && tid == 0) { const long long t1 = clock64(); atomicAdd(&F.psd_stats[4], (unsigned long long)(t1 - tp0)); atomicAdd(&F.psd_stats[5], (unsigned long long)(t1 - t_iter0)); }
+            }
 #endif
             if (!check && !last) {
                 for (int e = tid; e < l; e += NT) { const double ue = proj_e(e); U[e] = ue; W[e] += alpha * (ue - UT[e]); }

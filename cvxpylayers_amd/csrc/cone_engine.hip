@@ -446,10 +446,13 @@ int ce_destroy(ce_handle h) {
     hipFree(h->d_sp_drow); hipFree(h->d_sp_srow_col); hipFree(h->d_sp_scol_ptr); hipFree(h->d_sp_scol_row); hipFree(h->d_sp_rowslot); hipFree(h->d_sp_AdT); hipFree(h->d_sp_sval);
     for (auto &v : h->ev) for (auto &p : v) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
     if (h->d_psd_stats) {
-        unsigned long long c[4] = {0, 0, 0, 0};
+        unsigned long long c[16] = {0};
         if (hipDeviceSynchronize() == hipSuccess && hipMemcpy(c, h->d_psd_stats, sizeof(c), hipMemcpyDeviceToHost) == hipSuccess)
-            fprintf(stderr, "[cone_engine] PSD projections %llu: refinement steps %llu (%.2f per projection), warm Jacobi fall-backs %llu, cold starts %llu\n",
-                    c[0], c[1], c[0] ? (double)c[1] / (double)c[0] : 0.0, c[2], c[3]);
+            fprintf(stderr, "[cone_engine] PSD projections %llu: refinement steps %llu (%.2f per projection), warm Jacobi fall-backs %llu, cold starts %llu; "
+                            "clock64 ticks per projection %.0f (of which Jacobi sweeps %.0f), per iteration up to the end of the projection %.0f\n",
+                    c[0], c[1], c[0] ? (double)c[1] / (double)c[0] : 0.0, c[2], c[3], c[0] ? (double)c[4] / c[0] : 0.0, c[0] ? (double)c[6] / c[0] : 0.0, c[0] ? (double)c[5] / c[0] : 0.0),
+            fprintf(stderr, "[cone_engine]   ticks per projection by phase: T=SV,R %.0f | D=V'T %.0f | E %.0f | reduce %.0f | V+=VE %.0f | X, store %.0f\n",
+                    (double)c[8] / c[0], (double)c[9] / c[0], (double)c[10] / c[0], (double)c[11] / c[0], (double)c[12] / c[0], (double)c[13] / c[0]);
         hipFree(h->d_psd_stats);
     }
     delete h;
@@ -684,7 +687,7 @@ int ce_solve_shared_a(ce_handle h, int B, int r, int RP, const double *AdT, cons
 #undef SA_ATTR
         h->sa_fwd_attr = true;
     }
-    if (!h->d_psd_stats && T.ns > 0) { const char *e = getenv("CE_PSD_STATS"); if (e && atoi(e) != 0) { HIPCHK(hipMalloc(&h->d_psd_stats, 4 * sizeof(unsigned long long))); HIPCHK(hipMemset(h->d_psd_stats, 0, 4 * sizeof(unsigned long long))); } }
+    if (!h->d_psd_stats && T.ns > 0) { const char *e = getenv("CE_PSD_STATS"); if (e && atoi(e) != 0) { HIPCHK(hipMalloc(&h->d_psd_stats, 16 * sizeof(unsigned long long))); HIPCHK(hipMemset(h->d_psd_stats, 0, 16 * sizeof(unsigned long long))); } }
     int psd_refine = 1; if (const char *e = getenv("CE_PSD_REFINE")) psd_refine = atoi(e) != 0;
     SaFwd F{r, RP, AdT, drow, srow_col, srow_val, scol_ptr, scol_row, gs, Dv, Ev, h->d_psd_stats, psd_refine};
     {
