@@ -27,6 +27,7 @@ struct SaFwd {
     const double *gs;            // [n]      sum over the singleton rows of column j of d0_i a_i^2
     const double *Dv, *Ev;       // [m], [n] equilibration
     unsigned long long *psd_stats;   // debug (CE_PSD_STATS=1): projections / refinement steps / warm Jacobi fall-backs / cold starts, or null
+    double *aa_ws;                   // Anderson acceleration history, [B][5][lp] doubles of global memory (touched on two of every acceleration_interval iterations), or null: plain iteration
     int psd_refine;                  // 1: eigen-refinement on the matrix cores (default); 0 (CE_PSD_REFINE=0): warm-started Jacobi sweeps only, restart at check iterations (round 2)
 };
 
@@ -204,6 +205,16 @@ k_sa_fwd(DevT T, SaFwd F, ce_settings S, const double *__restrict__ BHg, const d
     int status = 0, iter = 0, last_scale_iter = 0, n_log = 0;
     double sum_log = 0;
     bool done = false, resume = false;
+    // Anderson acceleration of the iteration map w -> F(w): type I, one secant pair, residual safeguard, switched off after AA_MAX_REJECT rejections --
+    // the algorithm of k_fwd2 (ce_forward_v2.h) and of the oracle with aa_mem = 1.  Every acceleration_interval iterations, with x = input and
+    // f = output of the last iteration, g = x - f, s = x - x_prev, y = g - g_prev, d = f - f_prev:  w <- f - (s.g / (s.y + 1e-8 |s||y|)) d;  the
+    // next iteration's residual is the safeguard.  The five history vectors live in GLOBAL memory (L2): they are touched on two of every ten
+    // iterations only, and LDS is what limits the residency of this kernel.
+    bool aa_on = S.acceleration_lookback > 0 && F.aa_ws != nullptr, aa_pending = false;
+    const int aa_int = S.acceleration_interval > 0 ? S.acceleration_interval : 10;
+    int aa_iter = 0, aa_rej = 0;
+    double aa_normg = 0;
+    double *const aaWP = F.aa_ws ? F.aa_ws + (size_t)inst * 5 * lp : nullptr, *const aaXP = aaWP + lp, *const aaFP = aaXP + lp, *const aaFS = aaFP + lp, *const aaXS = aaFS + lp;
     double res3[3] = {NAN, NAN, NAN};
     while (!done) {
         refresh();
@@ -216,14 +227,56 @@ k_sa_fwd(DevT T, SaFwd F, ce_settings S, const double *__restrict__ BHg, const d
             if (iter >= S.max_iters) { done = true; break; }
             const bool check = (iter % CONVERGED_INTERVAL) == 0, last = iter + 1 >= S.max_iters;
             const long long t_iter0 = F.psd_stats ? clock64() : 0;
+            if (aa_on) {
+                if (aa_pending) {      // safeguard: residual of the map at the accelerated point against the residual before the step
+                    double rs[1] = {0};
+                    for (int e = tid; e < l; e += NT) { const double dd = aaWP[e] - W[e]; rs[0] = fma(dd, dd, rs[0]); }
+                    block_reduce_n<1, NW>(rs, 0u, red);
+                    if (!(sqrt(rs[0]) <= aa_normg)) {
+                        for (int e = tid; e < l; e += NT) W[e] = aaFS[e];
+                        aa_iter = 0;
+                        if (++aa_rej >= AA_MAX_REJECT) aa_on = false;
+                        __syncthreads();
+                    }
+                    aa_pending = false;
+                }
+                if (aa_on && iter > 0 && iter % aa_int == 0) {
+                    if (aa_iter > 0) {
+                        double rr[5] = {0, 0, 0, 0, 0};
+                        for (int e = tid; e < l; e += NT) {
+                            const double xv = aaWP[e], fv = W[e], gv = xv - fv, xp = aaXP[e], fp = aaFP[e];
+                            const double sv = xv - xp, yv = gv - (xp - fp);
+                            rr[0] = fma(sv, sv, rr[0]); rr[1] = fma(yv, yv, rr[1]); rr[2] = fma(sv, yv, rr[2]); rr[3] = fma(sv, gv, rr[3]); rr[4] = fma(gv, gv, rr[4]);
+                        }
+                        block_reduce_n<5, NW>(rr, 0u, red);
+                        const double mm = rr[2] + 1e-8 * sqrt(rr[0]) * sqrt(rr[1]), gam = rr[3] / mm;
+                        const bool ok = fabs(mm) > 1e-300 && fabs(gam) < 1e10;
+                        for (int e = tid; e < l; e += NT) {
+                            const double xv = aaWP[e], fv = W[e], fp = aaFP[e];
+                            aaXP[e] = xv; aaFP[e] = fv;
+                            if (ok) { aaFS[e] = fv; aaXS[e] = xv; W[e] = fv - gam * (fv - fp); }
+                        }
+                        if (ok) { aa_normg = sqrt(rr[4]); aa_pending = true; } else aa_iter = 0;
+                    } else {
+                        for (int e = tid; e < l; e += NT) { aaXP[e] = aaWP[e]; aaFP[e] = W[e]; }
+                    }
+                    aa_iter++;
+                    __syncthreads();
+                }
+            }
             if (check && iter > 0) {       // keep the homogeneous iterate in range
                 double rn[1] = {0};
                 for (int e = tid; e < l; e += NT) rn[0] = fma(W[e], W[e], rn[0]);
                 block_reduce_n<1, NW>(rn, 0u, red);
                 const double nw = sqrt(rn[0]);
-                if (nw > 0) { const double f = sqrt((double)l) / nw; for (int e = tid; e < l; e += NT) W[e] *= f; }
+                if (nw > 0) {
+                    const double f = sqrt((double)l) / nw;
+                    for (int e = tid; e < l; e += NT) W[e] *= f;
+                    if (aa_on) { for (int e = tid; e < l; e += NT) { aaXP[e] *= f; aaFP[e] *= f; aaFS[e] *= f; aaXS[e] *= f; } aa_normg *= f; }      // the map is positively homogeneous
+                }
                 __syncthreads();
             }
+            if (aa_on && (aa_pending || (iter + 1) % aa_int == 0)) for (int e = tid; e < l; e += NT) aaWP[e] = W[e];      // input of this iteration, where the next one needs it
             // tau-tilde needs phi.w: the partial sums ride on the barriers of the products below
             {
                 double rt = 0;
@@ -372,7 +425,7 @@ k_sa_fwd(DevT T, SaFwd F, ce_settings S, const double *__restrict__ BHg, const d
                             if (ns2 != scale && (factor > sqrt(10.0) || factor < 1.0 / sqrt(10.0))) {
                                 const double dy_ratio = ns2 / scale;       // keep (s, kappa):  w_y+ = rsk_y / r_y+ + 2 ut_y - u_y
                                 for (int e = tid + n; e < l - 1; e += NT) { const double ue = U[e], ute = UT[e]; W[e] = (ue + W[e] - 2 * ute) * dy_ratio + 2 * ute - ue; }
-                                n_log = 0; sum_log = 0; last_scale_iter = iter; scale = ns2; rescale = true;
+                                n_log = 0; sum_log = 0; last_scale_iter = iter; scale = ns2; rescale = true; aa_iter = 0; aa_pending = false;
                                 __syncthreads();
                             }
                         }

@@ -70,6 +70,7 @@ struct ce_engine {
     // split of the A part into singleton rows and sp_r <= 64 dense rows (ce_shared_a_ops.h); sp_RP == 0: more than 64 rows with several entries
     int sp_r = 0, sp_RP = 0;
     bool sa_fwd_attr = false, sa_lsqr_attr = false;
+    double *d_aa_ws = nullptr; size_t aa_ws_bytes = 0;   // Anderson-acceleration history of the shared-A forward kernel ([B][5][lp])
     unsigned long long *d_psd_stats = nullptr;     // CE_PSD_STATS=1: counters of the PSD projection (printed to stderr by ce_destroy)   // MaxDynamicSharedMemorySize is per device: set once per engine (an engine is bound to one device, one caller thread)
     int psd_first = 0;           // first row of the first PSD block (m when the template has none)
     int *d_sp_drow = nullptr, *d_sp_srow_col = nullptr, *d_sp_scol_ptr = nullptr, *d_sp_scol_row = nullptr, *d_sp_rowslot = nullptr;
@@ -443,7 +444,7 @@ int ce_destroy(ce_handle h) {
     hipSetDevice(h->device);
     hipFree(h->d_rowidx); hipFree(h->d_colidx); hipFree(h->d_rowcone); hipFree(h->d_qoff); hipFree(h->d_soff); hipFree(h->d_sord); hipFree(h->d_pw); hipFree(h->d_idx_p); hipFree(h->d_pmap); hipFree(h->d_prow); hipFree(h->d_pcol);
     hipFree(h->wsA); hipFree(h->wsdA); hipFree(h->gws); hipFree(h->d_idx_at); hipFree(h->d_idx_ar); hipFree(h->d_idx_b); hipFree(h->d_row_perm); hipFree(h->d_k_rowcone); hipFree(h->d_k_qoff); hipFree(h->d_csc_ptr); hipFree(h->d_csr_ptr); hipFree(h->d_csr_col); hipFree(h->d_csr_src);
-    hipFree(h->d_sp_drow); hipFree(h->d_sp_srow_col); hipFree(h->d_sp_scol_ptr); hipFree(h->d_sp_scol_row); hipFree(h->d_sp_rowslot); hipFree(h->d_sp_AdT); hipFree(h->d_sp_sval);
+    hipFree(h->d_sp_drow); hipFree(h->d_sp_srow_col); hipFree(h->d_sp_scol_ptr); hipFree(h->d_sp_scol_row); hipFree(h->d_sp_rowslot); hipFree(h->d_sp_AdT); hipFree(h->d_sp_sval); hipFree(h->d_aa_ws);
     for (auto &v : h->ev) for (auto &p : v) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
     if (h->d_psd_stats) {
         unsigned long long c[16] = {0};
@@ -689,7 +690,14 @@ int ce_solve_shared_a(ce_handle h, int B, int r, int RP, const double *AdT, cons
     }
     if (!h->d_psd_stats && T.ns > 0) { const char *e = getenv("CE_PSD_STATS"); if (e && atoi(e) != 0) { HIPCHK(hipMalloc(&h->d_psd_stats, 16 * sizeof(unsigned long long))); HIPCHK(hipMemset(h->d_psd_stats, 0, 16 * sizeof(unsigned long long))); } }
     int psd_refine = 1; if (const char *e = getenv("CE_PSD_REFINE")) psd_refine = atoi(e) != 0;
-    SaFwd F{r, RP, AdT, drow, srow_col, srow_val, scol_ptr, scol_row, gs, Dv, Ev, h->d_psd_stats, psd_refine};
+    double *aa_ws = nullptr;
+    if (settings->acceleration_lookback > 0) {
+        const size_t l = (size_t)T.n + T.m + 1, lp = l + (l & 1);
+        int rc = ensure(&h->d_aa_ws, &h->aa_ws_bytes, sizeof(double) * (size_t)B * 5 * lp);
+        if (rc) return rc;
+        aa_ws = h->d_aa_ws;
+    }
+    SaFwd F{r, RP, AdT, drow, srow_col, srow_val, scol_ptr, scol_row, gs, Dv, Ev, h->d_psd_stats, aa_ws, psd_refine};
     {
         ProfScope ps(h, 0, (hipStream_t)stream);
 #define LAUNCH_SA(NTV, ...) hipLaunchKernelGGL((k_sa_fwd<__VA_ARGS__>), dim3(B), dim3(NTV), lds, (hipStream_t)stream, T, F, *settings, b_hat, c_hat, sigma, nrm_b0, nrm_c0, warm_x, warm_y, warm_s, x, y, s, iters, status, resid)

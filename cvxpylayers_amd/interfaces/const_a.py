@@ -203,12 +203,14 @@ def solve_const_a(eng, A_bm: torch.Tensor, q_eval: torch.Tensor, settings, warm=
                                      nrm_b0.data_ptr(), nrm_c0.data_ptr(), C.byref(settings), ptr(wx), ptr(wy), ptr(ws), xo.data_ptr(), yo.data_ptr(),
                                      so.data_ptr(), it_o.data_ptr(), st_o.data_ptr(), rs_o.data_ptr(), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
             if rc == 0:
+                eng._note_acceleration(settings, honoured=True, path="shared-A forward kernel")     # k_sa_fwd implements it (one-pair history, like k_fwd2)
                 eng.last_const_a_kernel = "k_sa_fwd"
                 _tick("k_sa_fwd (enqueued)")
                 return xo, yo, so, it_o, st_o, rs_o
             if rc not in (-2, -3):
                 _lib.check(rc, "ce_solve_shared_a")
     eng.last_const_a_kernel = "batch GEMM"
+    eng._note_acceleration(settings, honoured=False, path="constant-A batch-GEMM path")
     # ---- one eigendecomposition serves every instance and every rescale:  A^T D0 A = Q Lam Q^T
     d0 = torch.ones(m, **f64); d0[:z] = ZERO_CONE_FACTOR
     lam, Q = torch.linalg.eigh(At @ (d0[:, None] * A))

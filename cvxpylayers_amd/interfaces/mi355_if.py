@@ -160,8 +160,7 @@ class ConeEngine:
         if P_bm is None and self._use_const_a(A_bm):
             from cvxpylayers_amd.interfaces.const_a import solve_const_a
             self.last_path = "const_a"
-            self._note_acceleration(settings, honoured=False, path="constant-A (batch GEMM) path")
-            return solve_const_a(self, A_bm, q_eval, settings, warm=warm)
+            return solve_const_a(self, A_bm, q_eval, settings, warm=warm)      # (notes itself whether its kernel honours the acceleration)
         self.last_path = "per_instance"
         self._note_acceleration(settings, honoured=bool(_lib.lib().ce_acceleration_available(self._h)), path="size-generic forward kernels")
         if warm is not None:       # the engine reads the initial point from the output buffers (ce_settings.warm_start)
