@@ -185,6 +185,18 @@ class ConeEngine:
         _lib.check(rc, "ce_solve")
         return x, y, s, iters, status, resid
 
+    def status_summary(self, status: torch.Tensor) -> tuple[int, int]:
+        """(min status, number of Solved/Inaccurate) of a status vector on this engine's device: one launch + an 8-byte pinned copy + one stream sync."""
+        if status.numel() == 0:
+            return 1, 0
+        if getattr(self, "_summary_host", None) is None:
+            self._summary_host = torch.empty(2, dtype=torch.int32, pin_memory=True)
+        with torch.cuda.device(self.device):
+            stream = torch.cuda.current_stream(self.device)
+            _lib.check(_lib.lib().ce_status_summary(self._h, int(status.numel()), status.data_ptr(), self._summary_host.data_ptr(), C.c_void_p(stream.cuda_stream)), "ce_status_summary")
+            stream.synchronize()
+        return int(self._summary_host[0]), int(self._summary_host[1])
+
     def _note_acceleration(self, settings, honoured: bool, path: str):
         """Records whether this solve ran with Anderson acceleration (`last_acceleration`, surfaced as info["acceleration"]) and warns
         ONCE per engine when a positive acceleration_lookback -- explicit or the SCS default -- is not honoured by the selected path."""
@@ -467,15 +479,20 @@ class _ConeLayer(torch.autograd.Function):
             x, y, s, iters, status, resid = eng.solve(A_bm, q_dev, settings, warm=warm, P_bm=P_bm)
             path = eng.last_path          # recorded per call: the backward of THIS node must not follow a later solve's path
             eng._last_solution = (x.detach(), y.detach(), s)
+            # The reference raises from forward() when an instance fails (diffcp_if.py:365-372), so the host has to learn the outcome here: one tiny
+            # reduction kernel + 8 bytes into pinned memory behind the solve (ce_status_summary) and ONE stream synchronisation -- not the status
+            # vector through a pageable copy plus host-side reductions.  Per-instance inspection happens only on the failure path.
+            min_status, n_inaccurate = eng.status_summary(status)
+        any_failed = min_status < 0
+        if any_failed and merged_args.get("raise_on_error", True):
             st = status.cpu()
-        if bool((st < 0).any()) and merged_args.get("raise_on_error", True):
             bad = int((st < 0).nonzero()[0])
             raise SolverError(f"Solver mi355 returned status {STATUS_NAMES.get(int(st[bad]), int(st[bad]))} "
                               f"for instance {bad} ({int((st < 0).sum())} of {batch_size} instances failed)")
-        if bool((st == 2).any()):
+        if n_inaccurate:
             warnings.warn("Solved/Inaccurate.")
         failed = None
-        if bool((st < 0).any()):
+        if any_failed:
             # raise_on_error=False: per-instance failure masking.  Rows of failed instances (infeasible / unbounded /
             # failed) come back as NaN -- never a half-converged iterate -- and their parameter gradients as zero (backward), so that one
             # bad instance of a training batch neither poisons nor silently steers the others.  info["status"] says which.

@@ -91,8 +91,8 @@ void ce_default_settings(ce_settings *s);
  * library short structs.  Bindings must check  ce_abi_version() == CE_ABI_VERSION  and  ce_struct_size(which) == sizeof(their
  * struct)  (which: 0 ce_template, 1 ce_settings) once at load time and refuse to continue otherwise (cvxpylayers_amd/_lib.py
  * does; tests/test_cabi.py checks the stub printed in INTEGRATION.md the same way).  CE_ABI_VERSION is bumped whenever a struct
- * layout, an entry point's signature or the meaning of an argument changes (6: ce_default_settings = SCS defaults incl. acceleration_lookback 10; ce_acceleration_available added). */
-#define CE_ABI_VERSION 6
+ * layout, an entry point's signature or the meaning of an argument changes (7: ce_status_summary added; 6: ce_default_settings = SCS defaults incl. acceleration_lookback 10, ce_acceleration_available). */
+#define CE_ABI_VERSION 7
 int ce_abi_version(void);
 int ce_struct_size(int which);
 /* 1 when ce_solve / ce_solve_qp on this engine honour ce_settings.acceleration_lookback > 0 (second-generation forward kernel with
@@ -140,6 +140,12 @@ int ce_vjp(ce_handle h, int B,
  * device buffers.  Used by the plugin to turn the reference's batch-minor A_eval (nnz_aug x B) into the
  * engine-native batch-major (B x nnz_aug) once, into a tensor it keeps for backward. */
 int ce_transpose(ce_handle h, int rows, int cols, const double *in, double *out, void *stream);
+
+/* Enqueues, behind whatever produced status[] (B int32 on the device), the reduction summary_host[0] = min_i status[i], summary_host[1] = #{i: status[i]
+ * == 2} and its copy to summary_host (2 ints of PINNED host memory).  The caller synchronises the stream (or an event) before reading it.  This is the
+ * only host <- device traffic a forward call of the Python plugin needs in order to honour the reference's contract that a failed instance raises
+ * SolverError from forward() (diffcp_if.py:365-372 raises inside the call): 8 bytes instead of the status vector. */
+int ce_status_summary(ce_handle h, int B, const int *status, int *summary_host, void *stream);
 
 /*
  * Quadratic objective (templates created with nnz_p > 0): ce_solve / ce_vjp with the values of P  <- P_eval of the QP-capable

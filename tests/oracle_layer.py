@@ -62,3 +62,28 @@ class OracleLayer:
 
     def __call__(self, *params):
         return _Fn.apply(self, *params)
+
+
+class OraclePlugin(torch.autograd.Function):
+    """The plugin calling convention of the reference (`apply(P_eval, q_eval, A_eval, cl_ctx, solver_args, needs_grad, warm_start) -> (primal, dual,
+    aux, data)`, 7-tuple backward; diffcp_if.py:327-403) served by the CPU oracle: what the multi-rank CPU tests shard instead of a stand-in.
+    cl_ctx: a CanonTemplate (its A_structure / cone_dims are what a solver ctx carries).  Inputs batch-minor (n+1, B) / (nnz_aug, B)."""
+
+    @staticmethod
+    def forward(ctx, P_eval, q_eval, A_eval, cl_ctx, solver_args, needs_grad=True, warm_start=None):
+        tpl = cl_ctx
+        idx, ptr, (m, n1) = tpl.A_structure
+        cone = P.ConeTemplate(n=n1 - 1, m=m, indices=np.asarray(idx), indptr=np.asarray(ptr), cones=dict(tpl.cone_dims))
+        A, b, c = cone.dense_from_values(A_eval.detach().numpy(), q_eval.detach().numpy())
+        args = {"eps": 1e-10, "max_iters": 200000, **(solver_args or {})}
+        args.pop("mode", None)
+        r = oracle.solve_batch(A, b, c, tpl.cone_dims, **args)
+        ctx.cone, ctx.saved, ctx.cones = cone, (A, b, c, r), tpl.cone_dims
+        return torch.from_numpy(r["x"].copy()), torch.from_numpy(r["y"].copy()), {"iters": torch.from_numpy(r["iters"].copy()), "status": torch.from_numpy(r["status"].copy())}, None
+
+    @staticmethod
+    def backward(ctx, dprimal, ddual, _i, _d):
+        A, b, c, r = ctx.saved
+        g = oracle.adjoint_batch(A, b, c, ctx.cones, r["x"], r["y"], r["s"], dprimal.contiguous().numpy(), ddual.contiguous().numpy(), mode="dense")
+        dA_eval, dq_eval = ctx.cone.values_from_dense(g["dA"], g["db"], g["dc"])
+        return None, torch.from_numpy(dq_eval), torch.from_numpy(dA_eval), None, None, None, None

@@ -359,3 +359,27 @@ def test_affine_probing_with_a_quadratic_objective_builds_the_P_map():
     vals = tpl.P_map @ pvec
     want = (0.5 * (Pp + Pp.T) + np.eye(n))[idx, np.repeat(np.arange(n), np.diff(ptr))]
     np.testing.assert_allclose(vals, want, atol=1e-14)
+
+
+@pytest.mark.gpu
+def test_failure_masking_keeps_the_good_instances_and_zeroes_the_bad_gradients():
+    """solver_args={"raise_on_error": False} (per-instance failure masking): an infeasible instance inside a batch comes back as NaN
+    with zero parameter gradient, the other instances and their gradients are untouched, info["status"] says which; the default still raises."""
+    from cvxpylayers_amd.interfaces.mi355_if import SolverError
+
+    def builder(p):          # min x  s.t.  x >= p0,  x <= p1   (infeasible when p0 > p1);  x* = p0, dx/dp0 = 1
+        return np.array([[-1.0], [1.0]]), np.array([-float(p[0]), float(p[1])]), np.array([1.0])
+    tpl = template_from_affine_builder(builder, [(2,)], {"z": 0, "l": 2, "q": []}, [VariableRecovery(slice(0, 1), None, (1,))])
+    layer = CvxpyLayer(template=tpl, solver_args={"eps": 1e-9})
+    p = torch.tensor([[0.5, 2.0], [1.0, -1.0], [-0.3, 0.7]], device="cuda", requires_grad=True)       # instance 1 is infeasible
+    with pytest.raises(SolverError):
+        layer(p)
+    x, = layer(p, solver_args={"raise_on_error": False})
+    st = layer.info["status"].cpu().numpy()
+    assert st[0] == 1 and st[2] == 1 and st[1] < 0
+    xv = x.detach().cpu().numpy()[:, 0]
+    assert np.isnan(xv[1]) and abs(xv[0] - 0.5) < 1e-6 and abs(xv[2] + 0.3) < 1e-6
+    torch.nan_to_num(x, nan=0.0).sum().backward()             # (a NaN-aware loss, as a training loop that masks failed samples would write it)
+    g = p.grad.cpu().numpy()
+    assert np.isfinite(g).all() and np.abs(g[1]).max() == 0.0
+    np.testing.assert_allclose(g[0], [1.0, 0.0], atol=1e-5); np.testing.assert_allclose(g[2], [1.0, 0.0], atol=1e-5)

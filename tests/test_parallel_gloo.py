@@ -1,6 +1,10 @@
-"""N>1 path on CPU: world_size-2 gloo processes exercise the batch sharding helpers of cvxpylayers_amd/parallel.py
-(shard bounds, differentiable all-gather of primal/dual rows with its reduce-scatter backward, all-reduce of
-broadcast-parameter gradients, sharded_apply plumbing with a stand-in layer function)."""
+"""N>1 path on CPU: world_size-2 gloo processes exercise the batch sharding of cvxpylayers_amd/parallel.py --
+  * shard bounds, the differentiable all-gather of primal/dual rows with both gradient contracts, ragged shards (stand-in layer function);
+  * the REAL plugin calling convention (tests/oracle_layer.OraclePlugin: same 7-argument apply / 7-tuple backward as MI355's and DIFFCP's plugin,
+    solved by the CPU oracle) sharded over two ranks and checked against the fixtures recorded from the reference's own glue
+    (tests/golden/refglue_*.npz): gathered primal / dual, this rank's columns of dA_eval / dq_eval, and -- through the frontend's flattening
+    of an UNBATCHED parameter (torch/cvxpylayer.py:111-117: expand -> its gradient is a sum over the batch) -- allreduce_broadcast_grad;
+  * bench.py --dry-run-ranks 2: the script's own self-spawn / rendezvous / max-over-ranks timing / JSON plumbing on CPU."""
 import os
 import sys
 
@@ -85,3 +89,70 @@ def _worker(rank, world, port, ragged):
 def test_world_size_2_gloo(ragged):
     port = 29500 + (os.getpid() % 2000) + (1 if ragged else 0)
     mp.spawn(_worker, args=(2, port, ragged), nprocs=2, join=True)
+
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _real_plugin_worker(rank, world, port):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import numpy as np
+    import ref_cases
+    from oracle_layer import OraclePlugin
+    from cvxpylayers_amd.parallel import allreduce_broadcast_grad, shard_bounds, sharded_apply
+    # ---- (1) plugin boundary, all parameters batched: the metric shape, B = 6 -> 3 instances per rank
+    f = np.load(os.path.join(GOLD, "refglue_metric_shape.npz"))
+    tpl = ref_cases.CASES["metric_shape"]()["template"]
+    B = f["A_eval"].shape[1]
+    A = torch.tensor(f["A_eval"], requires_grad=True); q = torch.tensor(f["q_eval"], requires_grad=True)
+    primal, dual, info = sharded_apply(OraclePlugin, q, A, tpl, dict(ref_cases.SOLVER_ARGS), True, total=B)
+    assert tuple(primal.shape) == f["primal"].shape and tuple(dual.shape) == f["dual"].shape
+    assert np.abs(primal.detach().numpy() - f["primal"]).max() < 1e-8 and np.abs(dual.detach().numpy() - f["dual"]).max() < 1e-8
+    ((primal * torch.tensor(f["dprimal"])).sum() + (dual * torch.tensor(f["ddual"])).sum()).backward()      # the same loss on every rank ("replicated")
+    lo, hi = shard_bounds(B, rank, world)
+    want_A = np.zeros_like(f["dA_eval"]); want_A[:, lo:hi] = f["dA_eval"][:, lo:hi]
+    want_q = np.zeros_like(f["dq_eval"]); want_q[:, lo:hi] = f["dq_eval"][:, lo:hi]
+    sc = 1.0 + np.abs(f["dA_eval"]).max()
+    assert np.abs(A.grad.numpy() - want_A).max() < 1e-5 * sc and np.abs(q.grad.numpy() - want_q).max() < 1e-5 * sc
+    # ---- (2) a broadcast (unbatched) parameter through the frontend's flattening: ridge LS, F unbatched, g batched, B = 5 (ragged 3 + 2)
+    f = np.load(os.path.join(GOLD, "refglue_ridge_mixed.npz"))
+    tpl = ref_cases.CASES["ridge_mixed"]()["template"]
+    F = torch.tensor(f["param0"], requires_grad=True); g = torch.tensor(f["param1"], requires_grad=True)
+    B = g.shape[0]
+    flat = [F.t().reshape(-1)[None, :].expand(B, -1), g]                 # Fortran flattening; expand = the broadcast whose backward sums over the batch
+    p = torch.zeros(B, tpl.n_params_total + 1, dtype=torch.float64); p[:, -1] = 1.0
+    cols = []
+    for v, off in zip(flat, tpl.col_offsets):
+        cols.append((off, v))
+    p = torch.cat([v for _, v in sorted(cols, key=lambda t: t[0])] + [torch.ones(B, 1, dtype=torch.float64)], dim=1)
+    A_eval = torch.tensor(tpl.A_map.toarray()) @ p.t(); q_eval = torch.tensor(tpl.q_map.toarray()) @ p.t()
+    np.testing.assert_allclose(A_eval.detach().numpy(), f["A_eval"], atol=1e-12)
+    primal, dual, info = sharded_apply(OraclePlugin, q_eval, A_eval, tpl, dict(ref_cases.SOLVER_ARGS), True, total=B)
+    x = primal[:, tpl.var_recover[0].primal]
+    assert np.abs(x.detach().numpy() - f["out0"]).max() < 1e-8
+    (x * torch.tensor(f["weight0"])).sum().backward()
+    lo, hi = shard_bounds(B, rank, world)
+    want_g = np.zeros_like(f["grad1"]); want_g[lo:hi] = f["grad1"][lo:hi]
+    assert np.abs(g.grad.numpy() - want_g).max() < 1e-6                  # batched parameter: this rank's rows only
+    assert np.abs(F.grad.numpy() - f["grad0"]).max() > 1e-3              # broadcast parameter: a PARTIAL sum before the all-reduce ...
+    Fg = allreduce_broadcast_grad(F.grad.clone())
+    assert np.abs(Fg.numpy() - f["grad0"]).max() < 1e-6                  # ... and the reference's gradient (sum over the whole batch) after it
+    dist.destroy_process_group()
+
+
+def test_world_size_2_gloo_with_the_real_plugin_convention_against_reference_fixtures():
+    port = 29500 + (os.getpid() % 2000) + 7
+    mp.spawn(_real_plugin_worker, args=(2, port), nprocs=2, join=True)
+
+
+def test_bench_dry_run_ranks_exercises_the_self_spawn_plumbing():
+    import json
+    import subprocess
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run-ranks", "2", "--steps", "2"], capture_output=True, text=True, timeout=300,
+                         env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")})
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, (out.stdout[-400:], out.stderr[-800:])
+    rec = json.loads(lines[0])
+    assert rec["dry_run"] and rec["ranks"] == 2 and rec["gather_ok"] and rec["backend"] == "gloo" and rec["master_addr"] == "127.0.0.1"
