@@ -438,7 +438,8 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
             const int prow = __builtin_amdgcn_readfirstlane(misc[4 + buf]);
             const int ipv = prow / BGR;
             const double piv = pinfo[buf];
-            if (fabs(piv) < ptol) continue;                    // uniform: free variable (see above); no row is consumed
+            if (__builtin_amdgcn_readfirstlane(fabs(piv) < ptol ? 1 : 0)) continue;      // free variable (see above), no row is consumed.  readfirstlane: the value is the same in
+                                                                                          // every lane, but only a scalar condition lets the compiler keep the loop body free of exec masking
             double pinv = __builtin_amdgcn_rcp(piv);           // hardware seed + two Newton steps (the IEEE divide expansion is
             pinv = fma(fma(-piv, pinv, 1.0), pinv, pinv);      // three times as long and sits on the critical path of every pivot)
             pinv = fma(fma(-piv, pinv, 1.0), pinv, pinv);

@@ -70,7 +70,7 @@ struct ce_engine {
     // split of the A part into singleton rows and sp_r <= 64 dense rows (ce_shared_a_ops.h); sp_RP == 0: more than 64 rows with several entries
     int sp_r = 0, sp_RP = 0;
     bool sa_fwd_attr = false, sa_lsqr_attr = false;
-    int *d_summary = nullptr;                              // ce_status_summary staging (2 ints)
+    int *d_summary = nullptr; unsigned summary_next = 0;   // ce_status_summary staging (8 slots of 3 ints)
     double *d_aa_ws = nullptr; size_t aa_ws_bytes = 0;   // Anderson-acceleration history of the shared-A forward kernel ([B][5][lp])
     unsigned long long *d_psd_stats = nullptr;     // CE_PSD_STATS=1: counters of the PSD projection (printed to stderr by ce_destroy)   // MaxDynamicSharedMemorySize is per device: set once per engine (an engine is bound to one device, one caller thread)
     int psd_first = 0;           // first row of the first PSD block (m when the template has none)
@@ -603,24 +603,26 @@ int ce_vjp_qp(ce_handle h, int B, const double *A_vals, long sA_k, long sA_b, co
     return CE_OK;
 }
 
-// min over the batch of status[] and the number of "solved, inaccurate" (2) entries: what a caller needs to decide whether the slow path
-// (per-instance inspection, error message) is necessary at all
+// summary of an int32 vector v[B] (status of a forward call, or adj_status of a backward call): out[0] = min v, out[1] = #{v == 2} ("solved,
+// inaccurate"), out[2] = #{(v & 3) != 0} (adjoint flags: bits 0-1 = failed / too many active rows): what a caller needs to decide whether
+// the slow path (per-instance inspection, messages) is necessary at all
 __global__ void __launch_bounds__(256) k_status_summary(int B, const int *__restrict__ status, int *__restrict__ out) {
-    int mn = 0x7fffffff, n2 = 0;
-    for (int i = threadIdx.x; i < B; i += 256) { const int s = status[i]; mn = min(mn, s); n2 += (s == 2); }
-    for (int o = 32; o > 0; o >>= 1) { mn = min(mn, __shfl_xor(mn, o)); n2 += __shfl_xor(n2, o); }
-    __shared__ int sm[8];
-    if ((threadIdx.x & 63) == 0) { sm[threadIdx.x >> 6] = mn; sm[4 + (threadIdx.x >> 6)] = n2; }
+    int mn = 0x7fffffff, n2 = 0, nf = 0;
+    for (int i = threadIdx.x; i < B; i += 256) { const int s = status[i]; mn = min(mn, s); n2 += (s == 2); nf += ((s & 3) != 0); }
+    for (int o = 32; o > 0; o >>= 1) { mn = min(mn, __shfl_xor(mn, o)); n2 += __shfl_xor(n2, o); nf += __shfl_xor(nf, o); }
+    __shared__ int sm[12];
+    if ((threadIdx.x & 63) == 0) { sm[threadIdx.x >> 6] = mn; sm[4 + (threadIdx.x >> 6)] = n2; sm[8 + (threadIdx.x >> 6)] = nf; }
     __syncthreads();
-    if (threadIdx.x == 0) { out[0] = min(min(sm[0], sm[1]), min(sm[2], sm[3])); out[1] = sm[4] + sm[5] + sm[6] + sm[7]; }
+    if (threadIdx.x == 0) { out[0] = min(min(sm[0], sm[1]), min(sm[2], sm[3])); out[1] = sm[4] + sm[5] + sm[6] + sm[7]; out[2] = sm[8] + sm[9] + sm[10] + sm[11]; }
 }
 int ce_status_summary(ce_handle h, int B, const int *status, int *summary_host, void *stream) {
     if (!h || B <= 0 || !status || !summary_host) { g_err = "null argument"; return CE_E_BADARG; }
     HIPCHK(hipSetDevice(h->device));
-    if (!h->d_summary) HIPCHK(hipMalloc(&h->d_summary, 2 * sizeof(int)));
-    hipLaunchKernelGGL(k_status_summary, dim3(1), dim3(256), 0, (hipStream_t)stream, B, status, h->d_summary);
+    if (!h->d_summary) HIPCHK(hipMalloc(&h->d_summary, 8 * 4 * sizeof(int)));
+    int *slot = h->d_summary + 4 * (h->summary_next++ & 7);      // a few calls may be in flight on the stream before the caller synchronises
+    hipLaunchKernelGGL(k_status_summary, dim3(1), dim3(256), 0, (hipStream_t)stream, B, status, slot);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(summary_host, h->d_summary, 2 * sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIPCHK(hipMemcpyAsync(summary_host, slot, 3 * sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
     return CE_OK;
 }
 

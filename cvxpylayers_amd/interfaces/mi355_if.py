@@ -185,17 +185,26 @@ class ConeEngine:
         _lib.check(rc, "ce_solve")
         return x, y, s, iters, status, resid
 
+    def enqueue_summary(self, vec: torch.Tensor, slot: int):
+        """ce_status_summary of an int32 device vector into pinned slot `slot` (0: status of this forward, 1: adjoint flags of the previous backward);
+        read with read_summaries() after ONE stream synchronisation."""
+        if getattr(self, "_summary_host", None) is None:
+            self._summary_host = torch.zeros((2, 4), dtype=torch.int32).pin_memory()
+        stream = torch.cuda.current_stream(self.device)
+        _lib.check(_lib.lib().ce_status_summary(self._h, int(vec.numel()), vec.data_ptr(), self._summary_host[slot].data_ptr(), C.c_void_p(stream.cuda_stream)), "ce_status_summary")
+
+    def read_summaries(self):
+        torch.cuda.current_stream(self.device).synchronize()
+        return self._summary_host.tolist()
+
     def status_summary(self, status: torch.Tensor) -> tuple[int, int]:
-        """(min status, number of Solved/Inaccurate) of a status vector on this engine's device: one launch + an 8-byte pinned copy + one stream sync."""
+        """(min status, number of Solved/Inaccurate) of a status vector on this engine's device: one launch + a 12-byte pinned copy + one stream sync."""
         if status.numel() == 0:
             return 1, 0
-        if getattr(self, "_summary_host", None) is None:
-            self._summary_host = torch.empty(2, dtype=torch.int32, pin_memory=True)
         with torch.cuda.device(self.device):
-            stream = torch.cuda.current_stream(self.device)
-            _lib.check(_lib.lib().ce_status_summary(self._h, int(status.numel()), status.data_ptr(), self._summary_host.data_ptr(), C.c_void_p(stream.cuda_stream)), "ce_status_summary")
-            stream.synchronize()
-        return int(self._summary_host[0]), int(self._summary_host[1])
+            self.enqueue_summary(status, 0)
+            r = self.read_summaries()
+        return int(r[0][0]), int(r[0][1])
 
     def _note_acceleration(self, settings, honoured: bool, path: str):
         """Records whether this solve ran with Anderson acceleration (`last_acceleration`, surfaced as info["acceleration"]) and warns
@@ -409,16 +418,25 @@ class MI355_ctx:
         return self._engines[idx]
 
 
-def _warn_flagged_adjoint(eng):
-    """Deferred check of the previous backward's per-instance flags (degenerate active set: more active rows than the direct
-    solve holds / singular pivot, or LSQR iteration limit): their gradients are zero or inexact.  Done at the next call so that
-    the backward path itself never synchronises the host."""
+def _enqueue_flagged_adjoint(eng):
+    """Deferred check of the previous backward's per-instance flags (more active rows than the direct solve holds, LSQR iteration limit: their
+    gradients are zero or inexact).  Done at the NEXT forward call so that the backward path itself never synchronises the host: the flags are
+    summarised on the device (ce_status_summary) and read together with this forward's status, behind one stream synchronisation."""
     pend, eng._pending_adj = getattr(eng, "_pending_adj", None) or [], []
-    for adj, bs in pend:
-        nbad = int(((adj & 3) != 0).sum())       # bit 2 (4): rank-deficient system, basic solution returned like the reference's LSQR does -- not a failure
-        if nbad:
-            warnings.warn(f"MI355 adjoint: {nbad} of {bs} instances of the previous backward pass were flagged (degenerate active "
-                          "set or iteration limit); their gradients are unreliable")
+    if not pend:
+        return None
+    adj, bs = pend[-1]                       # (older entries belong to backward calls whose forward was followed by another forward: already reported or superseded)
+    if adj.numel() == 0:
+        return None
+    eng.enqueue_summary(adj, 1)
+    return bs
+
+
+def _report_flagged_adjoint(summary_row, bs):
+    nbad = int(summary_row[2])               # bits 0-1; bit 2 (4) = rank-deficient system, basic solution returned like the reference's LSQR does -- not a failure
+    if nbad:
+        warnings.warn(f"MI355 adjoint: {nbad} of {bs} instances of the previous backward pass were flagged (degenerate active "
+                      "set or iteration limit); their gradients are unreliable")
 
 
 def _detect_batch_size(con_values) -> tuple[int, bool]:
@@ -444,7 +462,6 @@ class _ConeLayer(torch.autograd.Function):
         if not torch.cuda.is_available():
             raise RuntimeError("MI355 solver needs a ROCm GPU; there is no CPU fallback (use solver='DIFFCP' on CPU)")
         eng = ctx.engine(dev)
-        _warn_flagged_adjoint(eng)
         merged_args = {**ctx.options}
         if solver_args:
             merged_args.update(solver_args)
@@ -482,7 +499,16 @@ class _ConeLayer(torch.autograd.Function):
             # The reference raises from forward() when an instance fails (diffcp_if.py:365-372), so the host has to learn the outcome here: one tiny
             # reduction kernel + 8 bytes into pinned memory behind the solve (ce_status_summary) and ONE stream synchronisation -- not the status
             # vector through a pageable copy plus host-side reductions.  Per-instance inspection happens only on the failure path.
-            min_status, n_inaccurate = eng.status_summary(status)
+            adj_bs = _enqueue_flagged_adjoint(eng)
+            if status.numel():
+                eng.enqueue_summary(status, 0)
+                summ = eng.read_summaries()
+                min_status, n_inaccurate = int(summ[0][0]), int(summ[0][1])
+            else:
+                summ = eng.read_summaries() if adj_bs is not None else None
+                min_status, n_inaccurate = 1, 0
+            if adj_bs is not None:
+                _report_flagged_adjoint(summ[1], adj_bs)
         any_failed = min_status < 0
         if any_failed and merged_args.get("raise_on_error", True):
             st = status.cpu()

@@ -141,10 +141,11 @@ int ce_vjp(ce_handle h, int B,
  * engine-native batch-major (B x nnz_aug) once, into a tensor it keeps for backward. */
 int ce_transpose(ce_handle h, int rows, int cols, const double *in, double *out, void *stream);
 
-/* Enqueues, behind whatever produced status[] (B int32 on the device), the reduction summary_host[0] = min_i status[i], summary_host[1] = #{i: status[i]
- * == 2} and its copy to summary_host (2 ints of PINNED host memory).  The caller synchronises the stream (or an event) before reading it.  This is the
- * only host <- device traffic a forward call of the Python plugin needs in order to honour the reference's contract that a failed instance raises
- * SolverError from forward() (diffcp_if.py:365-372 raises inside the call): 8 bytes instead of the status vector. */
+/* Enqueues, behind whatever produced v[] (B int32 on the device: the status of a forward call or the adj_status of a backward call), the reduction
+ * summary_host[0] = min_i v[i], [1] = #{i: v[i] == 2}, [2] = #{i: (v[i] & 3) != 0} and its copy to summary_host (3 ints of PINNED host memory).  The caller
+ * synchronises the stream (or an event) before reading it.  This is the only host <- device traffic a forward call of the Python plugin needs in order to
+ * honour the reference's contract that a failed instance raises SolverError from forward() (diffcp_if.py:365-372 raises inside the call): 12 bytes instead
+ * of the status vector. */
 int ce_status_summary(ce_handle h, int B, const int *status, int *summary_host, void *stream);
 
 /*
