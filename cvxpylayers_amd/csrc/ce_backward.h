@@ -41,7 +41,8 @@ k_backward(DevT T, int nkcap, int ldk, const double *__restrict__ Avals, const d
     int *ckind = ip; ip += nqs;      // cone kind: 0 = interior of K* (all EQ), 1 = in -K (all FREE), 2 = boundary
     int *ceq = ip; ip += nqs;        // equality index of the e_y row of a boundary cone
     int *perm = ip; ip += nkcap;
-    int *misc = ip; ip += 4;         // [0] n_eq, [1] pivot row, [2] flags
+    int *misc = ip; ip += 4;         // [0] n_eq, [1] pivot row / pivot found, [2] flags
+    int *colrow = ip; ip += nkcap;   // unblocked elimination: position (in perm) of the pivot row of column k, -1: free variable
 
     load_instance(T, Avals + (size_t)inst * T.nnz_aug, A, bv);
     for (int j = tid; j < n; j += NT) xv[j] = xg[(size_t)inst * n + j];
@@ -326,24 +327,30 @@ k_backward(DevT T, int nkcap, int ldk, const double *__restrict__ Avals, const d
         }
         __syncthreads();
     } else {
+    // Rank-revealing like k_backward_rt (and the oracle's dense elimination): a column without an acceptable pivot among the unused rows is a FREE
+    // variable (set to zero, skipped, no row consumed) -- redundant equality rows / degenerate active sets, where the reference's LSQR returns a
+    // solution of the consistent system.  `rcur` = number of rows used so far (the pivot row of column k sits at position colrow[k] of perm).
+    int rcur = 0;
     for (int k = 0; k < NK; k++) {
-        if (tid < 64) {   // pivot search by wave 0 over logical rows k..NK-1
-            double best = -1; int bi = k;
-            for (int i = k + tid; i < NK; i += 64) { const double v = fabs(K[perm[i] * ldk + k]); if (v > best) { best = v; bi = i; } }
+        if (tid < 64) {   // pivot search by wave 0 over the unused rows rcur..NK-1
+            double best = -1; int bi = rcur;
+            for (int i = rcur + tid; i < NK; i += 64) { const double v = fabs(K[perm[i] * ldk + k]); if (v > best) { best = v; bi = i; } }
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) {
                 const double ob = __shfl_xor(best, o); const int oi = __shfl_xor(bi, o);
                 if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
             }
             if (tid == 0) {
-                const int t = perm[k]; perm[k] = perm[bi]; perm[bi] = t;
-                if (best < ptol) { misc[2] = 1; }
+                if (best >= ptol && rcur < NK) { const int t = perm[rcur]; perm[rcur] = perm[bi]; perm[bi] = t; misc[1] = 1; }
+                else { misc[1] = 0; misc[2] |= 4; }
             }
         }
         __syncthreads();
-        const int pk = perm[k];
-        double piv = K[pk * ldk + k];
-        if (fabs(piv) < ptol) piv = (piv < 0 ? -ptol : ptol);
+        const bool have = misc[1] != 0;                        // uniform
+        if (tid == 0) colrow[k] = have ? rcur : -1;
+        if (!have) { __syncthreads(); continue; }              // (misc[1] is rewritten by the next search)
+        const int pk = perm[rcur];
+        const double piv = K[pk * ldk + k];
         const double pinv = 1.0 / piv;
         // rank-1 update of columns k+1 .. NK: a 16 x 16 thread grid walks rows / columns (no integer division in the loop)
         {
@@ -356,7 +363,7 @@ k_backward(DevT T, int nkcap, int ldk, const double *__restrict__ Avals, const d
 #pragma unroll
                 for (int u = 0; u < 8; u++) { const int jj = j0 + 16 * u; pr[u] = jj <= NK ? prow[jj] : 0.0; }
                 for (int i = ty; i < NK; i += 16) {
-                    if (i == k) continue;
+                    if (i == rcur) continue;
                     double *row = K + perm[i] * ldk;
                     const double f = row[k] * pinv;          // (column k itself is not touched by this step)
                     if (f != 0.0) {
@@ -369,14 +376,14 @@ k_backward(DevT T, int nkcap, int ldk, const double *__restrict__ Avals, const d
                 }
             }
         }
+        rcur++;
         __syncthreads();
     }
-    // solution: sol_k = rhs[perm[k]] / K[perm[k]][k];  r_x -> rx, multipliers rho -> bv (b is not needed by the adjoint)
+    // solution: sol_k = rhs[pivot row of k] / K[that row][k] (0 for a free variable);  r_x -> rx, multipliers rho -> bv (b is not needed by the adjoint)
     for (int k = tid; k < NK; k += NT) {
-        const int pk = perm[k];
-        double piv = K[pk * ldk + k];
-        if (fabs(piv) < ptol) piv = (piv < 0 ? -ptol : ptol);
-        const double sol = K[pk * ldk + NK] / piv;
+        const int rk_ = colrow[k];
+        double sol = 0.0;
+        if (rk_ >= 0) { const int pk = perm[rk_]; sol = K[pk * ldk + NK] / K[pk * ldk + k]; }
         if (k < n) rx[k] = sol; else bv[k - n] = sol;
     }
     __syncthreads();

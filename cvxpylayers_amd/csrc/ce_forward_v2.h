@@ -472,14 +472,75 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
     };
 
     // ---- (re)factor:  G <- (rho_x I + A^T Dy A)^{-1} (LDS);  g, h.g, phi.   Clobbers ZB, TV, PX, S1..S4.
+    double g_scale = 0.0;          // the scale G (in LDS) was computed for; 0: none yet
     auto refactor = [&]() {
         F2_STAMP(7);
         const Co co(wave);
         const int tid = co.t;
         const int j1 = co.j1, c1 = co.c1, i2 = co.i2, c2 = co.c2, jg = co.jg, cg = co.cg;
         const bool own1 = (c1 == 0) && (j1 < n), own2 = (c2 == 0) && (i2 < m), owng = (cg == 0) && (jg < n);
-        materialize_ar(co);
         double sreg[TG];
+#pragma unroll
+        for (int s = 0; s < TG; s++) sreg[s] = 0.0;
+        // RESCALE without refactoring.  Dy is proportional to the scale (zero-cone rows included), so with f = scale_new / scale_old
+        //     S_new = rho I + f (S_old - rho I) = f (S_old + delta I),   delta = rho (1 - f) / f,        G_new = (1 / f) (I + delta G)^-1 G
+        // and since rho_x = 1e-6 is tiny against the spectrum of A^T Dy A, x = |delta| |G|_F is ~1e-4: the Neumann series
+        //     (I + delta G)^-1 G = G - delta G^2 + delta^2 G^3 - ...   =  Y_K,   Y_0 = G,  Y_{j+1} = G - delta G Y_j
+        // reaches 1e-15 relative accuracy in K = 2-4 products of n x n matrices, against S formation + blocked Gauss-Jordan (three quarters of
+        // a refactorisation, which costs as much as ~35 iterations and runs about once per instance after the initial one).  Y_j stays in the
+        // (jg, cg) register tile of the inversion; a row of Y_j is spread over the CHG adjacent lanes of its row group and is broadcast from
+        // there (ds_bpermute), G is read from LDS; only when x > 1e-2 (S nearly singular) the full refactorisation below runs.
+        bool fast = false;
+        if constexpr (!HASP) {
+            if (T.f2_neumann && g_scale > 0.0) {
+                const double f = uniform_d(scale / g_scale), delta = uniform_d(rho_x * (1.0 - f) / f);
+                double r[1] = {0};
+                if (jg < n) {
+                    const double2 *src = reinterpret_cast<const double2 *>(Gm + jg * ldg + TG * cg);
+#pragma unroll
+                    for (int s2 = 0; s2 < TG / 2; s2++) { const double2 v = src[s2]; sreg[2 * s2] = v.x; sreg[2 * s2 + 1] = v.y; r[0] = fma(v.x, v.x, fma(v.y, v.y, r[0])); }
+                }
+                block_reduce_n<1, NW>(r, 0u, red);
+                const double xx = uniform_d(fabs(delta) * sqrt(r[0]));
+                int K = 0;
+                if (xx <= 1e-5) K = 2; else if (xx <= 1.5e-4) K = 3; else if (xx <= 1e-3) K = 4; else if (xx <= 1e-2) K = 7;      // x^(K+1) <= 1e-15
+                if (K > 0) {
+                    fast = true;
+                    double greg[TG];
+#pragma unroll
+                    for (int s = 0; s < TG; s++) greg[s] = sreg[s];
+                    const int lane_base = (threadIdx.x & 63) & ~(CHG - 1);
+                    for (int it = 0; it < K; it++) {
+                        double zz[TG];
+#pragma unroll
+                        for (int s = 0; s < TG; s++) zz[s] = 0.0;
+#pragma unroll
+                        for (int q = 0; q < CHG; q++) {
+                            const int src_lane = (lane_base + q) << 2;
+#pragma unroll
+                            for (int s = 0; s < TG; s++) {
+                                const int kcol = TG * q + s;
+                                const int lo = __builtin_amdgcn_ds_bpermute(src_lane, __double2loint(sreg[s])), hi = __builtin_amdgcn_ds_bpermute(src_lane, __double2hiint(sreg[s]));
+                                const double yk = __hiloint2double(hi, lo);                      // Y_j[jg][kcol]
+                                if (kcol < n) {                                                   // uniform (rows of G beyond n do not exist)
+                                    const double2 *gr = reinterpret_cast<const double2 *>(Gm + kcol * ldg + TG * cg);
+#pragma unroll
+                                    for (int s2 = 0; s2 < TG / 2; s2++) { const double2 v = gr[s2]; zz[2 * s2] = fma(yk, v.x, zz[2 * s2]); zz[2 * s2 + 1] = fma(yk, v.y, zz[2 * s2 + 1]); }
+                                }
+                            }
+                        }
+#pragma unroll
+                        for (int s = 0; s < TG; s++) sreg[s] = fma(-delta, zz[s], greg[s]);
+                    }
+                    const double rf = 1.0 / f;
+#pragma unroll
+                    for (int s = 0; s < TG; s++) sreg[s] = (jg < n) ? sreg[s] * rf : 0.0;
+                    __syncthreads();                 // every lane has finished reading the old G
+                }
+            }
+        }
+        if (!fast) {
+        materialize_ar(co);
 #pragma unroll
         for (int s = 0; s < TG; s++) sreg[s] = 0.0;
         // S = A-hat^T Dy A-hat on the matrix cores (v_mfma_f64_16x16x4_f64).  Row panels of A-hat are staged through the (not yet used)
@@ -639,7 +700,9 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
                 __syncthreads();
             }
         });
+        }      // (!fast)
         F2_STAMP(9);
+        g_scale = uniform_d(scale);
         if constexpr (HASP) { if (sc[7] != 0.0) return; }      // (uniform: read after the loop's last barrier) -> status FAILED below
         // G to LDS (the panel data in that region is dead), scratch back to zero
         if (jg < n) {

@@ -18,6 +18,7 @@ struct DevT {
     int nep, eoff;        // exponential cones (3 rows each) and their first row (after the PSD blocks: SCS row order z,l,q,s,ep,p)
     int np;               // 3-d power cones, after the exponential cones
     const double *pw;     // [np] exponent a of x^a y^(1-a) >= |z|; a < 0: the dual cone of exponent |a| (SCS convention)
+    int f2_neumann;       // k_fwd2: a rescale updates G by a Neumann series instead of refactoring (CE_F2_NEUMANN=0 disables)
     int gen_blocked_f, gen_blocked_b;   // size-generic kernels with G / K in global memory: LDS holds the panels of the blocked eliminations (else: unblocked)
 };
 

@@ -133,7 +133,7 @@ static size_t bwd_lds_bytes(const DevT &T, bool a_lds, bool k_lds, int nkcap, in
     if (k_lds) d += (size_t)nkcap * ldk;
     d += 5 * (size_t)m + 2 * (size_t)n + 2 * (size_t)nqs * n + 6 * nqs + PB + NW * 8;
     if (!k_lds && panel) d += generic_lu_panel_doubles(nkcap);
-    size_t ints = 2 * (size_t)m + 2 * nqs + nkcap + 4;
+    size_t ints = 2 * (size_t)m + 2 * nqs + 2 * (size_t)nkcap + 4;      // (perm + colrow)
     return d * 8 + ints * 4 + 16;
 }
 
@@ -422,6 +422,7 @@ int ce_create(const ce_template *tpl, int device, ce_handle *out) {
     else if (bwd_lds_bytes(T, true, false, h->nkcap, h->ldk) <= LDS_LIMIT) h->bwd_mode = 1;
     else if (bwd_lds_bytes(T, false, false, h->nkcap, h->ldk) <= LDS_LIMIT) h->bwd_mode = 2;
     else { ce_destroy(h); g_err = "instance vectors do not fit LDS"; return CE_E_TOO_LARGE; }
+    { const char *e = getenv("CE_F2_NEUMANN"); T.f2_neumann = (e && atoi(e) == 0) ? 0 : 1; }
     T.gen_blocked_b = (h->bwd_mode >= 1 && bwd_lds_bytes(T, h->bwd_mode <= 1, false, h->nkcap, h->ldk, true) <= LDS_LIMIT) ? 1 : 0;
     h->bwd_lds = bwd_lds_bytes(T, h->bwd_mode <= 1, h->bwd_mode == 0, h->nkcap, h->ldk, T.gen_blocked_b != 0);
     if (!getenv("CE_FORCE_GENERIC")) {

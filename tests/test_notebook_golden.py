@@ -115,3 +115,11 @@ def test_resource_allocation_layer_matches_its_kkt_solution(make):
     y, = layer(torch.tensor(budget), torch.tensor(1.0 / P), torch.tensor(alpha))
     ex = nc.resource_allocation_exact(budget, 1.0 / P, alpha)
     assert np.abs(y.detach().cpu().numpy() - ex).max() <= 2e-6
+
+
+@pytest.mark.gpu
+def test_supply_chain_notebook_trace_on_the_size_generic_kernels(monkeypatch):
+    """The same training trace with the register-tiled kernels switched off (CE_FORCE_GENERIC=1: k_forward / k_backward, the fall-backs for
+    templates beyond n = 98): their elimination is rank-revealing as well (degenerate active sets are the rule in this LP-like policy)."""
+    monkeypatch.setenv("CE_FORCE_GENERIC", "1")
+    test_supply_chain_notebook_training_trace(_gpu_layer)
