@@ -491,7 +491,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
         // (jg, cg) register tile of the inversion; a row of Y_j is spread over the CHG adjacent lanes of its row group and is broadcast from
         // there (ds_bpermute), G is read from LDS; only when x > 1e-2 (S nearly singular) the full refactorisation below runs.
         bool fast = false;
-        if constexpr (!HASP) {
+        if constexpr (!HASP && TG <= 14) {       // (the wide-tile variants have no registers to spare for Y, G and Z segments: they refactor)
             if (T.f2_neumann && g_scale > 0.0) {
                 const double f = uniform_d(scale / g_scale), delta = uniform_d(rho_x * (1.0 - f) / f);
                 double r[1] = {0};
