@@ -130,7 +130,7 @@ __device__ __forceinline__ void psd_sweeps_wg(double *Sm, double *Vm, int k, int
 // has drifted from orthogonality or a refinement step was already taken).
 // Storage: COMPACT k x k row-major matrices with pitch P >= k (no zero padding; the MFMA operand reads are guarded), the contraction runs
 // over ceil(k / 4) steps of 4 instead of the padded KP / 4 (k = 20: 5 steps, not 8).
-// out(M, N, sum_K A(M, K) B(K, N)) for M, N < k, with A(M, K) = pA[M * sAm + K * sAk] (* wK[K] when wK != null) and B(K, N) = pB[K * sBk + N * sBn].
+// out(M, N, sum_K A(M, K) B(K, N)) for M, N < k, with A(M, K) = pA[M * sAm + K * sAk] (* max(wK[K], 0) when wK != null) and B(K, N) = pB[K * sBk + N * sBn].
 // Address arithmetic is what this costs (the products themselves are five MFMA instructions per tile at k = 20): row / column indices beyond k
 // are CLAMPED instead of guarded (their results are never stored), each lane keeps one base pointer per operand and steps it by a uniform
 // stride, the operands of up to five contraction steps are loaded before their products are issued; only a contraction index beyond k
@@ -154,7 +154,7 @@ __device__ __forceinline__ void psd_gemm_kk(int k, const double *pA, int sAm, in
                 if (st < KS) {                                     // uniform
                     const int kc = (kk < k) ? 4 * st : (k - 1 - lg);       // clamped contraction index (relative to the lane's lg)
                     a[u] = qa[kc * sAk]; b[u] = qb[kc * sBk];
-                    if (qw) a[u] *= qw[kc];
+                    if (qw) a[u] *= fmax(qw[kc], 0.0);            // (wK: eigenvalues; the product wants their positive parts)
                     if (kk >= k) a[u] = 0.0;
                 } else { a[u] = 0.0; b[u] = 0.0; }
             }
@@ -170,9 +170,14 @@ __host__ __device__ inline int psd_refine_pitch(int k) { return k | 1; }        
 // LDS doubles of the scratch shared by all blocks of an instance (S, T / E, D, R + rotation parameters + eigenvalues + lam); every block keeps k P more (V)
 __host__ __device__ inline int psd_refine_scratch_doubles(int kmax) { return 4 * kmax * psd_refine_pitch(kmax) + 4 * kmax + 16; }
 
-// phase timing (debug, stats != null): ticks are accumulated in registers and flushed once per projection -- a global atomic per phase would stall
-// the instrumented wave for longer than the phase itself
+// phase timing: debug builds only (-DCE_PSD_TIMING; ticks are accumulated in registers and flushed once per projection -- a global atomic per phase
+// would stall the instrumented wave for longer than the phase itself).  In the product build the macro is empty: the tick registers and clock reads
+// pushed k_sa_fwd further into scratch.
+#ifdef CE_PSD_TIMING
 #define PSD_TICK(slot) do { if (stats) { const long long t_ = clock64(); tk[(slot) - 8] += t_ - tph; tph = t_; } } while (0)
+#else
+#define PSD_TICK(slot) do { } while (0)
+#endif
 
 // One refinement loop.  Returns 0: converged (Va: eigenvectors, ev: eigenvalues);  1: the very first step would leave the basin of the first-order
 // correction and Va is still the caller's orthonormal V: D = Va^T S Va was written to Dm (not symmetrised) for Jacobi sweeps;  2: start over (cold).
@@ -187,13 +192,16 @@ __host__ __device__ inline int psd_refine_scratch_doubles(int kmax) { return 4 *
 template <int NTH>
 __device__ __forceinline__ int psd_refine_loop_fused(int k, int P, const double *Sm, double *&Va, double *&Vb, double *Tm, double *Dm, double *lam, double *ev,
                                                       double *red, unsigned long long *stats, int refine, int maxl, long long (&tk)[6]) {
+    (void)tk;
     constexpr int NW = NTH / 64, KSM = 5;                      // k <= 20: five contraction steps (the caller routes larger blocks to the LDS loop)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lg = lane >> 4, lc = lane & 15;
     const int KT = (k + 15) >> 4, KS = (k + 3) >> 2;
     const bool has_tile = wave < KT * KT;
     const int ti = (KT == 2) ? (wave >> 1) : 0, tj = (KT == 2) ? (wave & 1) : 0;
     const int am = 16 * ti + lc, bn = 16 * tj + lc, amc = min(am, k - 1), bnc = min(bn, k - 1);
+#ifdef CE_PSD_TIMING
     long long tph = stats ? clock64() : 0;
+#endif
     double prev_off = 0;
     for (int it = 0; it < maxl; it++) {
         psd_v4d aD = {0.0, 0.0, 0.0, 0.0}, aG = {0.0, 0.0, 0.0, 0.0};         // D tile, (V^T V) tile
@@ -377,31 +385,31 @@ __device__ __forceinline__ void psd_project_refine(double *zsvec, int k, double 
         __syncthreads();
         Va = Vst;
         const bool coarse = refine && attempt == 0;                 // first fall-back: sweep into the basin of the refinement only
+#ifdef CE_PSD_TIMING
         const long long tj0 = stats ? clock64() : 0;
+#endif
         psd_sweeps_wg<NTH>(Dm, Vst, k, P, cs, red, coarse ? 1e-6 : 0.0);
+#ifdef CE_PSD_TIMING
         if (stats && tid == 0) atomicAdd(&stats[6], (unsigned long long)(clock64() - tj0));
+#endif
         if (coarse) { res = 3; continue; }                          // (the sweeps end with the barriers of their last reduction)
         for (int i = tid; i < k; i += NT) ev[i] = Dm[i * P + i];
         __syncthreads();
         break;
     }
     if (stats && tid == 0) atomicAdd(&stats[0], 1ull);
+#ifdef CE_PSD_TIMING
     long long tph = stats ? clock64() : 0;
-    for (int i = tid; i < k; i += NT) ev[i] = fmax(ev[i], 0.0);
-    __syncthreads();
-    // X = (Va diag(w+)) Va^T ;  the refined eigenvectors return to the block's own buffer in the same phase
-    psd_gemm_kk<NTH>(k, Va, P, 1, Va, 1, P, ev, [&](int M, int N, double v) { Tm[M * P + N] = v; });
+#endif
+    // X = (Va diag(w+)) Va^T, written straight into the svec (lower triangle; the two triangles of the product differ by rounding only, and S
+    // itself was copied out of zsvec at the start); the refined eigenvectors return to the block's own buffer in the same phase
+    psd_gemm_kk<NTH>(k, Va, P, 1, Va, 1, P, ev, [&](int M, int N, double v) { if (M >= N) zsvec[N * k - (N * (N - 1)) / 2 + (M - N)] = (M == N) ? v : v * M_SQRT2; });
     if (Va != Vst) for (int idx = tid; idx < k * k; idx += NT) { const int i = psd_fdiv(idx, rk), j = idx - i * k; Vst[i * P + j] = Va[i * P + j]; }
     __syncthreads();
-    for (int idx = tid; idx < k * k; idx += NT) {          // lower triangle (a >= b) -> svec position b k - b (b - 1) / 2 + (a - b)
-        const int a = psd_fdiv(idx, rk), b = idx - a * k;
-        if (a < b) continue;
-        const double v = 0.5 * (Tm[a * P + b] + Tm[b * P + a]);
-        zsvec[b * k - (b * (b - 1)) / 2 + (a - b)] = (a == b) ? v : v * M_SQRT2;
-    }
-    __syncthreads();
     PSD_TICK(13);
+#ifdef CE_PSD_TIMING
     if (stats && tid == 0) for (int q = 0; q < 6; q++) atomicAdd(&stats[8 + q], (unsigned long long)tk[q]);
+#endif
 }
 
 // LDS doubles needed: 3 * KP * (KP + 1) + 2 * k + 8  (+ the reduction scratch of block_reduce_n)

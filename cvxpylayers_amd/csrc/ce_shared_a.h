@@ -45,9 +45,8 @@ __device__ __forceinline__ void sa_spmv(const int *__restrict__ ptr, const int *
 // LDS doubles.  nvv: rows in front of the first PSD block (v = y - s is kept for those only; PSD blocks read y - s once, at the start).
 // The partial sums of the dense-row products (2 NT doubles) share the PSD scratch matrices when the template has PSD blocks.
 __host__ __device__ inline size_t sa_lsqr_lds_doubles(int n, int m, int nq, int ns, int maxs, int RP, int nvv, int ntri = 0) {
-    const size_t pm = ns > 0 ? (size_t)maxs * psd_refine_pitch(maxs) : 0;      // compact k x k matrices (ce_psd_mfma.h)
-    const size_t scr = ns > 0 ? ((RP > 0 && 2 * pm < 2 * (size_t)NT) ? 2 * (size_t)NT : 2 * pm) : 0;      // H, Y scratch (also holds the 2 NT partial sums of the dense-row products)
-    return (size_t)(RP > 0 ? 2 * RP + (ns > 0 ? 0 : 2 * NT) : 0) + (size_t)(ns > 0 ? 2 * ns * pm + scr + 2 * maxs + 8 + ((2 * ns * pm + scr) & 1) : 0) + NW * 8 +
+    const int kp = ns > 0 ? psd_mfma_kp(maxs) : 0;
+    return (size_t)(RP > 0 ? 2 * RP + (ns > 0 ? 0 : 2 * NT) : 0) + (size_t)(ns > 0 ? (2 * ns + 2) * kp * (kp + 1) + 2 * kp + 8 : 0) + NW * 8 +
            (size_t)(nvv + (nvv & 1)) + 6 * (size_t)m + 4 * (size_t)n + 5 * (size_t)(nq > 0 ? nq : 1) + 16 + 9 * (size_t)ntri + (ntri & 1);
 }
 
@@ -61,19 +60,18 @@ k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, cons
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int tid = threadIdx.x, inst = blockIdx.x;
     const int n = T.n, m = T.m, z = T.z, nl = T.l, nq = T.nq, ns = T.ns;
-    const int P = ns > 0 ? psd_refine_pitch(T.maxs) : 1, PM = ns > 0 ? T.maxs * P : 0;      // compact k x k matrices, common pitch (ce_psd_mfma.h)
+    const int KP = ns > 0 ? psd_mfma_kp(T.maxs) : 0, P = KP + 1, PM = KP * P;
+    const float rKP = KP > 0 ? 1.0f / (float)KP : 1.0f;
     const int ntri = T.nep + T.np;
     const int psd_first = ns > 0 ? T.soff[0] : T.eoff, nvv = psd_first + (psd_first & 1);      // rows in front of the PSD blocks / the triples
     double *p = sm;                                          // (everything read with 16-byte accesses sits at the start: even sizes only)
     double *wyd = p, *vd = p, *part = p;
     if constexpr (RP > 0) { wyd = p; p += RP; vd = p; p += RP; if (ns == 0) { part = p; p += 2 * NT; } }
-    double *Hm = p, *Ym = p + PM;                            // PSD scratch
-    p += (ns > 0 ? ((RP > 0 && 2 * PM < 2 * NT) ? 2 * NT : 2 * PM) : 0);
-    if (RP > 0 && ns > 0) part = Hm;                         // partial sums of the dense-row products (2 NT doubles), used between dproj calls only
+    double *Hm = p; p += PM; double *Ym = p; p += PM;        // PSD scratch
+    if (RP > 0 && ns > 0) part = Hm;                         // partial sums of the dense-row products: 2 NT <= 2 PM doubles, used between dproj calls only
     double *Um = p; p += (size_t)ns * PM;                    // eigenvectors of smat(v_c), per cone
     double *Bm = p; p += (size_t)ns * PM;                    // divided differences, per cone
-    double *cs = p; p += (ns > 0 ? 2 * T.maxs + 8 : 0);
-    p += (size_t)(p - sm) & 1;
+    double *cs = p; p += (ns > 0 ? 2 * KP + 8 : 0);
     double *red = p; p += NW * 8;
     double *vv = p; p += nvv;          // v = y - s, rows in front of the PSD blocks
     double *uy = p; p += m; double *vy = p; p += m; double *wy = p; p += m; double *ry = p; p += m; double *ty = p; p += m; double *qv = p; p += m;
@@ -112,21 +110,23 @@ k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, cons
         const int k = T.sord[c];
         double *U = Um + (size_t)c * PM, *Bc = Bm + (size_t)c * PM;
         const double *ys = y + T.soff[c], *ss = s + T.soff[c];
-        const float rk_ = 1.0f / (float)k;
-        for (int idx = tid; idx < k * k; idx += NT) {
-            const int i = psd_fdiv(idx, rk_), j = idx - i * k;
-            const int a = i >= j ? i : j, b = i >= j ? j : i; const int e = b * k - (b * (b - 1)) / 2 + (a - b); const double v0 = ys[e] - ss[e];
-            Hm[i * P + j] = (a == b) ? v0 : v0 * M_SQRT1_2; U[i * P + j] = (i == j) ? 1.0 : 0.0;
+        for (int idx = tid; idx < KP * KP; idx += NT) {
+            const int i = psd_fdiv(idx, rKP), j = idx - i * KP;
+            double sv = 0.0;
+            if (i < k && j < k) { const int a = i >= j ? i : j, b = i >= j ? j : i; const int e = b * k - (b * (b - 1)) / 2 + (a - b); const double v0 = ys[e] - ss[e]; sv = (a == b) ? v0 : v0 * M_SQRT1_2; }
+            Hm[i * P + j] = sv; U[i * P + j] = (i == j && i < k) ? 1.0 : 0.0;
         }
         __syncthreads();
         psd_sweeps_wg<NT>(Hm, U, k, P, cs, red);
-        for (int idx = tid; idx < k * k; idx += NT) {
-            const int i = psd_fdiv(idx, rk_), j = idx - i * k;
-            const double wi = Hm[i * P + i], wj = Hm[j * P + j];
-            double bv;
-            if (wi > 0 && wj > 0) bv = 1.0;
-            else if (wi <= 0 && wj <= 0) bv = 0.0;
-            else { const double den = wi - wj; bv = (fmax(wi, 0.0) - fmax(wj, 0.0)) / (den == 0 ? 1.0 : den); }
+        for (int idx = tid; idx < KP * KP; idx += NT) {
+            const int i = psd_fdiv(idx, rKP), j = idx - i * KP;
+            double bv = 0.0;
+            if (i < k && j < k) {
+                const double wi = Hm[i * P + i], wj = Hm[j * P + j];
+                if (wi > 0 && wj > 0) bv = 1.0;
+                else if (wi <= 0 && wj <= 0) bv = 0.0;
+                else { const double den = wi - wj; bv = (fmax(wi, 0.0) - fmax(wj, 0.0)) / (den == 0 ? 1.0 : den); }
+            }
             Bc[i * P + j] = bv;
         }
         __syncthreads();
@@ -165,26 +165,26 @@ k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, cons
             }
             sink(i, o);
         }
-        for (int c = 0; c < ns; c++) {      // PSD block: Z = U (B o (U^T H U)) U^T on the matrix cores (compact k x k operands, ce_psd_mfma.h)
-            const int k = T.sord[c], off = T.soff[c];
-            const float rk_ = 1.0f / (float)k;
+        for (int c = 0; c < ns; c++) {      // PSD block: Z = U (B o (U^T H U)) U^T on the matrix cores
+            const int k = T.sord[c], off = T.soff[c], KT = KP / 16;
             const double *U = Um + (size_t)c * PM, *Bc = Bm + (size_t)c * PM;
-            for (int idx = tid; idx < k * k; idx += NT) {
-                const int i = psd_fdiv(idx, rk_), j = idx - i * k;
-                const int a = i >= j ? i : j, b = i >= j ? j : i; const double v0 = h[off + b * k - (b * (b - 1)) / 2 + (a - b)] * hs;
-                Hm[i * P + j] = (a == b) ? v0 : v0 * M_SQRT1_2;
+            for (int idx = tid; idx < KP * KP; idx += NT) {
+                const int i = psd_fdiv(idx, rKP), j = idx - i * KP;
+                double sv = 0.0;
+                if (i < k && j < k) { const int a = i >= j ? i : j, b = i >= j ? j : i; const double v0 = h[off + b * k - (b * (b - 1)) / 2 + (a - b)] * hs; sv = (a == b) ? v0 : v0 * M_SQRT1_2; }
+                Hm[i * P + j] = sv;
             }
             __syncthreads();
-            psd_gemm_kk<NT>(k, Hm, P, 1, U, P, 1, nullptr, [&](int M, int N, double v) { Ym[M * P + N] = v; });                    // H U
+            psd_mfma_gemm<NT>(KT, [&](int M, int K) { return Hm[K * P + M]; }, [&](int K, int N) { return U[K * P + N]; }, [&](int M, int N, double v) { Ym[M * P + N] = v; });   // H U
             __syncthreads();
-            psd_gemm_kk<NT>(k, U, 1, P, Ym, P, 1, nullptr, [&](int M, int N, double v) { Hm[M * P + N] = v * Bc[M * P + N]; });   // B o (U^T H U)
+            psd_mfma_gemm<NT>(KT, [&](int M, int K) { return U[K * P + M]; }, [&](int K, int N) { return Ym[K * P + N]; }, [&](int M, int N, double v) { Hm[M * P + N] = v * Bc[M * P + N]; });   // B o (U^T H U)
             __syncthreads();
-            psd_gemm_kk<NT>(k, U, P, 1, Hm, P, 1, nullptr, [&](int M, int N, double v) { Ym[M * P + N] = v; });                    // U Y
+            psd_mfma_gemm<NT>(KT, [&](int M, int K) { return U[M * P + K]; }, [&](int K, int N) { return Hm[K * P + N]; }, [&](int M, int N, double v) { Ym[M * P + N] = v; });   // U Y
             __syncthreads();
-            psd_gemm_kk<NT>(k, Ym, P, 1, U, 1, P, nullptr, [&](int M, int N, double v) { Hm[M * P + N] = v; });                    // (U Y) U^T
+            psd_mfma_gemm<NT>(KT, [&](int M, int K) { return Ym[M * P + K]; }, [&](int K, int N) { return U[N * P + K]; }, [&](int M, int N, double v) { Hm[M * P + N] = v; });   // (U Y) U^T
             __syncthreads();
             for (int idx = tid; idx < k * k; idx += NT) {          // lower triangle (a >= b) -> svec position
-                const int a = psd_fdiv(idx, rk_), b = idx - a * k;
+                const int a = psd_fdiv(idx, 1.0f / (float)k), b = idx - a * k;
                 if (a < b) continue;
                 const double v0 = 0.5 * (Hm[a * P + b] + Hm[b * P + a]);
                 sink(off + b * k - (b * (b - 1)) / 2 + (a - b), (a == b) ? v0 : v0 * M_SQRT2);

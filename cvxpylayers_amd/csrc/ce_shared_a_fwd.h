@@ -27,7 +27,9 @@ struct SaFwd {
     const double *gs;            // [n]      sum over the singleton rows of column j of d0_i a_i^2
     const double *Dv, *Ev;       // [m], [n] equilibration
     unsigned long long *psd_stats;   // debug (CE_PSD_STATS=1): projections / refinement steps / warm Jacobi fall-backs / cold starts, or null
-    double *aa_ws;                   // Anderson acceleration history, [B][5][lp] doubles of global memory (touched on two of every acceleration_interval iterations), or null: plain iteration
+    double *aa_ws;                   // Anderson acceleration history, [B][4][lp] doubles of global memory (x_prev, f_prev, f_save, [w_prev when it does not fit LDS]; read once
+                                     // per acceleration_interval iterations), or null: plain iteration
+    int aa_w_lds;                    // the input of the last iteration (w_prev: read by the safeguard, written on two of ten iterations) lives in LDS
     int psd_refine;                  // 1: eigen-refinement on the matrix cores (default); 0 (CE_PSD_REFINE=0): warm-started Jacobi sweeps only, restart at check iterations (round 2)
 };
 
@@ -77,6 +79,7 @@ k_sa_fwd(DevT T, SaFwd F, ce_settings S, const double *__restrict__ BHg, const d
     double *sc = p; p += 32;
     const int ntri = T.nep + T.np;
     double *troot = p; p += ntri + (ntri & 1);              // exponential / power triples: root of the previous projection (warm start of the Newton iteration)
+    double *aaW_lds = p; if (F.aa_w_lds) p += lp;           // Anderson acceleration: input of the last iteration
     const int *c_srow_col = F.srow_col, *c_rowcone = T.rowcone, *c_scol_ptr = F.scol_ptr, *c_scol_row = F.scol_row, *c_qoff = T.qoff, *c_drow = F.drow;
     const double *c_srow_val = F.srow_val;
     if constexpr (CIDX) {
@@ -93,7 +96,9 @@ k_sa_fwd(DevT T, SaFwd F, ce_settings S, const double *__restrict__ BHg, const d
     }
     const double *ch = CHg + (size_t)inst * n;              // c-hat stays in global memory (read in refresh / checks only)
     const double rho_x = S.rho_x, rtau = TAU_FACTOR, alpha = S.alpha;
-    const double sigma = sigma_g[inst], isg = 1.0 / sigma;
+    // loop-carried values that are equal in every lane live in scalar registers (uniform_d = readfirstlane, ce_forward_v2.h): the 256-thread
+    // instantiation sits at the 256-VGPR ceiling and every VGPR held across the iteration loop is one more scratch reload per iteration
+    const double sigma = uniform_d(sigma_g[inst]), isg = uniform_d(1.0 / sigma);
     double scale = S.scale;
     auto dyv = [&](int i) -> double { return (i < z) ? ZERO_CONE_FACTOR * scale : scale; };
 
@@ -182,7 +187,7 @@ k_sa_fwd(DevT T, SaFwd F, ce_settings S, const double *__restrict__ BHg, const d
         for (int j = tid; j < n; j += NT) { G[j] = tv[j]; PHI[j] = rho_x * px[j]; rr[0] = fma(ch[j], tv[j], rr[0]); }
         for (int i = tid; i < m; i += NT) rr[0] = fma(bh[i], G[n + i], rr[0]);
         block_reduce_n<1, NW>(rr, 0u, red);
-        hg = rr[0]; inv_den = 1.0 / (rtau + hg);
+        hg = uniform_d(rr[0]); inv_den = uniform_d(1.0 / (rtau + hg));
         if (tid == 0) { G[l - 1] = 0.0; PHI[l - 1] = 0.0; }
         __syncthreads();
     };
@@ -213,8 +218,9 @@ k_sa_fwd(DevT T, SaFwd F, ce_settings S, const double *__restrict__ BHg, const d
     bool aa_on = S.acceleration_lookback > 0 && F.aa_ws != nullptr, aa_pending = false;
     const int aa_int = S.acceleration_interval > 0 ? S.acceleration_interval : 10;
     int aa_iter = 0, aa_rej = 0;
-    double aa_normg = 0;
-    double *const aaWP = F.aa_ws ? F.aa_ws + (size_t)inst * 5 * lp : nullptr, *const aaXP = aaWP + lp, *const aaFP = aaXP + lp, *const aaFS = aaFP + lp, *const aaXS = aaFS + lp;
+    double aa_normg = 0, aa_hs = 1.0;     // |g| before the step ; factor by which the stored history has to be scaled (the renormalisations of w since it was stored)
+    double *const aaXP = F.aa_ws ? F.aa_ws + (size_t)inst * 4 * lp : nullptr, *const aaFP = aaXP + lp, *const aaFS = aaFP + lp;
+    double *const aaWP = F.aa_w_lds ? aaW_lds : aaFS + lp;      // (generic pointer: LDS when it fits, else the fourth global vector)
     double res3[3] = {NAN, NAN, NAN};
     while (!done) {
         refresh();
@@ -226,14 +232,16 @@ k_sa_fwd(DevT T, SaFwd F, ce_settings S, const double *__restrict__ BHg, const d
         for (;;) {
             if (iter >= S.max_iters) { done = true; break; }
             const bool check = (iter % CONVERGED_INTERVAL) == 0, last = iter + 1 >= S.max_iters;
+#ifdef CE_PSD_TIMING
             const long long t_iter0 = F.psd_stats ? clock64() : 0;
+#endif
             if (aa_on) {
                 if (aa_pending) {      // safeguard: residual of the map at the accelerated point against the residual before the step
                     double rs[1] = {0};
                     for (int e = tid; e < l; e += NT) { const double dd = aaWP[e] - W[e]; rs[0] = fma(dd, dd, rs[0]); }
                     block_reduce_n<1, NW>(rs, 0u, red);
                     if (!(sqrt(rs[0]) <= aa_normg)) {
-                        for (int e = tid; e < l; e += NT) W[e] = aaFS[e];
+                        for (int e = tid; e < l; e += NT) W[e] = aaFS[e] * aa_hs;
                         aa_iter = 0;
                         if (++aa_rej >= AA_MAX_REJECT) aa_on = false;
                         __syncthreads();
@@ -244,21 +252,23 @@ k_sa_fwd(DevT T, SaFwd F, ce_settings S, const double *__restrict__ BHg, const d
                     if (aa_iter > 0) {
                         double rr[5] = {0, 0, 0, 0, 0};
                         for (int e = tid; e < l; e += NT) {
-                            const double xv = aaWP[e], fv = W[e], gv = xv - fv, xp = aaXP[e], fp = aaFP[e];
+                            const double xv = aaWP[e], fv = W[e], gv = xv - fv, xp = aaXP[e] * aa_hs, fp = aaFP[e] * aa_hs;
                             const double sv = xv - xp, yv = gv - (xp - fp);
                             rr[0] = fma(sv, sv, rr[0]); rr[1] = fma(yv, yv, rr[1]); rr[2] = fma(sv, yv, rr[2]); rr[3] = fma(sv, gv, rr[3]); rr[4] = fma(gv, gv, rr[4]);
                         }
                         block_reduce_n<5, NW>(rr, 0u, red);
-                        const double mm = rr[2] + 1e-8 * sqrt(rr[0]) * sqrt(rr[1]), gam = rr[3] / mm;
+                        const double mm = rr[2] + 1e-8 * sqrt(rr[0]) * sqrt(rr[1]), gam = uniform_d(rr[3] / mm);
                         const bool ok = fabs(mm) > 1e-300 && fabs(gam) < 1e10;
-                        for (int e = tid; e < l; e += NT) {
-                            const double xv = aaWP[e], fv = W[e], fp = aaFP[e];
+                        for (int e = tid; e < l; e += NT) {                      // (second read of the history: L2-warm)
+                            const double xv = aaWP[e], fv = W[e], fp = aaFP[e] * aa_hs;
                             aaXP[e] = xv; aaFP[e] = fv;
-                            if (ok) { aaFS[e] = fv; aaXS[e] = xv; W[e] = fv - gam * (fv - fp); }
+                            if (ok) { aaFS[e] = fv; W[e] = fv - gam * (fv - fp); }
                         }
-                        if (ok) { aa_normg = sqrt(rr[4]); aa_pending = true; } else aa_iter = 0;
+                        aa_hs = 1.0;
+                        if (ok) { aa_normg = uniform_d(sqrt(rr[4])); aa_pending = true; } else aa_iter = 0;
                     } else {
                         for (int e = tid; e < l; e += NT) { aaXP[e] = aaWP[e]; aaFP[e] = W[e]; }
+                        aa_hs = 1.0;
                     }
                     aa_iter++;
                     __syncthreads();
@@ -272,7 +282,7 @@ k_sa_fwd(DevT T, SaFwd F, ce_settings S, const double *__restrict__ BHg, const d
                 if (nw > 0) {
                     const double f = sqrt((double)l) / nw;
                     for (int e = tid; e < l; e += NT) W[e] *= f;
-                    if (aa_on) { for (int e = tid; e < l; e += NT) { aaXP[e] *= f; aaFP[e] *= f; aaFS[e] *= f; aaXS[e] *= f; } aa_normg *= f; }      // the map is positively homogeneous
+                    if (aa_on) { aa_hs = uniform_d(aa_hs * f); aa_normg = uniform_d(aa_normg * f); }      // the map is positively homogeneous: the stored history scales with w (lazily)
                 }
                 __syncthreads();
             }
@@ -367,10 +377,14 @@ k_sa_fwd(DevT T, SaFwd F, ce_settings S, const double *__restrict__ BHg, const d
             };
 #ifndef SA_SKIP_PSD        // (debug builds time the kernel without the projection)
             if constexpr (NTH == 256) {        // (templates with PSD blocks always run the 256-thread instantiation)
+#ifdef CE_PSD_TIMING
                 const long long tp0 = (F.psd_stats && ns > 0) ? clock64() : 0;
+#endif
                 for (int c = 0; c < ns; c++)   // PSD blocks: warm-started eigen-refinement on the matrix cores (Jacobi sweeps as the fall-back), eigenvectors stay in LDS
                     psd_project_refine<NT>(zb + n + T.soff[c], T.sord[c], Vst + (size_t)c * PM, Sm, Tm, Dm, Rm, cs, red, (iter > 0 && (F.psd_refine || !check)) ? 1 : 0, F.psd_stats, F.psd_refine);
+#ifdef CE_PSD_TIMING
                 if (F.psd_stats && ns > 0 && tid == 0) { const long long t1 = clock64(); atomicAdd(&F.psd_stats[4], (unsigned long long)(t1 - tp0)); atomicAdd(&F.psd_stats[5], (unsigned long long)(t1 - t_iter0)); }
+#endif
             }
 #endif
             if (!check && !last) {
@@ -407,7 +421,7 @@ k_sa_fwd(DevT T, SaFwd F, ce_settings S, const double *__restrict__ BHg, const d
                 const double nrm_b0 = nb0_g[inst], nrm_c0 = nc0_g[inst];
                 if (tau > 0) {
                     const double res_pri = rp / tau, res_dual = rd / tau, gap = fabs(ctx + bty) / tau;
-                    res3[0] = res_pri; res3[1] = res_dual; res3[2] = gap;
+                    res3[0] = uniform_d(res_pri); res3[1] = uniform_d(res_dual); res3[2] = uniform_d(gap);
                     const double prl = fmax(fmax(nrm_b0 * tau, nsn), nax) / tau, drl = fmax(nrm_c0 * tau, naty) / tau;
                     const double grl = fmax(fabs(ctx), fabs(bty)) / tau;
                     if (res_pri <= S.eps_abs + S.eps_rel * prl && res_dual <= S.eps_abs + S.eps_rel * drl && gap <= S.eps_abs + S.eps_rel * grl) { status = 1; stop = true; }
@@ -418,14 +432,14 @@ k_sa_fwd(DevT T, SaFwd F, ce_settings S, const double *__restrict__ BHg, const d
                     const double dp = fmax(fmax(nax, nsn), nrm_b0 * tau), dd = fmax(naty, nrm_c0 * tau);
                     const double rel_p = rp / (dp > 0 ? dp : 1), rel_d = rd / (dd > 0 ? dd : 1);
                     if (rel_p > 0 && rel_d > 0 && isfinite(rel_p) && isfinite(rel_d)) {
-                        sum_log += ce_log(rel_p, mtab) - ce_log(rel_d, mtab); n_log++;
+                        sum_log = uniform_d(sum_log + ce_log(rel_p, mtab) - ce_log(rel_d, mtab)); n_log++;
                         const double factor = ce_exp(0.5 * sum_log / n_log, mtab);
                         if (iter - last_scale_iter >= RESCALING_MIN_ITERS) {
                             const double ns2 = fmin(fmax(scale * factor, MIN_SCALE_VALUE), MAX_SCALE_VALUE);
                             if (ns2 != scale && (factor > sqrt(10.0) || factor < 1.0 / sqrt(10.0))) {
                                 const double dy_ratio = ns2 / scale;       // keep (s, kappa):  w_y+ = rsk_y / r_y+ + 2 ut_y - u_y
                                 for (int e = tid + n; e < l - 1; e += NT) { const double ue = U[e], ute = UT[e]; W[e] = (ue + W[e] - 2 * ute) * dy_ratio + 2 * ute - ue; }
-                                n_log = 0; sum_log = 0; last_scale_iter = iter; scale = ns2; rescale = true; aa_iter = 0; aa_pending = false;
+                                n_log = 0; sum_log = 0; last_scale_iter = iter; scale = uniform_d(ns2); rescale = true; aa_iter = 0; aa_pending = false;
                                 __syncthreads();
                             }
                         }

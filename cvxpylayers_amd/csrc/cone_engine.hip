@@ -715,14 +715,17 @@ int ce_solve_shared_a(ce_handle h, int B, int r, int RP, const double *AdT, cons
     }
     if (!h->d_psd_stats && T.ns > 0) { const char *e = getenv("CE_PSD_STATS"); if (e && atoi(e) != 0) { HIPCHK(hipMalloc(&h->d_psd_stats, 16 * sizeof(unsigned long long))); HIPCHK(hipMemset(h->d_psd_stats, 0, 16 * sizeof(unsigned long long))); } }
     int psd_refine = 1; if (const char *e = getenv("CE_PSD_REFINE")) psd_refine = atoi(e) != 0;
-    double *aa_ws = nullptr;
+    double *aa_ws = nullptr; int aa_w_lds = 0;
     if (settings->acceleration_lookback > 0) {
         const size_t l = (size_t)T.n + T.m + 1, lp = l + (l & 1);
-        int rc = ensure(&h->d_aa_ws, &h->aa_ws_bytes, sizeof(double) * (size_t)B * 5 * lp);
+        int rc = ensure(&h->d_aa_ws, &h->aa_ws_bytes, sizeof(double) * (size_t)B * 4 * lp);
         if (rc) return rc;
         aa_ws = h->d_aa_ws;
+        // the input of the last iteration in LDS when that does not cost a workgroup per CU (config 4: 68.7 + 3.5 KB, still two per CU)
+        const size_t per_cu = nth == 256 ? LDS_LIMIT / 2 : LDS_LIMIT;
+        if (lds + lp * 8 <= per_cu || (lds > LDS_LIMIT / 2 && lds + lp * 8 <= LDS_LIMIT)) { aa_w_lds = 1; lds += lp * 8; }
     }
-    SaFwd F{r, RP, AdT, drow, srow_col, srow_val, scol_ptr, scol_row, gs, Dv, Ev, h->d_psd_stats, aa_ws, psd_refine};
+    SaFwd F{r, RP, AdT, drow, srow_col, srow_val, scol_ptr, scol_row, gs, Dv, Ev, h->d_psd_stats, aa_ws, aa_w_lds, psd_refine};
     {
         ProfScope ps(h, 0, (hipStream_t)stream);
 #define LAUNCH_SA(NTV, ...) hipLaunchKernelGGL((k_sa_fwd<__VA_ARGS__>), dim3(B), dim3(NTV), lds, (hipStream_t)stream, T, F, *settings, b_hat, c_hat, sigma, nrm_b0, nrm_c0, warm_x, warm_y, warm_s, x, y, s, iters, status, resid)

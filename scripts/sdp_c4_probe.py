@@ -26,7 +26,8 @@ A_eval, q_eval = tpl.values_from_dense(Ab, b, c)
 dev = torch.device("cuda", 0)
 eng = ConeEngine(tpl.indices, tpl.indptr, tpl.n, tpl.m, cones, dev)
 A_bm = torch.from_numpy(A_eval).to(dev).t().contiguous(); q_t = torch.from_numpy(q_eval).to(dev)
-st = make_settings(dict(eps=eps, max_iters=20000, acceleration_lookback=1))      # (the oracle below runs the same one-pair acceleration)
+aa = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+st = make_settings(dict(eps=eps, max_iters=20000, acceleration_lookback=aa))      # (the oracle below runs the same: one-pair acceleration or plain)
 eng.solve(A_bm, q_t, st); torch.cuda.synchronize()      # warm-up: rocBLAS / rocSOLVER initialisation, kernel loading
 t0 = time.perf_counter(); x, y, s, it, status, res = eng.solve(A_bm, q_t, st); torch.cuda.synchronize(); t1 = time.perf_counter()
 print("path", eng.last_path, getattr(eng, "last_const_a_kernel", None), "B", B, "eps", eps, "fwd %.1f ms  iters mean %.0f max %d  solved %.3f" % ((t1 - t0) * 1e3, it.float().mean().item(), int(it.max()), (status == 1).float().mean().item()))
@@ -35,7 +36,7 @@ eng.vjp(A_bm, x, y, s, dx, dy); torch.cuda.synchronize()
 t0 = time.perf_counter(); dA, dq, adj = eng.vjp(A_bm, x, y, s, dx, dy); torch.cuda.synchronize(); t1 = time.perf_counter()
 print("bwd %.1f ms, LSQR not converged for %d" % ((t1 - t0) * 1e3, int((adj != 0).sum())), "LSQR iterations mean", float(getattr(eng, "last_lsqr_iters", torch.zeros(1)).float().mean()))
 nb = min(B, 8)
-t0 = time.perf_counter(); ref = oracle.solve_batch(Ab[:nb], b[:nb], c[:nb], cones, eps=eps, max_iters=20000, acceleration_lookback=1); t1 = time.perf_counter()
+t0 = time.perf_counter(); ref = oracle.solve_batch(Ab[:nb], b[:nb], c[:nb], cones, eps=eps, max_iters=20000, acceleration_lookback=aa); t1 = time.perf_counter()
 print("oracle %d instances %.2f s (%d threads), iters %s" % (nb, t1 - t0, oracle.num_threads(), ref["iters"][:4]), "max |x - x_ref|", np.abs(x.cpu().numpy()[:nb] - ref["x"]).max())
 
 del eng
