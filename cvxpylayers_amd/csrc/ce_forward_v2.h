@@ -498,15 +498,21 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
                 if (jg < n) {
                     const double2 *src = reinterpret_cast<const double2 *>(Gm + jg * ldg + TG * cg);
 #pragma unroll
-                    for (int s2 = 0; s2 < TG / 2; s2++) { const double2 v = src[s2]; sreg[2 * s2] = v.x; sreg[2 * s2 + 1] = v.y; r[0] = fma(v.x, v.x, fma(v.y, v.y, r[0])); }
+                    for (int s2 = 0; s2 < TG / 2; s2++) { const double2 v = src[s2]; r[0] = fma(v.x, v.x, fma(v.y, v.y, r[0])); }
                 }
                 block_reduce_n<1, NW>(r, 0u, red);
-                const double xx = uniform_d(fabs(delta) * sqrt(r[0]));
-                int K = 0;
-                if (xx <= 1e-5) K = 2; else if (xx <= 1.5e-4) K = 3; else if (xx <= 1e-3) K = 4; else if (xx <= 1e-2) K = 7;      // x^(K+1) <= 1e-15
+                // x = |delta| |G|_F through its binary exponent (no fp64 literals: they would be hoisted into registers held across the iteration loop):
+                // x < 2^-17 -> K = 2, < 2^-13 -> 3, < 2^-10 -> 4, < 2^-7 -> 7   (x^(K+1) <= ~1e-15), else the full refactorisation
+                const int ex = __builtin_amdgcn_readfirstlane((__double2hiint(fabs(delta) * sqrt(r[0])) >> 20) & 0x7ff) - 1023;
+                const int K = ex < -17 ? 2 : (ex < -13 ? 3 : (ex < -10 ? 4 : (ex < -7 ? 7 : 0)));
                 if (K > 0) {
                     fast = true;
                     double greg[TG];
+                    if (jg < n) {
+                        const double2 *src = reinterpret_cast<const double2 *>(Gm + jg * ldg + TG * cg);
+#pragma unroll
+                        for (int s2 = 0; s2 < TG / 2; s2++) { const double2 v = src[s2]; sreg[2 * s2] = v.x; sreg[2 * s2 + 1] = v.y; }
+                    }
 #pragma unroll
                     for (int s = 0; s < TG; s++) greg[s] = sreg[s];
                     const int lane_base = (threadIdx.x & 63) & ~(CHG - 1);
@@ -514,6 +520,8 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
                         double zz[TG];
 #pragma unroll
                         for (int s = 0; s < TG; s++) zz[s] = 0.0;
+                        int goff = TG * cg;                       // LDS offset of G[kcol][TG cg], advanced row by row.  Opaque to the optimiser: the 56 row addresses are
+                        asm volatile("" : "+v"(goff));            // invariant across `it` and would otherwise be hoisted into 56 VGPRs (the G / Y segments then spill)
 #pragma unroll
                         for (int q = 0; q < CHG; q++) {
                             const int src_lane = (lane_base + q) << 2;
@@ -523,7 +531,8 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
                                 const int lo = __builtin_amdgcn_ds_bpermute(src_lane, __double2loint(sreg[s])), hi = __builtin_amdgcn_ds_bpermute(src_lane, __double2hiint(sreg[s]));
                                 const double yk = __hiloint2double(hi, lo);                      // Y_j[jg][kcol]
                                 if (kcol < n) {                                                   // uniform (rows of G beyond n do not exist)
-                                    const double2 *gr = reinterpret_cast<const double2 *>(Gm + kcol * ldg + TG * cg);
+                                    const double2 *gr = reinterpret_cast<const double2 *>(Gm + goff);
+                                    goff += ldg;
 #pragma unroll
                                     for (int s2 = 0; s2 < TG / 2; s2++) { const double2 v = gr[s2]; zz[2 * s2] = fma(yk, v.x, zz[2 * s2]); zz[2 * s2 + 1] = fma(yk, v.y, zz[2 * s2 + 1]); }
                                 }
