@@ -548,3 +548,24 @@ def test_anderson_acceleration_in_the_shared_A_kernel_matches_the_oracle(cfg):
             assert not np.array_equal(ref["iters"], plain["iters"]) or eps > 1e-5
     finally:
         os.environ.pop("CE_CONST_A", None)
+
+
+def test_rescale_by_neumann_series_gives_the_iterates_of_a_refactorisation(monkeypatch):
+    """k_fwd2 updates G = (rho I + A^T Dy A)^-1 by a Neumann series when the adaptive scale changes (ce_forward_v2.h, refactor()): same solutions and the
+    SAME iteration counts as the build that refactors (CE_F2_NEUMANN=0), on long runs where every instance rescales (LPs: hundreds to thousands of iterations)."""
+    from cvxpylayers_amd.interfaces.mi355_if import ConeEngine, make_settings
+    n, cones, B = 30, {"z": 2, "l": 40, "q": [6, 5]}, 48
+    tpl = P.dense_template(n, cones)
+    A, b, c = P.generate(n, cones, B, seed=5)
+    A_eval, q_eval = tpl.values_from_dense(A, b, c)
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("CE_F2_NEUMANN", flag)            # read at ce_create
+        eng = ConeEngine(tpl.indices, tpl.indptr, tpl.n, tpl.m, tpl.cones, torch.device("cuda", 0))
+        A_bm = eng.to_batch_major(torch.from_numpy(A_eval).cuda())
+        x, y, s, iters, status, resid = eng.solve(A_bm, torch.from_numpy(q_eval).cuda(), make_settings(dict(eps=1e-9, max_iters=100000, acceleration_lookback=0)))
+        out[flag] = (x.cpu().numpy(), iters.cpu().numpy(), status.cpu().numpy())
+    assert (out["1"][2] == 1).all() and (out["0"][2] == 1).all()
+    assert out["1"][1].max() > 150                                             # past RESCALING_MIN_ITERS: rescales happened
+    assert np.array_equal(out["1"][1], out["0"][1]), (out["1"][1], out["0"][1])
+    assert np.abs(out["1"][0] - out["0"][0]).max() < 1e-9
