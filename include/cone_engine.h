@@ -203,7 +203,8 @@ int ce_ca_psd(ce_handle h, int B, int lp, double *U, const int *active, void *st
 /* The same projection on the matrix cores (v_mfma_f64_16x16x4_f64), warm-started from the eigenvectors of the previous call: Vstate
  * (B, ns, maxs * maxs; row-major k x k per block) is caller-owned state, warm = 0: no previous call.  Warm calls REFINE the previous
  * decomposition (R = I - V^T V, D = V^T S V, first-order correction V <- V + V E, quadratically convergent, orthogonality self-correcting:
- * no periodic restart needed) and fall back to Jacobi sweeps when a correction would exceed 1/2 for some pair.  PSD orders <= 39. */
+ * no periodic restart needed) and fall back to Jacobi sweeps when a correction would leave the basin of the first-order step.  warm: 0 cold, 1 warm;
+ * bit 1 (warm = 3) is a debugging switch: warm-started Jacobi sweeps only, no refinement (scripts/psd_refine_debug.py).  PSD orders <= 39. */
 int ce_ca_psd_mfma(ce_handle h, int B, int lp, double *U, double *Vstate, int warm, const int *active, void *stream);
 /* Exponential / power cone triples of the cone input U (B, lp) projected in place (after ce_ca_step, like ce_ca_psd); roots
  * (B, nep + np) is caller-owned state: each cone's root of the previous iteration (zero-initialised). */
