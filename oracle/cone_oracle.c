@@ -16,11 +16,14 @@
  *   backward: Agrawal et al., "Differentiating through a cone program" (diffcp):
  *             z=(x, y-s, 1), M = (Q-I) DPi(z) + I, solve M^T r = dz (LSQR, or dense elimination),
  *             dA = r_y x^T - y r_x^T (antisymmetrised outer products), db, dc.
- * PARITY PIN: there are no golden vectors for this path in the reference and the
- * reference cannot be executed in this image, so SCS/diffcp ITERATE parity is UNPINNED.  What is
- * pinned (tests/test_oracle_known_answers.py): every closed-form known-answer problem the
- * reference's own tests assert (ridge LS, min-norm equality, box QP/ReLU, LP vertex, SOC, SDP,
- * infeasible/unbounded status) and central finite differences of the forward solve.
+ * PARITY PIN (round 3): the oracle IS pinned on outputs of the real cvxpylayers -> diffcp -> SCS stack: the numbers stored in the cell outputs of the
+ * reference's example notebooks (/root/reference/examples/torch/{optimal_transport, lqr, tutorial, supply_chain}.ipynb), parsed into
+ * tests/golden/ref_notebook_*.npz by tests/golden/make_notebook_golden.py and reproduced in tests/test_notebook_golden.py: forward values of an
+ * exponential-cone layer and diffcp's gradients through it (to the printed 4 decimals), an SDP solved by SCS (to SCS's own 6e-6), a least-squares
+ * layer, and eight epochs of a training trace whose every point depends on the adjoints of 100 solves (to the printed 5 digits).  Also pinned
+ * (tests/test_oracle_known_answers.py, tests/test_independent_checks.py): every closed-form known-answer problem the reference's own tests assert,
+ * central finite differences of the forward solve, scipy's HiGHS on LPs, conic optimality certificates.  NOT pinned: SCS's iterate sequence
+ * (iteration counts are this restatement's; no reference output records them) -- e.g. the one-pair Anderson acceleration and its give-up rule.
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this file.
  *
