@@ -73,15 +73,25 @@ __device__ __forceinline__ void sqrt_rsqrt(double q, double &s, double &rinv) {
 }
 
 // blocked register tile . LDS vector (vec already offset to the lane's segment, 16-byte aligned)
+#ifndef F2_SEG_PARTS
+#define F2_SEG_PARTS 1
+#endif
 template <int CH, int TT>
 __device__ __forceinline__ double seg_dot(const double (&tile)[TT], const double *vec) {
     const double2 *v2 = reinterpret_cast<const double2 *>(vec);
     double a0 = 0, a1 = 0;       // (four chains were tried: the two extra accumulators push the iteration loop into scratch spills)
+    // Long segments go in F2_SEG_PARTS fenced parts: the machine scheduler keeps only 1-4 of the 13 reads of a 26-term product in flight (it
+    // serialised the A p_x phase completely: ten LDS round trips), with a fence every part's reads are issued together: one round trip per part.
+    constexpr int NB = TT / 2, PARTS = NB > 8 ? F2_SEG_PARTS : 1, H = (NB + PARTS - 1) / PARTS;
 #pragma unroll
-    for (int k = 0; k < TT / 2; k++) {
-        const double2 v = v2[k];
-        a0 = fma(tile[2 * k], v.x, a0);
-        a1 = fma(tile[2 * k + 1], v.y, a1);
+    for (int p = 0; p < PARTS; p++) {
+#pragma unroll
+        for (int k = p * H; k < (p + 1) * H && k < NB; k++) {
+            const double2 v = v2[k];
+            a0 = fma(tile[2 * k], v.x, a0);
+            a1 = fma(tile[2 * k + 1], v.y, a1);
+        }
+        if (p + 1 < PARTS) __builtin_amdgcn_sched_barrier(0);
     }
     return group_reduce<CH, false>(a0 + a1);
 }
@@ -90,8 +100,18 @@ template <int CH, int TT>
 __device__ __forceinline__ double seg_dot_lds(const double *row, const double *vec) {
     const double2 *r2 = reinterpret_cast<const double2 *>(row), *v2 = reinterpret_cast<const double2 *>(vec);
     double a0 = 0, a1 = 0;
+    // two halves with a scheduling fence between them: left alone, the machine scheduler issues eight reads and then serialises the rest in pairs
+    // (each pair a full LDS round trip); fenced, the second half's reads go out together once the first half's registers are free
+    constexpr int H = (TT / 2 + 1) / 2;
 #pragma unroll
-    for (int k = 0; k < TT / 2; k++) {
+    for (int k = 0; k < H; k++) {
+        const double2 r = r2[k], v = v2[k];
+        a0 = fma(r.x, v.x, a0);
+        a1 = fma(r.y, v.y, a1);
+    }
+    if constexpr (TT / 2 > 4) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = H; k < TT / 2; k++) {
         const double2 r = r2[k], v = v2[k];
         a0 = fma(r.x, v.x, a0);
         a1 = fma(r.y, v.y, a1);
@@ -916,18 +936,23 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
         __syncthreads();
         if constexpr (WL) {
             // P2 + P3 fused: q = A p_x ; tau-tilde ; u-tilde ; cone projection ; relaxed update.  The cone blocks of y are wave-local.
-            const double tau_t = (rtau * sm[L::O_WP + 2] + sm[L::O_WP] + sm[L::O_WP + 1]) * inv_den;
-            const double q = seg_dot<CHA, T2>(ar, sm + L::O_PX + T2 * c2);
-            const bool upd = !check && !last;          // fast path: the relaxed update happens here (else after the convergence check)
+            // Latency is what this phase costs (three workgroups per CU hide some of it, not all): every LDS round trip that can be issued early is.
+            // (1) operands that do not depend on this phase's product are requested BEFORE it and arrive while it runs;
+            // (2) the product's own 13-read stream comes next, fenced, so that the scheduler pipelines it (left alone it serialised the reads: ten round trips);
+            // (3) the cone's entries are fetched with one unrolled batch of reads (cones of <= 13 rows) instead of a loop of dependent four-packs.
             const int ee = OY + i2;
-            double we = 0, ute = 0, ze = 0;
-            int cd = 0;
+            const bool upd = !check && !last;          // fast path: the relaxed update happens here (else after the convergence check)
+            double we = 0, gve = 0;
+            int cd = 0, soc_r0 = 0;
+            if (own2) { we = sm[L::O_W + ee]; gve = sm[L::O_GV + ee]; cd = socd[i2]; soc_r0 = socr[i2]; }      // cd 0: zero-cone row (dual free), 1: nonnegative row, > 1: row of an SOC
+            const double q = seg_dot<CHA, T2>(ar, sm + L::O_PX + T2 * c2);
+            __builtin_amdgcn_sched_barrier(0);
+            const double tau_t = (rtau * sm[L::O_WP + 2] + sm[L::O_WP] + sm[L::O_WP + 1]) * inv_den;
+            double ute = 0, ze = 0;
             if (own2) {
-                we = sm[L::O_W + ee];
                 const double py = we + dyv(i2) * q;
-                ute = py - tau_t * sm[L::O_GV + ee];
+                ute = py - tau_t * gve;
                 ze = 2 * ute - we;
-                cd = socd[i2];                          // 0: zero-cone row (dual free), 1: nonnegative row, > 1: row of an SOC
                 if (cd == 1 && ze < 0) ze = 0;
                 sm[L::O_UT + ee] = ute; sm[L::O_ZB + ee] = ze;
             }
@@ -935,13 +960,23 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
             if (own2) {
                 double ue = ze;
                 if (cd > 1) {
-                    const int soc_r0 = socr[i2];
                     const double *zc = sm + L::O_ZB + OY + soc_r0;
                     const double t0 = zc[0];
                     double q0 = 0, q1 = 0;
-                    for (int k = 1; k < cd; k += 4) {
-                        const double z0 = zc[k], z1 = (k + 1 < cd) ? zc[k + 1] : 0.0, z2 = (k + 2 < cd) ? zc[k + 2] : 0.0, z3 = (k + 3 < cd) ? zc[k + 3] : 0.0;
-                        q0 = fma(z0, z0, q0); q1 = fma(z1, z1, q1); q0 = fma(z2, z2, q0); q1 = fma(z3, z3, q1);
+                    if (cd <= 13) {      // (the reads past the cone stay inside the vector -- its pads included -- and are masked)
+                        double zv[12];
+#pragma unroll
+                        for (int u = 0; u < 12; u++) zv[u] = zc[1 + u];
+#pragma unroll
+                        for (int u = 0; u < 12; u += 2) {
+                            const double z0 = (1 + u < cd) ? zv[u] : 0.0, z1 = (2 + u < cd) ? zv[u + 1] : 0.0;
+                            q0 = fma(z0, z0, q0); q1 = fma(z1, z1, q1);
+                        }
+                    } else {
+                        for (int k = 1; k < cd; k += 4) {
+                            const double z0 = zc[k], z1 = (k + 1 < cd) ? zc[k + 1] : 0.0, z2 = (k + 2 < cd) ? zc[k + 2] : 0.0, z3 = (k + 3 < cd) ? zc[k + 3] : 0.0;
+                            q0 = fma(z0, z0, q0); q1 = fma(z1, z1, q1); q0 = fma(z2, z2, q0); q1 = fma(z3, z3, q1);
+                        }
                     }
                     const double qq = q0 + q1;
                     double nz = 0, rinv = 0;
