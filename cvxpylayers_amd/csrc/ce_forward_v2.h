@@ -405,25 +405,41 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
                 const int r0 = socr[i2], d = abs(socd[i2]);
                 if (d > 1) {   // block-average inside the SOC / PSD block so the scaled cone is still the cone
                     float s0 = 0, s1 = 0;
-                    int i = 0;
-                    for (; i + 1 < d; i += 2) { s0 += fRn[r0 + i]; s1 += fRn[r0 + i + 1]; }
-                    if (i < d) s0 += fRn[r0 + i];
+                    if (d <= 12) {   // one batch of reads, masked (a loop of dependent pairs costs d / 2 LDS round trips per pass; the reads past the block stay inside the vector)
+                        float v[12];
+#pragma unroll
+                        for (int u = 0; u < 12; u++) v[u] = fRn[r0 + u];
+#pragma unroll
+                        for (int u = 0; u < 12; u += 2) { s0 += (u < d) ? v[u] : 0.0f; s1 += (u + 1 < d) ? v[u + 1] : 0.0f; }
+                    } else {
+                        int i = 0;
+                        for (; i + 1 < d; i += 2) { s0 += fRn[r0 + i]; s1 += fRn[r0 + i + 1]; }
+                        if (i < d) s0 += fRn[r0 + i];
+                    }
                     a = (s0 + s1) * __builtin_amdgcn_rcpf((float)d);
                 }
                 fDt[i2] = __builtin_amdgcn_rsqf(clampf(a));
             }
             __syncthreads();
             {
+                // every scaling factor of this pass is requested in ONE batch (the FP32 tiles leave the registers for it); multiplying as the values
+                // arrive -- what the scheduler made of the plain loops -- kept two reads in flight: ~10 LDS round trips per pass instead of ~2
                 const float ej = fEt[j1 < NP ? j1 : 0];            // pad entries are 0
-                const f2v ej2 = {ej, ej};
-                const f2v *d2 = reinterpret_cast<const f2v *>(fDt + T1 * c1);
-#pragma unroll
-                for (int k = 0; k < T1 / 2; k++) atv[k] *= d2[k] * ej2;
                 const float di = fDt[i2 < MP ? i2 : 0];
-                const f2v di2 = {di, di};
+                const f2v *d2 = reinterpret_cast<const f2v *>(fDt + T1 * c1);
                 const f2v *e2 = reinterpret_cast<const f2v *>(fEt + T2 * c2);
+                f2v dd[T1 / 2], ee[T2 / 2];
 #pragma unroll
-                for (int k = 0; k < T2 / 2; k++) arv[k] *= e2[k] * di2;
+                for (int k = 0; k < T1 / 2; k++) dd[k] = d2[k];
+#pragma unroll
+                for (int k = 0; k < T2 / 2; k++) ee[k] = e2[k];
+                __builtin_amdgcn_sched_barrier(0);
+                const f2v ej2 = {ej, ej};
+                const f2v di2 = {di, di};
+#pragma unroll
+                for (int k = 0; k < T1 / 2; k++) atv[k] *= dd[k] * ej2;
+#pragma unroll
+                for (int k = 0; k < T2 / 2; k++) arv[k] *= ee[k] * di2;
                 if constexpr (HASP) {
                     const Co cop(wave);
                     const float eg = fEt[cop.jg < NP ? cop.jg : 0];
