@@ -14,6 +14,9 @@
 //     blocking (rows {ra+16i} x columns {cb+16j}: TI + TJ LDS reads feed TI*TJ FMAs per cone row).
 #pragma once
 
+// v_max_f64 without the canonicalisation fmax() puts in front of it (operands are finite by construction)
+__device__ __forceinline__ double vmax_raw(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
 constexpr int BG = 16;   // default thread grid is BG x BG
 constexpr int BGC = 16;  // column residues (always one DPP row wide)
 
@@ -58,7 +61,7 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
     double *fvec = p; p += n;        // sum over boundary cones of [ a_s (e_s.d) + A_c^T P d / (1 - lam) ]
     double *cinfo = p; p += 6 * nqs; // per cone: lambda, nz, e_y.d, e_s.d
     double *pivrow = p; p += BGR * TI;   // pivot value of the row that served as pivot
-    double *pinfo = p; p += 2;          // pivot value per buffer
+    double *pinfo = p + ((p - sm) & 1); p = pinfo + 4;      // per buffer one 16-byte record {pivot value, pivot row}: ONE ds_read_b128 after the pivot's barrier
     double *red = p; p += NWB * 8;
     double *psdU = p, *psdEv = p, *lamr = p, *psdScr = p, *expW = p;     // PSD: eigenvectors per cone, eigenvalues, DPi eigenvalue per rotated row, scratch
     if constexpr (PSD) { psdU = p; p += T.ns * T.maxs * T.maxs; psdEv = p; p += T.ns * T.maxs; lamr = p; p += m; psdScr = p; p += 2 * NWB * T.maxs * T.maxs + 2 * T.maxs + 8;   /* one (X, W) pair per wave */ expW = p; p += 9 * (T.nep + T.np); }
@@ -409,7 +412,9 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
             double *cbuf = colbuf + buf * BGR * TI;
             if (cb == ck) {   // the 16 lanes owning column k: pivot search + publish the column
                 // arg max |K[r][k]| over the rows not yet used, as ONE v_max_f64 per candidate: positive doubles order like their
-                // bit patterns, so the row index rides in the 8 lowest mantissa bits (255 - r: ties go to the smallest row)
+                // bit patterns, so the row index rides in the 8 lowest mantissa bits (255 - r: ties go to the smallest row).
+                // Branch-free (a used row contributes the key 0) and with the bare instruction: fmax() canonicalises both operands first
+                // (two more v_max_f64 per step of a chain every other wave is waiting for).
                 double best = 0.0;       // key 0: no candidate
 #pragma unroll
                 for (int i = 0; i < TI; i++) {
@@ -417,27 +422,40 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
                     const double v = fabs(kt[i][jk]);
                     const int lo = (__double2loint(v) & ~0xFF) | (255 - r);
                     const double key = __hiloint2double(__double2hiint(v), lo);
-                    if (r < NK && !((rowdone >> i) & 1u)) best = fmax(best, key);
+                    best = vmax_raw(best, (r < NK && !((rowdone >> i) & 1u)) ? key : 0.0);
                 }
-                best = fmax(best, dpp_mov<0xB1>(best));     // quad_perm [1,0,3,2]
-                best = fmax(best, dpp_mov<0x4E>(best));     // quad_perm [2,3,0,1]
-                best = fmax(best, dpp_mov<0x141>(best));    // row_half_mirror
-                best = fmax(best, dpp_mov<0x140>(best));    // row_mirror
-                if constexpr (BGR == 32) best = fmax(best, __shfl_xor(best, 16));      // the column's owners span two DPP rows
+                best = vmax_raw(best, dpp_mov<0xB1>(best));     // quad_perm [1,0,3,2]
+                best = vmax_raw(best, dpp_mov<0x4E>(best));     // quad_perm [2,3,0,1]
+                best = vmax_raw(best, dpp_mov<0x141>(best));    // row_half_mirror
+                best = vmax_raw(best, dpp_mov<0x140>(best));    // row_mirror
+                if constexpr (BGR == 32) best = vmax_raw(best, __shfl_xor(best, 16));      // the column's owners span two DPP rows
                 const int bi = 255 - (__double2loint(best) & 0xFF);
-                const bool tiny = best < ptol;               // no acceptable pivot in this column (best == 0: no candidate row left, bi is meaningless)
+                const bool tiny = best < ptol;               // no acceptable pivot in this column (best == 0: no candidate row left, bi = 255 is no row)
+                double pv = 0.0;
 #pragma unroll
                 for (int i = 0; i < TI; i++) {
                     const int r = ra + BGR * i;
                     const double v = kt[i][jk];
-                    if (r == bi) { pinfo[buf] = tiny ? 0.0 : v; cbuf[r] = 0.0; } else cbuf[r] = v;
+                    const bool isp = r == bi;
+                    cbuf[r] = isp ? 0.0 : v;                 // (the pivot row's own entry is published as 0)
+                    pv = isp ? v : pv;
                 }
-                if (ra == 0) { misc[4 + buf] = bi; if (tiny) { misc[2] |= 4; pinfo[buf] = 0.0; } }
+                if (ra == (bi & (BGR - 1))) {                // the lane that holds row bi (bi = 255: some lane, value 0)
+                    pinfo[2 * buf] = tiny ? 0.0 : pv;
+                    reinterpret_cast<int *>(pinfo + 2 * buf + 1)[0] = bi;
+                }
+                if (ra == 0 && tiny) misc[2] |= 4;
             }
             __syncthreads();
-            const int prow = __builtin_amdgcn_readfirstlane(misc[4 + buf]);
+            // the record and this thread's multipliers are requested together (the multipliers do not depend on the record): one LDS round trip
+            // where the pivot row, then the pivot value, then the multipliers used to be three
+            const double2 rec = *reinterpret_cast<const double2 *>(pinfo + 2 * buf);
+            double cv[TI];
+#pragma unroll
+            for (int i = 0; i < TI; i++) cv[i] = cbuf[ra + BGR * i];
+            const int prow = __builtin_amdgcn_readfirstlane(__double2loint(rec.y));
             const int ipv = prow / BGR;
-            const double piv = pinfo[buf];
+            const double piv = rec.x;
             if (__builtin_amdgcn_readfirstlane(fabs(piv) < ptol ? 1 : 0)) continue;      // free variable (see above), no row is consumed.  readfirstlane: the value is the same in
                                                                                           // every lane, but only a scalar condition lets the compiler keep the loop body free of exec masking
             double pinv = __builtin_amdgcn_rcp(piv);           // hardware seed + two Newton steps (the IEEE divide expansion is
@@ -465,7 +483,7 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
 #pragma unroll
             for (int i = 0; i < TI; i++) {
                 if (i >= ilim) continue;     // uniform: pad row slots
-                const double f = cbuf[ra + BGR * i] * pinv;      // the pivot row's own entry was published as 0
+                const double f = cv[i] * pinv;      // the pivot row's own entry was published as 0
 #pragma unroll
                 for (int j = jk; j < TJ; j++) kt[i][j] = fma(-f, rw[j], kt[i][j]);
             }

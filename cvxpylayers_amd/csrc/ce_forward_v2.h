@@ -360,6 +360,10 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
         float *const fRn = reinterpret_cast<float *>(sm + L::O_ZB + OY);
         auto clampf = [](float v) -> float { return v < (float)MIN_SCALE ? 1.0f : (v > (float)MAX_SCALE ? (float)MAX_SCALE : v); };
         double Eacc = 1.0, Dacc = 1.0;        // accumulated scalings of this thread's column / row (owners write them once, after the passes)
+        // The column-layout tile belongs to ONE column and the row-layout tile to ONE row: their own factor is the same for all 26 entries, so it is
+        // kept as a scalar (ecum, dcum) that multiplies the tile's norm instead of being multiplied into every entry in every pass (half the v_pk_mul_f32)
+        float ecum = 1.0f, dcum = 1.0f;
+        const int blk_r0 = own2 ? socr[i2] : 0, blk_d = own2 ? abs(socd[i2]) : 0;      // this row's cone block (read once: two LDS round trips less per pass)
         for (int pass = 0; pass < NUM_RUIZ_PASSES + NUM_L2_PASSES; pass++) {
             const bool l2 = pass >= NUM_RUIZ_PASSES;
             float *const fEt = (pass & 1) ? fEt1 : fEt0;                  // column scaling of this pass (x-indexed)
@@ -370,14 +374,14 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
                 for (int k = 0; k < T1 / 2; k++) { cn = fmaf(atv[k].x, atv[k].x, cn); cn = fmaf(atv[k].y, atv[k].y, cn); }
 #pragma unroll
                 for (int k = 0; k < T2 / 2; k++) { rn = fmaf(arv[k].x, arv[k].x, rn); rn = fmaf(arv[k].y, arv[k].y, rn); }
-                cn = sqrtf(group_reduce_f<CHT, false>(cn)); rn = sqrtf(group_reduce_f<CHA, false>(rn));
+                cn = ecum * sqrtf(group_reduce_f<CHT, false>(cn)); rn = dcum * sqrtf(group_reduce_f<CHA, false>(rn));
             } else {
                 float c0 = 0, c1_ = 0, r0 = 0, r1 = 0;
 #pragma unroll
                 for (int k = 0; k < T1 / 2; k += 2) { c0 = fmaxf(fmaxf(c0, fabsf(atv[k].x)), fabsf(atv[k].y)); if (k + 1 < T1 / 2) c1_ = fmaxf(fmaxf(c1_, fabsf(atv[k + 1].x)), fabsf(atv[k + 1].y)); }
 #pragma unroll
                 for (int k = 0; k < T2 / 2; k += 2) { r0 = fmaxf(fmaxf(r0, fabsf(arv[k].x)), fabsf(arv[k].y)); if (k + 1 < T2 / 2) r1 = fmaxf(fmaxf(r1, fabsf(arv[k + 1].x)), fabsf(arv[k + 1].y)); }
-                cn = group_reduce_f<CHT, true>(fmaxf(c0, c1_)); rn = group_reduce_f<CHA, true>(fmaxf(r0, r1));
+                cn = ecum * group_reduce_f<CHT, true>(fmaxf(c0, c1_)); rn = dcum * group_reduce_f<CHA, true>(fmaxf(r0, r1));
             }
             if constexpr (HASP) {      // columns of [P-hat; A-hat]: the column norm of A-hat is combined with that of P-hat after the barrier
                 const Co cop(wave);
@@ -402,7 +406,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
             }
             if (own2) {
                 float a = rn;
-                const int r0 = socr[i2], d = abs(socd[i2]);
+                const int r0 = blk_r0, d = blk_d;
                 if (d > 1) {   // block-average inside the SOC / PSD block so the scaled cone is still the cone
                     float s0 = 0, s1 = 0;
                     if (d <= 12) {   // one batch of reads, masked (a loop of dependent pairs costs d / 2 LDS round trips per pass; the reads past the block stay inside the vector)
@@ -434,12 +438,11 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
 #pragma unroll
                 for (int k = 0; k < T2 / 2; k++) ee[k] = e2[k];
                 __builtin_amdgcn_sched_barrier(0);
-                const f2v ej2 = {ej, ej};
-                const f2v di2 = {di, di};
 #pragma unroll
-                for (int k = 0; k < T1 / 2; k++) atv[k] *= dd[k] * ej2;
+                for (int k = 0; k < T1 / 2; k++) atv[k] *= dd[k];
 #pragma unroll
-                for (int k = 0; k < T2 / 2; k++) arv[k] *= ee[k] * di2;
+                for (int k = 0; k < T2 / 2; k++) arv[k] *= ee[k];
+                ecum *= ej; dcum *= di;
                 if constexpr (HASP) {
                     const Co cop(wave);
                     const float eg = fEt[cop.jg < NP ? cop.jg : 0];

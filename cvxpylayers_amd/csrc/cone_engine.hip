@@ -146,7 +146,7 @@ constexpr int BRT_NV = 4;
 static const int BRT_VARIANTS[BRT_NV][4] = {{4, 4, 4, 16}, {7, 7, 4, 16}, {7, 7, 7, 16}, {7, 13, 7, 32}};
 static size_t bwd_rt_lds_bytes(const DevT &T, int TI, int TJ, int BGR) {
     const int n = T.n, m = T.m, nqs = std::max(T.nq, 1);
-    size_t d = (size_t)m * n /* lda = n */ + 3 * (size_t)m + 2 * (size_t)n + 6 * nqs + BGR * TI + 2 + (BGR * 16 / 64) * 8 + bwd_rt_union_doubles(n, m, nqs, TI, TJ, BGR);
+    size_t d = (size_t)m * n /* lda = n */ + 3 * (size_t)m + 2 * (size_t)n + 6 * nqs + BGR * TI + 5 /* pinfo: two 16-byte records + alignment */ + (BGR * 16 / 64) * 8 + bwd_rt_union_doubles(n, m, nqs, TI, TJ, BGR);
     if (T.ns > 0 || T.nep + T.np > 0) d += (size_t)T.ns * T.maxs * T.maxs + (size_t)T.ns * T.maxs + m + 2 * (size_t)(BGR * 16 / 64) * T.maxs * T.maxs + 2 * T.maxs + 8 + 9 * (size_t)(T.nep + T.np);
     size_t ints = 2 * (size_t)m + 2 * nqs + BGC * TJ + BGR * TI + (BGR * 16 / 64) + 1 + 8;
     return d * 8 + ints * 4 + 16;
