@@ -292,14 +292,17 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
         if (ckind[c] != 2) continue;                       // uniform
         const double lam = cinfo[6 * c], th = lam / (1 - lam);
         const int r0 = T.qoff[c], r1 = T.qoff[c + 1];
-#pragma unroll 2
+#pragma unroll 4
         for (int ii = r0; ii < r1; ii++) {
             const double *row = A + ii * lda;
             double ar[TH], ac[TH];
+            // unguarded reads (a guarded read is a branch per entry, a select two more VALU operations per value): an index past the row's n entries stays
+            // inside the LDS carve (the following row, or the vectors behind the last one), and the tile entries it pollutes -- row or column index
+            // >= n -- are reset after the accumulation
 #pragma unroll
-            for (int i = 0; i < TH; i++) ar[i] = (ra + BGR * i < n) ? th * row[ra + BGR * i] : 0.0;
+            for (int i = 0; i < TH; i++) ar[i] = th * row[ra + BGR * i];
 #pragma unroll
-            for (int j = 0; j < TH; j++) ac[j] = (cb + BGC * j < n) ? row[cb + BGC * j] : 0.0;
+            for (int j = 0; j < TH; j++) ac[j] = row[cb + BGC * j];
 #pragma unroll
             for (int i = 0; i < TH; i++)
 #pragma unroll
@@ -314,6 +317,10 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
                 if (r < n && cc < n) kt[i][j] = fma(-th, ayc[r] * ayc[cc] + asc[r] * asc[cc], kt[i][j]);
             }
     }
+#pragma unroll
+    for (int i = 0; i < TH; i++)
+#pragma unroll
+        for (int j = 0; j < TH; j++) if (ra + BGR * i >= n || cb + BGC * j >= n) kt[i][j] = 0.0;
     if constexpr (PSD) {   // weighted rows of rotated PSD blocks: H += theta_t a_t^T a_t
         for (int t = T.soff[0]; t < T.eoff + 3 * (T.nep + T.np); t++) {
             if (rkind[t] != RK_MIX) continue;              // uniform
