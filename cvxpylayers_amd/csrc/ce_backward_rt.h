@@ -249,11 +249,18 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
         if (ckind[c] != 2) continue;
         const int r0 = T.qoff[c], r1 = T.qoff[c + 1];
         const double inz = 1.0 / cinfo[6 * c + 1];
-        double a = 0;
-        for (int i = r0 + 1; i < r1; i++) a = fma(A[i * lda + j], vv[i], a);
-        a *= inz;
-        ay[idx] = (A[r0 * lda + j] + a) * M_SQRT1_2;
-        as[idx] = (A[r0 * lda + j] - a) * M_SQRT1_2;
+        double a = 0, a1 = 0;
+        const double a00 = A[r0 * lda + j];
+        for (int i = r0 + 1; i < r1; i += 4) {       // four rows per step, reads requested together (index clamped, contribution masked): a dependent loop costs one LDS round trip per row
+            double av[4], wv[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int iu = min(i + u, r1 - 1); av[u] = A[iu * lda + j]; wv[u] = vv[iu]; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const double w = (i + u < r1) ? wv[u] : 0.0; if (u & 1) a1 = fma(av[u], w, a1); else a = fma(av[u], w, a); }
+        }
+        a = (a + a1) * inz;
+        ay[idx] = (a00 + a) * M_SQRT1_2;
+        as[idx] = (a00 - a) * M_SQRT1_2;
     }
     __syncthreads();
     // ---- fvec[j] = sum_c [ a_s (e_s.d) + (A_c^T d - a_y (e_y.d) - a_s (e_s.d)) / (1 - lam) ]
@@ -266,10 +273,18 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
                 if (ckind[c] != 2) continue;
                 const int r0 = T.qoff[c], r1 = T.qoff[c + 1];
                 const double lam = cinfo[6 * c], eyd = cinfo[6 * c + 2], esd = cinfo[6 * c + 3];
-                double g = 0;
-                for (int i = r0; i < r1; i++) g = fma(A[i * lda + j], dv[i], g);
-                const double a = g - ay[c * n + j] * eyd - as[c * n + j] * esd;      // A_c^T P d
-                acc += as[c * n + j] * esd + a / (1 - lam);
+                double g = 0, g1 = 0;
+                const double ayj = ay[c * n + j], asj = as[c * n + j];
+                for (int i = r0; i < r1; i += 4) {
+                    double av[4], wv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) { const int iu = min(i + u, r1 - 1); av[u] = A[iu * lda + j]; wv[u] = dv[iu]; }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) { const double w = (i + u < r1) ? wv[u] : 0.0; if (u & 1) g1 = fma(av[u], w, g1); else g = fma(av[u], w, g); }
+                }
+                g += g1;
+                const double a = g - ayj * eyd - asj * esd;      // A_c^T P d
+                acc += asj * esd + a / (1 - lam);
             }
             if constexpr (PSD) {
                 for (int t = T.soff[0] + part; t < T.eoff + 3 * (T.nep + T.np); t += 4)
@@ -580,17 +595,24 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
     }
     CE_STAMP(6);
     // ---- outputs in the boundary convention: dA_eval = [-dA.data, db[b_idx]], dq_eval = [dc, 0]   (diffcp_if.py:91-92)
-#pragma unroll 4
+    // x and y are staged in LDS (fvec and dv are dead): the gathers of the entry loop then are LDS reads behind ONE level of global loads (the
+    // template's index pair), eight entries in flight per lane
+    double *const xs = fvec, *const ys = dv;
+    for (int j = tid; j < n; j += NTB) xs[j] = xg[(size_t)inst * n + j];
+    for (int i = tid; i < m; i += NTB) ys[i] = yg[(size_t)inst * m + i];
+    __syncthreads();
+#pragma unroll 8
     for (int k = tid; k < T.nnz_aug; k += NTB) {
         const int i = T.rowidx[k], j = T.colidx[k];
-        const double val = (j < n) ? -(xg[(size_t)inst * n + j] * vv[i] - yg[(size_t)inst * m + i] * rx[j]) : -vv[i];   // x, y: L1-resident gathers
+        const int jc = j < n ? j : 0;
+        const double val = (j < n) ? -(xs[jc] * vv[i] - ys[i] * rx[jc]) : -vv[i];
         dAo[(size_t)inst * T.nnz_aug + k] = val;
     }
     for (int j = tid; j <= n; j += NTB) dqo[j * sdqk + inst * sdqb] = (j < n) ? -rx[j] : 0.0;
     if (dPo) {
         for (int k = tid; k < nnzP; k += NTB) {
             const int i = prow[k], j = pcol[k];
-            const double v = -0.5 * (rx[i] * xg[(size_t)inst * n + j] + rx[j] * xg[(size_t)inst * n + i]);
+            const double v = -0.5 * (rx[i] * xs[j] + rx[j] * xs[i]);
             dPo[(size_t)inst * nnzP + k] = (p_tri && i != j) ? 2.0 * v : v;
         }
     }

@@ -108,16 +108,37 @@ __device__ __forceinline__ double clamp_scale(double v) { return v < MIN_SCALE ?
 
 // scatter one instance's boundary values (batch-major row of [A_cvx | b_cvx] values) into dense solver form
 __device__ __forceinline__ void load_instance(const DevT &T, const double *vals, double *A, double *bv) {
-    const int n = T.n, m = T.m, lda = T.lda;
+    const int n = T.n, m = T.m, lda = T.lda, nnz = T.nnz_aug;
+    // The first chunk of (value, row, column) triples is requested BEFORE the zero fill and its barrier, and every chunk keeps 3 x LU loads per lane
+    // in flight: with one workgroup per instance this phase is a chain of HBM latencies (5 chunks of 4 used to cost ~24 k cycles at the metric shape).
+    constexpr int LU = 8;
+    double v0[LU]; int r0[LU], c0[LU];
+#pragma unroll
+    for (int u = 0; u < LU; u++) {
+        const int k = threadIdx.x + u * NT, kc = k < nnz ? k : 0;
+        v0[u] = vals[kc]; r0[u] = T.rowidx[kc]; c0[u] = k < nnz ? T.colidx[kc] : -1;      // c = -1: no entry
+    }
     for (int i = threadIdx.x; i < m * lda; i += NT) A[i] = 0.0;
     for (int i = threadIdx.x; i < m; i += NT) bv[i] = 0.0;
     __syncthreads();
-#pragma unroll 4
-    for (int k = threadIdx.x; k < T.nnz_aug; k += NT) {
-        const double val = vals[k];
-        const int r = T.rowidx[k], c = T.colidx[k];
-        if (c < n) A[r * lda + c] = -val;      // solver sees A = -A_cvx (diffcp_if.py:65)
-        else bv[r] = val;                      // b = b_cvx          (diffcp_if.py:66)
+#pragma unroll
+    for (int u = 0; u < LU; u++) {
+        if (c0[u] < 0) continue;
+        if (c0[u] < n) A[r0[u] * lda + c0[u]] = -v0[u];      // solver sees A = -A_cvx (diffcp_if.py:65)
+        else bv[r0[u]] = v0[u];                             // b = b_cvx          (diffcp_if.py:66)
+    }
+    for (int kb = LU * NT; kb < nnz; kb += LU * NT) {
+#pragma unroll
+        for (int u = 0; u < LU; u++) {
+            const int k = kb + threadIdx.x + u * NT, kc = k < nnz ? k : 0;
+            v0[u] = vals[kc]; r0[u] = T.rowidx[kc]; c0[u] = k < nnz ? T.colidx[kc] : -1;
+        }
+#pragma unroll
+        for (int u = 0; u < LU; u++) {
+            if (c0[u] < 0) continue;
+            if (c0[u] < n) A[r0[u] * lda + c0[u]] = -v0[u];
+            else bv[r0[u]] = v0[u];
+        }
     }
     __syncthreads();
 }
