@@ -123,6 +123,9 @@ __device__ __forceinline__ double seg_dot_lds(const double *row, const double *v
 // rows padded to a multiple of 4 ints (16-byte aligned), so that a thread fetches its row with dwordx4 loads off ONE base address
 // (immediate offsets).  The slot-major layout of round 1 (base[k * NT + t]) needed one 64-bit address per slot beyond the
 // 12-bit immediate range: 2 x 22 address VGPRs computed, spilled and reloaded in every refactor().
+#ifndef F2_IDX_FENCE
+#define F2_IDX_FENCE 8
+#endif
 template <int TT> constexpr int idx_stride = (TT + 3) & ~3;
 // tile[k] = f(k, map entry) for k < TT, CHUNK loads of 4 entries in flight at a time
 template <int TT, class F>
@@ -136,7 +139,7 @@ __device__ __forceinline__ void for_each_idx(const int *__restrict__ base, int t
         if (4 * c4 + 1 < TT) f(std::integral_constant<int, 1>{}, 4 * c4 + 1, ix.y);
         if (4 * c4 + 2 < TT) f(std::integral_constant<int, 2>{}, 4 * c4 + 2, ix.z);
         if (4 * c4 + 3 < TT) f(std::integral_constant<int, 3>{}, 4 * c4 + 3, ix.w);
-        if (c4 % 2 == 1) __builtin_amdgcn_sched_barrier(0);       // bounded number of loads in flight (register peak)
+        if (c4 % F2_IDX_FENCE == F2_IDX_FENCE - 1) __builtin_amdgcn_sched_barrier(0);       // bounded number of loads in flight (register peak)
     }
 }
 
@@ -964,9 +967,10 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
             double we = 0, gve = 0;
             int cd = 0, soc_r0 = 0;
             if (own2) { we = sm[L::O_W + ee]; gve = sm[L::O_GV + ee]; cd = socd[i2]; soc_r0 = socr[i2]; }      // cd 0: zero-cone row (dual free), 1: nonnegative row, > 1: row of an SOC
+            const double wp0 = sm[L::O_WP], wp1 = sm[L::O_WP + 1], wp2 = sm[L::O_WP + 2];
             const double q = seg_dot<CHA, T2>(ar, sm + L::O_PX + T2 * c2);
             __builtin_amdgcn_sched_barrier(0);
-            const double tau_t = (rtau * sm[L::O_WP + 2] + sm[L::O_WP] + sm[L::O_WP + 1]) * inv_den;
+            const double tau_t = (rtau * wp2 + wp0 + wp1) * inv_den;
             double ute = 0, ze = 0;
             if (own2) {
                 const double py = we + dyv(i2) * q;
