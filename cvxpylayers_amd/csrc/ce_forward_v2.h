@@ -859,9 +859,20 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
             const double *zc = sm + L::O_ZB + OY + soc_r0;
             const double t0 = zc[0];
             double q0 = 0, q1 = 0;
-            for (int k = 1; k < soc_d; k += 4) {
-                const double z0 = zc[k], z1 = (k + 1 < soc_d) ? zc[k + 1] : 0.0, z2 = (k + 2 < soc_d) ? zc[k + 2] : 0.0, z3 = (k + 3 < soc_d) ? zc[k + 3] : 0.0;
-                q0 = fma(z0, z0, q0); q1 = fma(z1, z1, q1); q0 = fma(z2, z2, q0); q1 = fma(z3, z3, q1);
+            if (soc_d <= 13) {       // one batch of reads, masked (the reads past the cone stay inside the vector, pads included)
+                double zv[12];
+#pragma unroll
+                for (int u = 0; u < 12; u++) zv[u] = zc[1 + u];
+#pragma unroll
+                for (int u = 0; u < 12; u += 2) {
+                    const double z0 = (1 + u < soc_d) ? zv[u] : 0.0, z1 = (2 + u < soc_d) ? zv[u + 1] : 0.0;
+                    q0 = fma(z0, z0, q0); q1 = fma(z1, z1, q1);
+                }
+            } else {
+                for (int k = 1; k < soc_d; k += 4) {
+                    const double z0 = zc[k], z1 = (k + 1 < soc_d) ? zc[k + 1] : 0.0, z2 = (k + 2 < soc_d) ? zc[k + 2] : 0.0, z3 = (k + 3 < soc_d) ? zc[k + 3] : 0.0;
+                    q0 = fma(z0, z0, q0); q1 = fma(z1, z1, q1); q0 = fma(z2, z2, q0); q1 = fma(z3, z3, q1);
+                }
             }
             const double q = q0 + q1;
             double nz = 0, rinv = 0;
@@ -1030,8 +1041,11 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
         } else {
         // P2: q = A p_x ; tau-tilde ; u-tilde ; cone input
         {
-            double tau_t = (rtau * sm[L::O_W + OT] + sm[L::O_WP] + sm[L::O_WP + 1]) * inv_den;
+            // (operands that do not depend on the product are requested before it, the product's stream is fenced: see the wave-local variant above)
+            const double wt0 = sm[L::O_W + OT], wp0 = sm[L::O_WP], wp1 = sm[L::O_WP + 1];
             const double q = seg_dot<CHA, T2>(ar, sm + L::O_PX + T2 * c2);
+            __builtin_amdgcn_sched_barrier(0);
+            double tau_t = (rtau * wt0 + wp0 + wp1) * inv_den;
             if constexpr (HASP) {
                 // positive root of (r_tau + h.g - g^T P g) t^2 + (-(r_tau w_tau + h.p) + 2 p^T P g) t - p^T P p = 0, with
                 // p^T P p = rho_x p_x.(w_x - p_x) - (A p_x).p_y  (first block row of the linear system: no extra product)

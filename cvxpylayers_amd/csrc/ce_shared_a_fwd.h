@@ -16,6 +16,12 @@
 #pragma once
 #include "ce_shared_a_ops.h"
 
+#ifdef CE_TIMING   // debug build: shader cycles per phase of the iteration (thread 0, accumulated in registers), written over the first entries of the instance's s row
+#define SA_T(k) do { const long long t1_ = __builtin_readcyclecounter(); sa_tacc[k] += t1_ - sa_t0; sa_t0 = t1_; } while (0)
+#else
+#define SA_T(k) do { } while (0)
+#endif
+
 struct SaFwd {
     int r, RP;                   // dense rows, padded to a multiple of 16
     const double *AdT;           // [n][RP]  equilibrated dense rows, transposed (solver sign), zero padded
@@ -222,8 +228,12 @@ k_sa_fwd(DevT T, SaFwd F, ce_settings S, const double *__restrict__ BHg, const d
     double *const aaXP = F.aa_ws ? F.aa_ws + (size_t)inst * 4 * lp : nullptr, *const aaFP = aaXP + lp, *const aaFS = aaFP + lp;
     double *const aaWP = F.aa_w_lds ? aaW_lds : aaFS + lp;      // (generic pointer: LDS when it fits, else the fourth global vector)
     double res3[3] = {NAN, NAN, NAN};
+#ifdef CE_TIMING
+    long long sa_tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, sa_t0 = __builtin_readcyclecounter();
+#endif
     while (!done) {
         refresh();
+        SA_T(0);
         if (resume) {      // relaxed update owed by the iteration a rescale interrupted
             for (int e = tid; e < l; e += NT) W[e] += alpha * (U[e] - UT[e]);
             __syncthreads();
@@ -305,6 +315,7 @@ k_sa_fwd(DevT T, SaFwd F, ce_settings S, const double *__restrict__ BHg, const d
                 px[j] = acc * dgi[j];
             }
             __syncthreads();
+            SA_T(1);
             sa_dense_partials<NT, RP>(F.AdT, n, px, part);
             for (int a = tid >> 3; a < RP; a += NT / 8) {       // K0 w_d : eight lanes per row
                 const double *kr = K0 + a * LK;
@@ -314,6 +325,7 @@ k_sa_fwd(DevT T, SaFwd F, ce_settings S, const double *__restrict__ BHg, const d
                 if ((tid & 7) == 0) zd[a] = s_;
             }
             __syncthreads();
+            SA_T(2);
             if (tid < RP) { constexpr int ng = 2 * NT / RP; double s_ = -zd[tid]; for (int gg = 0; gg < ng; gg++) s_ += part[gg * RP + tid]; vd[tid] = s_; }      // A_d u
             __syncthreads();
             for (int a = tid >> 3; a < RP; a += NT / 8) {       // z = K^-1 (A_d u)
@@ -324,8 +336,10 @@ k_sa_fwd(DevT T, SaFwd F, ce_settings S, const double *__restrict__ BHg, const d
                 if ((tid & 7) == 0) { const double zv = a < r ? s_ : 0.0; zd[a] = zv; dyd[RP + a] = wyd[a] + zv; }
             }
             __syncthreads();
+            SA_T(3);
             sa_rows_dot<NT, RP>(F.AdT, n, dyd + RP, [&](int, int) { return 0.0; }, [&](int j, double a) { px[j] -= dgi[j] * a; });
             __syncthreads();
+            SA_T(4);
             double rts = 0;
 #pragma unroll
             for (int w = 0; w < NW; w++) rts += red[w];
@@ -343,6 +357,7 @@ k_sa_fwd(DevT T, SaFwd F, ce_settings S, const double *__restrict__ BHg, const d
                 UT[e] = ute; zb[e] = ze;
             }
             __syncthreads();
+            SA_T(5);
             if (nq > 0) {
                 for (int c = tid >> 6; c < nq; c += NW) {         // one wave per cone
                     const int r0 = n + c_qoff[c], r1 = n + c_qoff[c + 1];
@@ -387,9 +402,11 @@ k_sa_fwd(DevT T, SaFwd F, ce_settings S, const double *__restrict__ BHg, const d
 #endif
             }
 #endif
+            SA_T(6);
             if (!check && !last) {
                 for (int e = tid; e < l; e += NT) { const double ue = proj_e(e); U[e] = ue; W[e] += alpha * (ue - UT[e]); }
                 __syncthreads();
+                SA_T(7);
                 iter++;
                 continue;
             }
@@ -451,6 +468,7 @@ k_sa_fwd(DevT T, SaFwd F, ce_settings S, const double *__restrict__ BHg, const d
             if (rescale) { resume = true; break; }
             for (int e = tid; e < l; e += NT) W[e] += alpha * (U[e] - UT[e]);
             __syncthreads();
+            SA_T(8);
             iter++;
         }
     }
@@ -473,6 +491,10 @@ k_sa_fwd(DevT T, SaFwd F, ce_settings S, const double *__restrict__ BHg, const d
         yo[(size_t)inst * m + i] = (solved || infeas) ? di * uy * it : NAN;
         so[(size_t)inst * m + i] = infeas ? NAN : sh / di * it;
     }
+#ifdef CE_TIMING
+    __syncthreads();
+    if (tid == 0) for (int k = 0; k < 12; k++) so[(size_t)inst * m + k] = (double)sa_tacc[k];
+#endif
     if (tid == 0) {
         iters_o[inst] = iter; status_o[inst] = status;
         if (resid_o) { resid_o[3 * inst] = res3[0]; resid_o[3 * inst + 1] = res3[1]; resid_o[3 * inst + 2] = res3[2]; }
