@@ -76,13 +76,13 @@ __device__ __forceinline__ void sqrt_rsqrt(double q, double &s, double &rinv) {
 #ifndef F2_SEG_PARTS
 #define F2_SEG_PARTS 1
 #endif
-template <int CH, int TT>
+template <int CH, int TT, int PARTS_ = F2_SEG_PARTS>
 __device__ __forceinline__ double seg_dot(const double (&tile)[TT], const double *vec) {
     const double2 *v2 = reinterpret_cast<const double2 *>(vec);
     double a0 = 0, a1 = 0;       // (four chains were tried: the two extra accumulators push the iteration loop into scratch spills)
     // Long segments go in F2_SEG_PARTS fenced parts: the machine scheduler keeps only 1-4 of the 13 reads of a 26-term product in flight (it
     // serialised the A p_x phase completely: ten LDS round trips), with a fence every part's reads are issued together: one round trip per part.
-    constexpr int NB = TT / 2, PARTS = NB > 8 ? F2_SEG_PARTS : 1, H = (NB + PARTS - 1) / PARTS;
+    constexpr int NB = TT / 2, PARTS = NB > 8 ? PARTS_ : 1, H = (NB + PARTS - 1) / PARTS;
 #pragma unroll
     for (int p = 0; p < PARTS; p++) {
 #pragma unroll
@@ -951,7 +951,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
             if (aa_on && nw > 0 && threadIdx.x == 0) sc[8] *= sqrt((double)l) / nw;
             __syncthreads();
         }
-        if (aa_on && ev) aaWP[ve] = sm[L::O_W + ve];      // input of this iteration (read again at the top of the next one, after barriers)
+        if (aa_on && ev && (aa_pending || (iter + 1) % aa_int == 0)) aaWP[ve] = sm[L::O_W + ve];      // input of this iteration, kept where the top of the next one reads it (the safeguard after a step, the step itself every aa_int iterations)
         // P1a: t = rho_x w_x - A^T w_y   (+ phi . w from the two spare column groups)
         {
             const double *wvec = sm + L::O_W + ((j1 == n + 1 && T1 * c1 < n) ? OX : OY) + T1 * c1;
