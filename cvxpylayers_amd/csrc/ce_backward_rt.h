@@ -84,8 +84,8 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
 #endif
     CE_STAMP(0);
     load_instance(T, Avals + (size_t)inst * T.nnz_aug, A, bv);
-    for (int i = tid; i < m; i += NTB) vv[i] = yg[(size_t)inst * m + i] - sg[(size_t)inst * m + i];
-    if (tid < 8) misc[tid] = 0;
+    for (int i = tid; i < m; i += NTB) { vv[i] = yg[(size_t)inst * m + i] - sg[(size_t)inst * m + i]; dv[i] = dyg[(size_t)inst * m + i]; }      // dv: the incoming dy for now (one coalesced
+    if (tid < 8) misc[tid] = 0;                                                                                                                    // pass; the per-cone code below used to read it from global memory row by row)
     __syncthreads();
     CE_STAMP(1);
     // ---- classify
@@ -95,8 +95,15 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
         int kind; double lam = 0, nz = 0;
         if (d == 1) kind = vv[r0] >= 0 ? 0 : 1;
         else {
-            for (int i = r0 + 1; i < r1; i++) nz = fma(vv[i], vv[i], nz);
-            nz = sqrt(nz);
+            double nz1 = 0;
+            for (int i = r0 + 1; i < r1; i += 4) {     // four rows per step, reads requested together (clamped index, masked contribution)
+                double w[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) w[u] = vv[min(i + u, r1 - 1)];
+#pragma unroll
+                for (int u = 0; u < 4; u++) { const double t = (i + u < r1) ? w[u] : 0.0; if (u & 1) nz1 = fma(t, t, nz1); else nz = fma(t, t, nz); }
+            }
+            nz = sqrt(nz + nz1);
             const double t0 = vv[r0];
             if (nz <= t0) kind = 0; else if (nz <= -t0) kind = 1; else { kind = 2; lam = (t0 + nz) / (2 * nz); }
         }
@@ -225,21 +232,44 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
     }
     CE_STAMP(2);
     // ---- d = DPi(v) dy, per-cone scalars
-    for (int i = tid; i < z + T.l; i += NTB) dv[i] = rkind[i] == RK_EQ ? dyg[(size_t)inst * m + i] : 0.0;
+    // (dv holds dy: transformed in place; PSD / exponential rows were already replaced by the rotation above)
+    for (int i = tid; i < z + T.l; i += NTB) { if (rkind[i] != RK_EQ) dv[i] = 0.0; }
     for (int c = tid; c < nq; c += NTB) {
         const int r0 = T.qoff[c], r1 = T.qoff[c + 1];
-        const double *h = dyg + (size_t)inst * m;
-        if (ckind[c] == 0) { for (int i = r0; i < r1; i++) dv[i] = h[i]; }
+        if (ckind[c] == 0) { /* dv = dy */ }
         else if (ckind[c] == 1) { for (int i = r0; i < r1; i++) dv[i] = 0.0; }
         else {
-            const double t0 = vv[r0], nz = cinfo[6 * c + 1];
-            double zh = 0; for (int i = r0 + 1; i < r1; i++) zh = fma(vv[i], h[i], zh);
-            dv[r0] = (nz * h[r0] + zh) / (2 * nz);
-            for (int i = r0 + 1; i < r1; i++) dv[i] = (vv[i] * h[r0] + (t0 + nz) * h[i] - t0 * vv[i] * zh / (nz * nz)) / (2 * nz);
-            double zd = 0; for (int i = r0 + 1; i < r1; i++) zd = fma(vv[i], dv[i], zd);
-            zd /= nz;
-            cinfo[6 * c + 2] = (dv[r0] + zd) * M_SQRT1_2;   // e_y . d
-            cinfo[6 * c + 3] = (dv[r0] - zd) * M_SQRT1_2;   // e_s . d
+            // one pass over the cone, four rows per step with their reads in flight together:  z.h  first, then d_i and z.d in the same sweep
+            const double t0 = vv[r0], nz = cinfo[6 * c + 1], h0 = dv[r0];
+            double zh = 0, zh1 = 0;
+            for (int i = r0 + 1; i < r1; i += 4) {
+                double w[4], hh[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) { const int iu = min(i + u, r1 - 1); w[u] = vv[iu]; hh[u] = dv[iu]; }
+#pragma unroll
+                for (int u = 0; u < 4; u++) { const double t = (i + u < r1) ? w[u] : 0.0; if (u & 1) zh1 = fma(t, hh[u], zh1); else zh = fma(t, hh[u], zh); }
+            }
+            zh += zh1;
+            const double i2n = 1.0 / (2 * nz), cz = t0 * zh / (nz * nz);
+            const double d0 = (nz * h0 + zh) * i2n;
+            double zd = 0, zd1 = 0;
+            for (int i = r0 + 1; i < r1; i += 4) {
+                double w[4], hh[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) { const int iu = min(i + u, r1 - 1); w[u] = vv[iu]; hh[u] = dv[iu]; }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if (i + u < r1) {
+                        const double di = (w[u] * h0 + (t0 + nz) * hh[u] - w[u] * cz) * i2n;
+                        dv[i + u] = di;
+                        if (u & 1) zd1 = fma(w[u], di, zd1); else zd = fma(w[u], di, zd);
+                    }
+                }
+            }
+            dv[r0] = d0;
+            zd = (zd + zd1) / nz;
+            cinfo[6 * c + 2] = (d0 + zd) * M_SQRT1_2;   // e_y . d
+            cinfo[6 * c + 3] = (d0 - zd) * M_SQRT1_2;   // e_s . d
         }
     }
     __syncthreads();
