@@ -136,7 +136,8 @@ k_backward(DevT T, int nkcap, int ldk, const double *__restrict__ Avals, const d
         rx[r] = val;
     }
     __syncthreads();
-    // ---- assemble K = [[H, -B^T],[B, 0]] | rhs
+    // ---- assemble K = [[H, -B^T],[B, 0]] | rhs   (a lambda: the blocked elimination below re-assembles when it meets a rank-deficient system)
+    auto assemble = [&]() {
     for (int idx = tid; idx < NK * (NK + 1); idx += NT) {
         const int r = idx / (NK + 1), cidx = idx % (NK + 1);
         double val = 0;
@@ -218,6 +219,8 @@ k_backward(DevT T, int nkcap, int ldk, const double *__restrict__ Avals, const d
     for (int c = tid; c < nq; c += NT) if (ceq[c] >= 0) K[(n + ceq[c]) * ldk + NK] = cinfo[6 * c + 2];
     for (int i = tid; i < NK; i += NT) perm[i] = i;
     __syncthreads();
+    };
+    assemble();
     // ---- Gauss-Jordan with partial pivoting on [K | rhs]
     double kmax;
     {
@@ -227,7 +230,8 @@ k_backward(DevT T, int nkcap, int ldk, const double *__restrict__ Avals, const d
         kmax = r[0];
     }
     const double ptol = 1e-13 * (kmax > 0 ? kmax : 1.0);
-    if (!K_LDS && T.gen_blocked_b) {
+    bool unblocked = !(!K_LDS && T.gen_blocked_b);
+    if (!unblocked) {
         // BLOCKED Gauss-Jordan with partial pivoting, sixteen pivots per pass over the global-memory matrix (the unblocked loop below streams the
         // whole [K | rhs] once per pivot: at n = 200 that is 0.98 MB x NK steps per instance, HBM-bound).  Per block of columns k0 .. k0 + nb - 1:
         //   1. the column panel (all rows) goes to LDS and the nb pivot steps run on it alone: pivot search, multipliers L[i][kk] for every other row;
@@ -321,12 +325,22 @@ k_backward(DevT T, int nkcap, int ldk, const double *__restrict__ Avals, const d
             }
             __syncthreads();
         }
-        for (int k = tid; k < NK; k += NT) {
-            const double sol = K[(size_t)perm[k] * ldk + NK] / pivv[k];
-            if (k < n) rx[k] = sol; else bv[k - n] = sol;
+        if (misc[2] & 1) {
+            // A vanishing pivot (redundant equality rows, a degenerate active set): sixteen pivots per pass cannot skip a column.  K is rebuilt (f still sits in rx,
+            // the solution has not been written) and the rank-revealing elimination below takes over -- rare, and correct instead of flagged.
+            __syncthreads();
+            if (tid == 0) misc[2] = 0;
+            assemble();
+            unblocked = true;
+        } else {
+            for (int k = tid; k < NK; k += NT) {
+                const double sol = K[(size_t)perm[k] * ldk + NK] / pivv[k];
+                if (k < n) rx[k] = sol; else bv[k - n] = sol;
+            }
+            __syncthreads();
         }
-        __syncthreads();
-    } else {
+    }
+    if (unblocked) {
     // Rank-revealing like k_backward_rt (and the oracle's dense elimination): a column without an acceptable pivot among the unused rows is a FREE
     // variable (set to zero, skipped, no row consumed) -- redundant equality rows / degenerate active sets, where the reference's LSQR returns a
     // solution of the consistent system.  `rcur` = number of rows used so far (the pivot row of column k sits at position colrow[k] of perm).

@@ -424,6 +424,7 @@ int ce_create(const ce_template *tpl, int device, ce_handle *out) {
     else { ce_destroy(h); g_err = "instance vectors do not fit LDS"; return CE_E_TOO_LARGE; }
     { const char *e = getenv("CE_F2_NEUMANN"); T.f2_neumann = (e && atoi(e) == 0) ? 0 : 1; }
     T.gen_blocked_b = (h->bwd_mode >= 1 && bwd_lds_bytes(T, h->bwd_mode <= 1, false, h->nkcap, h->ldk, true) <= LDS_LIMIT) ? 1 : 0;
+    { const char *gb = getenv("CE_GEN_BLOCKED"); if (gb && !strcmp(gb, "0")) T.gen_blocked_b = 0; }      // A/B switch (tests): the unblocked elimination of the size-generic backward kernel
     h->bwd_lds = bwd_lds_bytes(T, h->bwd_mode <= 1, h->bwd_mode == 0, h->nkcap, h->ldk, T.gen_blocked_b != 0);
     if (!getenv("CE_FORCE_GENERIC")) {
         for (int v = 0; v < BRT_NV; v++) {

@@ -569,3 +569,40 @@ def test_rescale_by_neumann_series_gives_the_iterates_of_a_refactorisation(monke
     assert out["1"][1].max() > 150                                             # past RESCALING_MIN_ITERS: rescales happened
     assert np.array_equal(out["1"][1], out["0"][1]), (out["1"][1], out["0"][1])
     assert np.abs(out["1"][0] - out["0"][0]).max() < 1e-9
+
+
+def test_blocked_generic_backward_is_rank_revealing(monkeypatch):
+    """n = 120 with per-instance A and K in global memory (the blocked Gauss-Jordan of the size-generic backward kernel) on a template with a REDUNDANT
+    equality row (row 1 = row 0, consistent right-hand side): sixteen pivots per pass cannot skip a column, so the kernel rebuilds K and hands over to
+    the rank-revealing unblocked elimination.  Same gradients as the unblocked path run on its own (CE_GEN_BLOCKED=0), status bit 2 (= 4: rank deficient,
+    not a failure), finite everywhere; on the same template WITHOUT the redundancy the blocked path itself answers (status 0)."""
+    from cvxpylayers_amd.interfaces.mi355_if import ConeEngine, make_settings
+    cones = {"z": 2, "l": 58, "q": [21] * 6}
+    n, B = 120, 4
+    tpl = P.dense_template(n, cones)
+    A, b, c = P.generate(n, cones, B, seed=11)
+    outs = {}
+    for redundant in (True, False):
+        A2, b2 = A.copy(), b.copy()
+        if redundant:
+            A2[:, 1, :] = A2[:, 0, :]; b2[:, 1] = b2[:, 0]
+        A_eval, q_eval = tpl.values_from_dense(A2, b2, c)
+        for blocked in ("1", "0"):
+            monkeypatch.setenv("CE_GEN_BLOCKED", blocked)
+            eng = ConeEngine(tpl.indices, tpl.indptr, tpl.n, tpl.m, cones, torch.device("cuda", 0))
+            assert eng.launch_info()["bwd_mode"] == 2
+            A_bm = torch.from_numpy(A_eval).cuda().t().contiguous(); q_t = torch.from_numpy(q_eval).cuda()
+            x, y, s, it, st, res = eng.solve(A_bm, q_t, make_settings(dict(eps=1e-9, max_iters=100000, acceleration_lookback=0)))
+            assert (st == 1).all()
+            g = torch.Generator(device="cpu").manual_seed(5)
+            dx = torch.randn(x.shape, generator=g, dtype=torch.float64).cuda(); dy = torch.randn(y.shape, generator=g, dtype=torch.float64).cuda()
+            dA, dq, adj = eng.vjp(A_bm, x, y, s, dx, dy)
+            torch.cuda.synchronize()
+            outs[(redundant, blocked)] = (dA.cpu().numpy().copy(), dq.cpu().numpy().copy(), adj.cpu().numpy().copy())
+    for redundant in (True, False):
+        (dA1, dq1, adj1), (dA0, dq0, adj0) = outs[(redundant, "1")], outs[(redundant, "0")]
+        assert np.isfinite(dA1).all() and np.isfinite(dq1).all()
+        want = 4 if redundant else 0
+        assert (adj1 == want).all() and (adj0 == want).all(), (redundant, adj1, adj0)
+        sc = 1 + np.abs(dA0).max()
+        assert np.abs(dA1 - dA0).max() < (1e-12 if redundant else 1e-6) * sc and np.abs(dq1 - dq0).max() < (1e-12 if redundant else 1e-6) * (1 + np.abs(dq0).max())
