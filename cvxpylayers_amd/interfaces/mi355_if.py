@@ -185,6 +185,17 @@ class ConeEngine:
         _lib.check(rc, "ce_solve")
         return x, y, s, iters, status, resid
 
+    def zeros_like_cached(self, t: torch.Tensor) -> torch.Tensor:
+        """A read-only zero tensor of t's shape on this engine's device, allocated once per shape (the cotangent of an output the loss does not use)."""
+        cache = self.__dict__.setdefault("_zero_cache", {})
+        key = tuple(t.shape)
+        z = cache.get(key)
+        if z is None:
+            if len(cache) > 8:
+                cache.clear()
+            z = cache[key] = torch.zeros(key, dtype=torch.float64, device=self.device)
+        return z
+
     def enqueue_summary(self, vec: torch.Tensor, slot: int):
         """ce_status_summary of an int32 device vector into pinned slot `slot` (0: status of this forward, 1: adjoint flags of the previous backward);
         read with read_summaries() after ONE stream synchronisation."""
@@ -540,6 +551,7 @@ class _ConeLayer(torch.autograd.Function):
         _, _, info, backward_data = outputs
         ctx.info = info
         ctx.backward_data = backward_data
+        ctx.set_materialize_grads(False)      # an unused output (the duals, most of the time) arrives as None instead of a freshly filled zero tensor: one launch less per step
 
     @staticmethod
     @torch.autograd.function.once_differentiable
@@ -549,9 +561,11 @@ class _ConeLayer(torch.autograd.Function):
             raise RuntimeError("backward called on a layer evaluated with needs_grad=False")
         eng, A_bm, x, y, s, batch_minor_in, P_bm, path, failed = saved
         dP = None
+        if dprimal is None and ddual is None:         # nothing flows back through this node
+            return None, None, None, None, None, None, None
         with torch.cuda.device(eng.device):
-            dx = dprimal.to(device=eng.device, dtype=torch.float64).contiguous()
-            dy = ddual.to(device=eng.device, dtype=torch.float64).contiguous()
+            dx = dprimal.to(device=eng.device, dtype=torch.float64).contiguous() if dprimal is not None else eng.zeros_like_cached(x)
+            dy = ddual.to(device=eng.device, dtype=torch.float64).contiguous() if ddual is not None else eng.zeros_like_cached(y)
             if failed is not None:          # masked instances: NaN outputs upstream produce NaN cotangents; they contribute nothing
                 keep = ~failed[:, None]
                 dx = torch.where(keep, dx, torch.zeros_like(dx)); dy = torch.where(keep, dy, torch.zeros_like(dy))
