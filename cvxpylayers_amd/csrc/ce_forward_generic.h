@@ -33,6 +33,12 @@ k_forward(DevT T, ce_settings S, const double *__restrict__ Avals, const double 
     double *socc = p; p += 2 * (nq > 0 ? nq : 1);
     double *wpart = p; p += NW;  // per-wave partials of phi . w
     double *sc = p; p += 2 * n;  // refactor() right-hand sides (keeps u / ut intact across a rescale)
+    // PSD / exponential / power cones (the size-generic kernel serves every cone type: templates beyond the register-tiled kernels' sizes):
+    // Jacobi scratch S, V, (c, s, p, q) per pair of ce_forward_v2.h's psd_project, and the previous root of every triple (Newton warm start, ce_expcone.h)
+    double *psdS = p, *psdV = p, *psdC = p;
+    if (T.ns > 0) { psdS = p; p += T.maxs * T.maxs; psdV = p; p += T.maxs * T.maxs; psdC = p; p += 2 * T.maxs + 8; }
+    const int ntri = T.nep + T.np;
+    double *troot = p; p += ntri;
     p += (size_t)(p - sm) & 1;   // (16-byte alignment of what follows)
     double *pan = p;             // !G_LDS: panels of the blocked inversion (generic_gj_panel_doubles(n))
 
@@ -42,6 +48,7 @@ k_forward(DevT T, ce_settings S, const double *__restrict__ Avals, const double 
     auto G_times = [&](const double *v, double *out) { if constexpr (G_LDS) mv_cols_partial(G, ldg, n, n, v, out); else mv_cols_g(G, ldg, n, n, v, out); };
 
     // ---------------------------------------------------------------- load
+    for (int c = tid; c < ntri; c += NT) troot[c] = 0.0;
     load_instance(T, Avals + (size_t)inst * T.nnz_aug, A, bv);
     for (int j = tid; j < n; j += NT) { cv[j] = qv[j * sqk + inst * sqb]; Ev[j] = 1.0; }
     for (int i = tid; i < m; i += NT) Dv[i] = 1.0;
@@ -97,7 +104,7 @@ k_forward(DevT T, ce_settings S, const double *__restrict__ Avals, const double 
                 const int CH = chunks_for(m); double a = part[i];
                 for (int c = 1; c < CH; c++) a = l2 ? a + part[c * m + i] : fmax(a, part[c * m + i]);
                 if (l2) a = sqrt(a);
-                tv[i] = (T.rowcone[i] < 0) ? 1.0 / sqrt(clamp_scale(a)) : a;   // SOC rows: raw norm, averaged below
+                tv[i] = (i < z + T.l) ? 1.0 / sqrt(clamp_scale(a)) : a;        // cone rows (SOC, PSD, triples): raw norm, averaged below
             }
             for (int j = tid; j < n; j += NT) {
                 const int CH = chunks_for(n); double a = part2[j];
@@ -106,9 +113,13 @@ k_forward(DevT T, ce_settings S, const double *__restrict__ Avals, const double 
                 u[j] = 1.0 / sqrt(clamp_scale(a));                                // Et (u is free scratch here)
             }
             __syncthreads();
-            if (nq > 0) {   // block-average the row scaling inside each SOC so the scaled cone is still the cone
-                for (int c = tid; c < nq; c += NT) {
-                    const int r0 = T.qoff[c], r1 = T.qoff[c + 1]; double a = 0;
+            if (nq + T.ns + ntri > 0) {   // block-average the row scaling inside each cone block so the scaled cone is still the cone
+                for (int c = tid; c < nq + T.ns + ntri; c += NT) {
+                    int r0, r1;
+                    if (c < nq) { r0 = T.qoff[c]; r1 = T.qoff[c + 1]; }
+                    else if (c < nq + T.ns) { r0 = T.soff[c - nq]; r1 = T.soff[c - nq + 1]; }
+                    else { r0 = T.eoff + 3 * (c - nq - T.ns); r1 = r0 + 3; }
+                    double a = 0;
                     for (int i = r0; i < r1; i++) a += tv[i];
                     if (r1 > r0) { a = 1.0 / sqrt(clamp_scale(a / (r1 - r0))); for (int i = r0; i < r1; i++) tv[i] = a; }
                 }
@@ -368,7 +379,7 @@ k_forward(DevT T, ce_settings S, const double *__restrict__ Avals, const double 
                 const int i = e - n;
                 const double py = w[e] + dyv(i) * sum_parts(part, m, i);
                 ute = py - tau_t * g[e]; ue = 2 * ute - w[e];
-                if (i >= z && T.rowcone[i] < 0 && ue < 0) ue = 0;      // nonneg rows; zero-cone dual is free
+                if (i >= z && i < z + T.l && ue < 0) ue = 0;            // nonneg rows; zero-cone dual is free
             } else { ute = tau_t; ue = fmax(0.0, 2 * tau_t - w[e]); }
             ut[e] = ute; u[e] = ue;
         }
@@ -390,7 +401,16 @@ k_forward(DevT T, ce_settings S, const double *__restrict__ Avals, const double 
             __syncthreads();
             for (int i = tid + (z + T.l); i < m; i += NT) {
                 const int c = T.rowcone[i];
-                u[n + i] = (i == T.qoff[c]) ? socc[2 * c] : socc[2 * c + 1] * u[n + i];
+                if (c >= 0) u[n + i] = (i == T.qoff[c]) ? socc[2 * c] : socc[2 * c + 1] * u[n + i];
+            }
+            __syncthreads();
+        }
+        // S8': PSD blocks (workgroup-parallel Jacobi in LDS, ce_forward_v2.h) and exponential / power triples (one thread per cone, ce_expcone.h), in place
+        for (int c = 0; c < T.ns; c++) psd_project<NT>(u + n + T.soff[c], T.sord[c], psdS, psdV, psdC, red);
+        if (ntri > 0) {
+            for (int c = tid; c < ntri; c += NT) {
+                double *zc = u + n + T.eoff + 3 * c;
+                if (c < T.nep) exp_project_dual(zc, troot + c); else pow_project_dual_of_entry(zc, T.pw[c - T.nep], troot + c);
             }
             __syncthreads();
         }

@@ -5,6 +5,7 @@ namespace {
 #include "ce_expcone.h"
 #include "ce_forward_rt.h"        // (first: group_reduce / DPP helpers used by the size-generic kernel's global-memory products)
 #include "ce_global_mv.h"
+#include "ce_forward_v2.h"        // (psd_project: the workgroup-parallel Jacobi projection shared with k_fwd2<PSD>)
 #include "ce_forward_generic.h"
 }  // namespace
 

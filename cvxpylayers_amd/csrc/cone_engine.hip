@@ -109,6 +109,8 @@ static size_t fwd_lds_bytes(const DevT &T, bool a_lds, bool g_lds, bool panel = 
     if (a_lds) d += (size_t)m * T.lda;
     if (g_lds) d += (size_t)n * T.ldg;
     d += 2 * (size_t)m + 2 * (size_t)n + 5 * (size_t)l + std::max(n, m) + 2 * (size_t)PB + NW * 8 + 2 * std::max(T.nq, 1) + NW + 2 * (size_t)n;
+    if (T.ns > 0) d += 2 * (size_t)T.maxs * T.maxs + 2 * (size_t)T.maxs + 8;      // PSD cones: Jacobi scratch of psd_project (ce_forward_generic.h carve)
+    d += (size_t)(T.nep + T.np) + 1;                                               // roots of the exponential / power triples (+ alignment)
     if (!g_lds && panel) d += generic_gj_panel_doubles(n) + 2;      // panels of the blocked inversion of the global-memory G
     return d * 8 + 16;
 }
@@ -344,7 +346,7 @@ int ce_create(const ce_template *tpl, int device, ce_handle *out) {
     // (modes 1, 2: the blocked inversion needs its column panel in LDS; templates where that does not fit keep the unblocked loop)
     T.gen_blocked_f = (h->fwd_mode >= 1 && fwd_lds_bytes(T, h->fwd_mode <= 1, false, true) <= LDS_LIMIT) ? 1 : 0;
     h->fwd_lds = fwd_lds_bytes(T, h->fwd_mode <= 1, h->fwd_mode == 0, T.gen_blocked_f != 0);
-    if (!getenv("CE_FORCE_GENERIC")) {
+    if (!getenv("CE_FORCE_GENERIC") && T.ns == 0 && T.nep + T.np == 0) {      // (k_forward_rt: zero / nonnegative / second-order cones only)
         for (int v = 0; v < 3; v++) { int vp, ld; size_t by; if (rt_fits(T, v, &vp, &by, &ld)) { h->rt_variant = v; h->rt_vp = vp; h->fwd_lds = by; h->fwd_mode = 3; h->rt_lda = ld; break; } }
     }
     const char *fwd_env = getenv("CE_FWD");      // "v2" (default when it fits), "rt", "generic": A/B switch for benchmarking
@@ -510,8 +512,8 @@ int ce_solve_qp(ce_handle h, int B, const double *A_vals, long sA_k, long sA_b, 
     if (!P_vals && h->qp_native) { g_err = "template created with a P structure: P_vals is required"; return CE_E_BADARG; }
     HIPCHK(hipSetDevice(h->device));
     hipStream_t st = (hipStream_t)stream;
-    if (h->T.nep + h->T.np > 0 && h->fwd_mode != 4) { g_err = "exponential / power cones: the template does not fit the LDS-resident forward kernel (n <= 98, m <= 120 this round)"; return CE_E_UNSUPPORTED; }
-    if (h->T.ns > 0 && h->fwd_mode != 4) { g_err = "PSD cones: per-instance A does not fit the LDS-resident forward kernel (n <= 98, m <= 120 this round); only batch-invariant A is supported at this size (constant-A path)"; return CE_E_UNSUPPORTED; }
+    // (PSD / exponential / power cones beyond k_fwd2's sizes run on the size-generic kernel: fwd_mode 0..2)
+    if ((h->T.ns > 0 || h->T.nep + h->T.np > 0) && h->fwd_mode == 3) { g_err = "PSD / exponential / power cones: internal error, k_forward_rt selected"; return CE_E_UNSUPPORTED; }
     ce_settings S; if (settings) S = *settings; else ce_default_settings(&S);
     if (!(h->fwd_mode == 4 && h->aa_ok)) S.acceleration_lookback = 0;       // only k_fwd2 implements it (and only when its vectors fit LDS)
     if (S.acceleration_interval <= 0) S.acceleration_interval = 10;

@@ -606,3 +606,15 @@ def test_blocked_generic_backward_is_rank_revealing(monkeypatch):
         assert (adj1 == want).all() and (adj0 == want).all(), (redundant, adj1, adj0)
         sc = 1 + np.abs(dA0).max()
         assert np.abs(dA1 - dA0).max() < (1e-12 if redundant else 1e-6) * sc and np.abs(dq1 - dq0).max() < (1e-12 if redundant else 1e-6) * (1 + np.abs(dq0).max())
+
+
+@pytest.mark.parametrize("cones,n", [({"z": 0, "l": 30, "q": [5], "s": [], "ep": 50}, 60),            # m = 185 > 160: 50 exponential cones beyond k_fwd2
+                                     ({"z": 5, "l": 40, "q": [], "s": [14]}, 80),                     # m = 150 > 120 at n = 80 > 62: a 14 x 14 PSD block beyond k_fwd2
+                                     ({"z": 2, "l": 100, "q": [6, 4], "s": [6], "ep": 12, "p": [0.3, -0.6]}, 72)])      # every cone type at once, m = 175
+def test_every_cone_type_on_the_size_generic_forward_kernel(cones, n):
+    """PSD / exponential / power cones with per-instance A beyond the sizes of k_fwd2 (n <= 62 with m <= 160, n <= 104 with m <= 120): the size-generic forward kernel projects them
+    (workgroup-parallel Jacobi in LDS, one thread per triple) with block-averaged equilibration, the 512-thread register-tiled backward kernel
+    differentiates them; both against the oracle."""
+    eng = run_parity(n, cones, 4, seed=21, eps=1e-9, max_iters=200000)
+    info = eng.launch_info()
+    assert info["fwd_mode"] in (0, 1, 2) and info["bwd_mode"] == 3, info
