@@ -34,6 +34,11 @@ k_backward(DevT T, int nkcap, int ldk, const double *__restrict__ Avals, const d
     double *cinfo = p; p += 6 * nqs; // per cone: lambda, nz, e_y.d, e_s.d, (spare)
     double *part = p; p += PB;
     double *red = p; p += NW * 8;
+    // PSD / exponential / power cones (same construction as k_backward_rt<PSD>, ce_backward_rt.h): eigenvectors per PSD cone, its eigenvalues, the DPi eigenvalue of every
+    // rotated row, scratch of the Jacobi solver and of the column rotations (one (X, W) pair per wave), the 3 x 3 eigenvector matrices of the triples
+    const bool has_psd = T.ns > 0 || T.nep + T.np > 0;
+    double *psdU = p, *psdEv = p, *lamr = p, *psdScr = p, *expW = p;
+    if (has_psd) { psdU = p; p += T.ns * T.maxs * T.maxs; psdEv = p; p += T.ns * T.maxs; lamr = p; p += m; psdScr = p; p += 2 * NW * T.maxs * T.maxs + 2 * T.maxs + 8; expW = p; p += 9 * (T.nep + T.np); }
     double *pan = p; if (!K_LDS && T.gen_blocked_b) p += generic_lu_panel_doubles(nkcap);      // panels of the blocked elimination (K in global memory)
     int *ip = (int *)p;
     int *rkind = ip; ip += m;        // row kind
@@ -67,6 +72,84 @@ k_backward(DevT T, int nkcap, int ldk, const double *__restrict__ Avals, const d
         for (int i = r0; i < r1; i++) rkind[i] = kind == 0 ? RK_EQ : (kind == 1 ? RK_FREE : RK_SOCB);
     }
     __syncthreads();
+    if (has_psd) {
+        // PSD cones: V = smat(v_c) = U Lambda U^T.  DPi(v) is diagonal in the orthonormal basis svec(sym(u_a u_b^T)) with eigenvalue B_ab; the rows of the cone are
+        // ROTATED into that basis in place, A_c <- Q^T A_c, Q^T x = svec(U^T smat(x) U): afterwards every rotated row is an ordinary equality (B = 1) / free (B = 0) /
+        // weighted (theta = B / (1 - B)) row and the machinery below applies.  (A may live in global memory here: the rotation streams the cone's rows once.)
+        const int lane = tid & 63, wid = tid >> 6;
+        for (int c = 0; c < T.ns; c++) {
+            const int k = T.sord[c], r0 = T.soff[c], d = k * (k + 1) / 2;
+            double *Um = psdU + c * T.maxs * T.maxs, *ev = psdEv + c * T.maxs;
+            psd_jacobi<NT>(vv + r0, k, psdScr, Um, psdScr + 2 * T.maxs * T.maxs, red);     // eigenvalues on diag(psdScr), vectors in Um
+            for (int i = tid; i < k; i += NT) ev[i] = psdScr[i * k + i];
+            __syncthreads();
+            for (int g0 = 0; g0 <= n; g0 += NW) {        // the n columns of A_c and (as column n) the incoming dy_c; one column per wave at a time
+                const int col = g0 + wid;
+                double *X = psdScr + wid * 2 * T.maxs * T.maxs, *W = X + T.maxs * T.maxs;
+                if (col <= n) {
+                    for (int idx = lane; idx < k * k; idx += 64) {
+                        const int i = idx / k, j = idx - i * k, a = i >= j ? i : j, b = i >= j ? j : i;
+                        const int pos = b * k - (b * (b - 1)) / 2 + (a - b);
+                        const double v = (col < n) ? A[(size_t)(r0 + pos) * lda + col] : dyg[(size_t)inst * m + r0 + pos];
+                        X[idx] = (a == b) ? v : v * M_SQRT1_2;
+                    }
+                }
+                __syncthreads();
+                if (col <= n) {
+                    for (int idx = lane; idx < k * k; idx += 64) {       // W = X U
+                        const int i = idx / k, j = idx - i * k;
+                        double acc = 0; for (int a = 0; a < k; a++) acc = fma(X[i * k + a], Um[a * k + j], acc);
+                        W[idx] = acc;
+                    }
+                }
+                __syncthreads();
+                if (col <= n) {
+                    for (int pos = lane; pos < d; pos += 64) {           // T = U^T W, packed back as svec
+                        int b = 0, rem = pos; while (rem >= k - b) { rem -= k - b; b++; }
+                        const int a = b + rem;
+                        double acc = 0; for (int i = 0; i < k; i++) acc = fma(Um[i * k + a], W[i * k + b], acc);
+                        const double t = (a == b) ? acc : acc * M_SQRT2;
+                        if (col < n) A[(size_t)(r0 + pos) * lda + col] = t;
+                        else {
+                            const double la = ev[a], lb = ev[b];
+                            const double Bv = (la > 0 && lb > 0) ? 1.0 : ((la <= 0 && lb <= 0) ? 0.0 : fmax(la, lb) / (fmax(la, lb) - fmin(la, lb)));
+                            lamr[r0 + pos] = Bv; dv[r0 + pos] = Bv * t;
+                            rkind[r0 + pos] = (Bv == 1.0) ? RK_EQ : (Bv == 0.0 ? RK_FREE : RK_MIX);
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        // Exponential / power cones: S = D Pi_K*(v_c) = W diag(theta) W^T (3 x 3, one thread per cone); the triple's rows are rotated, A_c <- W^T A_c
+        if (T.nep + T.np > 0) {
+            for (int c = tid; c < T.nep + T.np; c += NT) {
+                const int r0 = T.eoff + 3 * c;
+                double W[9], th[3];
+                if (c < T.nep) exp_dual_eig(vv + r0, W, th); else pow_dual_eig(vv + r0, T.pw[c - T.nep], W, th);
+                const double *h = dyg + (size_t)inst * m + r0;
+#pragma unroll
+                for (int a = 0; a < 3; a++) {
+                    const double t = W[a] * h[0] + W[3 + a] * h[1] + W[6 + a] * h[2];     // (W^T dy)_a
+                    double Bv = th[a];
+                    if (Bv < 1e-9) Bv = 0.0; else if (Bv > 1.0 - 1e-9) Bv = 1.0;
+                    lamr[r0 + a] = Bv; dv[r0 + a] = Bv * t;
+                    rkind[r0 + a] = (Bv == 1.0) ? RK_EQ : (Bv == 0.0 ? RK_FREE : RK_MIX);
+                }
+#pragma unroll
+                for (int k = 0; k < 9; k++) expW[9 * c + k] = W[k];
+            }
+            __syncthreads();
+            for (int idx = tid; idx < (T.nep + T.np) * n; idx += NT) {
+                const int c = idx / n, j = idx - c * n, r0 = T.eoff + 3 * c;
+                const double *W = expW + 9 * c;
+                const double a0 = A[(size_t)r0 * lda + j], a1 = A[(size_t)(r0 + 1) * lda + j], a2 = A[(size_t)(r0 + 2) * lda + j];
+#pragma unroll
+                for (int a = 0; a < 3; a++) A[(size_t)(r0 + a) * lda + j] = W[a] * a0 + W[3 + a] * a1 + W[6 + a] * a2;
+            }
+            __syncthreads();
+        }
+    }
     if (tid == 0) {   // equality numbering (serial scan; m is small)
         int ne = 0;
         for (int i = 0; i < m; i++) eqrow[i] = (rkind[i] == RK_EQ) ? ne++ : -1;
@@ -120,7 +203,8 @@ k_backward(DevT T, int nkcap, int ldk, const double *__restrict__ Avals, const d
     for (int i = tid; i < m; i += NT) {
         double w = 0;
         if (i < z + T.l) w = (rkind[i] == RK_FREE) ? dv[i] : 0.0;
-        else { const int c = T.rowcone[i]; if (c >= 0) { if (ckind[c] == 1) w = dv[i]; else if (ckind[c] == 2) w = dv[i] / (1 - cinfo[6 * c]); } }
+        else { const int c = T.rowcone[i]; if (c >= 0) { if (ckind[c] == 1) w = dv[i]; else if (ckind[c] == 2) w = dv[i] / (1 - cinfo[6 * c]); }
+               else if (has_psd && rkind[i] == RK_MIX) w = dv[i] / (1 - lamr[i]); }      // rotated PSD / triple rows: weighted rows (free rows carry d = 0)
         qv2[i] = w;
     }
     __syncthreads();
@@ -151,6 +235,10 @@ k_backward(DevT T, int nkcap, int ldk, const double *__restrict__ Avals, const d
                 a -= ay[c * n + r] * ay[c * n + cidx] + as[c * n + r] * as[c * n + cidx];
                 val = fma(th, a, val);
             }
+            if (has_psd) {      // weighted rows of rotated PSD blocks / triples: H += theta_t a_t^T a_t
+                for (int t = (T.ns > 0 ? T.soff[0] : T.eoff); t < T.eoff + 3 * (T.nep + T.np); t++)
+                    if (rkind[t] == RK_MIX) val = fma(lamr[t] / (1 - lamr[t]), A[t * lda + r] * A[t * lda + cidx], val);
+            }
         } else if (r < n && cidx == NK) {   // f (computed above as one product with A^T)
             val = rx[r];
         } else if (r >= n && cidx == NK) {  // d_B  (filled below by the owning row / cone)
@@ -164,7 +252,7 @@ k_backward(DevT T, int nkcap, int ldk, const double *__restrict__ Avals, const d
         // instruction), upper-triangular 16 x 16 tiles over the waves, mirrored on store.  (Was n^2 scalar dot products over the cone rows.)
         typedef double v4d __attribute__((ext_vector_type(4)));
         double *wrow = qv2;                                    // per-row weight (free again: f has been formed)
-        for (int i = tid; i < m; i += NT) { const int c = (i >= z + T.l) ? T.rowcone[i] : -1; wrow[i] = (c >= 0 && ckind[c] == 2) ? cinfo[6 * c] / (1 - cinfo[6 * c]) : 0.0; }
+        for (int i = tid; i < m; i += NT) { const int c = (i >= z + T.l) ? T.rowcone[i] : -1; wrow[i] = (c >= 0 && ckind[c] == 2) ? cinfo[6 * c] / (1 - cinfo[6 * c]) : ((has_psd && i >= z + T.l && c < 0 && rkind[i] == RK_MIX) ? lamr[i] / (1 - lamr[i]) : 0.0); }
         __syncthreads();
         const int KT = (n + 15) / 16, wave = tid >> 6, lane = tid & 63, lg = lane >> 4, lc = lane & 15;
         const int i_first = z + T.l;                            // cone rows only
@@ -430,6 +518,45 @@ k_backward(DevT T, int nkcap, int ldk, const double *__restrict__ Avals, const d
         }
     }
     __syncthreads();
+    if (has_psd) {   // r~ in the rotated basis, then r_y,c = Q r~ = svec(U smat(r~) U^T)  /  W r~
+        for (int t = (T.ns > 0 ? T.soff[0] : T.eoff) + tid; t < T.eoff + 3 * (T.nep + T.np); t += NT) {
+            const int rk = rkind[t];
+            vv[t] = (rk == RK_EQ) ? bv[eqrow[t]] : (rk == RK_FREE ? dv[t] : (dv[t] - lamr[t] * qv2[t]) / (1 - lamr[t]));
+        }
+        __syncthreads();
+        for (int c = 0; c < T.ns; c++) {
+            const int k = T.sord[c], r0 = T.soff[c], d = k * (k + 1) / 2;
+            const double *Um = psdU + c * T.maxs * T.maxs;
+            double *X = psdScr, *W = X + T.maxs * T.maxs;
+            for (int idx = tid; idx < k * k; idx += NT) {
+                const int i = idx / k, j = idx - i * k, a = i >= j ? i : j, b = i >= j ? j : i;
+                const double v = vv[r0 + b * k - (b * (b - 1)) / 2 + (a - b)];
+                X[idx] = (a == b) ? v : v * M_SQRT1_2;
+            }
+            __syncthreads();
+            for (int idx = tid; idx < k * k; idx += NT) {           // W = U X
+                const int i = idx / k, j = idx - i * k;
+                double acc = 0; for (int a = 0; a < k; a++) acc = fma(Um[i * k + a], X[a * k + j], acc);
+                W[idx] = acc;
+            }
+            __syncthreads();
+            for (int pos = tid; pos < d; pos += NT) {               // T = W U^T
+                int b = 0, rem = pos; while (rem >= k - b) { rem -= k - b; b++; }
+                const int a = b + rem;
+                double acc = 0; for (int e = 0; e < k; e++) acc = fma(W[a * k + e], Um[b * k + e], acc);
+                vv[r0 + pos] = (a == b) ? acc : acc * M_SQRT2;
+            }
+            __syncthreads();
+        }
+        for (int c = tid; c < T.nep + T.np; c += NT) {                     // r_y,c = W r~
+            const int r0 = T.eoff + 3 * c;
+            const double *W = expW + 9 * c;
+            const double t0 = vv[r0], t1 = vv[r0 + 1], t2 = vv[r0 + 2];
+#pragma unroll
+            for (int a = 0; a < 3; a++) vv[r0 + a] = W[3 * a] * t0 + W[3 * a + 1] * t1 + W[3 * a + 2] * t2;
+        }
+        __syncthreads();
+    }
     // ---- outputs in the boundary convention: dA_eval = [-dA.data, db[b_idx]], dq_eval = [dc, 0]
     //      dA_ij = x_j r_y,i - y_i r_x,j ; db = -r_y ; dc = -r_x     (r_tau pinned to 0)
     for (int k = tid; k < T.nnz_aug; k += NT) {

@@ -5,6 +5,7 @@ namespace {
 #include "ce_expcone.h"
 #include "ce_forward_rt.h"        // group_reduce / DPP helpers
 #include "ce_global_mv.h"
+#include "ce_forward_v2.h"        // (psd_jacobi: the workgroup-parallel Jacobi eigensolver shared with k_fwd2<PSD> / k_backward_rt<PSD>)
 #include "ce_backward.h"
 }  // namespace
 

@@ -134,6 +134,7 @@ static size_t bwd_lds_bytes(const DevT &T, bool a_lds, bool k_lds, int nkcap, in
     if (a_lds) d += (size_t)m * T.lda;
     if (k_lds) d += (size_t)nkcap * ldk;
     d += 5 * (size_t)m + 2 * (size_t)n + 2 * (size_t)nqs * n + 6 * nqs + PB + NW * 8;
+    if (T.ns > 0 || T.nep + T.np > 0) d += (size_t)T.ns * T.maxs * T.maxs + (size_t)T.ns * T.maxs + m + 2 * (size_t)NW * T.maxs * T.maxs + 2 * T.maxs + 8 + 9 * (size_t)(T.nep + T.np);      // ce_backward.h carve
     if (!k_lds && panel) d += generic_lu_panel_doubles(nkcap);
     size_t ints = 2 * (size_t)m + 2 * nqs + 2 * (size_t)nkcap + 4;      // (perm + colrow)
     return d * 8 + ints * 4 + 16;
@@ -568,7 +569,7 @@ int ce_vjp_qp(ce_handle h, int B, const double *A_vals, long sA_k, long sA_b, co
     HIPCHK(hipSetDevice(h->device));
     hipStream_t st = (hipStream_t)stream;
     const DevT &T = h->T;
-    if ((T.ns > 0 || T.nep + T.np > 0) && (h->bwd_mode != 3 || !BRT_HAS_PSD)) { g_err = "PSD / exponential cones: adjoint not available for this template size"; return CE_E_UNSUPPORTED; }
+    if ((T.ns > 0 || T.nep + T.np > 0) && h->bwd_mode == 3 && !BRT_HAS_PSD) { g_err = "PSD / exponential cones: the register-tiled adjoint was built without them"; return CE_E_UNSUPPORTED; }
     const double *Abm = nullptr;
     int rc;
     if (A_vals) { rc = to_batch_major(h, B, A_vals, sA_k, sA_b, st, &Abm); if (rc) return rc; }

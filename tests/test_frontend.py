@@ -182,11 +182,13 @@ def test_sdp_min_eigenvector_value_dual_and_gradient():
 
 
 @pytest.mark.gpu
-def test_logistic_regression_layer_through_the_exponential_cone():
+@pytest.mark.parametrize("N", [12, 40])
+def test_logistic_regression_layer_through_the_exponential_cone(N):
     """The logistic-regression layer of reference tests/test_torch.py:158-230: data Z = lab * X is the parameter, the fitted
-    weights come back; the gradient of sum(w*) wrt the data is checked against autograd through an unrolled Newton solve."""
+    weights come back; the gradient of sum(w*) wrt the data is checked against autograd through an unrolled Newton solve.
+    N = 12: the register / LDS-resident kernels; N = 40 (80 exponential cones, per-instance A well beyond their sizes): the size-generic kernels."""
     rng = np.random.default_rng(1)
-    N, d, lam = 12, 3, 0.5
+    d, lam = 3, 0.5
     X = rng.standard_normal((N, d)); lab = np.sign(X @ np.array([1.0, -2.0, 0.5]) + 0.3 * rng.standard_normal(N))
 
     def builder(Z):

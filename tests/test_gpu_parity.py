@@ -618,3 +618,15 @@ def test_every_cone_type_on_the_size_generic_forward_kernel(cones, n):
     eng = run_parity(n, cones, 4, seed=21, eps=1e-9, max_iters=200000)
     info = eng.launch_info()
     assert info["fwd_mode"] in (0, 1, 2) and info["bwd_mode"] == 3, info
+
+
+@pytest.mark.parametrize("cones,n", [({"z": 5, "l": 40, "q": [], "s": [14]}, 100),                                     # m = 150: dense A (120 KB) + the PSD scratch exceed the register-tiled adjoint's LDS
+                                     ({"z": 0, "l": 30, "q": [7], "s": [], "ep": 60}, 120),                            # n = 120, m = 217: sixty exponential cones
+                                     ({"z": 3, "l": 80, "q": [9, 5], "s": [8, 5], "ep": 10, "p": [0.25, -0.5]}, 118)])  # every cone type, two PSD blocks, m = 184
+def test_every_cone_type_on_the_size_generic_kernels_forward_and_backward(cones, n):
+    """Beyond the register-tiled adjoint as well (n > 112, or A + the PSD scratch beyond LDS): the size-generic backward kernel rotates PSD blocks and
+    triples into the eigenbasis of their projection's derivative (the construction of k_backward_rt<PSD>, with A possibly in global memory) -- no
+    CE_E_UNSUPPORTED left for per-instance templates with these cones."""
+    eng = run_parity(n, cones, 3, seed=23, eps=1e-9, max_iters=200000)
+    info = eng.launch_info()
+    assert info["fwd_mode"] in (0, 1, 2) and info["bwd_mode"] in (0, 1, 2), info
