@@ -12,6 +12,11 @@
 //
 // Cones: zero / nonnegative / second-order / PSD / exponential / 3-d power.
 #pragma once
+#ifdef CE_TIMING   // debug build: shader cycles per phase of the LSQR iteration (thread 0, in registers), written over the first entries of the instance's dA row
+#define LS_T(k) do { const long long t1_ = __builtin_readcyclecounter(); ls_tacc[k] += t1_ - ls_t0; ls_t0 = t1_; } while (0)
+#else
+#define LS_T(k) do { } while (0)
+#endif
 #include "ce_shared_a_ops.h"
 
 struct SaStruct {            // sparse structure of the template's A part (device arrays, built once per engine)
@@ -206,19 +211,25 @@ k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, cons
             __syncthreads();
             sa_fused_pass<NT, RP>(F.AdT, n, wyd, xin,
                                   [&](int j, int k8) { double acc = 0; for (int k = F.scol_ptr[j] + k8; k < F.scol_ptr[j + 1]; k += 8) { const int i = F.scol_row[k]; acc = fma(F.srow_val[i], yin[i], acc); } return acc; },
-                                  fx, part);
+                                  fx, part, F.sing_i, F.sing_v, yin);
             __syncthreads();
-            for (int i = tid; i < m; i += NT) {
-                const int c = F.srow_col[i];
-                if (c >= 0) fy(i, F.srow_val[i] * xin[c]);
-                else {
-                    const int a = F.rowslot[i];                  // slot of a dense row, -1: empty row
-                    double s_ = 0;
-                    if (a >= 0) {
+            for (int i0 = tid; i0 < m; i0 += 4 * NT) {          // four rows per step: their index / value loads (global memory) are requested together
+                int cc[4], aa[4]; double sv4[4];
 #pragma unroll
-                        for (int w = 0; w < NW; w++) s_ += part[w * RP + a];
+                for (int u = 0; u < 4; u++) { const int i = min(i0 + u * NT, m - 1); cc[u] = F.srow_col[i]; aa[u] = F.rowslot[i]; sv4[u] = F.srow_val[i]; }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int i = i0 + u * NT;
+                    if (i >= m) break;
+                    if (cc[u] >= 0) fy(i, sv4[u] * xin[cc[u]]);
+                    else {
+                        double s_ = 0;                               // slot of a dense row, -1: empty row
+                        if (aa[u] >= 0) {
+#pragma unroll
+                            for (int w = 0; w < NW; w++) s_ += part[w * RP + aa[u]];
+                        }
+                        fy(i, s_);
                     }
-                    fy(i, s_);
                 }
             }
             __syncthreads();
@@ -259,14 +270,21 @@ k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, cons
     double rhobar = alfa, phibar = beta, anorm = 0, xxnorm = 0, zz = 0, cs2 = -1, sn2 = 0;
     bool live = bnorm > 0 && alfa * beta > 0;
     int itn = 0;
+#ifdef CE_TIMING
+    long long ls_tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ls_t0 = __builtin_readcyclecounter();
+#endif
     while (live && itn < itn_lim) {
         itn++;
+        LS_T(7);
         // (tx, ty) = N v :  tx = -A^T vy ;  ty = DPi(A vx - vy) + vy ;   u-hat = t - alfa u
         acc = 0;
         both_products(vy, vx, [&](int j, double a) { const double v = -a - alfa * ux[j]; ux[j] = v; acc = fma(v, v, acc); },
                       [&](int i, double a) { ty[i] = a - vy[i]; });
+        LS_T(0);
         dproj(ty, 1.0, [&](int i, double o) { const double v = o + vy[i] - alfa * uy[i]; uy[i] = v; acc = fma(v, v, acc); });
+        LS_T(1);
         beta = sqrt(sum_all(acc));
+        LS_T(2);
         ib = 1.0 / safe(beta);
         anorm = sqrt(anorm * anorm + alfa * alfa + beta * beta);
         // u = u-hat / beta ;  q = DPi(uy) ;  (tx, ty) = N^T u ;  v-hat = t - beta v
@@ -275,10 +293,13 @@ k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, cons
         if (ntri > 0) __syncthreads();
         for (int i = tid; i < m; i += NT) uy[i] *= ib;
         __syncthreads();
+        LS_T(3);
         acc = 0;
         both_products(qv, ux, [&](int j, double a) { const double v = a - beta * vx[j]; vx[j] = v; acc = fma(v, v, acc); },
                       [&](int i, double a) { const double v = -a - qv[i] + uy[i] - beta * vy[i]; vy[i] = v; acc = fma(v, v, acc); });
+        LS_T(4);
         alfa = sqrt(sum_all(acc));
+        LS_T(5);
         const double rho = sqrt(rhobar * rhobar + beta * beta);
         const double cs_ = rhobar / safe(rho), sn = beta / safe(rho);
         const double theta = sn * alfa; rhobar = -cs_ * alfa; const double phi = cs_ * phibar; phibar = sn * phibar; const double tau = sn * phi;
@@ -286,6 +307,7 @@ k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, cons
         for (int j = tid; j < n; j += NT) { const double v = vx[j] * ia, w = wx[j]; vx[j] = v; rx[j] += t1 * w; wx[j] = v + t2 * w; }
         for (int i = tid; i < m; i += NT) { const double v = vy[i] * ia, w = wy[i]; vy[i] = v; ry[i] += t1 * w; wy[i] = v + t2 * w; }
         __syncthreads();
+        LS_T(6);
         const double delta = sn2 * rho, gambar = -cs2 * rho, rhs = phi - delta * zz, zbar = rhs / safe(fabs(gambar)) * (gambar > 0 ? 1.0 : (gambar < 0 ? -1.0 : 0.0));
         const double xnorm = sqrt(xxnorm + zbar * zbar);
         const double gamma = sqrt(gambar * gambar + theta * theta);
@@ -304,5 +326,9 @@ k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, cons
         dA[k] = (c < n) ? -(x[c] * ry[r] - y[r] * rx[c]) : -ry[r];
     }
     for (int j = tid; j <= n; j += NT) dqo[j * sdqk + inst * sdqb] = (j < n) ? -rx[j] : 0.0;
+#ifdef CE_TIMING
+    __syncthreads();
+    if (tid == 0) for (int k = 0; k < 8; k++) dA[k] = (double)ls_tacc[k];
+#endif
     if (tid == 0) { if (adj_status) adj_status[inst] = live ? 1 : 0; if (iters_o) iters_o[inst] = itn; }
 }

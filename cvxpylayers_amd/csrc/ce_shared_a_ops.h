@@ -13,6 +13,8 @@ struct SaSplit {
     const double *srow_val;
     const int *scol_ptr, *scol_row;
     const int *rowslot;          // [m] slot a of a dense row, -1 otherwise
+    const int *sing_i;           // [n] the singleton row of column j when it has exactly one (the rule: bounds, -I embeddings), -1: none, -2: several (walk scol_ptr / scol_row)
+    const double *sing_v;        // [n] its value (filled with srow_val by k_sa_fill_split)
 };
 
 // out[a] = sum_j AdT[j][a] xin[j]  (a < RP).  Thread (a-pair, g) sums rows j = g, g + ng, ... with eight 16-byte loads in flight (RP / 2 lanes
@@ -75,8 +77,12 @@ __device__ __forceinline__ void sa_rows_dot(const double *__restrict__ AdT, int 
 // v[a] = sum_j AdT[j][a] xin[j]:  part[wave * RP + a], to be summed over the NTH / 64 waves by the caller after a barrier.  Lane layout of
 // sa_rows_dot (eight lanes per row, lane k holds a = 16 i + 2 k, 16 i + 2 k + 1); every lane accumulates its 2 RP / 16 entries of v over the
 // rows it visits, the eight row groups of a wave are folded with three shuffles per entry.  No trailing barrier.
+// sing_i / sing_v / yin (may be null): the singleton part of column j is  sing_v[j] * yin[sing_i[j]]  when the column has exactly one singleton row -- two loads that
+// depend on j only and are requested with the row's matrix loads, instead of the three-level chain scol_ptr -> scol_row -> srow_val inside extra() that every row
+// group used to wait for (config 5: 33 k of an 81 k-cycle LSQR iteration per product).  extra() still serves columns with several singleton rows.
 template <int NTH, int RP, class FE, class FO>
-__device__ __forceinline__ void sa_fused_pass(const double *__restrict__ AdT, int n, const double *w, const double *xin, FE &&extra, FO &&out, double *part) {
+__device__ __forceinline__ void sa_fused_pass(const double *__restrict__ AdT, int n, const double *w, const double *xin, FE &&extra, FO &&out, double *part,
+                                              const int *__restrict__ sing_i = nullptr, const double *__restrict__ sing_v = nullptr, const double *yin = nullptr) {
     constexpr int NL = RP / 16, RS = NTH / 8, UR = RP == 64 ? 2 : 4;      // rows in flight per lane (RP = 64: two, the accumulators need the registers)
     const int tid = threadIdx.x, k8 = tid & 7;
     const double2 *w2 = reinterpret_cast<const double2 *>(w) + k8;
@@ -85,19 +91,22 @@ __device__ __forceinline__ void sa_fused_pass(const double *__restrict__ AdT, in
     for (int i = 0; i < NL; i++) vacc[i] = double2{0.0, 0.0};
     for (int j0 = tid >> 3; j0 < n; j0 += UR * RS) {
         double2 rv[UR][NL];
+        int si[UR]; double sv[UR];
 #pragma unroll
         for (int u = 0; u < UR; u++) {
             const int j = j0 + u * RS, jc = j < n ? j : n - 1;
             const double2 *row = reinterpret_cast<const double2 *>(AdT + (size_t)jc * RP) + k8;
 #pragma unroll
             for (int i = 0; i < NL; i++) rv[u][i] = row[8 * i];
+            si[u] = sing_i ? sing_i[jc] : -2; sv[u] = sing_i ? sing_v[jc] : 0.0;
         }
 #pragma unroll
         for (int u = 0; u < UR; u++) {
             const int j = j0 + u * RS;
             const bool ok = j < n;
             const double xv = ok ? xin[j] : 0.0;
-            double a0 = ok ? extra(j, k8) : 0.0, a1 = 0;
+            double a0 = 0, a1 = 0;
+            if (ok) { if (si[u] >= 0) a0 = (k8 == 0) ? sv[u] * yin[si[u]] : 0.0; else if (si[u] == -2) a0 = extra(j, k8); }
 #pragma unroll
             for (int i = 0; i < NL; i++) {
                 const double2 wv = w2[8 * i];
@@ -141,9 +150,11 @@ __device__ __forceinline__ void sa_AT_times(const ST &F, int n, const double *yi
 // fills A_d^T and the singleton values of a split from the boundary's value order (solver sign: A = -A_cvx); one thread per entry.
 // AdT must be zeroed beforehand.  rowslot[i]: slot a of a dense row, -1 for a singleton / empty row.
 __global__ void k_sa_fill_split(int nnzA, int RP, const int *__restrict__ rowidx, const int *__restrict__ colidx, const int *__restrict__ rowslot,
-                                const double *__restrict__ vals, double *__restrict__ AdT, double *__restrict__ srow_val) {
+                                const double *__restrict__ vals, double *__restrict__ AdT, double *__restrict__ srow_val,
+                                const int *__restrict__ sing_i = nullptr, double *__restrict__ sing_v = nullptr) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= nnzA) return;
     const int i = rowidx[k], a = rowslot[i];
-    if (a >= 0) AdT[(size_t)colidx[k] * RP + a] = -vals[k]; else srow_val[i] = -vals[k];
+    if (a >= 0) AdT[(size_t)colidx[k] * RP + a] = -vals[k];
+    else { srow_val[i] = -vals[k]; if (sing_i && sing_i[colidx[k]] == i) sing_v[colidx[k]] = -vals[k]; }
 }

@@ -74,7 +74,7 @@ struct ce_engine {
     double *d_aa_ws = nullptr; size_t aa_ws_bytes = 0;   // Anderson-acceleration history of the shared-A forward kernel ([B][5][lp])
     unsigned long long *d_psd_stats = nullptr;     // CE_PSD_STATS=1: counters of the PSD projection (printed to stderr by ce_destroy)   // MaxDynamicSharedMemorySize is per device: set once per engine (an engine is bound to one device, one caller thread)
     int psd_first = 0;           // first row of the first PSD block (m when the template has none)
-    int *d_sp_drow = nullptr, *d_sp_srow_col = nullptr, *d_sp_scol_ptr = nullptr, *d_sp_scol_row = nullptr, *d_sp_rowslot = nullptr;
+    int *d_sp_drow = nullptr, *d_sp_srow_col = nullptr, *d_sp_scol_ptr = nullptr, *d_sp_scol_row = nullptr, *d_sp_rowslot = nullptr, *d_sp_sing_i = nullptr; double *d_sp_sing_v = nullptr;
     double *d_sp_AdT = nullptr, *d_sp_sval = nullptr;
     bool wl = false; int wl_nq = 0; int *d_row_perm = nullptr, *d_k_rowcone = nullptr, *d_k_qoff = nullptr;   // rows packed so that cones are wave-local (k_fwd2 WL)
     int brt_variant = -1;                          // register-tiled backward kernel variant (-1: generic kernel)
@@ -329,7 +329,10 @@ int ce_create(const ce_template *tpl, int device, ce_handle *out) {
             for (int i = 0; i < tpl->m; i++) if (srow_col[i] >= 0) scol_row[sfill[srow_col[i]]++] = i;
             if (drow.empty()) drow.push_back(0);
             auto up = [&](int **dst, const std::vector<int> &v) -> int { HIPCHK(hipMalloc(dst, sizeof(int) * v.size())); HIPCHK(hipMemcpy(*dst, v.data(), sizeof(int) * v.size(), hipMemcpyHostToDevice)); return 0; };
-            if (up(&h->d_sp_drow, drow) || up(&h->d_sp_srow_col, srow_col) || up(&h->d_sp_scol_ptr, scol_ptr) || up(&h->d_sp_scol_row, scol_row) || up(&h->d_sp_rowslot, rowslot)) return CE_E_HIP;
+            std::vector<int> sing_i(std::max(tpl->n, 1), -1);      // the one singleton row of a column (-1: none, -2: several)
+            for (int j = 0; j < tpl->n; j++) { const int cnt = scol_ptr[j + 1] - scol_ptr[j]; sing_i[j] = cnt == 1 ? scol_row[scol_ptr[j]] : (cnt == 0 ? -1 : -2); }
+            if (up(&h->d_sp_drow, drow) || up(&h->d_sp_srow_col, srow_col) || up(&h->d_sp_scol_ptr, scol_ptr) || up(&h->d_sp_scol_row, scol_row) || up(&h->d_sp_rowslot, rowslot) || up(&h->d_sp_sing_i, sing_i)) return CE_E_HIP;
+            HIPCHK(hipMalloc(&h->d_sp_sing_v, sizeof(double) * std::max(tpl->n, 1)));
             HIPCHK(hipMalloc(&h->d_sp_AdT, sizeof(double) * (size_t)std::max(tpl->n, 1) * h->sp_RP));
             HIPCHK(hipMalloc(&h->d_sp_sval, sizeof(double) * std::max(tpl->m, 1)));
         }
@@ -450,7 +453,7 @@ int ce_destroy(ce_handle h) {
     hipSetDevice(h->device);
     hipFree(h->d_rowidx); hipFree(h->d_colidx); hipFree(h->d_rowcone); hipFree(h->d_qoff); hipFree(h->d_soff); hipFree(h->d_sord); hipFree(h->d_pw); hipFree(h->d_idx_p); hipFree(h->d_pmap); hipFree(h->d_prow); hipFree(h->d_pcol);
     hipFree(h->wsA); hipFree(h->wsdA); hipFree(h->gws); hipFree(h->d_idx_at); hipFree(h->d_idx_ar); hipFree(h->d_idx_b); hipFree(h->d_row_perm); hipFree(h->d_k_rowcone); hipFree(h->d_k_qoff); hipFree(h->d_csc_ptr); hipFree(h->d_csr_ptr); hipFree(h->d_csr_col); hipFree(h->d_csr_src);
-    hipFree(h->d_sp_drow); hipFree(h->d_sp_srow_col); hipFree(h->d_sp_scol_ptr); hipFree(h->d_sp_scol_row); hipFree(h->d_sp_rowslot); hipFree(h->d_sp_AdT); hipFree(h->d_sp_sval); hipFree(h->d_aa_ws); hipFree(h->d_summary);
+    hipFree(h->d_sp_drow); hipFree(h->d_sp_srow_col); hipFree(h->d_sp_scol_ptr); hipFree(h->d_sp_scol_row); hipFree(h->d_sp_rowslot); hipFree(h->d_sp_sing_i); hipFree(h->d_sp_sing_v); hipFree(h->d_sp_AdT); hipFree(h->d_sp_sval); hipFree(h->d_aa_ws); hipFree(h->d_summary);
     for (auto &v : h->ev) for (auto &p : v) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
     if (h->d_psd_stats) {
         unsigned long long c[16] = {0};
@@ -759,11 +762,12 @@ int ce_vjp_shared_a(ce_handle h, int B, const double *A_vals0, const double *x, 
         h->sa_lsqr_attr = true;
     }
     SaStruct S{h->d_csc_ptr, h->d_rowidx, h->d_csr_ptr, h->d_csr_col, h->d_csr_src, T.nnzA};
-    SaSplit F{h->sp_r, RP, h->d_sp_AdT, h->d_sp_drow, h->d_sp_srow_col, h->d_sp_sval, h->d_sp_scol_ptr, h->d_sp_scol_row, h->d_sp_rowslot};
+    SaSplit F{h->sp_r, RP, h->d_sp_AdT, h->d_sp_drow, h->d_sp_srow_col, h->d_sp_sval, h->d_sp_scol_ptr, h->d_sp_scol_row, h->d_sp_rowslot, h->d_sp_sing_i, h->d_sp_sing_v};
     if (RP > 0) {      // the values may differ between calls: refill A_d^T / singleton values from this call's A (n RP + m doubles)
         HIPCHK(hipMemsetAsync(h->d_sp_AdT, 0, sizeof(double) * (size_t)T.n * RP, (hipStream_t)stream));
         HIPCHK(hipMemsetAsync(h->d_sp_sval, 0, sizeof(double) * T.m, (hipStream_t)stream));
-        if (T.nnzA > 0) hipLaunchKernelGGL(k_sa_fill_split, dim3((T.nnzA + 255) / 256), dim3(256), 0, (hipStream_t)stream, T.nnzA, RP, h->d_rowidx, h->d_colidx, h->d_sp_rowslot, A_vals0, h->d_sp_AdT, h->d_sp_sval);
+        HIPCHK(hipMemsetAsync(h->d_sp_sing_v, 0, sizeof(double) * T.n, (hipStream_t)stream));
+        if (T.nnzA > 0) hipLaunchKernelGGL(k_sa_fill_split, dim3((T.nnzA + 255) / 256), dim3(256), 0, (hipStream_t)stream, T.nnzA, RP, h->d_rowidx, h->d_colidx, h->d_sp_rowslot, A_vals0, h->d_sp_AdT, h->d_sp_sval, h->d_sp_sing_i, h->d_sp_sing_v);
     }
     {
         ProfScope ps(h, 1, (hipStream_t)stream);

@@ -29,3 +29,16 @@ for k, nm in ((0, "refresh (per iteration share)"), (1, "phi.w + wyd + t' gather
               (5, "elementwise ut / cone input"), (6, "cones (SOC / PSD / exp)"), (7, "project + update (fast path)"), (8, "check iterations (residual products etc., per iteration share)")):
     print(f"  {nm:62s} {per_iter[:, k].mean():10.1f} cycles / iteration")
 print(f"  {'sum':62s} {per_iter[:, :9].sum(axis=1).mean():10.1f}")
+
+# ---- adjoint (k_sa_lsqr): cycles per phase of one LSQR iteration
+dx = torch.ones_like(x); dy = torch.zeros_like(y)
+dA, dq, adj = eng.vjp(A_bm, x, y, s, dx, dy, path="const_a")
+torch.cuda.synchronize()
+li = getattr(eng, "last_lsqr_iters", None)
+li = li.cpu().numpy().astype(float)[:, None] if li is not None else np.ones((B, 1))
+t = dA.t()[:, :8].cpu().numpy() / li
+print("k_sa_lsqr: LSQR iterations mean", float(li.mean()))
+for k, nm in ((0, "N v: both products (fused pass over A_d^T + row loop)"), (1, "cone derivative D Pi (A vx - vy) + u-hat"), (2, "|u-hat| (block reduce)"),
+              (3, "u scaling + q = D Pi(u_y)"), (4, "N^T u: both products"), (5, "|v-hat| (block reduce)"), (6, "v, w, r updates"), (7, "scalar recurrences / loop top")):
+    print(f"  {nm:62s} {t[:, k].mean():10.1f} cycles / LSQR iteration")
+print(f"  {'sum':62s} {t.sum(axis=1).mean():10.1f}")
