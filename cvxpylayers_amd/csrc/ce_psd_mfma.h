@@ -39,13 +39,21 @@ __device__ __forceinline__ void psd_rotation(double app, double aqq, double apq,
 
 // D = A B on KT x KT tiles of 16 x 16; fa(M, K), fb(K, N): operand elements, out(M, N, v): result sink.  All waves of the workgroup call it.
 template <int NTH, class FA, class FB, class FO>
-__device__ __forceinline__ void psd_mfma_gemm(int KT, FA &&fa, FB &&fb, FO &&out) {
+__device__ __forceinline__ void psd_mfma_gemm(int KT, FA &&fa, FB &&fb, FO &&out, int ks = 0) {
+    // ks: contraction steps that carry data ((k + 3) / 4 for a k x k block in zero-padded storage; 0: all 4 KT).  The operands of five steps are requested together, then
+    // the five MFMAs run back to back (a plain loop waits one LDS round trip per MFMA, eight per tile at KT = 2); a step past ks multiplies by a zero A operand.
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, lg = lane >> 4, lc = lane & 15;
+    const int nst = ks > 0 ? ks : 4 * KT, smax = 4 * KT - 1;
     for (int t = wave; t < KT * KT; t += NTH / 64) {
         const int ti = t / KT, tj = t - ti * KT;
         psd_v4d acc = {0.0, 0.0, 0.0, 0.0};
-        for (int s = 0; s < 4 * KT; s++)
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(fa(16 * ti + lc, 4 * s + lg), fb(4 * s + lg, 16 * tj + lc), acc, 0, 0, 0);
+        for (int s0 = 0; s0 < nst; s0 += 5) {
+            double a[5], b[5];
+#pragma unroll
+            for (int u = 0; u < 5; u++) { const int sc = min(s0 + u, smax); a[u] = fa(16 * ti + lc, 4 * sc + lg); b[u] = fb(4 * sc + lg, 16 * tj + lc); if (s0 + u >= nst) a[u] = 0.0; }
+#pragma unroll
+            for (int u = 0; u < 5; u++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
+        }
 #pragma unroll
         for (int r = 0; r < 4; r++) out(16 * ti + lg + 4 * r, 16 * tj + lc, acc[r]);
     }
@@ -149,17 +157,15 @@ __device__ __forceinline__ void psd_gemm_kk(int k, const double *pA, int sAm, in
         for (int s0 = 0; s0 < KS; s0 += CH) {
             double a[CH], b[CH];
 #pragma unroll
-            for (int u = 0; u < CH; u++) {
-                const int st = s0 + u, kk = 4 * st + lg;
-                if (st < KS) {                                     // uniform
-                    const int kc = (kk < k) ? 4 * st : (k - 1 - lg);       // clamped contraction index (relative to the lane's lg)
-                    a[u] = qa[kc * sAk]; b[u] = qb[kc * sBk];
-                    if (qw) a[u] *= fmax(qw[kc], 0.0);            // (wK: eigenvalues; the product wants their positive parts)
-                    if (kk >= k) a[u] = 0.0;
-                } else { a[u] = 0.0; b[u] = 0.0; }
+            for (int u = 0; u < CH; u++) {       // branch-free: every operand of the chunk is requested before the first MFMA (a guarded step is a scalar branch around
+                const int st = s0 + u, kk = 4 * st + lg;                   // its loads AND its MFMA: one LDS round trip per MFMA); a step past k multiplies by a zero A operand
+                const int kc = (kk < k) ? 4 * st : (k - 1 - lg);           // clamped contraction index (relative to the lane's lg)
+                a[u] = qa[kc * sAk]; b[u] = qb[kc * sBk];
+                if (qw) a[u] *= fmax(qw[kc], 0.0);                         // (wK: eigenvalues; the product wants their positive parts)
+                if (kk >= k) a[u] = 0.0;
             }
 #pragma unroll
-            for (int u = 0; u < CH; u++) if (s0 + u < KS) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
+            for (int u = 0; u < CH; u++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
         }
 #pragma unroll
         for (int r = 0; r < 4; r++) { const int M = 16 * ti + lg + 4 * r; if (M < k && bn < k) out(M, bn, acc[r]); }
@@ -206,28 +212,32 @@ __device__ __forceinline__ int psd_refine_loop_fused(int k, int P, const double 
     for (int it = 0; it < maxl; it++) {
         psd_v4d aD = {0.0, 0.0, 0.0, 0.0}, aG = {0.0, 0.0, 0.0, 0.0};         // D tile, (V^T V) tile
         if (has_tile) {
-            // contraction index of step u for this lane: 4 u + lg, clamped to k - 1; steps beyond k contribute zero through the A operand
-            double bv[KSM];
-#pragma unroll
-            for (int u = 0; u < KSM; u++) if (u < KS) bv[u] = Va[min(4 * u + lg, k - 1) * P + bnc];
-            psd_v4d aT0 = {0.0, 0.0, 0.0, 0.0}, aT1 = {0.0, 0.0, 0.0, 0.0};
+            // contraction index of step u for this lane: 4 u + lg, clamped to k - 1; steps beyond k contribute zero through the A operand.  ALL operands of the phase are
+            // requested up front and every step runs unconditionally (a step past k multiplies by a zero A operand): guarded steps (`if (u < KS)`, a scalar branch around
+            // each MFMA) made every MFMA wait for its own LDS round trip -- ten in a row for T, five more for D / R
+            double bv[KSM], a0[KSM], a1[KSM], av[KSM];
             {
-                const double *srow = Sm + min(lc, k - 1) * P;
+                const double *srow = Sm + min(lc, k - 1) * P, *srow1 = Sm + min(16 + lc, k - 1) * P;
 #pragma unroll
-                for (int u = 0; u < KSM; u++) if (u < KS) { const int kk = 4 * u + lg; const double a = (kk < k) ? srow[min(kk, k - 1)] : 0.0; aT0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv[u], aT0, 0, 0, 0); }
-                if (KT == 2) {
-                    const double *srow1 = Sm + min(16 + lc, k - 1) * P;
-#pragma unroll
-                    for (int u = 0; u < KSM; u++) if (u < KS) { const int kk = 4 * u + lg; const double a = (kk < k) ? srow1[min(kk, k - 1)] : 0.0; aT1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv[u], aT1, 0, 0, 0); }
+                for (int u = 0; u < KSM; u++) {
+                    const int kc = min(4 * u + lg, k - 1);
+                    bv[u] = Va[kc * P + bnc]; a0[u] = srow[kc]; a1[u] = (KT == 2) ? srow1[kc] : 0.0; av[u] = Va[kc * P + amc];
                 }
+#pragma unroll
+                for (int u = 0; u < KSM; u++) if (4 * u + lg >= k) { a0[u] = 0.0; a1[u] = 0.0; av[u] = 0.0; }
+            }
+            psd_v4d aT0 = {0.0, 0.0, 0.0, 0.0}, aT1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int u = 0; u < KSM; u++) aT0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], bv[u], aT0, 0, 0, 0);
+            if (KT == 2) {
+#pragma unroll
+                for (int u = 0; u < KSM; u++) aT1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], bv[u], aT1, 0, 0, 0);
             }
 #pragma unroll
-            for (int u = 0; u < KSM; u++) if (u < KS) {
-                const int kk = 4 * u + lg;
-                const double av = (kk < k) ? Va[min(kk, k - 1) * P + amc] : 0.0;
+            for (int u = 0; u < KSM; u++) {
                 const double tb = (u < 4) ? aT0[u & 3] : aT1[u & 3];
-                aD = __builtin_amdgcn_mfma_f64_16x16x4f64(av, tb, aD, 0, 0, 0);
-                aG = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv[u], aG, 0, 0, 0);
+                aD = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], tb, aD, 0, 0, 0);
+                aG = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], aG, 0, 0, 0);
             }
             if (ti == tj) {
 #pragma unroll

@@ -180,13 +180,13 @@ k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, cons
                 Hm[i * P + j] = sv;
             }
             __syncthreads();
-            psd_mfma_gemm<NT>(KT, [&](int M, int K) { return Hm[K * P + M]; }, [&](int K, int N) { return U[K * P + N]; }, [&](int M, int N, double v) { Ym[M * P + N] = v; });   // H U
+            psd_mfma_gemm<NT>(KT, [&](int M, int K) { return Hm[K * P + M]; }, [&](int K, int N) { return U[K * P + N]; }, [&](int M, int N, double v) { Ym[M * P + N] = v; }, (k + 3) >> 2);   // H U
             __syncthreads();
-            psd_mfma_gemm<NT>(KT, [&](int M, int K) { return U[K * P + M]; }, [&](int K, int N) { return Ym[K * P + N]; }, [&](int M, int N, double v) { Hm[M * P + N] = v * Bc[M * P + N]; });   // B o (U^T H U)
+            psd_mfma_gemm<NT>(KT, [&](int M, int K) { return U[K * P + M]; }, [&](int K, int N) { return Ym[K * P + N]; }, [&](int M, int N, double v) { Hm[M * P + N] = v * Bc[M * P + N]; }, (k + 3) >> 2);   // B o (U^T H U)
             __syncthreads();
-            psd_mfma_gemm<NT>(KT, [&](int M, int K) { return U[M * P + K]; }, [&](int K, int N) { return Hm[K * P + N]; }, [&](int M, int N, double v) { Ym[M * P + N] = v; });   // U Y
+            psd_mfma_gemm<NT>(KT, [&](int M, int K) { return U[M * P + K]; }, [&](int K, int N) { return Hm[K * P + N]; }, [&](int M, int N, double v) { Ym[M * P + N] = v; }, (k + 3) >> 2);   // U Y
             __syncthreads();
-            psd_mfma_gemm<NT>(KT, [&](int M, int K) { return Ym[M * P + K]; }, [&](int K, int N) { return U[N * P + K]; }, [&](int M, int N, double v) { Hm[M * P + N] = v; });   // (U Y) U^T
+            psd_mfma_gemm<NT>(KT, [&](int M, int K) { return Ym[M * P + K]; }, [&](int K, int N) { return U[N * P + K]; }, [&](int M, int N, double v) { Hm[M * P + N] = v; }, (k + 3) >> 2);   // (U Y) U^T
             __syncthreads();
             for (int idx = tid; idx < k * k; idx += NT) {          // lower triangle (a >= b) -> svec position
                 const int a = psd_fdiv(idx, 1.0f / (float)k), b = idx - a * k;
