@@ -505,6 +505,8 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
             double cv[TI];
 #pragma unroll
             for (int i = 0; i < TI; i++) cv[i] = cbuf[ra + BGR * i];
+#pragma unroll
+            for (int i = 0; i < TI; i++) asm volatile("" : "+v"(cv[i]));      // (pins the reads HERE: the optimiser otherwise sinks them below the free-variable branch, behind the record's round trip)
             const int prow = __builtin_amdgcn_readfirstlane(__double2loint(rec.y));
             const int ipv = prow / BGR;
             const double piv = rec.x;
