@@ -8,10 +8,12 @@ export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/$TAG
 mkdir -p "$OUT"
 has() { [[ " $STAGES " == *" $1 "* ]]; }
+# a broken box (first kernel of every process faults, then hangs until its timeout) once ate 25 GPU-minutes: check the device first and bail out
+if ! timeout 180 python -c "import torch; assert float(torch.ones(1024, device='cuda').sum().item()) == 1024.0" > "$OUT/device_check.log" 2>&1; then echo "device check FAILED: aborting the pass" | tee "$OUT/summary.txt"; tail -3 "$OUT/device_check.log"; exit 3; fi
 BENCH_ARGS=${BENCH_ARGS:-}
 if has tests; then
   echo "== pytest -m gpu" | tee "$OUT/summary.txt"
-  timeout ${TEST_TIMEOUT:-1500} python -m pytest tests -m gpu -q ${PYTEST_ARGS:--x} --durations=15 2>&1 | tail -40 | tee "$OUT/pytest.log" | tail -25 | tee -a "$OUT/summary.txt"
+  timeout ${TEST_TIMEOUT:-600} python -m pytest tests -m gpu -q ${PYTEST_ARGS:--x} --durations=15 2>&1 | tail -40 | tee "$OUT/pytest.log" | tail -25 | tee -a "$OUT/summary.txt"
   echo "== smoke" | tee -a "$OUT/summary.txt"
   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids | tail -3 | tee -a "$OUT/summary.txt"
 fi
