@@ -201,7 +201,7 @@ __device__ __forceinline__ int psd_refine_loop_fused(int k, int P, const double 
     (void)tk;
     constexpr int NW = NTH / 64, KSM = 5;                      // k <= 20: five contraction steps (the caller routes larger blocks to the LDS loop)
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, lg = lane >> 4, lc = lane & 15;
-    const int KT = (k + 15) >> 4, KS = (k + 3) >> 2;
+    const int KT = (k + 15) >> 4;
     const bool has_tile = wave < KT * KT;
     const int ti = (KT == 2) ? (wave >> 1) : 0, tj = (KT == 2) ? (wave & 1) : 0;
     const int am = 16 * ti + lc, bn = 16 * tj + lc, amc = min(am, k - 1), bnc = min(bn, k - 1);
