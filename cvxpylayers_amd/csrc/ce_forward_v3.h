@@ -20,7 +20,7 @@
 // Set-up (equilibration, S = rho I + A^T Dy A on the matrix cores, blocked Gauss-Jordan, g / phi) is k_fwd2's, on k_fwd2's tile
 // layouts, which are dead when the iteration tiles are materialised.  Iterates are those of k_fwd2 up to the summation order of the
 // products.  Shapes: plain cones, n <= 50, at most 8 second-order cones of <= 13 rows, m <= 104 after packing; everything else stays
-// on k_fwd2.  CE_FWD3=0 selects k_fwd2 for these shapes too (A/B switch).
+// on k_fwd2.  OPT-IN (CE_FWD3=1): on MI355X the iteration is not faster than k_fwd2 (see the measurements quoted in DESIGN.md).
 #pragma once
 
 template <int K>

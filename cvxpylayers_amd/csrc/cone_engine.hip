@@ -444,10 +444,10 @@ int ce_create(const ce_template *tpl, int device, ce_handle *out) {
         }
     }
     {   // third-generation forward kernel (ce_forward_v3.h): shapes of k_fwd2's variant 2 whose rows pack into 8 x 13 slots with one cone per pair of lane rows
-        const char *f3_env = getenv("CE_FWD3");                        // "0": stay on k_fwd2 (A/B switch)
+        const char *f3_env = getenv("CE_FWD3");                        // "1": run these templates on k_fwd3.  OPT-IN: measured on MI355X it does not beat k_fwd2 (profiles/r04/b_*, c_*)
         constexpr int YO3 = 13, NPAIR3 = 8, XO3 = 13, TY3 = 26, TA3 = 25, MS3 = YO3 * NPAIR3, LDG3 = 58;
         std::vector<int> ko, sr, sd;
-        if (h->fwd_mode == 4 && h->f2_variant == 2 && h->nnz_p == 0 && !(f3_env && !strcmp(f3_env, "0")) && T.n <= 2 * TA3 && T.n <= 4 * XO3 - 1 && pack_rows3(tpl, YO3, NPAIR3, ko, sr, sd)) {
+        if (h->fwd_mode == 4 && h->f2_variant == 2 && h->nnz_p == 0 && (f3_env && !strcmp(f3_env, "1")) && T.n <= 2 * TA3 && T.n <= 4 * XO3 - 1 && pack_rows3(tpl, YO3, NPAIR3, ko, sr, sd)) {
             const int *V = F2_VARIANTS[2];
             const int CHT = V[0], T1 = V[1], CHA = V[2], T2 = V[3], NTH = V[6];
             const int S1 = (T1 + 3) & ~3, S2 = (T2 + 3) & ~3, S3a = (TY3 + 3) & ~3, S3r = (TA3 + 3) & ~3;

@@ -38,6 +38,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <stdio.h>
+#include <malloc.h>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -829,12 +830,21 @@ int oc_num_threads(void) {
 #endif
 }
 
+/* The per-instance routines allocate their workspaces with calloc / malloc.  Blocks above glibc's mmap threshold (128 KB: the dense (n+m+1)^2 system of the
+ * adjoint, the Anderson history) would be mmap'ed and unmapped once per instance, and with many OpenMP threads those calls serialise on the process's
+ * address-space lock -- the timed CPU baseline then measures the kernel's mm lock, not the solver.  Keep them in the per-thread arenas instead. */
+static void tune_malloc(void) {
+    static int done = 0;
+    if (!done) { mallopt(M_MMAP_THRESHOLD, 256 << 20); mallopt(M_TRIM_THRESHOLD, 512 << 20); mallopt(M_TOP_PAD, 16 << 20); done = 1; }
+}
+
 /* A: [B][m][n] row-major dense, b: [B][m], c: [B][n]; outputs x [B][n], y,s [B][m], iters/status [B], resid [B][3] */
 int oc_solve_batch_qp(int B, int n, int m, const double *A, const double *b, const double *c, const double *Pq,
                       int z, int l, int nq, const int *q, int ns, const int *s, int nep, int np, const double *pw, const oc_opts *o,
                       double *x, double *y, double *sv, int *iters, int *status, double *resid, int nthreads) {
     oc_cones K = { z, l, nq, ns, q, s, nep, np, pw };
     if (cone_rows(&K) != m) return -1;
+    tune_malloc();
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
 #endif
@@ -861,6 +871,7 @@ int oc_adjoint_batch_qp(int B, int n, int m, const double *A, const double *b, c
                         double *dA, double *db, double *dc, double *dP, int *lsqr_iters, int nthreads) {
     oc_cones K = { z, l, nq, ns, q, s, nep, np, pw };
     if (cone_rows(&K) != m) return -1;
+    tune_malloc();
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
 #endif

@@ -1,0 +1,213 @@
+"""The BASELINE.json configurations at their STATED batch sizes, and the bench's exact solver settings against the oracle
+(VERDICT round 3, items 1a / 1b):
+
+  * config M with bench.py's solver_args (eps 1e-4, acceleration_lookback 10 -- SCS's default --, max_iters 10000) against the
+    oracle run with the SAME arguments (a ten-pair history there, the engine's one-pair history here): status, (x, y, s),
+    and the histogram of the per-instance iteration counts;
+  * C3 at B = 4096, C4 at B = 1024, C5 at B = 16384: the KKT certificate of EVERY instance (primal / dual residual, gap, cone
+    membership of s and y, complementarity), a random subset of 48 instances against the oracle (solution and adjoint), and the
+    kernel the shared-A configurations actually ran on.
+The oracle needs minutes for whole batches of these sizes, hence the subsets; the certificates are size-independent properties.
+Tolerances: solutions 1e-6 (1 + |.|_inf) at eps 1e-8, KKT residuals 50 eps, gradients 1e-5 relative."""
+import numpy as np
+import pytest
+import torch
+
+from cvxpylayers_amd import problems as P
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel_rows(a, b):
+    return np.abs(a - b).max(axis=1) / (1.0 + np.abs(b).max(axis=1))
+
+
+def _engine(tpl, cones):
+    from cvxpylayers_amd.interfaces.mi355_if import ConeEngine
+    return ConeEngine(tpl.indices, tpl.indptr, tpl.n, tpl.m, cones, torch.device("cuda", 0))
+
+
+def _db_from_dA(tpl, dA_np, B):
+    cols = np.repeat(np.arange(tpl.n + 1), np.diff(tpl.indptr))
+    db = np.zeros((B, tpl.m))
+    for kk in np.nonzero(cols == tpl.n)[0]:
+        db[:, tpl.indices[kk]] = dA_np[kk]
+    return db
+
+
+def _cone_violation(v, cones, dual=False):
+    """largest violation of v in K (or K*) over the batch: zero rows (primal: |v|, dual: free), nonneg rows, SOC blocks, PSD blocks"""
+    off = 0; worst = 0.0
+    z = cones.get("z", 0)
+    if z and not dual:
+        worst = max(worst, float(v[:, :z].abs().max()))
+    off += z
+    l = cones.get("l", 0)
+    if l:
+        worst = max(worst, float((-v[:, off:off + l]).max()))
+    off += l
+    for d in cones.get("q", []):
+        blk = v[:, off:off + d]
+        worst = max(worst, float((torch.linalg.vector_norm(blk[:, 1:], dim=1) - blk[:, 0]).max()))
+        off += d
+    for k in cones.get("s", []):
+        d = k * (k + 1) // 2
+        S = torch.from_numpy(P.svec_to_sym(v[:, off:off + d].cpu().numpy(), k)).to(v.device)
+        worst = max(worst, float((-torch.linalg.eigvalsh(S)[:, 0]).max()))
+        off += d
+    return worst
+
+
+def _kkt_all(A_t, b_t, c_t, x, y, s, cones, eps, shared):
+    """KKT certificate of every instance, on the GPU (A_t: (m, n) shared or (B, m, n))"""
+    Ax = x @ A_t.T if shared else torch.einsum("bij,bj->bi", A_t, x)
+    ATy = y @ A_t if shared else torch.einsum("bij,bi->bj", A_t, y)
+    rp = (Ax + s - b_t).abs().amax(dim=1) / (1 + b_t.abs().amax(dim=-1))
+    rd = (ATy + c_t).abs().amax(dim=1) / (1 + c_t.abs().amax(dim=1))
+    ctx = (c_t * x).sum(dim=1); bty = (b_t * y).sum(dim=1)
+    gap = (ctx + bty).abs() / (1 + ctx.abs())
+    assert float(rp.max()) < 50 * eps and float(rd.max()) < 50 * eps and float(gap.max()) < 50 * eps, (float(rp.max()), float(rd.max()), float(gap.max()))
+    assert _cone_violation(s, cones) < 100 * eps and _cone_violation(y, cones, dual=True) < 100 * eps
+    comp = (s * y).sum(dim=1).abs() / (1 + ctx.abs())
+    assert float(comp.max()) < 100 * eps, float(comp.max())
+
+
+# ------------------------------------------------------------------ 1a: the bench's exact settings
+def test_metric_config_with_the_bench_settings_against_the_oracle_with_the_same_settings():
+    from cvxpylayers_amd.interfaces.mi355_if import make_settings
+    from oracle import oracle
+    cfg = P.CONFIGS["M"]; n, cones, B = cfg["n"], cfg["cones"], 256
+    tpl = P.dense_template(n, cones)
+    A, b, c = P.generate(n, cones, B, seed=0)                                   # bench.py's batch (first 256 instances of seed 0)
+    A_eval, q_eval = tpl.values_from_dense(A, b, c)
+    eng = _engine(tpl, cones)
+    args = dict(eps=1e-4, acceleration_lookback=10, max_iters=10000)           # bench.py solver_args
+    x, y, s, iters, status, resid = eng.solve(torch.from_numpy(A_eval).cuda().t().contiguous(), torch.from_numpy(q_eval).cuda(), make_settings(dict(args)))
+    assert eng.last_acceleration
+    ref = oracle.solve_batch(A, b, c, cones, **args)                            # aa_mem = 10
+    st = status.cpu().numpy(); it = iters.cpu().numpy().astype(int)
+    assert (st == ref["status"]).all() and (st == 1).all()
+    tol = 20 * 1e-4                                                             # both sides are eps-accurate solutions reached along different accelerated paths
+    for got, want in ((x, ref["x"]), (y, ref["y"]), (s, ref["s"])):
+        assert _rel_rows(got.cpu().numpy(), want).max() < tol, _rel_rows(got.cpu().numpy(), want).max()
+    d = np.abs(it - ref["iters"])
+    hist = np.bincount(d // 25, minlength=4)
+    assert (d <= 25).mean() >= 0.95, hist                                       # the histogram, not the mean: at most one check interval apart
+    assert abs(it.mean() - ref["iters"].mean()) < 2.5, (it.mean(), ref["iters"].mean())
+
+
+# ------------------------------------------------------------------ 1b: C3 / C4 / C5 at their stated batch
+def test_C3_socp_n100_at_B4096():
+    from cvxpylayers_amd.interfaces.mi355_if import make_settings
+    from oracle import oracle
+    cfg = P.CONFIGS["C3"]; n, cones, B = cfg["n"], cfg["cones"], 4096
+    tpl = P.dense_template(n, cones)
+    A, b, c = P.generate(n, cones, B, seed=3)
+    A_eval, q_eval = tpl.values_from_dense(A, b, c)
+    eng = _engine(tpl, cones)
+    A_bm = torch.from_numpy(A_eval).cuda().t().contiguous(); q_t = torch.from_numpy(q_eval).cuda()
+    eps = 1e-8
+    x, y, s, iters, status, resid = eng.solve(A_bm, q_t, make_settings(dict(acceleration_lookback=0, eps=eps, max_iters=50000)))
+    assert eng.last_path == "per_instance" and bool((status == 1).all())
+    _kkt_all(torch.from_numpy(A).cuda(), torch.from_numpy(b).cuda(), torch.from_numpy(c).cuda(), x, y, s, cones, eps, shared=False)
+    dA, dq, adj = eng.vjp(A_bm, x, y, s, torch.ones_like(x), torch.zeros_like(y), path="per_instance")
+    assert int((adj != 0).sum()) == 0
+    idx = np.random.default_rng(1).choice(B, 48, replace=False)
+    ref = oracle.solve_batch(A[idx], b[idx], c[idx], cones, eps=eps, max_iters=50000)
+    assert (ref["status"] == 1).all()
+    xs, ys, ss = x.cpu().numpy()[idx], y.cpu().numpy()[idx], s.cpu().numpy()[idx]
+    assert _rel_rows(xs, ref["x"]).max() < 1e-6 and _rel_rows(ys, ref["y"]).max() < 1e-6 and _rel_rows(ss, ref["s"]).max() < 1e-6
+    assert np.abs(iters.cpu().numpy()[idx].astype(int) - ref["iters"]).max() <= 25
+    g = oracle.adjoint_batch(A[idx], b[idx], c[idx], cones, ref["x"], ref["y"], ref["s"], np.ones_like(ref["x"]), np.zeros_like(ref["y"]), mode="dense")
+    dq_np = dq.cpu().numpy(); dA_np = dA.cpu().numpy()
+    assert _rel_rows(dq_np[:n].T[idx], g["dc"]).max() < 1e-5
+    assert _rel_rows(_db_from_dA(tpl, dA_np, B)[idx], g["db"]).max() < 1e-5
+    cols = np.repeat(np.arange(n + 1), np.diff(tpl.indptr)); ka = np.nonzero(cols < n)[0]
+    assert _rel_rows(-dA_np[ka].T[idx], g["dA"][:, tpl.indices[ka], cols[ka]]).max() < 1e-5      # dA_eval = -dA.data (diffcp_if.py:91)
+
+
+def test_C4_sdp_20x20_at_B1024():
+    from cvxpylayers_amd.interfaces.mi355_if import make_settings
+    from oracle import oracle
+    B = 1024
+    A, b, c, cones, tpl = P.sdp_c4_batch(B, seed=0)
+    A_eval, q_eval = tpl.values_from_dense(np.broadcast_to(A, (B,) + A.shape).copy(), b, c)          # A shared, b and c per instance
+    eng = _engine(tpl, cones)
+    A_bm = torch.from_numpy(A_eval).cuda().t().contiguous(); q_t = torch.from_numpy(q_eval).cuda()
+    eps = 1e-8
+    x, y, s, iters, status, resid = eng.solve(A_bm, q_t, make_settings(dict(acceleration_lookback=0, eps=eps, max_iters=50000)))
+    assert eng.last_path == "const_a" and eng.last_const_a_kernel == "k_sa_fwd", (eng.last_path, getattr(eng, "last_const_a_kernel", None))
+    assert bool((status == 1).all())
+    _kkt_all(torch.from_numpy(A).cuda(), torch.from_numpy(b).cuda(), torch.from_numpy(c).cuda(), x, y, s, cones, eps, shared=True)
+    dA, dq, adj = eng.vjp(A_bm, x, y, s, torch.ones_like(x), torch.zeros_like(y), path="const_a")
+    assert int((adj != 0).sum()) == 0
+    idx = np.random.default_rng(1).choice(B, 48, replace=False)
+    Ab = np.broadcast_to(A, (48,) + A.shape).copy()
+    ref = oracle.solve_batch(Ab, b[idx], c[idx], cones, eps=eps, max_iters=50000)
+    assert (ref["status"] == 1).all()
+    xs, ys, ss = x.cpu().numpy()[idx], y.cpu().numpy()[idx], s.cpu().numpy()[idx]
+    assert _rel_rows(xs, ref["x"]).max() < 1e-6 and _rel_rows(ys, ref["y"]).max() < 1e-6 and _rel_rows(ss, ref["s"]).max() < 1e-6
+    g = oracle.adjoint_batch(Ab, b[idx], c[idx], cones, ref["x"], ref["y"], ref["s"], np.ones_like(ref["x"]), np.zeros_like(ref["y"]), mode="dense")
+    assert _rel_rows(dq.cpu().numpy()[:tpl.n].T[idx], g["dc"]).max() < 1e-5
+    assert _rel_rows(_db_from_dA(tpl, dA.cpu().numpy(), B)[idx], g["db"]).max() < 1e-5
+
+
+def test_C5_portfolio_n501_at_B16384():
+    from cvxpylayers_amd.interfaces.mi355_if import make_settings
+    from oracle import oracle
+    B = 16384
+    A, b, c, cones, tpl = P.portfolio_c5_batch(B, seed=0)
+    A1, _ = tpl.values_from_dense(A[None], b[None], c[:1])           # A, b shared: tile one instance's values (the dense (B, m, n) array would be 36 GB)
+    eng = _engine(tpl, cones)
+    A_bm = torch.from_numpy(A1[:, 0]).cuda().repeat(B, 1).contiguous()
+    q_t = torch.from_numpy(np.concatenate([c.T, np.zeros((1, B))], axis=0)).cuda()
+    eps = 1e-6          # the splitting converges slowly on this LP-like program (4 000 - 9 000 iterations at 1e-6, > 1e5 at 1e-8, on both sides)
+    x, y, s, iters, status, resid = eng.solve(A_bm, q_t, make_settings(dict(acceleration_lookback=0, eps=eps, max_iters=100000)))
+    assert eng.last_path == "const_a" and eng.last_const_a_kernel == "k_sa_fwd", (eng.last_path, getattr(eng, "last_const_a_kernel", None))
+    # (the splitting crawls on a handful of these LP-like instances: 2 of 16384 are still "solved / inaccurate" after 100 000 iterations -- on the
+    # oracle as well; they are counted, not hidden, and everything below is asserted on the solved ones)
+    ok = status == 1
+    assert int(ok.sum()) >= B - 8 and bool(((status == 1) | (status == 2)).all()), torch.bincount(status + 10)
+    A_t = torch.from_numpy(A).cuda(); b_t = torch.from_numpy(b).cuda(); c_t = torch.from_numpy(c).cuda()
+    _kkt_all(A_t, b_t[None].expand(int(ok.sum()), -1), c_t[ok], x[ok], y[ok], s[ok], cones, eps, shared=True)
+    # the portfolio's own statement of feasibility: budget, no short positions, the risk cone
+    w, t = x[ok][:, :500], x[ok][:, 500]
+    assert float((w.sum(dim=1) - 1).abs().max()) < 1e-4 and float(w.min()) > -1e-4
+    assert float((torch.linalg.vector_norm(w @ (-A_t[502:, :500].T), dim=1) - t).max()) < 1e-4
+    idx = np.sort(np.random.default_rng(1).choice(np.nonzero(ok.cpu().numpy())[0], 48, replace=False))
+    Ab = np.broadcast_to(A, (48,) + A.shape).copy(); bb = np.broadcast_to(b, (48,) + b.shape).copy()
+    ref = oracle.solve_batch(Ab, bb, c[idx], cones, eps=eps, max_iters=100000)
+    assert (ref["status"] == 1).all()
+    xs, ys, ss = x.cpu().numpy()[idx], y.cpu().numpy()[idx], s.cpu().numpy()[idx]
+    assert _rel_rows(xs, ref["x"]).max() < 1e-6 and _rel_rows(ys, ref["y"]).max() < 1e-6 and _rel_rows(ss, ref["s"]).max() < 1e-6
+    assert np.abs(iters.cpu().numpy()[idx].astype(int) - ref["iters"]).max() <= 25
+    # adjoint of dx = 1 over the WHOLE batch at the engine's own solutions: finite and flag-free everywhere ...
+    dA, dq, adj = eng.vjp(A_bm, x, y, s, torch.ones_like(x), torch.zeros_like(y), path="const_a")
+    assert int((adj[ok] != 0).sum()) == 0 and bool(torch.isfinite(dq[:, ok]).all())
+    # ... and, on the subset, at the ORACLE's solutions (so that only the adjoint solves are compared).  Instances at a vertex of the feasible
+    # set (as many active rows as variables: the solution is locally constant) are compared with the oracle's dense elimination to 1e-5.  The
+    # others sit on a degenerate face: the reduced system is singular, a minimum-norm least-squares solve (LSQR: diffcp's default and this
+    # path) and an elimination with pivoting return different elements -- THOSE are compared with the oracle's LSQR mode (diffcp's semantics)
+    # at LSQR's own accuracy instead of being dropped.
+    xo, yo, so = (torch.from_numpy(ref[k]).cuda() for k in ("x", "y", "s"))
+    dA2, dq2, adj2 = eng.vjp(A_bm[idx], xo, yo, so, torch.ones_like(xo), torch.zeros_like(yo), path="const_a")
+    assert int((adj2 != 0).sum()) == 0
+    g = oracle.adjoint_batch(Ab, bb, c[idx], cones, ref["x"], ref["y"], ref["s"], np.ones_like(ref["x"]), np.zeros_like(ref["y"]), mode="dense")
+    dc_gpu = dq2.cpu().numpy()[:tpl.n].T
+    db_gpu = _db_from_dA(tpl, dA2.cpu().numpy(), 48)
+    brows = tpl.b_idx
+
+    def err_against(gg):
+        return np.maximum(np.abs(dc_gpu - gg["dc"]).max(axis=1) / (1 + np.abs(gg["dc"]).max(axis=1)),
+                          np.abs(db_gpu[:, brows] - gg["db"][:, brows]).max(axis=1) / (1 + np.abs(gg["db"]).max(axis=1)))
+    err = err_against(g)
+    v = ref["y"] - ref["s"]
+    n_act = (v[:, 1:501] > 0).sum(axis=1) + 1 + 51                  # active bounds + budget row + the SOC rows (dual in the interior)
+    regular = n_act >= tpl.n
+    assert err[regular].max() < 1e-5, (regular.mean(), err[regular].max())
+    if (~regular).any():
+        gl = oracle.adjoint_batch(Ab[~regular], bb[~regular], c[idx][~regular], cones, ref["x"][~regular], ref["y"][~regular], ref["s"][~regular],
+                                  np.ones_like(ref["x"][~regular]), np.zeros_like(ref["y"][~regular]), mode="lsqr", lsqr_atol=1e-12, lsqr_btol=1e-12, lsqr_iter_lim=20000)
+        el = np.maximum(np.abs(dc_gpu[~regular] - gl["dc"]).max(axis=1) / (1 + np.abs(gl["dc"]).max(axis=1)),
+                        np.abs(db_gpu[~regular][:, brows] - gl["db"][:, brows]).max(axis=1) / (1 + np.abs(gl["db"]).max(axis=1)))
+        assert el.max() < 5e-3, (el, err[~regular])
