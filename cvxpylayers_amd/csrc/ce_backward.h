@@ -317,7 +317,7 @@ k_backward(DevT T, int nkcap, int ldk, const double *__restrict__ Avals, const d
         block_reduce<1>(r, 1u, red);
         kmax = r[0];
     }
-    const double ptol = 1e-13 * (kmax > 0 ? kmax : 1.0);
+    const double ptol = CE_RANK_TOL * (kmax > 0 ? kmax : 1.0);
     bool unblocked = !(!K_LDS && T.gen_blocked_b);
     if (!unblocked) {
         // BLOCKED Gauss-Jordan with partial pivoting, sixteen pivots per pass over the global-memory matrix (the unblocked loop below streams the

@@ -435,7 +435,7 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
 #pragma unroll
             for (int j = 0; j < TJ; j++) if (cb + BGC * j < NK) r[0] = fmax(r[0], fabs(kt[i][j]));
         block_reduce_n<1, NWB>(r, 1u, red);
-        ptol = 1e-11 * (r[0] > 0 ? r[0] : 1.0);     // rank tolerance of the oracle's dense elimination (oracle/cone_oracle.c dense_solve_MT)
+        ptol = CE_RANK_TOL * (r[0] > 0 ? r[0] : 1.0);     // rank tolerance of the oracle's dense elimination (ce_common.h)
     }
     __syncthreads();                 // a_y / a_s are dead: the union region becomes colbuf / rowbuf
     for (int i = tid; i < 2 * BGR * TI; i += NTB) colbuf[i] = 0.0;

@@ -12,6 +12,10 @@ constexpr int NUM_L2_PASSES = 1;
 constexpr double MIN_SCALE = 1e-4, MAX_SCALE = 1e4;
 constexpr double MIN_SCALE_VALUE = 1e-6, MAX_SCALE_VALUE = 1e6;
 constexpr double TAU_FACTOR = 10.0, ZERO_CONE_FACTOR = 1000.0;
+// rank tolerance of the adjoint's eliminations, relative to max |K|: ONE constant for k_backward_rt, both paths of the size-generic k_backward and the oracle's
+// dense elimination (oracle/cone_oracle.c dense_solve_MT, `best <= 1e-11 * amax0`): a pivot below it is a FREE variable (diffcp's LSQR returns a solution of the
+// consistent system there, diffcp_if.py:73-96), whatever kernel the template's size selects
+constexpr double CE_RANK_TOL = 1e-11;
 
 // DevT (the device-side template description) lives in ce_types.h, shared by all translation units
 

@@ -846,7 +846,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
     const int aa_int = S.acceleration_interval;
     double *const aaWP = Gm + gsz + (PSD ? ((T.ns > 0 ? 2 * T.maxs * T.maxs + 2 * T.maxs + 8 : 0) + T.nep + T.np) : 0) + (HASP ? NP : 0);
     double *const aaXP = aaWP + VP, *const aaFP = aaXP + VP, *const aaFS = aaFP + VP, *const aaXS = aaFS + VP;
-    int aa_iter = 0; bool aa_pending = false;      // (|g| before the step lives in sc[8]: no register across the loop)
+    int aa_iter = 0; bool aa_pending = false, aa_stale = false;      // (|g| before the step lives in sc[8]: no register across the loop)
     const bool big_soc = T.maxq > SOC_SMALL;
     bool resume = false;     // true: the iteration interrupted by a rescale still owes its relaxed update
 
@@ -918,7 +918,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
                 }
                 aa_pending = false;
             }
-            if (aa_on && iter > 0 && iter % aa_int == 0) {
+            if (aa_on && iter > 0 && iter % aa_int == 0 && !aa_stale) {      // (aa_stale: the kept input predates a rescale -- with an interval that puts a step right behind a check iteration it would pair a pre-rescale input with a post-rescale output)
                 const double xv = ev ? aaWP[ve] : 0.0, fv = ev ? sm[L::O_W + ve] : 0.0, gv = xv - fv;
                 if (aa_iter > 0) {
                     const double xp = ev ? aaXP[ve] : 0.0, fp = ev ? aaFP[ve] : 0.0;
@@ -951,7 +951,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
             if (aa_on && nw > 0 && threadIdx.x == 0) sc[8] *= sqrt((double)l) / nw;
             __syncthreads();
         }
-        if (aa_on && ev && (aa_pending || (iter + 1) % aa_int == 0)) aaWP[ve] = sm[L::O_W + ve];      // input of this iteration, kept where the top of the next one reads it (the safeguard after a step, the step itself every aa_int iterations)
+        if (aa_on && (aa_pending || (iter + 1) % aa_int == 0)) { aa_stale = false; if (ev) aaWP[ve] = sm[L::O_W + ve]; }      // input of this iteration, kept where the top of the next one reads it (the safeguard after a step, the step itself every aa_int iterations)
         // P1a: t = rho_x w_x - A^T w_y   (+ phi . w from the two spare column groups)
         {
             const double *wvec = sm + L::O_W + ((j1 == n + 1 && T1 * c1 < n) ? OX : OY) + T1 * c1;
@@ -1200,7 +1200,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
                                 const double d0 = ue + sm[L::O_W + ve] - 2 * ute;
                                 sm[L::O_W + ve] = d0 * dy_ratio + 2 * ute - ue;
                             }
-                            n_log = 0; last_scale_iter = iter; scale = uniform_d(ns2); aa_iter = 0; aa_pending = false;
+                            n_log = 0; last_scale_iter = iter; scale = uniform_d(ns2); aa_iter = 0; aa_pending = false; aa_stale = true;
                             __syncthreads();
                             sc[SC_SUMLOG] = 0.0;
                             rescale = true;

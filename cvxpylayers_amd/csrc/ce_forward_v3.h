@@ -577,7 +577,7 @@ k_fwd3(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
     const int aa_int = S.acceleration_interval;
     double *const aaWP = Gm + gsz;
     double *const aaXP = aaWP + VP, *const aaFP = aaXP + VP, *const aaFS = aaFP + VP, *const aaXS = aaFS + VP;
-    int aa_iter = 0; bool aa_pending = false;      // (|g| before the step lives in sc[8]: no register across the loop)
+    int aa_iter = 0; bool aa_pending = false, aa_stale = false;      // (|g| before the step lives in sc[8]: no register across the loop)
     bool resume = false;     // true: the iteration interrupted by a rescale still owes its relaxed update
     auto slot_of = [&](int e) -> int { return (e < m) ? OY + e : (e < m + n ? OX + (e - m) : OT); };
 
@@ -610,7 +610,7 @@ k_fwd3(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
                 }
                 aa_pending = false;
             }
-            if (aa_on && iter > 0 && iter % aa_int == 0) {
+            if (aa_on && iter > 0 && iter % aa_int == 0 && !aa_stale) {      // (aa_stale: the kept input predates a rescale -- with an interval that puts a step right behind a check iteration it would pair a pre-rescale input with a post-rescale output)
                 const double xv = ev ? aaWP[ve] : 0.0, fv = ev ? sm[L::O_W + ve] : 0.0, gv = xv - fv;
                 if (aa_iter > 0) {
                     const double xp = ev ? aaXP[ve] : 0.0, fp = ev ? aaFP[ve] : 0.0;
@@ -643,7 +643,7 @@ k_fwd3(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
             if (aa_on && nw > 0 && threadIdx.x == 0) sc[8] *= sqrt((double)l) / nw;
             __syncthreads();
         }
-        if (aa_on && ev && (aa_pending || (iter + 1) % aa_int == 0)) aaWP[ve] = sm[L::O_W + ve];      // input of this iteration, kept where the top of the next one reads it
+        if (aa_on && (aa_pending || (iter + 1) % aa_int == 0)) { aa_stale = false; if (ev) aaWP[ve] = sm[L::O_W + ve]; }      // input of this iteration, kept where the top of the next one reads it
         const int lane = e & 63, rg = lane >> 4, el = lane & 15, jx = XO * wave + el;
         const bool upd = !check && !last;          // fast path: the relaxed update happens inside the A p_x phase (else after the convergence check)
         // P1a: t = rho_x w_x - A^T w_y ; the spare output (column n) is phi_y . w_y ; phi_x . w_x as one partial per wave
@@ -799,7 +799,7 @@ k_fwd3(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
                                 const double d0 = ue + sm[L::O_W + ve] - 2 * ute;
                                 sm[L::O_W + ve] = d0 * dy_ratio + 2 * ute - ue;
                             }
-                            n_log = 0; last_scale_iter = iter; scale = uniform_d(ns2); aa_iter = 0; aa_pending = false;
+                            n_log = 0; last_scale_iter = iter; scale = uniform_d(ns2); aa_iter = 0; aa_pending = false; aa_stale = true;
                             __syncthreads();
                             sc[SC_SUMLOG] = 0.0;
                             rescale = true;

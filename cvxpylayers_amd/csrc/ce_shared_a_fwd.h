@@ -221,7 +221,7 @@ k_sa_fwd(DevT T, SaFwd F, ce_settings S, const double *__restrict__ BHg, const d
     // f = output of the last iteration, g = x - f, s = x - x_prev, y = g - g_prev, d = f - f_prev:  w <- f - (s.g / (s.y + 1e-8 |s||y|)) d;  the
     // next iteration's residual is the safeguard.  The five history vectors live in GLOBAL memory (L2): they are touched on two of every ten
     // iterations only, and LDS is what limits the residency of this kernel.
-    bool aa_on = S.acceleration_lookback > 0 && F.aa_ws != nullptr, aa_pending = false;
+    bool aa_on = S.acceleration_lookback > 0 && F.aa_ws != nullptr, aa_pending = false, aa_stale = false;
     const int aa_int = S.acceleration_interval > 0 ? S.acceleration_interval : 10;
     int aa_iter = 0, aa_rej = 0;
     double aa_normg = 0, aa_hs = 1.0;     // |g| before the step ; factor by which the stored history has to be scaled (the renormalisations of w since it was stored)
@@ -258,7 +258,7 @@ k_sa_fwd(DevT T, SaFwd F, ce_settings S, const double *__restrict__ BHg, const d
                     }
                     aa_pending = false;
                 }
-                if (aa_on && iter > 0 && iter % aa_int == 0) {
+                if (aa_on && iter > 0 && iter % aa_int == 0 && !aa_stale) {      // (aa_stale: see k_fwd2)
                     if (aa_iter > 0) {
                         double rr[5] = {0, 0, 0, 0, 0};
                         for (int e = tid; e < l; e += NT) {
@@ -296,7 +296,7 @@ k_sa_fwd(DevT T, SaFwd F, ce_settings S, const double *__restrict__ BHg, const d
                 }
                 __syncthreads();
             }
-            if (aa_on && (aa_pending || (iter + 1) % aa_int == 0)) for (int e = tid; e < l; e += NT) aaWP[e] = W[e];      // input of this iteration, where the next one needs it
+            if (aa_on && (aa_pending || (iter + 1) % aa_int == 0)) { aa_stale = false; for (int e = tid; e < l; e += NT) aaWP[e] = W[e]; }      // input of this iteration, where the next one needs it
             // tau-tilde needs phi.w: the partial sums ride on the barriers of the products below
             {
                 double rt = 0;
@@ -456,7 +456,7 @@ k_sa_fwd(DevT T, SaFwd F, ce_settings S, const double *__restrict__ BHg, const d
                             if (ns2 != scale && (factor > sqrt(10.0) || factor < 1.0 / sqrt(10.0))) {
                                 const double dy_ratio = ns2 / scale;       // keep (s, kappa):  w_y+ = rsk_y / r_y+ + 2 ut_y - u_y
                                 for (int e = tid + n; e < l - 1; e += NT) { const double ue = U[e], ute = UT[e]; W[e] = (ue + W[e] - 2 * ute) * dy_ratio + 2 * ute - ue; }
-                                n_log = 0; sum_log = 0; last_scale_iter = iter; scale = uniform_d(ns2); rescale = true; aa_iter = 0; aa_pending = false;
+                                n_log = 0; sum_log = 0; last_scale_iter = iter; scale = uniform_d(ns2); rescale = true; aa_iter = 0; aa_pending = false; aa_stale = true;
                                 __syncthreads();
                             }
                         }

@@ -64,6 +64,7 @@ struct ce_engine {
     const double *retained_A = nullptr; int retained_B = 0;
     // launch plan
     int fwd_mode = 0, bwd_mode = 0; size_t fwd_lds = 0, bwd_lds = 0; int nkcap = 0, ldk = 0;
+    uintptr_t summary_host_checked = 0; char *summary_host_dev = nullptr;      // ce_status_summary: the last 64-byte line of host memory examined and its device alias (null: not mapped)
     int rt_variant = -1, rt_vp = 0, rt_lda = 0;   // register-tiled forward kernel variant (-1: generic kernel)
     int f2_variant = -1; int *d_idx_at = nullptr, *d_idx_ar = nullptr, *d_idx_b = nullptr; int f2_ldg = 0;   // second-generation forward kernel
     int *d_csc_ptr = nullptr, *d_csr_ptr = nullptr, *d_csr_col = nullptr, *d_csr_src = nullptr;   // sparse structure of the A part (shared-A kernels)
@@ -71,7 +72,7 @@ struct ce_engine {
     int sp_r = 0, sp_RP = 0;
     bool sa_fwd_attr = false, sa_lsqr_attr = false;
     int *d_summary = nullptr; unsigned summary_next = 0;   // ce_status_summary staging (8 slots of 3 ints)
-    double *d_aa_ws = nullptr; size_t aa_ws_bytes = 0;   // Anderson-acceleration history of the shared-A forward kernel ([B][5][lp])
+    double *d_aa_ws = nullptr; size_t aa_ws_bytes = 0;   // Anderson-acceleration history of the shared-A forward kernel ([B][4][lp])
     unsigned long long *d_psd_stats = nullptr;     // CE_PSD_STATS=1: counters of the PSD projection (printed to stderr by ce_destroy)   // MaxDynamicSharedMemorySize is per device: set once per engine (an engine is bound to one device, one caller thread)
     int psd_first = 0;           // first row of the first PSD block (m when the template has none)
     int *d_sp_drow = nullptr, *d_sp_srow_col = nullptr, *d_sp_scol_ptr = nullptr, *d_sp_scol_row = nullptr, *d_sp_rowslot = nullptr, *d_sp_sing_i = nullptr; double *d_sp_sing_v = nullptr;
@@ -522,7 +523,7 @@ int ce_destroy(ce_handle h) {
                             "clock64 ticks per projection %.0f (of which Jacobi sweeps %.0f), per iteration up to the end of the projection %.0f\n",
                     c[0], c[1], c[0] ? (double)c[1] / (double)c[0] : 0.0, c[2], c[3], c[0] ? (double)c[4] / c[0] : 0.0, c[0] ? (double)c[6] / c[0] : 0.0, c[0] ? (double)c[5] / c[0] : 0.0),
             fprintf(stderr, "[cone_engine]   ticks per projection by phase: T=SV,R %.0f | D=V'T %.0f | E %.0f | reduce %.0f | V+=VE %.0f | X, store %.0f\n",
-                    (double)c[8] / c[0], (double)c[9] / c[0], (double)c[10] / c[0], (double)c[11] / c[0], (double)c[12] / c[0], (double)c[13] / c[0]);
+                    (double)c[8] / (c[0] ? c[0] : 1), (double)c[9] / (c[0] ? c[0] : 1), (double)c[10] / (c[0] ? c[0] : 1), (double)c[11] / (c[0] ? c[0] : 1), (double)c[12] / (c[0] ? c[0] : 1), (double)c[13] / (c[0] ? c[0] : 1));
         hipFree(h->d_psd_stats);
     }
     delete h;
@@ -684,12 +685,28 @@ __global__ void __launch_bounds__(256) k_status_summary(int B, const int *__rest
     __shared__ int sm[12];
     if ((threadIdx.x & 63) == 0) { sm[threadIdx.x >> 6] = mn; sm[4 + (threadIdx.x >> 6)] = n2; sm[8 + (threadIdx.x >> 6)] = nf; }
     __syncthreads();
-    if (threadIdx.x == 0) { out[0] = min(min(sm[0], sm[1]), min(sm[2], sm[3])); out[1] = sm[4] + sm[5] + sm[6] + sm[7]; out[2] = sm[8] + sm[9] + sm[10] + sm[11]; }
+    if (threadIdx.x == 0) { out[0] = min(min(sm[0], sm[1]), min(sm[2], sm[3])); out[1] = sm[4] + sm[5] + sm[6] + sm[7]; out[2] = sm[8] + sm[9] + sm[10] + sm[11]; __threadfence_system(); }      // (out may be mapped host memory)
 }
 int ce_status_summary(ce_handle h, int B, const int *status, int *summary_host, void *stream) {
     if (!h || B <= 0 || !status || !summary_host) { g_err = "null argument"; return CE_E_BADARG; }
     HIPCHK(hipSetDevice(h->device));
     if (!h->d_summary) HIPCHK(hipMalloc(&h->d_summary, 8 * 4 * sizeof(int)));
+    // Pinned host memory is mapped into the device's address space: the kernel stores the three ints there itself (no copy kernel behind it: two launches
+    // less per step of the plugin).  Anything else (the pointer is checked once and remembered) goes through a device slot and an asynchronous copy.
+    const uintptr_t page = (uintptr_t)summary_host & ~(uintptr_t)63;      // (the plugin alternates two slots of one 32-byte pinned buffer: remember the 64-byte line)
+    if (page != h->summary_host_checked) {
+        hipPointerAttribute_t at; char *dp = nullptr;
+        const bool mapped = hipPointerGetAttributes(&at, (void *)page) == hipSuccess && at.type == hipMemoryTypeHost &&
+                            hipHostGetDevicePointer((void **)&dp, (void *)page, 0) == hipSuccess && dp != nullptr;
+        (void)hipGetLastError();
+        h->summary_host_checked = page; h->summary_host_dev = mapped ? dp : nullptr;
+    }
+    if (h->summary_host_dev) {
+        int *out = reinterpret_cast<int *>(h->summary_host_dev + ((uintptr_t)summary_host - page));
+        hipLaunchKernelGGL(k_status_summary, dim3(1), dim3(256), 0, (hipStream_t)stream, B, status, out);
+        HIPCHK(hipGetLastError());
+        return CE_OK;
+    }
     int *slot = h->d_summary + 4 * (h->summary_next++ & 7);      // a few calls may be in flight on the stream before the caller synchronises
     hipLaunchKernelGGL(k_status_summary, dim3(1), dim3(256), 0, (hipStream_t)stream, B, status, slot);
     HIPCHK(hipGetLastError());

@@ -40,6 +40,32 @@ _KNOWN_ARGS = {"eps", "eps_abs", "eps_rel", "eps_infeas", "max_iters", "alpha", 
                "n_jobs_forward", "n_jobs_backward", "warm_starts", "raise_on_error"}
 
 
+_WARNED: set = set()
+
+
+def _warn_once(key: str, msg: str):
+    """one warning per process and topic (the plugin is called once per training step: repeating it would drown the log)"""
+    if key not in _WARNED:
+        _WARNED.add(key)
+        warnings.warn(msg, stacklevel=3)
+
+
+def note_ignored_args(merged_args: dict, explicit_lookback: bool):
+    """The reference's solver arguments this plugin ACCEPTS but does not act on, said once instead of swallowed silently (diffcp_if.py:356-367 forwards them to
+    diffcp / SCS):  acceleration_lookback > 1 -- the kernels keep ONE secant pair whatever the lookback (SCS keeps `lookback` pairs; same fixed point,
+    iteration counts within 2.5 % on the BASELINE configurations);  mode / solve_method -- the adjoint is a rank-revealing direct elimination for per-instance
+    templates and LSQR for shared-A templates, not selectable;  n_jobs_forward / n_jobs_backward -- the batch runs on the GPU."""
+    lb = merged_args.get("acceleration_lookback")
+    if lb is not None and int(lb) > 1:
+        _warn_once("lookback", f"MI355 solver: acceleration_lookback={int(lb)}" + ("" if explicit_lookback else " (SCS's default, which the reference forwards)") +
+                   " runs as type-I Anderson acceleration with a ONE-pair history (memory 1), not a " + str(int(lb)) + "-pair history; "
+                   "pass acceleration_lookback=1 to say so explicitly, 0 to iterate plainly")
+    for k in ("mode", "solve_method", "n_jobs_forward", "n_jobs_backward"):
+        if k in merged_args:
+            _warn_once(k, f"MI355 solver: solver_args[{k!r}]={merged_args[k]!r} is accepted for compatibility with the DIFFCP plugin and ignored "
+                          "(the adjoint method is fixed per template, the batch is solved on the GPU)")
+
+
 def dims_to_solver_dict(dims) -> dict:
     """ConeDims (attrs zero/nonneg/soc/exp/psd/p3d) or an SCS-style dict -> {"z","l","q","ep","s","p"}
     (what cvxpy.reductions.solvers.conic_solvers.scs_conif.dims_to_solver_dict returns; diffcp_if.py:8,150)."""
@@ -436,11 +462,14 @@ def _enqueue_flagged_adjoint(eng):
     pend, eng._pending_adj = getattr(eng, "_pending_adj", None) or [], []
     if not pend:
         return None
-    adj, bs = pend[-1]                       # (older entries belong to backward calls whose forward was followed by another forward: already reported or superseded)
-    if adj.numel() == 0:
+    # every backward since the last forward is reported (a layer applied several times in one graph -- the 20 time steps of the supply-chain loop -- leaves
+    # several entries): one flag vector, one summary
+    pend = [(a, b) for a, b in pend if a.numel()]
+    if not pend:
         return None
+    adj = pend[0][0] if len(pend) == 1 else torch.cat([a.reshape(-1) for a, _ in pend])
     eng.enqueue_summary(adj, 1)
-    return bs
+    return sum(b for _, b in pend)
 
 
 def _report_flagged_adjoint(summary_row, bs):
@@ -481,6 +510,8 @@ class _ConeLayer(torch.autograd.Function):
         # algorithm here, at the C ABI and in the reference.  The engine keeps a one-pair history whatever the lookback (iteration
         # counts within 2.5 % of lookback 10 on every BASELINE configuration, profiles/r02/aa_memory.json).
         settings = make_settings(merged_args)
+        note_ignored_args({"acceleration_lookback": settings.acceleration_lookback, **{k: merged_args[k] for k in ("mode", "solve_method", "n_jobs_forward", "n_jobs_backward") if k in merged_args}},
+                          explicit_lookback="acceleration_lookback" in merged_args)
         if warm_start is None and merged_args.get("warm_starts") is not None:
             # diffcp's solve argument (diffcp_if.py:365-367 forwards it): one (x, y, s) triple per instance
             ws = merged_args["warm_starts"]
@@ -513,6 +544,13 @@ class _ConeLayer(torch.autograd.Function):
             adj_bs = _enqueue_flagged_adjoint(eng)
             if status.numel():
                 eng.enqueue_summary(status, 0)
+            # everything the host can prepare without knowing the outcome happens BEFORE the one synchronisation of this call: the GPU is idle from the
+            # end of the solve until the caller's backward reaches it, so host work placed behind the wait is added to that gap
+            primal = x.to(in_device)
+            dual = y.to(in_device)
+            info = dict(iters=iters, status=status, resid=resid, acceleration=getattr(eng, "last_acceleration", False))
+            saved = (eng, A_bm, x.detach(), y.detach(), s, batch_minor_in, P_bm, path, None) if needs_grad else None
+            if status.numel():
                 summ = eng.read_summaries()
                 min_status, n_inaccurate = int(summ[0][0]), int(summ[0][1])
             else:
@@ -536,14 +574,13 @@ class _ConeLayer(torch.autograd.Function):
             failed = (status < 0)
             x = torch.where(failed[:, None], torch.full_like(x, float("nan")), x)
             y = torch.where(failed[:, None], torch.full_like(y, float("nan")), y)
-        primal = x.to(in_device)
-        dual = y.to(in_device)
-        info = dict(iters=iters, status=status, resid=resid, acceleration=getattr(eng, "last_acceleration", False))
+            primal = x.to(in_device)
+            dual = y.to(in_device)
+            saved = (eng, A_bm, x.detach(), y.detach(), s, batch_minor_in, P_bm, path, failed) if needs_grad else None
         # x / y are handed back as `primal` / `dual` (same objects when the input lives on the engine's device), and autograd
         # attaches this node to them: keeping the SAME objects on the node would form a reference cycle (node -> saved ->
         # primal -> grad_fn -> node) that only the cyclic GC breaks, i.e. 167 MB buffers pile up for many steps and the
         # caching allocator falls back to hipMalloc (3 ms each).  Detached aliases share the storage without the cycle.
-        saved = (eng, A_bm, x.detach(), y.detach(), s, batch_minor_in, P_bm, path, failed) if needs_grad else None
         return primal, dual, info, (saved, batch_size, originally_unbatched, in_device)
 
     @staticmethod

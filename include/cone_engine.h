@@ -145,7 +145,9 @@ int ce_transpose(ce_handle h, int rows, int cols, const double *in, double *out,
  * summary_host[0] = min_i v[i], [1] = #{i: v[i] == 2}, [2] = #{i: (v[i] & 3) != 0} and its copy to summary_host (3 ints of PINNED host memory).  The caller
  * synchronises the stream (or an event) before reading it.  This is the only host <- device traffic a forward call of the Python plugin needs in order to
  * honour the reference's contract that a failed instance raises SolverError from forward() (diffcp_if.py:365-372 raises inside the call): 12 bytes instead
- * of the status vector. */
+ * of the status vector.  When summary_host is pinned memory mapped into the device's address space (hipHostMalloc / torch's pin_memory) the kernel stores
+ * there directly; any other host pointer goes through one of EIGHT rotating device slots and an asynchronous copy: at most eight such calls may be in flight
+ * on the stream between two synchronisations of the caller. */
 int ce_status_summary(ce_handle h, int B, const int *status, int *summary_host, void *stream);
 
 /*

@@ -473,7 +473,7 @@ static int solve_one(int n, int m, const double *A0, const double *b0, const dou
     double *aS = aab, *aY = aS ? aS + (size_t)aa_mem * l : NULL, *aD = aS ? aY + (size_t)aa_mem * l : NULL;
     double *aXp = aS ? aD + (size_t)aa_mem * l : NULL, *aFp = aS ? aXp + l : NULL, *aGp = aS ? aFp + l : NULL, *wprev = aS ? aGp + l : NULL,
            *aFsave = aS ? wprev + l : NULL, *aXsave = aS ? aFsave + l : NULL, *aG = aS ? aXsave + l : NULL, *aM = aS ? aG + l : NULL;
-    int aa_iter = 0, aa_pending = 0, aa_rej = 0, aa_live = 1; double aa_normg = 0;
+    int aa_iter = 0, aa_pending = 0, aa_rej = 0, aa_live = 1, aa_stale = 0; double aa_normg = 0;
     for (iter = 0; iter < o->max_iters; iter++) {
         int check = (iter % CONVERGED_INTERVAL) == 0;
         if (aa_mem > 0 && aa_pending) {      /* safeguard: residual of the map at the accelerated point */
@@ -481,7 +481,7 @@ static int solve_one(int n, int m, const double *A0, const double *b0, const dou
             if (!(dn <= aa_normg)) { memcpy(w, aFsave, sizeof(double) * l); memcpy(wprev, aXsave, sizeof(double) * l); aa_iter = 0; if (++aa_rej >= AA_MAX_REJECT) aa_live = 0; }
             aa_pending = 0;
         }
-        if (aa_mem > 0 && aa_live && iter > 0 && iter % aa_int == 0) {
+        if (aa_mem > 0 && aa_live && iter > 0 && iter % aa_int == 0 && !aa_stale) {      /* aa_stale: wprev predates a rescale (possible only with intervals that put a step right behind a check iteration) */
             for (int i = 0; i < l; i++) aG[i] = wprev[i] - w[i];          /* x = wprev, f = w */
             if (aa_iter > 0) {
                 int idx = (aa_iter - 1) % aa_mem;
@@ -519,7 +519,7 @@ static int solve_one(int n, int m, const double *A0, const double *b0, const dou
             double nw = norm2(w, l); if (nw > 0) { double f = sqrt((double)l) / nw; for (int i = 0; i < l; i++) w[i] *= f;
                 if (aa_mem > 0) { for (size_t i = 0; i < (size_t)(3 * aa_mem + 7) * l; i++) aab[i] *= f; aa_normg *= f; } }
         }
-        if (aa_mem > 0) memcpy(wprev, w, sizeof(double) * l);
+        if (aa_mem > 0) { memcpy(wprev, w, sizeof(double) * l); aa_stale = 0; }
         /* (1) linear-system step: p = (R_z+M_zz)^{-1} R_z w_z : kkt rhs (rho_x w_x, -r_y w_y) */
         for (int j = 0; j < n; j++) t1[j] = rho_x * w[j];
         for (int i = 0; i < m; i++) t2[i] = -ry[i] * w[n + i];
@@ -577,7 +577,7 @@ static int solve_one(int n, int m, const double *A0, const double *b0, const dou
                     if (iter - last_scale_iter >= RESCALING_MIN_ITERS) {
                         double ns2 = fmin(fmax(scale * factor, MIN_SCALE_VALUE), MAX_SCALE_VALUE);
                         if (ns2 != scale && (factor > sqrt(10.0) || factor < 1.0 / sqrt(10.0))) {
-                            sum_log = 0; n_log = 0; last_scale_iter = iter; scale = ns2; n_rescale++; aa_iter = 0; aa_pending = 0;
+                            sum_log = 0; n_log = 0; last_scale_iter = iter; scale = ns2; n_rescale++; aa_iter = 0; aa_pending = 0; aa_stale = 1;
                             set_ry(ry, m, K, scale);
                             if (factor_kkt(A, Pm, ry, rho_x, m, n, L)) { status = OC_FAILED; break; }
                             for (int i = 0; i < m; i++) t1[i] = -b[i];

@@ -16,6 +16,8 @@ HIP engine (GPU).
   ref_notebook_supply.npz    supply_chain.ipynb cell 9: closed-loop cost of the baseline policy (17 digits: 20 sequential forward solves) and
                              the validation costs after each of the first SGD epochs (5 digits: each one forward + diffcp backward through
                              20 time steps x batch 5, so they pin the gradients as well)
+  ref_notebook_denoise.npz   signal_denoising.ipynb cells 15-18: mean squared error of the smoothing layer (two SOCs of 102 and 101 rows, n = 102) over the
+                             500 training signals for ten values of lambda, and over the 100 validation signals at the best lambda (4 decimals each)
 """
 import json
 import os
@@ -112,5 +114,44 @@ def supply():
     print("supply", base, valid[:8])
 
 
+def denoise():
+    """signal_denoising.ipynb cells 3, 14-18: the one-parameter smoothing layer  min ||x - y||^2 + lam ||diff(y)||^2  evaluated by the reference on the WHOLE
+    training set (batch of 500 signals of length 100) for ten values of lam, and on the validation set (100 signals) at the best one: mean squared errors
+    printed to 4 decimals.  The data are regenerated with the notebook's seeds; that they ARE the notebook's data is checked on the printed value for
+    lam = 0 (there y = x whatever the solver does: the printed mse is a function of the data alone)."""
+    import math
+    cs = cells("signal_denoising.ipynb")
+    txt = out_text(find_cell(cs, "for value in tqdm(lambda_values)"))
+    lams = [float(v) for v in re.findall(r"lambda\s+tensor\((" + _NUM + r")\)", txt)]
+    mses = [float(v) for v in re.findall(r"mse tensor\((" + _NUM + r")\)", txt)]
+    assert len(lams) == 10 and len(mses) == 10, (lams, mses)
+    best = numbers(out_text(find_cell(cs, "print(best_lambda)")))[0]
+    lowest = numbers(out_text(find_cell(cs, "print(lowest_loss)")))[0]
+    val_mse = numbers(out_text(find_cell(cs, "print(one_param_mse)")))[0]
+    src = "".join(find_cell(cs, "torch.random.manual_seed(0)")["source"])
+    assert "np.random.seed(0)" in src and "N_train = 500" in src and "n = 100" in src
+    torch.set_default_dtype(torch.double)
+    torch.random.manual_seed(0); np.random.seed(0)                 # cell 3
+    N_train, N_val, n = 500, 100, 100
+    Sigma_sqrt = 0.1 * np.random.randn(n, n)
+    Sigma = Sigma_sqrt.T @ Sigma_sqrt
+    normal = torch.distributions.MultivariateNormal(loc=torch.zeros(n), covariance_matrix=torch.tensor(Sigma))
+    eval_pts = torch.linspace(0, 2 * math.pi, n)
+    X, bs = [], []
+    for i in range(N_train + N_val):
+        b = np.random.uniform(low=1, high=3)
+        x = torch.cos(b * eval_pts).clone(); x += normal.sample()
+        X.append(x.numpy()); bs.append(b)
+    torch.set_default_dtype(torch.float32)
+    X = np.stack(X); bs = np.asarray(bs)
+    Y = np.cos(bs[:, None] * eval_pts.double().numpy()[None, :])
+    assert abs(((X[:N_train] - Y[:N_train]) ** 2).mean() - mses[0]) < 5.1e-5, "seeded data != the notebook's data (lam = 0 is y = x)"
+    lam_exact = np.linspace(0, 20, 10)                             # torch.linspace(0, 20, 10): the printed values are these, rounded
+    assert np.abs(lam_exact - np.asarray(lams)).max() < 5.1e-5 and abs(best - lam_exact[7]) < 5.1e-5 and abs(lowest - min(mses)) < 1e-12
+    np.savez_compressed(os.path.join(HERE, "ref_notebook_denoise.npz"), X=X, b=bs, eval_pts=eval_pts.double().numpy(), lams=lam_exact, mse=np.asarray(mses),
+                        best=np.array(lam_exact[7]), val_mse=np.array(val_mse), N_train=N_train)
+    print("denoise", lams, mses, best, val_mse)
+
+
 if __name__ == "__main__":
-    ot(); lqr(); tutorial(); supply()
+    ot(); lqr(); tutorial(); supply(); denoise()

@@ -101,6 +101,22 @@ def fit_lr_template(mtrain, nfeat=1):
                                         [VariableRecovery(slice(0, n), None, (n,)), VariableRecovery(slice(n, n + 1), None, ())])
 
 
+def denoise_template(n=100):
+    """signal_denoising.ipynb cell 14:  min ||x - y||^2 + lam ||diff(y)||^2;  parameters [x (n,), lam ()], variable y (n,).
+    v = (y, t1, t2):  ||y - x||^2 <= t1,  ||D y||^2 <= t2 (D: first differences),  c = (0, 1, lam).  A does not depend on the parameters: the batch
+    of 500 signals the notebook evaluates runs on the shared-A kernels."""
+    nv = n + 2
+    D = np.diff(np.eye(n), axis=0)
+
+    def builder(x, lam):
+        A1, b1 = kit._soc_sumsq_rows(np.eye(n), -np.asarray(x), n, nv)
+        A2, b2 = kit._soc_sumsq_rows(D, np.zeros(n - 1), n + 1, nv)
+        c = np.zeros(nv); c[n] = 1.0; c[n + 1] = float(np.asarray(lam).reshape(-1)[0])
+        return np.vstack([A1, A2]), np.concatenate([b1, b2]), c
+    cones = dict(z=0, l=0, q=[n + 2, n + 1])
+    return template_from_affine_builder(builder, [(n,), ()], cones, [VariableRecovery(slice(0, n), None, (n,))])
+
+
 def resource_allocation_template(m=10):
     """resource_allocation.ipynb cell 2:  max sum t  s.t.  sum y = B, y >= 0, -exp(-alpha_i u_i) >= alpha_i t_i, u = y * inverse_p;
     parameters [B (), inverse_p (m,), alpha (m,)], variable y (m,).   v = (y, u, t);  (-alpha_i u_i, 1, -alpha_i t_i) in K_exp."""

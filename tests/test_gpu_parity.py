@@ -672,3 +672,43 @@ def test_k_fwd3_opt_in_matches_the_oracle(monkeypatch):
         assert (st2.cpu().numpy() == ref["status"]).all()
         for got, want in ((x2, ref["x"]), (y2, ref["y"]), (s2, ref["s"])):
             assert (np.abs(got.cpu().numpy() - want).max(axis=1) / (1 + np.abs(want).max(axis=1))).max() < 1e-6
+
+
+def test_rank_tolerance_is_one_constant_across_the_adjoint_kernels(monkeypatch):
+    """A template with a REDUNDANT equality row (row 1 = row 0, consistent right-hand side) on the register-tiled adjoint (the default for this size) and on
+    the size-generic kernel (CE_FORCE_GENERIC=1) with its unblocked and its blocked elimination: the same rank tolerance (CE_RANK_TOL = 1e-11 max|K|, the
+    oracle's) decides what a vanishing pivot is in all of them, so the three return the same basic solution and the same flag (4: rank deficient)."""
+    from cvxpylayers_amd.interfaces.mi355_if import ConeEngine, make_settings
+    cones = {"z": 3, "l": 20, "q": [6, 5]}
+    n, B = 24, 8
+    tpl = P.dense_template(n, cones)
+    A, b, c = P.generate(n, cones, B, seed=21)
+    A[:, 1, :] = A[:, 0, :]; b[:, 1] = b[:, 0]
+    A_eval, q_eval = tpl.values_from_dense(A, b, c)
+    outs = {}
+    for key, env in (("rt", {}), ("generic_unblocked", {"CE_FORCE_GENERIC": "1", "CE_GEN_BLOCKED": "0"}), ("generic_blocked", {"CE_FORCE_GENERIC": "1", "CE_GEN_BLOCKED": "1"})):
+        for k in ("CE_FORCE_GENERIC", "CE_GEN_BLOCKED"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        eng = ConeEngine(tpl.indices, tpl.indptr, tpl.n, tpl.m, cones, torch.device("cuda", 0))
+        assert (eng.launch_info()["bwd_mode"] == 3) == (key == "rt"), (key, eng.launch_info())
+        A_bm = torch.from_numpy(A_eval).cuda().t().contiguous(); q_t = torch.from_numpy(q_eval).cuda()
+        if key == "rt":
+            x, y, s, it, st, res = eng.solve(A_bm, q_t, make_settings(dict(eps=1e-8, max_iters=200000, acceleration_lookback=0)))
+            assert ((st == 1) | (st == 2)).all(), st          # (only a common point at which the three eliminations are compared is needed)
+            sol = (x, y, s)
+        g = torch.Generator(device="cpu").manual_seed(5)
+        dx = torch.randn(sol[0].shape, generator=g, dtype=torch.float64).cuda(); dy = torch.randn(sol[1].shape, generator=g, dtype=torch.float64).cuda()
+        dA, dq, adj = eng.vjp(A_bm, *sol, dx, dy)          # (the SAME solution for the three: only the eliminations differ)
+        torch.cuda.synchronize()
+        outs[key] = (dA.cpu().numpy().copy(), dq.cpu().numpy().copy(), adj.cpu().numpy().copy())
+    ref = outs["rt"]
+    assert (ref[2] == 4).all(), ref[2]
+    for key in ("generic_unblocked", "generic_blocked"):
+        dA, dq, adj = outs[key]
+        assert (adj == 4).all(), (key, adj)
+        assert np.isfinite(dA).all() and np.isfinite(dq).all()
+        # dA, db, dc are the same for every solution of the consistent singular system only up to the free variable's choice: both kernels set it to zero
+        assert np.abs(dq - ref[1]).max() < 1e-8 * (1 + np.abs(ref[1]).max()), (key, np.abs(dq - ref[1]).max())
+        assert np.abs(dA - ref[0]).max() < 1e-8 * (1 + np.abs(ref[0]).max()), (key, np.abs(dA - ref[0]).max())

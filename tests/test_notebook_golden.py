@@ -11,6 +11,7 @@ against the notebook is the notebook's rounding / solver tolerance.
   optimal transport   9 exponential cones + 6 equalities + 9 nonneg; forward P and diffcp's adjoint (x.grad, y.grad of P[2,2])
   LQR SDP             PSD cones of order 6 and 4; forward (optimal value 17 digits, P_lqr 8 decimals)
   tutorial fit_lr     SOC(32) + SOC(3) + 2 nonneg; forward (a, b)
+  signal denoising    SOC(102) + SOC(101), n = 102, BATCH OF 500 (the training set in one call): mean squared error for ten values of lambda + validation
   supply chain        4 equalities + 26 nonneg + SOC(6): closed-loop baseline cost (20 sequential solves) and the validation cost after
                       each of 7 SGD epochs (each = forward + adjoint through 20 time steps x batch 5): pins the gradients over training
 """
@@ -76,6 +77,34 @@ def test_tutorial_notebook_fit_lr(make):
     R = np.concatenate([f["Xtrain"], np.ones((X.shape[0], 1))], 1)
     ex = np.linalg.lstsq(R, f["ytrain"], rcond=None)[0]
     assert abs(a.item() - ex[0]) <= 1e-7 and abs(b.item() - ex[1]) <= 1e-7
+
+
+@pytest.mark.parametrize("make", BACKENDS)
+def test_signal_denoising_notebook_mse_over_the_training_set(make):
+    """signal_denoising.ipynb cells 15-18: the reference evaluated the smoothing layer on ALL 500 training signals (one batch) for ten values of lambda and printed
+    the mean squared error against the clean signals, then on the 100 validation signals at the best lambda.  Batch of 500, n = 102, two second-order
+    cones of 102 and 101 rows (the shape of BASELINE config 3 with the batch of a training set), solver_args as in the notebook.  The oracle leg replays
+    four of the ten values (the whole sweep costs it minutes), the engine all of them; the closed form (I + lam D^T D)^-1 x is the independent check."""
+    f = np.load(os.path.join(GOLD, "ref_notebook_denoise.npz"))
+    n, Nt = 100, int(f["N_train"])
+    X = torch.tensor(f["X"]); Y = torch.tensor(np.cos(f["b"][:, None] * f["eval_pts"][None, :]))
+    Xt, Yt, Xv, Yv = X[:Nt], Y[:Nt], X[Nt:], Y[Nt:]
+    layer = make(nc.denoise_template(n), eps=1e-6, max_iters=10000, acceleration_lookback=0)          # cell 15: acceleration_lookback 0, max_iters 10000 (SCS's default eps is looser still)
+    on_gpu = make is _gpu_layer
+    D = np.diff(np.eye(n), axis=0)
+    which = range(1, 10) if on_gpu else (1, 4, 7, 9)             # (lambda = 0 is y = x and pinned the DATA in the generator; its cone program has a free epigraph variable)
+    for k in which:
+        lam = float(f["lams"][k])
+        y, = layer(Xt, torch.tensor(lam, dtype=torch.float64))
+        y = y.cpu() if y.is_cuda else y
+        mse = float((y - Yt).pow(2).mean(dim=1).mean())
+        assert abs(mse - float(f["mse"][k])) <= PRINT4, (k, lam, mse, float(f["mse"][k]))               # "mse tensor(0.1784)" ...
+        exact = Xt.numpy() @ np.linalg.inv(np.eye(n) + lam * D.T @ D).T
+        assert np.abs(y.numpy() - exact).max() <= 3e-4                                                  # the solver's own accuracy at eps 1e-6 (|y| ~ 1)
+    yv, = layer(Xv, torch.tensor(float(f["best"]), dtype=torch.float64))                                 # cell 18
+    yv = yv.cpu() if yv.is_cuda else yv
+    assert abs(float((yv - Yv).pow(2).mean(dim=1).mean()) - float(f["val_mse"])) <= PRINT4              # "tensor(0.0897)"
+    assert int(np.argmin(f["mse"])) == 7 and abs(float(f["lams"][7]) - float(f["best"])) < 1e-12        # the notebook's model selection: lambda = 15.5556
 
 
 @pytest.mark.parametrize("make", BACKENDS)

@@ -1,0 +1,44 @@
+"""Solver arguments the plugin accepts for compatibility with the DIFFCP plugin (diffcp_if.py:356-367) but does not act on are SAID, once per
+process and topic, not swallowed: acceleration_lookback > 1 (one-pair history), mode / solve_method / n_jobs_*."""
+import warnings
+
+import pytest
+
+
+def _fresh():
+    from cvxpylayers_amd.interfaces import mi355_if
+    mi355_if._WARNED.clear()
+    return mi355_if
+
+
+def test_lookback_beyond_one_pair_is_said_once():
+    m = _fresh()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        m.note_ignored_args({"acceleration_lookback": 10}, explicit_lookback=False)
+        m.note_ignored_args({"acceleration_lookback": 10}, explicit_lookback=False)
+        m.note_ignored_args({"acceleration_lookback": 5}, explicit_lookback=True)
+    assert len(w) == 1 and "ONE-pair" in str(w[0].message) and "SCS's default" in str(w[0].message)
+
+
+@pytest.mark.parametrize("lb", [0, 1])
+def test_lookback_zero_and_one_are_exactly_what_runs(lb):
+    m = _fresh()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        m.note_ignored_args({"acceleration_lookback": lb}, explicit_lookback=True)
+    assert not w
+
+
+def test_mode_and_n_jobs_are_accepted_and_reported():
+    m = _fresh()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        m.note_ignored_args({"acceleration_lookback": 0, "mode": "lsqr", "n_jobs_forward": 4}, explicit_lookback=True)
+        m.note_ignored_args({"acceleration_lookback": 0, "mode": "dense", "n_jobs_backward": -1}, explicit_lookback=True)
+    msgs = [str(x.message) for x in w]
+    assert len(msgs) == 3 and any("'mode'" in t for t in msgs) and any("n_jobs_forward" in t for t in msgs) and any("n_jobs_backward" in t for t in msgs)
+    # and they still pass validation (unknown names do not)
+    m.make_settings({"mode": "lsqr", "n_jobs_forward": 4, "eps": 1e-6})
+    with pytest.raises(ValueError):
+        m.make_settings({"lookback": 3})
