@@ -285,7 +285,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
        double *__restrict__ xo, double *__restrict__ yo, double *__restrict__ so, int *__restrict__ iters_o,
        int *__restrict__ status_o, double *__restrict__ resid_o,
        const double *__restrict__ Pvals_g = nullptr, int nnzP = 0, const int *__restrict__ idx_p = nullptr,
-       const int *__restrict__ row_perm = nullptr) {
+       const int *__restrict__ row_perm = nullptr, const int *__restrict__ order = nullptr) {
     static_assert(!(WL && (PSD || HASP)), "wave-local cone exchange: plain cones only");
     constexpr int NT = NTH, NW = NTH / 64;        // threads / waves per workgroup of this instantiation (shadow the file-level defaults)
     using L = F2<CHT, T1, CHA, T2, CHG, TG, NW>;
@@ -299,7 +299,9 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
     int *const socd = socr + MP;                                   // [MP] its dimension (0: not an SOC row)
     double *const Gm = sm + L::O_G + MP;                           // 2*MP ints = MP doubles
 
-    const int tid = threadIdx.x, inst = blockIdx.x;
+    // order: workgroup -> instance.  Workgroups are dispatched in index order, so a permutation sorted by EXPECTED duration, longest first, shortens the
+    // tail of the launch (the last slots to drain run the short instances); the host derives it from the iteration counts of the previous call (ce_set_dispatch_history)
+    const int tid = threadIdx.x, inst = order ? order[blockIdx.x] : blockIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = T.n, m = T.m, l = n + m + 1, ldg = T.ldg, nq = T.nq, z = T.z;
     const int gsz = max(max(n * ldg, 4 * L::LDP), 16 * NP);        // doubles of the G region: G itself, one 4-row panel of the S formation, the exchange
@@ -351,7 +353,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
         f2v atv[T1 / 2], arv[T2 / 2];
         float pf[HASP ? TG : 1];
         if constexpr (HASP) {
-            const double *pv = Pvals_g + (size_t)blockIdx.x * nnzP;
+            const double *pv = Pvals_g + (size_t)inst * nnzP;
 #pragma unroll
             for (int k = 0; k < TG; k++) { const int ix = idx_p[tid * idx_stride<TG> + k]; pf[k] = ix >= 0 ? (float)pv[ix] : 0.0f; }
         }
@@ -496,7 +498,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
     double gPg = 0;                                                  // g_x^T P-hat g_x
     double *const PgV = Gm + gsz;                                // [NP] P-hat g_x   (HASP only; dynamic tail of the LDS carve)
     auto materialize_p = [&](const Co &co, double (&pg)[TG]) {
-        const double *pv = Pvals_g + (size_t)blockIdx.x * nnzP;
+        const double *pv = Pvals_g + (size_t)inst * nnzP;
         const double ej = sm[L::O_EV + (co.jg < NP ? co.jg : 0)];
         const double *evs = sm + L::O_EV + TG * co.cg;
         for_each_idx<TG>(idx_p, co.t, [&](auto, int k, int ix) { pg[k] = ix >= 0 ? pv[ix] * (ej * evs[k]) : 0.0; });
@@ -813,7 +815,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
         // warm start from the caller's (x, y, s): u = (x^, y^, 1), v = (0, s^, 0) in the equilibrated space, and the fixed point
         // of the iteration map has w = u + R^-1 v.   x^ = sigma x / E, y^ = sigma y / D, s^ = sigma D s.
         const double sg = sc[SC_SIGMA];
-        const int inst_ = blockIdx.x;
+        const int inst_ = inst;
         double wx = 0, wy = 0; bool bad = false;
         const int e = threadIdx.x;
         if (e < n) { wx = sg * xo[(size_t)inst_ * n + e] / sm[L::O_EV + e]; bad = !(fabs(wx) < 1e300); }

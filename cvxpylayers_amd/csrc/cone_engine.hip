@@ -78,6 +78,8 @@ struct ce_engine {
     int *d_sp_drow = nullptr, *d_sp_srow_col = nullptr, *d_sp_scol_ptr = nullptr, *d_sp_scol_row = nullptr, *d_sp_rowslot = nullptr, *d_sp_sing_i = nullptr; double *d_sp_sing_v = nullptr;
     double *d_sp_AdT = nullptr, *d_sp_sval = nullptr;
     bool wl = false; int wl_nq = 0; int *d_row_perm = nullptr, *d_k_rowcone = nullptr, *d_k_qoff = nullptr;   // rows packed so that cones are wave-local (k_fwd2 WL)
+    // longest-first dispatch (ce_set_dispatch_history): workgroup -> instance order for the next solve of the same batch size, from this solve's iteration counts
+    bool dispatch_history = false; int *d_order = nullptr; int order_B = 0, order_cap = 0;
     bool f3 = false; int *d_idx_at3 = nullptr, *d_idx_ar3 = nullptr, *d_slot_soc = nullptr;      // third-generation forward kernel (k_fwd3, fwd_mode 5): iteration-tile gather maps, cone layout of the y slots
     int brt_variant = -1;                          // register-tiled backward kernel variant (-1: generic kernel)
     // quadratic objective
@@ -513,7 +515,7 @@ int ce_destroy(ce_handle h) {
     if (!h) return CE_OK;
     hipSetDevice(h->device);
     hipFree(h->d_rowidx); hipFree(h->d_colidx); hipFree(h->d_rowcone); hipFree(h->d_qoff); hipFree(h->d_soff); hipFree(h->d_sord); hipFree(h->d_pw); hipFree(h->d_idx_p); hipFree(h->d_pmap); hipFree(h->d_prow); hipFree(h->d_pcol);
-    hipFree(h->wsA); hipFree(h->wsdA); hipFree(h->gws); hipFree(h->d_idx_at); hipFree(h->d_idx_ar); hipFree(h->d_idx_b); hipFree(h->d_row_perm); hipFree(h->d_idx_at3); hipFree(h->d_idx_ar3); hipFree(h->d_slot_soc); hipFree(h->d_k_rowcone); hipFree(h->d_k_qoff); hipFree(h->d_csc_ptr); hipFree(h->d_csr_ptr); hipFree(h->d_csr_col); hipFree(h->d_csr_src);
+    hipFree(h->wsA); hipFree(h->wsdA); hipFree(h->gws); hipFree(h->d_idx_at); hipFree(h->d_idx_ar); hipFree(h->d_idx_b); hipFree(h->d_order); hipFree(h->d_row_perm); hipFree(h->d_idx_at3); hipFree(h->d_idx_ar3); hipFree(h->d_slot_soc); hipFree(h->d_k_rowcone); hipFree(h->d_k_qoff); hipFree(h->d_csc_ptr); hipFree(h->d_csr_ptr); hipFree(h->d_csr_col); hipFree(h->d_csr_src);
     hipFree(h->d_sp_drow); hipFree(h->d_sp_srow_col); hipFree(h->d_sp_scol_ptr); hipFree(h->d_sp_scol_row); hipFree(h->d_sp_rowslot); hipFree(h->d_sp_sing_i); hipFree(h->d_sp_sing_v); hipFree(h->d_sp_AdT); hipFree(h->d_sp_sval); hipFree(h->d_aa_ws); hipFree(h->d_summary);
     for (auto &v : h->ev) for (auto &p : v) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
     if (h->d_psd_stats) {
@@ -563,6 +565,8 @@ static int to_batch_major(ce_engine *h, int B, const double *vals, long sk, long
     return CE_OK;
 }
 
+__global__ void k_dispatch_order(int B, const int *__restrict__ iters, int *__restrict__ order);      // (defined next to ce_set_dispatch_history)
+
 int ce_qp_native(ce_handle h) { return (h && h->qp_native) ? 1 : 0; }
 
 int ce_solve(ce_handle h, int B, const double *A_vals, long sA_k, long sA_b, const double *q_vals, long sq_k, long sq_b,
@@ -600,6 +604,7 @@ int ce_solve_qp(ce_handle h, int B, const double *A_vals, long sA_k, long sA_b, 
         fa.T = T; fa.S = S; fa.Abm = Abm; fa.q = q_vals; fa.sqk = sq_k; fa.sqb = sq_b; fa.idx_at = h->d_idx_at; fa.idx_ar = h->d_idx_ar; fa.idx_b = h->d_idx_b;
         fa.x = x; fa.y = y; fa.s = s; fa.iters = iters; fa.status = status; fa.resid = resid; fa.P = P_vals; fa.nnz_p = h->nnz_p; fa.idx_p = h->d_idx_p; fa.gA = gA; fa.gG = gG;
         int lrc;
+        fa.order = (h->dispatch_history && h->order_B == B && h->fwd_mode == 4) ? h->d_order : nullptr;
         if (h->fwd_mode == 5) {
             fa.T.ldg = h->f2_ldg; fa.row_perm = h->d_row_perm; fa.idx_at3 = h->d_idx_at3; fa.idx_ar3 = h->d_idx_ar3; fa.slot_soc = h->d_slot_soc;
             lrc = ce_launch_fwd3(B, h->fwd_lds, st, fa);
@@ -618,6 +623,12 @@ int ce_solve_qp(ce_handle h, int B, const double *A_vals, long sA_k, long sA_b, 
         if (lrc) { g_err = "internal: no forward kernel for the planned variant"; return CE_E_BADARG; }
     }
     HIPCHK(hipGetLastError());
+    if (h->dispatch_history && h->fwd_mode == 4) {      // the order of the NEXT solve of this batch size (behind the solve on the same stream: ~5 us)
+        if (h->order_cap < B) { hipFree(h->d_order); h->d_order = nullptr; h->order_cap = 0; HIPCHK(hipMalloc(&h->d_order, sizeof(int) * (size_t)B)); h->order_cap = B; }
+        hipLaunchKernelGGL(k_dispatch_order, dim3(1), dim3(256), 0, st, B, iters, h->d_order);
+        HIPCHK(hipGetLastError());
+        h->order_B = B;
+    }
     return CE_OK;
 }
 
@@ -685,8 +696,31 @@ __global__ void __launch_bounds__(256) k_status_summary(int B, const int *__rest
     __shared__ int sm[12];
     if ((threadIdx.x & 63) == 0) { sm[threadIdx.x >> 6] = mn; sm[4 + (threadIdx.x >> 6)] = n2; sm[8 + (threadIdx.x >> 6)] = nf; }
     __syncthreads();
-    if (threadIdx.x == 0) { out[0] = min(min(sm[0], sm[1]), min(sm[2], sm[3])); out[1] = sm[4] + sm[5] + sm[6] + sm[7]; out[2] = sm[8] + sm[9] + sm[10] + sm[11]; __threadfence_system(); }      // (out may be mapped host memory)
+    if (threadIdx.x == 0) {
+        out[0] = min(min(sm[0], sm[1]), min(sm[2], sm[3])); out[1] = sm[4] + sm[5] + sm[6] + sm[7]; out[2] = sm[8] + sm[9] + sm[10] + sm[11];
+        __threadfence_system();          // (out may be mapped host memory: the three values are visible to the host before the flag)
+        __hip_atomic_store(out + 3, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);      // out[3] = 1: "ready" -- a host that cleared it before the call may poll it instead of synchronising the stream
+    }
 }
+// order[] = the instances sorted by iteration count, largest first (counting sort over check intervals; ties in arbitrary order): one workgroup
+__global__ void __launch_bounds__(256) k_dispatch_order(int B, const int *__restrict__ iters, int *__restrict__ order) {
+    constexpr int NB = 512;                       // buckets of CONVERGED_INTERVAL iterations; anything longer shares the last one
+    __shared__ int cnt[NB];
+    for (int b = threadIdx.x; b < NB; b += 256) cnt[b] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < B; i += 256) { const int b = min(max(iters[i], 0) / CONVERGED_INTERVAL, NB - 1); atomicAdd(&cnt[NB - 1 - b], 1); }      // (bucket 0 = longest)
+    __syncthreads();
+    if (threadIdx.x == 0) { int acc = 0; for (int b = 0; b < NB; b++) { const int c = cnt[b]; cnt[b] = acc; acc += c; } }
+    __syncthreads();
+    for (int i = threadIdx.x; i < B; i += 256) { const int b = min(max(iters[i], 0) / CONVERGED_INTERVAL, NB - 1); order[atomicAdd(&cnt[NB - 1 - b], 1)] = i; }
+}
+int ce_set_dispatch_history(ce_handle h, int on) {
+    if (!h) { g_err = "null argument"; return CE_E_BADARG; }
+    h->dispatch_history = on != 0;
+    if (!on) h->order_B = 0;
+    return CE_OK;
+}
+
 int ce_status_summary(ce_handle h, int B, const int *status, int *summary_host, void *stream) {
     if (!h || B <= 0 || !status || !summary_host) { g_err = "null argument"; return CE_E_BADARG; }
     HIPCHK(hipSetDevice(h->device));
@@ -710,7 +744,7 @@ int ce_status_summary(ce_handle h, int B, const int *status, int *summary_host, 
     int *slot = h->d_summary + 4 * (h->summary_next++ & 7);      // a few calls may be in flight on the stream before the caller synchronises
     hipLaunchKernelGGL(k_status_summary, dim3(1), dim3(256), 0, (hipStream_t)stream, B, status, slot);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(summary_host, slot, 3 * sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIPCHK(hipMemcpyAsync(summary_host, slot, 4 * sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));      // (three values + the ready flag)
     return CE_OK;
 }
 

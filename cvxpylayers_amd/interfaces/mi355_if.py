@@ -37,7 +37,7 @@ STATUS_NAMES = {1: "Solved", 2: "Solved/Inaccurate", -1: "Unbounded", -2: "Infea
 
 _KNOWN_ARGS = {"eps", "eps_abs", "eps_rel", "eps_infeas", "max_iters", "alpha", "rho_x", "scale", "normalize",
                "adaptive_scale", "acceleration_lookback", "acceleration_interval", "verbose", "mode", "solve_method",
-               "n_jobs_forward", "n_jobs_backward", "warm_starts", "raise_on_error"}
+               "n_jobs_forward", "n_jobs_backward", "warm_starts", "raise_on_error", "dispatch_history"}
 
 
 _WARNED: set = set()
@@ -141,6 +141,12 @@ class ConeEngine:
         self._h = h
         self.qp_native = bool(self.nnz_p) and bool(L.ce_qp_native(h))     # P runs inside the kernels (else: epigraph form upstream)
 
+    def set_dispatch_history(self, on: bool):
+        """Longest-first dispatch from the previous call's iteration counts (include/cone_engine.h ce_set_dispatch_history): a scheduling hint, results are
+        bit-identical either way."""
+        _lib.check(_lib.lib().ce_set_dispatch_history(self._h, int(bool(on))), "ce_set_dispatch_history")
+        self.dispatch_history = bool(on)
+
     def __del__(self):
         try:
             if getattr(self, "_h", None):
@@ -227,12 +233,28 @@ class ConeEngine:
         read with read_summaries() after ONE stream synchronisation."""
         if getattr(self, "_summary_host", None) is None:
             self._summary_host = torch.zeros((2, 4), dtype=torch.int32).pin_memory()
+            self._summary_np = self._summary_host.numpy()          # (shares the pinned memory)
+        self._summary_np[slot, 3] = 0                               # "ready" flag, set by the device after the three values
+        self._summary_last_slot = slot
         stream = torch.cuda.current_stream(self.device)
         _lib.check(_lib.lib().ce_status_summary(self._h, int(vec.numel()), vec.data_ptr(), self._summary_host[slot].data_ptr(), C.c_void_p(stream.cuda_stream)), "ce_status_summary")
 
     def read_summaries(self):
-        torch.cuda.current_stream(self.device).synchronize()
-        return self._summary_host.tolist()
+        """Waits for the summaries enqueued on this stream and returns them.  The last one enqueued carries a ready flag in pinned memory: polling it
+        (a few hundred microseconds at most -- the stream holds one solve) spares the wake-up latency of a blocking stream synchronisation, which sits
+        in the gap between the forward and the backward kernel of a training step.  CE_SPIN_WAIT=0: always synchronise the stream."""
+        import os
+        import time
+        slot = getattr(self, "_summary_last_slot", None)
+        if slot is not None and os.environ.get("CE_SPIN_WAIT") != "0":
+            arr, t0 = self._summary_np, time.perf_counter()
+            while arr[slot, 3] == 0:
+                if time.perf_counter() - t0 > 0.25:                 # long solves: hand the core back
+                    torch.cuda.current_stream(self.device).synchronize()
+                    break
+        else:
+            torch.cuda.current_stream(self.device).synchronize()
+        return self._summary_np.tolist()
 
     def status_summary(self, status: torch.Tensor) -> tuple[int, int]:
         """(min status, number of Solved/Inaccurate) of a status vector on this engine's device: one launch + a 12-byte pinned copy + one stream sync."""
@@ -452,6 +474,10 @@ class MI355_ctx:
             pst = (self.quad.p_indices, self.quad.p_indptr) if self.quad is not None and self.quad.sym_perm is not None else None
             self._engines[idx] = ConeEngine(self.A_structure[0], self.A_structure[1], self.A_shape[1] - 1, self.A_shape[0],
                                             self.cone_dict, torch.device("cuda", idx), p_structure=pst)
+            # A layer is called again and again on related batches (training steps, sweeps): dispatch the instances that ran longest last time first
+            # (options={"dispatch_history": False} or CE_DISPATCH_HISTORY=0 switch it off; see include/cone_engine.h)
+            import os
+            self._engines[idx].set_dispatch_history(bool(self.options.get("dispatch_history", True)) and os.environ.get("CE_DISPATCH_HISTORY") != "0")
         return self._engines[idx]
 
 

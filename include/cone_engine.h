@@ -91,8 +91,8 @@ void ce_default_settings(ce_settings *s);
  * library short structs.  Bindings must check  ce_abi_version() == CE_ABI_VERSION  and  ce_struct_size(which) == sizeof(their
  * struct)  (which: 0 ce_template, 1 ce_settings) once at load time and refuse to continue otherwise (cvxpylayers_amd/_lib.py
  * does; tests/test_cabi.py checks the stub printed in INTEGRATION.md the same way).  CE_ABI_VERSION is bumped whenever a struct
- * layout, an entry point's signature or the meaning of an argument changes (7: ce_status_summary added; 6: ce_default_settings = SCS defaults incl. acceleration_lookback 10, ce_acceleration_available). */
-#define CE_ABI_VERSION 7
+ * layout, an entry point's signature or the meaning of an argument changes (8: ce_set_dispatch_history added, ce_status_summary writes a fourth "ready" int; 7: ce_status_summary added; 6: ce_default_settings = SCS defaults incl. acceleration_lookback 10, ce_acceleration_available). */
+#define CE_ABI_VERSION 8
 int ce_abi_version(void);
 int ce_struct_size(int which);
 /* 1 when ce_solve / ce_solve_qp on this engine honour ce_settings.acceleration_lookback > 0 (second-generation forward kernel with
@@ -142,8 +142,9 @@ int ce_vjp(ce_handle h, int B,
 int ce_transpose(ce_handle h, int rows, int cols, const double *in, double *out, void *stream);
 
 /* Enqueues, behind whatever produced v[] (B int32 on the device: the status of a forward call or the adj_status of a backward call), the reduction
- * summary_host[0] = min_i v[i], [1] = #{i: v[i] == 2}, [2] = #{i: (v[i] & 3) != 0} and its copy to summary_host (3 ints of PINNED host memory).  The caller
- * synchronises the stream (or an event) before reading it.  This is the only host <- device traffic a forward call of the Python plugin needs in order to
+ * summary_host[0] = min_i v[i], [1] = #{i: v[i] == 2}, [2] = #{i: (v[i] & 3) != 0} and its copy to summary_host (FOUR ints of PINNED host memory: the
+ * fourth is set to 1 after the three values are visible).  The caller synchronises the stream (or an event) before reading it -- or clears
+ * summary_host[3] before the call and polls it.  This is the only host <- device traffic a forward call of the Python plugin needs in order to
  * honour the reference's contract that a failed instance raises SolverError from forward() (diffcp_if.py:365-372 raises inside the call): 12 bytes instead
  * of the status vector.  When summary_host is pinned memory mapped into the device's address space (hipHostMalloc / torch's pin_memory) the kernel stores
  * there directly; any other host pointer goes through one of EIGHT rotating device slots and an asynchronous copy: at most eight such calls may be in flight
@@ -251,6 +252,14 @@ int ce_solve_shared_a(ce_handle h, int B, int r, int RP, const double *AdT, cons
  */
 int ce_vjp_shared_a(ce_handle h, int B, const double *A_vals0, const double *x, const double *y, const double *s, const double *dx, const double *dy,
                     double *dA_bm, double *dq_vals, long sdq_k, long sdq_b, int *adj_status, int *lsqr_iters, double atol, double btol, int iter_lim, void *stream);
+
+/* Longest-first dispatch.  Workgroups are dispatched in index order and one workgroup owns one instance, so the tail of a forward launch is set by the
+ * instances that happen to start last: when they are long ones the last slots drain slowly (13 % of the metric configuration's kernel time).  With the switch
+ * on, every ce_solve also records the order "instances by iteration count, largest first" (one tiny kernel behind the solve) and the NEXT ce_solve of the
+ * same batch size dispatches its workgroups in that order.  It is a scheduling hint only -- results are bit-identical in any order -- and it pays exactly
+ * when consecutive calls see related instances in the same positions (full-batch training loops, parameter sweeps over a fixed data set, this repository's
+ * benchmark); on unrelated batches it is neutral.  Register-tiled forward kernels only (fwd_mode 4).  Off by default at the C ABI. */
+int ce_set_dispatch_history(ce_handle h, int on);
 
 /* Introspection used by bench.py / tests: per-kernel HIP-event timing on the launch stream. */
 int ce_set_profiling(ce_handle h, int enable);

@@ -679,11 +679,11 @@ def test_rank_tolerance_is_one_constant_across_the_adjoint_kernels(monkeypatch):
     the size-generic kernel (CE_FORCE_GENERIC=1) with its unblocked and its blocked elimination: the same rank tolerance (CE_RANK_TOL = 1e-11 max|K|, the
     oracle's) decides what a vanishing pivot is in all of them, so the three return the same basic solution and the same flag (4: rank deficient)."""
     from cvxpylayers_amd.interfaces.mi355_if import ConeEngine, make_settings
-    cones = {"z": 3, "l": 20, "q": [6, 5]}
     n, B = 24, 8
+    A0, b0, c = P.generate(n, {"z": 2, "l": 20, "q": [6, 5]}, B, seed=21)
+    A = np.concatenate([A0[:, :1, :], A0], axis=1); b = np.concatenate([b0[:, :1], b0], axis=1)      # equality row 0 twice: consistent, and (x0, (0, y0)) stays a certificate
+    cones = {"z": 3, "l": 20, "q": [6, 5]}
     tpl = P.dense_template(n, cones)
-    A, b, c = P.generate(n, cones, B, seed=21)
-    A[:, 1, :] = A[:, 0, :]; b[:, 1] = b[:, 0]
     A_eval, q_eval = tpl.values_from_dense(A, b, c)
     outs = {}
     for key, env in (("rt", {}), ("generic_unblocked", {"CE_FORCE_GENERIC": "1", "CE_GEN_BLOCKED": "0"}), ("generic_blocked", {"CE_FORCE_GENERIC": "1", "CE_GEN_BLOCKED": "1"})):
@@ -712,3 +712,36 @@ def test_rank_tolerance_is_one_constant_across_the_adjoint_kernels(monkeypatch):
         # dA, db, dc are the same for every solution of the consistent singular system only up to the free variable's choice: both kernels set it to zero
         assert np.abs(dq - ref[1]).max() < 1e-8 * (1 + np.abs(ref[1]).max()), (key, np.abs(dq - ref[1]).max())
         assert np.abs(dA - ref[0]).max() < 1e-8 * (1 + np.abs(ref[0]).max()), (key, np.abs(dA - ref[0]).max())
+
+
+def test_longest_first_dispatch_is_a_scheduling_hint_only():
+    """ce_set_dispatch_history: the second solve of a batch dispatches its workgroups by the first solve's iteration counts, longest first.  Every instance is
+    computed by the same code whatever workgroup index it gets: solutions, iteration counts and statuses are BIT-identical with the hint on and off, and for a
+    different batch of the same size (a stale order is still a permutation)."""
+    from cvxpylayers_amd.interfaces.mi355_if import ConeEngine, make_settings
+    cfg = P.CONFIGS["M"]; n, cones, B = cfg["n"], cfg["cones"], 777
+    tpl = P.dense_template(n, cones)
+    eng = ConeEngine(tpl.indices, tpl.indptr, tpl.n, tpl.m, cones, torch.device("cuda", 0))
+    st = lambda: make_settings(dict(eps=1e-4, max_iters=10000, acceleration_lookback=10))
+    outs = []
+    for seed in (0, 1):
+        A, b, c = P.generate(n, cones, B, seed=seed)
+        A_eval, q_eval = tpl.values_from_dense(A, b, c)
+        A_bm = torch.from_numpy(A_eval).cuda().t().contiguous(); q_t = torch.from_numpy(q_eval).cuda()
+        eng.set_dispatch_history(False)
+        ref = [t.clone() for t in eng.solve(A_bm, q_t, st())]
+        eng.set_dispatch_history(True)
+        first = [t.clone() for t in eng.solve(A_bm, q_t, st())]          # seed 0: no order yet; seed 1: the order of seed 0's batch (stale, harmless)
+        second = [t.clone() for t in eng.solve(A_bm, q_t, st())]         # dispatched by `first`'s iteration counts
+        for got in (first, second):
+            for a_, b_ in zip(got, ref):
+                assert torch.equal(a_, b_)
+        assert len(torch.unique(ref[3])) > 1                              # (the batch does have instances of different length)
+        outs.append(ref)
+    # smaller batch afterwards: the recorded order (777 entries) must not be applied
+    A, b, c = P.generate(n, cones, 100, seed=2)
+    A_eval, q_eval = tpl.values_from_dense(A, b, c)
+    A_bm = torch.from_numpy(A_eval).cuda().t().contiguous(); q_t = torch.from_numpy(q_eval).cuda()
+    x1 = eng.solve(A_bm, q_t, st())[0].clone()
+    eng.set_dispatch_history(False)
+    assert torch.equal(x1, eng.solve(A_bm, q_t, st())[0])

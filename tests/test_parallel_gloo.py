@@ -147,6 +147,46 @@ def test_world_size_2_gloo_with_the_real_plugin_convention_against_reference_fix
     mp.spawn(_real_plugin_worker, args=(2, port), nprocs=2, join=True)
 
 
+def _frontend_worker(rank, world, port):
+    """The FRONTEND's own code on two ranks: cvxpylayers_amd.torch.CvxpyLayer.validate_params / _flatten_params (a broadcast parameter is expanded there:
+    its gradient is a sum over the batch) and _recover_results_torch, around parallel.sharded_apply with the CPU oracle behind the plugin convention.  Only
+    the two device-only pieces are replaced: the parameter maps are applied with the layer's own (re-indexed) scipy matrices instead of the HIP SpMM, the
+    plugin is OraclePlugin instead of MI355's.  Checked against the fixture the REFERENCE's glue produced for this layer (outputs and both gradients)."""
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import numpy as np
+    import ref_cases
+    from oracle_layer import OraclePlugin
+    from cvxpylayers_amd.parallel import allreduce_broadcast_grad, shard_bounds, sharded_apply
+    from cvxpylayers_amd.torch import CvxpyLayer
+    f = np.load(os.path.join(GOLD, "refglue_ridge_mixed.npz"))
+    tpl = ref_cases.CASES["ridge_mixed"]()["template"]
+    layer = CvxpyLayer(template=tpl)                                          # (construction needs no device: engines are created at the first GPU call)
+    F = torch.tensor(f["param0"], requires_grad=True); g = torch.tensor(f["param1"], requires_grad=True)      # F unbatched (broadcast), g batched
+    batch = layer.validate_params([F, g])
+    B = batch[0]
+    p_bm = layer._flatten_params((F, g), batch)                                # the frontend's flattening (expand of the unbatched parameter)
+    A_bm = p_bm @ torch.tensor(layer._A.mat.toarray()).t(); q_bm = p_bm @ torch.tensor(layer._q.mat.toarray()).t()
+    np.testing.assert_allclose(A_bm.t().detach().numpy(), f["A_eval"], atol=1e-12)     # what the reference's maps hand the plugin
+    primal, dual, info = sharded_apply(OraclePlugin, q_bm.t(), A_bm.t(), tpl, dict(ref_cases.SOLVER_ARGS), True, total=B)
+    x, = layer._recover_results_torch(primal, dual, batch)                     # the frontend's recovery
+    assert np.abs(x.detach().numpy() - f["out0"]).max() < 1e-8
+    (x * torch.tensor(f["weight0"])).sum().backward()                          # the same loss on every rank (bench.py's contract)
+    lo, hi = shard_bounds(B, rank, world)
+    want_g = np.zeros_like(f["grad1"]); want_g[lo:hi] = f["grad1"][lo:hi]
+    assert np.abs(g.grad.numpy() - want_g).max() < 1e-6                        # batched parameter: this rank's rows, the others zero
+    Fg = allreduce_broadcast_grad(F.grad.clone())
+    assert np.abs(Fg.numpy() - f["grad0"]).max() < 1e-6                        # broadcast parameter: the single-process (reference) gradient after the all-reduce
+    assert np.abs(F.grad.numpy() - f["grad0"]).max() > 1e-3                    # ... which this rank alone does not hold
+    dist.destroy_process_group()
+
+
+def test_world_size_2_gloo_through_the_frontend_with_a_broadcast_parameter():
+    port = 29500 + (os.getpid() % 2000) + 11
+    mp.spawn(_frontend_worker, args=(2, port), nprocs=2, join=True)
+
+
 def test_bench_dry_run_ranks_exercises_the_self_spawn_plumbing():
     import json
     import subprocess
