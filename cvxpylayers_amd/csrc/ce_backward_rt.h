@@ -39,7 +39,10 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
               double *__restrict__ dAo, double *__restrict__ dqo, long sdqk, long sdqb, int *__restrict__ adj_status,
               const double *__restrict__ Pvals_g = nullptr, int nnzP = 0, const int *__restrict__ pmap = nullptr,
               const int *__restrict__ prow = nullptr, const int *__restrict__ pcol = nullptr, int p_tri = 0,
-              double *__restrict__ dPo = nullptr) {
+              double *__restrict__ dPo = nullptr, int retry = 0) {
+    // retry: second launch of a two-tile plan (cone_engine.hip ce_vjp_qp): a SMALLER tile variant has already served every instance whose system fits it
+    // and flagged the others (adj_status 2, zero gradient); this launch -- the template's worst-case tile -- recomputes the flagged ones only.
+    if (retry && adj_status[blockIdx.x] != 2) return;
     // Quadratic objective (Pvals_g != nullptr): the reduced adjoint system is [[H + P, -B^T], [B, 0]] (x-block of M^T r = dz gains
     // P r_x) and dP = -sym(r_x x^T) (oracle/cone_oracle.c adjoint_one with r_tau = 0).  pmap: n x n map to the entries of the P
     // structure (-1: structural zero); a one-triangle structure (p_tri) maps (i,j) and (j,i) to one entry, whose gradient is doubled.

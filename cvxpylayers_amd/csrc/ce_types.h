@@ -40,6 +40,7 @@ struct CeBwdArgs {
     double *dA, *dq; long sdqk, sdqb; int *adj;
     const double *P; int nnz_p; const int *pmap, *prow, *pcol; int p_tri; double *dP;
     double *gA, *gK;
+    int retry;                  // k_backward_rt: 1 = recompute only the instances an earlier launch flagged (adj == 2)
 };
 
 // launchers (one per kernel object file): 0 on success, -1 unknown variant

@@ -82,6 +82,7 @@ struct ce_engine {
     bool dispatch_history = false; int *d_order = nullptr; int order_B = 0, order_cap = 0;
     bool f3 = false; int *d_idx_at3 = nullptr, *d_idx_ar3 = nullptr, *d_slot_soc = nullptr;      // third-generation forward kernel (k_fwd3, fwd_mode 5): iteration-tile gather maps, cone layout of the y slots
     int brt_variant = -1;                          // register-tiled backward kernel variant (-1: generic kernel)
+    int brt_fast = -1; size_t bwd_lds_fast = 0;     // two-tile plan: a smaller tile serves the instances it holds (typical active sets), the worst-case tile retries the rest
     // quadratic objective
     int nnz_p = 0, p_tri = 0; bool qp_native = false;
     bool aa_ok = false;                            // the forward launch carries the LDS for the Anderson-acceleration vectors
@@ -149,8 +150,8 @@ static size_t bwd_lds_bytes(const DevT &T, bool a_lds, bool k_lds, int nkcap, in
 #endif
 // register-tiled backward variants {TI, TJ, TH}: K tile 16*TI x 16*TJ per workgroup, H tile 16*TH
 // {TI, TJ, TH, row residues BGR}: K tile BGR*TI x 16*TJ per workgroup of BGR*16 threads
-constexpr int BRT_NV = 4;
-static const int BRT_VARIANTS[BRT_NV][4] = {{4, 4, 4, 16}, {7, 7, 4, 16}, {7, 7, 7, 16}, {7, 13, 7, 32}};
+constexpr int BRT_NV = 6;
+static const int BRT_VARIANTS[BRT_NV][4] = {{4, 4, 4, 16}, {5, 5, 4, 16}, {6, 6, 4, 16}, {7, 7, 4, 16}, {7, 7, 7, 16}, {7, 13, 7, 32}};      // ({5,5,4}, {6,6,4}: plain cones only -- "fast" tiles of the two-tile plan)
 static size_t bwd_rt_lds_bytes(const DevT &T, int TI, int TJ, int BGR) {
     const int n = T.n, m = T.m, nqs = std::max(T.nq, 1);
     size_t d = (size_t)m * n /* lda = n */ + 3 * (size_t)m + 2 * (size_t)n + 6 * nqs + BGR * TI + 5 /* pinfo: two 16-byte records + alignment */ + (BGR * 16 / 64) * 8 + bwd_rt_union_doubles(n, m, nqs, TI, TJ, BGR);
@@ -496,10 +497,27 @@ int ce_create(const ce_template *tpl, int device, ce_handle *out) {
     { const char *gb = getenv("CE_GEN_BLOCKED"); if (gb && !strcmp(gb, "0")) T.gen_blocked_b = 0; }      // A/B switch (tests): the unblocked elimination of the size-generic backward kernel
     h->bwd_lds = bwd_lds_bytes(T, h->bwd_mode <= 1, h->bwd_mode == 0, h->nkcap, h->ldk, T.gen_blocked_b != 0);
     if (!getenv("CE_FORCE_GENERIC")) {
+        const bool plain = T.ns == 0 && T.nep + T.np == 0;
         for (int v = 0; v < BRT_NV; v++) {
             const int TI = BRT_VARIANTS[v][0], TJ = BRT_VARIANTS[v][1], TH = BRT_VARIANTS[v][2], BGR = BRT_VARIANTS[v][3];
+            if ((v == 1 || v == 2) && !plain) continue;              // (instantiated for plain cones only)
             if (h->nkcap <= BGC * TJ - 1 && h->nkcap <= BGR * TI && T.n <= BGC * TH && bwd_rt_lds_bytes(T, TI, TJ, BGR) <= LDS_LIMIT) {
                 h->brt_variant = v; h->bwd_mode = 3; h->bwd_lds = bwd_rt_lds_bytes(T, TI, TJ, BGR); break;
+            }
+        }
+        // Two-tile plan.  The tile above holds the template's WORST case (NK <= n + min(m, n): every row active); a typical optimum has far fewer equality
+        // rows -- the zero rows, about half of the nonnegative rows, one row per second-order cone on its boundary -- and on the worst-case tile most of
+        // every pivot's broadcast and rank-1 update runs over empty column slots (metric configuration: NK = 63 of 111, 4 of 7 slots).  When a smaller
+        // tile holds the typical system, it serves the batch first; instances that exceed it are flagged by the kernel (adj 2) and recomputed by a second
+        // launch of the worst-case tile that exits at once for everybody else.  CE_BWD_TWO_TILE=0 disables.
+        const char *tt = getenv("CE_BWD_TWO_TILE");
+        if (h->bwd_mode == 3 && plain && h->nnz_p == 0 && BRT_VARIANTS[h->brt_variant][3] == 16 && !(tt && !strcmp(tt, "0"))) {
+            const int typ = T.n + T.z + T.nq + (T.l + 1) / 2 + BGC;      // + one column slot of margin: a retry is expensive however few there are (its launch lasts as long as ONE instance
+                                                                          // takes on an otherwise idle device, ~0.09 ms at the metric configuration: profiles/r04/e_ab_bwd_two_tile.log)
+            const char *fv = getenv("CE_BWD_FAST_VARIANT");      // tests: force a (too small) first tile so that the retry launch has work
+            for (int v = (fv ? atoi(fv) : 0); v < h->brt_variant; v++) {
+                const int TI = BRT_VARIANTS[v][0], TJ = BRT_VARIANTS[v][1], TH = BRT_VARIANTS[v][2], BGR = BRT_VARIANTS[v][3];
+                if ((fv || (typ <= BGC * TJ - 1 && typ <= BGR * TI)) && T.n <= BGC * TH && bwd_rt_lds_bytes(T, TI, TJ, BGR) <= LDS_LIMIT) { h->brt_fast = v; h->bwd_lds_fast = bwd_rt_lds_bytes(T, TI, TJ, BGR); break; }
             }
         }
     }
@@ -673,6 +691,11 @@ int ce_vjp_qp(ce_handle h, int B, const double *A_vals, long sA_k, long sA_b, co
         int lrc;
         if (h->bwd_mode == 3) {
             ba.T.lda = T.n;
+            if (h->brt_fast >= 0 && adj_status && !P_vals) {          // two-tile plan (ce_create): the small tile for everybody, the worst-case tile for the instances it flagged
+                lrc = ce_launch_bwd_rt_plain(h->brt_fast, B, h->bwd_lds_fast, st, ba);
+                ba.retry = 1;
+                if (!lrc) lrc = ce_launch_bwd_rt_plain(h->brt_variant, B, h->bwd_lds, st, ba);
+            } else
             lrc = (T.ns > 0 || T.nep + T.np > 0) ? ce_launch_bwd_rt_psd(h->brt_variant, B, h->bwd_lds, st, ba) : ce_launch_bwd_rt_plain(h->brt_variant, B, h->bwd_lds, st, ba);
         } else lrc = ce_launch_bwd_generic(h->bwd_mode, B, h->bwd_lds, st, ba);
         if (lrc) { g_err = "internal: no backward kernel for the planned variant"; return CE_E_BADARG; }
