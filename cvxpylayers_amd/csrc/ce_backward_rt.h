@@ -39,7 +39,7 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
               double *__restrict__ dAo, double *__restrict__ dqo, long sdqk, long sdqb, int *__restrict__ adj_status,
               const double *__restrict__ Pvals_g = nullptr, int nnzP = 0, const int *__restrict__ pmap = nullptr,
               const int *__restrict__ prow = nullptr, const int *__restrict__ pcol = nullptr, int p_tri = 0,
-              double *__restrict__ dPo = nullptr, int retry = 0) {
+              double *__restrict__ dPo = nullptr, int retry = 0, int *__restrict__ nk_max = nullptr) {
     // retry: second launch of a two-tile plan (cone_engine.hip ce_vjp_qp): a SMALLER tile variant has already served every instance whose system fits it
     // and flagged the others (adj_status 2, zero gradient); this launch -- the template's worst-case tile -- recomputes the flagged ones only.
     if (retry && adj_status[blockIdx.x] != 2) return;
@@ -53,6 +53,8 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
     constexpr int NTB = BGR * BGC, NWB = NTB / 64;      // threads / waves of this instantiation
     const int ra = tid & (BGR - 1), cb = tid / BGR;
     constexpr int NKCAP = BGC * TJ - 1;          // column NK (the right-hand side) must exist: NK <= 16*TJ - 1, rows NK <= 16*TI
+    constexpr int THI = (TH * BGC + BGR - 1) / BGR;      // row slots of the H block (columns: TH slots of 16; rows: slots of BGR)
+    static_assert(THI <= TI && TH <= TJ, "the H block lives inside the tile");
 
     // ---- LDS carve.  U is a union region: {a_y, a_s} during assembly, {colbuf, rowbuf} during elimination, {part, A r_x} after.
     double *p = sm;
@@ -226,6 +228,7 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
     }
     const int neq = misc[0];
     const int NK = n + neq;
+    if (nk_max && tid == 0) atomicMax(nk_max, NK);          // (the host sizes the NEXT call's first tile by it)
     if (NK > NKCAP || NK > BGR * TI) {   // more active rows than the register tile holds: degenerate instance (flagged, zero gradient)
         for (int k = tid; k < T.nnz_aug; k += NTB) dAo[(size_t)inst * T.nnz_aug + k] = 0.0;
         for (int j = tid; j <= n; j += NTB) dqo[j * sdqk + inst * sdqb] = 0.0;
@@ -343,22 +346,22 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
 #pragma unroll 4
         for (int ii = r0; ii < r1; ii++) {
             const double *row = A + ii * lda;
-            double ar[TH], ac[TH];
+            double ar[THI], ac[TH];
             // unguarded reads (a guarded read is a branch per entry, a select two more VALU operations per value): an index past the row's n entries stays
             // inside the LDS carve (the following row, or the vectors behind the last one), and the tile entries it pollutes -- row or column index
             // >= n -- are reset after the accumulation
 #pragma unroll
-            for (int i = 0; i < TH; i++) ar[i] = th * row[ra + BGR * i];
+            for (int i = 0; i < THI; i++) ar[i] = th * row[ra + BGR * i];
 #pragma unroll
             for (int j = 0; j < TH; j++) ac[j] = row[cb + BGC * j];
 #pragma unroll
-            for (int i = 0; i < TH; i++)
+            for (int i = 0; i < THI; i++)
 #pragma unroll
                 for (int j = 0; j < TH; j++) kt[i][j] = fma(ar[i], ac[j], kt[i][j]);
         }
         const double *ayc = ay + c * n, *asc = as + c * n;
 #pragma unroll
-        for (int i = 0; i < TH; i++)
+        for (int i = 0; i < THI; i++)
 #pragma unroll
             for (int j = 0; j < TH; j++) {
                 const int r = ra + BGR * i, cc = cb + BGC * j;
@@ -366,7 +369,7 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
             }
     }
 #pragma unroll
-    for (int i = 0; i < TH; i++)
+    for (int i = 0; i < THI; i++)
 #pragma unroll
         for (int j = 0; j < TH; j++) if (ra + BGR * i >= n || cb + BGC * j >= n) kt[i][j] = 0.0;
     if constexpr (PSD) {   // weighted rows of rotated PSD blocks: H += theta_t a_t^T a_t
@@ -374,13 +377,13 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
             if (rkind[t] != RK_MIX) continue;              // uniform
             const double th = lamr[t] / (1 - lamr[t]);
             const double *row = A + t * lda;
-            double ar[TH], ac[TH];
+            double ar[THI], ac[TH];
 #pragma unroll
-            for (int i = 0; i < TH; i++) ar[i] = (ra + BGR * i < n) ? th * row[ra + BGR * i] : 0.0;
+            for (int i = 0; i < THI; i++) ar[i] = (ra + BGR * i < n) ? th * row[ra + BGR * i] : 0.0;
 #pragma unroll
             for (int j = 0; j < TH; j++) ac[j] = (cb + BGC * j < n) ? row[cb + BGC * j] : 0.0;
 #pragma unroll
-            for (int i = 0; i < TH; i++)
+            for (int i = 0; i < THI; i++)
 #pragma unroll
                 for (int j = 0; j < TH; j++) kt[i][j] = fma(ar[i], ac[j], kt[i][j]);
         }
@@ -388,7 +391,7 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
     if (Pvals_g) {   // uniform
         const double *pv = Pvals_g + (size_t)inst * nnzP;
 #pragma unroll
-        for (int i = 0; i < TH; i++)
+        for (int i = 0; i < THI; i++)
 #pragma unroll
             for (int j = 0; j < TH; j++) {
                 const int r = ra + BGR * i, cc = cb + BGC * j;

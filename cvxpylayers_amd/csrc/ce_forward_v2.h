@@ -839,6 +839,10 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
     __syncthreads();
 
     int status = 0, iter = 0, last_scale_iter = 0, n_log = 0;
+    // iter % acceleration_interval and iter % CONVERGED_INTERVAL as counters: the remainders of a run-time divisor were ~35 scalar instructions at the top of EVERY
+    // iteration (two of them: `iter` and `iter + 1`), on a path where one wave issues one instruction per four cycles
+    int aa_ph = 0, chk_ph = 0;
+    auto next_iter = [&]() { iter++; aa_ph = (aa_ph + 1 >= S.acceleration_interval) ? 0 : aa_ph + 1; chk_ph = (chk_ph + 1 == CONVERGED_INTERVAL) ? 0 : chk_ph + 1; };
     // Anderson acceleration of the iteration map w -> F(w) (type I, one secant pair; oracle/cone_oracle.c with aa_mem = 1):
     // every aa_int iterations, with x = input and f = output of the last iteration, g = x - f, s = x - x_prev, y = g - g_prev,
     // d = f - f_prev:  w <- f - (s.g / (s.y + 1e-8 |s||y|)) d.   The next iteration's residual is the safeguard: if it exceeds |g| the
@@ -895,7 +899,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
         const int e = Co::thread_id(wave);
         if (e < l) { const int ve = slot_of(e); sm[L::O_W + ve] += alpha * (sm[L::O_U + ve] - sm[L::O_UT + ve]); }
         __syncthreads();
-        resume = false; iter++;
+        resume = false; next_iter();
     }
     for (;;) {
         if (iter >= S.max_iters) { done = true; break; }
@@ -905,7 +909,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
         const int e = co.t;
         const int ve = slot_of(e);
         const bool ev = e < l;
-        const bool check = (iter % CONVERGED_INTERVAL) == 0;
+        const bool check = chk_ph == 0;
         const bool last = iter + 1 >= S.max_iters;
         if (aa_on) {      // (uniform)
             if (aa_pending) {      // safeguard: residual of the map at the accelerated point against the residual before the step
@@ -920,7 +924,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
                 }
                 aa_pending = false;
             }
-            if (aa_on && iter > 0 && iter % aa_int == 0 && !aa_stale) {      // (aa_stale: the kept input predates a rescale -- with an interval that puts a step right behind a check iteration it would pair a pre-rescale input with a post-rescale output)
+            if (aa_on && iter > 0 && aa_ph == 0 && !aa_stale) {      // (aa_stale: the kept input predates a rescale -- with an interval that puts a step right behind a check iteration it would pair a pre-rescale input with a post-rescale output)
                 const double xv = ev ? aaWP[ve] : 0.0, fv = ev ? sm[L::O_W + ve] : 0.0, gv = xv - fv;
                 if (aa_iter > 0) {
                     const double xp = ev ? aaXP[ve] : 0.0, fp = ev ? aaFP[ve] : 0.0;
@@ -953,7 +957,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
             if (aa_on && nw > 0 && threadIdx.x == 0) sc[8] *= sqrt((double)l) / nw;
             __syncthreads();
         }
-        if (aa_on && (aa_pending || (iter + 1) % aa_int == 0)) { aa_stale = false; if (ev) aaWP[ve] = sm[L::O_W + ve]; }      // input of this iteration, kept where the top of the next one reads it (the safeguard after a step, the step itself every aa_int iterations)
+        if (aa_on && (aa_pending || aa_ph + 1 == aa_int)) { aa_stale = false; if (ev) aaWP[ve] = sm[L::O_W + ve]; }      // input of this iteration, kept where the top of the next one reads it (the safeguard after a step, the step itself every aa_int iterations)
         // P1a: t = rho_x w_x - A^T w_y   (+ phi . w from the two spare column groups)
         {
             const double *wvec = sm + L::O_W + ((j1 == n + 1 && T1 * c1 < n) ? OX : OY) + T1 * c1;
@@ -1039,7 +1043,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
                 if (upd) sm[L::O_W + OT] = wt + alpha * (ut - tau_t);
             }
             __syncthreads();
-            if (upd) { iter++; continue; }
+            if (upd) { next_iter(); continue; }
         } else {
         // P2: q = A p_x ; tau-tilde ; u-tilde ; cone input
         {
@@ -1113,7 +1117,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
                 sm[L::O_W + ve] += alpha * (ue - sm[L::O_UT + ve]);
             }
             __syncthreads();
-            iter++;
+            next_iter();
             continue;
         }
         // ---- slow path (every CONVERGED_INTERVAL iterations, and the last one)
@@ -1212,11 +1216,11 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
             }
         }
         if (stop) { done = true; break; }
-        if (last) { iter++; done = true; break; }
+        if (last) { next_iter(); done = true; break; }
         if (rescale) { resume = true; break; }      // -> refactor() with the new scale, then finish this iteration
         if (ev) sm[L::O_W + ve] += alpha * (sm[L::O_U + ve] - sm[L::O_UT + ve]);
         __syncthreads();
-        iter++;
+        next_iter();
     }
     }
 

@@ -14,7 +14,7 @@ namespace {
 #ifndef CE_BRT_PSD
 #error "compile with -DCE_BRT_PSD=0|1"
 #endif
-#define BRT_ARGS a.T, a.Abm, a.x, a.y, a.s, a.dx, a.dy, a.dA, a.dq, a.sdqk, a.sdqb, a.adj, a.P, a.nnz_p, a.pmap, a.prow, a.pcol, a.p_tri, a.dP, a.retry
+#define BRT_ARGS a.T, a.Abm, a.x, a.y, a.s, a.dx, a.dy, a.dA, a.dq, a.sdqk, a.sdqb, a.adj, a.P, a.nnz_p, a.pmap, a.prow, a.pcol, a.p_tri, a.dP, a.retry, a.nk_max
 #define LAUNCH_BRT(NTHREADS, ...) hipLaunchKernelGGL((k_backward_rt<__VA_ARGS__>), dim3(B), dim3(NTHREADS), lds, st, BRT_ARGS)
 #define SETATTR(...) do { hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_backward_rt<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes); if (e_ != hipSuccess) return e_; } while (0)
 
@@ -26,13 +26,14 @@ int ce_launch_bwd_rt_plain(int variant, int B, size_t lds, hipStream_t st, const
     case 2: LAUNCH_BRT(256, 6, 6, 4); break;
     case 3: LAUNCH_BRT(256, 7, 7, 4); break;
     case 4: LAUNCH_BRT(256, 7, 7, 7); break;
-    case 5: LAUNCH_BRT(512, 7, 13, 7, false, 32); break;
+    case 5: LAUNCH_BRT(512, 5, 9, 7, false, 32); break;
+    case 6: LAUNCH_BRT(512, 7, 13, 7, false, 32); break;
     default: return -1;
     }
     return 0;
 }
 hipError_t ce_setattr_bwd_rt_plain(int bytes) {
-    SETATTR(4, 4, 4); SETATTR(5, 5, 4); SETATTR(6, 6, 4); SETATTR(7, 7, 4); SETATTR(7, 7, 7); SETATTR(7, 13, 7, false, 32);
+    SETATTR(4, 4, 4); SETATTR(5, 5, 4); SETATTR(6, 6, 4); SETATTR(7, 7, 4); SETATTR(7, 7, 7); SETATTR(5, 9, 7, false, 32); SETATTR(7, 13, 7, false, 32);
     return hipSuccess;
 }
 #else
@@ -41,7 +42,7 @@ int ce_launch_bwd_rt_psd(int variant, int B, size_t lds, hipStream_t st, const C
     case 0: LAUNCH_BRT(256, 4, 4, 4, true); break;
     case 3: LAUNCH_BRT(256, 7, 7, 4, true); break;
     case 4: LAUNCH_BRT(256, 7, 7, 7, true); break;
-    case 5: LAUNCH_BRT(512, 7, 13, 7, true, 32); break;
+    case 6: LAUNCH_BRT(512, 7, 13, 7, true, 32); break;
     default: return -1;
     }
     return 0;

@@ -41,6 +41,7 @@ struct CeBwdArgs {
     const double *P; int nnz_p; const int *pmap, *prow, *pcol; int p_tri; double *dP;
     double *gA, *gK;
     int retry;                  // k_backward_rt: 1 = recompute only the instances an earlier launch flagged (adj == 2)
+    int *nk_max;                // k_backward_rt: device maximum of the systems' order NK over the batch (NULL: not wanted)
 };
 
 // launchers (one per kernel object file): 0 on success, -1 unknown variant

@@ -82,7 +82,10 @@ struct ce_engine {
     bool dispatch_history = false; int *d_order = nullptr; int order_B = 0, order_cap = 0;
     bool f3 = false; int *d_idx_at3 = nullptr, *d_idx_ar3 = nullptr, *d_slot_soc = nullptr;      // third-generation forward kernel (k_fwd3, fwd_mode 5): iteration-tile gather maps, cone layout of the y slots
     int brt_variant = -1;                          // register-tiled backward kernel variant (-1: generic kernel)
-    int brt_fast = -1; size_t bwd_lds_fast = 0;     // two-tile plan: a smaller tile serves the instances it holds (typical active sets), the worst-case tile retries the rest
+    // two-tile plan of the register-tiled adjoint: a smaller tile serves the instances it holds, the worst-case tile re-runs the ones it flagged.  The smaller
+    // tile is chosen from the LARGEST system of the previous call of the same batch size (nk_*: device maximum, copied to pinned memory behind the launch)
+    bool two_tile = false; int fast_forced = -1;
+    int *d_nkmax = nullptr, *h_nkmax = nullptr; hipEvent_t nk_ev = nullptr; bool nk_pending = false, nk_have = false; int nk_last = 0, nk_B = 0;
     // quadratic objective
     int nnz_p = 0, p_tri = 0; bool qp_native = false;
     bool aa_ok = false;                            // the forward launch carries the LDS for the Anderson-acceleration vectors
@@ -150,8 +153,8 @@ static size_t bwd_lds_bytes(const DevT &T, bool a_lds, bool k_lds, int nkcap, in
 #endif
 // register-tiled backward variants {TI, TJ, TH}: K tile 16*TI x 16*TJ per workgroup, H tile 16*TH
 // {TI, TJ, TH, row residues BGR}: K tile BGR*TI x 16*TJ per workgroup of BGR*16 threads
-constexpr int BRT_NV = 6;
-static const int BRT_VARIANTS[BRT_NV][4] = {{4, 4, 4, 16}, {5, 5, 4, 16}, {6, 6, 4, 16}, {7, 7, 4, 16}, {7, 7, 7, 16}, {7, 13, 7, 32}};      // ({5,5,4}, {6,6,4}: plain cones only -- "fast" tiles of the two-tile plan)
+constexpr int BRT_NV = 7;
+static const int BRT_VARIANTS[BRT_NV][4] = {{4, 4, 4, 16}, {5, 5, 4, 16}, {6, 6, 4, 16}, {7, 7, 4, 16}, {7, 7, 7, 16}, {5, 9, 7, 32}, {7, 13, 7, 32}};      // ({5,5,4}, {6,6,4}, {5,9,7|32}: plain cones only -- added as "fast" tiles of the two-tile plan)
 static size_t bwd_rt_lds_bytes(const DevT &T, int TI, int TJ, int BGR) {
     const int n = T.n, m = T.m, nqs = std::max(T.nq, 1);
     size_t d = (size_t)m * n /* lda = n */ + 3 * (size_t)m + 2 * (size_t)n + 6 * nqs + BGR * TI + 5 /* pinfo: two 16-byte records + alignment */ + (BGR * 16 / 64) * 8 + bwd_rt_union_doubles(n, m, nqs, TI, TJ, BGR);
@@ -500,26 +503,21 @@ int ce_create(const ce_template *tpl, int device, ce_handle *out) {
         const bool plain = T.ns == 0 && T.nep + T.np == 0;
         for (int v = 0; v < BRT_NV; v++) {
             const int TI = BRT_VARIANTS[v][0], TJ = BRT_VARIANTS[v][1], TH = BRT_VARIANTS[v][2], BGR = BRT_VARIANTS[v][3];
-            if ((v == 1 || v == 2) && !plain) continue;              // (instantiated for plain cones only)
+            if ((v == 1 || v == 2 || v == 5) && !plain) continue;    // (instantiated for plain cones only)
             if (h->nkcap <= BGC * TJ - 1 && h->nkcap <= BGR * TI && T.n <= BGC * TH && bwd_rt_lds_bytes(T, TI, TJ, BGR) <= LDS_LIMIT) {
                 h->brt_variant = v; h->bwd_mode = 3; h->bwd_lds = bwd_rt_lds_bytes(T, TI, TJ, BGR); break;
             }
         }
-        // Two-tile plan.  The tile above holds the template's WORST case (NK <= n + min(m, n): every row active); a typical optimum has far fewer equality
-        // rows -- the zero rows, about half of the nonnegative rows, one row per second-order cone on its boundary -- and on the worst-case tile most of
-        // every pivot's broadcast and rank-1 update runs over empty column slots (metric configuration: NK = 63 of 111, 4 of 7 slots).  When a smaller
-        // tile holds the typical system, it serves the batch first; instances that exceed it are flagged by the kernel (adj 2) and recomputed by a second
-        // launch of the worst-case tile that exits at once for everybody else.  CE_BWD_TWO_TILE=0 disables.
-        const char *tt = getenv("CE_BWD_TWO_TILE");
-        if (h->bwd_mode == 3 && plain && h->nnz_p == 0 && BRT_VARIANTS[h->brt_variant][3] == 16 && !(tt && !strcmp(tt, "0"))) {
-            const int typ = T.n + T.z + T.nq + (T.l + 1) / 2 + BGC;      // + one column slot of margin: a retry is expensive however few there are (its launch lasts as long as ONE instance
-                                                                          // takes on an otherwise idle device, ~0.09 ms at the metric configuration: profiles/r04/e_ab_bwd_two_tile.log)
-            const char *fv = getenv("CE_BWD_FAST_VARIANT");      // tests: force a (too small) first tile so that the retry launch has work
-            for (int v = (fv ? atoi(fv) : 0); v < h->brt_variant; v++) {
-                const int TI = BRT_VARIANTS[v][0], TJ = BRT_VARIANTS[v][1], TH = BRT_VARIANTS[v][2], BGR = BRT_VARIANTS[v][3];
-                if ((fv || (typ <= BGC * TJ - 1 && typ <= BGR * TI)) && T.n <= BGC * TH && bwd_rt_lds_bytes(T, TI, TJ, BGR) <= LDS_LIMIT) { h->brt_fast = v; h->bwd_lds_fast = bwd_rt_lds_bytes(T, TI, TJ, BGR); break; }
-            }
-        }
+        // Two-tile plan.  The tile above holds the template's WORST case (NK <= n + min(m, n): every row active); the systems of a batch are usually much
+        // smaller (metric configuration: NK = 61 .. 81 of 111) and on the worst-case tile most of every pivot's broadcast and rank-1 update runs over
+        // empty column slots.  ce_vjp therefore serves the batch on the smallest tile that held the LARGEST system of the previous call (+ margin) and
+        // re-runs the instances that tile flags (adj 2) on the worst-case tile, which exits at once for everybody else.  A retry is expensive however few
+        // there are (its launch lasts as long as one instance takes on an idle device, ~0.09 ms at the metric configuration: profiles/r04/e_ab_bwd_two_tile.log),
+        // hence the history instead of an a-priori guess (config 3: half of the instances have a fully active cone, NK up to 170 of 200 -- no smaller tile).
+        // CE_BWD_TWO_TILE=0 disables; CE_BWD_FAST_VARIANT=v forces the first tile (tests).
+        const char *tt = getenv("CE_BWD_TWO_TILE"), *fv = getenv("CE_BWD_FAST_VARIANT");
+        h->two_tile = h->bwd_mode == 3 && plain && h->nnz_p == 0 && h->brt_variant > 0 && !(tt && !strcmp(tt, "0"));
+        h->fast_forced = fv ? atoi(fv) : -1;
     }
     if (h->qp_native && h->bwd_mode != 3) h->qp_native = false;      // the adjoint with P lives in the register-tiled backward kernel
     HIPCHK(ce_setattr_fwd_generic((int)LDS_LIMIT)); HIPCHK(ce_setattr_fwd_rt((int)LDS_LIMIT));
@@ -533,7 +531,7 @@ int ce_destroy(ce_handle h) {
     if (!h) return CE_OK;
     hipSetDevice(h->device);
     hipFree(h->d_rowidx); hipFree(h->d_colidx); hipFree(h->d_rowcone); hipFree(h->d_qoff); hipFree(h->d_soff); hipFree(h->d_sord); hipFree(h->d_pw); hipFree(h->d_idx_p); hipFree(h->d_pmap); hipFree(h->d_prow); hipFree(h->d_pcol);
-    hipFree(h->wsA); hipFree(h->wsdA); hipFree(h->gws); hipFree(h->d_idx_at); hipFree(h->d_idx_ar); hipFree(h->d_idx_b); hipFree(h->d_order); hipFree(h->d_row_perm); hipFree(h->d_idx_at3); hipFree(h->d_idx_ar3); hipFree(h->d_slot_soc); hipFree(h->d_k_rowcone); hipFree(h->d_k_qoff); hipFree(h->d_csc_ptr); hipFree(h->d_csr_ptr); hipFree(h->d_csr_col); hipFree(h->d_csr_src);
+    hipFree(h->wsA); hipFree(h->wsdA); hipFree(h->gws); hipFree(h->d_idx_at); hipFree(h->d_idx_ar); hipFree(h->d_idx_b); hipFree(h->d_order); hipFree(h->d_nkmax); if (h->h_nkmax) hipHostFree(h->h_nkmax); if (h->nk_ev) hipEventDestroy(h->nk_ev); hipFree(h->d_row_perm); hipFree(h->d_idx_at3); hipFree(h->d_idx_ar3); hipFree(h->d_slot_soc); hipFree(h->d_k_rowcone); hipFree(h->d_k_qoff); hipFree(h->d_csc_ptr); hipFree(h->d_csr_ptr); hipFree(h->d_csr_col); hipFree(h->d_csr_src);
     hipFree(h->d_sp_drow); hipFree(h->d_sp_srow_col); hipFree(h->d_sp_scol_ptr); hipFree(h->d_sp_scol_row); hipFree(h->d_sp_rowslot); hipFree(h->d_sp_sing_i); hipFree(h->d_sp_sing_v); hipFree(h->d_sp_AdT); hipFree(h->d_sp_sval); hipFree(h->d_aa_ws); hipFree(h->d_summary);
     for (auto &v : h->ev) for (auto &p : v) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
     if (h->d_psd_stats) {
@@ -691,14 +689,32 @@ int ce_vjp_qp(ce_handle h, int B, const double *A_vals, long sA_k, long sA_b, co
         int lrc;
         if (h->bwd_mode == 3) {
             ba.T.lda = T.n;
-            if (h->brt_fast >= 0 && adj_status && !P_vals) {          // two-tile plan (ce_create): the small tile for everybody, the worst-case tile for the instances it flagged
-                lrc = ce_launch_bwd_rt_plain(h->brt_fast, B, h->bwd_lds_fast, st, ba);
+            int fast = -1; size_t fast_lds = 0;
+            if (h->two_tile && adj_status && !P_vals) {
+                if (!h->d_nkmax) { HIPCHK(hipMalloc(&h->d_nkmax, sizeof(int))); HIPCHK(hipHostMalloc(&h->h_nkmax, sizeof(int))); HIPCHK(hipEventCreateWithFlags(&h->nk_ev, hipEventDisableTiming)); }
+                if (h->nk_pending && hipEventQuery(h->nk_ev) == hipSuccess) { h->nk_last = *h->h_nkmax; h->nk_pending = false; h->nk_have = true; }
+                (void)hipGetLastError();          // (hipErrorNotReady of the query is not an error)
+                const int need = (h->nk_have && !h->nk_pending && h->nk_B == B) ? h->nk_last + 8 : (1 << 30);
+                for (int v = (h->fast_forced >= 0 ? h->fast_forced : 0); v < h->brt_variant; v++) {
+                    const int TI = BRT_VARIANTS[v][0], TJ = BRT_VARIANTS[v][1], TH = BRT_VARIANTS[v][2], BGR = BRT_VARIANTS[v][3];
+                    if ((h->fast_forced >= 0 || (need <= BGC * TJ - 1 && need <= BGR * TI)) && T.n <= BGC * TH && bwd_rt_lds_bytes(T, TI, TJ, BGR) <= LDS_LIMIT) { fast = v; fast_lds = bwd_rt_lds_bytes(T, TI, TJ, BGR); break; }
+                }
+                HIPCHK(hipMemsetAsync(h->d_nkmax, 0, sizeof(int), st));
+                ba.nk_max = h->d_nkmax;
+            }
+            if (fast >= 0) {
+                lrc = ce_launch_bwd_rt_plain(fast, B, fast_lds, st, ba);
                 ba.retry = 1;
                 if (!lrc) lrc = ce_launch_bwd_rt_plain(h->brt_variant, B, h->bwd_lds, st, ba);
             } else
             lrc = (T.ns > 0 || T.nep + T.np > 0) ? ce_launch_bwd_rt_psd(h->brt_variant, B, h->bwd_lds, st, ba) : ce_launch_bwd_rt_plain(h->brt_variant, B, h->bwd_lds, st, ba);
         } else lrc = ce_launch_bwd_generic(h->bwd_mode, B, h->bwd_lds, st, ba);
         if (lrc) { g_err = "internal: no backward kernel for the planned variant"; return CE_E_BADARG; }
+        if (ba.nk_max) {      // the largest system of this call, for the tile choice of the next one (read once the copy has landed: no synchronisation here)
+            HIPCHK(hipMemcpyAsync(h->h_nkmax, h->d_nkmax, sizeof(int), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipEventRecord(h->nk_ev, st));
+            h->nk_pending = true; h->nk_B = B;
+        }
     }
     if (need_tr) {
         ProfScope ps(h, 2, st);

@@ -751,8 +751,8 @@ def test_longest_first_dispatch_is_a_scheduling_hint_only():
 
 
 def test_two_tile_adjoint_plan_gives_the_single_tile_gradients(monkeypatch):
-    """k_backward_rt's tile holds the template's worst case (every row active); the two-tile plan serves the batch on a smaller tile first and re-runs the
-    instances that do not fit it on the worst-case tile (ce_create, cone_engine.hip).  Same elimination, same pivots, the same fused multiply-adds per
+    """k_backward_rt's tile holds the template's worst case (every row active); the two-tile plan serves the batch on a smaller tile first -- sized by the
+    largest system of the previous call -- and re-runs the instances that do not fit it on the worst-case tile (ce_vjp_qp, cone_engine.hip).  Same elimination, same pivots, the same fused multiply-adds per
     entry whatever the tile: the gradients are BIT-identical to the single-tile plan -- by default (few or no retries at the metric shape) and with a first
     tile forced too small (CE_BWD_FAST_VARIANT=0: 63 unknowns, about half of the instances are retried)."""
     from cvxpylayers_amd.interfaces.mi355_if import ConeEngine, make_settings
@@ -777,6 +777,9 @@ def test_two_tile_adjoint_plan_gives_the_single_tile_gradients(monkeypatch):
             dx = torch.randn(x.shape, generator=g, dtype=torch.float64).cuda(); dy = torch.randn(y.shape, generator=g, dtype=torch.float64).cuda()
         dA, dq, adj = eng.vjp(A_bm, *sol, dx, dy)
         torch.cuda.synchronize()
+        if key != "single":           # the first call of an engine has no history (worst-case tile): the SECOND one runs the plan
+            dA, dq, adj = eng.vjp(A_bm, *sol, dx, dy)
+            torch.cuda.synchronize()
         outs[key] = (dA.clone(), dq.clone(), adj.clone())
     assert int((outs["single"][2] != 0).sum()) == 0
     v = sol[1] - sol[2]
