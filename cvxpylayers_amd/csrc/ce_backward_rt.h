@@ -339,6 +339,50 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
 #pragma unroll
         for (int j = 0; j < TJ; j++) kt[i][j] = 0.0;
     // H block (r < n, c < n): H = sum_c theta_c (A_c^T A_c - a_y a_y^T - a_s a_s^T), accumulated straight into the tile
+    if constexpr (BGR == 16) {
+        // ... on the MATRIX CORES, with the accumulators landing in the 2-D cyclic tile layout directly.  H = sum_k w_k a_k a_k^T over the rows of the boundary
+        // cones (w = theta_c) and, per cone, a_y and a_s (w = -theta_c).  v_mfma_f64_16x16x4_f64 computes D[M][N] += sum_k Aop[M][k] Bop[k][N] (4 rows k per
+        // instruction) and leaves D[(l >> 4) + 4 r][l & 15] in register r of lane l.  Thread (ra, cb) = (l & 15, 4 wave + (l >> 4)) owns K[ra + 16 i][cb + 16 j]:
+        // with N <-> the row residue (p = N + 16 i) and M <-> the columns of THIS wave (q = 4 wave + (M & 3) + 16 (M >> 2)), register r of the accumulator of
+        // row block i IS kt[i][r] -- no staging, no exchange.  (Round 3 formed the same Gram matrix on the matrix cores but had to move it through global
+        // memory into the tile layout, which ate the gain; the scalar accumulation it replaces was 52 k of the kernel's 297 k cycles: 8 LDS reads per 16 FMAs.)
+        typedef double v4d __attribute__((ext_vector_type(4)));
+        constexpr int NCS = (TH + 3) / 4;                     // column sets of four slots
+        v4d acc[THI][NCS];
+#pragma unroll
+        for (int i = 0; i < THI; i++)
+#pragma unroll
+            for (int s2 = 0; s2 < NCS; s2++) acc[i][s2] = v4d{0.0, 0.0, 0.0, 0.0};
+        const int lane = tid & 63, l15 = lane & 15, l4 = lane >> 4, wv = tid >> 6;
+        int qa[NCS];
+#pragma unroll
+        for (int s2 = 0; s2 < NCS; s2++) qa[s2] = 4 * wv + (l15 & 3) + 16 * ((l15 >> 2) + 4 * s2);
+        for (int c = 0; c < nq; c++) {
+            if (ckind[c] != 2) continue;                       // uniform
+            const double lam = cinfo[6 * c], th = lam / (1 - lam);
+            const int r0 = T.qoff[c], r1 = T.qoff[c + 1];
+            for (int k0 = r0; k0 < r1 + 2; k0 += 4) {          // the cone's rows, then a_y, a_s; four per instruction, this lane supplies row k0 + (l >> 4)
+                const int kk = k0 + l4;
+                const double *src = kk < r1 ? A + kk * lda : (kk == r1 ? ay + c * n : as + c * n);
+                const double wgt = kk < r1 ? th : (kk < r1 + 2 ? -th : 0.0);
+                double av[NCS], bv[THI];
+#pragma unroll
+                for (int s2 = 0; s2 < NCS; s2++) { const double v = src[qa[s2] < n ? qa[s2] : 0]; av[s2] = qa[s2] < n ? wgt * v : 0.0; }
+#pragma unroll
+                for (int i = 0; i < THI; i++) { const int pb = l15 + 16 * i; const double v = src[pb < n ? pb : 0]; bv[i] = pb < n ? v : 0.0; }
+#pragma unroll
+                for (int i = 0; i < THI; i++)
+#pragma unroll
+                    for (int s2 = 0; s2 < NCS; s2++) acc[i][s2] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s2], bv[i], acc[i][s2], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < THI; i++)
+#pragma unroll
+            for (int s2 = 0; s2 < NCS; s2++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) if (4 * s2 + r < TH) kt[i][4 * s2 + r] = acc[i][s2][r];
+    } else {
     for (int c = 0; c < nq; c++) {
         if (ckind[c] != 2) continue;                       // uniform
         const double lam = cinfo[6 * c], th = lam / (1 - lam);
@@ -367,6 +411,7 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
                 const int r = ra + BGR * i, cc = cb + BGC * j;
                 if (r < n && cc < n) kt[i][j] = fma(-th, ayc[r] * ayc[cc] + asc[r] * asc[cc], kt[i][j]);
             }
+    }
     }
 #pragma unroll
     for (int i = 0; i < THI; i++)
