@@ -285,7 +285,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
        double *__restrict__ xo, double *__restrict__ yo, double *__restrict__ so, int *__restrict__ iters_o,
        int *__restrict__ status_o, double *__restrict__ resid_o,
        const double *__restrict__ Pvals_g = nullptr, int nnzP = 0, const int *__restrict__ idx_p = nullptr,
-       const int *__restrict__ row_perm = nullptr, const int *__restrict__ order = nullptr) {
+       const int *__restrict__ row_perm = nullptr, const int *__restrict__ order = nullptr, int *__restrict__ iters2 = nullptr) {
     static_assert(!(WL && (PSD || HASP)), "wave-local cone exchange: plain cones only");
     constexpr int NT = NTH, NW = NTH / 64;        // threads / waves per workgroup of this instantiation (shadow the file-level defaults)
     using L = F2<CHT, T1, CHA, T2, CHG, TG, NW>;
@@ -1254,6 +1254,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
         }
         if (tid_w == 0) {
             iters_o[inst] = iter; status_o[inst] = status;
+            if (iters2) iters2[inst] = iter;
             if (resid_o) { resid_o[3 * inst] = sc[SC_RP]; resid_o[3 * inst + 1] = sc[SC_RD]; resid_o[3 * inst + 2] = sc[SC_GAP]; }
         }
     }

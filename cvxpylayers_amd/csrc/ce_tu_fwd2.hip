@@ -12,7 +12,7 @@ namespace {
 #error "compile with -DCE_F2_KIND=0|1|2"
 #endif
 
-#define F2_ARGS a.T, a.S, a.Abm, a.q, a.sqk, a.sqb, a.idx_at, a.idx_ar, a.idx_b, a.x, a.y, a.s, a.iters, a.status, a.resid, a.P, a.nnz_p, a.idx_p, a.row_perm, a.order
+#define F2_ARGS a.T, a.S, a.Abm, a.q, a.sqk, a.sqb, a.idx_at, a.idx_ar, a.idx_b, a.x, a.y, a.s, a.iters, a.status, a.resid, a.P, a.nnz_p, a.idx_p, a.row_perm, a.order, a.iters2
 #define LAUNCH_F2(NTHREADS, ...) hipLaunchKernelGGL((k_fwd2<__VA_ARGS__>), dim3(B), dim3(NTHREADS), lds, st, F2_ARGS)
 #define SETATTR(...) do { hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fwd2<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes); if (e_ != hipSuccess) return e_; } while (0)
 

@@ -32,6 +32,7 @@ struct CeFwdArgs {
     const int *row_perm;        // k_fwd2 WL variants: kernel row -> template row (NULL: rows in template order); k_fwd3: y slot -> template row (-1: padding slot)
     const int *idx_at3, *idx_ar3, *slot_soc;   // k_fwd3: gather maps of the iteration tiles, cone layout of the y slots ([2][slots]: first slot of the slot's SOC, cone dimension)
     double *gA, *gG;            // global residency workspaces of the size-generic kernel
+    int *iters2;                // k_fwd2: second copy of the iteration counts (engine-owned; NULL: not wanted)
     const int *order;           // k_fwd2 / k_fwd3: workgroup -> instance (NULL: identity); longest-first dispatch from the previous call's iteration counts
 };
 struct CeBwdArgs {

@@ -80,12 +80,13 @@ struct ce_engine {
     bool wl = false; int wl_nq = 0; int *d_row_perm = nullptr, *d_k_rowcone = nullptr, *d_k_qoff = nullptr;   // rows packed so that cones are wave-local (k_fwd2 WL)
     // longest-first dispatch (ce_set_dispatch_history): workgroup -> instance order for the next solve of the same batch size, from this solve's iteration counts
     bool dispatch_history = false; int *d_order = nullptr; int order_B = 0, order_cap = 0;
+    int *d_iters2 = nullptr; int iters2_cap = 0, order_pending_B = 0;      // engine-owned copy of the last solve's iteration counts (the caller's buffer may be gone when the order is computed)
     bool f3 = false; int *d_idx_at3 = nullptr, *d_idx_ar3 = nullptr, *d_slot_soc = nullptr;      // third-generation forward kernel (k_fwd3, fwd_mode 5): iteration-tile gather maps, cone layout of the y slots
     int brt_variant = -1;                          // register-tiled backward kernel variant (-1: generic kernel)
     // two-tile plan of the register-tiled adjoint: a smaller tile serves the instances it holds, the worst-case tile re-runs the ones it flagged.  The smaller
     // tile is chosen from the LARGEST system of the previous call of the same batch size (nk_*: device maximum, copied to pinned memory behind the launch)
     bool two_tile = false; int fast_forced = -1;
-    int *d_nkmax = nullptr, *h_nkmax = nullptr; hipEvent_t nk_ev = nullptr; bool nk_pending = false, nk_have = false; int nk_last = 0, nk_B = 0;
+    int *d_nkmax = nullptr, *h_nkmax = nullptr; hipEvent_t nk_ev = nullptr; bool nk_pending = false, nk_have = false, nk_zeroed = false; int nk_last = 0, nk_B = 0;
     // quadratic objective
     int nnz_p = 0, p_tri = 0; bool qp_native = false;
     bool aa_ok = false;                            // the forward launch carries the LDS for the Anderson-acceleration vectors
@@ -531,7 +532,7 @@ int ce_destroy(ce_handle h) {
     if (!h) return CE_OK;
     hipSetDevice(h->device);
     hipFree(h->d_rowidx); hipFree(h->d_colidx); hipFree(h->d_rowcone); hipFree(h->d_qoff); hipFree(h->d_soff); hipFree(h->d_sord); hipFree(h->d_pw); hipFree(h->d_idx_p); hipFree(h->d_pmap); hipFree(h->d_prow); hipFree(h->d_pcol);
-    hipFree(h->wsA); hipFree(h->wsdA); hipFree(h->gws); hipFree(h->d_idx_at); hipFree(h->d_idx_ar); hipFree(h->d_idx_b); hipFree(h->d_order); hipFree(h->d_nkmax); if (h->h_nkmax) hipHostFree(h->h_nkmax); if (h->nk_ev) hipEventDestroy(h->nk_ev); hipFree(h->d_row_perm); hipFree(h->d_idx_at3); hipFree(h->d_idx_ar3); hipFree(h->d_slot_soc); hipFree(h->d_k_rowcone); hipFree(h->d_k_qoff); hipFree(h->d_csc_ptr); hipFree(h->d_csr_ptr); hipFree(h->d_csr_col); hipFree(h->d_csr_src);
+    hipFree(h->wsA); hipFree(h->wsdA); hipFree(h->gws); hipFree(h->d_idx_at); hipFree(h->d_idx_ar); hipFree(h->d_idx_b); hipFree(h->d_order); hipFree(h->d_iters2); hipFree(h->d_nkmax); if (h->h_nkmax) hipHostFree(h->h_nkmax); if (h->nk_ev) hipEventDestroy(h->nk_ev); hipFree(h->d_row_perm); hipFree(h->d_idx_at3); hipFree(h->d_idx_ar3); hipFree(h->d_slot_soc); hipFree(h->d_k_rowcone); hipFree(h->d_k_qoff); hipFree(h->d_csc_ptr); hipFree(h->d_csr_ptr); hipFree(h->d_csr_col); hipFree(h->d_csr_src);
     hipFree(h->d_sp_drow); hipFree(h->d_sp_srow_col); hipFree(h->d_sp_scol_ptr); hipFree(h->d_sp_scol_row); hipFree(h->d_sp_rowslot); hipFree(h->d_sp_sing_i); hipFree(h->d_sp_sing_v); hipFree(h->d_sp_AdT); hipFree(h->d_sp_sval); hipFree(h->d_aa_ws); hipFree(h->d_summary);
     for (auto &v : h->ev) for (auto &p : v) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
     if (h->d_psd_stats) {
@@ -581,7 +582,8 @@ static int to_batch_major(ce_engine *h, int B, const double *vals, long sk, long
     return CE_OK;
 }
 
-__global__ void k_dispatch_order(int B, const int *__restrict__ iters, int *__restrict__ order);      // (defined next to ce_set_dispatch_history)
+struct ce_engine;
+static int flush_dispatch_order(ce_engine *h, hipStream_t st);      // (defined next to ce_set_dispatch_history)
 
 int ce_qp_native(ce_handle h) { return (h && h->qp_native) ? 1 : 0; }
 
@@ -614,12 +616,18 @@ int ce_solve_qp(ce_handle h, int B, const double *A_vals, long sA_k, long sA_b, 
         if (rc) return rc;
         gG = h->gws; gA = h->gws + (size_t)B * perG;
     }
+    bool fa_iters2 = false;
     {
         ProfScope ps(h, 0, st);
         CeFwdArgs fa{};
         fa.T = T; fa.S = S; fa.Abm = Abm; fa.q = q_vals; fa.sqk = sq_k; fa.sqb = sq_b; fa.idx_at = h->d_idx_at; fa.idx_ar = h->d_idx_ar; fa.idx_b = h->d_idx_b;
         fa.x = x; fa.y = y; fa.s = s; fa.iters = iters; fa.status = status; fa.resid = resid; fa.P = P_vals; fa.nnz_p = h->nnz_p; fa.idx_p = h->d_idx_p; fa.gA = gA; fa.gG = gG;
         int lrc;
+        if (h->dispatch_history && h->fwd_mode == 4) {
+            rc = flush_dispatch_order(h, st); if (rc) return rc;          // (a solve whose status was never summarised: the order is still owed)
+            if (h->iters2_cap < B) { hipFree(h->d_iters2); h->d_iters2 = nullptr; h->iters2_cap = 0; HIPCHK(hipMalloc(&h->d_iters2, sizeof(int) * (size_t)B)); h->iters2_cap = B; }
+            fa.iters2 = h->d_iters2; fa_iters2 = true;
+        }
         fa.order = (h->dispatch_history && h->order_B == B && h->fwd_mode == 4) ? h->d_order : nullptr;
         if (h->fwd_mode == 5) {
             fa.T.ldg = h->f2_ldg; fa.row_perm = h->d_row_perm; fa.idx_at3 = h->d_idx_at3; fa.idx_ar3 = h->d_idx_ar3; fa.slot_soc = h->d_slot_soc;
@@ -639,12 +647,7 @@ int ce_solve_qp(ce_handle h, int B, const double *A_vals, long sA_k, long sA_b, 
         if (lrc) { g_err = "internal: no forward kernel for the planned variant"; return CE_E_BADARG; }
     }
     HIPCHK(hipGetLastError());
-    if (h->dispatch_history && h->fwd_mode == 4) {      // the order of the NEXT solve of this batch size (behind the solve on the same stream: ~5 us)
-        if (h->order_cap < B) { hipFree(h->d_order); h->d_order = nullptr; h->order_cap = 0; HIPCHK(hipMalloc(&h->d_order, sizeof(int) * (size_t)B)); h->order_cap = B; }
-        hipLaunchKernelGGL(k_dispatch_order, dim3(1), dim3(256), 0, st, B, iters, h->d_order);
-        HIPCHK(hipGetLastError());
-        h->order_B = B;
-    }
+    if (fa_iters2) h->order_pending_B = B;          // (computed by flush_dispatch_order, off the critical path)
     return CE_OK;
 }
 
@@ -699,7 +702,7 @@ int ce_vjp_qp(ce_handle h, int B, const double *A_vals, long sA_k, long sA_b, co
                     const int TI = BRT_VARIANTS[v][0], TJ = BRT_VARIANTS[v][1], TH = BRT_VARIANTS[v][2], BGR = BRT_VARIANTS[v][3];
                     if ((h->fast_forced >= 0 || (need <= BGC * TJ - 1 && need <= BGR * TI)) && T.n <= BGC * TH && bwd_rt_lds_bytes(T, TI, TJ, BGR) <= LDS_LIMIT) { fast = v; fast_lds = bwd_rt_lds_bytes(T, TI, TJ, BGR); break; }
                 }
-                HIPCHK(hipMemsetAsync(h->d_nkmax, 0, sizeof(int), st));
+                if (!h->nk_zeroed) { HIPCHK(hipMemsetAsync(h->d_nkmax, 0, sizeof(int), st)); h->nk_zeroed = true; }      // (first call; afterwards the counter is reset behind the read-back)
                 ba.nk_max = h->d_nkmax;
             }
             if (fast >= 0) {
@@ -713,6 +716,7 @@ int ce_vjp_qp(ce_handle h, int B, const double *A_vals, long sA_k, long sA_b, co
         if (ba.nk_max) {      // the largest system of this call, for the tile choice of the next one (read once the copy has landed: no synchronisation here)
             HIPCHK(hipMemcpyAsync(h->h_nkmax, h->d_nkmax, sizeof(int), hipMemcpyDeviceToHost, st));
             HIPCHK(hipEventRecord(h->nk_ev, st));
+            HIPCHK(hipMemsetAsync(h->d_nkmax, 0, sizeof(int), st));          // for the next call (kept off the path in front of its kernel)
             h->nk_pending = true; h->nk_B = B;
         }
     }
@@ -722,7 +726,7 @@ int ce_vjp_qp(ce_handle h, int B, const double *A_vals, long sA_k, long sA_b, co
         hipLaunchKernelGGL(k_transpose, grid, dim3(256), 0, st, dAbm, dA_vals, B, K);
     }
     HIPCHK(hipGetLastError());
-    return CE_OK;
+    return flush_dispatch_order(h, st);
 }
 
 // summary of an int32 vector v[B] (status of a forward call, or adj_status of a backward call): out[0] = min v, out[1] = #{v == 2} ("solved,
@@ -744,19 +748,38 @@ __global__ void __launch_bounds__(256) k_status_summary(int B, const int *__rest
 // order[] = the instances sorted by iteration count, largest first (counting sort over check intervals; ties in arbitrary order): one workgroup
 __global__ void __launch_bounds__(256) k_dispatch_order(int B, const int *__restrict__ iters, int *__restrict__ order) {
     constexpr int NB = 512;                       // buckets of CONVERGED_INTERVAL iterations; anything longer shares the last one
-    __shared__ int cnt[NB];
+    __shared__ int cnt[NB], tmp[NB];
     for (int b = threadIdx.x; b < NB; b += 256) cnt[b] = 0;
     __syncthreads();
     for (int i = threadIdx.x; i < B; i += 256) { const int b = min(max(iters[i], 0) / CONVERGED_INTERVAL, NB - 1); atomicAdd(&cnt[NB - 1 - b], 1); }      // (bucket 0 = longest)
     __syncthreads();
-    if (threadIdx.x == 0) { int acc = 0; for (int b = 0; b < NB; b++) { const int c = cnt[b]; cnt[b] = acc; acc += c; } }
+    // exclusive prefix sum over the buckets (two per thread, log-step scan: a serial loop over 512 LDS entries cost 13 us on the path to the status read-back)
+    int *src = cnt, *dst = tmp;
+    for (int off = 1; off < NB; off <<= 1) {
+        for (int b = threadIdx.x; b < NB; b += 256) dst[b] = src[b] + (b >= off ? src[b - off] : 0);
+        __syncthreads();
+        int *t = src; src = dst; dst = t;
+    }
+    for (int b = threadIdx.x; b < NB; b += 256) dst[b] = b > 0 ? src[b - 1] : 0;          // inclusive -> exclusive
     __syncthreads();
-    for (int i = threadIdx.x; i < B; i += 256) { const int b = min(max(iters[i], 0) / CONVERGED_INTERVAL, NB - 1); order[atomicAdd(&cnt[NB - 1 - b], 1)] = i; }
+    for (int i = threadIdx.x; i < B; i += 256) { const int b = min(max(iters[i], 0) / CONVERGED_INTERVAL, NB - 1); order[atomicAdd(&dst[NB - 1 - b], 1)] = i; }
+}
+// the order of the NEXT solve is computed off the critical path: behind the status summary (the host is busy with autograd then, the device idle), or at the
+// latest in front of the next solve / behind the next adjoint
+static int flush_dispatch_order(ce_engine *h, hipStream_t st) {
+    if (!h->order_pending_B) return CE_OK;
+    const int B = h->order_pending_B;
+    h->order_pending_B = 0;
+    if (h->order_cap < B) { hipFree(h->d_order); h->d_order = nullptr; h->order_cap = 0; HIPCHK(hipMalloc(&h->d_order, sizeof(int) * (size_t)B)); h->order_cap = B; }
+    hipLaunchKernelGGL(k_dispatch_order, dim3(1), dim3(256), 0, st, B, h->d_iters2, h->d_order);
+    HIPCHK(hipGetLastError());
+    h->order_B = B;
+    return CE_OK;
 }
 int ce_set_dispatch_history(ce_handle h, int on) {
     if (!h) { g_err = "null argument"; return CE_E_BADARG; }
     h->dispatch_history = on != 0;
-    if (!on) h->order_B = 0;
+    if (!on) { h->order_B = 0; h->order_pending_B = 0; }
     return CE_OK;
 }
 
@@ -778,13 +801,13 @@ int ce_status_summary(ce_handle h, int B, const int *status, int *summary_host, 
         int *out = reinterpret_cast<int *>(h->summary_host_dev + ((uintptr_t)summary_host - page));
         hipLaunchKernelGGL(k_status_summary, dim3(1), dim3(256), 0, (hipStream_t)stream, B, status, out);
         HIPCHK(hipGetLastError());
-        return CE_OK;
+        return flush_dispatch_order(h, (hipStream_t)stream);          // (behind the summary: the host reads the flag while this runs)
     }
     int *slot = h->d_summary + 4 * (h->summary_next++ & 7);      // a few calls may be in flight on the stream before the caller synchronises
     hipLaunchKernelGGL(k_status_summary, dim3(1), dim3(256), 0, (hipStream_t)stream, B, status, slot);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(summary_host, slot, 4 * sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));      // (three values + the ready flag)
-    return CE_OK;
+    return flush_dispatch_order(h, (hipStream_t)stream);
 }
 
 int ce_transpose(ce_handle h, int rows, int cols, const double *in, double *out, void *stream) {

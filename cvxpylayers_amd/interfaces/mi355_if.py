@@ -229,10 +229,10 @@ class ConeEngine:
         return z
 
     def enqueue_summary(self, vec: torch.Tensor, slot: int):
-        """ce_status_summary of an int32 device vector into pinned slot `slot` (0: status of this forward, 1: adjoint flags of the previous backward);
-        read with read_summaries() after ONE stream synchronisation."""
+        """ce_status_summary of an int32 device vector into pinned slot `slot` (0: status of this forward; 1, 2: adjoint flags of backward calls);
+        read with read_summaries() once the LAST one enqueued is ready."""
         if getattr(self, "_summary_host", None) is None:
-            self._summary_host = torch.zeros((2, 4), dtype=torch.int32).pin_memory()
+            self._summary_host = torch.zeros((3, 4), dtype=torch.int32).pin_memory()          # slot 0: status of a forward; slots 1, 2: adjoint flags of backward calls, alternating
             self._summary_np = self._summary_host.numpy()          # (shares the pinned memory)
         self._summary_np[slot, 3] = 0                               # "ready" flag, set by the device after the three values
         self._summary_last_slot = slot
@@ -481,25 +481,43 @@ class MI355_ctx:
         return self._engines[idx]
 
 
-def _enqueue_flagged_adjoint(eng):
-    """Deferred check of the previous backward's per-instance flags (more active rows than the direct solve holds, LSQR iteration limit: their
-    gradients are zero or inexact).  Done at the NEXT forward call so that the backward path itself never synchronises the host: the flags are
-    summarised on the device (ce_status_summary) and read together with this forward's status, behind one stream synchronisation."""
-    pend, eng._pending_adj = getattr(eng, "_pending_adj", None) or [], []
-    if not pend:
-        return None
-    # every backward since the last forward is reported (a layer applied several times in one graph -- the 20 time steps of the supply-chain loop -- leaves
-    # several entries): one flag vector, one summary
-    pend = [(a, b) for a, b in pend if a.numel()]
-    if not pend:
-        return None
-    adj = pend[0][0] if len(pend) == 1 else torch.cat([a.reshape(-1) for a, _ in pend])
-    eng.enqueue_summary(adj, 1)
-    return sum(b for _, b in pend)
+def _note_adjoint_flags(eng, adj, bs):
+    """Called at the END of a backward call: the per-instance flags of the adjoint (more active rows than the direct solve holds, LSQR iteration limit: such
+    gradients are zero or inexact) are summarised on the device behind the adjoint kernel -- no host synchronisation on the backward path -- into one of two
+    alternating pinned slots.  The NEXT forward call reports them (everything enqueued before its status summary is complete when that is read).  A layer
+    applied several times in one graph (the 20 time steps of the supply-chain loop) runs several backward calls between two forwards: the slot a new call is
+    about to reuse is folded into the running count first."""
+    if adj.numel() == 0:
+        return
+    pend = getattr(eng, "_adj_pending", None)
+    if pend is None:
+        pend = eng._adj_pending = []
+        eng._adj_seq, eng._adj_count, eng._adj_total = 0, 0, 0
+    slot = 1 + (eng._adj_seq & 1)
+    eng._adj_seq += 1
+    for k in [k for k, (sl, _) in enumerate(pend) if sl == slot]:          # written two backward calls ago: long complete, but make sure before it is overwritten
+        if getattr(eng, "_summary_np", None) is not None and eng._summary_np[slot, 3] == 0:
+            torch.cuda.current_stream(eng.device).synchronize()
+        _fold_adjoint(eng, pend.pop(k))
+    eng.enqueue_summary(adj, slot)
+    pend.append((slot, bs))
 
 
-def _report_flagged_adjoint(summary_row, bs):
-    nbad = int(summary_row[2])               # bits 0-1; bit 2 (4) = rank-deficient system, basic solution returned like the reference's LSQR does -- not a failure
+def _fold_adjoint(eng, entry):
+    slot, bs = entry
+    eng._adj_count += int(eng._summary_np[slot, 2])     # bits 0-1; bit 2 (4) = rank-deficient system, basic solution returned like the reference's LSQR does -- not a failure
+    eng._adj_total += bs
+
+
+def _report_flagged_adjoints(eng):
+    """forward side: every backward enqueued before this forward's status summary has finished by the time that summary is read"""
+    pend = getattr(eng, "_adj_pending", None)
+    if not pend and not getattr(eng, "_adj_total", 0):
+        return
+    while pend:
+        _fold_adjoint(eng, pend.pop())
+    nbad, bs = eng._adj_count, eng._adj_total
+    eng._adj_count = eng._adj_total = 0
     if nbad:
         warnings.warn(f"MI355 adjoint: {nbad} of {bs} instances of the previous backward pass were flagged (degenerate active "
                       "set or iteration limit); their gradients are unreliable")
@@ -567,7 +585,6 @@ class _ConeLayer(torch.autograd.Function):
             # The reference raises from forward() when an instance fails (diffcp_if.py:365-372), so the host has to learn the outcome here: one tiny
             # reduction kernel + 8 bytes into pinned memory behind the solve (ce_status_summary) and ONE stream synchronisation -- not the status
             # vector through a pageable copy plus host-side reductions.  Per-instance inspection happens only on the failure path.
-            adj_bs = _enqueue_flagged_adjoint(eng)
             if status.numel():
                 eng.enqueue_summary(status, 0)
             # everything the host can prepare without knowing the outcome happens BEFORE the one synchronisation of this call: the GPU is idle from the
@@ -579,11 +596,9 @@ class _ConeLayer(torch.autograd.Function):
             if status.numel():
                 summ = eng.read_summaries()
                 min_status, n_inaccurate = int(summ[0][0]), int(summ[0][1])
+                _report_flagged_adjoints(eng)          # (the flags of the backward calls since the last forward: summarised behind their kernels, complete by now)
             else:
-                summ = eng.read_summaries() if adj_bs is not None else None
                 min_status, n_inaccurate = 1, 0
-            if adj_bs is not None:
-                _report_flagged_adjoint(summ[1], adj_bs)
         any_failed = min_status < 0
         if any_failed and merged_args.get("raise_on_error", True):
             st = status.cpu()
@@ -643,8 +658,8 @@ class _ConeLayer(torch.autograd.Function):
             if P_bm is not None:
                 dP = torch.where(failed[None, :].to(dP.device), torch.zeros_like(dP), dP)
         ctx.adj_status = adj
-        pend = getattr(eng, "_pending_adj", None) or []
-        eng._pending_adj = (pend + [(adj, batch_size)])[-8:]     # inspected at the next forward call (no host sync on the backward path)
+        with torch.cuda.device(eng.device):
+            _note_adjoint_flags(eng, adj, batch_size)            # reported by the next forward call (no host sync on the backward path)
         dA = dA.to(in_device)
         dq = dq.to(in_device)
         if originally_unbatched:
