@@ -171,6 +171,28 @@ struct F2Co {
     }
 };
 
+// block_reduce_n (ce_forward_rt.h) with the wave index handed in as a scalar and the lane id recomputed on the spot: the
+// per-wave slot address is then scalar, and no VGPR carries the thread id through the main loop for it (it used to be the
+// kernel's last spill: 4 bytes per lane written to scratch at set-up, = 4 MB of HBM writes per launch of the metric batch)
+template <int K, int NWV>
+__device__ __forceinline__ void block_reduce_w(double (&v)[K], unsigned maxmask, double *red, int wave) {
+#pragma unroll
+    for (int k = 0; k < K; k++) v[k] = ((maxmask >> k) & 1u) ? wave_reduce_dpp<true>(v[k]) : wave_reduce_dpp<false>(v[k]);
+    if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) {
+#pragma unroll
+        for (int k = 0; k < K; k++) red[wave * K + k] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        double a = red[k];
+#pragma unroll
+        for (int w = 1; w < NWV; w++) a = ((maxmask >> k) & 1u) ? fmax(a, red[w * K + k]) : a + red[w * K + k];
+        v[k] = a;
+    }
+    __syncthreads();
+}
+
 #ifdef CE_TIMING
 #define F2_STAMP(i) do { __syncthreads(); if (threadIdx.x == 0) f2_tstamp[i] = __builtin_readcyclecounter(); } while (0)
 #else
@@ -333,8 +355,8 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
         double r[2] = {0, 0};
         for (int i = tid; i < m; i += NT) r[0] = fmax(r[0], fabs(sm[L::O_BV + i]));
         for (int j = tid; j < n; j += NT) r[1] = fmax(r[1], fabs(sm[L::O_CV + j]));
-        block_reduce_n<2, NW>(r, 3u, red);
-        sc[SC_NB0] = r[0]; sc[SC_NC0] = r[1]; sc[SC_SIGMA] = 1.0;
+        block_reduce_w<2, NW>(r, 3u, red, wave);
+        sc[SC_NB0] = r[0]; sc[SC_NC0] = r[1]; sc[SC_SIGMA] = 1.0; sc[9] = 0.0;      // sc[9]: safeguard rejections so far
     }
     F2_STAMP(1);
     // ---------------------------------------------------------------- equilibration (SCS normalize: 25 Ruiz passes + 1 l2 pass)
@@ -465,7 +487,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
         double r[2] = {0, 0};
         for (int i = tid; i < m; i += NT) { const double v = sm[L::O_BV + i] * sm[L::O_DV + i]; sm[L::O_BV + i] = v; r[0] = fmax(r[0], fabs(v)); }
         for (int j = tid; j < n; j += NT) { const double v = sm[L::O_CV + j] * sm[L::O_EV + j]; sm[L::O_CV + j] = v; r[1] = fmax(r[1], fabs(v)); }
-        block_reduce_n<2, NW>(r, 3u, red);
+        block_reduce_w<2, NW>(r, 3u, red, wave);
         const double sigma = 1.0 / clamp_scale(fmax(r[0], r[1]));
         sc[SC_SIGMA] = sigma;
         for (int i = tid; i < m; i += NT) sm[L::O_BV + i] *= sigma;
@@ -544,7 +566,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
 #pragma unroll
                     for (int s2 = 0; s2 < TG / 2; s2++) { const double2 v = src[s2]; r[0] = fma(v.x, v.x, fma(v.y, v.y, r[0])); }
                 }
-                block_reduce_n<1, NW>(r, 0u, red);
+                block_reduce_w<1, NW>(r, 0u, red, wave);
                 // x = |delta| |G|_F through its binary exponent (no fp64 literals: they would be hoisted into registers held across the iteration loop):
                 // x < 2^-17 -> K = 2, < 2^-13 -> 3, < 2^-10 -> 4, < 2^-7 -> 7   (x^(K+1) <= ~1e-15), else the full refactorisation
                 const int ex = __builtin_amdgcn_readfirstlane((__double2hiint(fabs(delta) * sqrt(r[0])) >> 20) & 0x7ff) - 1023;
@@ -785,7 +807,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
             if (owng) PgV[jg] = a;
             __syncthreads();
             double rg[1] = {tid < n ? sm[L::O_GV + OX + tid] * PgV[tid] : 0.0};
-            block_reduce_n<1, NW>(rg, 0u, red);
+            block_reduce_w<1, NW>(rg, 0u, red, wave);
             gPg = uniform_d(rg[0]);
         }
         materialize_ar(co);
@@ -800,7 +822,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
             }
             if (tid < n) { r[0] += sm[L::O_CV + tid] * sm[L::O_GV + OX + tid]; sm[L::O_PHI + OX + tid] = rho_x * sm[L::O_PX + tid]; }
         }
-        block_reduce_n<1, NW>(r, 0u, red);
+        block_reduce_w<1, NW>(r, 0u, red, wave);
         hg = uniform_d(r[0]);
         inv_den = uniform_d(1.0 / (rtau + hg));
         load_phi_tile(co);
@@ -826,7 +848,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
             bad = bad || !(fabs(v) < 1e300);
         }
         double rb[1] = {bad ? 1.0 : 0.0};
-        block_reduce_n<1, NW>(rb, 1u, red);          // (max over the workgroup; __syncthreads_or would add static LDS)
+        block_reduce_w<1, NW>(rb, 1u, red, wave);          // (max over the workgroup; __syncthreads_or would add static LDS)
         if (rb[0] == 0.0) {
             if (e < n) sm[L::O_W + OX + e] = wx;
             for (int i = e; i < m; i += NT) {
@@ -848,7 +870,6 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
     // d = f - f_prev:  w <- f - (s.g / (s.y + 1e-8 |s||y|)) d.   The next iteration's residual is the safeguard: if it exceeds |g| the
     // step is undone and the history dropped.  Vectors (VP doubles each) live in the dynamic tail of the LDS carve.
     bool aa_on = S.acceleration_lookback > 0;      // cleared after AA_MAX_REJECT safeguard rejections (robustness rule, see the oracle)
-    int aa_rej = 0;
     const int aa_int = S.acceleration_interval;
     double *const aaWP = Gm + gsz + (PSD ? ((T.ns > 0 ? 2 * T.maxs * T.maxs + 2 * T.maxs + 8 : 0) + T.nep + T.np) : 0) + (HASP ? NP : 0);
     double *const aaXP = aaWP + VP, *const aaFP = aaXP + VP, *const aaFS = aaFP + VP, *const aaXS = aaFS + VP;
@@ -915,12 +936,13 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
             if (aa_pending) {      // safeguard: residual of the map at the accelerated point against the residual before the step
                 const double dd = ev ? aaWP[ve] - sm[L::O_W + ve] : 0.0;
                 double r[1] = {dd * dd};
-                block_reduce_n<1, NW>(r, 0u, red);
+                block_reduce_w<1, NW>(r, 0u, red, wave);
                 if (!(uniform_d(sqrt(r[0])) <= sc[8])) {
                     if (ev) { sm[L::O_W + ve] = aaFS[ve]; aaWP[ve] = aaXS[ve]; }
                     aa_iter = 0;
-                    if (++aa_rej >= AA_MAX_REJECT) aa_on = false;
+                    if (Co::thread_id(wave) == 0) sc[9] += 1.0;      // (the count lives in LDS: a register for it across the loop ends up in scratch)
                     __syncthreads();
+                    if (uniform_d(sc[9]) >= AA_MAX_REJECT) aa_on = false;
                 }
                 aa_pending = false;
             }
@@ -930,13 +952,13 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
                     const double xp = ev ? aaXP[ve] : 0.0, fp = ev ? aaFP[ve] : 0.0;
                     const double sv = xv - xp, yv = gv - (xp - fp), dv = fv - fp;
                     double r[5] = {sv * sv, yv * yv, sv * yv, sv * gv, gv * gv};
-                    block_reduce_n<5, NW>(r, 0u, red);
+                    block_reduce_w<5, NW>(r, 0u, red, wave);
                     const double mm = uniform_d(r[2] + 1e-8 * sqrt(r[0]) * sqrt(r[1]));
                     const double gam = uniform_d(r[3] / mm);
                     if (ev) { aaXP[ve] = xv; aaFP[ve] = fv; }
                     if ((__double2hiint(mm) & 0x7fffffff) > 0x01b00000 /* |mm| > ~1e-300, without an fp64 literal */ && fabs(gam) < 1e10) {
                         if (ev) { aaFS[ve] = fv; aaXS[ve] = xv; sm[L::O_W + ve] = fv - gam * dv; }
-                        if (threadIdx.x == 0) sc[8] = sqrt(r[4]);
+                        if (Co::thread_id(wave) == 0) sc[8] = sqrt(r[4]);
                         aa_pending = true;
                     } else aa_iter = 0;
                 } else if (ev) { aaXP[ve] = xv; aaFP[ve] = fv; }
@@ -947,14 +969,14 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
         if (check && iter > 0) {   // keep the homogeneous iterate in range
             const double we = ev ? sm[L::O_W + ve] : 0.0;
             double r[1] = {we * we};
-            block_reduce_n<1, NW>(r, 0u, red);
+            block_reduce_w<1, NW>(r, 0u, red, wave);
             const double nw = uniform_d(sqrt(r[0]));
             if (nw > 0 && ev) {
                 const double fsc = sqrt((double)l) / nw;
                 sm[L::O_W + ve] = we * fsc;
                 if (aa_on) { aaXP[ve] *= fsc; aaFP[ve] *= fsc; aaFS[ve] *= fsc; aaXS[ve] *= fsc; }     // the map is positively homogeneous
             }
-            if (aa_on && nw > 0 && threadIdx.x == 0) sc[8] *= sqrt((double)l) / nw;
+            if (aa_on && nw > 0 && Co::thread_id(wave) == 0) sc[8] *= sqrt((double)l) / nw;
             __syncthreads();
         }
         if (aa_on && (aa_pending || aa_ph + 1 == aa_int)) { aa_stale = false; if (ev) aaWP[ve] = sm[L::O_W + ve]; }      // input of this iteration, kept where the top of the next one reads it (the safeguard after a step, the step itself every aa_int iterations)
@@ -970,7 +992,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
         {
             const double a = seg_dot_lds<CHG, TG>(Gm + (jg < n ? jg : 0) * ldg + TG * cg, sm + L::O_TV + TG * cg);
             if (owng) sm[L::O_PX + jg] = a;
-            if (WL && threadIdx.x == 0) sm[L::O_WP + 2] = sm[L::O_W + OT];   // snapshot of w_tau: the fused phase below rewrites it while other waves still need it
+            if (WL && Co::thread_id(wave) == 0) sm[L::O_WP + 2] = sm[L::O_W + OT];   // snapshot of w_tau: the fused phase below rewrites it while other waves still need it
         }
         __syncthreads();
         if constexpr (WL) {
@@ -1058,7 +1080,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
                 double r3[3] = {0, 0, 0};
                 if (own2) { const double py = sm[L::O_W + OY + i2] + dyv(i2) * q; r3[0] = q * py; }
                 if (e < n) { const double px = sm[L::O_PX + e]; r3[1] = px * (sm[L::O_W + OX + e] - px); r3[2] = px * PgV[e]; }
-                block_reduce_n<3, NW>(r3, 0u, red);
+                block_reduce_w<3, NW>(r3, 0u, red, wave);
                 const double pPp = rho_x * r3[1] - r3[0];
                 const double qa = rtau + hg - gPg, qb = -(rtau * sm[L::O_W + OT] + sm[L::O_WP] + sm[L::O_WP + 1]) + 2 * r3[2];
                 tau_t = uniform_d((-qb + sqrt(fmax(qb * qb + 4 * qa * fmax(pPp, 0.0), 0.0))) / (2 * qa));
@@ -1102,7 +1124,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
             for (int c = 0; c < T.ns; c++) psd_project<NTH>(sm + L::O_ZB + OY + T.soff[c], T.sord[c], psdS, psdV, psdC, red);
             if (T.nep + T.np > 0) {   // exponential / power cones: one thread per cone, root warm-started from the previous iteration (ce_expcone.h)
                 double *expR = Gm + gsz + (T.ns > 0 ? 2 * T.maxs * T.maxs + 2 * T.maxs + 8 : 0);
-                for (int c = threadIdx.x; c < T.nep + T.np; c += NTH) {
+                for (int c = Co::thread_id(wave); c < T.nep + T.np; c += NTH) {
                     double *zc = sm + L::O_ZB + OY + T.eoff + 3 * c;
                     if (c < T.nep) exp_project_dual(zc, expR + c); else pow_project_dual_of_entry(zc, T.pw[c - T.nep], expR + c);
                 }
@@ -1169,9 +1191,9 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
                 r[4] = fabs(pxj + aty + cj * tau * sc_); r[5] = fabs(aty);
                 r[6] = cj * sm[L::O_U + OX + j] * isg * isg;
             }
-            block_reduce_n<8, NW>(r, 0x3Fu, red);
+            block_reduce_w<8, NW>(r, 0x3Fu, red, wave);
             double nPx = 0, xPx = 0;
-            if constexpr (HASP) { block_reduce_n<2, NW>(rP, 0x1u, red); nPx = uniform_d(rP[0]); xPx = uniform_d(rP[1]); }
+            if constexpr (HASP) { block_reduce_w<2, NW>(rP, 0x1u, red, wave); nPx = uniform_d(rP[0]); xPx = uniform_d(rP[1]); }
             // the reduced values are equal in every lane: move them to scalar registers so that the convergence logic below
             // is scalar code with uniform branches (and n_log / last_scale_iter / status stay scalar)
             const double rp = uniform_d(r[0]), nax = uniform_d(r[1]), ns = uniform_d(r[2]), naxs = uniform_d(r[3]), rd = uniform_d(r[4]),
@@ -1236,7 +1258,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
         const int e = tid_w;
         if (e < m) r[1] = sm[L::O_BV + e] * sm[L::O_U + OY + e] * isg * isg;
         else if (e < m + n) r[0] = sm[L::O_CV + (e - m)] * sm[L::O_U + OX + (e - m)] * isg * isg;
-        block_reduce_n<2, NW>(r, 0u, red);
+        block_reduce_w<2, NW>(r, 0u, red, wave);
         if (tau > kap) status = 2; else if (r[1] < r[0]) status = -7; else status = -6;
     }
     // ---------------------------------------------------------------- write back (un-normalise)

@@ -153,5 +153,33 @@ def denoise():
     print("denoise", lams, mses, best, val_mse)
 
 
+def adp():
+    """convex_approximate_dynamic_programming.ipynb cell 3: the 100 `(iter k) loss: v` lines of the training run (printed with %g: 6 significant digits).
+    Every line after the first depends on the GRADIENTS of all steps before it (SGD with momentum through 200 chained policy solves per step)."""
+    cs = cells("convex_approximate_dynamic_programming.ipynb")
+    cell = find_cell(cs, "results = train(iters=100)")
+    src = "".join(cell["source"])
+    assert "lr=.02, momentum=.9" in src and "def eval_loss(N=8, T=25)" in src and "torch.manual_seed(1)" in src
+    losses = [float(v) for v in re.findall(r"\(iter \d+\) loss: (" + _NUM + ")", out_text(cell))]
+    assert len(losses) == 100, len(losses)
+    np.savez(os.path.join(HERE, "ref_notebook_adp.npz"), losses=np.asarray(losses))
+    print("adp", losses[:5], "...", losses[-1])
+
+
+def monotone():
+    """monotonic_output_regression.ipynb cells 5-6, 9-12: numbers the reference printed with full precision -- the validation loss of the least-squares fit
+    (a function of the DATA, whose targets Y, Yval are outputs of the layer on batches of 100 and 50), the loss of the layer at the least-squares and at the
+    true parameters, and the first validation loss of the training run (theta = 0).  The training trace itself is not replayable: its batches come from
+    DataLoader(shuffle=True), whose use of the global generator changed between torch releases."""
+    cs = cells("monotonic_output_regression.ipynb")
+    one = lambda src: numbers(out_text([c for c in cs if c["cell_type"] == "code" and "".join(c["source"]).strip() == src][0]))[0]
+    first_val = float(re.search(r"001 \| (" + _NUM + ")", out_text(find_cell(cs, "val_losses, train_losses = fit("))).group(1))
+    src = "".join(find_cell(cs, "def get_data(N, n, m, theta)")["source"])
+    assert "torch.manual_seed(0)" in src and "get_data(100, n, m, theta_true)" in src and "get_data(50, n, m, theta_true)" in src
+    np.savez(os.path.join(HERE, "ref_notebook_monotone.npz"), lstsq_val_loss=np.array(one("lstsq_val_loss")), bayes_val_loss=np.array(one("bayes_val_loss")),
+             train_loss_lstsq=np.array(one("print(loss(X, Y, theta_lstsq).item())")), first_val_loss=np.array(first_val), n=20, m=10)
+    print("monotone", one("lstsq_val_loss"), one("bayes_val_loss"), one("print(loss(X, Y, theta_lstsq).item())"), first_val)
+
+
 if __name__ == "__main__":
-    ot(); lqr(); tutorial(); supply(); denoise()
+    ot(); lqr(); tutorial(); supply(); denoise(); adp(); monotone()

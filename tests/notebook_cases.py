@@ -137,6 +137,78 @@ def resource_allocation_template(m=10):
     return template_from_affine_builder(builder, [(), (m,), (m,)], cones, [VariableRecovery(slice(0, m), None, (m,))])
 
 
+def adp_policy_template(n=2, m=3):
+    """convex_approximate_dynamic_programming.ipynb cell 2:  min 1/2 ||P_sqrt u||^2 + x^T y + q^T u  s.t.  ||u|| <= 1, y = P_21 u;
+    parameters [x (n,1), P_sqrt (m,m), P_21 (n,m), q (m,1)], variable u (m,1) (y is the DPP device that keeps x^T P_21 u affine in each parameter).
+    v = (u, y, t):  y - P_21 u = 0 (zero cone),  (1, u) in SOC(m + 1),  ||P_sqrt u||^2 <= t,  c = (q, x, 1/2)."""
+    nv = m + n + 1
+
+    def builder(x, Ps, P21, q):
+        Az = np.zeros((n, nv)); Az[:, :m] = -np.asarray(P21); Az[:, m:m + n] = np.eye(n)
+        Aq = np.zeros((m + 1, nv)); bq = np.zeros(m + 1); bq[0] = 1.0
+        Aq[1:, :m] = -np.eye(m)                            # s = (1, u)
+        As, bs = kit._soc_sumsq_rows(np.asarray(Ps), np.zeros(m), m + n, nv)
+        c = np.zeros(nv); c[:m] = np.asarray(q).reshape(m); c[m:m + n] = np.asarray(x).reshape(n); c[m + n] = 0.5
+        return np.vstack([Az, Aq, As]), np.concatenate([np.zeros(n), bq, bs]), c
+    cones = dict(z=n, l=0, q=[m + 1, m + 2])
+    return template_from_affine_builder(builder, [(n, 1), (m, m), (n, m), (m, 1)], cones, [VariableRecovery(slice(0, m), None, (m, 1))])
+
+
+def adp_problem():
+    """The data of convex_approximate_dynamic_programming.ipynb cell 2 (np.random.seed(1)) and the LQR initialisation of cell 3."""
+    from scipy.linalg import solve_discrete_are, sqrtm
+    np.random.seed(1)
+    n, m = 2, 3
+    A = np.eye(n) + 1e-2 * np.random.randn(n, n)
+    B = 1e-2 / 3 * np.random.randn(n, m)
+    P_lqr = solve_discrete_are(A, B, np.eye(n), np.eye(m))
+    return dict(n=n, m=m, A=A, B=B, P_sqrt0=np.real(sqrtm(np.eye(m) + B.T @ P_lqr @ B)), P_21_0=A.T @ P_lqr @ B)
+
+
+def adp_train(policy, iters, device="cpu"):
+    """cell 3's train(): SGD with momentum on (P_sqrt, P_21, q) through N = 8 closed-loop roll-outs of T = 25 policy solves each (200 chained
+    forward solves and their adjoints per step), same RNG call sequence.  Returns the losses it would print."""
+    import torch
+    d = adp_problem(); n, m = d["n"], d["m"]
+    P_sqrt = torch.tensor(d["P_sqrt0"], device=device).requires_grad_(True)
+    P_21 = torch.tensor(d["P_21_0"], device=device).requires_grad_(True)
+    q = torch.zeros((m, 1), dtype=torch.double, device=device, requires_grad=True)
+    A_t, B_t = torch.tensor(d["A"], device=device), torch.tensor(d["B"], device=device)
+
+    def evaluate(T):
+        x = torch.zeros(n, 1, dtype=torch.double, device=device); cost = 0.0
+        for _ in range(T):
+            u, = policy(x, P_sqrt, P_21, q)
+            cost = cost + (x.t() @ x + u.t() @ u).squeeze() / T                        # Q = I, R = I
+            x = A_t @ x + B_t @ u + (.2 * torch.randn(n, 1).double()).to(device)      # drawn in float32 on the CPU like the notebook
+        return cost
+    opt = torch.optim.SGD([P_sqrt, P_21, q], lr=.02, momentum=.9)
+    out = []
+    for _ in range(iters):
+        torch.manual_seed(1)                                                           # "use same seeds each iteration"
+        opt.zero_grad()
+        loss = sum(evaluate(25) for _ in range(8)) / 8
+        loss.backward(); opt.step()
+        out.append(loss.item())
+    return out
+
+
+def monotone_template(m=10):
+    """monotonic_output_regression.ipynb cell 3:  min ||y - yhat||_2  s.t.  diff(y) >= 0;  parameter yhat (m,), variable y (m,).
+    v = (y, t):  y[i+1] - y[i] >= 0,  (t, y - yhat) in SOC(m + 1),  c = (0, 1).  Its solution is the isotonic regression of yhat."""
+    nv = m + 1
+
+    def builder(yhat):
+        Al = np.zeros((m - 1, nv))
+        for i in range(m - 1):
+            Al[i, i] = 1.0; Al[i, i + 1] = -1.0
+        Aq = np.zeros((m + 1, nv)); bq = np.zeros(m + 1)
+        Aq[0, m] = -1.0; Aq[1:, :m] = -np.eye(m); bq[1:] = -np.asarray(yhat)
+        c = np.zeros(nv); c[m] = 1.0
+        return np.vstack([Al, Aq]), np.concatenate([np.zeros(m - 1), bq]), c
+    return template_from_affine_builder(builder, [(m,)], dict(z=0, l=m - 1, q=[m + 1]), [VariableRecovery(slice(0, m), None, (m,))])
+
+
 # ---------------------------------------------------------------------------------------------- independent high-precision answers
 def sinkhorn(C, a, b, eps, iters=20000):
     """Entropic OT by Sinkhorn's fixed point in torch (differentiable): P = diag(u) exp(-C/eps) diag(v).  Stationarity of the

@@ -12,6 +12,9 @@ against the notebook is the notebook's rounding / solver tolerance.
   LQR SDP             PSD cones of order 6 and 4; forward (optimal value 17 digits, P_lqr 8 decimals)
   tutorial fit_lr     SOC(32) + SOC(3) + 2 nonneg; forward (a, b)
   signal denoising    SOC(102) + SOC(101), n = 102, BATCH OF 500 (the training set in one call): mean squared error for ten values of lambda + validation
+  convex ADP          2 equalities + SOC(4) + SOC(5), four parameters (A, c and the cone rows all depend on them): the printed training losses -- each step is
+                      200 chained forward solves and their adjoints, SGD with momentum: step k pins the gradients of steps < k
+  monotone regression 9 nonneg + SOC(11), batches of 100 / 50: losses printed with 17 digits (targets = outputs of the reference's layer)
   supply chain        4 equalities + 26 nonneg + SOC(6): closed-loop baseline cost (20 sequential solves) and the validation cost after
                       each of 7 SGD epochs (each = forward + adjoint through 20 time steps x batch 5): pins the gradients over training
 """
@@ -105,6 +108,50 @@ def test_signal_denoising_notebook_mse_over_the_training_set(make):
     yv = yv.cpu() if yv.is_cuda else yv
     assert abs(float((yv - Yv).pow(2).mean(dim=1).mean()) - float(f["val_mse"])) <= PRINT4              # "tensor(0.0897)"
     assert int(np.argmin(f["mse"])) == 7 and abs(float(f["lams"][7]) - float(f["best"])) < 1e-12        # the notebook's model selection: lambda = 15.5556
+
+
+@pytest.mark.parametrize("make", BACKENDS)
+def test_convex_adp_notebook_training_losses(make):
+    """convex_approximate_dynamic_programming.ipynb cell 3: `(iter k) loss: v`, printed with %g (6 significant digits).  loss_0 is forward only (200 chained
+    solves whose parameters are the previous solves' outputs); every later loss has gone through diffcp's adjoint of all 200 solves of every earlier step
+    (gradients w.r.t. P_sqrt -- cone rows --, P_21 -- equality rows of A -- and q -- the objective), accumulated by SGD with momentum."""
+    f = np.load(os.path.join(GOLD, "ref_notebook_adp.npz"))
+    on_gpu = make is _gpu_layer
+    steps = 10 if on_gpu else 5
+    layer = make(nc.adp_policy_template())
+    got = nc.adp_train(lambda *p: layer(*p), steps, device="cuda" if on_gpu else "cpu")
+    want = f["losses"][:steps]
+    assert np.abs(np.asarray(got) - want).max() <= 1.5e-5, (got, want)              # 5e-6 print rounding + the notebook's solver tolerance over 200 solves
+    assert abs(want[-1] - want[0]) > 1e-2                                             # the trace moves by 1000x the tolerance: the gradients are pinned
+
+
+@pytest.mark.parametrize("make", BACKENDS)
+def test_monotone_regression_notebook_losses(make):
+    """monotonic_output_regression.ipynb cells 5-6, 9-12 (the notebook runs in double: `from algorithms import fit` sets the default dtype).  The targets Y / Yval
+    are OUTPUTS of the reference's layer on batches of 100 / 50, so `lstsq_val_loss` pins its forward pass through the data; the two layer losses pin ours."""
+    from sklearn.isotonic import isotonic_regression
+    f = np.load(os.path.join(GOLD, "ref_notebook_monotone.npz"))
+    n, m = int(f["n"]), int(f["m"])
+    layer = make(nc.monotone_template(m))
+    call = lambda p: (lambda y: y.cpu() if y.is_cuda else y)(layer(p)[0])
+    torch.manual_seed(0)                                                              # cell 5
+    theta_true = torch.randn(n, m, dtype=torch.float64)
+
+    def get_data(N):
+        X = torch.randn(N, n, dtype=torch.float64)
+        return X, call(X @ theta_true + torch.randn(N, m, dtype=torch.float64))
+    X, Y = get_data(100); Xval, Yval = get_data(50)
+    mse = torch.nn.MSELoss()
+    theta_lstsq = torch.linalg.solve(X.t() @ X, X.t() @ Y)
+    TOL = 1e-5                                                                         # the notebook's own solver tolerance (we land 5e-7 ... 2e-6 from its digits)
+    assert abs(mse(Xval @ theta_lstsq, Yval).item() - float(f["lstsq_val_loss"])) <= TOL          # 3.3753725951890483
+    assert abs(mse(call(Xval @ theta_true), Yval).item() - float(f["bayes_val_loss"])) <= TOL      # 0.2637994455876921
+    assert abs(mse(call(X @ theta_lstsq), Y).item() - float(f["train_loss_lstsq"])) <= TOL         # 1.5115945280018195
+    assert abs(mse(call(Xval @ torch.zeros(n, m, dtype=torch.float64)), Yval).item() - float(f["first_val_loss"])) <= 5.1e-6      # "001 | 6.37966"
+    # independent: the layer is the isotonic regression of its input (pool-adjacent-violators, exact)
+    P = (Xval @ theta_true).numpy()
+    exact = np.stack([isotonic_regression(r) for r in P])
+    assert np.abs(call(Xval @ theta_true).numpy() - exact).max() <= 1e-7
 
 
 @pytest.mark.parametrize("make", BACKENDS)
