@@ -166,8 +166,11 @@ struct F2Co {
         return (wave << 6) + lane;
     }
     __device__ __forceinline__ explicit F2Co(int wave) {
-        t = thread_id(wave);
-        j1 = t / CHT; c1 = t % CHT; i2 = t / CHA; c2 = t % CHA; jg = t / CHG; cg = t % CHG;
+        // unsigned: the signed quotient / remainder of a value the compiler cannot prove non-negative is a 6-instruction sequence per pair, and the products
+        // T1 * c1 ... below become quarter-rate 32-bit multiplies; with the remainders' ranges known they are shifts / 24-bit multiplies
+        const unsigned u = (unsigned)thread_id(wave);
+        t = (int)u;
+        j1 = (int)(u / CHT); c1 = (int)(u % CHT); i2 = (int)(u / CHA); c2 = (int)(u % CHA); jg = (int)(u / CHG); cg = (int)(u % CHG);
     }
 };
 
@@ -390,7 +393,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
         // The column-layout tile belongs to ONE column and the row-layout tile to ONE row: their own factor is the same for all 26 entries, so it is
         // kept as a scalar (ecum, dcum) that multiplies the tile's norm instead of being multiplied into every entry in every pass (half the v_pk_mul_f32)
         float ecum = 1.0f, dcum = 1.0f;
-        const int blk_r0 = own2 ? socr[i2] : 0, blk_d = own2 ? abs(socd[i2]) : 0;      // this row's cone block (read once: two LDS round trips less per pass)
+        const int blk_r0 = (i2 < m) ? socr[i2] : 0, blk_d = (i2 < m) ? abs(socd[i2]) : 0;      // this row's cone block (read once: two LDS round trips less per pass)
         for (int pass = 0; pass < NUM_RUIZ_PASSES + NUM_L2_PASSES; pass++) {
             const bool l2 = pass >= NUM_RUIZ_PASSES;
             float *const fEt = (pass & 1) ? fEt1 : fEt0;                  // column scaling of this pass (x-indexed)
@@ -431,17 +434,26 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
             if constexpr (HASP) {
                 if (own1) { const float pn = fPn[j1]; fEt[j1] = __builtin_amdgcn_rsqf(clampf(l2 ? sqrtf(cn * cn + pn) : fmaxf(cn, pn))); }
             }
+            // block sums of <= 12 rows: the CHA lanes of a row share the masked batch of reads (as in the iteration's cone norm) and add their shares with a DPP butterfly
+            constexpr int NEQ = (12 + CHA - 1) / CHA;
+            float ssh = 0;
+            if (blk_d > 1 && blk_d <= 12) {   // (the reads past the block stay inside the vector)
+                const int off = (int)__umul24((unsigned)c2, (unsigned)NEQ);
+                const float *fr = fRn + blk_r0 + off;
+                const int lim = blk_d - off;
+                float v[NEQ];
+#pragma unroll
+                for (int u = 0; u < NEQ; u++) v[u] = fr[u];
+#pragma unroll
+                for (int u = 0; u < NEQ; u++) ssh += (u < lim) ? v[u] : 0.0f;
+            }
+            ssh = group_reduce_f<CHA, false>(ssh);
             if (own2) {
                 float a = rn;
                 const int r0 = blk_r0, d = blk_d;
                 if (d > 1) {   // block-average inside the SOC / PSD block so the scaled cone is still the cone
-                    float s0 = 0, s1 = 0;
-                    if (d <= 12) {   // one batch of reads, masked (a loop of dependent pairs costs d / 2 LDS round trips per pass; the reads past the block stay inside the vector)
-                        float v[12];
-#pragma unroll
-                        for (int u = 0; u < 12; u++) v[u] = fRn[r0 + u];
-#pragma unroll
-                        for (int u = 0; u < 12; u += 2) { s0 += (u < d) ? v[u] : 0.0f; s1 += (u + 1 < d) ? v[u + 1] : 0.0f; }
+                    float s0 = ssh, s1 = 0;
+                    if (d <= 12) {
                     } else {
                         int i = 0;
                         for (; i + 1 < d; i += 2) { s0 += fRn[r0 + i]; s1 += fRn[r0 + i + 1]; }
@@ -990,7 +1002,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
         __syncthreads();
         // P1b: p_x = G t
         {
-            const double a = seg_dot_lds<CHG, TG>(Gm + (jg < n ? jg : 0) * ldg + TG * cg, sm + L::O_TV + TG * cg);
+            const double a = seg_dot_lds<CHG, TG>(Gm + __mul24(jg < n ? jg : 0, ldg) + TG * cg, sm + L::O_TV + TG * cg);      // (24-bit multiply: full rate)
             if (owng) sm[L::O_PX + jg] = a;
             if (WL && Co::thread_id(wave) == 0) sm[L::O_WP + 2] = sm[L::O_W + OT];   // snapshot of w_tau: the fused phase below rewrites it while other waves still need it
         }
@@ -1005,7 +1017,8 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
             const bool upd = !check && !last;          // fast path: the relaxed update happens here (else after the convergence check)
             double we = 0, gve = 0;
             int cd = 0, soc_r0 = 0;
-            if (own2) { we = sm[L::O_W + ee]; gve = sm[L::O_GV + ee]; cd = socd[i2]; soc_r0 = socr[i2]; }      // cd 0: zero-cone row (dual free), 1: nonnegative row, > 1: row of an SOC
+            if (own2) { we = sm[L::O_W + ee]; gve = sm[L::O_GV + ee]; }
+            if (i2 < m) { cd = socd[i2]; soc_r0 = socr[i2]; }      // cd 0: zero-cone row (dual free), 1: nonnegative row, > 1: row of an SOC.  (Every lane of the row: they share the norm's work below)
             const double wp0 = sm[L::O_WP], wp1 = sm[L::O_WP + 1], wp2 = sm[L::O_WP + 2];
             const double q = seg_dot<CHA, T2>(ar, sm + L::O_PX + T2 * c2);
             __builtin_amdgcn_sched_barrier(0);
@@ -1019,21 +1032,33 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
                 sm[L::O_UT + ee] = ute; sm[L::O_ZB + ee] = ze;
             }
             wave_lds_exchange();
+            // |tail|^2 of a cone of <= 13 rows: the CHA lanes of a row each sum NE of the 12 candidate entries and the shares are added with a DPP butterfly (every row used to
+            // sum all 12 itself: 12 reads, 12 compares, 24 selects and 12 FMAs per lane and iteration on a kernel that is bound by the instructions it issues)
+            constexpr int NE = (12 + CHA - 1) / CHA;
+            double qsh = 0;
+            if (cd > 1 && cd <= 13) {      // (the reads past the cone stay inside the vector -- its pads included -- and are masked)
+                const int off = (int)__umul24((unsigned)c2, (unsigned)NE);      // (v_mul_u32_u24: full rate; the 32-bit multiply is a quarter-rate instruction)
+                const double *zc = sm + L::O_ZB + OY + soc_r0 + 1 + off;
+                const int lim = cd - 1 - off;            // this lane's entries u < lim belong to the cone
+                double zv[NE];
+#pragma unroll
+                for (int u = 0; u < NE; u++) zv[u] = zc[u];
+                double q0 = 0, q1 = 0;
+#pragma unroll
+                for (int u = 0; u < NE; u++) {
+                    const double zz = (u < lim) ? zv[u] : 0.0;
+                    if (u & 1) q1 = fma(zz, zz, q1); else q0 = fma(zz, zz, q0);
+                }
+                qsh = q0 + q1;
+            }
+            qsh = group_reduce<CHA, false>(qsh);
             if (own2) {
                 double ue = ze;
                 if (cd > 1) {
                     const double *zc = sm + L::O_ZB + OY + soc_r0;
                     const double t0 = zc[0];
-                    double q0 = 0, q1 = 0;
-                    if (cd <= 13) {      // (the reads past the cone stay inside the vector -- its pads included -- and are masked)
-                        double zv[12];
-#pragma unroll
-                        for (int u = 0; u < 12; u++) zv[u] = zc[1 + u];
-#pragma unroll
-                        for (int u = 0; u < 12; u += 2) {
-                            const double z0 = (1 + u < cd) ? zv[u] : 0.0, z1 = (2 + u < cd) ? zv[u + 1] : 0.0;
-                            q0 = fma(z0, z0, q0); q1 = fma(z1, z1, q1);
-                        }
+                    double q0 = qsh, q1 = 0;
+                    if (cd <= 13) {
                     } else {
                         for (int k = 1; k < cd; k += 4) {
                             const double z0 = zc[k], z1 = (k + 1 < cd) ? zc[k + 1] : 0.0, z2 = (k + 2 < cd) ? zc[k + 2] : 0.0, z3 = (k + 3 < cd) ? zc[k + 3] : 0.0;
