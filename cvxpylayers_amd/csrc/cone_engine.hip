@@ -703,7 +703,11 @@ int ce_vjp_qp(ce_handle h, int B, const double *A_vals, long sA_k, long sA_b, co
             int fast = -1; size_t fast_lds = 0;
             if (h->two_tile && adj_status && !P_vals) {
                 if (!h->d_nkmax) { HIPCHK(hipMalloc(&h->d_nkmax, sizeof(int))); HIPCHK(hipHostMalloc(&h->h_nkmax, sizeof(int))); HIPCHK(hipEventCreateWithFlags(&h->nk_ev, hipEventDisableTiming)); }
-                if (h->nk_pending && hipEventQuery(h->nk_ev) == hipSuccess) { h->nk_last = *h->h_nkmax; h->nk_pending = false; h->nk_have = true; }
+                if (h->nk_pending && hipEventQuery(h->nk_ev) == hipSuccess) {
+                    h->nk_last = *h->h_nkmax; h->nk_pending = false; h->nk_have = true;
+                    static const bool nk_debug = getenv("CE_NK_DEBUG") != nullptr;
+                    if (nk_debug) fprintf(stderr, "cone_engine: largest adjoint system of the previous call: NK = %d (B = %d)\n", h->nk_last, h->nk_B);
+                }
                 (void)hipGetLastError();          // (hipErrorNotReady of the query is not an error)
                 const int need = (h->nk_have && !h->nk_pending && h->nk_B == B) ? h->nk_last + 8 : (1 << 30);
                 for (int v = (h->fast_forced >= 0 ? h->fast_forced : 0); v < h->brt_variant; v++) {

@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from cvxpylayers_amd import problems as P
 from cvxpylayers_amd.interfaces.mi355_if import ConeEngine, make_settings
-cfg = P.CONFIGS[sys.argv[1] if len(sys.argv) > 1 else "M"]; n, cones = cfg["n"], cfg["cones"]; B = 4096
+cfg = P.CONFIGS[sys.argv[1] if len(sys.argv) > 1 else "M"]; n, cones = cfg["n"], cfg["cones"]; B = int(sys.argv[2]) if len(sys.argv) > 2 else 4096      # (B = 256: one workgroup per CU, the latency of one instance)
 tpl = P.dense_template(n, cones)
 A, b, c = P.generate(n, cones, B, seed=0)
 A_eval, q_eval = tpl.values_from_dense(A, b, c)
