@@ -168,7 +168,7 @@ def sq_limiter(kernel_short):
             if k.startswith(kernel_short) and isinstance(v, dict):
                 keep = {kk: vv for kk, vv in v.items() if kk in ("valu_busy", "wait_any", "wait_inst_any", "active_inst_any", "lds_conflict", "mfma_util")}      # shares of wave time
                 return dict(source=os.path.relpath(f, ROOT), kernel=k, counters=keep,
-                            reading="per wave: fp64 VALU busy for a fifth of the time, the rest waiting on barriers, LDS and dependent chains; per CU (three workgroups): VALU issue ~2/3 busy and the LDS pipe ~5/6 busy with operand reads (profiles/r04/n_fwd_instructions_per_wave_iteration.txt) -- the iteration is LDS-bandwidth / latency bound, not HBM or MFMA bound")
+                            reading="per wave: fp64 VALU busy for a fifth of the time, the rest waiting on barriers, LDS and dependent chains; per CU (three workgroups): VALU issue ~2/3 busy and the LDS pipe ~5/6 busy with operand reads (profiles/r04/n_fwd_instructions_per_wave_iteration.txt) -- bound by LDS operand delivery and the latency of one workgroup's barrier-separated phases, not by HBM or MFMA")
     return None
 
 
