@@ -198,8 +198,11 @@ __device__ __forceinline__ void block_reduce_w(double (&v)[K], unsigned maxmask,
 
 #ifdef CE_TIMING
 #define F2_STAMP(i) do { __syncthreads(); if (threadIdx.x == 0) f2_tstamp[i] = __builtin_readcyclecounter(); } while (0)
+// cycles per phase of the iteration, accumulated over the iterations of the instance (wave 0's clock; the values are the same in every lane: scalar registers)
+#define F2_ACC(k) do { const long long t1_ = __builtin_readcyclecounter(); f2_tacc[k] += t1_ - f2_t0; f2_t0 = t1_; } while (0)
 #else
 #define F2_STAMP(i) do { } while (0)
+#define F2_ACC(k) do { } while (0)
 #endif
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -334,8 +337,9 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
     const double *const vals = Avals + (size_t)inst * T.nnz_aug;
 
 #ifdef CE_TIMING
-    __shared__ long long f2_tstamp[16];
-    if (threadIdx.x < 16) f2_tstamp[threadIdx.x] = 0;
+    __shared__ long long f2_tstamp[24];
+    if (threadIdx.x < 24) f2_tstamp[threadIdx.x] = 0;
+    long long f2_tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, f2_t0 = 0;
 #endif
     F2_STAMP(0);
     for (int i = tid; i < L::O_G; i += NT) sm[i] = 0.0;
@@ -992,6 +996,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
             __syncthreads();
         }
         if (aa_on && (aa_pending || aa_ph + 1 == aa_int)) { aa_stale = false; if (ev) aaWP[ve] = sm[L::O_W + ve]; }      // input of this iteration, kept where the top of the next one reads it (the safeguard after a step, the step itself every aa_int iterations)
+        F2_ACC(0);      // top of the iteration (acceleration bookkeeping, coordinates)
         // P1a: t = rho_x w_x - A^T w_y   (+ phi . w from the two spare column groups)
         {
             const double *wvec = sm + L::O_W + ((j1 == n + 1 && T1 * c1 < n) ? OX : OY) + T1 * c1;
@@ -999,14 +1004,18 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
             if (own1) sm[L::O_TV + j1] = rho_x * sm[L::O_W + OX + j1] - a;
             else if (c1 == 0 && j1 <= n + 1) sm[L::O_WP + (j1 - n)] = a;          // phi_y . w_y , phi_x . w_x
         }
+        F2_ACC(1);      // P1a up to its barrier
         __syncthreads();
+        F2_ACC(2);      // the barrier
         // P1b: p_x = G t
         {
             const double a = seg_dot_lds<CHG, TG>(Gm + __mul24(jg < n ? jg : 0, ldg) + TG * cg, sm + L::O_TV + TG * cg);      // (24-bit multiply: full rate)
             if (owng) sm[L::O_PX + jg] = a;
             if (WL && Co::thread_id(wave) == 0) sm[L::O_WP + 2] = sm[L::O_W + OT];   // snapshot of w_tau: the fused phase below rewrites it while other waves still need it
         }
+        F2_ACC(3);      // P1b up to its barrier
         __syncthreads();
+        F2_ACC(2);
         if constexpr (WL) {
             // P2 + P3 fused: q = A p_x ; tau-tilde ; u-tilde ; cone projection ; relaxed update.  The cone blocks of y are wave-local.
             // Latency is what this phase costs (three workgroups per CU hide some of it, not all): every LDS round trip that can be issued early is.
@@ -1031,6 +1040,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
                 if (cd == 1 && ze < 0) ze = 0;
                 sm[L::O_UT + ee] = ute; sm[L::O_ZB + ee] = ze;
             }
+            F2_ACC(4);      // fused phase: product, tau, cone input
             wave_lds_exchange();
             // |tail|^2 of a cone of <= 13 rows: the CHA lanes of a row each sum NE of the 12 candidate entries and the shares are added with a DPP butterfly (every row used to
             // sum all 12 itself: 12 reads, 12 compares, 24 selects and 12 FMAs per lane and iteration on a kernel that is bound by the instructions it issues)
@@ -1089,7 +1099,9 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
                 sm[L::O_UT + OT] = tau_t; sm[L::O_U + OT] = ut;
                 if (upd) sm[L::O_W + OT] = wt + alpha * (ut - tau_t);
             }
+            F2_ACC(5);      // fused phase: projection, relaxed update
             __syncthreads();
+            F2_ACC(2);
             if (upd) { next_iter(); continue; }
         } else {
         // P2: q = A p_x ; tau-tilde ; u-tilde ; cone input
@@ -1307,6 +1319,8 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
     }
 #ifdef CE_TIMING
     F2_STAMP(5);
-    if (threadIdx.x < 12) so[(size_t)inst * m + threadIdx.x] = (double)f2_tstamp[threadIdx.x];
+    if (threadIdx.x < 8) f2_tstamp[16 + threadIdx.x] = f2_tacc[threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x < 24) so[(size_t)inst * m + threadIdx.x] = (double)f2_tstamp[threadIdx.x];
 #endif
 }
