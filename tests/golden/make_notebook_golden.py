@@ -181,5 +181,20 @@ def monotone():
     print("monotone", one("lstsq_val_loss"), one("bayes_val_loss"), one("print(loss(X, Y, theta_lstsq).item())"), first_val)
 
 
+def constrained_lqr():
+    """constrained_lqr.ipynb cells 13-16: the closed-loop cost of the LQR value function used as a control-Lyapunov policy (17 digits; 100 sequential batch-6 solves at eps 1e-8) and
+    the `it: k, loss: v` lines of the training run (3 decimals).  Both start from sqrtm(P_lqr), P_lqr = the notebook's own CVXPY / SCS solve of the LQR SDP, which the notebook asserts
+    against the Riccati solution only to atol 1e-3 (its printed optimal value is 6.4e-5 from tr(P_are W)); the test starts from the Riccati solution and carries that slack."""
+    cs = cells("constrained_lqr.ipynb")
+    clf = numbers(out_text([c for c in cs if c["cell_type"] == "code" and "".join(c["source"]).strip() == "clf_lqr, clf_lb"][0]))
+    txt = out_text(find_cell(cs, "opt = torch.optim.SGD([P_sqrt, q], lr=.1)"))
+    losses = [float(v) for v in re.findall(r"it: \d+, loss: (" + _NUM + "), dist", txt)]
+    val = numbers(out_text(find_cell(cs, "P_lqr = P.value")))[0]
+    src = "".join(find_cell(cs, "np.random.seed(1)")["source"])
+    assert "n, m = 8, 2" in src and "u_max = .1" in src and len(losses) == 100
+    np.savez(os.path.join(HERE, "ref_notebook_clqr.npz"), clf_lqr=np.array(clf[0]), losses=np.asarray(losses[:10]), sdp_value=np.array(val))
+    print("constrained_lqr", clf[0], losses[:6], val)
+
+
 if __name__ == "__main__":
-    ot(); lqr(); tutorial(); supply(); denoise(); adp(); monotone()
+    ot(); lqr(); tutorial(); supply(); denoise(); adp(); monotone(); constrained_lqr()

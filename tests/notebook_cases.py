@@ -193,6 +193,58 @@ def adp_train(policy, iters, device="cpu"):
     return out
 
 
+def constrained_lqr_problem():
+    """constrained_lqr.ipynb cell 2 (np.random.seed(1)): n = 8 states, m = 2 inputs, |u|_inf <= 0.1, noise std 0.5."""
+    from scipy.linalg import solve_discrete_are
+    np.random.seed(1)
+    n, m = 8, 2
+    A = np.random.randn(n, n)
+    A /= np.max(np.abs(np.linalg.eig(A)[0]))
+    B = np.random.randn(n, m)
+    return dict(n=n, m=m, A=A, B=B, noise=np.sqrt(.25), u_max=.1, P_are=solve_discrete_are(A, B, np.eye(n), np.eye(m)))
+
+
+def constrained_lqr_template(A, B, u_max):
+    """constrained_lqr.ipynb cell 7:  min u^T R0 u + ||P_sqrt xnext||^2 + q^T xnext  s.t.  xnext = A x + B u, |u|_inf <= u_max  (R0 = I);
+    parameters [x (n,1), P_sqrt (n,n), q (n,)], variable u (m,1).  v = (u, xnext, t1, t2): xnext - B u = A x (the parameter x enters b),
+    +-u <= u_max, ||u||^2 <= t1, ||P_sqrt xnext||^2 <= t2 (the parameter P_sqrt enters the cone rows), c = (0, q, 1, 1)."""
+    n, m = B.shape
+    nv = m + n + 2
+
+    def builder(x, Ps, q):
+        Az = np.zeros((n, nv)); Az[:, :m] = -B; Az[:, m:m + n] = np.eye(n)
+        Al = np.zeros((2 * m, nv))
+        for i in range(m):
+            Al[i, i] = 1.0; Al[m + i, i] = -1.0
+        A1, b1 = kit._soc_sumsq_rows(np.eye(m), np.zeros(m), m + n, nv)
+        Pf = np.zeros((n, m + n)); Pf[:, m:] = np.asarray(Ps)
+        A2, b2 = kit._soc_sumsq_rows(Pf, np.zeros(n), m + n + 1, nv)
+        c = np.zeros(nv); c[m:m + n] = np.asarray(q).reshape(n); c[m + n] = 1.0; c[m + n + 1] = 1.0
+        return np.vstack([Az, Al, A1, A2]), np.concatenate([A @ np.asarray(x).reshape(n), np.full(2 * m, u_max), b1, b2]), c
+    return template_from_affine_builder(builder, [(n, 1), (n, n), (n,)], dict(z=n, l=2 * m, q=[m + 2, n + 2]), [VariableRecovery(slice(0, m), None, (m, 1))])
+
+
+def constrained_lqr_loss(policy, d, device="cpu"):
+    """cell 12's closed-loop cost: batch of `batch_size` trajectories, `time_horizon` policy solves in sequence, same RNG call sequence (the notebook runs in double)."""
+    import torch
+    n = d["n"]
+    At, Bt = torch.tensor(d["A"], device=device), torch.tensor(d["B"], device=device)
+    noise = float(d["noise"])
+
+    def loss(time_horizon, batch_size, P_sqrt, q, seed=None):
+        if seed is not None:
+            torch.manual_seed(seed)
+        x = (noise * torch.randn(batch_size, n, 1, dtype=torch.float64)).to(device)
+        Pb = P_sqrt.repeat(batch_size, 1, 1); qb = q.repeat(batch_size, 1)
+        total = 0.0
+        for _ in range(time_horizon):
+            u, = policy(x, Pb, qb)
+            total = total + ((x * x).sum() + (u * u).sum()) / (time_horizon * batch_size)          # Q0 = I, R0 = I
+            x = At @ x + Bt @ u + (noise * torch.randn(batch_size, n, 1, dtype=torch.float64)).to(device)
+        return total
+    return loss
+
+
 def monotone_template(m=10):
     """monotonic_output_regression.ipynb cell 3:  min ||y - yhat||_2  s.t.  diff(y) >= 0;  parameter yhat (m,), variable y (m,).
     v = (y, t):  y[i+1] - y[i] >= 0,  (t, y - yhat) in SOC(m + 1),  c = (0, 1).  Its solution is the isotonic regression of yhat."""

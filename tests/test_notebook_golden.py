@@ -15,6 +15,7 @@ against the notebook is the notebook's rounding / solver tolerance.
   convex ADP          2 equalities + SOC(4) + SOC(5), four parameters (A, c and the cone rows all depend on them): the printed training losses -- each step is
                       200 chained forward solves and their adjoints, SGD with momentum: step k pins the gradients of steps < k
   monotone regression 9 nonneg + SOC(11), batches of 100 / 50: losses printed with 17 digits (targets = outputs of the reference's layer)
+  constrained LQR     8 equalities + 4 nonneg + SOC(4) + SOC(10), batch 6: closed-loop cost over 100 sequential solves and the first three training losses (coarse: see the test)
   supply chain        4 equalities + 26 nonneg + SOC(6): closed-loop baseline cost (20 sequential solves) and the validation cost after
                       each of 7 SGD epochs (each = forward + adjoint through 20 time steps x batch 5): pins the gradients over training
 """
@@ -152,6 +153,37 @@ def test_monotone_regression_notebook_losses(make):
     P = (Xval @ theta_true).numpy()
     exact = np.stack([isotonic_regression(r) for r in P])
     assert np.abs(call(Xval @ theta_true).numpy() - exact).max() <= 1e-7
+
+
+@pytest.mark.parametrize("make", BACKENDS)
+def test_constrained_lqr_notebook_closed_loop_cost_and_first_steps(make):
+    """constrained_lqr.ipynb cells 13-16 (n = 8 states, |u|_inf <= 0.1; zero + nonneg + SOC(4) + SOC(10), three parameters, batch 6, solver_args of the notebook:
+    eps 1e-8, acceleration_lookback 0).  A COARSE pin, and the tolerances say why: the notebook starts from sqrtm(P_lqr) with P_lqr its own CVXPY / SCS solve of the LQR SDP
+    (printed optimal value 6.4e-5 from tr(P_are W), asserted against Riccati to atol 1e-3 by the notebook itself) and several of its 600 solves per cost ended Solved/Inaccurate;
+    we start from the Riccati solution.  Closed-loop cost (100 sequential solves x batch 6): 1.1e-4 from the 17 printed digits (6.5e-6 relative).  The first training
+    steps (each = 600 solves + adjoints, SGD lr 0.1): the printed losses drop 16.940 -> 14.258 -> 14.035 and we follow within 2.5e-3, i.e. the first gradient step is pinned to 0.1 %."""
+    from scipy.linalg import sqrtm
+    f = np.load(os.path.join(GOLD, "ref_notebook_clqr.npz"))
+    d = nc.constrained_lqr_problem()
+    assert abs(np.trace(d["P_are"]) * 0.25 - float(f["sdp_value"])) < 1e-4                   # cell 3's printed SDP value vs Riccati: the slack of the start point
+    on_gpu = make is _gpu_layer
+    dev = "cuda" if on_gpu else "cpu"
+    layer = make(nc.constrained_lqr_template(d["A"], d["B"], d["u_max"]), eps=1e-8, max_iters=10000, acceleration_lookback=0)
+    loss = nc.constrained_lqr_loss(lambda *p: layer(*p), d, device=dev)
+    P_sqrt = torch.tensor(np.real(sqrtm(d["P_are"])), device=dev).requires_grad_(True)
+    q = torch.zeros(d["n"], dtype=torch.float64, device=dev, requires_grad=True)
+    opt = torch.optim.SGD([P_sqrt, q], lr=.1)
+    steps = 3
+    for k in range(steps):
+        with torch.no_grad():
+            v = loss(100, 6, P_sqrt.detach(), q.detach(), seed=0).item()
+        if k == 0:
+            assert abs(v - float(f["clf_lqr"])) <= 3e-4, v                                      # cell 14: 16.940040755077668
+        assert abs(v - float(f["losses"][k])) <= 2.5e-3, (k, v, float(f["losses"][k]))           # "it: 00k, loss: ..." (3 decimals)
+        opt.zero_grad()
+        loss(100, 6, P_sqrt, q, seed=k + 1).backward()
+        opt.step()
+    assert f["losses"][0] - f["losses"][2] > 2.5                                              # the trace moves by 1000x the tolerance
 
 
 @pytest.mark.parametrize("make", BACKENDS)
