@@ -200,9 +200,13 @@ __device__ __forceinline__ void block_reduce_w(double (&v)[K], unsigned maxmask,
 #define F2_STAMP(i) do { __syncthreads(); if (threadIdx.x == 0) f2_tstamp[i] = __builtin_readcyclecounter(); } while (0)
 // cycles per phase of the iteration, accumulated over the iterations of the instance (wave 0's clock; the values are the same in every lane: scalar registers)
 #define F2_ACC(k) do { const long long t1_ = __builtin_readcyclecounter(); f2_tacc[k] += t1_ - f2_t0; f2_t0 = t1_; } while (0)
+#define F2_EACC(k) do { const long long t1_ = __builtin_readcyclecounter(); f2_eacc[k] += t1_ - f2_t0; f2_t0 = t1_; } while (0)
+#define F2_T0() do { f2_t0 = __builtin_readcyclecounter(); } while (0)
 #else
 #define F2_STAMP(i) do { } while (0)
 #define F2_ACC(k) do { } while (0)
+#define F2_EACC(k) do { } while (0)
+#define F2_T0() do { } while (0)
 #endif
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -337,9 +341,10 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
     const double *const vals = Avals + (size_t)inst * T.nnz_aug;
 
 #ifdef CE_TIMING
-    __shared__ long long f2_tstamp[24];
+    __shared__ long long f2_tstamp[24], f2_tstamp2[8];
     if (threadIdx.x < 24) f2_tstamp[threadIdx.x] = 0;
     long long f2_tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, f2_t0 = 0;
+    long long f2_eacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // equilibration pass [0..3], Gauss-Jordan block [4..7]
 #endif
     F2_STAMP(0);
     for (int i = tid; i < L::O_G; i += NT) sm[i] = 0.0;
@@ -398,6 +403,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
         // kept as a scalar (ecum, dcum) that multiplies the tile's norm instead of being multiplied into every entry in every pass (half the v_pk_mul_f32)
         float ecum = 1.0f, dcum = 1.0f;
         const int blk_r0 = (i2 < m) ? socr[i2] : 0, blk_d = (i2 < m) ? abs(socd[i2]) : 0;      // this row's cone block (read once: two LDS round trips less per pass)
+        F2_T0();
         for (int pass = 0; pass < NUM_RUIZ_PASSES + NUM_L2_PASSES; pass++) {
             const bool l2 = pass >= NUM_RUIZ_PASSES;
             float *const fEt = (pass & 1) ? fEt1 : fEt0;                  // column scaling of this pass (x-indexed)
@@ -434,6 +440,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
                 if (own1) fEt[j1] = __builtin_amdgcn_rsqf(clampf(cn));
             }
             if (own2) fRn[i2] = rn;          // raw row norms
+            F2_EACC(0);      // norms, butterflies, column factor, row norms out
             if constexpr (WL) wave_lds_exchange(); else __syncthreads();
             if constexpr (HASP) {
                 if (own1) { const float pn = fPn[j1]; fEt[j1] = __builtin_amdgcn_rsqf(clampf(l2 ? sqrtf(cn * cn + pn) : fmaxf(cn, pn))); }
@@ -467,7 +474,9 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
                 }
                 fDt[i2] = __builtin_amdgcn_rsqf(clampf(a));
             }
+            F2_EACC(1);      // block sums, row factor
             __syncthreads();
+            F2_EACC(2);      // the barrier
             {
                 // every scaling factor of this pass is requested in ONE batch (the FP32 tiles leave the registers for it); multiplying as the values
                 // arrive -- what the scheduler made of the plain loops -- kept two reads in flight: ~10 LDS round trips per pass instead of ~2
@@ -495,6 +504,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
                 }
                 Eacc *= (double)ej; Dacc *= (double)di;
             }
+            F2_EACC(3);      // factor reads + scaling
             // no barrier: the next pass writes the other ping-pong buffers (and the row norms, last read before the barrier above)
         }
         if (own1) sm[L::O_EV + j1] = Eacc;
@@ -724,6 +734,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
         int cnt = 0;
         publish(std::integral_constant<int, 0>{}, 0, 0);
         __syncthreads();
+        F2_T0();
         static_for<NBLK>([&](auto blk_c) {
             constexpr int blk = decltype(blk_c)::value, kk0 = 4 * blk;
             constexpr int NBS = (TG - kk0) < 4 ? (TG - kk0) : 4;                         // slots of this block that exist
@@ -734,11 +745,20 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
                 const int nbv = min(NBS, n - k0);                                        // pivots of this block (the rest: identity)
                 const double *rb = rbuf(buf), *cb = cbuf(buf);
                 if (jg < n) {
+                    // the 4 x 4 pivot block: two 16-byte reads per row (k0 is even, the rows are 16-byte aligned; a block that runs past n reads into the next row / the column panel,
+                    // which the fix-up below overwrites).  The guarded element-wise form was 16 scalar branches around 16 ds_read_b64 at the head of every block's dependency chain.
                     double a[4][4];
 #pragma unroll
-                    for (int q = 0; q < 4; q++)
+                    for (int q = 0; q < 4; q++) {
+                        const double2 v0 = *reinterpret_cast<const double2 *>(rb + q * NP + k0), v1 = *reinterpret_cast<const double2 *>(rb + q * NP + k0 + 2);
+                        a[q][0] = v0.x; a[q][1] = v0.y; a[q][2] = v1.x; a[q][3] = v1.y;
+                    }
+                    if (nbv < 4) {      // (uniform, at most twice per inversion) pad with the identity
 #pragma unroll
-                        for (int q2 = 0; q2 < 4; q2++) a[q][q2] = (q < nbv && q2 < nbv) ? rb[q * NP + k0 + q2] : (q == q2 ? 1.0 : 0.0);
+                        for (int q = 0; q < 4; q++)
+#pragma unroll
+                            for (int q2 = 0; q2 < 4; q2++) if (!(q < nbv && q2 < nbv)) a[q][q2] = (q == q2 ? 1.0 : 0.0);
+                    }
                     bool bad = false;
 #pragma unroll
                     for (int p = 0; p < 4; p++) {      // in-place inverse of the 4 x 4 block (no pivoting: S is positive definite)
@@ -758,6 +778,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
                         }
                         a[p][p] = pinv;
                     }
+                    F2_EACC(4);      // pivot block read + its 4 x 4 inverse
                     if constexpr (HASP) { if (bad && jg == k0 && cg == 0) sc[7] = 1.0; }     // S not positive definite: P is not PSD
                     const double2 c01 = reinterpret_cast<const double2 *>(cb + 4 * jg)[0];
                     double2 c23 = make_double2(0.0, 0.0);
@@ -771,6 +792,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
                         const double wp = qrow == 0 ? a[0][q] : (qrow == 1 ? a[1][q] : (qrow == 2 ? a[2][q] : a[3][q]));
                         w[q] = prow_thread ? wp : wc;
                     }
+                    F2_EACC(5);      // multipliers
                     const double2 *r0 = reinterpret_cast<const double2 *>(rb + TG * cg), *r1 = reinterpret_cast<const double2 *>(rb + NP + TG * cg),
                                   *r2 = reinterpret_cast<const double2 *>(rb + 2 * NP + TG * cg), *r3 = reinterpret_cast<const double2 *>(rb + 3 * NP + TG * cg);
 #pragma unroll
@@ -785,10 +807,12 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
                         for (int q = 0; q < NBS; q++) sreg[kk0 + q] = w[q];       // the block columns themselves
                     }
                 }
+                F2_EACC(6);      // rank-4 update of the tile
                 if (cgk + 1 < nv) publish(std::integral_constant<int, blk>{}, cgk + 1, buf ^ 1);
                 else if (nvn) publish(std::integral_constant<int, (blk + 1 < NBLK ? blk + 1 : blk)>{}, 0, buf ^ 1);
                 cnt++;
                 __syncthreads();
+                F2_EACC(7);      // publish the next panel + the barrier
             }
         });
         }      // (!fast)
@@ -829,7 +853,10 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
         materialize_ar(co);
         double r[1] = {0};
         {
-            const double agx = seg_dot<CHA, T2>(ar, sm + L::O_GV + OX + T2 * c2), agk = seg_dot<CHA, T2>(ar, sm + L::O_PX + T2 * c2);
+            const double agx = seg_dot<CHA, T2>(ar, sm + L::O_GV + OX + T2 * c2);
+            __builtin_amdgcn_sched_barrier(0);      // (left alone the scheduler interleaves the two products one read at a time: 20 serialised LDS round trips)
+            const double agk = seg_dot<CHA, T2>(ar, sm + L::O_PX + T2 * c2);
+            __builtin_amdgcn_sched_barrier(0);
             if (own2) {
                 const double bi = sm[L::O_BV + i2];
                 const double gy = dyv(i2) * (agx + bi);
@@ -1320,7 +1347,9 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
 #ifdef CE_TIMING
     F2_STAMP(5);
     if (threadIdx.x < 8) f2_tstamp[16 + threadIdx.x] = f2_tacc[threadIdx.x];
+    if (threadIdx.x < 8) f2_tstamp2[threadIdx.x] = f2_eacc[threadIdx.x];
     __syncthreads();
     if (threadIdx.x < 24) so[(size_t)inst * m + threadIdx.x] = (double)f2_tstamp[threadIdx.x];
+    if (threadIdx.x < 8) so[(size_t)inst * m + 24 + threadIdx.x] = (double)f2_tstamp2[threadIdx.x];
 #endif
 }

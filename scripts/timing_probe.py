@@ -13,7 +13,7 @@ eng = ConeEngine(tpl.indices, tpl.indptr, tpl.n, tpl.m, cones, dev)
 A_bm = torch.from_numpy(A_eval).to(dev).t().contiguous(); q_t = torch.from_numpy(q_eval).to(dev)
 x, y, s, it, st, res = eng.solve(A_bm, q_t, make_settings(dict(eps=1e-4, max_iters=10000)))
 torch.cuda.synchronize()
-ts = s[:, :24].cpu().numpy()
+ts = s[:, :32].cpu().numpy()
 print("forward phases (cycles, mean over instances); iters mean", it.float().mean().item())
 for nm, a, b2 in (("init+load b,c", 0, 1), ("equilibration", 1, 2), ("refactor: materialize+S", 7, 8), ("refactor: GJ", 8, 9), ("refactor: g,phi", 9, 10),
                   ("first refactor total (2->3 includes)", 2, 3), ("iterations (incl. later refactors)", 3, 4), ("writeback", 4, 5), ("total", 0, 5)):
@@ -25,6 +25,10 @@ if acc.sum() > 0:
     for k, nm in enumerate(("top of the iteration", "P1a  A^T w_y up to its barrier", "the three barriers", "P1b  G t up to its barrier", "fused: A p_x, tau, cone input", "fused: projection, update")):
         print(f"  {nm:38s} {(acc[:, k] / itn).mean():10.1f}")
     print(f"  {'sum':38s} {(acc[:, :6].sum(1) / itn).mean():10.1f}")
+ea = ts[:, 24:32]
+if ea.sum() > 0:
+    print("equilibration pass (cycles per pass, 26 passes):   " + "  ".join(f"{nm} {ea[:, k].mean() / 26:7.1f}" for k, nm in enumerate(("norms+column factor", "block sums+row factor", "barrier", "factor reads+scaling"))))
+    print("Gauss-Jordan block (cycles per block, 13 blocks):  " + "  ".join(f"{nm} {ea[:, 4 + k].mean() / 13:7.1f}" for k, nm in enumerate(("pivot block+inverse", "multipliers", "rank-4 update", "publish+barrier"))))
 x, y, s, it, st, res = eng.solve(A_bm, q_t, make_settings(dict(eps=1e-4, max_iters=10000)))
 dx = torch.ones_like(x); dy = torch.zeros_like(y)
 dA, dq, adj = eng.vjp(A_bm, x, y, s, dx, dy)
