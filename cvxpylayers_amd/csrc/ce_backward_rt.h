@@ -17,13 +17,19 @@
 // v_max_f64 without the canonicalisation fmax() puts in front of it (operands are finite by construction)
 __device__ __forceinline__ double vmax_raw(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
+// max(a, |b|) with the bare instruction (b's sign bit may carry anything)
+__device__ __forceinline__ double vmax_abs(double a, double b) { double r; asm("v_max_f64 %0, %1, |%2|" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
 constexpr int BG = 16;   // default thread grid is BG x BG
 constexpr int BGC = 16;  // column residues (always one DPP row wide)
 
 #ifdef CE_TIMING   // debug build: phase durations (shader cycles) of every workgroup overwrite the first entries of its dA row
 #define CE_STAMP(i) do { __syncthreads(); if (threadIdx.x == 0) tstamp[i] = __builtin_readcyclecounter(); } while (0)
+// cycles per phase of one pivot of the elimination, accumulated over the pivots (this wave's clock)
+#define CE_BACC(k) do { const long long t1_ = __builtin_readcyclecounter(); bacc[k] += t1_ - bt0; bt0 = t1_; } while (0)
 #else
 #define CE_STAMP(i) do { } while (0)
+#define CE_BACC(k) do { } while (0)
 #endif
 
 __host__ __device__ inline int bwd_rt_union_doubles(int n, int m, int nqs, int TI, int TJ, int BGR = 16) {
@@ -86,6 +92,7 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
 
 #ifdef CE_TIMING
     __shared__ long long tstamp[12];
+    long long bacc[6] = {0, 0, 0, 0, 0, 0}, bt0 = 0;
 #endif
     CE_STAMP(0);
     load_instance(T, Avals + (size_t)inst * T.nnz_aug, A, bv);
@@ -484,7 +491,7 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
 #pragma unroll
         for (int i = 0; i < TI; i++)
 #pragma unroll
-            for (int j = 0; j < TJ; j++) if (cb + BGC * j < NK) r[0] = fmax(r[0], fabs(kt[i][j]));
+            for (int j = 0; j < TJ; j++) r[0] = vmax_abs(r[0], (cb + BGC * j < NK) ? kt[i][j] : 0.0);      // (two alternating chains would not help: the block reduction behind it is what everybody waits for)
         block_reduce_n<1, NWB>(r, 1u, red);
         ptol = CE_RANK_TOL * (r[0] > 0 ? r[0] : 1.0);     // rank tolerance of the oracle's dense elimination (ce_common.h)
     }
@@ -503,7 +510,14 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
     //   (2) the pivot row is broadcast INSIDE each 16-lane row with ds_bpermute (the lane with ra == prow % 16 holds exactly
     //       the entries K[prow][cb + 16 j] its row-mates need), so no second LDS round trip / barrier is required
     //   (3) rank-1 update of the live part of the tile (row slots >= ceil(NK/16) and column slots < jk are skipped)
+#ifdef CE_TIMING
+    bt0 = __builtin_readcyclecounter();
+#endif
     unsigned rowdone = 0;     // bit i: row ra + 16 i has served as pivot
+    unsigned nkmask = 0;      // bit i: row ra + BGR i < NK
+#pragma unroll
+    for (int i = 0; i < TI; i++) nkmask |= (ra + BGR * i < NK) ? (1u << i) : 0u;
+    const int ridx0 = 255 - ra;            // search key of row ra + BGR i carries 255 - row in its eight lowest mantissa bits
     const int ilim = (NK + BGR - 1) / BGR;          // row slots in use
     const int lane_base = ((tid & 63) & ~(BGR - 1)) << 2;     // byte address of the first lane of this thread's row group for ds_bpermute
 #pragma unroll
@@ -519,13 +533,13 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
                 // Branch-free (a used row contributes the key 0) and with the bare instruction: fmax() canonicalises both operands first
                 // (two more v_max_f64 per step of a chain every other wave is waiting for).
                 double best = 0.0;       // key 0: no candidate
+                const unsigned alive = nkmask & ~rowdone;      // bit i: row ra + BGR i exists and has not served as pivot
 #pragma unroll
                 for (int i = 0; i < TI; i++) {
-                    const int r = ra + BGR * i;
-                    const double v = fabs(kt[i][jk]);
-                    const int lo = (__double2loint(v) & ~0xFF) | (255 - r);
-                    const double key = __hiloint2double(__double2hiint(v), lo);
-                    best = vmax_raw(best, (r < NK && !((rowdone >> i) & 1u)) ? key : 0.0);
+                    const int am = __builtin_amdgcn_sbfe((int)alive, i, 1);       // 0 or -1 (v_bfe_i32): a dead row's key is 0, with two ANDs instead of compares and selects
+                    const double v = kt[i][jk];
+                    const int lo = ((__double2loint(v) & ~0xFF) | (ridx0 - BGR * i)) & am;
+                    best = vmax_abs(best, __hiloint2double(__double2hiint(v) & am, lo));      // (|.| is an operand modifier of the instruction: the sign bit rides along)
                 }
                 best = vmax_raw(best, dpp_mov<0xB1>(best));     // quad_perm [1,0,3,2]
                 best = vmax_raw(best, dpp_mov<0x4E>(best));     // quad_perm [2,3,0,1]
@@ -534,22 +548,22 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
                 if constexpr (BGR == 32) best = vmax_raw(best, __shfl_xor(best, 16));      // the column's owners span two DPP rows
                 const int bi = 255 - (__double2loint(best) & 0xFF);
                 const bool tiny = best < ptol;               // no acceptable pivot in this column (best == 0: no candidate row left, bi = 255 is no row)
-                double pv = 0.0;
 #pragma unroll
-                for (int i = 0; i < TI; i++) {
-                    const int r = ra + BGR * i;
-                    const double v = kt[i][jk];
-                    const bool isp = r == bi;
-                    cbuf[r] = isp ? 0.0 : v;                 // (the pivot row's own entry is published as 0)
-                    pv = isp ? v : pv;
-                }
+                for (int i = 0; i < TI; i++) cbuf[ra + BGR * i] = kt[i][jk];      // the whole column, unconditionally ...
                 if (ra == (bi & (BGR - 1))) {                // the lane that holds row bi (bi = 255: some lane, value 0)
+                    const int ib = bi / BGR;
+                    double pv = 0.0;
+#pragma unroll
+                    for (int i = 0; i < TI; i++) pv = (ib == i) ? kt[i][jk] : pv;
+                    if (bi < BGR * TI) cbuf[bi] = 0.0;       // ... then the pivot row's own entry is overwritten with 0 (same wave: LDS writes stay in program order)
                     pinfo[2 * buf] = tiny ? 0.0 : pv;
                     reinterpret_cast<int *>(pinfo + 2 * buf + 1)[0] = bi;
                 }
                 if (ra == 0 && tiny) misc[2] |= 4;
             }
+            CE_BACC(0);      // pivot search + publish (the column's owners; everybody else arrives here at once)
             __syncthreads();
+            CE_BACC(1);      // the barrier
             // the record and this thread's multipliers are requested together (the multipliers do not depend on the record): one LDS round trip
             // where the pivot row, then the pivot value, then the multipliers used to be three
             const double2 rec = *reinterpret_cast<const double2 *>(pinfo + 2 * buf);
@@ -570,6 +584,7 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
                 rowdone |= 1u << ipv;
                 if (cb == 0) { colof[prow] = k; pivrow[prow] = piv; }
             }
+            CE_BACC(2);      // record + multipliers read, reciprocal
             // pivot row: broadcast inside each 16-lane row
             double rw[TJ];
             const int src = lane_base + ((prow & (BGR - 1)) << 2);
@@ -584,6 +599,7 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
                     }
                 }
             }
+            CE_BACC(3);      // pivot row by ds_bpermute
             if (cb <= ck) rw[jk] = 0.0;      // columns <= k of this slot are finished
 #pragma unroll
             for (int i = 0; i < TI; i++) {
@@ -592,6 +608,7 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
 #pragma unroll
                 for (int j = jk; j < TJ; j++) kt[i][j] = fma(-f, rw[j], kt[i][j]);
             }
+            CE_BACC(4);      // rank-1 update
         }
     }
     __syncthreads();
@@ -705,5 +722,7 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
     if (tid < 7) dAo[(size_t)inst * T.nnz_aug + tid] = (double)(tstamp[tid + 1] - tstamp[tid]);
     if (tid == 8) dAo[(size_t)inst * T.nnz_aug + 8] = (double)(tstamp[8] - tstamp[3]);
     if (tid == 7) dAo[(size_t)inst * T.nnz_aug + 7] = (double)NK;
+    if (tid == 9) for (int k = 0; k < 5; k++) dAo[(size_t)inst * T.nnz_aug + 9 + k] = (double)bacc[k];      // (wave 0's view)
+    if (tid == 255) for (int k = 0; k < 5; k++) dAo[(size_t)inst * T.nnz_aug + 14 + k] = (double)bacc[k];     // (wave 3's view)
 #endif
 }

@@ -35,9 +35,11 @@ dA, dq, adj = eng.vjp(A_bm, x, y, s, dx, dy)
 torch.cuda.synchronize()
 dA, dq, adj = eng.vjp(A_bm, x, y, s, dx, dy)          # (the second call runs the two-tile plan: the first has no history)
 torch.cuda.synchronize()
-t = dA.t()[:, :9].cpu().numpy()
+t = dA.t()[:, :19].cpu().numpy()
 names = ["load", "classify+number", "dv,ay,as,fvec", "assemble", "ptol+GJ", "solve+q+ry", "output", "NK"]
 for k, nm in enumerate(names):
     print(f"{nm:18s} mean {t[:, k].mean():12.1f}  max {t[:, k].max():12.1f}")
 print("assemble: H part", t[:, 8].mean())
 print("sum of phases", t[:, :7].sum(1).mean())
+for w0, nm in ((9, "wave 0"), (14, "wave 3")):
+    print(f"elimination, cycles per pivot ({nm}): " + "  ".join(f"{lab} {(t[:, w0 + k] / t[:, 7]).mean():7.1f}" for k, lab in enumerate(("search+publish", "barrier", "reads+reciprocal", "pivot row bpermute", "update"))))
