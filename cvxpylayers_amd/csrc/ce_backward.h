@@ -571,13 +571,22 @@ k_backward(DevT T, int nkcap, int ldk, const double *__restrict__ Avals, const d
 // ================================================================================================
 // layout kernels: (R x C) row-major <-> (C x R) row-major, fp64, 32x32 LDS tiles (+1 pad)
 // ================================================================================================
+// TS x TS tiles.  TS = 64 (the default of the launch sites, CE_TR_TILE): a wave reads and writes whole 512-byte row segments (with 32 a wave touches two 256-byte pieces of
+// different rows) and every thread keeps 16 independent loads in flight before the barrier.
+template <int TS>
 __global__ void __launch_bounds__(256) k_transpose(const double *__restrict__ in, double *__restrict__ out, int R, int C) {
-    __shared__ double tile[32][33];
-    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
-    for (int r = ty; r < 32; r += 8) { const int rr = by + r, cc = bx + tx; if (rr < R && cc < C) tile[r][tx] = in[(size_t)rr * C + cc]; }
+    __shared__ double tile[TS][TS + 1];
+    constexpr int RS = 256 / TS;          // rows of the tile per pass
+    const int bx = blockIdx.x * TS, by = blockIdx.y * TS;
+    const int tx = threadIdx.x % TS, ty = threadIdx.x / TS;
+    double v[TS / RS];
+#pragma unroll
+    for (int u = 0; u < TS / RS; u++) { const int rr = by + ty + RS * u, cc = bx + tx; v[u] = (rr < R && cc < C) ? in[(size_t)rr * C + cc] : 0.0; }
+#pragma unroll
+    for (int u = 0; u < TS / RS; u++) tile[ty + RS * u][tx] = v[u];
     __syncthreads();
-    for (int r = ty; r < 32; r += 8) { const int cc = bx + r, rr = by + tx; if (rr < R && cc < C) out[(size_t)cc * R + rr] = tile[tx][r]; }
+#pragma unroll
+    for (int u = 0; u < TS / RS; u++) { const int cc = bx + ty + RS * u, rr = by + tx; if (rr < R && cc < C) out[(size_t)cc * R + rr] = tile[tx][ty + RS * u]; }
 }
 
 

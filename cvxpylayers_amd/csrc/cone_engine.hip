@@ -551,6 +551,12 @@ int ce_destroy(ce_handle h) {
     return CE_OK;
 }
 
+// (rows x cols) row-major -> (cols x rows) row-major
+static void launch_transpose(hipStream_t st, const double *in, double *out, int rows, int cols) {
+    static const int ts = [] { const char *e = getenv("CE_TR_TILE"); return (e && atoi(e) == 32) ? 32 : 64; }();
+    if (ts == 32) hipLaunchKernelGGL(k_transpose<32>, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, st, in, out, rows, cols);
+    else hipLaunchKernelGGL(k_transpose<64>, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, st, in, out, rows, cols);
+}
 static int ensure(double **ptr, size_t *have, size_t need) {
     if (*have >= need) return CE_OK;
     if (*ptr) hipFree(*ptr);
@@ -583,8 +589,7 @@ static int to_batch_major(ce_engine *h, int B, const double *vals, long sk, long
     if (rc) return rc;
     {
         ProfScope ps(h, 2, st);
-        dim3 grid((B + 31) / 32, (K + 31) / 32);
-        hipLaunchKernelGGL(k_transpose, grid, dim3(256), 0, st, vals, h->wsA, K, B);
+        launch_transpose(st, vals, h->wsA, K, B);
     }
     *out = h->wsA;
     return CE_OK;
@@ -734,8 +739,7 @@ int ce_vjp_qp(ce_handle h, int B, const double *A_vals, long sA_k, long sA_b, co
     }
     if (need_tr) {
         ProfScope ps(h, 2, st);
-        dim3 grid((K + 31) / 32, (B + 31) / 32);
-        hipLaunchKernelGGL(k_transpose, grid, dim3(256), 0, st, dAbm, dA_vals, B, K);
+        launch_transpose(st, dAbm, dA_vals, B, K);
     }
     HIPCHK(hipGetLastError());
     return flush_dispatch_order(h, st);
@@ -828,8 +832,7 @@ int ce_transpose(ce_handle h, int rows, int cols, const double *in, double *out,
     hipStream_t st = (hipStream_t)stream;
     {
         ProfScope ps(h, 2, st);
-        dim3 grid((cols + 31) / 32, (rows + 31) / 32);
-        hipLaunchKernelGGL(k_transpose, grid, dim3(256), 0, st, in, out, rows, cols);
+        launch_transpose(st, in, out, rows, cols);
     }
     HIPCHK(hipGetLastError());
     return CE_OK;
