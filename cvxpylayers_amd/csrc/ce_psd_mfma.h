@@ -51,6 +51,7 @@ __device__ __forceinline__ void psd_mfma_gemm(int KT, FA &&fa, FB &&fb, FO &&out
             double a[5], b[5];
 #pragma unroll
             for (int u = 0; u < 5; u++) { const int sc = min(s0 + u, smax); a[u] = fa(16 * ti + lc, 4 * sc + lg); b[u] = fb(4 * sc + lg, 16 * tj + lc); if (s0 + u >= nst) a[u] = 0.0; }
+            __builtin_amdgcn_sched_barrier(0);      // (keeps the five operand pairs in flight together: see psd_gemm_kk)
 #pragma unroll
             for (int u = 0; u < 5; u++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
         }
@@ -164,6 +165,7 @@ __device__ __forceinline__ void psd_gemm_kk(int k, const double *pA, int sAm, in
                 if (qw) a[u] *= fmax(qw[kc], 0.0);                         // (wK: eigenvalues; the product wants their positive parts)
                 if (kk >= k) a[u] = 0.0;
             }
+            __builtin_amdgcn_sched_barrier(0);      // (without the fence the scheduler sinks every operand pair next to its MFMA again: one LDS round trip per product step)
 #pragma unroll
             for (int u = 0; u < CH; u++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
         }

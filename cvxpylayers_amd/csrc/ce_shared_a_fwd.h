@@ -326,7 +326,19 @@ k_sa_fwd(DevT T, SaFwd F, ce_settings S, const double *__restrict__ BHg, const d
             }
             __syncthreads();
             SA_T(2);
-            if (tid < RP) { constexpr int ng = 2 * NT / RP; double s_ = -zd[tid]; for (int gg = 0; gg < ng; gg++) s_ += part[gg * RP + tid]; vd[tid] = s_; }      // A_d u
+            if (tid < RP) {      // A_d u: the partial sums are requested together (the plain loop waited for every pair of them: eight LDS round trips in series with everybody else at the barrier)
+                constexpr int ng = 2 * NT / RP, CHK = ng < 16 ? ng : 16;       // (in batches of at most 16: ng is 64 for the narrowest variant)
+                double s_ = -zd[tid];
+#pragma unroll
+                for (int g0 = 0; g0 < ng; g0 += CHK) {
+                    double pv[CHK];
+#pragma unroll
+                    for (int gg = 0; gg < CHK; gg++) pv[gg] = part[(g0 + gg) * RP + tid];
+#pragma unroll
+                    for (int gg = 0; gg < CHK; gg++) s_ += pv[gg];
+                }
+                vd[tid] = s_;
+            }
             __syncthreads();
             for (int a = tid >> 3; a < RP; a += NT / 8) {       // z = K^-1 (A_d u)
                 const double *kr = Kinv + a * LK;
@@ -341,8 +353,13 @@ k_sa_fwd(DevT T, SaFwd F, ce_settings S, const double *__restrict__ BHg, const d
             __syncthreads();
             SA_T(4);
             double rts = 0;
+            {
+                double rw[NW];          // (requested together: the plain sum waited for each pair)
 #pragma unroll
-            for (int w = 0; w < NW; w++) rts += red[w];
+                for (int w = 0; w < NW; w++) rw[w] = red[w];
+#pragma unroll
+                for (int w = 0; w < NW; w++) rts += rw[w];
+            }
             const double tau_t = (rtau * W[l - 1] + rts) * inv_den;
             for (int e = tid; e < l; e += NT) {
                 double ute, ze;

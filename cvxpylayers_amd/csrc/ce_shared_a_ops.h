@@ -39,7 +39,19 @@ __device__ __forceinline__ void sa_dense_times(const double *__restrict__ AdT, i
     constexpr int ng = 2 * NTH / RP;
     sa_dense_partials<NTH, RP>(AdT, n, xin, part);
     __syncthreads();
-    if (threadIdx.x < RP) { double s_ = 0; for (int gg = 0; gg < ng; gg++) s_ += part[gg * RP + threadIdx.x]; out[threadIdx.x] = s_; }
+    if (threadIdx.x < RP) {
+        constexpr int CHK = ng < 16 ? ng : 16;       // the partial sums are requested in batches (the plain loop waited for every pair of them)
+        double s_ = 0;
+#pragma unroll
+        for (int g0 = 0; g0 < ng; g0 += CHK) {
+            double pv[CHK];
+#pragma unroll
+            for (int gg = 0; gg < CHK; gg++) pv[gg] = part[(g0 + gg) * RP + threadIdx.x];
+#pragma unroll
+            for (int gg = 0; gg < CHK; gg++) s_ += pv[gg];
+        }
+        out[threadIdx.x] = s_;
+    }
     __syncthreads();
 }
 
@@ -51,6 +63,11 @@ __device__ __forceinline__ void sa_rows_dot(const double *__restrict__ AdT, int 
     constexpr int NL = RP / 16, RS = NTH / 8;
     const int tid = threadIdx.x, k8 = tid & 7;
     const double2 *w2 = reinterpret_cast<const double2 *>(w) + k8;
+    // this lane's entries of w, ONCE: they do not change over the rows, but out() writes LDS, so the compiler re-read them for every row, one read at a time
+    // (4 serialised LDS round trips per row group behind the row's own loads: profiles/r03/i_serial_chains_static.txt)
+    double2 wr[NL];
+#pragma unroll
+    for (int i = 0; i < NL; i++) wr[i] = w2[8 * i];
     for (int j0 = tid >> 3; j0 < n; j0 += 4 * RS) {
         double2 rv[4][NL];
 #pragma unroll
@@ -66,7 +83,7 @@ __device__ __forceinline__ void sa_rows_dot(const double *__restrict__ AdT, int 
             const bool ok = j < n;                       // (uniform over the eight lanes of a row)
             double a0 = ok ? extra(j, k8) : 0.0, a1 = 0;
 #pragma unroll
-            for (int i = 0; i < NL; i++) { const double2 wv = w2[8 * i]; a0 = fma(rv[u][i].x, wv.x, a0); a1 = fma(rv[u][i].y, wv.y, a1); }
+            for (int i = 0; i < NL; i++) { a0 = fma(rv[u][i].x, wr[i].x, a0); a1 = fma(rv[u][i].y, wr[i].y, a1); }
             const double acc = group_reduce<8, false>(a0 + a1);
             if (ok && k8 == 0) out(j, acc);
         }
@@ -86,9 +103,9 @@ __device__ __forceinline__ void sa_fused_pass(const double *__restrict__ AdT, in
     constexpr int NL = RP / 16, RS = NTH / 8, UR = RP == 64 ? 2 : 4;      // rows in flight per lane (RP = 64: two, the accumulators need the registers)
     const int tid = threadIdx.x, k8 = tid & 7;
     const double2 *w2 = reinterpret_cast<const double2 *>(w) + k8;
-    double2 vacc[NL];
+    double2 vacc[NL], wr[NL];          // (wr: this lane's entries of w, read once -- see sa_rows_dot)
 #pragma unroll
-    for (int i = 0; i < NL; i++) vacc[i] = double2{0.0, 0.0};
+    for (int i = 0; i < NL; i++) { vacc[i] = double2{0.0, 0.0}; wr[i] = w2[8 * i]; }
     for (int j0 = tid >> 3; j0 < n; j0 += UR * RS) {
         double2 rv[UR][NL];
         int si[UR]; double sv[UR];
@@ -109,7 +126,7 @@ __device__ __forceinline__ void sa_fused_pass(const double *__restrict__ AdT, in
             if (ok) { if (si[u] >= 0) a0 = (k8 == 0) ? sv[u] * yin[si[u]] : 0.0; else if (si[u] == -2) a0 = extra(j, k8); }
 #pragma unroll
             for (int i = 0; i < NL; i++) {
-                const double2 wv = w2[8 * i];
+                const double2 wv = wr[i];
                 a0 = fma(rv[u][i].x, wv.x, a0); a1 = fma(rv[u][i].y, wv.y, a1);
                 vacc[i].x = fma(rv[u][i].x, xv, vacc[i].x); vacc[i].y = fma(rv[u][i].y, xv, vacc[i].y);
             }
