@@ -74,9 +74,12 @@ __device__ __forceinline__ void block_reduce_n(double (&v)[K], unsigned maxmask,
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < K; k++) {
-        double a = red[k];
+        double t[NWV];          // the waves' partial results, requested together (the plain chain waited for each of them: NWV LDS round trips in series behind the barrier)
 #pragma unroll
-        for (int w = 1; w < NWV; w++) a = ((maxmask >> k) & 1u) ? fmax(a, red[w * K + k]) : a + red[w * K + k];
+        for (int w = 0; w < NWV; w++) t[w] = red[w * K + k];
+        double a = t[0];
+#pragma unroll
+        for (int w = 1; w < NWV; w++) a = ((maxmask >> k) & 1u) ? fmax(a, t[w]) : a + t[w];
         v[k] = a;
     }
     __syncthreads();
