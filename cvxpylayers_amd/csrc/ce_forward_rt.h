@@ -22,45 +22,7 @@ constexpr int SOC_SMALL = 32;   // cones up to this size: every row thread recom
 constexpr int RT_NVEC = 14;
 constexpr int RT_EXTRA = NW2 * 8 + NW2 + 16;   // red, wpart, scalars
 
-template <int CTRL>
-__device__ __forceinline__ double dpp_mov(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    // every lane has a valid source for these controls (quad_perm, row_mirror, row_half_mirror) and all rows / banks are enabled:
-    // with bound_ctrl the "old" operand is dead, which spares the v_mov that would otherwise initialise the destination
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xF, 0xF, true);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xF, 0xF, true);
-    return __hiloint2double(hi, lo);
-}
-// all-reduce inside aligned groups of CH consecutive lanes (CH in 1,2,4,8,16); every lane of the wave must be active
-template <int CH, bool MAX>
-__device__ __forceinline__ double group_reduce(double v) {
-    auto op = [](double a, double b) { return MAX ? fmax(a, b) : a + b; };
-    if constexpr (CH >= 2) v = op(v, dpp_mov<0xB1>(v));     // quad_perm [1,0,3,2]
-    if constexpr (CH >= 4) v = op(v, dpp_mov<0x4E>(v));     // quad_perm [2,3,0,1]
-    if constexpr (CH >= 8) v = op(v, dpp_mov<0x141>(v));    // row_half_mirror
-    if constexpr (CH >= 16) v = op(v, dpp_mov<0x140>(v));   // row_mirror
-    return v;
-}
-
-// DPP move with a row mask: rows outside the mask receive 0.0 (identity for sums and for maxima of non-negative values)
-template <int CTRL, int ROWMASK>
-__device__ __forceinline__ double dpp_mov_rows(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROWMASK, 0xF, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROWMASK, 0xF, false);
-    return __hiloint2double(hi, lo);
-}
-// full wave64 reduction without the LDS crossbar: 4 intra-row DPP stages, row_bcast15 / row_bcast31, then lane 63 is
-// read into scalar registers (the result is wave-uniform).  MAX is only used on non-negative values.
-template <bool MAX>
-__device__ __forceinline__ double wave_reduce_dpp(double v) {
-    auto op = [](double a, double b) { return MAX ? fmax(a, b) : a + b; };
-    v = group_reduce<16, MAX>(v);
-    v = op(v, dpp_mov_rows<0x142, 0xA>(v));    // row_bcast:15 into rows 1 and 3
-    v = op(v, dpp_mov_rows<0x143, 0xC>(v));    // row_bcast:31 into rows 2 and 3
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
-    return __hiloint2double(hi, lo);
-}
+// (dpp_mov, group_reduce, dpp_mov_rows, wave_reduce_dpp: ce_common.h)
 
 template <int K, int NWV>
 __device__ __forceinline__ void block_reduce_n(double (&v)[K], unsigned maxmask, double *red) {
