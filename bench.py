@@ -266,7 +266,7 @@ def main():
     # after process start see the ramp).  Untimed steps until 0.3 s have passed, in ADDITION to the W warm-up steps of the contract; reported as `prewarm_steps`.
     prewarm_steps = 0
     t_pw = time.perf_counter()
-    while time.perf_counter() - t_pw < 0.3:
+    while (time.perf_counter() - t_pw < 0.3) if world == 1 else (prewarm_steps < 100):      # (several ranks: a FIXED count -- every step holds a collective, the ranks must agree on their number)
         info = step(); prewarm_steps += 1
         if prewarm_steps % 8 == 0:
             torch.cuda.synchronize()
