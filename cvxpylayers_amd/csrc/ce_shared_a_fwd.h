@@ -125,7 +125,13 @@ k_sa_fwd(DevT T, SaFwd F, ce_settings S, const double *__restrict__ BHg, const d
         for (int a = tid >> 3; a < RP; a += NT / 8) {       // zd = K^-1 vd : eight lanes per row
             const double *kr = Kinv + a * LK;
             double s_ = 0;
-            for (int b = tid & 7; b < r; b += 8) s_ = fma(kr[b], vd[b], s_);
+            {      // this lane's RP / 8 products with their operands requested together (the run-time bound b < r made it a chain of r / 8 LDS round trips; the padding of K and of the vector is zero)
+                double kv[RP / 8], xv[RP / 8];
+            #pragma unroll
+                for (int bb = 0; bb < RP / 8; bb++) { const int b = (tid & 7) + 8 * bb; kv[bb] = kr[b]; xv[bb] = vd[b]; }
+            #pragma unroll
+                for (int bb = 0; bb < RP / 8; bb++) s_ = fma(kv[bb], xv[bb], s_);
+            }
             s_ = group_reduce<8, false>(s_);
             if ((tid & 7) == 0) zd[a] = a < r ? s_ : 0.0;
         }
@@ -320,7 +326,13 @@ k_sa_fwd(DevT T, SaFwd F, ce_settings S, const double *__restrict__ BHg, const d
             for (int a = tid >> 3; a < RP; a += NT / 8) {       // K0 w_d : eight lanes per row
                 const double *kr = K0 + a * LK;
                 double s_ = 0;
-                for (int b = tid & 7; b < r; b += 8) s_ = fma(kr[b], wyd[b], s_);
+                {      // this lane's RP / 8 products with their operands requested together (the run-time bound b < r made it a chain of r / 8 LDS round trips; the padding of K and of the vector is zero)
+                    double kv[RP / 8], xv[RP / 8];
+                #pragma unroll
+                    for (int bb = 0; bb < RP / 8; bb++) { const int b = (tid & 7) + 8 * bb; kv[bb] = kr[b]; xv[bb] = wyd[b]; }
+                #pragma unroll
+                    for (int bb = 0; bb < RP / 8; bb++) s_ = fma(kv[bb], xv[bb], s_);
+                }
                 s_ = group_reduce<8, false>(s_);
                 if ((tid & 7) == 0) zd[a] = s_;
             }
@@ -343,7 +355,13 @@ k_sa_fwd(DevT T, SaFwd F, ce_settings S, const double *__restrict__ BHg, const d
             for (int a = tid >> 3; a < RP; a += NT / 8) {       // z = K^-1 (A_d u)
                 const double *kr = Kinv + a * LK;
                 double s_ = 0;
-                for (int b = tid & 7; b < r; b += 8) s_ = fma(kr[b], vd[b], s_);
+                {      // this lane's RP / 8 products with their operands requested together (the run-time bound b < r made it a chain of r / 8 LDS round trips; the padding of K and of the vector is zero)
+                    double kv[RP / 8], xv[RP / 8];
+                #pragma unroll
+                    for (int bb = 0; bb < RP / 8; bb++) { const int b = (tid & 7) + 8 * bb; kv[bb] = kr[b]; xv[bb] = vd[b]; }
+                #pragma unroll
+                    for (int bb = 0; bb < RP / 8; bb++) s_ = fma(kv[bb], xv[bb], s_);
+                }
                 s_ = group_reduce<8, false>(s_);
                 if ((tid & 7) == 0) { const double zv = a < r ? s_ : 0.0; zd[a] = zv; dyd[RP + a] = wyd[a] + zv; }
             }
