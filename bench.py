@@ -208,6 +208,8 @@ def main():
     ap.add_argument("--eps", type=float, default=1e-4, help="eps_abs=eps_rel (SCS default 1e-4)")
     ap.add_argument("--cpu-sample", type=int, default=4096)
     ap.add_argument("--dispatch-history", type=int, default=1, help="longest-first dispatch from the previous step's iteration counts (the plugin's default); 0: index order")
+    ap.add_argument("--rotate", type=int, default=4, help="K distinct seeded batches resident in HBM, visited round-robin by the warm-up and the timed loop (K = 1: one batch "
+                                                          "re-solved every step, which lets the plugin's history heuristics replay instead of predict)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--accel", type=int, default=10,
                     help="acceleration_lookback handed to both sides.  10 (default) = SCS's own default, which diffcp forwards: type-I Anderson "
@@ -246,20 +248,33 @@ def main():
     n, cones, B = cfg["n"], cfg["cones"], args.batch
     tpl = P.dense_template(n, cones)
     solver_args = {"eps": args.eps, "max_iters": 10000, "acceleration_lookback": args.accel}
-    A, b, c = P.generate(n, cones, B, seed=rank)
-    A_eval, q_eval = tpl.values_from_dense(A, b, c)
     ctx = MI355_ctx(None, tpl.problem_data_index, cones, options={**solver_args, "dispatch_history": bool(args.dispatch_history)})
-    A_t = torch.from_numpy(A_eval).to(dev).requires_grad_()      # (nnz_aug, B) batch-minor, as the frontend hands it over
-    q_t = torch.from_numpy(q_eval).to(dev).requires_grad_()
+    # K distinct batches (seeds rank, rank + world, ...: no two ranks and no two slots share one), all resident in HBM before anything is timed.  The loop visits
+    # them round-robin, so what the plugin remembers of the previous call (iteration counts -> dispatch order, the largest adjoint system -> tile) belongs to a
+    # DIFFERENT batch of the same distribution: the heuristics have to predict, as in a training loop over fresh mini-batches.
+    K_rot = max(1, args.rotate)
+    batches = []
+    for k in range(K_rot):
+        A, b, c = P.generate(n, cones, B, seed=rank + world * k)
+        A_eval, q_eval = tpl.values_from_dense(A, b, c)
+        batches.append((torch.from_numpy(A_eval).to(dev).requires_grad_(),      # (nnz_aug, B) batch-minor, as the frontend hands it over
+                        torch.from_numpy(q_eval).to(dev).requires_grad_()))
+    del A, b, c, A_eval, q_eval
     eng = ctx.engine(dev)
+    step_no = [0]
+    last_info = [None] * K_rot          # the most recent `info` of every slot (iteration counts of ALL rotating batches enter the flop count)
 
-    def step():
+    def step(fixed=None):
+        slot = (step_no[0] % K_rot) if fixed is None else fixed
+        A_t, q_t = batches[slot]
+        step_no[0] += 1
         A_t.grad = None
         q_t.grad = None
         primal, dual, info, _ = _CvxpyLayer.apply(None, q_t, A_t, ctx, {}, True, None)
         if world > 1:
             primal, dual = gather_solution(primal, dual)      # one fused RCCL all-gather per step
         primal.sum().backward()
+        last_info[slot] = info
         return info
 
     # clock ramp: a run as short as the driver's (--steps 20 --warmup 5: 60 ms of GPU work) would be timed on a GPU that has not reached its steady clocks yet (ROUND_NOTES.md: short measurements right
@@ -294,19 +309,23 @@ def main():
     bwd_ms, nb = eng.profile(1)
     lay_ms, nl = eng.profile(2)
     eng.set_profiling(False)
-    # the same step with the OTHER dispatch order (the plugin dispatches the instances that iterated longest in the previous call first: this benchmark
-    # re-solves one batch, so the hint is exact here; a loop over unrelated batches gets the index-order number)
-    other_ms = None
-    if world == 1:
-        eng.set_dispatch_history(not args.dispatch_history)
+    # Two more timings of the same step, outside the headline (one rank only): `index_order` = the rotation with the dispatch history switched off, `replay` = ONE
+    # batch re-solved every step with the history on (the previous call's iteration counts and largest adjoint system are then exact: what rounds 1-4 reported).
+    def timed(ns, fixed=None):
         for _ in range(3):
-            step()
+            step(fixed)
         torch.cuda.synchronize(); t1 = time.perf_counter()
-        ns_other = max(5, min(args.steps, 40))
-        for _ in range(ns_other):
-            step()
+        for _ in range(ns):
+            step(fixed)
         torch.cuda.synchronize()
-        other_ms = (time.perf_counter() - t1) * 1e3 / ns_other
+        return (time.perf_counter() - t1) * 1e3 / ns
+    other_ms = replay_ms = None
+    if world == 1:
+        ns_other = max(8, min(args.steps, 40))
+        eng.set_dispatch_history(not args.dispatch_history)
+        other_ms = timed(ns_other)
+        eng.set_dispatch_history(True)
+        replay_ms = timed(ns_other, fixed=0)
         eng.set_dispatch_history(bool(args.dispatch_history))
     allgather_ms = None
     if world > 1:         # the exchange step on its own: one fused RCCL all-gather of (B, n + m) rows per step (HIP events on this stream)
@@ -325,14 +344,16 @@ def main():
         ms_per_step = 1e3 * dt / args.steps
         value = world * B * args.steps / dt
         m, nnzA = tpl.m, tpl.nnzA
-        iters = info["iters"].cpu().numpy().astype(np.float64)
+        slots = [li for li in last_info if li is not None]
+        iters = torch.stack([li["iters"] for li in slots]).cpu().numpy().astype(np.float64)          # (slots visited, B)
+        solved = float(np.mean([float((li["status"] == 1).float().mean().item()) for li in slots]))
         # algorithmic HBM bytes per instance: forward 8(nnzA+m+n) read + 8(n+2m) written
         fwd_bytes = 8 * (nnzA + m + n) + 8 * (n + 2 * m)
         bwd_bytes = 8 * (nnzA + 2 * n + 3 * m) + 8 * (nnzA + m + n)
         ach = fwd_bytes * B / (fwd_ms * 1e-3) / 1e9 if fwd_ms > 0 else 0.0
         traffic, traffic_src = pmc_traffic("k_fwd")
         # algorithmic fp64 flops of the forward kernel: setup m n^2 + n^3/3, per iteration 4 nnzA + 2 n^2 + 10(n+m)
-        flops = B * (m * n * n + n ** 3 / 3.0) + float(iters.sum()) * (4 * nnzA + 2 * n * n + 10 * (n + m))
+        flops = B * (m * n * n + n ** 3 / 3.0) + float(iters.sum(axis=1).mean()) * (4 * nnzA + 2 * n * n + 10 * (n + m))
         vtf = flops / (fwd_ms * 1e-3) / 1e12 if fwd_ms > 0 else 0.0
         out = {
             "metric": ("forward+backward problems/sec, batch=4096 n=50 m=100 SOC" if (args.config == "M" and B == 4096) else
@@ -342,9 +363,10 @@ def main():
             "config": {"workload": f"config {args.config}: n={n} m={m} cones l={cones.get('l', 0)} q={cones.get('q', [])} dense A "
                                    f"(nnzA={nnzA}), A,b,c batched, B={B} per GPU, eps_abs=eps_rel={args.eps}, max_iters=10000, "
                                    + (f"Anderson acceleration (SCS default: acceleration_lookback={args.accel}, interval 10; engine: one-pair history)" if args.accel > 0 else "acceleration off")
-                                   + "; step = plugin forward (layout pass + solve + status) + backward (adjoint VJP of sum(x))",
-                       "batch_per_gpu": B, "parallelism": f"batch-shard x{world}", "acceleration_lookback": int(args.accel),
-                       "solved_fraction": float((info["status"] == 1).float().mean().item()), "mean_iters": float(iters.mean())},
+                                   + f"; {K_rot} distinct seeded batches resident in HBM, visited round-robin (warm-up and timed steps)" +
+                                   "; step = plugin forward (layout pass + solve + status) + backward (adjoint VJP of sum(x))",
+                       "batch_per_gpu": B, "rotating_batches": K_rot, "parallelism": f"batch-shard x{world}", "acceleration_lookback": int(args.accel),
+                       "solved_fraction": solved, "mean_iters": float(iters.mean())},
             "roofline": {"bound": "valu-issue/latency", "kernel": "forward (k_fwd2 / k_forward_rt / k_forward): the longest kernel of the step",
                          "achieved": vtf, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s", "frac": vtf / FP64_VALU_PEAK_TF,
                          "traffic": traffic, "traffic_source": traffic_src, "algorithmic_flops_per_launch": flops,
@@ -357,10 +379,12 @@ def main():
             "kernels_ms": {"k_forward": fwd_ms, "k_backward": bwd_ms, "k_transpose": lay_ms, "launches": [nf, nb, nl],
                            "bwd_algorithmic_GBps": bwd_bytes * B / (bwd_ms * 1e-3) / 1e9 if bwd_ms > 0 else 0.0},
             "iters": {"mean": float(iters.mean()), "max": float(iters.max())},
-            "dispatch": {"history": bool(args.dispatch_history), "ms_per_step_with_history": ms_per_step if args.dispatch_history else other_ms,
-                         "ms_per_step_index_order": other_ms if args.dispatch_history else ms_per_step,
-                         "note": "workgroups are dispatched longest-first by the PREVIOUS step's iteration counts (plugin default, results bit-identical); this benchmark re-solves "
-                                 "one batch, so the prediction is exact: on unrelated batches expect the index-order figure"},
+            "dispatch": {"history": bool(args.dispatch_history), "ms_per_step_rotating_with_history": ms_per_step if args.dispatch_history else other_ms,
+                         "ms_per_step_rotating_index_order": other_ms if args.dispatch_history else ms_per_step,
+                         "ms_per_step_replay_one_batch": replay_ms,
+                         "note": "workgroups are dispatched longest-first by the PREVIOUS call's iteration counts and the adjoint's first tile is sized by the PREVIOUS call's largest "
+                                 "system (plugin defaults, results bit-identical).  `value` is measured on rotating batches, where both are predictions from a different batch; "
+                                 "`replay` re-solves one batch (both exact) and is reported for comparison with rounds 1-4 only"},
             "launch": eng.launch_info(),
         }
         if allgather_ms is not None:

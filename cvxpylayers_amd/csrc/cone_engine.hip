@@ -962,7 +962,7 @@ int ce_vjp_shared_a(ce_handle h, int B, const double *A_vals0, const double *x, 
     }
     {
         ProfScope ps(h, 1, (hipStream_t)stream);
-#define LAUNCH_SAL(RPV) hipLaunchKernelGGL(k_sa_lsqr<RPV>, dim3(B), dim3(NT), lds, (hipStream_t)stream, T, S, F, A_vals0, x, y, s, dx, dy, dA_bm, dq_vals, sdq_k, sdq_b, adj_status, lsqr_iters, atol, btol, iter_lim > 0 ? iter_lim : 4 * (T.n + T.m))
+#define LAUNCH_SAL(RPV) hipLaunchKernelGGL(k_sa_lsqr<RPV>, dim3(B), dim3(NT), lds, (hipStream_t)stream, T, S, F, A_vals0, x, y, s, dx, dy, dA_bm, dq_vals, sdq_k, sdq_b, adj_status, lsqr_iters, atol, btol, iter_lim > 0 ? iter_lim : 2 * (T.n + T.m + 1))
         if (RP == 0) LAUNCH_SAL(0); else if (RP == 16) LAUNCH_SAL(16); else if (RP == 32) LAUNCH_SAL(32); else LAUNCH_SAL(64);
 #undef LAUNCH_SAL
     }

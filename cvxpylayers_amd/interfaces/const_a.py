@@ -426,8 +426,12 @@ def _psd_eig(v, psd):
     return out
 
 
-def vjp_const_a(eng, A_bm, x, y, s, dx, dy, batch_minor_out=False, atol=1e-12, btol=1e-12, iter_factor=4):
-    """Returns dA (nnz_aug, B), dq (n+1, B), adj_status (B,) in the boundary convention (diffcp_if.py:91-92)."""
+def vjp_const_a(eng, A_bm, x, y, s, dx, dy, batch_minor_out=False, atol=1e-8, btol=1e-8, iter_lim=0):
+    """Returns dA (nnz_aug, B), dq (n+1, B), adj_status (B,) in the boundary convention (diffcp_if.py:91-92).
+    atol / btol / iter_lim: LSQR's stopping rule; the defaults are diffcp's (1e-8, 1e-8, 2 N with N = n + m + 1: what diffcp_if.py:86 runs and
+    oracle/cone_oracle.c:85,712 restates); the plugin forwards solver_args["lsqr_atol" / "lsqr_btol" / "lsqr_iter_lim"] (mi355_if.lsqr_rule)."""
+    if iter_lim <= 0:
+        iter_lim = 2 * (eng.n + eng.m + 1)
     dev = A_bm.device
     n, m, B = eng.n, eng.m, A_bm.shape[0]
     import os as _os
@@ -446,7 +450,7 @@ def vjp_const_a(eng, A_bm, x, y, s, dx, dy, batch_minor_out=False, atol=1e-12, b
         adj = torch.empty((B,), dtype=torch.int32, device=dev); its = torch.empty((B,), dtype=torch.int32, device=dev)
         xc, yc, sc_, dxc, dyc = (t.to(torch.float64).contiguous() for t in (x, y, s, dx, dy))
         rc = _lib.lib().ce_vjp_shared_a(eng._h, B, A_bm.data_ptr(), xc.data_ptr(), yc.data_ptr(), sc_.data_ptr(), dxc.data_ptr(), dyc.data_ptr(),
-                                        dA_bm.data_ptr(), dq.data_ptr(), B, 1, adj.data_ptr(), its.data_ptr(), atol, btol, iter_factor * (n + m),
+                                        dA_bm.data_ptr(), dq.data_ptr(), B, 1, adj.data_ptr(), its.data_ptr(), atol, btol, int(iter_lim),
                                         C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
         if rc == 0:
             eng.last_lsqr_iters = its
@@ -502,7 +506,7 @@ def vjp_const_a(eng, A_bm, x, y, s, dx, dy, batch_minor_out=False, atol=1e-12, b
     anorm = torch.zeros(B, **f64); ddnorm = torch.zeros(B, **f64); xxnorm = torch.zeros(B, **f64)
     zz = torch.zeros(B, **f64); cs2 = -torch.ones(B, **f64); sn2 = torch.zeros(B, **f64)
     live = live & (alfa * beta > 0)
-    itn_lim = iter_factor * (n + m)
+    itn_lim = int(iter_lim)
 
     def lsqr_iter(st):
         """one LSQR iteration as a pure function of the state tuple (so that a block of them can be captured in a HIP graph)"""

@@ -37,7 +37,20 @@ STATUS_NAMES = {1: "Solved", 2: "Solved/Inaccurate", -1: "Unbounded", -2: "Infea
 
 _KNOWN_ARGS = {"eps", "eps_abs", "eps_rel", "eps_infeas", "max_iters", "alpha", "rho_x", "scale", "normalize",
                "adaptive_scale", "acceleration_lookback", "acceleration_interval", "verbose", "mode", "solve_method",
-               "n_jobs_forward", "n_jobs_backward", "warm_starts", "raise_on_error", "dispatch_history"}
+               "n_jobs_forward", "n_jobs_backward", "warm_starts", "raise_on_error", "dispatch_history",
+               "lsqr_atol", "lsqr_btol", "lsqr_iter_lim"}
+
+# Stopping rule of the LSQR adjoint (shared-A templates).  diffcp's adjoint (diffcp_if.py:86 -> adj_batch, mode="lsqr") runs LSQR with atol = btol = 1e-8 and an
+# iteration limit of 2 N on its N = n + m + 1 operator; the oracle restates exactly that (oracle/cone_oracle.c:85,712).  solver_args may override:
+# lsqr_atol / lsqr_btol / lsqr_iter_lim (callers that need gradients to 1e-5 against a direct elimination pass tight values explicitly).
+LSQR_ATOL, LSQR_BTOL = 1e-8, 1e-8
+
+
+def lsqr_rule(merged_args: dict, n: int, m: int) -> tuple:
+    """(atol, btol, iter_lim) of the shared-A adjoint from merged solver_args; defaults = diffcp's"""
+    lim = merged_args.get("lsqr_iter_lim")
+    return (float(merged_args.get("lsqr_atol", LSQR_ATOL)), float(merged_args.get("lsqr_btol", LSQR_BTOL)),
+            int(lim) if lim not in (None, 0) else 2 * (n + m + 1))
 
 
 _WARNED: set = set()
@@ -286,13 +299,14 @@ class ConeEngine:
             return False
         return is_constant_A(A_bm, self.nnzA)
 
-    def vjp(self, A_bm, x, y, s, dx, dy, batch_minor_out: bool = False, P_bm=None, path: str | None = None):
+    def vjp(self, A_bm, x, y, s, dx, dy, batch_minor_out: bool = False, P_bm=None, path: str | None = None, lsqr: tuple | None = None):
         """Returns dA (nnz_aug, B), dq (n+1, B), adj_status (B,).  dA is a transposed view of a batch-major buffer (the
         engine-native layout, no extra pass) unless batch_minor_out: then it is (nnz_aug, B) contiguous -- the layout of a
         reference-style A_eval, so that autograd can accumulate it into the leaf without a strided copy (one engine layout pass).
         path: the path ("per_instance" / "const_a") of the forward call being differentiated, as recorded by the caller right
         after solve() -- the autograd node keeps it, so interleaved forward calls of one layer cannot redirect a pending backward.
-        None (direct engine users with one solve in flight): the path of the most recent solve()."""
+        None (direct engine users with one solve in flight): the path of the most recent solve().
+        lsqr: (atol, btol, iter_lim) of the shared-A LSQR adjoint (lsqr_rule); None = diffcp's 1e-8 / 1e-8 / 2 (n + m + 1).  Ignored by the direct eliminations."""
         B = A_bm.shape[0]
         dev = self.device
         if B == 0:
@@ -302,7 +316,8 @@ class ConeEngine:
             path = getattr(self, "last_path", None)
         if path == "const_a" and (self.launch_info()["bwd_mode"] in (1, 2) or __import__("os").environ.get("CE_CONST_A") == "1"):
             from cvxpylayers_amd.interfaces.const_a import vjp_const_a      # shared A: batched LSQR with GEMMs over the batch
-            return vjp_const_a(self, A_bm, x, y, s, dx, dy, batch_minor_out=batch_minor_out)
+            atol, btol, lim = lsqr if lsqr is not None else lsqr_rule({}, self.n, self.m)
+            return vjp_const_a(self, A_bm, x, y, s, dx, dy, batch_minor_out=batch_minor_out, atol=atol, btol=btol, iter_lim=lim)
         dq = torch.empty((self.n + 1, B), dtype=torch.float64, device=dev)
         adj = torch.empty((B,), dtype=torch.int32, device=dev)
         if batch_minor_out:
@@ -592,7 +607,8 @@ class _ConeLayer(torch.autograd.Function):
             primal = x.to(in_device)
             dual = y.to(in_device)
             info = dict(iters=iters, status=status, resid=resid, acceleration=getattr(eng, "last_acceleration", False))
-            saved = (eng, A_bm, x.detach(), y.detach(), s, batch_minor_in, P_bm, path, None) if needs_grad else None
+            lsqr = lsqr_rule(merged_args, eng.n, eng.m)
+            saved = (eng, A_bm, x.detach(), y.detach(), s, batch_minor_in, P_bm, path, None, lsqr) if needs_grad else None
             if status.numel():
                 summ = eng.read_summaries()
                 min_status, n_inaccurate = int(summ[0][0]), int(summ[0][1])
@@ -617,7 +633,7 @@ class _ConeLayer(torch.autograd.Function):
             y = torch.where(failed[:, None], torch.full_like(y, float("nan")), y)
             primal = x.to(in_device)
             dual = y.to(in_device)
-            saved = (eng, A_bm, x.detach(), y.detach(), s, batch_minor_in, P_bm, path, failed) if needs_grad else None
+            saved = (eng, A_bm, x.detach(), y.detach(), s, batch_minor_in, P_bm, path, failed, lsqr) if needs_grad else None
         # x / y are handed back as `primal` / `dual` (same objects when the input lives on the engine's device), and autograd
         # attaches this node to them: keeping the SAME objects on the node would form a reference cycle (node -> saved ->
         # primal -> grad_fn -> node) that only the cyclic GC breaks, i.e. 167 MB buffers pile up for many steps and the
@@ -637,7 +653,7 @@ class _ConeLayer(torch.autograd.Function):
         saved, batch_size, originally_unbatched, in_device = ctx.backward_data
         if saved is None:
             raise RuntimeError("backward called on a layer evaluated with needs_grad=False")
-        eng, A_bm, x, y, s, batch_minor_in, P_bm, path, failed = saved
+        eng, A_bm, x, y, s, batch_minor_in, P_bm, path, failed, lsqr = saved
         dP = None
         if dprimal is None and ddual is None:         # nothing flows back through this node
             return None, None, None, None, None, None, None
@@ -649,10 +665,10 @@ class _ConeLayer(torch.autograd.Function):
                 dx = torch.where(keep, dx, torch.zeros_like(dx)); dy = torch.where(keep, dy, torch.zeros_like(dy))
                 x = torch.where(keep, x, torch.zeros_like(x)); y = torch.where(keep, y, torch.zeros_like(y)); s = torch.where(keep, s, torch.zeros_like(s))
             if P_bm is not None:
-                dA, dq, adj, dP_bm = eng.vjp(A_bm, x, y, s, dx, dy, batch_minor_out=batch_minor_in, P_bm=P_bm, path=path)
+                dA, dq, adj, dP_bm = eng.vjp(A_bm, x, y, s, dx, dy, batch_minor_out=batch_minor_in, P_bm=P_bm, path=path, lsqr=lsqr)
                 dP = dP_bm.t().to(in_device)
             else:
-                dA, dq, adj = eng.vjp(A_bm, x, y, s, dx, dy, batch_minor_out=batch_minor_in, path=path)
+                dA, dq, adj = eng.vjp(A_bm, x, y, s, dx, dy, batch_minor_out=batch_minor_in, path=path, lsqr=lsqr)
         if failed is not None:
             dA = torch.where(failed[None, :], torch.zeros_like(dA), dA); dq = torch.where(failed[None, :], torch.zeros_like(dq), dq)
             if P_bm is not None:

@@ -206,6 +206,23 @@ def box_qp_batch(nx: int, B: int, seed: int = 0):
     return np.broadcast_to(A, (B, m, n)).copy(), b, c, cones
 
 
+def native_box_qp_batch(nx: int, B: int, seed: int = 0):
+    """BASELINE config 2 in its NATIVE form: min 1/2 x^T (2 F^T F) x - 2 g^T F x  s.t.  lo <= x <= hi -- the same F, g, lo, hi as
+    box_qp_batch (same seed, same draws), P = 2 F^T F shared, 2 nx nonnegative rows.  Returns (A (2nx, nx) shared, b (B, 2nx), q (B, nx), P (nx, nx),
+    p_structure = CSC structure of the upper triangle (indices, indptr, (nx, nx)), p_values (nnzP,))."""
+    rng = np.random.default_rng(seed)
+    F = rng.standard_normal((nx, nx)) / np.sqrt(nx); g = rng.standard_normal((B, nx))
+    lo = -0.5 - 0.5 * rng.random((B, nx)); hi = 0.5 + 0.5 * rng.random((B, nx))
+    A = np.concatenate([-np.eye(nx), np.eye(nx)], axis=0)
+    rows, ptr = [], [0]
+    for j in range(nx):
+        rows.extend(range(j + 1)); ptr.append(len(rows))
+    pst = (np.asarray(rows, dtype=np.int32), np.asarray(ptr, dtype=np.int32), (nx, nx))
+    Pm = 2 * F.T @ F
+    pv = Pm[pst[0], np.repeat(np.arange(nx), np.diff(pst[1]))]
+    return A, np.concatenate([-lo, hi], axis=1), -2 * g @ F, Pm, pst, pv
+
+
 def sdp_c4_batch(B: int, seed: int = 0, k: int = 20, neq: int = 20):
     """BASELINE config 4: SDP with one k x k PSD cone, x = svec(X) (n = k(k+1)/2 = 210), `neq` equality rows
     <A_j, X> = b_j and the PSD block s = svec(X) (A_psd = -I): m = neq + n = 230.  A is SHARED by the batch; b and c (= svec(C)) are

@@ -245,8 +245,8 @@ int ce_solve_shared_a(ce_handle h, int B, int r, int RP, const double *AdT, cons
  * parameters: diffcp's adjoint system (r_tau = 0) solved by LSQR -- diffcp's own default mode -- entirely inside one kernel, one
  * workgroup per instance, A applied from its sparse structure, the PSD cone's derivative on the matrix cores.  A_vals0: the nnz_aug
  * boundary values of ONE instance (the A part is shared); x, y, s, dx, dy as ce_vjp; dA_bm (B, nnz_aug) batch-major; dq at
- * [k * sdq_k + i * sdq_b]; adj_status[i] = 1 when LSQR hit iter_lim (0: 4 (n + m)); lsqr_iters (B) or NULL; atol / btol: LSQR stopping
- * tolerances.  The engine refills its own scratch (split of this call's A values) on `stream`: one engine, one stream at a time.  All cone types (zero / nonnegative / second-order / PSD / exponential / power: the triples' derivative is a symmetrised
+ * [k * sdq_k + i * sdq_b]; adj_status[i] = 1 when LSQR hit iter_lim (0: diffcp's 2 (n + m + 1)); lsqr_iters (B) or NULL; atol / btol: LSQR stopping
+ * tolerances (diffcp runs 1e-8 / 1e-8: the plugin's default, solver_args lsqr_atol / lsqr_btol / lsqr_iter_lim override).  The engine refills its own scratch (split of this call's A values) on `stream`: one engine, one stream at a time.  All cone types (zero / nonnegative / second-order / PSD / exponential / power: the triples' derivative is a symmetrised
  * 3 x 3 block computed once per call); CE_E_TOO_LARGE when the LSQR vectors of one instance exceed LDS (callers fall back to the batched
  * path of const_a.py).
  */

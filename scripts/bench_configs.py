@@ -63,20 +63,9 @@ def run(name, tpl, cones, A_eval, q_eval, eps, reps, note, P_eval=None, p_struct
 
 
 def native_box_qp(B, nx=50, seed=0):
-    """BASELINE config 2 in its native form: min 1/2 x^T (2 F^T F) x - 2 g^T F x, lo <= x <= hi; same F, g, lo, hi as box_qp_batch"""
-    rng = np.random.default_rng(seed)
-    F = rng.standard_normal((nx, nx)) / np.sqrt(nx); g = rng.standard_normal((B, nx))
-    lo = -0.5 - 0.5 * rng.random((B, nx)); hi = 0.5 + 0.5 * rng.random((B, nx))
-    An = np.concatenate([-np.eye(nx), np.eye(nx)], axis=0)
-    rows, ptr = [], [0]
-    for j in range(nx):
-        rows.extend(range(j + 1)); ptr.append(len(rows))
-    pst = (np.asarray(rows, dtype=np.int32), np.asarray(ptr, dtype=np.int32), (nx, nx))
-    Pm = 2 * F.T @ F
-    pv = Pm[pst[0], np.repeat(np.arange(nx), np.diff(pst[1]))]
-    return An, np.concatenate([-lo, hi], axis=1), -2 * g @ F, pst, np.broadcast_to(pv[:, None], (len(pv), B)).copy()
-
-
+    """BASELINE config 2 in its native form (problems.native_box_qp_batch): min 1/2 x^T (2 F^T F) x - 2 g^T F x, lo <= x <= hi; same F, g, lo, hi as box_qp_batch"""
+    An, bn, qn, _, pst, pv = P.native_box_qp_batch(nx, B, seed)
+    return An, bn, qn, pst, np.broadcast_to(pv[:, None], (len(pv), B)).copy()
 
 
 WANT = [k for k in os.environ.get("CONFIGS", "M,C2,C2Q,C2N,C3,C4,C5,E").split(",") if k]

@@ -169,3 +169,8 @@ def geo_mean_max(w, total, alpha=0.5):
     A[1, 0] = A[2, 1] = A[3, 2] = -1.0
     xs = np.array([alpha * total / w[0], (1 - alpha) * total / w[1]])
     return A, b, c, dict(z=1, l=0, q=[], s=[], ep=0, p=[alpha]), xs
+
+
+# The shared-A adjoint stops like diffcp's LSQR by default (atol = btol = 1e-8, 2 N iterations: mi355_if.lsqr_rule).  Tests that compare its gradients with a
+# DIRECT elimination to 1e-5 ask for a tight solve explicitly -- the same triple as solver_args lsqr_atol / lsqr_btol / lsqr_iter_lim.
+TIGHT_LSQR = (1e-12, 1e-12, 20000)

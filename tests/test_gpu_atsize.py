@@ -9,6 +9,7 @@ import pytest
 import torch
 
 from cvxpylayers_amd import problems as P
+from kit import TIGHT_LSQR
 
 pytestmark = pytest.mark.gpu
 
@@ -99,7 +100,7 @@ def test_C5_portfolio_n501_at_size():
     A_eval, _ = tpl.values_from_dense(Ab, bb, c)
     A_bm = torch.from_numpy(A_eval).cuda().t().contiguous()
     xo, yo, so = (torch.from_numpy(ref[k]).cuda() for k in ("x", "y", "s"))
-    dA2, dq2, adj2 = eng.vjp(A_bm, xo, yo, so, torch.ones_like(xo), torch.zeros_like(yo), path="const_a")
+    dA2, dq2, adj2 = eng.vjp(A_bm, xo, yo, so, torch.ones_like(xo), torch.zeros_like(yo), path="const_a", lsqr=TIGHT_LSQR)
     g = oracle.adjoint_batch(Ab, bb, c, cones, ref["x"], ref["y"], ref["s"], np.ones_like(ref["x"]), np.zeros_like(ref["y"]), mode="dense")
     assert int((adj2 != 0).sum().item()) == 0
     # Per instance: at a vertex of the feasible set (as many active rows as variables) the solution is locally constant and both

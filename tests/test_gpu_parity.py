@@ -9,6 +9,7 @@ import torch
 
 import kit
 from cvxpylayers_amd import problems as P
+from kit import TIGHT_LSQR
 
 pytestmark = pytest.mark.gpu
 
@@ -59,7 +60,7 @@ def run_parity(n, cones, B, seed, eps, pattern=None, max_iters=20000):
     g = oracle.adjoint_batch(A, b, c, cones, ref["x"], ref["y"], ref["s"], dx, dy, mode="dense" if tight else "lsqr")
     gtol = 1e-5 if tight else 2e-3
     xr, yr, sr = (torch.from_numpy(ref[k]).cuda() for k in ("x", "y", "s"))   # differentiate at the oracle's point
-    dA, dq, adj = eng.vjp(A_bm, xr, yr, sr, torch.from_numpy(dx).cuda(), torch.from_numpy(dy).cuda())
+    dA, dq, adj = eng.vjp(A_bm, xr, yr, sr, torch.from_numpy(dx).cuda(), torch.from_numpy(dy).cuda(), lsqr=TIGHT_LSQR)
     torch.cuda.synchronize()
     assert (adj.cpu().numpy() == 0).all()
     dA = dA.cpu().numpy(); dq = dq.cpu().numpy()
@@ -215,7 +216,7 @@ def test_constant_A_gemm_path_matches_oracle(monkeypatch):
             dx = rng.standard_normal(ref["x"].shape); dy = rng.standard_normal(ref["y"].shape)
             g = oracle.adjoint_batch(A, b, c, cones, ref["x"], ref["y"], ref["s"], dx, dy, mode="dense")
             xr, yr, sr = (torch.from_numpy(ref[k]).cuda() for k in ("x", "y", "s"))
-            dA, dq, adj = eng.vjp(A_bm, xr, yr, sr, torch.from_numpy(dx).cuda(), torch.from_numpy(dy).cuda())
+            dA, dq, adj = eng.vjp(A_bm, xr, yr, sr, torch.from_numpy(dx).cuda(), torch.from_numpy(dy).cuda(), lsqr=TIGHT_LSQR)
             assert (adj.cpu().numpy() == 0).all()
             dA = dA.cpu().numpy(); dq = dq.cpu().numpy()
             cols = np.repeat(np.arange(n + 1), np.diff(tpl.indptr))
@@ -254,7 +255,7 @@ def test_constant_A_path_is_selected_for_large_shared_templates():
     dx = rng.standard_normal(ref["x"].shape)
     g = oracle.adjoint_batch(Ab, bb, c, cones, ref["x"], ref["y"], ref["s"], dx, np.zeros_like(ref["y"]), mode="dense")
     xr, yr, sr = (torch.from_numpy(ref[k]).cuda() for k in ("x", "y", "s"))
-    dA, dq, adj = eng.vjp(A_bm, xr, yr, sr, torch.from_numpy(dx).cuda(), torch.zeros_like(yr))
+    dA, dq, adj = eng.vjp(A_bm, xr, yr, sr, torch.from_numpy(dx).cuda(), torch.zeros_like(yr), lsqr=TIGHT_LSQR)
     assert (adj.cpu().numpy() == 0).all()
     assert np.abs(dq.cpu().numpy()[:n] - g["dc"].T).max() < 1e-5 * (1 + np.abs(g["dc"]).max())
 
@@ -279,7 +280,7 @@ def test_constant_A_path_with_psd_cone(monkeypatch):
     dx = rng.standard_normal(ref["x"].shape); dy = rng.standard_normal(ref["y"].shape)
     g = oracle.adjoint_batch(A, b, c, cones, ref["x"], ref["y"], ref["s"], dx, dy, mode="dense")
     xr, yr, sr = (torch.from_numpy(ref[k]).cuda() for k in ("x", "y", "s"))
-    dA, dq, adj = eng.vjp(A_bm, xr, yr, sr, torch.from_numpy(dx).cuda(), torch.from_numpy(dy).cuda())
+    dA, dq, adj = eng.vjp(A_bm, xr, yr, sr, torch.from_numpy(dx).cuda(), torch.from_numpy(dy).cuda(), lsqr=TIGHT_LSQR)
     assert (adj.cpu().numpy() == 0).all()
     assert np.abs(dq.cpu().numpy()[:n] - g["dc"].T).max() < 1e-5 * (1 + np.abs(g["dc"]).max())
 
@@ -403,7 +404,7 @@ def test_constant_A_path_with_exp_and_power_cones(monkeypatch):
     dx = rng.standard_normal(ref["x"].shape); dy = rng.standard_normal(ref["y"].shape)
     g = oracle.adjoint_batch(A, b, c, cones, ref["x"], ref["y"], ref["s"], dx, dy, mode="dense")
     xr, yr, sr = (torch.from_numpy(ref[k]).cuda() for k in ("x", "y", "s"))
-    dA, dq, adj = eng.vjp(A_bm, xr, yr, sr, torch.from_numpy(dx).cuda(), torch.from_numpy(dy).cuda())
+    dA, dq, adj = eng.vjp(A_bm, xr, yr, sr, torch.from_numpy(dx).cuda(), torch.from_numpy(dy).cuda(), lsqr=TIGHT_LSQR)
     assert (adj.cpu().numpy() == 0).all()
     assert np.abs(dq.cpu().numpy()[:n] - g["dc"].T).max() < 1e-5 * (1 + np.abs(g["dc"]).max())
 
@@ -454,7 +455,7 @@ def test_shared_A_kernels_with_exp_and_power_cones(monkeypatch):
     dx = rng.standard_normal(ref["x"].shape); dy = rng.standard_normal(ref["y"].shape)
     g = oracle.adjoint_batch(Ab, b, c, cones, ref["x"], ref["y"], ref["s"], dx, dy, mode="dense")
     xr, yr, sr = (torch.from_numpy(ref[k]).cuda() for k in ("x", "y", "s"))
-    dA, dq, adj = eng.vjp(A_bm, xr, yr, sr, torch.from_numpy(dx).cuda(), torch.from_numpy(dy).cuda())
+    dA, dq, adj = eng.vjp(A_bm, xr, yr, sr, torch.from_numpy(dx).cuda(), torch.from_numpy(dy).cuda(), lsqr=TIGHT_LSQR)
     if os.environ.get("CE_SA_KERNEL") != "0":
         assert eng.last_lsqr_iters is not None
     good = ok & (adj.cpu().numpy() == 0)
