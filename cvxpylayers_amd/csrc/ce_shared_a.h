@@ -1,9 +1,11 @@
 // ce_shared_a.h -- SHARED-A adjoint: diffcp's adjoint solved by LSQR entirely inside ONE kernel, one workgroup per instance.
 //
-// For templates whose A does not depend on the parameters (only b, c vary: BASELINE configurations 4 and 5) the operator of the reduced
-// adjoint system
-//        N (r_x, r_y) = ( -A^T r_y ,  DPi (A r_x - r_y) + r_y )  =  ( dx , DPi dy )                (r_tau = 0, oracle/cone_oracle.c adjoint_one)
-// uses the SAME sparse matrix for every instance; only DPi = D Pi_K*(y - s) is per instance.  Round 1 ran LSQR on it from Python (every
+// For templates whose A does not depend on the parameters (only b, c vary: BASELINE configurations 4 and 5) the operator of diffcp's adjoint
+// system  M^T r = dz,  r = (r_x, r_y, r_tau)  (oracle/cone_oracle.c apply_MT / apply_M / adjoint_one):
+//        M^T r = ( -A^T r_y - c r_tau ,  DPi (A r_x - b r_tau - r_y) + r_y ,  c.r_x + b.r_y ),      dz = ( dx , DPi dy , -(x.dx + y.dy) )
+// uses the SAME sparse matrix for every instance; only DPi = D Pi_K*(y - s), b and c are per instance.  The kernel runs LSQR on the FULL
+// (n + m + 1) operator, as diffcp does: on rank-deficient systems (degenerate faces) LSQR returns the minimum-norm solution of THAT system, and
+// pinning r_tau = 0 (rounds 1-4; still what a null q_vals selects) returns a different element -- equal gradients only where the system is regular.  Round 1 ran LSQR on it from Python (every
 // operator application two rocBLAS GEMMs over the batch with the DENSE A plus ~30 small torch kernels: launch-bound, 250 ms for 1024
 // instances of the 20 x 20 SDP).  Here every LSQR vector of an instance lives in LDS, A is applied from its sparse structure (CSR for A v,
 // CSC for A^T v; values and indices stream from L2, shared by all workgroups), the convergence test is evaluated in the kernel, and the
@@ -26,6 +28,7 @@ struct SaStruct {            // sparse structure of the template's A part (devic
     const int *csr_col;      // [nnzA]
     const int *csr_src;      // [nnzA]    position of the entry in the value order
     int nnzA;
+    const int *bpos;         // [m]       position of the row's b entry in the value order (-1: structurally zero)
 };
 
 constexpr int SA_G = 8;      // lanes per row / column of a sparse product (DPP butterfly over 8 lanes)
@@ -59,7 +62,7 @@ __host__ __device__ inline size_t sa_lsqr_lds_doubles(int n, int m, int nq, int 
 // the CSR / CSC structure (any sparsity pattern, but rows of very different lengths serialise on the longest).
 template <int RP>
 __global__ void __launch_bounds__(NT, 3)
-k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, const double *__restrict__ xg, const double *__restrict__ yg,
+k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, long sAb, const double *__restrict__ qg, long sqk, long sqb, const double *__restrict__ xg, const double *__restrict__ yg,
           const double *__restrict__ sg, const double *__restrict__ dxg, const double *__restrict__ dyg, double *__restrict__ dAo,
           double *__restrict__ dqo, long sdqk, long sdqb, int *__restrict__ adj_status, int *__restrict__ iters_o, double atol, double btol, int itn_lim) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -85,6 +88,12 @@ k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, cons
     p += (size_t)(p - sm) & 1;
     double *Jt = p; p += 9 * (size_t)ntri;                    // exponential / power triples: symmetrised 3 x 3 derivative of the dual-cone projection
     const double *x = xg + (size_t)inst * n, *y = yg + (size_t)inst * m, *s = sg + (size_t)inst * m;
+    // the tau row / column of the operator: c_j from the boundary's q values, b_i from this instance's value row (both stay in global memory: L2-resident, read
+    // with the loads of the products they join; LDS has no room for two more vectors at three workgroups per CU).  qg == null: r_tau pinned to 0.
+    const bool TAU = qg != nullptr;
+    const double *cq = TAU ? qg + (size_t)inst * sqb : nullptr;
+    const double *Ab = Avals0 + (size_t)inst * sAb;
+    auto bval = [&](int i) -> double { if (!TAU) return 0.0; const int pb = S.bpos[i]; return pb >= 0 ? Ab[pb] : 0.0; };
 
     for (int i = tid; i < psd_first; i += NT) vv[i] = y[i] - s[i];
     __syncthreads();
@@ -211,60 +220,70 @@ k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, cons
             __syncthreads();
             sa_fused_pass<NT, RP>(F.AdT, n, wyd, xin,
                                   [&](int j, int k8) { double acc = 0; for (int k = F.scol_ptr[j] + k8; k < F.scol_ptr[j + 1]; k += 8) { const int i = F.scol_row[k]; acc = fma(F.srow_val[i], yin[i], acc); } return acc; },
-                                  fx, part, F.sing_i, F.sing_v, yin);
+                                  fx, part, F.sing_i, F.sing_v, yin, cq, sqk);
             __syncthreads();
             for (int i0 = tid; i0 < m; i0 += 4 * NT) {          // four rows per step: their index / value loads (global memory) are requested together
-                int cc[4], aa[4]; double sv4[4];
+                int cc[4], aa[4], pb[4]; double sv4[4], bb[4];
 #pragma unroll
-                for (int u = 0; u < 4; u++) { const int i = min(i0 + u * NT, m - 1); cc[u] = F.srow_col[i]; aa[u] = F.rowslot[i]; sv4[u] = F.srow_val[i]; }
+                for (int u = 0; u < 4; u++) { const int i = min(i0 + u * NT, m - 1); cc[u] = F.srow_col[i]; aa[u] = F.rowslot[i]; sv4[u] = F.srow_val[i]; pb[u] = TAU ? S.bpos[i] : -1; }
+#pragma unroll
+                for (int u = 0; u < 4; u++) bb[u] = pb[u] >= 0 ? Ab[pb[u]] : 0.0;          // (second level of the chain, the four of them together)
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     const int i = i0 + u * NT;
                     if (i >= m) break;
-                    if (cc[u] >= 0) fy(i, sv4[u] * xin[cc[u]]);
+                    if (cc[u] >= 0) fy(i, sv4[u] * xin[cc[u]], bb[u]);
                     else {
                         double s_ = 0;                               // slot of a dense row, -1: empty row
                         if (aa[u] >= 0) {
 #pragma unroll
                             for (int w = 0; w < NW; w++) s_ += part[w * RP + aa[u]];
                         }
-                        fy(i, s_);
+                        fy(i, s_, bb[u]);
                     }
                 }
             }
             __syncthreads();
         } else {
-            sa_spmv(S.csc_ptr, S.csc_row, (const int *)nullptr, Avals0, n, [&](int i) { return yin[i]; }, [&](int j, double a) { fx(j, -a); });
-            sa_spmv(S.csr_ptr, S.csr_col, S.csr_src, Avals0, m, [&](int j) { return xin[j]; }, [&](int i, double a) { fy(i, -a); });
+            sa_spmv(S.csc_ptr, S.csc_row, (const int *)nullptr, Avals0, n, [&](int i) { return yin[i]; }, [&](int j, double a) { fx(j, -a, TAU ? cq[(size_t)j * sqk] : 0.0); });
+            sa_spmv(S.csr_ptr, S.csr_col, S.csr_src, Avals0, m, [&](int j) { return xin[j]; }, [&](int i, double a) { fy(i, -a, bval(i)); });
             __syncthreads();
         }
     };
     auto safe = [](double t) -> double { return t > 0 ? t : 1.0; };
-    auto sum_all = [&](double v) -> double { double r[1] = {v}; block_reduce<1>(r, 0u, red); return r[0]; };
+    // (sum of squares, tau-row dot product) over the workgroup in one reduction
+    auto sum_two = [&](double v, double w, double &wsum) -> double { double r[2] = {v, w}; block_reduce<2>(r, 0u, red); wsum = r[1]; return r[0]; };
 
-    // ---- LSQR (Paige & Saunders) on N r = (dx, DPi dy)
-    //      N (r_x, r_y) = (-A^T r_y, DPi(A r_x - r_y) + r_y),     N^T (p_x, p_y) = (A^T q, -A p_x - q + p_y),  q = DPi(p_y)
-    double acc = 0;
-    for (int j = tid; j < n; j += NT) { const double v = dxg[(size_t)inst * n + j]; ux[j] = v; rx[j] = 0.0; acc = fma(v, v, acc); }
-    for (int i = tid; i < m; i += NT) { ty[i] = dyg[(size_t)inst * m + i]; ry[i] = 0.0; }
+    // ---- LSQR (Paige & Saunders) on  N r = dz,  N = M^T  (the tau components ut, vt, wt, rt are workgroup-uniform scalars in registers)
+    //      N   (r_x, r_y, r_t) = ( -A^T r_y - c r_t ,  DPi(A r_x - b r_t - r_y) + r_y ,  c.r_x + b.r_y )
+    //      N^T (p_x, p_y, p_t) = (  A^T q + c p_t   , -A p_x + b p_t - q + p_y          , -c.p_x - b.q   ),     q = DPi(p_y)
+    double acc = 0, acct = 0, dsum = 0;
+    for (int j = tid; j < n; j += NT) { const double v = dxg[(size_t)inst * n + j]; ux[j] = v; rx[j] = 0.0; acc = fma(v, v, acc); acct = fma(x[j], v, acct); }
+    for (int i = tid; i < m; i += NT) { const double v = dyg[(size_t)inst * m + i]; ty[i] = v; ry[i] = 0.0; acct = fma(y[i], v, acct); }
     __syncthreads();
     dproj(ty, 1.0, [&](int i, double o) { uy[i] = o; acc = fma(o, o, acc); });
-    const double bnorm = sqrt(sum_all(acc));
+    acc = sum_two(acc, acct, dsum);
+    double ut = TAU ? -dsum : 0.0, vt = 0.0, wt = 0.0, rt = 0.0;          // dz_tau = -(x.dx + y.dy)
+    const double bnorm = sqrt(fma(ut, ut, acc));
     double beta = bnorm, ib = 1.0 / safe(beta);
-    // u <- u / beta ;  q = DPi(uy) ;  (vx, vy) = N^T u
+    // u <- u / beta ;  q = DPi(uy) ;  v = N^T u
     for (int j = tid; j < n; j += NT) ux[j] *= ib;
     dproj(uy, ib, [&](int i, double o) { qv[i] = o; });
     if (ntri > 0) __syncthreads();                       // a triple's thread reads three rows of uy that other threads rescale below
     for (int i = tid; i < m; i += NT) uy[i] *= ib;       // (every other read of uy by dproj is behind one of its barriers, or by the row's own thread)
+    ut *= ib;
     __syncthreads();
-    acc = 0;
-    both_products(qv, ux, [&](int j, double a) { vx[j] = a; acc = fma(a, a, acc); },
-                  [&](int i, double a) { const double v = -a - qv[i] + uy[i]; vy[i] = v; acc = fma(v, v, acc); });
-    double alfa = sqrt(sum_all(acc));
+    acc = 0; acct = 0;
+    both_products(qv, ux, [&](int j, double a, double cj) { const double v = fma(cj, ut, a); vx[j] = v; acc = fma(v, v, acc); acct = fma(cj, ux[j], acct); },
+                  [&](int i, double a, double bi) { const double v = fma(bi, ut, -a - qv[i] + uy[i]); vy[i] = v; acc = fma(v, v, acc); acct = fma(bi, qv[i], acct); });
+    acc = sum_two(acc, acct, dsum);
+    vt = TAU ? -dsum : 0.0;
+    double alfa = sqrt(fma(vt, vt, acc));
     {
         const double ia = 1.0 / safe(alfa);
         for (int j = tid; j < n; j += NT) { const double v = vx[j] * ia; vx[j] = v; wx[j] = v; }
         for (int i = tid; i < m; i += NT) { const double v = vy[i] * ia; vy[i] = v; wy[i] = v; }
+        vt *= ia; wt = vt;
     }
     __syncthreads();
     double rhobar = alfa, phibar = beta, anorm = 0, xxnorm = 0, zz = 0, cs2 = -1, sn2 = 0;
@@ -276,14 +295,16 @@ k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, cons
     while (live && itn < itn_lim) {
         itn++;
         LS_T(7);
-        // (tx, ty) = N v :  tx = -A^T vy ;  ty = DPi(A vx - vy) + vy ;   u-hat = t - alfa u
-        acc = 0;
-        both_products(vy, vx, [&](int j, double a) { const double v = -a - alfa * ux[j]; ux[j] = v; acc = fma(v, v, acc); },
-                      [&](int i, double a) { ty[i] = a - vy[i]; });
+        // t = N v :  tx = -A^T vy - c vt ;  ty = DPi(A vx - b vt - vy) + vy ;  tt = c.vx + b.vy ;   u-hat = t - alfa u
+        acc = 0; acct = 0;
+        both_products(vy, vx, [&](int j, double a, double cj) { const double v = -a - cj * vt - alfa * ux[j]; ux[j] = v; acc = fma(v, v, acc); acct = fma(cj, vx[j], acct); },
+                      [&](int i, double a, double bi) { const double vyi = vy[i]; ty[i] = a - bi * vt - vyi; acct = fma(bi, vyi, acct); });
         LS_T(0);
         dproj(ty, 1.0, [&](int i, double o) { const double v = o + vy[i] - alfa * uy[i]; uy[i] = v; acc = fma(v, v, acc); });
         LS_T(1);
-        beta = sqrt(sum_all(acc));
+        acc = sum_two(acc, acct, dsum);
+        ut = TAU ? dsum - alfa * ut : 0.0;
+        beta = sqrt(fma(ut, ut, acc));
         LS_T(2);
         ib = 1.0 / safe(beta);
         anorm = sqrt(anorm * anorm + alfa * alfa + beta * beta);
@@ -292,13 +313,16 @@ k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, cons
         dproj(uy, ib, [&](int i, double o) { qv[i] = o; });
         if (ntri > 0) __syncthreads();
         for (int i = tid; i < m; i += NT) uy[i] *= ib;
+        ut *= ib;
         __syncthreads();
         LS_T(3);
-        acc = 0;
-        both_products(qv, ux, [&](int j, double a) { const double v = a - beta * vx[j]; vx[j] = v; acc = fma(v, v, acc); },
-                      [&](int i, double a) { const double v = -a - qv[i] + uy[i] - beta * vy[i]; vy[i] = v; acc = fma(v, v, acc); });
+        acc = 0; acct = 0;
+        both_products(qv, ux, [&](int j, double a, double cj) { const double v = fma(cj, ut, a) - beta * vx[j]; vx[j] = v; acc = fma(v, v, acc); acct = fma(cj, ux[j], acct); },
+                      [&](int i, double a, double bi) { const double qi = qv[i]; const double v = fma(bi, ut, -a - qi + uy[i]) - beta * vy[i]; vy[i] = v; acc = fma(v, v, acc); acct = fma(bi, qi, acct); });
         LS_T(4);
-        alfa = sqrt(sum_all(acc));
+        acc = sum_two(acc, acct, dsum);
+        vt = TAU ? -dsum - beta * vt : 0.0;
+        alfa = sqrt(fma(vt, vt, acc));
         LS_T(5);
         const double rho = sqrt(rhobar * rhobar + beta * beta);
         const double cs_ = rhobar / safe(rho), sn = beta / safe(rho);
@@ -306,6 +330,7 @@ k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, cons
         const double t1 = phi / safe(rho), t2 = -theta / safe(rho), ia = 1.0 / safe(alfa);
         for (int j = tid; j < n; j += NT) { const double v = vx[j] * ia, w = wx[j]; vx[j] = v; rx[j] += t1 * w; wx[j] = v + t2 * w; }
         for (int i = tid; i < m; i += NT) { const double v = vy[i] * ia, w = wy[i]; vy[i] = v; ry[i] += t1 * w; wy[i] = v + t2 * w; }
+        { vt *= ia; rt = fma(t1, wt, rt); wt = fma(t2, wt, vt); }
         __syncthreads();
         LS_T(6);
         const double delta = sn2 * rho, gambar = -cs2 * rho, rhs = phi - delta * zz, zbar = rhs / safe(fabs(gambar)) * (gambar > 0 ? 1.0 : (gambar < 0 ? -1.0 : 0.0));
@@ -319,13 +344,13 @@ k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, cons
     }
     __syncthreads();
     // ---- outputs in the boundary convention: dA_eval = [-dA.data, db[b_idx]], dq_eval = [dc, 0]  (diffcp_if.py:91-92);
-    //      dA_ij = x_j r_y,i - y_i r_x,j ,  db = -r_y ,  dc = -r_x
+    //      dA_ij = x_j r_y,i - y_i r_x,j ,  db = y r_tau - r_y ,  dc = x r_tau - r_x        (oracle/cone_oracle.c adjoint_one: dQ = r Pi(z)^T antisymmetrised)
     double *dA = dAo + (size_t)inst * T.nnz_aug;
     for (int k = tid; k < T.nnz_aug; k += NT) {
         const int r = T.rowidx[k], c = T.colidx[k];
-        dA[k] = (c < n) ? -(x[c] * ry[r] - y[r] * rx[c]) : -ry[r];
+        dA[k] = (c < n) ? -(x[c] * ry[r] - y[r] * rx[c]) : fma(y[r], rt, -ry[r]);
     }
-    for (int j = tid; j <= n; j += NT) dqo[j * sdqk + inst * sdqb] = (j < n) ? -rx[j] : 0.0;
+    for (int j = tid; j <= n; j += NT) dqo[j * sdqk + inst * sdqb] = (j < n) ? fma(x[j], rt, -rx[j]) : 0.0;
 #ifdef CE_TIMING
     __syncthreads();
     if (tid == 0) for (int k = 0; k < 8; k++) dA[k] = (double)ls_tacc[k];

@@ -97,9 +97,12 @@ __device__ __forceinline__ void sa_rows_dot(const double *__restrict__ AdT, int 
 // sing_i / sing_v / yin (may be null): the singleton part of column j is  sing_v[j] * yin[sing_i[j]]  when the column has exactly one singleton row -- two loads that
 // depend on j only and are requested with the row's matrix loads, instead of the three-level chain scol_ptr -> scol_row -> srow_val inside extra() that every row
 // group used to wait for (config 5: 33 k of an 81 k-cycle LSQR iteration per product).  extra() still serves columns with several singleton rows.
+// cex / cex_stride (may be null): a per-column scalar of the caller (the adjoint's c_j, strided in the boundary layout), requested WITH the row's matrix loads and
+// handed to out(j, value, cex_j) -- a load inside out() would sit behind the row group's reduction, one exposed L2 round trip per row group.
 template <int NTH, int RP, class FE, class FO>
 __device__ __forceinline__ void sa_fused_pass(const double *__restrict__ AdT, int n, const double *w, const double *xin, FE &&extra, FO &&out, double *part,
-                                              const int *__restrict__ sing_i = nullptr, const double *__restrict__ sing_v = nullptr, const double *yin = nullptr) {
+                                              const int *__restrict__ sing_i = nullptr, const double *__restrict__ sing_v = nullptr, const double *yin = nullptr,
+                                              const double *__restrict__ cex = nullptr, long cex_stride = 0) {
     constexpr int NL = RP / 16, RS = NTH / 8, UR = RP == 64 ? 2 : 4;      // rows in flight per lane (RP = 64: two, the accumulators need the registers)
     const int tid = threadIdx.x, k8 = tid & 7;
     const double2 *w2 = reinterpret_cast<const double2 *>(w) + k8;
@@ -108,7 +111,7 @@ __device__ __forceinline__ void sa_fused_pass(const double *__restrict__ AdT, in
     for (int i = 0; i < NL; i++) { vacc[i] = double2{0.0, 0.0}; wr[i] = w2[8 * i]; }
     for (int j0 = tid >> 3; j0 < n; j0 += UR * RS) {
         double2 rv[UR][NL];
-        int si[UR]; double sv[UR];
+        int si[UR]; double sv[UR], ce[UR];
 #pragma unroll
         for (int u = 0; u < UR; u++) {
             const int j = j0 + u * RS, jc = j < n ? j : n - 1;
@@ -116,6 +119,7 @@ __device__ __forceinline__ void sa_fused_pass(const double *__restrict__ AdT, in
 #pragma unroll
             for (int i = 0; i < NL; i++) rv[u][i] = row[8 * i];
             si[u] = sing_i ? sing_i[jc] : -2; sv[u] = sing_i ? sing_v[jc] : 0.0;
+            ce[u] = cex ? cex[(size_t)jc * cex_stride] : 0.0;
         }
 #pragma unroll
         for (int u = 0; u < UR; u++) {
@@ -131,7 +135,7 @@ __device__ __forceinline__ void sa_fused_pass(const double *__restrict__ AdT, in
                 vacc[i].x = fma(rv[u][i].x, xv, vacc[i].x); vacc[i].y = fma(rv[u][i].y, xv, vacc[i].y);
             }
             const double acc = group_reduce<8, false>(a0 + a1);
-            if (ok && k8 == 0) out(j, acc);
+            if (ok && k8 == 0) { if constexpr (std::is_invocable_v<FO, int, double, double>) out(j, acc, ce[u]); else out(j, acc); }
         }
     }
 #pragma unroll

@@ -77,6 +77,7 @@ struct ce_engine {
     int psd_first = 0;           // first row of the first PSD block (m when the template has none)
     int *d_sp_drow = nullptr, *d_sp_srow_col = nullptr, *d_sp_scol_ptr = nullptr, *d_sp_scol_row = nullptr, *d_sp_rowslot = nullptr, *d_sp_sing_i = nullptr; double *d_sp_sing_v = nullptr;
     double *d_sp_AdT = nullptr, *d_sp_sval = nullptr;
+    int *d_bpos = nullptr;      // [m] position of the row's b entry in the boundary's value order (-1: structurally zero): the tau column of the shared-A adjoint
     bool wl = false; int wl_nq = 0; int *d_row_perm = nullptr, *d_k_rowcone = nullptr, *d_k_qoff = nullptr;   // rows packed so that cones are wave-local (k_fwd2 WL)
     // longest-first dispatch (ce_set_dispatch_history): workgroup -> instance order for the next solve of the same batch size, from this solve's iteration counts
     bool dispatch_history = false; int *d_order = nullptr; int order_B = 0, order_cap = 0;
@@ -347,6 +348,10 @@ int ce_create(const ce_template *tpl, int device, ce_handle *out) {
         HIPCHK(hipMemcpy(h->d_csr_ptr, rptr.data(), sizeof(int) * (tpl->m + 1), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(h->d_csr_col, rcol.data(), sizeof(int) * rcol.size(), hipMemcpyHostToDevice));
         HIPCHK(hipMemcpy(h->d_csr_src, rsrc.data(), sizeof(int) * rsrc.size(), hipMemcpyHostToDevice));
+        std::vector<int> bpos(tpl->m, -1);
+        for (int k = tpl->indptr[tpl->n]; k < tpl->indptr[tpl->n + 1]; k++) bpos[tpl->indices[k]] = k;
+        HIPCHK(hipMalloc(&h->d_bpos, sizeof(int) * tpl->m));
+        HIPCHK(hipMemcpy(h->d_bpos, bpos.data(), sizeof(int) * tpl->m, hipMemcpyHostToDevice));
         // split: rows with one entry / rows with several
         std::vector<int> drow, rowslot(tpl->m, -1), srow_col(tpl->m, -1);
         for (int i = 0; i < tpl->m; i++) {
@@ -534,7 +539,7 @@ int ce_destroy(ce_handle h) {
     hipSetDevice(h->device);
     hipFree(h->d_rowidx); hipFree(h->d_colidx); hipFree(h->d_rowcone); hipFree(h->d_qoff); hipFree(h->d_soff); hipFree(h->d_sord); hipFree(h->d_pw); hipFree(h->d_idx_p); hipFree(h->d_pmap); hipFree(h->d_prow); hipFree(h->d_pcol);
     hipFree(h->wsA); hipFree(h->wsdA); hipFree(h->gws); hipFree(h->d_idx_at); hipFree(h->d_idx_ar); hipFree(h->d_idx_b); hipFree(h->d_order); hipFree(h->d_iters2); hipFree(h->d_nkmax); if (h->h_nkmax) hipHostFree(h->h_nkmax); if (h->nk_ev) hipEventDestroy(h->nk_ev); hipFree(h->d_row_perm); hipFree(h->d_idx_at3); hipFree(h->d_idx_ar3); hipFree(h->d_slot_soc); hipFree(h->d_k_rowcone); hipFree(h->d_k_qoff); hipFree(h->d_csc_ptr); hipFree(h->d_csr_ptr); hipFree(h->d_csr_col); hipFree(h->d_csr_src);
-    hipFree(h->d_sp_drow); hipFree(h->d_sp_srow_col); hipFree(h->d_sp_scol_ptr); hipFree(h->d_sp_scol_row); hipFree(h->d_sp_rowslot); hipFree(h->d_sp_sing_i); hipFree(h->d_sp_sing_v); hipFree(h->d_sp_AdT); hipFree(h->d_sp_sval); hipFree(h->d_aa_ws); hipFree(h->d_summary);
+    hipFree(h->d_sp_drow); hipFree(h->d_sp_srow_col); hipFree(h->d_sp_scol_ptr); hipFree(h->d_sp_scol_row); hipFree(h->d_sp_rowslot); hipFree(h->d_sp_sing_i); hipFree(h->d_sp_sing_v); hipFree(h->d_sp_AdT); hipFree(h->d_sp_sval); hipFree(h->d_bpos); hipFree(h->d_aa_ws); hipFree(h->d_summary);
     for (auto &v : h->ev) for (auto &p : v) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
     for (auto &e : h->ev_pool) hipEventDestroy(e);
     if (h->d_psd_stats) {
@@ -935,7 +940,8 @@ int ce_solve_shared_a(ce_handle h, int B, int r, int RP, const double *AdT, cons
     HIPCHK(hipGetLastError());
     return CE_OK;
 }
-int ce_vjp_shared_a(ce_handle h, int B, const double *A_vals0, const double *x, const double *y, const double *s, const double *dx, const double *dy,
+int ce_vjp_shared_a(ce_handle h, int B, const double *A_vals0, long sA_b, const double *q_vals, long sq_k, long sq_b,
+                    const double *x, const double *y, const double *s, const double *dx, const double *dy,
                     double *dA_bm, double *dq_vals, long sdq_k, long sdq_b, int *adj_status, int *lsqr_iters, double atol, double btol, int iter_lim, void *stream) {
     if (!h || B <= 0 || !A_vals0 || !x || !y || !s || !dx || !dy || !dA_bm || !dq_vals) { g_err = "null argument"; return CE_E_BADARG; }
     const DevT &T = h->T;
@@ -952,7 +958,7 @@ int ce_vjp_shared_a(ce_handle h, int B, const double *A_vals0, const double *x, 
 #undef SA_ATTR
         h->sa_lsqr_attr = true;
     }
-    SaStruct S{h->d_csc_ptr, h->d_rowidx, h->d_csr_ptr, h->d_csr_col, h->d_csr_src, T.nnzA};
+    SaStruct S{h->d_csc_ptr, h->d_rowidx, h->d_csr_ptr, h->d_csr_col, h->d_csr_src, T.nnzA, h->d_bpos};
     SaSplit F{h->sp_r, RP, h->d_sp_AdT, h->d_sp_drow, h->d_sp_srow_col, h->d_sp_sval, h->d_sp_scol_ptr, h->d_sp_scol_row, h->d_sp_rowslot, h->d_sp_sing_i, h->d_sp_sing_v};
     if (RP > 0) {      // the values may differ between calls: refill A_d^T / singleton values from this call's A (n RP + m doubles)
         HIPCHK(hipMemsetAsync(h->d_sp_AdT, 0, sizeof(double) * (size_t)T.n * RP, (hipStream_t)stream));
@@ -962,7 +968,7 @@ int ce_vjp_shared_a(ce_handle h, int B, const double *A_vals0, const double *x, 
     }
     {
         ProfScope ps(h, 1, (hipStream_t)stream);
-#define LAUNCH_SAL(RPV) hipLaunchKernelGGL(k_sa_lsqr<RPV>, dim3(B), dim3(NT), lds, (hipStream_t)stream, T, S, F, A_vals0, x, y, s, dx, dy, dA_bm, dq_vals, sdq_k, sdq_b, adj_status, lsqr_iters, atol, btol, iter_lim > 0 ? iter_lim : 2 * (T.n + T.m + 1))
+#define LAUNCH_SAL(RPV) hipLaunchKernelGGL(k_sa_lsqr<RPV>, dim3(B), dim3(NT), lds, (hipStream_t)stream, T, S, F, A_vals0, sA_b, q_vals, sq_k, sq_b, x, y, s, dx, dy, dA_bm, dq_vals, sdq_k, sdq_b, adj_status, lsqr_iters, atol, btol, iter_lim > 0 ? iter_lim : 2 * (T.n + T.m + 1))
         if (RP == 0) LAUNCH_SAL(0); else if (RP == 16) LAUNCH_SAL(16); else if (RP == 32) LAUNCH_SAL(32); else LAUNCH_SAL(64);
 #undef LAUNCH_SAL
     }

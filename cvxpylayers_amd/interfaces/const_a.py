@@ -426,10 +426,12 @@ def _psd_eig(v, psd):
     return out
 
 
-def vjp_const_a(eng, A_bm, x, y, s, dx, dy, batch_minor_out=False, atol=1e-8, btol=1e-8, iter_lim=0):
+def vjp_const_a(eng, A_bm, x, y, s, dx, dy, batch_minor_out=False, atol=1e-8, btol=1e-8, iter_lim=0, q_eval=None):
     """Returns dA (nnz_aug, B), dq (n+1, B), adj_status (B,) in the boundary convention (diffcp_if.py:91-92).
     atol / btol / iter_lim: LSQR's stopping rule; the defaults are diffcp's (1e-8, 1e-8, 2 N with N = n + m + 1: what diffcp_if.py:86 runs and
-    oracle/cone_oracle.c:85,712 restates); the plugin forwards solver_args["lsqr_atol" / "lsqr_btol" / "lsqr_iter_lim"] (mi355_if.lsqr_rule)."""
+    oracle/cone_oracle.c:85,712 restates); the plugin forwards solver_args["lsqr_atol" / "lsqr_btol" / "lsqr_iter_lim"] (mi355_if.lsqr_rule).
+    q_eval (n+1, B): the forward call's objective values.  With them the one-kernel LSQR solves diffcp's FULL (n + m + 1) system (tau row and column: b and c
+    enter); without them r_tau is pinned to 0 -- the same gradients wherever the system is regular, a different minimum-norm element on degenerate faces."""
     if iter_lim <= 0:
         iter_lim = 2 * (eng.n + eng.m + 1)
     dev = A_bm.device
@@ -449,7 +451,13 @@ def vjp_const_a(eng, A_bm, x, y, s, dx, dy, batch_minor_out=False, atol=1e-8, bt
         dA_bm = torch.empty((B, eng.nnz_aug), **f64_); dq = torch.empty((n + 1, B), **f64_)
         adj = torch.empty((B,), dtype=torch.int32, device=dev); its = torch.empty((B,), dtype=torch.int32, device=dev)
         xc, yc, sc_, dxc, dyc = (t.to(torch.float64).contiguous() for t in (x, y, s, dx, dy))
-        rc = _lib.lib().ce_vjp_shared_a(eng._h, B, A_bm.data_ptr(), xc.data_ptr(), yc.data_ptr(), sc_.data_ptr(), dxc.data_ptr(), dyc.data_ptr(),
+        if q_eval is not None:
+            qd = q_eval.detach().to(device=dev, dtype=torch.float64)
+            q_args = (qd.data_ptr(), qd.stride(0), qd.stride(1))
+        else:
+            q_args = (None, 0, 0)
+        assert A_bm.stride(1) == 1
+        rc = _lib.lib().ce_vjp_shared_a(eng._h, B, A_bm.data_ptr(), A_bm.stride(0), *q_args, xc.data_ptr(), yc.data_ptr(), sc_.data_ptr(), dxc.data_ptr(), dyc.data_ptr(),
                                         dA_bm.data_ptr(), dq.data_ptr(), B, 1, adj.data_ptr(), its.data_ptr(), atol, btol, int(iter_lim),
                                         C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
         if rc == 0:

@@ -202,6 +202,7 @@ class ConeEngine:
                                  f"{tuple(warm[0].shape)}, {tuple(warm[1].shape)}, {tuple(warm[2].shape)}")
         if P_bm is not None and not self.qp_native:
             raise RuntimeError("quadratic objective on an engine without native P support (use the epigraph form)")
+        self._last_q = q_eval          # (direct engine users: vjp() without q_eval differentiates the most recent solve)
         if P_bm is None and self._use_const_a(A_bm):
             from cvxpylayers_amd.interfaces.const_a import solve_const_a
             self.last_path = "const_a"
@@ -299,14 +300,15 @@ class ConeEngine:
             return False
         return is_constant_A(A_bm, self.nnzA)
 
-    def vjp(self, A_bm, x, y, s, dx, dy, batch_minor_out: bool = False, P_bm=None, path: str | None = None, lsqr: tuple | None = None):
+    def vjp(self, A_bm, x, y, s, dx, dy, batch_minor_out: bool = False, P_bm=None, path: str | None = None, lsqr: tuple | None = None, q_eval=None):
         """Returns dA (nnz_aug, B), dq (n+1, B), adj_status (B,).  dA is a transposed view of a batch-major buffer (the
         engine-native layout, no extra pass) unless batch_minor_out: then it is (nnz_aug, B) contiguous -- the layout of a
         reference-style A_eval, so that autograd can accumulate it into the leaf without a strided copy (one engine layout pass).
         path: the path ("per_instance" / "const_a") of the forward call being differentiated, as recorded by the caller right
         after solve() -- the autograd node keeps it, so interleaved forward calls of one layer cannot redirect a pending backward.
         None (direct engine users with one solve in flight): the path of the most recent solve().
-        lsqr: (atol, btol, iter_lim) of the shared-A LSQR adjoint (lsqr_rule); None = diffcp's 1e-8 / 1e-8 / 2 (n + m + 1).  Ignored by the direct eliminations."""
+        lsqr: (atol, btol, iter_lim) of the shared-A LSQR adjoint (lsqr_rule); None = diffcp's 1e-8 / 1e-8 / 2 (n + m + 1).  Ignored by the direct eliminations.
+        q_eval: the forward call's (n+1, B) objective values; the shared-A LSQR adjoint then solves diffcp's full (n + m + 1) system (const_a.vjp_const_a)."""
         B = A_bm.shape[0]
         dev = self.device
         if B == 0:
@@ -316,8 +318,11 @@ class ConeEngine:
             path = getattr(self, "last_path", None)
         if path == "const_a" and (self.launch_info()["bwd_mode"] in (1, 2) or __import__("os").environ.get("CE_CONST_A") == "1"):
             from cvxpylayers_amd.interfaces.const_a import vjp_const_a      # shared A: batched LSQR with GEMMs over the batch
+            if q_eval is None:          # direct engine users with one solve in flight: the objective of the most recent solve() of this batch size
+                lq = getattr(self, "_last_q", None)
+                q_eval = lq if (lq is not None and lq.dim() == 2 and lq.shape[1] == B) else None
             atol, btol, lim = lsqr if lsqr is not None else lsqr_rule({}, self.n, self.m)
-            return vjp_const_a(self, A_bm, x, y, s, dx, dy, batch_minor_out=batch_minor_out, atol=atol, btol=btol, iter_lim=lim)
+            return vjp_const_a(self, A_bm, x, y, s, dx, dy, batch_minor_out=batch_minor_out, atol=atol, btol=btol, iter_lim=lim, q_eval=q_eval)
         dq = torch.empty((self.n + 1, B), dtype=torch.float64, device=dev)
         adj = torch.empty((B,), dtype=torch.int32, device=dev)
         if batch_minor_out:
@@ -608,7 +613,7 @@ class _ConeLayer(torch.autograd.Function):
             dual = y.to(in_device)
             info = dict(iters=iters, status=status, resid=resid, acceleration=getattr(eng, "last_acceleration", False))
             lsqr = lsqr_rule(merged_args, eng.n, eng.m)
-            saved = (eng, A_bm, x.detach(), y.detach(), s, batch_minor_in, P_bm, path, None, lsqr) if needs_grad else None
+            saved = (eng, A_bm, x.detach(), y.detach(), s, batch_minor_in, P_bm, path, None, lsqr, q_dev if path == "const_a" else None) if needs_grad else None
             if status.numel():
                 summ = eng.read_summaries()
                 min_status, n_inaccurate = int(summ[0][0]), int(summ[0][1])
@@ -633,7 +638,7 @@ class _ConeLayer(torch.autograd.Function):
             y = torch.where(failed[:, None], torch.full_like(y, float("nan")), y)
             primal = x.to(in_device)
             dual = y.to(in_device)
-            saved = (eng, A_bm, x.detach(), y.detach(), s, batch_minor_in, P_bm, path, failed, lsqr) if needs_grad else None
+            saved = (eng, A_bm, x.detach(), y.detach(), s, batch_minor_in, P_bm, path, failed, lsqr, q_dev if path == "const_a" else None) if needs_grad else None
         # x / y are handed back as `primal` / `dual` (same objects when the input lives on the engine's device), and autograd
         # attaches this node to them: keeping the SAME objects on the node would form a reference cycle (node -> saved ->
         # primal -> grad_fn -> node) that only the cyclic GC breaks, i.e. 167 MB buffers pile up for many steps and the
@@ -653,7 +658,7 @@ class _ConeLayer(torch.autograd.Function):
         saved, batch_size, originally_unbatched, in_device = ctx.backward_data
         if saved is None:
             raise RuntimeError("backward called on a layer evaluated with needs_grad=False")
-        eng, A_bm, x, y, s, batch_minor_in, P_bm, path, failed, lsqr = saved
+        eng, A_bm, x, y, s, batch_minor_in, P_bm, path, failed, lsqr, q_saved = saved
         dP = None
         if dprimal is None and ddual is None:         # nothing flows back through this node
             return None, None, None, None, None, None, None
@@ -668,7 +673,7 @@ class _ConeLayer(torch.autograd.Function):
                 dA, dq, adj, dP_bm = eng.vjp(A_bm, x, y, s, dx, dy, batch_minor_out=batch_minor_in, P_bm=P_bm, path=path, lsqr=lsqr)
                 dP = dP_bm.t().to(in_device)
             else:
-                dA, dq, adj = eng.vjp(A_bm, x, y, s, dx, dy, batch_minor_out=batch_minor_in, path=path, lsqr=lsqr)
+                dA, dq, adj = eng.vjp(A_bm, x, y, s, dx, dy, batch_minor_out=batch_minor_in, path=path, lsqr=lsqr, q_eval=q_saved)
         if failed is not None:
             dA = torch.where(failed[None, :], torch.zeros_like(dA), dA); dq = torch.where(failed[None, :], torch.zeros_like(dq), dq)
             if P_bm is not None:

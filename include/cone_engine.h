@@ -91,8 +91,8 @@ void ce_default_settings(ce_settings *s);
  * library short structs.  Bindings must check  ce_abi_version() == CE_ABI_VERSION  and  ce_struct_size(which) == sizeof(their
  * struct)  (which: 0 ce_template, 1 ce_settings) once at load time and refuse to continue otherwise (cvxpylayers_amd/_lib.py
  * does; tests/test_cabi.py checks the stub printed in INTEGRATION.md the same way).  CE_ABI_VERSION is bumped whenever a struct
- * layout, an entry point's signature or the meaning of an argument changes (8: ce_set_dispatch_history added, ce_status_summary writes a fourth "ready" int; 7: ce_status_summary added; 6: ce_default_settings = SCS defaults incl. acceleration_lookback 10, ce_acceleration_available). */
-#define CE_ABI_VERSION 8
+ * layout, an entry point's signature or the meaning of an argument changes (9: ce_vjp_shared_a takes sA_b and q_vals -- the adjoint system gains diffcp's tau row and column --, its iter_lim default is diffcp's 2 (n + m + 1); 8: ce_set_dispatch_history added, ce_status_summary writes a fourth "ready" int; 7: ce_status_summary added; 6: ce_default_settings = SCS defaults incl. acceleration_lookback 10, ce_acceleration_available). */
+#define CE_ABI_VERSION 9
 int ce_abi_version(void);
 int ce_struct_size(int which);
 /* 1 when ce_solve / ce_solve_qp on this engine honour ce_settings.acceleration_lookback > 0 (second-generation forward kernel with
@@ -244,13 +244,18 @@ int ce_solve_shared_a(ce_handle h, int B, int r, int RP, const double *AdT, cons
  * Shared-A adjoint  <- _compute_gradients -> adj_batch (diffcp_if.py:73-96, 385-403) for templates whose A does not depend on the
  * parameters: diffcp's adjoint system (r_tau = 0) solved by LSQR -- diffcp's own default mode -- entirely inside one kernel, one
  * workgroup per instance, A applied from its sparse structure, the PSD cone's derivative on the matrix cores.  A_vals0: the nnz_aug
- * boundary values of ONE instance (the A part is shared); x, y, s, dx, dy as ce_vjp; dA_bm (B, nnz_aug) batch-major; dq at
+ * boundary values of instance 0 (the A part is shared); instance i's b entries are read at A_vals0 + i * sA_b (sA_b = nnz_aug for a batch-major
+ * value matrix, 0 when b is shared too); q_vals: c of instance i at [j * sq_k + i * sq_b] (as ce_solve).  With q_vals the system is diffcp's
+ * FULL (n + m + 1) adjoint system, tau row and column included -- on rank-deficient systems LSQR's minimum-norm solution is then diffcp's;
+ * q_vals == NULL pins r_tau = 0 (the n + m system of ABI <= 8: the same gradients wherever the system is regular).
+ * x, y, s, dx, dy as ce_vjp; dA_bm (B, nnz_aug) batch-major; dq at
  * [k * sdq_k + i * sdq_b]; adj_status[i] = 1 when LSQR hit iter_lim (0: diffcp's 2 (n + m + 1)); lsqr_iters (B) or NULL; atol / btol: LSQR stopping
  * tolerances (diffcp runs 1e-8 / 1e-8: the plugin's default, solver_args lsqr_atol / lsqr_btol / lsqr_iter_lim override).  The engine refills its own scratch (split of this call's A values) on `stream`: one engine, one stream at a time.  All cone types (zero / nonnegative / second-order / PSD / exponential / power: the triples' derivative is a symmetrised
  * 3 x 3 block computed once per call); CE_E_TOO_LARGE when the LSQR vectors of one instance exceed LDS (callers fall back to the batched
  * path of const_a.py).
  */
-int ce_vjp_shared_a(ce_handle h, int B, const double *A_vals0, const double *x, const double *y, const double *s, const double *dx, const double *dy,
+int ce_vjp_shared_a(ce_handle h, int B, const double *A_vals0, long sA_b, const double *q_vals, long sq_k, long sq_b,
+                    const double *x, const double *y, const double *s, const double *dx, const double *dy,
                     double *dA_bm, double *dq_vals, long sdq_k, long sdq_b, int *adj_status, int *lsqr_iters, double atol, double btol, int iter_lim, void *stream);
 
 /* Longest-first dispatch.  Workgroups are dispatched in index order and one workgroup owns one instance, so the tail of a forward launch is set by the

@@ -32,6 +32,8 @@ VARIANTS = {
     "k1024":      dict(CE_SA_FWD="1", CE_SA_KERNEL="1", CE_SA_NT="1024"),
     "kcsr":       dict(CE_SA_FWD="1", CE_SA_KERNEL="1", CE_SA_SPLIT="0"),
     "default":    dict(),
+    # the adjoint's LSQR stopping rule: rounds 1-4 (atol = btol = 1e-12, 4 (n + m) iterations) against diffcp's (1e-8, 1e-8, 2 (n + m + 1): the default since round 5)
+    "tight":      dict(_args=dict(lsqr_atol=1e-12, lsqr_btol=1e-12, lsqr_iter_lim=4 * (tpl.n + tpl.m))),
 }
 KEYS = ("CE_SA_FWD", "CE_SA_KERNEL", "CE_SA_NT", "CE_SA_SPLIT")
 ref = None
@@ -39,8 +41,8 @@ res = []
 wts = torch.from_numpy(np.random.default_rng(5).standard_normal((tpl.n, B))).to(dev) if True else None
 for name in (want or ["torch", "k512", "k256", "default"]):
     for k in KEYS: os.environ.pop(k, None)
-    os.environ.update(VARIANTS[name])
-    ctx = MI355_ctx(None, tpl.problem_data_index, cones, options={"eps": 1e-4, "max_iters": 20000, "raise_on_error": False})
+    os.environ.update({k: v for k, v in VARIANTS[name].items() if k != "_args"})
+    ctx = MI355_ctx(None, tpl.problem_data_index, cones, options={"eps": 1e-4, "max_iters": 20000, "raise_on_error": False, **VARIANTS[name].get("_args", {})})
     A_t = A_dev.detach().requires_grad_(); q_t = torch.from_numpy(q_eval).to(dev).requires_grad_()
     tf = tb = 0.0; reps = 2
     for rep in range(reps + 1):
@@ -53,7 +55,8 @@ for name in (want or ["torch", "k512", "k256", "default"]):
         if rep: tf += (t1 - t0) / reps; tb += (t2 - t1) / reps
     eng = ctx.engine(dev)
     out = dict(variant=name, cfg=cfg, B=B, fwd_ms=tf * 1e3, bwd_ms=tb * 1e3, iters_mean=float(info["iters"].float().mean()), solved=float((info["status"] == 1).float().mean()),
-               fwd_kernel=getattr(eng, "last_const_a_kernel", None), lsqr_iters=(float(eng.last_lsqr_iters.float().mean()) if getattr(eng, "last_lsqr_iters", None) is not None else None))
+               fwd_kernel=getattr(eng, "last_const_a_kernel", None), lsqr_iters=(float(eng.last_lsqr_iters.float().mean()) if getattr(eng, "last_lsqr_iters", None) is not None else None),
+               lsqr_iters_max=(int(eng.last_lsqr_iters.max()) if getattr(eng, "last_lsqr_iters", None) is not None else None))
     x = p.detach(); g = q_t.grad.detach(); gA = A_t.grad.detach()
     out["gq_max"] = float(g.abs().max()); out["gA_max"] = float(gA.abs().max())
     if ref is None: ref = (x.clone(), g.clone(), gA.clone())

@@ -202,7 +202,8 @@ def test_C2_lp_form_at_B4096_statuses_are_the_oracles():
     assert set(np.unique(st)) <= {1, 2} and (st == 2).sum() == (ref["status"] == 2).sum() >= 1          # the unsolved ones exist on both sides, and are the same
     d = np.abs(it - ref["iters"])
     assert (d <= 25).mean() >= 0.99 and abs(it.mean() - ref["iters"].mean()) < 0.01 * ref["iters"].mean(), (np.bincount(np.minimum(d // 25, 8)), it.mean(), ref["iters"].mean())
-    ok = st == 1
+    ok = (st == 1) & (it == ref["iters"])          # (instances that stopped at the same check: eps-accurate points of an LP a check apart can differ by more than 20 eps)
+    assert ok.mean() > 0.98
     for got, want in ((x, ref["x"]), (y, ref["y"]), (s, ref["s"])):
         assert _rel_rows(got.cpu().numpy()[ok], want[ok]).max() < 20 * 1e-4
     # the plugin's default (one-pair Anderson acceleration) against the oracle with the same memory
@@ -308,15 +309,15 @@ def test_C5_portfolio_n501_at_B16384():
     # adjoint of dx = 1 over the WHOLE batch at the engine's own solutions: finite and flag-free everywhere ...
     dA, dq, adj = eng.vjp(A_bm, x, y, s, torch.ones_like(x), torch.zeros_like(y), path="const_a", lsqr=TIGHT_LSQR)
     assert int((adj[ok] != 0).sum()) == 0 and bool(torch.isfinite(dq[:, ok]).all())
-    # ... and, on the subset, at the ORACLE's solutions (so that only the adjoint solves are compared).  Instances at a vertex of the feasible
-    # set (as many active rows as variables: the solution is locally constant) are compared with the oracle's dense elimination to 1e-5.  The
-    # others sit on a degenerate face: the reduced system is singular, a minimum-norm least-squares solve (LSQR: diffcp's default and this
-    # path) and an elimination with pivoting return different elements -- THOSE are compared with the oracle's LSQR mode (diffcp's semantics)
-    # at LSQR's own accuracy instead of being dropped.
+    # ... and, on the subset, at the ORACLE's solutions (so that only the adjoint solves are compared), against the oracle's LSQR mode -- diffcp's default and
+    # its semantics -- at matched tolerances.  Since round 5 the kernel runs LSQR on diffcp's FULL (n + m + 1) system (tau row and column): the two are then
+    # the minimum-norm solutions of the SAME system and agree to LSQR's accuracy on every instance, the ones on a degenerate face included (as many active
+    # rows as variables minus one: the system is singular there, and the r_tau = 0 reduction of rounds 1-4 returned a different element: 1e-3 .. 5e-3 apart).
+    # The oracle's DENSE elimination pins free variables to zero instead: it agrees at vertices only, and only as far as the eps-accurate point makes M singular
+    # along z (2e-5 .. 8e-5 at eps 1e-6), so it is compared loosely and on the regular instances only.
     xo, yo, so = (torch.from_numpy(ref[k]).cuda() for k in ("x", "y", "s"))
-    dA2, dq2, adj2 = eng.vjp(A_bm[idx], xo, yo, so, torch.ones_like(xo), torch.zeros_like(yo), path="const_a", lsqr=TIGHT_LSQR)
+    dA2, dq2, adj2 = eng.vjp(A_bm[idx], xo, yo, so, torch.ones_like(xo), torch.zeros_like(yo), path="const_a", lsqr=TIGHT_LSQR, q_eval=q_t[:, idx].contiguous())
     assert int((adj2 != 0).sum()) == 0
-    g = oracle.adjoint_batch(Ab, bb, c[idx], cones, ref["x"], ref["y"], ref["s"], np.ones_like(ref["x"]), np.zeros_like(ref["y"]), mode="dense")
     dc_gpu = dq2.cpu().numpy()[:tpl.n].T
     db_gpu = _db_from_dA(tpl, dA2.cpu().numpy(), 48)
     brows = tpl.b_idx
@@ -324,14 +325,20 @@ def test_C5_portfolio_n501_at_B16384():
     def err_against(gg):
         return np.maximum(np.abs(dc_gpu - gg["dc"]).max(axis=1) / (1 + np.abs(gg["dc"]).max(axis=1)),
                           np.abs(db_gpu[:, brows] - gg["db"][:, brows]).max(axis=1) / (1 + np.abs(gg["db"]).max(axis=1)))
-    err = err_against(g)
+    ones, zeros = np.ones_like(ref["x"]), np.zeros_like(ref["y"])
+    gl = oracle.adjoint_batch(Ab, bb, c[idx], cones, ref["x"], ref["y"], ref["s"], ones, zeros, mode="lsqr", lsqr_atol=TIGHT_LSQR[0], lsqr_btol=TIGHT_LSQR[1], lsqr_iter_lim=TIGHT_LSQR[2])
     v = ref["y"] - ref["s"]
     n_act = (v[:, 1:501] > 0).sum(axis=1) + 1 + 51                  # active bounds + budget row + the SOC rows (dual in the interior)
     regular = n_act >= tpl.n
-    assert err[regular].max() < 1e-5, (regular.mean(), err[regular].max())
-    if (~regular).any():
-        gl = oracle.adjoint_batch(Ab[~regular], bb[~regular], c[idx][~regular], cones, ref["x"][~regular], ref["y"][~regular], ref["s"][~regular],
-                                  np.ones_like(ref["x"][~regular]), np.zeros_like(ref["y"][~regular]), mode="lsqr", lsqr_atol=1e-12, lsqr_btol=1e-12, lsqr_iter_lim=20000)
-        el = np.maximum(np.abs(dc_gpu[~regular] - gl["dc"]).max(axis=1) / (1 + np.abs(gl["dc"]).max(axis=1)),
-                        np.abs(db_gpu[~regular][:, brows] - gl["db"][:, brows]).max(axis=1) / (1 + np.abs(gl["db"]).max(axis=1)))
-        assert el.max() < 5e-3, (el, err[~regular])
+    el = err_against(gl)
+    assert el.max() < 1e-5, (el, regular)                             # every instance, degenerate faces included (VERDICT round 4 item 1c asked for <= 5e-4)
+    gd = oracle.adjoint_batch(Ab, bb, c[idx], cones, ref["x"], ref["y"], ref["s"], ones, zeros, mode="dense")
+    assert err_against(gd)[regular].max() < 5e-4, (regular.mean(), err_against(gd)[regular].max())
+    # diffcp's own stopping rule (the plugin's default: atol = btol = 1e-8, 2 (n + m + 1) iterations) on both sides: the same element to LSQR's accuracy at that rule
+    dA3, dq3, adj3 = eng.vjp(A_bm[idx], xo, yo, so, torch.ones_like(xo), torch.zeros_like(yo), path="const_a", q_eval=q_t[:, idx].contiguous())
+    gdef = oracle.adjoint_batch(Ab, bb, c[idx], cones, ref["x"], ref["y"], ref["s"], ones, zeros, mode="lsqr")
+    assert int((adj3 != 0).sum()) == 0
+    e3 = np.abs(dq3.cpu().numpy()[:tpl.n].T - gdef["dc"]).max(axis=1) / (1 + np.abs(gdef["dc"]).max(axis=1))
+    assert e3.max() < 1e-4, e3
+    li = eng.last_lsqr_iters.cpu().numpy().astype(int)
+    assert np.abs(li - gdef["lsqr_iters"]).max() <= 3, (li, gdef["lsqr_iters"])          # the same recurrences: the same number of iterations (rounding may move the test by one)
