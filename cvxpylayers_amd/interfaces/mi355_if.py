@@ -38,19 +38,25 @@ STATUS_NAMES = {1: "Solved", 2: "Solved/Inaccurate", -1: "Unbounded", -2: "Infea
 _KNOWN_ARGS = {"eps", "eps_abs", "eps_rel", "eps_infeas", "max_iters", "alpha", "rho_x", "scale", "normalize",
                "adaptive_scale", "acceleration_lookback", "acceleration_interval", "verbose", "mode", "solve_method",
                "n_jobs_forward", "n_jobs_backward", "warm_starts", "raise_on_error", "dispatch_history",
-               "lsqr_atol", "lsqr_btol", "lsqr_iter_lim"}
+               "lsqr_atol", "lsqr_btol", "lsqr_iter_lim", "adjoint_system"}
 
 # Stopping rule of the LSQR adjoint (shared-A templates).  diffcp's adjoint (diffcp_if.py:86 -> adj_batch, mode="lsqr") runs LSQR with atol = btol = 1e-8 and an
 # iteration limit of 2 N on its N = n + m + 1 operator; the oracle restates exactly that (oracle/cone_oracle.c:85,712).  solver_args may override:
 # lsqr_atol / lsqr_btol / lsqr_iter_lim (callers that need gradients to 1e-5 against a direct elimination pass tight values explicitly).
+# adjoint_system: "full" (default) = diffcp's (n + m + 1) system M^T r = dz, tau row and column included -- LSQR then returns diffcp's minimum-norm element on
+# rank-deficient systems and takes diffcp's number of iterations;  "reduced" = r_tau pinned to 0 (the system of rounds 1-4: the same gradients wherever the
+# system is regular and the point accurate, a quarter of the LSQR iterations at loose eps, where the full system is nearly singular AND inconsistent).
 LSQR_ATOL, LSQR_BTOL = 1e-8, 1e-8
 
 
 def lsqr_rule(merged_args: dict, n: int, m: int) -> tuple:
-    """(atol, btol, iter_lim) of the shared-A adjoint from merged solver_args; defaults = diffcp's"""
+    """(atol, btol, iter_lim, system) of the shared-A adjoint from merged solver_args; defaults = diffcp's"""
     lim = merged_args.get("lsqr_iter_lim")
+    system = str(merged_args.get("adjoint_system", "full"))
+    if system not in ("full", "reduced"):
+        raise ValueError(f"MI355 solver: adjoint_system must be 'full' or 'reduced', got {system!r}")
     return (float(merged_args.get("lsqr_atol", LSQR_ATOL)), float(merged_args.get("lsqr_btol", LSQR_BTOL)),
-            int(lim) if lim not in (None, 0) else 2 * (n + m + 1))
+            int(lim) if lim not in (None, 0) else 2 * (n + m + 1), system)
 
 
 _WARNED: set = set()
@@ -307,7 +313,7 @@ class ConeEngine:
         path: the path ("per_instance" / "const_a") of the forward call being differentiated, as recorded by the caller right
         after solve() -- the autograd node keeps it, so interleaved forward calls of one layer cannot redirect a pending backward.
         None (direct engine users with one solve in flight): the path of the most recent solve().
-        lsqr: (atol, btol, iter_lim) of the shared-A LSQR adjoint (lsqr_rule); None = diffcp's 1e-8 / 1e-8 / 2 (n + m + 1).  Ignored by the direct eliminations.
+        lsqr: (atol, btol, iter_lim[, system]) of the shared-A LSQR adjoint (lsqr_rule); None = diffcp's 1e-8 / 1e-8 / 2 (n + m + 1) on the full system.  Ignored by the direct eliminations.
         q_eval: the forward call's (n+1, B) objective values; the shared-A LSQR adjoint then solves diffcp's full (n + m + 1) system (const_a.vjp_const_a)."""
         B = A_bm.shape[0]
         dev = self.device
@@ -321,7 +327,9 @@ class ConeEngine:
             if q_eval is None:          # direct engine users with one solve in flight: the objective of the most recent solve() of this batch size
                 lq = getattr(self, "_last_q", None)
                 q_eval = lq if (lq is not None and lq.dim() == 2 and lq.shape[1] == B) else None
-            atol, btol, lim = lsqr if lsqr is not None else lsqr_rule({}, self.n, self.m)
+            atol, btol, lim, system = (tuple(lsqr) + ("full",))[:4] if lsqr is not None else lsqr_rule({}, self.n, self.m)
+            if system == "reduced":
+                q_eval = None
             return vjp_const_a(self, A_bm, x, y, s, dx, dy, batch_minor_out=batch_minor_out, atol=atol, btol=btol, iter_lim=lim, q_eval=q_eval)
         dq = torch.empty((self.n + 1, B), dtype=torch.float64, device=dev)
         adj = torch.empty((B,), dtype=torch.int32, device=dev)

@@ -31,8 +31,8 @@ def sdp(B, k=20, neq=20, seed=0):
     return A, b, -(y0 @ A), cones
 
 
-def run(name, tpl, cones, A_eval, q_eval, eps, reps, note, P_eval=None, p_structure=None, min_seconds=1.0):
-    ctx = MI355_ctx(p_structure, tpl.problem_data_index, cones, options={"eps": eps, "max_iters": 20000, "raise_on_error": False, **({"acceleration_lookback": int(os.environ["CONFIGS_ACCEL"])} if "CONFIGS_ACCEL" in os.environ else {})})
+def run(name, tpl, cones, A_eval, q_eval, eps, reps, note, P_eval=None, p_structure=None, min_seconds=1.0, extra_opts=None):
+    ctx = MI355_ctx(p_structure, tpl.problem_data_index, cones, options={"eps": eps, "max_iters": 20000, "raise_on_error": False, **({"acceleration_lookback": int(os.environ["CONFIGS_ACCEL"])} if "CONFIGS_ACCEL" in os.environ else {}), **(extra_opts or {})})
     A_t = torch.from_numpy(A_eval).to(dev).t().contiguous().t().requires_grad_()      # (nnz_aug, B) view of batch-major storage
     q_t = torch.from_numpy(q_eval).to(dev).requires_grad_()
     P_t = torch.from_numpy(P_eval).to(dev).requires_grad_() if P_eval is not None else None
@@ -57,6 +57,7 @@ def run(name, tpl, cones, A_eval, q_eval, eps, reps, note, P_eval=None, p_struct
     out = dict(config=name, B=B, n=tpl.n, m=tpl.m, cones={k: (v if not isinstance(v, list) else (f"{len(v)}x{v[0]}" if v else "-")) for k, v in cones.items()},
                eps=eps, ms_per_step=dt * 1e3, problems_per_s=B / dt, iters_mean=float(it.mean()), iters_max=float(it.max()),
                solved=float((info["status"] == 1).float().mean()), path=ctx.engine(dev).last_path, reps=reps,
+               lsqr_iters_mean=(float(ctx.engine(dev).last_lsqr_iters.float().mean()) if getattr(ctx.engine(dev), "last_lsqr_iters", None) is not None else None),
                acceleration="plugin default (SCS acceleration_lookback 10; engine: one-pair history where the kernel implements it)", note=note)
     print(json.dumps(out), flush=True)
     return out
@@ -93,13 +94,16 @@ if "E" in WANT:
     res.append(run("E", tplE, ecfg["cones"], *tplE.values_from_dense(Ae, be, ce_), 1e-4, 10, "24 exponential cones + nonneg + SOC(4), n=40, m=88 (logistic-regression layer shape), dense random A"))
 if "C4" in WANT:
     A, b, c, cones, tpl = P.sdp_c4_batch(1024, seed=0)
-    res.append(run("C4", tpl, cones, *tpl.values_from_dense(np.broadcast_to(A, (1024,) + A.shape).copy(), b, c), 1e-4, 5, "SDP, one 20x20 PSD cone, A shared (BASELINE config 4)"))
+    vals4 = tpl.values_from_dense(np.broadcast_to(A, (1024,) + A.shape).copy(), b, c)
+    res.append(run("C4", tpl, cones, *vals4, 1e-4, 5, "SDP, one 20x20 PSD cone, A shared (BASELINE config 4); adjoint = LSQR on diffcp's full system with diffcp's stopping rule (plugin default)"))
+    res.append(run("C4r", tpl, cones, *vals4, 1e-4, 5, "the same with solver_args adjoint_system='reduced' (r_tau pinned to 0: the system of rounds 1-4)", extra_opts={"adjoint_system": "reduced"}))
 if "C5" in WANT:
     Bp = int(os.environ.get("C5_BATCH", "16384"))
     A, b, c, cones, tpl = P.portfolio_c5_batch(Bp, seed=0)
     A1, _ = tpl.values_from_dense(A[None], b[None], c[:1])          # A, b shared: tile one instance's values (the dense (B, m, n) array would be 36 GB)
-    res.append(run("C5", tpl, cones, np.repeat(A1, Bp, axis=1), np.concatenate([c.T, np.zeros((1, Bp))], axis=0), 1e-4, 2,
-                   "portfolio n=501, A shared, returns batched (BASELINE config 5), 1 GPU", min_seconds=0.0))
+    vals5 = (np.repeat(A1, Bp, axis=1), np.concatenate([c.T, np.zeros((1, Bp))], axis=0))
+    res.append(run("C5", tpl, cones, *vals5, 1e-4, 2, "portfolio n=501, A shared, returns batched (BASELINE config 5), 1 GPU; adjoint = LSQR on diffcp's full system with diffcp's stopping rule (plugin default)", min_seconds=0.0))
+    res.append(run("C5r", tpl, cones, *vals5, 1e-4, 2, "the same with solver_args adjoint_system='reduced' (r_tau pinned to 0: the system of rounds 1-4)", min_seconds=0.0, extra_opts={"adjoint_system": "reduced"}))
 out = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/configs.json"
 os.makedirs(os.path.dirname(out) or ".", exist_ok=True)
 json.dump(res, open(out, "w"), indent=1)
