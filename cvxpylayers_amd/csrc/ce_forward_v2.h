@@ -304,6 +304,11 @@ __device__ __forceinline__ void psd_project(double *zsvec, int k, double *Sm, do
 #ifndef F2_WPS
 #define F2_WPS 3
 #endif
+// F2_GJ_MFMA = 1 (default): the inversion of the reduced KKT matrix S runs as a blocked SWEEP on the matrix cores, on the accumulators the S formation left in
+// registers (see refactor()); 0: the blocked Gauss-Jordan on the (jg, cg) register tile (rounds 2-4; still what the quadratic-objective instantiations run).
+#ifndef F2_GJ_MFMA
+#define F2_GJ_MFMA 1
+#endif
 // HASP: quadratic objective 1/2 x^T P x (SCS 3's QP embedding, oracle/cone_oracle.c solve_one): P-hat = E P E joins the reduced
 // KKT matrix S = rho_x I + P-hat + A-hat^T Dy A-hat, tau-tilde becomes the positive root of a quadratic, the dual residual and
 // the gap get their P terms.  Pvals: (B, nnzP) values in the template's P structure; idx_p: gather map of the (jg, cg) tile
@@ -585,7 +590,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
         // a refactorisation, which costs as much as ~35 iterations and runs about once per instance after the initial one).  Y_j stays in the
         // (jg, cg) register tile of the inversion; a row of Y_j is spread over the CHG adjacent lanes of its row group and is broadcast from
         // there (ds_bpermute), G is read from LDS; only when x > 1e-2 (S nearly singular) the full refactorisation below runs.
-        bool fast = false;
+        bool fast = false, g_in_lds = false;      // g_in_lds: the inversion has already written G to LDS (matrix-core sweep)
         if constexpr (!HASP && TG <= 14) {       // (the wide-tile variants have no registers to spare for Y, G and Z segments: they refactor)
             if (T.f2_neumann && g_scale > 0.0) {
                 const double f = uniform_d(scale / g_scale), delta = uniform_d(rho_x * (1.0 - f) / f);
@@ -683,30 +688,146 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
                 }
                 __syncthreads();
             }
-            // S (rows and columns < n) to LDS, row-major with pitch ldg, then into the (jg, cg) register tile of the inversion
-            if (wave < NTILE) {
+            if constexpr (F2_GJ_MFMA && !HASP) {
+                // ---- inversion as a BLOCKED SWEEP on the matrix cores, in the accumulator layout the S formation ends in (no LDS round trip of S, no second
+                // register tile).  Sweeping the symmetric matrix on the index block K = {k0 .. k0 + 3}, with P = S[K, K]^-1, R = S[K, :] and C = S[:, K] = R^T:
+                //     S[i, j] <- S[i, j] - C_i P R[:, j]     S[i, K] <- C_i P     S[K, j] <- P R[:, j]     S[K, K] <- -P          (i, j outside K)
+                // keeps S symmetric, and after every block has been swept S = -(S_0)^-1.  One update is ONE rank-4 MFMA per 16 x 16 tile:
+                //     D = base + W R'',   W_i = -C_i P (rows outside K),  W_q = P[q, :] (rows of K),   R'' = R with its K columns replaced by -I,
+                //     base = S with the K columns and the K rows zeroed
+                // -- v_mfma_f64_16x16x4_f64 IS a rank-4 update.  Lane l = (lg, lc) supplies the A operand W[strip row lc][lg] and the B operand R''[lg][16 J + lc]:
+                // R (4 rows, published by the wave that owns them: accumulator register r0 of its tiles IS the B-operand layout) is read from LDS by every wave,
+                // and C comes from the SAME buffer by symmetry (C_i[p] = R[p][i]) -- no transposition inside the wave.  Every lane inverts the 4 x 4 pivot block
+                // itself (no second barrier), as the blocked Gauss-Jordan did.  One barrier per block; rows / columns n .. 16 NTILE - 1 are padded with the identity.
+                static_assert(8 * LDP <= 16 * NP, "two R buffers of four rows fit the exchange region");
+                constexpr int MAXB = 4 * NTILE;                       // blocks of the padded matrix
+                const int NB = (n + 3) >> 2;                          // blocks that hold a row < n
+                if (wave < NTILE) {
+                    static_for<NTILE>([&](auto Jc) {                  // diagonal: + rho_x (rows < n), identity (padding rows)
+                        constexpr int J = decltype(Jc)::value;
+                        if (wave == J) {
 #pragma unroll
-                for (int J = 0; J < NTILE; J++)
+                            for (int r = 0; r < 4; r++) { const int row = 16 * J + lg + 4 * r; if (lc == lg + 4 * r) acc[J][r] += (row < n ? rho_x : 1.0); }
+                        }
+                    });
+                    if (wave == 0) {
 #pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const int row = 16 * wave + lg + 4 * r, col = 16 * J + lc;
-                        if (row < n && col < L::NPg) Gm[row * ldg + col] = acc[J][r] + (row == col ? rho_x : 0.0);
+                        for (int J = 0; J < NTILE; J++) Gm[lg * LDP + 16 * J + lc] = acc[J][0];          // rows 0 .. 3 -> buffer 0
                     }
-            }
-            __syncthreads();
-            if (jg < n) {
-                const double2 *src = reinterpret_cast<const double2 *>(Gm + jg * ldg + TG * cg);
+                }
+                __syncthreads();
+                F2_STAMP(8);
+                F2_T0();
+                static_for<MAXB>([&](auto bc) {
+                    constexpr int b = decltype(bc)::value, k0 = 4 * b, wo = k0 / 16, r0 = (k0 % 16) / 4, c0 = k0 % 16;
+                    constexpr int k1 = k0 + 4, wn = (k1 / 16) % NTILE, r1 = (k1 % 16) / 4;          // owner wave / register of the NEXT block's rows
+                    if (b < NB) {                                     // (uniform)
+                        const double *Rb = Gm + (b & 1) * (4 * LDP);
+                        double *Rn = Gm + ((b + 1) & 1) * (4 * LDP);
+                        if (wave < NTILE) {
+                            double Bop[NTILE], Cop[4], a[4][4];
 #pragma unroll
-                for (int s = 0; s < TG / 2; s++) { const double2 v = src[s]; sreg[2 * s] = v.x; sreg[2 * s + 1] = v.y; }
-            }
-            __syncthreads();
-            if constexpr (HASP) {
-                double pg[TG];
-                materialize_p(co, pg);
+                            for (int J = 0; J < NTILE; J++) Bop[J] = Rb[lg * LDP + 16 * J + lc];
+                            {
+                                int coff = 16 * wave + lc;            // (opaque: keeps the four addresses from being hoisted out of the unrolled blocks)
+                                asm volatile("" : "+v"(coff));
 #pragma unroll
-                for (int s = 0; s < TG; s++) if (jg < n) sreg[s] += pg[s];
+                                for (int pq = 0; pq < 4; pq++) Cop[pq] = Rb[pq * LDP + coff];
+                            }
+#pragma unroll
+                            for (int q = 0; q < 4; q++) {
+                                const double2 v0 = *reinterpret_cast<const double2 *>(Rb + q * LDP + k0), v1 = *reinterpret_cast<const double2 *>(Rb + q * LDP + k0 + 2);
+                                a[q][0] = v0.x; a[q][1] = v0.y; a[q][2] = v1.x; a[q][3] = v1.y;
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int pv_ = 0; pv_ < 4; pv_++) {      // in-place inverse of the 4 x 4 block (no pivoting: the swept block is positive definite)
+                                const double pv = a[pv_][pv_];
+                                double pinv = __builtin_amdgcn_rcp(pv);
+                                pinv = fma(fma(-pv, pinv, 1.0), pinv, pinv);
+                                pinv = fma(fma(-pv, pinv, 1.0), pinv, pinv);
+#pragma unroll
+                                for (int j = 0; j < 4; j++) if (j != pv_) a[pv_][j] *= pinv;
+#pragma unroll
+                                for (int i = 0; i < 4; i++) if (i != pv_) {
+                                    const double f = a[i][pv_];
+#pragma unroll
+                                    for (int j = 0; j < 4; j++) if (j != pv_) a[i][j] = fma(-f, a[pv_][j], a[i][j]);
+                                    a[i][pv_] = -f * pinv;
+                                }
+                                a[pv_][pv_] = pinv;
+                            }
+                            F2_EACC(4);      // operand reads + the 4 x 4 inverse
+                            double w4[4];
+#pragma unroll
+                            for (int q = 0; q < 4; q++) w4[q] = -(Cop[0] * a[0][q] + Cop[1] * a[1][q] + Cop[2] * a[2][q] + Cop[3] * a[3][q]);
+                            double wsel = lg == 0 ? w4[0] : (lg == 1 ? w4[1] : (lg == 2 ? w4[2] : w4[3]));
+                            const int mr = lc - c0;                   // this lane's strip row, relative to the block
+                            const bool kcol = mr >= 0 && mr < 4;
+                            if (wave == wo) {                         // the strip that holds the rows of K: W_q = P[q, :], base 0
+                                double prow[4];
+#pragma unroll
+                                for (int q = 0; q < 4; q++) prow[q] = mr == 0 ? a[0][q] : (mr == 1 ? a[1][q] : (mr == 2 ? a[2][q] : a[3][q]));
+                                const double psel = lg == 0 ? prow[0] : (lg == 1 ? prow[1] : (lg == 2 ? prow[2] : prow[3]));
+                                wsel = kcol ? psel : wsel;
+#pragma unroll
+                                for (int J = 0; J < NTILE; J++) acc[J][r0] = 0.0;
+                            }
+#pragma unroll
+                            for (int r = 0; r < 4; r++) acc[wo][r] = kcol ? 0.0 : acc[wo][r];          // the K columns of the base (tile J0 = wo)
+                            Bop[wo] = kcol ? (mr == lg ? -1.0 : 0.0) : Bop[wo];                          // ... and of R'': -I
+                            F2_EACC(5);      // multipliers
+#pragma unroll
+                            for (int J = 0; J < NTILE; J++) acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(wsel, Bop[J], acc[J], 0, 0, 0);
+                            F2_EACC(6);      // rank-4 update
+                            if (b + 1 < NB && wave == wn) {
+#pragma unroll
+                                for (int J = 0; J < NTILE; J++) Rn[lg * LDP + 16 * J + lc] = acc[J][r1];
+                            }
+                        }
+                        __syncthreads();
+                        F2_EACC(7);      // publish the next rows + the barrier
+                    }
+                });
+                F2_STAMP(9);
+                // G = -(swept S) to LDS, row-major with pitch ldg (the R buffers are dead: every block ended with a barrier)
+                if (wave < NTILE) {
+#pragma unroll
+                    for (int J = 0; J < NTILE; J++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const int row = 16 * wave + lg + 4 * r, col = 16 * J + lc;
+                            if (row < n && col < L::NPg) Gm[row * ldg + col] = 0.0 - acc[J][r];
+                        }
+                }
+                g_in_lds = true;
+            } else {
+                // S (rows and columns < n) to LDS, row-major with pitch ldg, then into the (jg, cg) register tile of the inversion
+                if (wave < NTILE) {
+#pragma unroll
+                    for (int J = 0; J < NTILE; J++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const int row = 16 * wave + lg + 4 * r, col = 16 * J + lc;
+                            if (row < n && col < L::NPg) Gm[row * ldg + col] = acc[J][r] + (row == col ? rho_x : 0.0);
+                        }
+                }
+                __syncthreads();
+                if (jg < n) {
+                    const double2 *src = reinterpret_cast<const double2 *>(Gm + jg * ldg + TG * cg);
+#pragma unroll
+                    for (int s = 0; s < TG / 2; s++) { const double2 v = src[s]; sreg[2 * s] = v.x; sreg[2 * s + 1] = v.y; }
+                }
+                __syncthreads();
+                if constexpr (HASP) {
+                    double pg[TG];
+                    materialize_p(co, pg);
+#pragma unroll
+                    for (int s = 0; s < TG; s++) if (jg < n) sreg[s] += pg[s];
+                }
             }
         }
+        if (!g_in_lds) {
         F2_STAMP(8);
         // BLOCKED Gauss-Jordan inversion on the register tile: four pivots per workgroup barrier.  Block order: slots kk0 = 0, 4, 8, ...
         // (static), inside a slot block the lane groups cgk = 0, 1, ... that still hold a pivot < n; block K = columns / rows
@@ -818,12 +939,13 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
                 F2_EACC(7);      // publish the next panel + the barrier
             }
         });
-        }      // (!fast)
         F2_STAMP(9);
+        }      // (!g_in_lds)
+        }      // (!fast)
         g_scale = uniform_d(scale);
         if constexpr (HASP) { if (sc[7] != 0.0) return; }      // (uniform: read after the loop's last barrier) -> status FAILED below
         // G to LDS (the panel data in that region is dead), scratch back to zero
-        if (jg < n) {
+        if (!g_in_lds && jg < n) {
             double2 *dst = reinterpret_cast<double2 *>(Gm + jg * ldg + TG * cg);
 #pragma unroll
             for (int s = 0; s < TG / 2; s++) dst[s] = make_double2(sreg[2 * s], sreg[2 * s + 1]);
