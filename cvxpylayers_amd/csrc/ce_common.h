@@ -72,6 +72,9 @@ __device__ __forceinline__ double wave_max(double v) {
     return v;
 }
 // reduces K values over the workgroup; bit k of maxmask selects max instead of sum.  red: NW*K doubles of LDS.
+// Must be called in workgroup-uniform control flow by ALL NT threads: wave_sum's DPP broadcast reads lane 63 of every wave (an inactive lane there is
+// garbage, not a smaller sum), and the barriers below need every wave.
+static_assert(NT % 64 == 0, "block_reduce: whole waves only");
 template <int K>
 __device__ __forceinline__ void block_reduce(double (&v)[K], unsigned maxmask, double *red) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;

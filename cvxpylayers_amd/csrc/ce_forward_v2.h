@@ -740,42 +740,51 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
                                 a[q][0] = v0.x; a[q][1] = v0.y; a[q][2] = v1.x; a[q][3] = v1.y;
                             }
                             __builtin_amdgcn_sched_barrier(0);
+                            // Column lg of P = S[K, K]^-1, and nothing else: lane (lg, lc) feeds the matrix cores W[strip row lc][lg] = -C_i . P[:, lg], so it solves
+                            // S[K, K] xs = e_lg (elimination without pivoting -- the swept block is positive definite; the matrix is the same in every lane, the right-hand
+                            // side is the lane's) instead of inverting the block and selecting a column: a third of the arithmetic, and no select chains (which the
+                            // compiler turned into divergent branches, ~1.2 k cycles per block: profiles/r05/c_timing.log).  Every choice below is a BLEND with 0 / 1 lane
+                            // constants for the same reason.
+                            double e[4];
 #pragma unroll
-                            for (int pv_ = 0; pv_ < 4; pv_++) {      // in-place inverse of the 4 x 4 block (no pivoting: the swept block is positive definite)
-                                const double pv = a[pv_][pv_];
-                                double pinv = __builtin_amdgcn_rcp(pv);
-                                pinv = fma(fma(-pv, pinv, 1.0), pinv, pinv);
-                                pinv = fma(fma(-pv, pinv, 1.0), pinv, pinv);
+                            for (int k = 0; k < 4; k++) e[k] = (lg == k) ? 1.0 : 0.0;
+                            double pinv[4];
 #pragma unroll
-                                for (int j = 0; j < 4; j++) if (j != pv_) a[pv_][j] *= pinv;
+                            for (int k = 0; k < 4; k++) {
+                                const double pv = a[k][k];
+                                double pi_ = __builtin_amdgcn_rcp(pv);             // seed + two Newton steps instead of the IEEE divide
+                                pi_ = fma(fma(-pv, pi_, 1.0), pi_, pi_);
+                                pi_ = fma(fma(-pv, pi_, 1.0), pi_, pi_);
+                                pinv[k] = pi_;
 #pragma unroll
-                                for (int i = 0; i < 4; i++) if (i != pv_) {
-                                    const double f = a[i][pv_];
+                                for (int i = k + 1; i < 4; i++) {
+                                    const double lm = a[i][k] * pi_;
 #pragma unroll
-                                    for (int j = 0; j < 4; j++) if (j != pv_) a[i][j] = fma(-f, a[pv_][j], a[i][j]);
-                                    a[i][pv_] = -f * pinv;
+                                    for (int j = k + 1; j < 4; j++) a[i][j] = fma(-lm, a[k][j], a[i][j]);
+                                    e[i] = fma(-lm, e[k], e[i]);
                                 }
-                                a[pv_][pv_] = pinv;
                             }
-                            F2_EACC(4);      // operand reads + the 4 x 4 inverse
-                            double w4[4];
-#pragma unroll
-                            for (int q = 0; q < 4; q++) w4[q] = -(Cop[0] * a[0][q] + Cop[1] * a[1][q] + Cop[2] * a[2][q] + Cop[3] * a[3][q]);
-                            double wsel = lg == 0 ? w4[0] : (lg == 1 ? w4[1] : (lg == 2 ? w4[2] : w4[3]));
+                            double xs[4];
+                            xs[3] = e[3] * pinv[3];
+                            xs[2] = fma(-a[2][3], xs[3], e[2]) * pinv[2];
+                            xs[1] = fma(-a[1][3], xs[3], fma(-a[1][2], xs[2], e[1])) * pinv[1];
+                            xs[0] = fma(-a[0][3], xs[3], fma(-a[0][2], xs[2], fma(-a[0][1], xs[1], e[0]))) * pinv[0];
+                            F2_EACC(4);      // operand reads + the 4 x 4 solve
+                            double wsel = -(Cop[0] * xs[0] + Cop[1] * xs[1] + Cop[2] * xs[2] + Cop[3] * xs[3]);
                             const int mr = lc - c0;                   // this lane's strip row, relative to the block
                             const bool kcol = mr >= 0 && mr < 4;
-                            if (wave == wo) {                         // the strip that holds the rows of K: W_q = P[q, :], base 0
-                                double prow[4];
+                            const double nk = kcol ? 0.0 : 1.0;
+                            if (wave == wo) {                         // the strip that holds the rows of K: W_q = P[q, :] (= xs[q] by symmetry), base 0
+                                double psel = 0.0;
 #pragma unroll
-                                for (int q = 0; q < 4; q++) prow[q] = mr == 0 ? a[0][q] : (mr == 1 ? a[1][q] : (mr == 2 ? a[2][q] : a[3][q]));
-                                const double psel = lg == 0 ? prow[0] : (lg == 1 ? prow[1] : (lg == 2 ? prow[2] : prow[3]));
-                                wsel = kcol ? psel : wsel;
+                                for (int k = 0; k < 4; k++) psel = fma(xs[k], (mr == k) ? 1.0 : 0.0, psel);
+                                wsel = fma(wsel, nk, psel);
 #pragma unroll
                                 for (int J = 0; J < NTILE; J++) acc[J][r0] = 0.0;
                             }
 #pragma unroll
-                            for (int r = 0; r < 4; r++) acc[wo][r] = kcol ? 0.0 : acc[wo][r];          // the K columns of the base (tile J0 = wo)
-                            Bop[wo] = kcol ? (mr == lg ? -1.0 : 0.0) : Bop[wo];                          // ... and of R'': -I
+                            for (int r = 0; r < 4; r++) acc[wo][r] *= nk;                                  // the K columns of the base (tile J0 = wo)
+                            Bop[wo] = fma(Bop[wo], nk, (kcol && mr == lg) ? -1.0 : 0.0);                   // ... and of R'': -I
                             F2_EACC(5);      // multipliers
 #pragma unroll
                             for (int J = 0; J < NTILE; J++) acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(wsel, Bop[J], acc[J], 0, 0, 0);

@@ -75,7 +75,7 @@ def note_ignored_args(merged_args: dict, explicit_lookback: bool):
     iteration counts within 2.5 % on the BASELINE configurations);  mode / solve_method -- the adjoint is a rank-revealing direct elimination for per-instance
     templates and LSQR for shared-A templates, not selectable;  n_jobs_forward / n_jobs_backward -- the batch runs on the GPU."""
     lb = merged_args.get("acceleration_lookback")
-    if lb is not None and int(lb) > 1:
+    if explicit_lookback and lb is not None and int(lb) > 1:      # (the DEFAULT configuration stays silent -- valid calls must survive `-W error`; info["acceleration"] and the docs carry the one-pair fact)
         _warn_once("lookback", f"MI355 solver: acceleration_lookback={int(lb)}" + ("" if explicit_lookback else " (SCS's default, which the reference forwards)") +
                    " runs as type-I Anderson acceleration with a ONE-pair history (memory 1), not a " + str(int(lb)) + "-pair history; "
                    "pass acceleration_lookback=1 to say so explicitly, 0 to iterate plainly")
@@ -533,6 +533,10 @@ def _note_adjoint_flags(eng, adj, bs):
 
 def _fold_adjoint(eng, entry):
     slot, bs = entry
+    # the slot's ready flag, not stream order, says that its three counts have landed: a backward that ran on another stream than the forward whose summary
+    # was just read is not ordered by that read
+    if getattr(eng, "_summary_np", None) is not None and eng._summary_np[slot, 3] == 0:
+        torch.cuda.synchronize(eng.device)
     eng._adj_count += int(eng._summary_np[slot, 2])     # bits 0-1; bit 2 (4) = rank-deficient system, basic solution returned like the reference's LSQR does -- not a failure
     eng._adj_total += bs
 

@@ -148,7 +148,10 @@ int ce_transpose(ce_handle h, int rows, int cols, const double *in, double *out,
  * honour the reference's contract that a failed instance raises SolverError from forward() (diffcp_if.py:365-372 raises inside the call): 12 bytes instead
  * of the status vector.  When summary_host is pinned memory mapped into the device's address space (hipHostMalloc / torch's pin_memory) the kernel stores
  * there directly; any other host pointer goes through one of EIGHT rotating device slots and an asynchronous copy: at most eight such calls may be in flight
- * on the stream between two synchronisations of the caller. */
+ * on the stream between two synchronisations of the caller.
+ * LIFETIME: the engine remembers, per 64-byte line of host memory, whether the line is mapped and its device alias (one hipPointerGetAttributes per line,
+ * not per call).  A buffer handed to this function must therefore stay allocated AND pinned for as long as the engine lives (or until another line has
+ * been passed in between): freeing it and re-using the address for a different allocation leaves the engine with a stale alias. */
 int ce_status_summary(ce_handle h, int B, const int *status, int *summary_host, void *stream);
 
 /*

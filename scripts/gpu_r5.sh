@@ -13,7 +13,7 @@ if ! timeout 180 python -c "import torch; assert float(torch.ones(1024, device='
 BENCH_ARGS=${BENCH_ARGS:-}
 if has tests; then
   echo "== pytest -m gpu" | tee "$OUT/summary.txt"
-  timeout ${TEST_TIMEOUT:-600} python -m pytest tests -m gpu -q ${PYTEST_ARGS--x} --durations=15 2>&1 | tail -40 | tee "$OUT/pytest.log" | tail -25 | tee -a "$OUT/summary.txt"
+  timeout ${TEST_TIMEOUT:-600} python -m pytest tests -m gpu -q ${PYTEST_ARGS--x} --tb=short --durations=8 2>&1 | grep -v "Warning\|warnings.warn\|note_ignored_args" | tail -400 > "$OUT/pytest.log"; grep -E "^E  |^FAILED|passed|failed" "$OUT/pytest.log" | cut -c1-600 | tail -40 | tee -a "$OUT/summary.txt"
   echo "== smoke" | tee -a "$OUT/summary.txt"
   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v amdgpu.ids | tail -3 | tee -a "$OUT/summary.txt"
 fi

