@@ -74,7 +74,7 @@ def lib():
     L.ce_vjp.argtypes = [vp, C.c_int, dp, lg, lg, dp, lg, lg, dp, dp, dp, dp, dp, dp, lg, lg, dp, lg, lg, ip, vp]
     L.ce_solve_shared_a.argtypes = [vp, C.c_int, C.c_int, C.c_int, dp, ip, ip, dp, ip, ip, dp, dp, dp, dp, dp, dp, dp, dp, C.POINTER(CeSettings),
                                     dp, dp, dp, dp, dp, dp, ip, ip, dp, vp]
-    L.ce_vjp_shared_a.argtypes = [vp, C.c_int, dp, lg, dp, lg, lg, dp, dp, dp, dp, dp, dp, dp, lg, lg, ip, ip, C.c_double, C.c_double, C.c_int, vp]
+    L.ce_vjp_shared_a.argtypes = [vp, C.c_int, dp, lg, dp, lg, lg, dp, dp, dp, dp, dp, dp, dp, lg, lg, ip, ip, C.c_double, C.c_double, C.c_double, C.c_int, vp]
     L.ce_qp_native.argtypes = [vp]
     L.ce_acceleration_available.argtypes = [vp]
     L.ce_solve_qp.argtypes = [vp, C.c_int, dp, lg, lg, dp, lg, lg, dp, C.POINTER(CeSettings), dp, dp, dp, ip, ip, dp, vp]

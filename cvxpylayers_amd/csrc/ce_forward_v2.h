@@ -411,6 +411,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
         // kept as a scalar (ecum, dcum) that multiplies the tile's norm instead of being multiplied into every entry in every pass (half the v_pk_mul_f32)
         float ecum = 1.0f, dcum = 1.0f;
         const int blk_r0 = (i2 < m) ? socr[i2] : 0, blk_d = (i2 < m) ? abs(socd[i2]) : 0;      // this row's cone block (read once: two LDS round trips less per pass)
+        F2_STAMP(14);      // (the two FP32 tile gathers: first touch of the instance's values)
         F2_T0();
         for (int pass = 0; pass < NUM_RUIZ_PASSES + NUM_L2_PASSES; pass++) {
             const bool l2 = pass >= NUM_RUIZ_PASSES;
@@ -515,6 +516,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
             F2_EACC(3);      // factor reads + scaling
             // no barrier: the next pass writes the other ping-pong buffers (and the row norms, last read before the barrier above)
         }
+        F2_STAMP(15);      // (the 26 passes)
         if (own1) sm[L::O_EV + j1] = Eacc;
         if (own2) sm[L::O_DV + i2] = Dacc;
         __syncthreads();
@@ -968,12 +970,14 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
             if (own1) { const double cj = sm[L::O_CV + j1]; sm[L::O_S1 + j1] = cj - a; sm[L::O_S2 + j1] = cj + a; }   // rhs for g_x ; k = c + A^T Dy b
         }
         __syncthreads();
+        F2_STAMP(11);
         {
             const double *grow = Gm + (jg < n ? jg : 0) * ldg + TG * cg;
             const double gx = seg_dot_lds<CHG, TG>(grow, sm + L::O_S1 + TG * cg), gk = seg_dot_lds<CHG, TG>(grow, sm + L::O_S2 + TG * cg);
             if (owng) { sm[L::O_GV + OX + jg] = gx; sm[L::O_PX + jg] = gk; }
         }
         __syncthreads();
+        F2_STAMP(12);
         if constexpr (HASP) {      // P-hat g_x (vector, kept) and g_x^T P-hat g_x
             double pg[TG];
             materialize_p(co, pg);
@@ -999,6 +1003,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
             }
             if (tid < n) { r[0] += sm[L::O_CV + tid] * sm[L::O_GV + OX + tid]; sm[L::O_PHI + OX + tid] = rho_x * sm[L::O_PX + tid]; }
         }
+        F2_STAMP(13);
         block_reduce_w<1, NW>(r, 0u, red, wave);
         hg = uniform_d(r[0]);
         inv_den = uniform_d(1.0 / (rtau + hg));

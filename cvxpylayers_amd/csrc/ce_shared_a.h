@@ -64,7 +64,7 @@ template <int RP>
 __global__ void __launch_bounds__(NT, 3)
 k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, long sAb, const double *__restrict__ qg, long sqk, long sqb, const double *__restrict__ xg, const double *__restrict__ yg,
           const double *__restrict__ sg, const double *__restrict__ dxg, const double *__restrict__ dyg, double *__restrict__ dAo,
-          double *__restrict__ dqo, long sdqk, long sdqb, int *__restrict__ adj_status, int *__restrict__ iters_o, double atol, double btol, int itn_lim) {
+          double *__restrict__ dqo, long sdqk, long sdqb, int *__restrict__ adj_status, int *__restrict__ iters_o, double atol, double btol, double conlim, int itn_lim) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int tid = threadIdx.x, inst = blockIdx.x;
     const int n = T.n, m = T.m, z = T.z, nl = T.l, nq = T.nq, ns = T.ns;
@@ -253,6 +253,7 @@ k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, long
     auto safe = [](double t) -> double { return t > 0 ? t : 1.0; };
     // (sum of squares, tau-row dot product) over the workgroup in one reduction
     auto sum_two = [&](double v, double w, double &wsum) -> double { double r[2] = {v, w}; block_reduce<2>(r, 0u, red); wsum = r[1]; return r[0]; };
+    auto sum_three = [&](double v, double w, double u3, double &wsum, double &usum) -> double { double r[3] = {v, w, u3}; block_reduce<3>(r, 0u, red); wsum = r[1]; usum = r[2]; return r[0]; };
 
     // ---- LSQR (Paige & Saunders) on  N r = dz,  N = M^T  (the tau components ut, vt, wt, rt are workgroup-uniform scalars in registers)
     //      N   (r_x, r_y, r_t) = ( -A^T r_y - c r_t ,  DPi(A r_x - b r_t - r_y) + r_y ,  c.r_x + b.r_y )
@@ -279,10 +280,14 @@ k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, long
     acc = sum_two(acc, acct, dsum);
     vt = TAU ? -dsum : 0.0;
     double alfa = sqrt(fma(vt, vt, acc));
+    // |w|^2 of the current search direction, as per-thread partial sums: LSQR's estimate of cond(N) (the `conlim` stopping test) needs sum_k |w_k|^2 / rho_k^2;
+    // the partial sums ride on the first reduction of the NEXT iteration (no barrier of their own)
+    double wsq = 0, ddnorm = 0;
+    const double ctol = conlim > 0 ? 1.0 / conlim : 0.0;
     {
         const double ia = 1.0 / safe(alfa);
-        for (int j = tid; j < n; j += NT) { const double v = vx[j] * ia; vx[j] = v; wx[j] = v; }
-        for (int i = tid; i < m; i += NT) { const double v = vy[i] * ia; vy[i] = v; wy[i] = v; }
+        for (int j = tid; j < n; j += NT) { const double v = vx[j] * ia; vx[j] = v; wx[j] = v; wsq = fma(v, v, wsq); }
+        for (int i = tid; i < m; i += NT) { const double v = vy[i] * ia; vy[i] = v; wy[i] = v; wsq = fma(v, v, wsq); }
         vt *= ia; wt = vt;
     }
     __syncthreads();
@@ -302,7 +307,9 @@ k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, long
         LS_T(0);
         dproj(ty, 1.0, [&](int i, double o) { const double v = o + vy[i] - alfa * uy[i]; uy[i] = v; acc = fma(v, v, acc); });
         LS_T(1);
-        acc = sum_two(acc, acct, dsum);
+        double wsum = 0;
+        acc = sum_three(acc, acct, wsq, dsum, wsum);
+        wsum = fma(wt, wt, wsum);                          // |w_{k-1}|^2, tau component included
         ut = TAU ? dsum - alfa * ut : 0.0;
         beta = sqrt(fma(ut, ut, acc));
         LS_T(2);
@@ -328,8 +335,10 @@ k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, long
         const double cs_ = rhobar / safe(rho), sn = beta / safe(rho);
         const double theta = sn * alfa; rhobar = -cs_ * alfa; const double phi = cs_ * phibar; phibar = sn * phibar; const double tau = sn * phi;
         const double t1 = phi / safe(rho), t2 = -theta / safe(rho), ia = 1.0 / safe(alfa);
-        for (int j = tid; j < n; j += NT) { const double v = vx[j] * ia, w = wx[j]; vx[j] = v; rx[j] += t1 * w; wx[j] = v + t2 * w; }
-        for (int i = tid; i < m; i += NT) { const double v = vy[i] * ia, w = wy[i]; vy[i] = v; ry[i] += t1 * w; wy[i] = v + t2 * w; }
+        wsq = 0;
+        for (int j = tid; j < n; j += NT) { const double v = vx[j] * ia, w = wx[j], wn = v + t2 * w; vx[j] = v; rx[j] += t1 * w; wx[j] = wn; wsq = fma(wn, wn, wsq); }
+        for (int i = tid; i < m; i += NT) { const double v = vy[i] * ia, w = wy[i], wn = v + t2 * w; vy[i] = v; ry[i] += t1 * w; wy[i] = wn; wsq = fma(wn, wn, wsq); }
+        ddnorm += wsum / (safe(rho) * safe(rho));
         { vt *= ia; rt = fma(t1, wt, rt); wt = fma(t2, wt, vt); }
         __syncthreads();
         LS_T(6);
@@ -340,7 +349,10 @@ k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, long
         const double rnorm = phibar, arnorm = alfa * fabs(tau);
         const double test1 = rnorm / safe(bnorm), test2 = arnorm / (anorm * rnorm + 1e-300);
         const double rtol = btol + atol * anorm * xnorm / safe(bnorm);
-        if (test1 <= rtol || test2 <= atol) live = false;
+        // the remaining stopping tests of Paige & Saunders' LSQR as diffcp / the oracle run them (oracle/cone_oracle.c lsqr_MT): the condition estimate against
+        // conlim (1e8: ill-conditioned systems stop HERE, long before atol / btol are met) and the three machine-precision tests
+        const double test3 = 1.0 / (anorm * sqrt(ddnorm) + 1e-300), tt1 = test1 / (1.0 + anorm * xnorm / safe(bnorm));
+        if (test1 <= rtol || test2 <= atol || test3 <= ctol || 1.0 + test3 <= 1.0 || 1.0 + test2 <= 1.0 || 1.0 + tt1 <= 1.0) live = false;
     }
     __syncthreads();
     // ---- outputs in the boundary convention: dA_eval = [-dA.data, db[b_idx]], dq_eval = [dc, 0]  (diffcp_if.py:91-92);

@@ -426,7 +426,7 @@ def _psd_eig(v, psd):
     return out
 
 
-def vjp_const_a(eng, A_bm, x, y, s, dx, dy, batch_minor_out=False, atol=1e-8, btol=1e-8, iter_lim=0, q_eval=None):
+def vjp_const_a(eng, A_bm, x, y, s, dx, dy, batch_minor_out=False, atol=1e-8, btol=1e-8, iter_lim=0, q_eval=None, conlim=1e8):
     """Returns dA (nnz_aug, B), dq (n+1, B), adj_status (B,) in the boundary convention (diffcp_if.py:91-92).
     atol / btol / iter_lim: LSQR's stopping rule; the defaults are diffcp's (1e-8, 1e-8, 2 N with N = n + m + 1: what diffcp_if.py:86 runs and
     oracle/cone_oracle.c:85,712 restates); the plugin forwards solver_args["lsqr_atol" / "lsqr_btol" / "lsqr_iter_lim"] (mi355_if.lsqr_rule).
@@ -458,7 +458,7 @@ def vjp_const_a(eng, A_bm, x, y, s, dx, dy, batch_minor_out=False, atol=1e-8, bt
             q_args = (None, 0, 0)
         assert A_bm.stride(1) == 1
         rc = _lib.lib().ce_vjp_shared_a(eng._h, B, A_bm.data_ptr(), A_bm.stride(0), *q_args, xc.data_ptr(), yc.data_ptr(), sc_.data_ptr(), dxc.data_ptr(), dyc.data_ptr(),
-                                        dA_bm.data_ptr(), dq.data_ptr(), B, 1, adj.data_ptr(), its.data_ptr(), atol, btol, int(iter_lim),
+                                        dA_bm.data_ptr(), dq.data_ptr(), B, 1, adj.data_ptr(), its.data_ptr(), atol, btol, float(conlim), int(iter_lim),
                                         C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
         if rc == 0:
             eng.last_lsqr_iters = its

@@ -253,13 +253,14 @@ int ce_solve_shared_a(ce_handle h, int B, int r, int RP, const double *AdT, cons
  * q_vals == NULL pins r_tau = 0 (the n + m system of ABI <= 8: the same gradients wherever the system is regular).
  * x, y, s, dx, dy as ce_vjp; dA_bm (B, nnz_aug) batch-major; dq at
  * [k * sdq_k + i * sdq_b]; adj_status[i] = 1 when LSQR hit iter_lim (0: diffcp's 2 (n + m + 1)); lsqr_iters (B) or NULL; atol / btol: LSQR stopping
- * tolerances (diffcp runs 1e-8 / 1e-8: the plugin's default, solver_args lsqr_atol / lsqr_btol / lsqr_iter_lim override).  The engine refills its own scratch (split of this call's A values) on `stream`: one engine, one stream at a time.  All cone types (zero / nonnegative / second-order / PSD / exponential / power: the triples' derivative is a symmetrised
+ * tolerances (diffcp runs 1e-8 / 1e-8: the plugin's default, solver_args lsqr_atol / lsqr_btol / lsqr_iter_lim override); conlim: LSQR stops when its estimate
+ * of cond(M^T) exceeds it (diffcp / scipy default 1e8; <= 0 disables the test).  The engine refills its own scratch (split of this call's A values) on `stream`: one engine, one stream at a time.  All cone types (zero / nonnegative / second-order / PSD / exponential / power: the triples' derivative is a symmetrised
  * 3 x 3 block computed once per call); CE_E_TOO_LARGE when the LSQR vectors of one instance exceed LDS (callers fall back to the batched
  * path of const_a.py).
  */
 int ce_vjp_shared_a(ce_handle h, int B, const double *A_vals0, long sA_b, const double *q_vals, long sq_k, long sq_b,
                     const double *x, const double *y, const double *s, const double *dx, const double *dy,
-                    double *dA_bm, double *dq_vals, long sdq_k, long sdq_b, int *adj_status, int *lsqr_iters, double atol, double btol, int iter_lim, void *stream);
+                    double *dA_bm, double *dq_vals, long sdq_k, long sdq_b, int *adj_status, int *lsqr_iters, double atol, double btol, double conlim, int iter_lim, void *stream);
 
 /* Longest-first dispatch.  Workgroups are dispatched in index order and one workgroup owns one instance, so the tail of a forward launch is set by the
  * instances that happen to start last: when they are long ones the last slots drain slowly (13 % of the metric configuration's kernel time).  With the switch

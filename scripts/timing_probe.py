@@ -15,7 +15,8 @@ x, y, s, it, st, res = eng.solve(A_bm, q_t, make_settings(dict(eps=1e-4, max_ite
 torch.cuda.synchronize()
 ts = s[:, :32].cpu().numpy()
 print("forward phases (cycles, mean over instances); iters mean", it.float().mean().item())
-for nm, a, b2 in (("init+load b,c", 0, 1), ("equilibration", 1, 2), ("refactor: materialize+S", 7, 8), ("refactor: GJ", 8, 9), ("refactor: g,phi", 9, 10),
+for nm, a, b2 in (("init+load b,c", 0, 1), ("equilibration", 1, 2), ("  equilibration: FP32 tile gathers (first touch of A)", 1, 14), ("  equilibration: 26 passes", 14, 15), ("  equilibration: D, E out, b / c scaling, sigma", 15, 2), ("refactor: materialize+S", 7, 8), ("refactor: GJ", 8, 9), ("refactor: g,phi", 9, 10),
+                  ("  g,phi: zero, Dy b, gather A^T tile, A^T(Dy b)", 9, 11), ("  g,phi: G (c -+ a)", 11, 12), ("  g,phi: gather A tile, A gx, A gk", 12, 13), ("  g,phi: h.g reduce, phi tile, zero", 13, 10),
                   ("first refactor total (2->3 includes)", 2, 3), ("iterations (incl. later refactors)", 3, 4), ("writeback", 4, 5), ("total", 0, 5)):
     print(f"  {nm:38s} {(ts[:, b2] - ts[:, a]).mean():12.1f}")
 itn = it.float().cpu().numpy()
