@@ -325,8 +325,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
        double *__restrict__ xo, double *__restrict__ yo, double *__restrict__ so, int *__restrict__ iters_o,
        int *__restrict__ status_o, double *__restrict__ resid_o,
        const double *__restrict__ Pvals_g = nullptr, int nnzP = 0, const int *__restrict__ idx_p = nullptr,
-       const int *__restrict__ row_perm = nullptr, const int *__restrict__ order = nullptr, int *__restrict__ iters2 = nullptr,
-       const double *__restrict__ DEg = nullptr) {
+       const int *__restrict__ row_perm = nullptr, const int *__restrict__ order = nullptr, int *__restrict__ iters2 = nullptr) {
     static_assert(!(WL && (PSD || HASP)), "wave-local cone exchange: plain cones only");
     constexpr int NT = NTH, NW = NTH / 64;        // threads / waves per workgroup of this instantiation (shadow the file-level defaults)
     using L = F2<CHT, T1, CHA, T2, CHG, TG, NW>;
@@ -385,17 +384,141 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
     // problem, and termination is tested on un-normalised residuals -- so the Ruiz factors only need single precision (they
     // are accumulated in double).  The fp64 iteration tiles are afterwards built as A * (D * E) in double from the final D, E
     // (materialize_*), so both layouts hold exactly the same matrix.  FP32 halves the VALU cost and the registers of this phase.
-    // DEg != null: D and E of every instance were computed by k_f2_equil in front of this launch ([B][MP + NP] doubles: D, then E) -- the passes are latency-bound
-    // chains of small phases, and at this kernel's three waves per SIMD they left two thirds of the issue slots idle; a kernel with their register footprint only
-    // runs them at twice the occupancy.  DEg == null: the passes run here (quadratic-objective / PSD instantiations, CE_F2_EQUIL_KERNEL=0).
     if (S.normalize) {
-        if (DEg) {
-            const double *de = DEg + (size_t)inst * (MP + NP);
-            for (int i = tid; i < m; i += NT) sm[L::O_DV + i] = de[i];
-            for (int j = tid; j < n; j += NT) sm[L::O_EV + j] = de[MP + j];
-        } else {
-#include "ce_f2_ruiz.inc"
+        const Co co(wave);
+        const int j1 = co.j1, c1 = co.c1, i2 = co.i2, c2 = co.c2;
+        const bool own1 = (c1 == 0) && (j1 < n), own2 = (c2 == 0) && (i2 < m);
+        // tiles as packed pairs: the scaling of a pass is one v_pk_mul_f32 per pair and factor (gfx950 packed fp32 runs at twice the
+        // scalar fp32 rate), the inf-norms are v_max3_f32 chains, 1/sqrt is the hardware v_rsq_f32 (D, E are preconditioners:
+        // any positive scaling is valid, 1 ulp of single precision is more than enough)
+        typedef float f2v __attribute__((ext_vector_type(2)));
+        f2v atv[T1 / 2], arv[T2 / 2];
+        float pf[HASP ? TG : 1];
+        if constexpr (HASP) {
+            const double *pv = Pvals_g + (size_t)inst * nnzP;
+#pragma unroll
+            for (int k = 0; k < TG; k++) { const int ix = idx_p[tid * idx_stride<TG> + k]; pf[k] = ix >= 0 ? (float)pv[ix] : 0.0f; }
         }
+        float *const fPn = reinterpret_cast<float *>(sm + L::O_S3);          // column norms of P-hat (= row norms: symmetric)
+        for_each_idx<T1>(idx_at, tid, [&](auto, int k, int ix) { atv[k >> 1][k & 1] = ix >= 0 ? (float)(-vals[ix]) : 0.0f; });   // A = -A_cvx (diffcp_if.py:65)
+        for_each_idx<T2>(idx_ar, tid, [&](auto, int k, int ix) { arv[k >> 1][k & 1] = ix >= 0 ? (float)(-vals[ix]) : 0.0f; });
+        float *const fEt0 = reinterpret_cast<float *>(sm + L::O_S1), *const fEt1 = reinterpret_cast<float *>(sm + L::O_S2);
+        float *const fDt0 = reinterpret_cast<float *>(sm + L::O_U + OY), *const fDt1 = reinterpret_cast<float *>(sm + L::O_UT + OY);
+        float *const fRn = reinterpret_cast<float *>(sm + L::O_ZB + OY);
+        auto clampf = [](float v) -> float { return v < (float)MIN_SCALE ? 1.0f : (v > (float)MAX_SCALE ? (float)MAX_SCALE : v); };
+        double Eacc = 1.0, Dacc = 1.0;        // accumulated scalings of this thread's column / row (owners write them once, after the passes)
+        // The column-layout tile belongs to ONE column and the row-layout tile to ONE row: their own factor is the same for all 26 entries, so it is
+        // kept as a scalar (ecum, dcum) that multiplies the tile's norm instead of being multiplied into every entry in every pass (half the v_pk_mul_f32)
+        float ecum = 1.0f, dcum = 1.0f;
+        const int blk_r0 = (i2 < m) ? socr[i2] : 0, blk_d = (i2 < m) ? abs(socd[i2]) : 0;      // this row's cone block (read once: two LDS round trips less per pass)
+        F2_STAMP(14);      // (the two FP32 tile gathers: first touch of the instance's values)
+        F2_T0();
+        for (int pass = 0; pass < NUM_RUIZ_PASSES + NUM_L2_PASSES; pass++) {
+            const bool l2 = pass >= NUM_RUIZ_PASSES;
+            float *const fEt = (pass & 1) ? fEt1 : fEt0;                  // column scaling of this pass (x-indexed)
+            float *const fDt = (pass & 1) ? fDt1 : fDt0;                  // row scaling of this pass (y-indexed)
+            float cn = 0, rn = 0;
+            if (l2) {
+#pragma unroll
+                for (int k = 0; k < T1 / 2; k++) { cn = fmaf(atv[k].x, atv[k].x, cn); cn = fmaf(atv[k].y, atv[k].y, cn); }
+#pragma unroll
+                for (int k = 0; k < T2 / 2; k++) { rn = fmaf(arv[k].x, arv[k].x, rn); rn = fmaf(arv[k].y, arv[k].y, rn); }
+                cn = ecum * sqrtf(group_reduce_f<CHT, false>(cn)); rn = dcum * sqrtf(group_reduce_f<CHA, false>(rn));
+            } else {
+                float c0 = 0, c1_ = 0, r0 = 0, r1 = 0;
+#pragma unroll
+                for (int k = 0; k < T1 / 2; k += 2) { c0 = fmaxf(fmaxf(c0, fabsf(atv[k].x)), fabsf(atv[k].y)); if (k + 1 < T1 / 2) c1_ = fmaxf(fmaxf(c1_, fabsf(atv[k + 1].x)), fabsf(atv[k + 1].y)); }
+#pragma unroll
+                for (int k = 0; k < T2 / 2; k += 2) { r0 = fmaxf(fmaxf(r0, fabsf(arv[k].x)), fabsf(arv[k].y)); if (k + 1 < T2 / 2) r1 = fmaxf(fmaxf(r1, fabsf(arv[k + 1].x)), fabsf(arv[k + 1].y)); }
+                cn = ecum * group_reduce_f<CHT, true>(fmaxf(c0, c1_)); rn = dcum * group_reduce_f<CHA, true>(fmaxf(r0, r1));
+            }
+            if constexpr (HASP) {      // columns of [P-hat; A-hat]: the column norm of A-hat is combined with that of P-hat after the barrier
+                const Co cop(wave);
+                float pn = 0;
+                if (l2) {
+#pragma unroll
+                    for (int k = 0; k < TG; k++) pn = fmaf(pf[k], pf[k], pn);
+                    pn = group_reduce_f<CHG, false>(pn);          // squared
+                } else {
+#pragma unroll
+                    for (int k = 0; k < TG; k++) pn = fmaxf(pn, fabsf(pf[k]));
+                    pn = group_reduce_f<CHG, true>(pn);
+                }
+                if (cop.cg == 0 && cop.jg < n) fPn[cop.jg] = pn;
+            } else {
+                if (own1) fEt[j1] = __builtin_amdgcn_rsqf(clampf(cn));
+            }
+            if (own2) fRn[i2] = rn;          // raw row norms
+            F2_EACC(0);      // norms, butterflies, column factor, row norms out
+            if constexpr (WL) wave_lds_exchange(); else __syncthreads();
+            if constexpr (HASP) {
+                if (own1) { const float pn = fPn[j1]; fEt[j1] = __builtin_amdgcn_rsqf(clampf(l2 ? sqrtf(cn * cn + pn) : fmaxf(cn, pn))); }
+            }
+            // block sums of <= 12 rows: the CHA lanes of a row share the masked batch of reads (as in the iteration's cone norm) and add their shares with a DPP butterfly
+            constexpr int NEQ = (12 + CHA - 1) / CHA;
+            float ssh = 0;
+            if (blk_d > 1 && blk_d <= 12) {   // (the reads past the block stay inside the vector)
+                const int off = (int)__umul24((unsigned)c2, (unsigned)NEQ);
+                const float *fr = fRn + blk_r0 + off;
+                const int lim = blk_d - off;
+                float v[NEQ];
+#pragma unroll
+                for (int u = 0; u < NEQ; u++) v[u] = fr[u];
+#pragma unroll
+                for (int u = 0; u < NEQ; u++) ssh += (u < lim) ? v[u] : 0.0f;
+            }
+            ssh = group_reduce_f<CHA, false>(ssh);
+            if (own2) {
+                float a = rn;
+                const int r0 = blk_r0, d = blk_d;
+                if (d > 1) {   // block-average inside the SOC / PSD block so the scaled cone is still the cone
+                    float s0 = ssh, s1 = 0;
+                    if (d <= 12) {
+                    } else {
+                        int i = 0;
+                        for (; i + 1 < d; i += 2) { s0 += fRn[r0 + i]; s1 += fRn[r0 + i + 1]; }
+                        if (i < d) s0 += fRn[r0 + i];
+                    }
+                    a = (s0 + s1) * __builtin_amdgcn_rcpf((float)d);
+                }
+                fDt[i2] = __builtin_amdgcn_rsqf(clampf(a));
+            }
+            F2_EACC(1);      // block sums, row factor
+            __syncthreads();
+            F2_EACC(2);      // the barrier
+            {
+                // every scaling factor of this pass is requested in ONE batch (the FP32 tiles leave the registers for it); multiplying as the values
+                // arrive -- what the scheduler made of the plain loops -- kept two reads in flight: ~10 LDS round trips per pass instead of ~2
+                const float ej = fEt[j1 < NP ? j1 : 0];            // pad entries are 0
+                const float di = fDt[i2 < MP ? i2 : 0];
+                const f2v *d2 = reinterpret_cast<const f2v *>(fDt + T1 * c1);
+                const f2v *e2 = reinterpret_cast<const f2v *>(fEt + T2 * c2);
+                f2v dd[T1 / 2], ee[T2 / 2];
+#pragma unroll
+                for (int k = 0; k < T1 / 2; k++) dd[k] = d2[k];
+#pragma unroll
+                for (int k = 0; k < T2 / 2; k++) ee[k] = e2[k];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int k = 0; k < T1 / 2; k++) atv[k] *= dd[k];
+#pragma unroll
+                for (int k = 0; k < T2 / 2; k++) arv[k] *= ee[k];
+                ecum *= ej; dcum *= di;
+                if constexpr (HASP) {
+                    const Co cop(wave);
+                    const float eg = fEt[cop.jg < NP ? cop.jg : 0];
+                    const float2 *g2 = reinterpret_cast<const float2 *>(fEt + TG * cop.cg);
+#pragma unroll
+                    for (int k = 0; k < TG / 2; k++) { const float2 ee = g2[k]; pf[2 * k] *= eg * ee.x; pf[2 * k + 1] *= eg * ee.y; }
+                }
+                Eacc *= (double)ej; Dacc *= (double)di;
+            }
+            F2_EACC(3);      // factor reads + scaling
+            // no barrier: the next pass writes the other ping-pong buffers (and the row norms, last read before the barrier above)
+        }
+        F2_STAMP(15);      // (the 26 passes)
+        if (own1) sm[L::O_EV + j1] = Eacc;
+        if (own2) sm[L::O_DV + i2] = Dacc;
         __syncthreads();
         double r[2] = {0, 0};
         for (int i = tid; i < m; i += NT) { const double v = sm[L::O_BV + i] * sm[L::O_DV + i]; sm[L::O_BV + i] = v; r[0] = fmax(r[0], fabs(v)); }
@@ -1368,52 +1491,4 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
     if (threadIdx.x < 24) so[(size_t)inst * m + threadIdx.x] = (double)f2_tstamp[threadIdx.x];
     if (threadIdx.x < 8) so[(size_t)inst * m + 24 + threadIdx.x] = (double)f2_tstamp2[threadIdx.x];
 #endif
-}
-
-
-// ------------------------------------------------------------------------------------------------------------------
-// The equilibration passes of k_fwd2 as a kernel of their own: one workgroup per instance, the same tile layouts and the same arithmetic
-// (ce_f2_ruiz.inc is the ONE source of both), D and E written to DEg[inst][MP + NP].  Only the FP32 tiles and a few vectors are live, so
-// F2_EQ_WPS (default 5) waves per SIMD fit instead of k_fwd2's three: what is a chain of exposed LDS round trips and barriers there is hidden
-// behind other instances here.  Plain cones (no quadratic objective, no PSD / exponential blocks: those equilibrate inside k_fwd2).
-#ifndef F2_EQ_WPS
-#define F2_EQ_WPS 5
-#endif
-template <int CHT, int T1, int CHA, int T2, int CHG, int TG, int NTH = 256, bool WL = false>
-__global__ void __launch_bounds__(NTH, F2_EQ_WPS)
-k_f2_equil(DevT T, const double *__restrict__ Avals, const int *__restrict__ idx_at, const int *__restrict__ idx_ar, double *__restrict__ DEg) {
-    constexpr bool HASP = false;
-    constexpr int NT = NTH, NW = NTH / 64;
-    using L = F2<CHT, T1, CHA, T2, CHG, TG, NW>;
-    using Co = F2Co<CHT, CHA, CHG>;
-    constexpr int MP = L::MP, NP = L::NP, OY = L::OY;
-    extern __shared__ __attribute__((aligned(16))) double sm[];
-    int *const socr = reinterpret_cast<int *>(sm + L::O_G), *const socd = socr + MP;
-    const int tid = threadIdx.x, inst = blockIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n = T.n, m = T.m;
-    const double *const vals = Avals + (size_t)inst * T.nnz_aug;
-    const double *const Pvals_g = nullptr; const int *const idx_p = nullptr; const int nnzP = 0;      // (names the fragment mentions in its quadratic-objective branches)
-    (void)Pvals_g; (void)idx_p; (void)nnzP;
-#ifdef CE_TIMING
-    __shared__ long long f2_tstamp[24];
-    long long f2_eacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, f2_t0 = 0;
-    (void)f2_tstamp; (void)f2_eacc; (void)f2_t0;
-#endif
-    for (int i = tid; i < L::O_G; i += NT) sm[i] = 0.0;
-    for (int i = tid; i < MP; i += NT) {
-        int r0 = -1, d = 0;
-        if (i < m) { const int c = T.rowcone[i]; if (c >= 0) { r0 = T.qoff[c]; d = T.qoff[c + 1] - r0; } }
-        socr[i] = r0; socd[i] = d;
-    }
-    __syncthreads();
-    {
-#define F2_RUIZ_SPLIT 1
-#include "ce_f2_ruiz.inc"
-#undef F2_RUIZ_SPLIT
-    }
-    __syncthreads();
-    double *de = DEg + (size_t)inst * (MP + NP);
-    for (int i = tid; i < MP; i += NT) de[i] = i < m ? sm[L::O_DV + i] : 1.0;
-    for (int j = tid; j < NP; j += NT) de[MP + j] = j < n ? sm[L::O_EV + j] : 1.0;
 }

@@ -12,10 +12,7 @@ namespace {
 #error "compile with -DCE_F2_KIND=0|1|2"
 #endif
 
-#define F2_ARGS a.T, a.S, a.Abm, a.q, a.sqk, a.sqb, a.idx_at, a.idx_ar, a.idx_b, a.x, a.y, a.s, a.iters, a.status, a.resid, a.P, a.nnz_p, a.idx_p, a.row_perm, a.order, a.iters2, a.DE
-// the equilibration kernel in front of the solve (plain cones; a.DE == NULL: the passes run inside k_fwd2).  The kernel's row layout is k_fwd2's: a.T carries the packed cone layout of WL launches
-#define LAUNCH_EQ(NTHREADS, CHT, T1, CHA, T2, CHG, TG, WLV) do { if (a.DE && a.S.normalize) { using LE_ = F2<CHT, T1, CHA, T2, CHG, TG, NTHREADS / 64>; \
-    hipLaunchKernelGGL((k_f2_equil<CHT, T1, CHA, T2, CHG, TG, NTHREADS, WLV>), dim3(B), dim3(NTHREADS), (size_t)(LE_::O_G + LE_::MP) * 8, st, a.T, a.Abm, a.idx_at, a.idx_ar, a.DE); } } while (0)
+#define F2_ARGS a.T, a.S, a.Abm, a.q, a.sqk, a.sqb, a.idx_at, a.idx_ar, a.idx_b, a.x, a.y, a.s, a.iters, a.status, a.resid, a.P, a.nnz_p, a.idx_p, a.row_perm, a.order, a.iters2
 #define LAUNCH_F2(NTHREADS, ...) hipLaunchKernelGGL((k_fwd2<__VA_ARGS__>), dim3(B), dim3(NTHREADS), lds, st, F2_ARGS)
 #define SETATTR(...) do { hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fwd2<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes); if (e_ != hipSuccess) return e_; } while (0)
 
@@ -23,21 +20,21 @@ namespace {
 int ce_launch_fwd2_plain(int variant, int B, size_t lds, hipStream_t st, const CeFwdArgs &a) {
     if (a.row_perm) {      // rows packed so that every cone is wave-local (WL instantiations)
         switch (variant) {
-        case 0: LAUNCH_EQ(256, 16, 2, 8, 2, 16, 2, true); LAUNCH_F2(256, 16, 2, 8, 2, 16, 2, false, 256, false, true); break;
-        case 1: LAUNCH_EQ(256, 8, 8, 4, 8, 8, 4, true); LAUNCH_F2(256, 8, 8, 4, 8, 8, 4, false, 256, false, true); break;
-        case 2: LAUNCH_EQ(256, 4, 26, 2, 26, 4, 14, true); LAUNCH_F2(256, 4, 26, 2, 26, 4, 14, false, 256, false, true); break;
-        case 3: LAUNCH_EQ(512, 8, 20, 2, 32, 8, 8, true); LAUNCH_F2(512, 8, 20, 2, 32, 8, 8, false, 512, false, true); break;
-        case 4: LAUNCH_EQ(512, 4, 30, 4, 26, 4, 26, true); LAUNCH_F2(512, 4, 30, 4, 26, 4, 26, false, 512, false, true); break;
+        case 0: LAUNCH_F2(256, 16, 2, 8, 2, 16, 2, false, 256, false, true); break;
+        case 1: LAUNCH_F2(256, 8, 8, 4, 8, 8, 4, false, 256, false, true); break;
+        case 2: LAUNCH_F2(256, 4, 26, 2, 26, 4, 14, false, 256, false, true); break;
+        case 3: LAUNCH_F2(512, 8, 20, 2, 32, 8, 8, false, 512, false, true); break;
+        case 4: LAUNCH_F2(512, 4, 30, 4, 26, 4, 26, false, 512, false, true); break;
         default: return -1;
         }
         return 0;
     }
     switch (variant) {
-    case 0: LAUNCH_EQ(256, 16, 2, 8, 2, 16, 2, false); LAUNCH_F2(256, 16, 2, 8, 2, 16, 2); break;
-    case 1: LAUNCH_EQ(256, 8, 8, 4, 8, 8, 4, false); LAUNCH_F2(256, 8, 8, 4, 8, 8, 4); break;
-    case 2: LAUNCH_EQ(256, 4, 26, 2, 26, 4, 14, false); LAUNCH_F2(256, 4, 26, 2, 26, 4, 14); break;
-    case 3: LAUNCH_EQ(512, 8, 20, 2, 32, 8, 8, false); LAUNCH_F2(512, 8, 20, 2, 32, 8, 8, false, 512); break;
-    case 4: LAUNCH_EQ(512, 4, 30, 4, 26, 4, 26, false); LAUNCH_F2(512, 4, 30, 4, 26, 4, 26, false, 512); break;
+    case 0: LAUNCH_F2(256, 16, 2, 8, 2, 16, 2); break;
+    case 1: LAUNCH_F2(256, 8, 8, 4, 8, 8, 4); break;
+    case 2: LAUNCH_F2(256, 4, 26, 2, 26, 4, 14); break;
+    case 3: LAUNCH_F2(512, 8, 20, 2, 32, 8, 8, false, 512); break;
+    case 4: LAUNCH_F2(512, 4, 30, 4, 26, 4, 26, false, 512); break;
     default: return -1;
     }
     return 0;

@@ -34,7 +34,6 @@ struct CeFwdArgs {
     double *gA, *gG;            // global residency workspaces of the size-generic kernel
     int *iters2;                // k_fwd2: second copy of the iteration counts (engine-owned; NULL: not wanted)
     const int *order;           // k_fwd2 / k_fwd3: workgroup -> instance (NULL: identity); longest-first dispatch from the previous call's iteration counts
-    double *DE;                 // k_fwd2 (plain cones): [B][MP + NP] equilibration factors, filled by k_f2_equil in front of the solve (NULL: the passes run inside k_fwd2)
 };
 struct CeBwdArgs {
     DevT T; int nkcap, ldk;

@@ -81,8 +81,7 @@ struct ce_engine {
     bool wl = false; int wl_nq = 0; int *d_row_perm = nullptr, *d_k_rowcone = nullptr, *d_k_qoff = nullptr;   // rows packed so that cones are wave-local (k_fwd2 WL)
     // longest-first dispatch (ce_set_dispatch_history): workgroup -> instance order for the next solve of the same batch size, from this solve's iteration counts
     bool dispatch_history = false; int *d_order = nullptr; int order_B = 0, order_cap = 0;
-    int *d_iters2 = nullptr; int iters2_cap = 0, order_pending_B = 0;
-    double *d_DE = nullptr; size_t DE_bytes = 0; bool equil_kernel = false;      // k_f2_equil's output ([B][MP + NP] doubles); equil_kernel: plain cones on k_fwd2 (CE_F2_EQUIL_KERNEL=0 disables)      // engine-owned copy of the last solve's iteration counts (the caller's buffer may be gone when the order is computed)
+    int *d_iters2 = nullptr; int iters2_cap = 0, order_pending_B = 0;      // engine-owned copy of the last solve's iteration counts (the caller's buffer may be gone when the order is computed)
     bool f3 = false; int *d_idx_at3 = nullptr, *d_idx_ar3 = nullptr, *d_slot_soc = nullptr;      // third-generation forward kernel (k_fwd3, fwd_mode 5): iteration-tile gather maps, cone layout of the y slots
     int brt_variant = -1;                          // register-tiled backward kernel variant (-1: generic kernel)
     // two-tile plan of the register-tiled adjoint: a smaller tile serves the instances it holds, the worst-case tile re-runs the ones it flagged.  The smaller
@@ -433,7 +432,6 @@ int ce_create(const ce_template *tpl, int device, ce_handle *out) {
             HIPCHK(hipMemcpy(h->d_idx_ar, iar.data(), sizeof(int) * iar.size(), hipMemcpyHostToDevice));
             HIPCHK(hipMemcpy(h->d_idx_b, ib.data(), sizeof(int) * T.m, hipMemcpyHostToDevice));
             h->f2_variant = v; h->f2_ldg = ldg; h->fwd_lds = by; h->fwd_mode = 4;
-            { const char *e = getenv("CE_F2_EQUIL_KERNEL"); h->equil_kernel = !has_p && T.ns == 0 && T.nep + T.np == 0 && !(e && atoi(e) == 0); }
             {   // five more vectors (w_prev, x_prev, f_prev, f_save, x_save) when they fit: Anderson acceleration available
                 const F2Dims dd = f2_dims(v);
                 const size_t by_aa = by + 5 * (size_t)dd.VP * 8;
@@ -540,7 +538,7 @@ int ce_destroy(ce_handle h) {
     if (!h) return CE_OK;
     hipSetDevice(h->device);
     hipFree(h->d_rowidx); hipFree(h->d_colidx); hipFree(h->d_rowcone); hipFree(h->d_qoff); hipFree(h->d_soff); hipFree(h->d_sord); hipFree(h->d_pw); hipFree(h->d_idx_p); hipFree(h->d_pmap); hipFree(h->d_prow); hipFree(h->d_pcol);
-    hipFree(h->wsA); hipFree(h->wsdA); hipFree(h->gws); hipFree(h->d_idx_at); hipFree(h->d_idx_ar); hipFree(h->d_idx_b); hipFree(h->d_order); hipFree(h->d_iters2); hipFree(h->d_DE); hipFree(h->d_nkmax); if (h->h_nkmax) hipHostFree(h->h_nkmax); if (h->nk_ev) hipEventDestroy(h->nk_ev); hipFree(h->d_row_perm); hipFree(h->d_idx_at3); hipFree(h->d_idx_ar3); hipFree(h->d_slot_soc); hipFree(h->d_k_rowcone); hipFree(h->d_k_qoff); hipFree(h->d_csc_ptr); hipFree(h->d_csr_ptr); hipFree(h->d_csr_col); hipFree(h->d_csr_src);
+    hipFree(h->wsA); hipFree(h->wsdA); hipFree(h->gws); hipFree(h->d_idx_at); hipFree(h->d_idx_ar); hipFree(h->d_idx_b); hipFree(h->d_order); hipFree(h->d_iters2); hipFree(h->d_nkmax); if (h->h_nkmax) hipHostFree(h->h_nkmax); if (h->nk_ev) hipEventDestroy(h->nk_ev); hipFree(h->d_row_perm); hipFree(h->d_idx_at3); hipFree(h->d_idx_ar3); hipFree(h->d_slot_soc); hipFree(h->d_k_rowcone); hipFree(h->d_k_qoff); hipFree(h->d_csc_ptr); hipFree(h->d_csr_ptr); hipFree(h->d_csr_col); hipFree(h->d_csr_src);
     hipFree(h->d_sp_drow); hipFree(h->d_sp_srow_col); hipFree(h->d_sp_scol_ptr); hipFree(h->d_sp_scol_row); hipFree(h->d_sp_rowslot); hipFree(h->d_sp_sing_i); hipFree(h->d_sp_sing_v); hipFree(h->d_sp_AdT); hipFree(h->d_sp_sval); hipFree(h->d_bpos); hipFree(h->d_aa_ws); hipFree(h->d_summary);
     for (auto &v : h->ev) for (auto &p : v) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
     for (auto &e : h->ev_pool) hipEventDestroy(e);
@@ -656,11 +654,6 @@ int ce_solve_qp(ce_handle h, int B, const double *A_vals, long sA_k, long sA_b, 
             fa.T.ldg = h->f2_ldg;
             if (h->wl) {      // rows packed for the wave-local cone exchange: the kernel sees the cone layout in ITS row order
                 fa.row_perm = h->d_row_perm; fa.T.rowcone = h->d_k_rowcone; fa.T.qoff = h->d_k_qoff; fa.T.nq = h->wl_nq; fa.T.l = 0;
-            }
-            if (h->equil_kernel && !P_vals && S.normalize) {      // D, E of every instance from the equilibration kernel, launched by ce_launch_fwd2_plain in front of the solve
-                const F2Dims dd = f2_dims(h->f2_variant);
-                rc = ensure(&h->d_DE, &h->DE_bytes, sizeof(double) * (size_t)B * (dd.MP + dd.NP)); if (rc) return rc;
-                fa.DE = h->d_DE;
             }
             if (P_vals) lrc = ce_launch_fwd2_qp(h->f2_variant, B, h->fwd_lds, st, fa);
             else if (T.ns > 0 || T.nep + T.np > 0) lrc = ce_launch_fwd2_psd(h->f2_variant, B, h->fwd_lds, st, fa);
