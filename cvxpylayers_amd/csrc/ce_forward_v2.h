@@ -166,6 +166,46 @@ __device__ __forceinline__ void for_each_idx(const int *__restrict__ base, int t
     }
 }
 
+// Gather of one register tile in TWO fenced phases: every value load of the tile is issued (through a clamped index: structural zeros read entry 0 and are
+// masked afterwards) before the first value is used.  Left to itself the compiler emitted `global_load ; s_waitcnt vmcnt(0) ; multiply` per entry -- and, for
+// the guarded form `ix >= 0 ? vals[ix] : 0`, a branch around every load: 26 global round trips IN SERIES per gather, 25-36 k cycles of a 690 k-cycle instance
+// (profiles/r05/c_gather_serialised.txt).   f(k, ix, value) consumes entry k.
+#ifndef F2_GATHER_CHUNK
+#define F2_GATHER_CHUNK 14
+#endif
+template <int TT, class F>
+__device__ __forceinline__ void gather_tile(const int *__restrict__ base, int t, const double *__restrict__ vals, F &&f) {
+    const int4 *ip = reinterpret_cast<const int4 *>(reinterpret_cast<const char *>(base) + (unsigned)t * (unsigned)(idx_stride<TT> * sizeof(int)));
+    int4 ix4[idx_stride<TT> / 4];
+#pragma unroll
+    for (int c4 = 0; c4 < idx_stride<TT> / 4; c4++) ix4[c4] = ip[c4];
+    // in chunks of F2_GATHER_CHUNK entries: one global round trip per chunk, and a register peak of one chunk (the whole tile at once pushed loop-carried
+    // values of the iteration into scratch)
+    constexpr int CHK = F2_GATHER_CHUNK < TT ? F2_GATHER_CHUNK : TT;
+#pragma unroll
+    for (int k0 = 0; k0 < TT; k0 += CHK) {
+        double raw[CHK];
+#pragma unroll
+        for (int u = 0; u < CHK; u++) {
+            const int k = k0 + u < TT ? k0 + u : TT - 1;
+            const int4 q = ix4[k >> 2];
+            const int ix = (k & 3) == 0 ? q.x : ((k & 3) == 1 ? q.y : ((k & 3) == 2 ? q.z : q.w));
+            raw[u] = vals[ix < 0 ? 0 : ix];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < CHK; u++) {
+            const int k = k0 + u;
+            if (k < TT) {
+                const int4 q = ix4[k >> 2];
+                const int ix = (k & 3) == 0 ? q.x : ((k & 3) == 1 ? q.y : ((k & 3) == 2 ? q.z : q.w));
+                f(k, ix, raw[u]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // Orders LDS writes of this wave before LDS reads of this wave (other lanes' data).  LDS instructions of one wave execute in order,
 // so no hardware wait is needed beyond what the compiler inserts for the data dependence; the fences keep the COMPILER from moving
 // the reads above the writes.
@@ -391,7 +431,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
     }
     __syncthreads();
     ce_math_table_init(sm + L::O_MT, tid);
-    for (int i = tid; i < m; i += NT) { const int ix = idx_b[i]; sm[L::O_BV + i] = ix >= 0 ? vals[ix] : 0.0; sm[L::O_DV + i] = 1.0; }
+    for (int i = tid; i < m; i += NT) { const int ix = idx_b[i]; const double v = vals[ix < 0 ? 0 : ix]; sm[L::O_BV + i] = ix >= 0 ? v : 0.0; sm[L::O_DV + i] = 1.0; }
     for (int j = tid; j < n; j += NT) { sm[L::O_CV + j] = qv[j * sqk + inst * sqb]; sm[L::O_EV + j] = 1.0; }
     __syncthreads();
     {
@@ -420,11 +460,13 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
         if constexpr (HASP) {
             const double *pv = Pvals_g + (size_t)inst * nnzP;
 #pragma unroll
-            for (int k = 0; k < TG; k++) { const int ix = idx_p[tid * idx_stride<TG> + k]; pf[k] = ix >= 0 ? (float)pv[ix] : 0.0f; }
+            for (int k = 0; k < TG; k++) { const int ix = idx_p[tid * idx_stride<TG> + k]; const double v = pv[ix < 0 ? 0 : ix]; pf[k] = ix >= 0 ? (float)v : 0.0f; }
         }
         float *const fPn = reinterpret_cast<float *>(sm + L::O_S3);          // column norms of P-hat (= row norms: symmetric)
-        for_each_idx<T1>(idx_at, tid, [&](auto, int k, int ix) { atv[k >> 1][k & 1] = ix >= 0 ? (float)(-vals[ix]) : 0.0f; });   // A = -A_cvx (diffcp_if.py:65)
-        for_each_idx<T2>(idx_ar, tid, [&](auto, int k, int ix) { arv[k >> 1][k & 1] = ix >= 0 ? (float)(-vals[ix]) : 0.0f; });
+        // (every gather below loads UNCONDITIONALLY through a clamped index and selects afterwards: a guarded load `ix >= 0 ? vals[ix] : 0` is a branch around the load with
+        //  its own `s_waitcnt vmcnt(0)` -- 26 or 52 global round trips IN SERIES per gather, 25-36 k cycles each: profiles/r05/c_gather_serialised.txt)
+        gather_tile<T1>(idx_at, tid, vals, [&](int k, int ix, double v) { atv[k >> 1][k & 1] = ix >= 0 ? (float)(-v) : 0.0f; });   // A = -A_cvx (diffcp_if.py:65)
+        gather_tile<T2>(idx_ar, tid, vals, [&](int k, int ix, double v) { arv[k >> 1][k & 1] = ix >= 0 ? (float)(-v) : 0.0f; });
         float *const fEt0 = reinterpret_cast<float *>(sm + L::O_S1), *const fEt1 = reinterpret_cast<float *>(sm + L::O_S2);
         float *const fDt0 = reinterpret_cast<float *>(sm + L::O_U + OY), *const fDt1 = reinterpret_cast<float *>(sm + L::O_UT + OY);
         float *const fRn = reinterpret_cast<float *>(sm + L::O_ZB + OY);
@@ -568,12 +610,12 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
     auto materialize_at = [&](const Co &co) {
         const double ej = sm[L::O_EV + (co.j1 < NP ? co.j1 : 0)];
         const double *dv = sm + L::O_DV + 2 * co.c1;
-        for_each_idx<T1>(idx_at, co.t, [&](auto, int k, int ix) { at[k] = ix >= 0 ? -vals[ix] * (dv[2 * CHT * (k >> 1) + (k & 1)] * ej) : 0.0; });
+        gather_tile<T1>(idx_at, co.t, vals, [&](int k, int ix, double v) { at[k] = (-v * (dv[2 * CHT * (k >> 1) + (k & 1)] * ej)) * (ix >= 0 ? 1.0 : 0.0); });
     };
     auto materialize_ar = [&](const Co &co) {
         const double di = sm[L::O_DV + (co.i2 < MP ? co.i2 : 0)];
         const double *evs = sm + L::O_EV + T2 * co.c2;
-        for_each_idx<T2>(idx_ar, co.t, [&](auto, int k, int ix) { ar[k] = ix >= 0 ? -vals[ix] * (di * evs[k]) : 0.0; });
+        gather_tile<T2>(idx_ar, co.t, vals, [&](int k, int ix, double v) { ar[k] = (-v * (di * evs[k])) * (ix >= 0 ? 1.0 : 0.0); });
     };
     // P-hat row segment of the (jg, cg) layout, re-materialised wherever it is needed (S formation, P-hat g_x, the residual check)
     double gPg = 0;                                                  // g_x^T P-hat g_x
@@ -582,7 +624,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
         const double *pv = Pvals_g + (size_t)inst * nnzP;
         const double ej = sm[L::O_EV + (co.jg < NP ? co.jg : 0)];
         const double *evs = sm + L::O_EV + TG * co.cg;
-        for_each_idx<TG>(idx_p, co.t, [&](auto, int k, int ix) { pg[k] = ix >= 0 ? pv[ix] * (ej * evs[k]) : 0.0; });
+        gather_tile<TG>(idx_p, co.t, pv, [&](int k, int ix, double v) { pg[k] = (v * (ej * evs[k])) * (ix >= 0 ? 1.0 : 0.0); });
     };
     // The column groups j1 == n and j1 == n + 1 (idle in the A^T product) carry phi as two extra "columns", so that the
     // A^T w_y phase also yields phi_y . w_y and phi_x . w_x (the numerator of tau-tilde) without a separate reduction.

@@ -109,6 +109,39 @@ def test_broadcast_unbatched_parameter_sums_gradient_over_batch():
 
 
 @pytest.mark.gpu
+def test_shared_parameter_feeds_two_layers():
+    # reference tests/test_torch.py:387-413 (test_shared_parameter): ONE parameter tensor A feeds two least-squares layers with different constants b1, b2; the
+    # gradient of cat(x1, x2) with respect to A is the sum of both layers' contributions (there: gradcheck; here: autograd of the closed form x = (A^T A)^-1 A^T b)
+    rng = np.random.default_rng(243)
+    m, n = 10, 5
+    b1, b2 = rng.standard_normal(m), rng.standard_normal(m)
+
+    def ls_template(bc):
+        def builder(Ap):
+            Ac = np.zeros((m + 2, n + 1)); bcone = np.zeros(m + 2)
+            Ac[0, n] = -1.0; bcone[0] = 1.0                 # s0 = 1 + t
+            Ac[1, n] = 1.0; bcone[1] = 1.0                  # s1 = 1 - t
+            Ac[2:, :n] = -2.0 * Ap; bcone[2:] = -2.0 * bc   # s_ = 2 (A x - b)
+            c = np.zeros(n + 1); c[n] = 1.0
+            return Ac, bcone, c
+        return template_from_affine_builder(builder, [(m, n)], {"z": 0, "l": 0, "q": [m + 2]}, [VariableRecovery(slice(0, n), None, (n,))])
+    args = {"eps": 1e-10, "acceleration_lookback": 0, "max_iters": 10000}          # the reference test's solver_args
+    layer1 = CvxpyLayer(template=ls_template(b1), solver_args=args)
+    layer2 = CvxpyLayer(template=ls_template(b2), solver_args=args)
+    torch.manual_seed(243)
+    A = torch.randn(m, n, dtype=torch.float64, device="cuda", requires_grad=True)
+    wts = torch.linspace(0.5, 1.5, 2 * n, dtype=torch.float64, device="cuda")
+    (x1,) = layer1(A); (x2,) = layer2(A)
+    (torch.cat((x1, x2)) * wts).sum().backward()
+    A2 = A.detach().clone().requires_grad_()
+    bt = torch.tensor(np.stack([b1, b2], axis=1), dtype=torch.float64, device="cuda")
+    xc = torch.linalg.solve(A2.t() @ A2, A2.t() @ bt)                               # (n, 2)
+    (torch.cat((xc[:, 0], xc[:, 1])) * wts).sum().backward()
+    assert torch.allclose(torch.cat((x1, x2)), torch.cat((xc[:, 0], xc[:, 1])).detach(), atol=1e-6)
+    assert torch.allclose(A.grad, A2.grad, atol=1e-5), (A.grad - A2.grad).abs().max()
+
+
+@pytest.mark.gpu
 def test_box_qp_clip_and_batch_of_one_keeps_its_axis():
     # tests/test_moreau.py:258-269 (clip) and tests/test_torch.py:668-702 (batch of 1 != unbatched)
     layer = CvxpyLayer(template=boxqp_template(3), solver_args={"eps": 1e-9})
