@@ -1,11 +1,7 @@
 // ce_forward_v2.h -- forward kernel, second generation: one instance per 256-thread workgroup (4 wave64), 3 workgroups
 // per CU, BOTH operand layouts of A-hat in registers, G in LDS.
 //
-//   at[T1] : thread (j1 = tid / CHT, c1 = tid % CHT) holds T1 / 2 row PAIRS of column j1, interleaved over the CHT lanes of the column:
-//            at[k] = A[2 CHT (k / 2) + 2 c1 + (k % 2)][j1],  k < T1                                              -> A^T v
-//            (the CHT lanes of a column read 16 CHT contiguous bytes per load instruction from the instance's column-major values -- a blocked segment
-//            per lane put every lane of a wave on a different cache line: 26 loads x 64 lines, 20 k cycles per gather -- and the vector operand of the
-//            product is the same 16 CHT bytes for every column group: an LDS broadcast)
+//   at[T1] : thread (j1 = tid / CHT, c1 = tid % CHT) holds the column segment  A[T1*c1 + k][j1],  k < T1      -> A^T v
 //   ar[T2] : thread (i2 = tid / CHA, c2 = tid % CHA) holds the row segment     A[i2][T2*c2 + k],  k < T2      -> A v
 //   G      : (rho_x I + A^T Dy A)^{-1}, n x ldg doubles in LDS; thread (jg = tid / CHG, cg = tid % CHG) multiplies
 //            the row segment G[jg][TG*cg + k], k < TG                                                          -> G v
@@ -44,8 +40,6 @@ struct F2 {
     static_assert(NTILE <= NWARP && LDP >= NPa, "one 16-row strip of S per wave; a panel row holds a whole row tile");
     static_assert(T1 % 2 == 0 && T2 % 2 == 0 && TG % 2 == 0, "segments must be even for 16-byte LDS reads");
     static_assert(CHT <= 16 && CHA <= 16 && CHG <= 16, "DPP butterflies stay inside a row of 16 lanes");
-    // row of slot k of the column-layout tile of lane c1 (pairs of rows, interleaved over the CHT lanes of a column; cone_engine.hip builds idx_at with the same formula)
-    __host__ __device__ static constexpr int at_row(int c1, int k) { return 2 * CHT * (k >> 1) + 2 * c1 + (k & 1); }
 };
 
 // a value that is equal in every lane, moved to scalar registers (frees VGPRs in the iteration loop)
@@ -94,23 +88,6 @@ __device__ __forceinline__ double seg_dot(const double (&tile)[TT], const double
 #pragma unroll
         for (int k = p * H; k < (p + 1) * H && k < NB; k++) {
             const double2 v = v2[k];
-            a0 = fma(tile[2 * k], v.x, a0);
-            a1 = fma(tile[2 * k + 1], v.y, a1);
-        }
-        if (p + 1 < PARTS) __builtin_amdgcn_sched_barrier(0);
-    }
-    return group_reduce<CH, false>(a0 + a1);
-}
-// interleaved register tile (F2::at_row) . LDS vector: pair u of the lane is vec[2 CH u], vec[2 CH u + 1]   (vec already offset by 2 c1, 16-byte aligned)
-template <int CH, int TT, int PARTS_ = F2_SEG_PARTS>
-__device__ __forceinline__ double seg_dot_il(const double (&tile)[TT], const double *vec) {
-    double a0 = 0, a1 = 0;
-    constexpr int NB = TT / 2, PARTS = NB > 8 ? PARTS_ : 1, H = (NB + PARTS - 1) / PARTS;
-#pragma unroll
-    for (int p = 0; p < PARTS; p++) {
-#pragma unroll
-        for (int k = p * H; k < (p + 1) * H && k < NB; k++) {
-            const double2 v = *reinterpret_cast<const double2 *>(vec + 2 * CH * k);
             a0 = fma(tile[2 * k], v.x, a0);
             a1 = fma(tile[2 * k + 1], v.y, a1);
         }
@@ -556,11 +533,11 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
                 // arrive -- what the scheduler made of the plain loops -- kept two reads in flight: ~10 LDS round trips per pass instead of ~2
                 const float ej = fEt[j1 < NP ? j1 : 0];            // pad entries are 0
                 const float di = fDt[i2 < MP ? i2 : 0];
-                const float *d2b = fDt + 2 * c1;                    // (row pairs 2 CHT k + 2 c1: F2::at_row)
+                const f2v *d2 = reinterpret_cast<const f2v *>(fDt + T1 * c1);
                 const f2v *e2 = reinterpret_cast<const f2v *>(fEt + T2 * c2);
                 f2v dd[T1 / 2], ee[T2 / 2];
 #pragma unroll
-                for (int k = 0; k < T1 / 2; k++) dd[k] = *reinterpret_cast<const f2v *>(d2b + 2 * CHT * k);
+                for (int k = 0; k < T1 / 2; k++) dd[k] = d2[k];
 #pragma unroll
                 for (int k = 0; k < T2 / 2; k++) ee[k] = e2[k];
                 __builtin_amdgcn_sched_barrier(0);
@@ -609,8 +586,8 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
     double at[T1], ar[T2];
     auto materialize_at = [&](const Co &co) {
         const double ej = sm[L::O_EV + (co.j1 < NP ? co.j1 : 0)];
-        const double *dv = sm + L::O_DV + 2 * co.c1;
-        gather_tile<T1>(idx_at, co.t, vals, [&](int k, int ix, double v) { at[k] = (-v * (dv[2 * CHT * (k >> 1) + (k & 1)] * ej)) * (ix >= 0 ? 1.0 : 0.0); });
+        const double *dv = sm + L::O_DV + T1 * co.c1;
+        gather_tile<T1>(idx_at, co.t, vals, [&](int k, int ix, double v) { at[k] = (-v * (dv[k] * ej)) * (ix >= 0 ? 1.0 : 0.0); });
     };
     auto materialize_ar = [&](const Co &co) {
         const double di = sm[L::O_DV + (co.i2 < MP ? co.i2 : 0)];
@@ -631,10 +608,10 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
     auto load_phi_tile = [&](const Co &co) {
         if (co.j1 == n) {
 #pragma unroll
-            for (int k = 0; k < T1; k++) at[k] = sm[L::O_PHI + OY + L::at_row(co.c1, k)];       // pads of PHI are zero
+            for (int k = 0; k < T1; k++) at[k] = sm[L::O_PHI + OY + T1 * co.c1 + k];       // pads of PHI are zero
         } else if (co.j1 == n + 1) {
 #pragma unroll
-            for (int k = 0; k < T1; k++) { const int row = L::at_row(co.c1, k); at[k] = (row < n) ? sm[L::O_PHI + OX + (row < NP ? row : 0)] : 0.0; }
+            for (int k = 0; k < T1; k++) at[k] = (T1 * co.c1 + k < n) ? sm[L::O_PHI + OX + T1 * co.c1 + k] : 0.0;
         }
     };
 
@@ -1031,7 +1008,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
         __syncthreads();
         materialize_at(co);
         {
-            const double a = seg_dot_il<CHT, T1>(at, sm + L::O_ZB + OY + 2 * c1);
+            const double a = seg_dot<CHT, T1>(at, sm + L::O_ZB + OY + T1 * c1);
             if (own1) { const double cj = sm[L::O_CV + j1]; sm[L::O_S1 + j1] = cj - a; sm[L::O_S2 + j1] = cj + a; }   // rhs for g_x ; k = c + A^T Dy b
         }
         __syncthreads();
@@ -1230,9 +1207,8 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
         F2_ACC(0);      // top of the iteration (acceleration bookkeeping, coordinates)
         // P1a: t = rho_x w_x - A^T w_y   (+ phi . w from the two spare column groups)
         {
-            // (column group n + 1 carries phi_x: its rows index w_x; slots of rows >= n hold zeros and meet whatever finite values follow w_x in LDS)
-            const double *wvec = sm + L::O_W + (j1 == n + 1 ? OX : OY) + 2 * c1;
-            const double a = seg_dot_il<CHT, T1>(at, wvec);
+            const double *wvec = sm + L::O_W + ((j1 == n + 1 && T1 * c1 < n) ? OX : OY) + T1 * c1;
+            const double a = seg_dot<CHT, T1>(at, wvec);
             if (own1) sm[L::O_TV + j1] = rho_x * sm[L::O_W + OX + j1] - a;
             else if (c1 == 0 && j1 <= n + 1) sm[L::O_WP + (j1 - n)] = a;          // phi_y . w_y , phi_x . w_x
         }
@@ -1426,7 +1402,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
             }
             __builtin_amdgcn_sched_barrier(0);
             {
-                const double aty_raw = seg_dot_il<CHT, T1>(at, sm + L::O_U + OY + 2 * c1);      // A-hat^T y-hat
+                const double aty_raw = seg_dot<CHT, T1>(at, sm + L::O_U + OY + T1 * c1);      // A-hat^T y-hat
                 if (own1) sm[L::O_ZB + OX + j1] = aty_raw;
             }
             if constexpr (HASP) {      // P-hat x-hat, parked in TV (free between the products of two iterations)

@@ -418,7 +418,7 @@ int ce_create(const ce_template *tpl, int device, ce_handle *out) {
             for (int r = 0; r < T.m; r++) ib[r] = ib0[korig[r]];
             for (int t = 0; t < NTH; t++) {
                 const int j1 = t / CHT, c1 = t % CHT, i2 = t / CHA, c2 = t % CHA;
-                for (int k = 0; k < T1; k++) { const int r = 2 * CHT * (k >> 1) + 2 * c1 + (k & 1); if (j1 < T.n && r < T.m) iat[(size_t)t * S1 + k] = pos[(size_t)korig[r] * T.n + j1]; }      // (F2::at_row: row pairs interleaved over the CHT lanes of a column)
+                for (int k = 0; k < T1; k++) { const int r = T1 * c1 + k; if (j1 < T.n && r < T.m) iat[(size_t)t * S1 + k] = pos[(size_t)korig[r] * T.n + j1]; }
                 for (int k = 0; k < T2; k++) { const int c = T2 * c2 + k; if (i2 < T.m && c < T.n) iar[(size_t)t * S2 + k] = pos[(size_t)korig[i2] * T.n + c]; }
             }
             if (h->wl) {
