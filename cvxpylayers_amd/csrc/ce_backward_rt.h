@@ -95,7 +95,7 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
     long long bacc[6] = {0, 0, 0, 0, 0, 0}, bt0 = 0;
 #endif
     CE_STAMP(0);
-    load_instance(T, Avals + (size_t)inst * T.nnz_aug, A, bv);
+    load_instance<20>(T, Avals + (size_t)inst * T.nnz_aug, A, bv);      // (20 entries per lane in flight: the metric configuration's 5100 values in ONE round trip instead of three)
     for (int i = tid; i < m; i += NTB) { vv[i] = yg[(size_t)inst * m + i] - sg[(size_t)inst * m + i]; dv[i] = dyg[(size_t)inst * m + i]; }      // dv: the incoming dy for now (one coalesced
     if (tid < 8) misc[tid] = 0;                                                                                                                    // pass; the per-cone code below used to read it from global memory row by row)
     __syncthreads();
@@ -701,12 +701,29 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
     for (int j = tid; j < n; j += NTB) xs[j] = xg[(size_t)inst * n + j];
     for (int i = tid; i < m; i += NTB) ys[i] = yg[(size_t)inst * m + i];
     __syncthreads();
-#pragma unroll 8
-    for (int k = tid; k < T.nnz_aug; k += NTB) {
-        const int i = T.rowidx[k], j = T.colidx[k];
-        const int jc = j < n ? j : 0;
-        const double val = (j < n) ? -(xs[jc] * vv[i] - ys[i] * rx[jc]) : -vv[i];
-        dAo[(size_t)inst * T.nnz_aug + k] = val;
+    {
+        // eight entries per step in three fenced stages -- index pairs (global), operands (LDS, unconditional through a clamped column), stores: the plain loop
+        // (even with `#pragma unroll 8`) compiled to one global round trip, a divergent branch on `j < n` around the LDS reads and a store PER ENTRY, twenty times
+        // in series per lane (13 k cycles of a 220 k-cycle instance: profiles/r05/d_bwd_output_serialised.txt)
+        constexpr int OU = 8;
+        double *const dArow = dAo + (size_t)inst * T.nnz_aug;
+        const int nnz = T.nnz_aug;
+        for (int k0 = tid; k0 < nnz; k0 += OU * NTB) {
+            int ii[OU], jj[OU];
+#pragma unroll
+            for (int u = 0; u < OU; u++) { const int kk = min(k0 + u * NTB, nnz - 1); ii[u] = T.rowidx[kk]; jj[u] = T.colidx[kk]; }
+            __builtin_amdgcn_sched_barrier(0);
+            double xv[OU], rv[OU], vi[OU], yi[OU];
+#pragma unroll
+            for (int u = 0; u < OU; u++) { const int jc = jj[u] < n ? jj[u] : 0; xv[u] = xs[jc]; rv[u] = rx[jc]; vi[u] = vv[ii[u]]; yi[u] = ys[ii[u]]; }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < OU; u++) {
+                const double va = -(xv[u] * vi[u] - yi[u] * rv[u]);
+                const double val = (jj[u] < n) ? va : -vi[u];
+                if (k0 + u * NTB < nnz) dArow[k0 + u * NTB] = val;
+            }
+        }
     }
     for (int j = tid; j <= n; j += NTB) dqo[j * sdqk + inst * sdqb] = (j < n) ? -rx[j] : 0.0;
     if (dPo) {

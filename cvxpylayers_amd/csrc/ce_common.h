@@ -155,11 +155,11 @@ __host__ __device__ inline size_t generic_lu_panel_doubles(int nkcap) { return (
 __device__ __forceinline__ double clamp_scale(double v) { return v < MIN_SCALE ? 1.0 : (v > MAX_SCALE ? MAX_SCALE : v); }
 
 // scatter one instance's boundary values (batch-major row of [A_cvx | b_cvx] values) into dense solver form
+template <int LU = 8>
 __device__ __forceinline__ void load_instance(const DevT &T, const double *vals, double *A, double *bv) {
     const int n = T.n, m = T.m, lda = T.lda, nnz = T.nnz_aug;
     // The first chunk of (value, row, column) triples is requested BEFORE the zero fill and its barrier, and every chunk keeps 3 x LU loads per lane
     // in flight: with one workgroup per instance this phase is a chain of HBM latencies (5 chunks of 4 used to cost ~24 k cycles at the metric shape).
-    constexpr int LU = 8;
     double v0[LU]; int r0[LU], c0[LU];
 #pragma unroll
     for (int u = 0; u < LU; u++) {
