@@ -21,6 +21,13 @@ constexpr double CE_RANK_TOL = 1e-11;
 
 thread_local std::string g_err;
 
+// compile-time loop: f(std::integral_constant<int, i>{}) for i < N (anything that indexes a register array by the loop variable: a plain `#pragma unroll` of a
+// large body can silently stay rolled and put the array in scratch)
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+
 // ------------------------------------------------------------------------------------------------
 // workgroup reductions
 template <int CTRL>

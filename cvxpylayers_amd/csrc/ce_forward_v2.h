@@ -17,10 +17,6 @@
 // Algorithm, constants and the order of operations per iterate are those of oracle/cone_oracle.c (SCS 3 restated).
 #pragma once
 
-template <class F, int... I>
-__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
-template <int N, class F>
-__device__ __forceinline__ void static_for(F &&f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 template <int CHT, int T1, int CHA, int T2, int CHG, int TG, int NWARP = 4>
 struct F2 {
