@@ -520,58 +520,52 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
     const int ridx0 = 255 - ra;            // search key of row ra + BGR i carries 255 - row in its eight lowest mantissa bits
     const int ilim = (NK + BGR - 1) / BGR;          // row slots in use
     const int lane_base = ((tid & 63) & ~(BGR - 1)) << 2;     // byte address of the first lane of this thread's row group for ds_bpermute
-    // LOOK-AHEAD (round 5).  The pivot of column k + 1 is searched and published INSIDE step k, as soon as the two column slots that can hold column k + 1 have
-    // received pivot k's update -- by the 16 (32) lanes that own the column, while everybody else carries on with the rest of the update.  The barrier of step
-    // k + 1 then finds the column already published: the search (a quarter of a pivot's time, with 240 lanes waiting for 16) leaves the critical path of every
-    // wave but the owners'.  F2_BWD_LOOKAHEAD=0 restores the search at the top of the step.
-    auto search_publish = [&](auto jc, int kq) {      // the lanes with cb == kq % BGC: arg max |K[r][kq]| over the unused rows, the column and the pivot record -> LDS
-        constexpr int jq = decltype(jc)::value;
-        const int bufq = kq & 1;
-        double *cbq = colbuf + bufq * BGR * TI;
-        // arg max as ONE v_max_f64 per candidate: positive doubles order like their bit patterns, so the row index rides in the 8 lowest mantissa bits
-        // (255 - r: ties go to the smallest row).  Branch-free (a used row contributes the key 0), bare instruction (fmax() canonicalises both operands first).
-        double best = 0.0;       // key 0: no candidate
-        const unsigned alive = nkmask & ~rowdone;      // bit i: row ra + BGR i exists and has not served as pivot
 #pragma unroll
-        for (int i = 0; i < TI; i++) {
-            const int am = __builtin_amdgcn_sbfe((int)alive, i, 1);       // 0 or -1 (v_bfe_i32)
-            const double v = kt[i][jq];
-            const int lo = ((__double2loint(v) & ~0xFF) | (ridx0 - BGR * i)) & am;
-            best = vmax_abs(best, __hiloint2double(__double2hiint(v) & am, lo));      // (|.| is an operand modifier of the instruction: the sign bit rides along)
-        }
-        best = vmax_raw(best, dpp_mov<0xB1>(best));     // quad_perm [1,0,3,2]
-        best = vmax_raw(best, dpp_mov<0x4E>(best));     // quad_perm [2,3,0,1]
-        best = vmax_raw(best, dpp_mov<0x141>(best));    // row_half_mirror
-        best = vmax_raw(best, dpp_mov<0x140>(best));    // row_mirror
-        if constexpr (BGR == 32) best = vmax_raw(best, __shfl_xor(best, 16));      // the column's owners span two DPP rows
-        const int bi = 255 - (__double2loint(best) & 0xFF);
-        const bool tiny = best < ptol;               // no acceptable pivot in this column (best == 0: no candidate row left, bi = 255 is no row)
-#pragma unroll
-        for (int i = 0; i < TI; i++) cbq[ra + BGR * i] = kt[i][jq];      // the whole column, unconditionally ...
-        if (ra == (bi & (BGR - 1))) {                // the lane that holds row bi (bi = 255: some lane, value 0)
-            const int ib = bi / BGR;
-            double pv = 0.0;
-#pragma unroll
-            for (int i = 0; i < TI; i++) pv = (ib == i) ? kt[i][jq] : pv;
-            if (bi < BGR * TI) cbq[bi] = 0.0;       // ... then the pivot row's own entry is overwritten with 0 (same wave: LDS writes stay in program order)
-            pinfo[2 * bufq] = tiny ? 0.0 : pv;
-            reinterpret_cast<int *>(pinfo + 2 * bufq + 1)[0] = bi;
-        }
-        if (ra == 0 && tiny) misc[2] |= 4;
-    };
-    if (cb == 0 && NK > 0) search_publish(std::integral_constant<int, 0>{}, 0);
-    static_for<TJ>([&](auto jkc) {
-        constexpr int jk = decltype(jkc)::value;
-        constexpr int jk1 = jk + 1 < TJ ? jk + 1 : jk;      // (slot jk + 1 where it exists)
+    for (int jk = 0; jk < TJ; jk++) {
         for (int ck = 0; ck < BGC; ck++) {
             const int k = BGC * jk + ck;
             if (k >= NK) break;
             const int buf = k & 1;
             double *cbuf = colbuf + buf * BGR * TI;
-            CE_BACC(0);      // (the look-ahead search of the previous step, for its owners; everybody else arrives here at once)
+            if (cb == ck) {   // the 16 lanes owning column k: pivot search + publish the column
+                // arg max |K[r][k]| over the rows not yet used, as ONE v_max_f64 per candidate: positive doubles order like their
+                // bit patterns, so the row index rides in the 8 lowest mantissa bits (255 - r: ties go to the smallest row).
+                // Branch-free (a used row contributes the key 0) and with the bare instruction: fmax() canonicalises both operands first
+                // (two more v_max_f64 per step of a chain every other wave is waiting for).
+                double best = 0.0;       // key 0: no candidate
+                const unsigned alive = nkmask & ~rowdone;      // bit i: row ra + BGR i exists and has not served as pivot
+#pragma unroll
+                for (int i = 0; i < TI; i++) {
+                    const int am = __builtin_amdgcn_sbfe((int)alive, i, 1);       // 0 or -1 (v_bfe_i32): a dead row's key is 0, with two ANDs instead of compares and selects
+                    const double v = kt[i][jk];
+                    const int lo = ((__double2loint(v) & ~0xFF) | (ridx0 - BGR * i)) & am;
+                    best = vmax_abs(best, __hiloint2double(__double2hiint(v) & am, lo));      // (|.| is an operand modifier of the instruction: the sign bit rides along)
+                }
+                best = vmax_raw(best, dpp_mov<0xB1>(best));     // quad_perm [1,0,3,2]
+                best = vmax_raw(best, dpp_mov<0x4E>(best));     // quad_perm [2,3,0,1]
+                best = vmax_raw(best, dpp_mov<0x141>(best));    // row_half_mirror
+                best = vmax_raw(best, dpp_mov<0x140>(best));    // row_mirror
+                if constexpr (BGR == 32) best = vmax_raw(best, __shfl_xor(best, 16));      // the column's owners span two DPP rows
+                const int bi = 255 - (__double2loint(best) & 0xFF);
+                const bool tiny = best < ptol;               // no acceptable pivot in this column (best == 0: no candidate row left, bi = 255 is no row)
+#pragma unroll
+                for (int i = 0; i < TI; i++) cbuf[ra + BGR * i] = kt[i][jk];      // the whole column, unconditionally ...
+                if (ra == (bi & (BGR - 1))) {                // the lane that holds row bi (bi = 255: some lane, value 0)
+                    const int ib = bi / BGR;
+                    double pv = 0.0;
+#pragma unroll
+                    for (int i = 0; i < TI; i++) pv = (ib == i) ? kt[i][jk] : pv;
+                    if (bi < BGR * TI) cbuf[bi] = 0.0;       // ... then the pivot row's own entry is overwritten with 0 (same wave: LDS writes stay in program order)
+                    pinfo[2 * buf] = tiny ? 0.0 : pv;
+                    reinterpret_cast<int *>(pinfo + 2 * buf + 1)[0] = bi;
+                }
+                if (ra == 0 && tiny) misc[2] |= 4;
+            }
+            CE_BACC(0);      // pivot search + publish (the column's owners; everybody else arrives here at once)
             __syncthreads();
             CE_BACC(1);      // the barrier
             // the record and this thread's multipliers are requested together (the multipliers do not depend on the record): one LDS round trip
+            // where the pivot row, then the pivot value, then the multipliers used to be three
             const double2 rec = *reinterpret_cast<const double2 *>(pinfo + 2 * buf);
             double cv[TI];
 #pragma unroll
@@ -581,71 +575,42 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
             const int prow = __builtin_amdgcn_readfirstlane(__double2loint(rec.y));
             const int ipv = prow / BGR;
             const double piv = rec.x;
-            // free variable (rank-deficient system): no row is consumed, nothing is updated.  readfirstlane: the value is the same in every lane, but only a
-            // scalar condition lets the compiler keep the loop body free of exec masking
-            const bool freev = __builtin_amdgcn_readfirstlane(fabs(piv) < ptol ? 1 : 0) != 0;
-            const bool has_next = k + 1 < NK, wrap = ck + 1 == BGC;      // column k + 1 lives in slot jk (lanes cb == ck + 1) or, past the slot's last column, in slot jk + 1 (lanes cb == 0)
-            double pinv = 0.0;
+            if (__builtin_amdgcn_readfirstlane(fabs(piv) < ptol ? 1 : 0)) continue;      // free variable (see above), no row is consumed.  readfirstlane: the value is the same in
+                                                                                          // every lane, but only a scalar condition lets the compiler keep the loop body free of exec masking
+            double pinv = __builtin_amdgcn_rcp(piv);           // hardware seed + two Newton steps (the IEEE divide expansion is
+            pinv = fma(fma(-piv, pinv, 1.0), pinv, pinv);      // three times as long and sits on the critical path of every pivot)
+            pinv = fma(fma(-piv, pinv, 1.0), pinv, pinv);
+            if (ra == (prow & (BGR - 1))) {
+                rowdone |= 1u << ipv;
+                if (cb == 0) { colof[prow] = k; pivrow[prow] = piv; }
+            }
+            CE_BACC(2);      // record + multipliers read, reciprocal
+            // pivot row: broadcast inside each 16-lane row
             double rw[TJ];
             const int src = lane_base + ((prow & (BGR - 1)) << 2);
-            if (!freev) {
-                pinv = __builtin_amdgcn_rcp(piv);                  // hardware seed + two Newton steps (the IEEE divide expansion is
-                pinv = fma(fma(-piv, pinv, 1.0), pinv, pinv);      // three times as long and sits on the critical path of every pivot)
-                pinv = fma(fma(-piv, pinv, 1.0), pinv, pinv);
-                if (ra == (prow & (BGR - 1))) {
-                    rowdone |= 1u << ipv;
-                    if (cb == 0) { colof[prow] = k; pivrow[prow] = piv; }
-                }
-                CE_BACC(2);      // record + multipliers read, reciprocal
-                // pivot row, broadcast inside each 16-lane row with ds_bpermute -- the two slots that can hold column k + 1 first
 #pragma unroll
-                for (int i = 0; i < TI; i++) {
-                    if (ipv == i) {      // uniform
+            for (int i = 0; i < TI; i++) {
+                if (ipv == i) {      // uniform
 #pragma unroll
-                        for (int j = jk; j <= jk1; j++) {
-                            const double v = kt[i][j];
-                            const int lo = __builtin_amdgcn_ds_bpermute(src, __double2loint(v)), hi = __builtin_amdgcn_ds_bpermute(src, __double2hiint(v));
-                            rw[j] = __hiloint2double(hi, lo);
-                        }
+                    for (int j = jk; j < TJ; j++) {
+                        const double v = kt[i][j];
+                        const int lo = __builtin_amdgcn_ds_bpermute(src, __double2loint(v)), hi = __builtin_amdgcn_ds_bpermute(src, __double2hiint(v));
+                        rw[j] = __hiloint2double(hi, lo);
                     }
                 }
-                if (cb <= ck) rw[jk] = 0.0;      // columns <= k of this slot are finished
-#pragma unroll
-                for (int i = 0; i < TI; i++) {
-                    if (i >= ilim) continue;     // uniform: pad row slots
-                    const double f = cv[i] * pinv;      // the pivot row's own entry was published as 0
-#pragma unroll
-                    for (int j = jk; j <= jk1; j++) kt[i][j] = fma(-f, rw[j], kt[i][j]);
-                }
             }
-            CE_BACC(3);      // pivot row by ds_bpermute + update, leading slots
-            if (has_next) {      // look-ahead: column k + 1 is final now; its owners search and publish it into the other buffer
-                if (!wrap) { if (cb == ck + 1) search_publish(std::integral_constant<int, jk>{}, k + 1); }
-                else if constexpr (jk + 1 < TJ) { if (cb == 0) search_publish(std::integral_constant<int, jk1>{}, k + 1); }
+            CE_BACC(3);      // pivot row by ds_bpermute
+            if (cb <= ck) rw[jk] = 0.0;      // columns <= k of this slot are finished
+#pragma unroll
+            for (int i = 0; i < TI; i++) {
+                if (i >= ilim) continue;     // uniform: pad row slots
+                const double f = cv[i] * pinv;      // the pivot row's own entry was published as 0
+#pragma unroll
+                for (int j = jk; j < TJ; j++) kt[i][j] = fma(-f, rw[j], kt[i][j]);
             }
-            if (!freev) {
-#pragma unroll
-                for (int i = 0; i < TI; i++) {
-                    if (ipv == i) {      // uniform
-#pragma unroll
-                        for (int j = jk1 + 1; j < TJ; j++) {
-                            const double v = kt[i][j];
-                            const int lo = __builtin_amdgcn_ds_bpermute(src, __double2loint(v)), hi = __builtin_amdgcn_ds_bpermute(src, __double2hiint(v));
-                            rw[j] = __hiloint2double(hi, lo);
-                        }
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < TI; i++) {
-                    if (i >= ilim) continue;
-                    const double f = cv[i] * pinv;
-#pragma unroll
-                    for (int j = jk1 + 1; j < TJ; j++) kt[i][j] = fma(-f, rw[j], kt[i][j]);
-                }
-            }
-            CE_BACC(4);      // rank-1 update, trailing slots
+            CE_BACC(4);      // rank-1 update
         }
-    });
+    }
     __syncthreads();
     CE_STAMP(5);
     // ---- solution: sol[colof[r]] = rhs[r] / pivot(r);  r_x -> rx, multipliers -> bv

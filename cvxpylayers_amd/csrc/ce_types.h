@@ -29,11 +29,10 @@ struct CeFwdArgs {
     const int *idx_at, *idx_ar, *idx_b;
     double *x, *y, *s; int *iters, *status; double *resid;
     const double *P; int nnz_p; const int *idx_p;
-    const int *row_perm;        // k_fwd2 WL variants: kernel row -> template row (NULL: rows in template order); k_fwd3: y slot -> template row (-1: padding slot)
-    const int *idx_at3, *idx_ar3, *slot_soc;   // k_fwd3: gather maps of the iteration tiles, cone layout of the y slots ([2][slots]: first slot of the slot's SOC, cone dimension)
+    const int *row_perm;        // k_fwd2 WL variants: kernel row -> template row (NULL: rows in template order)
     double *gA, *gG;            // global residency workspaces of the size-generic kernel
     int *iters2;                // k_fwd2: second copy of the iteration counts (engine-owned; NULL: not wanted)
-    const int *order;           // k_fwd2 / k_fwd3: workgroup -> instance (NULL: identity); longest-first dispatch from the previous call's iteration counts
+    const int *order;           // k_fwd2: workgroup -> instance (NULL: identity); longest-first dispatch from the previous call's iteration counts
 };
 struct CeBwdArgs {
     DevT T; int nkcap, ldk;
@@ -49,7 +48,6 @@ struct CeBwdArgs {
 int ce_launch_fwd2_plain(int variant, int B, size_t lds, hipStream_t st, const CeFwdArgs &a);   // zero / nonneg / SOC
 int ce_launch_fwd2_psd(int variant, int B, size_t lds, hipStream_t st, const CeFwdArgs &a);     // + PSD / exponential / power cones
 int ce_launch_fwd2_qp(int variant, int B, size_t lds, hipStream_t st, const CeFwdArgs &a);      // quadratic objective inside the kernel
-int ce_launch_fwd3(int B, size_t lds, hipStream_t st, const CeFwdArgs &a);                      // zero / nonneg / SOC, lane-broadcast products (ce_forward_v3.h)
 int ce_launch_fwd_rt(int variant, int B, size_t lds, hipStream_t st, const CeFwdArgs &a);
 int ce_launch_fwd_generic(int mode, int B, size_t lds, hipStream_t st, const CeFwdArgs &a);
 int ce_launch_bwd_rt_plain(int variant, int B, size_t lds, hipStream_t st, const CeBwdArgs &a);
@@ -59,7 +57,6 @@ int ce_launch_bwd_generic(int mode, int B, size_t lds, hipStream_t st, const CeB
 hipError_t ce_setattr_fwd2_plain(int bytes);
 hipError_t ce_setattr_fwd2_psd(int bytes);
 hipError_t ce_setattr_fwd2_qp(int bytes);
-hipError_t ce_setattr_fwd3(int bytes);
 hipError_t ce_setattr_fwd_rt(int bytes);
 hipError_t ce_setattr_fwd_generic(int bytes);
 hipError_t ce_setattr_bwd_rt_plain(int bytes);

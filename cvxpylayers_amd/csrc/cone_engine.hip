@@ -82,7 +82,6 @@ struct ce_engine {
     // longest-first dispatch (ce_set_dispatch_history): workgroup -> instance order for the next solve of the same batch size, from this solve's iteration counts
     bool dispatch_history = false; int *d_order = nullptr; int order_B = 0, order_cap = 0;
     int *d_iters2 = nullptr; int iters2_cap = 0, order_pending_B = 0;      // engine-owned copy of the last solve's iteration counts (the caller's buffer may be gone when the order is computed)
-    bool f3 = false; int *d_idx_at3 = nullptr, *d_idx_ar3 = nullptr, *d_slot_soc = nullptr;      // third-generation forward kernel (k_fwd3, fwd_mode 5): iteration-tile gather maps, cone layout of the y slots
     int brt_variant = -1;                          // register-tiled backward kernel variant (-1: generic kernel)
     // two-tile plan of the register-tiled adjoint: a smaller tile serves the instances it holds, the worst-case tile re-runs the ones it flagged.  The smaller
     // tile is chosen from the LARGEST system of the previous call of the same batch size (nk_*: device maximum, copied to pinned memory behind the launch)
@@ -238,37 +237,11 @@ static bool pack_rows(const ce_template *tpl, int W, std::vector<int> &korig, st
     return (int)korig.size() == m;
 }
 
-// Row order for k_fwd3 (ce_forward_v3.h): NPAIR pairs of lane rows own YO y slots each.  Every second-order cone gets a pair of its own and sits at
-// the head of it (slots 0 .. d-1: the head of the cone is lane 0 of the row, the cone's norm a reduction inside the row); the single rows -- zero-cone
-// rows, nonnegative rows, cones of one row -- fill the remaining slots in template order; slots left over are PADDING (all-zero rows: korig -1).
-//   korig[slot]: template row or -1;  socr[slot]: first slot of the slot's cone (-1: none);  socd[slot]: 0 zero row / padding, 1 nonnegative, d cone rows
-static bool pack_rows3(const ce_template *tpl, int YO, int NPAIR, std::vector<int> &korig, std::vector<int> &socr, std::vector<int> &socd) {
-    if (tpl->ns > 0 || tpl->nep + tpl->np > 0) return false;
-    const int MS = YO * NPAIR;
-    korig.assign(MS, -1); socr.assign(MS, -1); socd.assign(MS, 0);
-    std::vector<std::pair<int, int>> singles;      // (template row, kind 0 / 1)
-    for (int i = 0; i < tpl->z; i++) singles.push_back({i, 0});
-    for (int i = 0; i < tpl->l; i++) singles.push_back({tpl->z + i, 1});
-    int row = tpl->z + tpl->l, pair = 0;
-    std::vector<int> used(NPAIR, 0);
-    for (int c = 0; c < tpl->nq; c++) {
-        const int d = tpl->q[c];
-        if (d == 1) { singles.push_back({row, 1}); row += 1; continue; }
-        if (d > YO || pair >= NPAIR) return false;
-        for (int k = 0; k < d; k++) { const int sl = YO * pair + k; korig[sl] = row + k; socr[sl] = YO * pair; socd[sl] = d; }
-        used[pair] = d; row += d; pair++;
-    }
-    size_t nx = 0;
-    for (int p = 0; p < NPAIR && nx < singles.size(); p++)
-        for (int k = used[p]; k < YO && nx < singles.size(); k++, nx++) { const int sl = YO * p + k; korig[sl] = singles[nx].first; socd[sl] = singles[nx].second; socr[sl] = singles[nx].second ? sl : -1; }
-    return nx == singles.size();
-}
-
 extern "C" {
 
 const char *ce_last_error(void) { return g_err.c_str(); }
 int ce_abi_version(void) { return CE_ABI_VERSION; }
-int ce_acceleration_available(ce_handle h) { return (h && (h->fwd_mode == 4 || h->fwd_mode == 5) && h->aa_ok) ? 1 : 0; }
+int ce_acceleration_available(ce_handle h) { return (h && h->fwd_mode == 4 && h->aa_ok) ? 1 : 0; }
 int ce_struct_size(int which) { return which == 0 ? (int)sizeof(ce_template) : which == 1 ? (int)sizeof(ce_settings) : -1; }
 
 void ce_default_settings(ce_settings *s) {
@@ -457,39 +430,6 @@ int ce_create(const ce_template *tpl, int device, ce_handle *out) {
             break;
         }
     }
-    {   // third-generation forward kernel (ce_forward_v3.h): shapes of k_fwd2's variant 2 whose rows pack into 8 x 13 slots with one cone per pair of lane rows
-        const char *f3_env = getenv("CE_FWD3");                        // "1": run these templates on k_fwd3.  OPT-IN: measured on MI355X it does not beat k_fwd2 (profiles/r04/b_*, c_*)
-        constexpr int YO3 = 13, NPAIR3 = 8, XO3 = 13, TY3 = 26, TA3 = 25, MS3 = YO3 * NPAIR3, LDG3 = 58;
-        std::vector<int> ko, sr, sd;
-        if (h->fwd_mode == 4 && h->f2_variant == 2 && h->nnz_p == 0 && (f3_env && !strcmp(f3_env, "1")) && T.n <= 2 * TA3 && T.n <= 4 * XO3 - 1 && pack_rows3(tpl, YO3, NPAIR3, ko, sr, sd)) {
-            const int *V = F2_VARIANTS[2];
-            const int CHT = V[0], T1 = V[1], CHA = V[2], T2 = V[3], NTH = V[6];
-            const int S1 = (T1 + 3) & ~3, S2 = (T2 + 3) & ~3, S3a = (TY3 + 3) & ~3, S3r = (TA3 + 3) & ~3;
-            std::vector<int> pos((size_t)T.m * T.n, -1), ib0(T.m, -1), ib(MS3, -1), iat((size_t)S1 * NTH, -1), iar((size_t)S2 * NTH, -1), iat3((size_t)S3a * NTH, -1), iar3((size_t)S3r * NTH, -1), ssoc(2 * MS3);
-            for (int j = 0; j <= T.n; j++)
-                for (int k = tpl->indptr[j]; k < tpl->indptr[j + 1]; k++) { if (j < T.n) pos[(size_t)tpl->indices[k] * T.n + j] = k; else ib0[tpl->indices[k]] = k; }
-            auto at = [&](int slot, int col) -> int { return (slot < MS3 && ko[slot] >= 0 && col < T.n) ? pos[(size_t)ko[slot] * T.n + col] : -1; };
-            for (int r = 0; r < MS3; r++) { ib[r] = ko[r] >= 0 ? ib0[ko[r]] : -1; ssoc[r] = sr[r]; ssoc[MS3 + r] = sd[r]; }
-            for (int t = 0; t < NTH; t++) {
-                const int j1 = t / CHT, c1 = t % CHT, i2 = t / CHA, c2 = t % CHA;                       // k_fwd2's layouts (set-up), rows = y slots
-                for (int k = 0; k < T1; k++) if (j1 < T.n) iat[(size_t)t * S1 + k] = at(T1 * c1 + k, j1);
-                for (int k = 0; k < T2; k++) iar[(size_t)t * S2 + k] = at(i2, T2 * c2 + k);
-                const int wave = t / 64, lane = t % 64, rg = lane / 16, el = lane % 16, pair = t / 32, hh = rg & 1;   // the iteration tiles
-                const int jx = XO3 * wave + el;
-                for (int k = 0; k < TY3; k++) if (el < XO3 && jx < T.n) iat3[(size_t)t * S3a + k] = at(TY3 * rg + k, jx);
-                for (int k = 0; k < TA3; k++) if (el < YO3) iar3[(size_t)t * S3r + k] = at(YO3 * pair + el, TA3 * hh + k);
-            }
-            hipFree(h->d_idx_at); hipFree(h->d_idx_ar); hipFree(h->d_idx_b); hipFree(h->d_row_perm); h->d_idx_at = h->d_idx_ar = h->d_idx_b = h->d_row_perm = nullptr;
-            auto up = [&](int **dst, const std::vector<int> &v) -> int { HIPCHK(hipMalloc(dst, sizeof(int) * v.size())); HIPCHK(hipMemcpy(*dst, v.data(), sizeof(int) * v.size(), hipMemcpyHostToDevice)); return 0; };
-            if (up(&h->d_idx_at, iat) || up(&h->d_idx_ar, iar) || up(&h->d_idx_b, ib) || up(&h->d_row_perm, ko) || up(&h->d_idx_at3, iat3) || up(&h->d_idx_ar3, iar3) || up(&h->d_slot_soc, ssoc)) return CE_E_HIP;
-            const F2Dims dd = f2_dims(2);
-            const int ntile = (dd.NPg + 15) / 16, ldp = (16 * ntile) % 32 == 16 ? 16 * ntile : 16 * ntile + 16;
-            const size_t gsz = std::max(std::max((size_t)T.n * LDG3, (size_t)4 * ldp), (size_t)16 * dd.NP);
-            const size_t by = ((size_t)dd.O_G + dd.MP + gsz) * 8, by_aa = by + 5 * (size_t)dd.VP * 8;
-            h->f3 = true; h->fwd_mode = 5; h->f2_ldg = LDG3; h->wl = false;
-            h->aa_ok = by_aa <= LDS_LIMIT; h->fwd_lds = h->aa_ok ? by_aa : by;
-        }
-    }
     if (fwd_env && !strcmp(fwd_env, "generic") && h->fwd_mode == 3) {   // forced generic kernel
         h->rt_variant = -1;
         if (fwd_lds_bytes(T, true, true) <= LDS_LIMIT) h->fwd_mode = 0; else if (fwd_lds_bytes(T, true, false) <= LDS_LIMIT) h->fwd_mode = 1; else h->fwd_mode = 2;
@@ -528,7 +468,7 @@ int ce_create(const ce_template *tpl, int device, ce_handle *out) {
     }
     if (h->qp_native && h->bwd_mode != 3) h->qp_native = false;      // the adjoint with P lives in the register-tiled backward kernel
     HIPCHK(ce_setattr_fwd_generic((int)LDS_LIMIT)); HIPCHK(ce_setattr_fwd_rt((int)LDS_LIMIT));
-    HIPCHK(ce_setattr_fwd3((int)LDS_LIMIT)); HIPCHK(ce_setattr_fwd2_plain((int)LDS_LIMIT)); HIPCHK(ce_setattr_fwd2_psd((int)LDS_LIMIT)); HIPCHK(ce_setattr_fwd2_qp((int)LDS_LIMIT));
+    HIPCHK(ce_setattr_fwd2_plain((int)LDS_LIMIT)); HIPCHK(ce_setattr_fwd2_psd((int)LDS_LIMIT)); HIPCHK(ce_setattr_fwd2_qp((int)LDS_LIMIT));
     HIPCHK(ce_setattr_bwd_rt_plain((int)LDS_LIMIT)); HIPCHK(ce_setattr_bwd_rt_psd((int)LDS_LIMIT)); HIPCHK(ce_setattr_bwd_generic((int)LDS_LIMIT));
     *out = h;
     return CE_OK;
@@ -538,7 +478,7 @@ int ce_destroy(ce_handle h) {
     if (!h) return CE_OK;
     hipSetDevice(h->device);
     hipFree(h->d_rowidx); hipFree(h->d_colidx); hipFree(h->d_rowcone); hipFree(h->d_qoff); hipFree(h->d_soff); hipFree(h->d_sord); hipFree(h->d_pw); hipFree(h->d_idx_p); hipFree(h->d_pmap); hipFree(h->d_prow); hipFree(h->d_pcol);
-    hipFree(h->wsA); hipFree(h->wsdA); hipFree(h->gws); hipFree(h->d_idx_at); hipFree(h->d_idx_ar); hipFree(h->d_idx_b); hipFree(h->d_order); hipFree(h->d_iters2); hipFree(h->d_nkmax); if (h->h_nkmax) hipHostFree(h->h_nkmax); if (h->nk_ev) hipEventDestroy(h->nk_ev); hipFree(h->d_row_perm); hipFree(h->d_idx_at3); hipFree(h->d_idx_ar3); hipFree(h->d_slot_soc); hipFree(h->d_k_rowcone); hipFree(h->d_k_qoff); hipFree(h->d_csc_ptr); hipFree(h->d_csr_ptr); hipFree(h->d_csr_col); hipFree(h->d_csr_src);
+    hipFree(h->wsA); hipFree(h->wsdA); hipFree(h->gws); hipFree(h->d_idx_at); hipFree(h->d_idx_ar); hipFree(h->d_idx_b); hipFree(h->d_order); hipFree(h->d_iters2); hipFree(h->d_nkmax); if (h->h_nkmax) hipHostFree(h->h_nkmax); if (h->nk_ev) hipEventDestroy(h->nk_ev); hipFree(h->d_row_perm); hipFree(h->d_k_rowcone); hipFree(h->d_k_qoff); hipFree(h->d_csc_ptr); hipFree(h->d_csr_ptr); hipFree(h->d_csr_col); hipFree(h->d_csr_src);
     hipFree(h->d_sp_drow); hipFree(h->d_sp_srow_col); hipFree(h->d_sp_scol_ptr); hipFree(h->d_sp_scol_row); hipFree(h->d_sp_rowslot); hipFree(h->d_sp_sing_i); hipFree(h->d_sp_sing_v); hipFree(h->d_sp_AdT); hipFree(h->d_sp_sval); hipFree(h->d_bpos); hipFree(h->d_aa_ws); hipFree(h->d_summary);
     for (auto &v : h->ev) for (auto &p : v) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
     for (auto &e : h->ev_pool) hipEventDestroy(e);
@@ -620,7 +560,7 @@ int ce_solve_qp(ce_handle h, int B, const double *A_vals, long sA_k, long sA_b, 
     // (PSD / exponential / power cones beyond k_fwd2's sizes run on the size-generic kernel: fwd_mode 0..2)
     if ((h->T.ns > 0 || h->T.nep + h->T.np > 0) && h->fwd_mode == 3) { g_err = "PSD / exponential / power cones: internal error, k_forward_rt selected"; return CE_E_UNSUPPORTED; }
     ce_settings S; if (settings) S = *settings; else ce_default_settings(&S);
-    if (!((h->fwd_mode == 4 || h->fwd_mode == 5) && h->aa_ok)) S.acceleration_lookback = 0;       // only k_fwd2 implements it (and only when its vectors fit LDS)
+    if (!(h->fwd_mode == 4 && h->aa_ok)) S.acceleration_lookback = 0;       // only k_fwd2 implements it (and only when its vectors fit LDS)
     if (S.acceleration_interval <= 0) S.acceleration_interval = 10;
     const double *Abm = nullptr;
     int rc = to_batch_major(h, B, A_vals, sA_k, sA_b, st, &Abm);
@@ -647,10 +587,7 @@ int ce_solve_qp(ce_handle h, int B, const double *A_vals, long sA_k, long sA_b, 
             fa.iters2 = h->d_iters2; fa_iters2 = true;
         }
         fa.order = (h->dispatch_history && h->order_B == B && h->fwd_mode == 4) ? h->d_order : nullptr;
-        if (h->fwd_mode == 5) {
-            fa.T.ldg = h->f2_ldg; fa.row_perm = h->d_row_perm; fa.idx_at3 = h->d_idx_at3; fa.idx_ar3 = h->d_idx_ar3; fa.slot_soc = h->d_slot_soc;
-            lrc = ce_launch_fwd3(B, h->fwd_lds, st, fa);
-        } else if (h->fwd_mode == 4) {
+        if (h->fwd_mode == 4) {
             fa.T.ldg = h->f2_ldg;
             if (h->wl) {      // rows packed for the wave-local cone exchange: the kernel sees the cone layout in ITS row order
                 fa.row_perm = h->d_row_perm; fa.T.rowcone = h->d_k_rowcone; fa.T.qoff = h->d_k_qoff; fa.T.nq = h->wl_nq; fa.T.l = 0;

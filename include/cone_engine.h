@@ -278,7 +278,7 @@ int ce_get_profile(ce_handle h, int which, double *mean_ms, int *launches);
 int ce_reset_profile(ce_handle h);
 /* LDS bytes per workgroup and residency mode chosen for (forward, backward); for DESIGN/bench reporting.
  * fwd_mode: 0..2 size-generic kernel (everything in LDS / G in global memory / A and G in global memory), 3 k_forward_rt, 4 k_fwd2 (register tiles,
- * LDS operand streams), 5 k_fwd3 (register tiles, lane-broadcast operands: ce_forward_v3.h; experimental, selected only with CE_FWD3=1 in the environment).
+ * LDS operand streams).
  * bwd_mode: 0..2 size-generic kernel, 3 k_backward_rt. */
 int ce_get_launch_info(ce_handle h, int *fwd_lds_bytes, int *bwd_lds_bytes, int *fwd_mode, int *bwd_mode);
 

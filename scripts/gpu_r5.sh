@@ -21,12 +21,6 @@ if has bench; then
   echo "== bench $BENCH_ARGS" | tee -a "$OUT/summary.txt"
   timeout 400 python bench.py $BENCH_ARGS 2>"$OUT/bench.err" | tee "$OUT/bench.json" | cut -c1-700 | tee -a "$OUT/summary.txt"
 fi
-if has ab3; then
-  echo "== A/B on this box: k_fwd2 (CE_FWD3=0) vs k_fwd3 (default)" | tee -a "$OUT/summary.txt"
-  for v in 0 1; do
-    CE_FWD3=$v timeout 300 python bench.py --no-cpu --steps 60 --warmup 10 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('CE_FWD3=$v', round(d['ms_per_step'],4), 'ms/step', round(d['value']), d['unit'], {k:(round(v,4) if isinstance(v,float) else v) for k,v in d['kernels_ms'].items()}, 'iters', d['iters'], 'mode', d['launch'])" | tee -a "$OUT/summary.txt"
-  done
-fi
 if has prof; then
   echo "== rocprofv3 kernel-trace stats" | tee -a "$OUT/summary.txt"
   (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/prof" -o trace --output-format csv -- python "$OLDPWD/bench.py" --no-cpu $BENCH_ARGS > "$OUT/prof.log" 2>&1)

@@ -636,48 +636,6 @@ def test_every_cone_type_on_the_size_generic_kernels_forward_and_backward(cones,
     assert info["fwd_mode"] in (0, 1, 2) and info["bwd_mode"] in (0, 1, 2), info
 
 
-# ------------------------------------------------------------------ k_fwd3 (lane-broadcast products), opt-in
-def test_k_fwd3_opt_in_matches_the_oracle(monkeypatch):
-    """CE_FWD3=1 runs the metric shape on the third-generation forward kernel (ce_forward_v3.h: v_fmac_f64_dpp row_newbcast products, one cone
-    per pair of lane rows, padding slots).  It is not the default (it does not beat k_fwd2 on MI355X) but it must stay correct: same
-    algorithm, same iterates up to the summation order -- solutions, statuses and iteration counts against the oracle, with and without
-    acceleration, warm start included."""
-    from oracle import oracle
-    from cvxpylayers_amd.interfaces.mi355_if import ConeEngine, make_settings
-    monkeypatch.setenv("CE_FWD3", "1")
-    cfg = P.CONFIGS["M"]; n, cones, B = cfg["n"], cfg["cones"], 96
-    tpl = P.dense_template(n, cones)
-    A, b, c = P.generate(n, cones, B, seed=11)
-    eng = ConeEngine(tpl.indices, tpl.indptr, tpl.n, tpl.m, cones, torch.device("cuda", 0))          # (not the cached engine: the switch is read at creation)
-    assert eng.launch_info()["fwd_mode"] == 5
-    A_eval, q_eval = tpl.values_from_dense(A, b, c)
-    A_bm = eng.to_batch_major(torch.from_numpy(A_eval).cuda()); q_t = torch.from_numpy(q_eval).cuda()
-    for eps, look in ((1e-4, 1), (1e-8, 0)):
-        ref = oracle.solve_batch(A, b, c, cones, eps=eps, max_iters=20000, acceleration_lookback=look)
-        x, y, s, iters, status, resid = eng.solve(A_bm, q_t, make_settings(dict(eps=eps, max_iters=20000, acceleration_lookback=look)))
-        assert (status.cpu().numpy() == ref["status"]).all() and (ref["status"] == 1).all()
-        tol = max(1e-6, 20 * eps)
-        for got, want in ((x, ref["x"]), (y, ref["y"]), (s, ref["s"])):
-            err = np.abs(got.cpu().numpy() - want).max(axis=1) / (1 + np.abs(want).max(axis=1))
-            assert err.max() < tol, err.max()
-        assert np.mean(np.abs(iters.cpu().numpy() - ref["iters"]) <= 25) > 0.9
-    # warm start from the solution: converged at the first check
-    xw, yw, sw, itw, stw, _ = eng.solve(A_bm, q_t, make_settings(dict(eps=1e-8, max_iters=20000, acceleration_lookback=0)), warm=(x, y, s))
-    assert (stw.cpu().numpy() == 1).all() and int(itw.max()) <= 50
-    # an LP (no second-order cone: every slot a single row) and a template with zero-cone rows among the fillers
-    for cones2, n2 in (({"z": 0, "l": 100, "q": []}, 50), ({"z": 6, "l": 30, "q": [9, 12, 5]}, 44)):
-        tpl2 = P.dense_template(n2, cones2)
-        A2, b2, c2 = P.generate(n2, cones2, 24, seed=5)
-        eng2 = ConeEngine(tpl2.indices, tpl2.indptr, tpl2.n, tpl2.m, cones2, torch.device("cuda", 0))
-        assert eng2.launch_info()["fwd_mode"] == 5, eng2.launch_info()
-        Ae, qe = tpl2.values_from_dense(A2, b2, c2)
-        ref = oracle.solve_batch(A2, b2, c2, cones2, eps=1e-8, max_iters=50000)
-        x2, y2, s2, it2, st2, _ = eng2.solve(eng2.to_batch_major(torch.from_numpy(Ae).cuda()), torch.from_numpy(qe).cuda(), make_settings(dict(eps=1e-8, max_iters=50000, acceleration_lookback=0)))
-        assert (st2.cpu().numpy() == ref["status"]).all()
-        for got, want in ((x2, ref["x"]), (y2, ref["y"]), (s2, ref["s"])):
-            assert (np.abs(got.cpu().numpy() - want).max(axis=1) / (1 + np.abs(want).max(axis=1))).max() < 1e-6
-
-
 def test_rank_tolerance_is_one_constant_across_the_adjoint_kernels(monkeypatch):
     """A template with a REDUNDANT equality row (row 1 = row 0, consistent right-hand side) on the register-tiled adjoint (the default for this size) and on
     the size-generic kernel (CE_FORCE_GENERIC=1) with its unblocked and its blocked elimination: the same rank tolerance (CE_RANK_TOL = 1e-11 max|K|, the
