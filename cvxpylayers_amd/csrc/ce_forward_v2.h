@@ -377,7 +377,9 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
 
     // order: workgroup -> instance.  Workgroups are dispatched in index order, so a permutation sorted by EXPECTED duration, longest first, shortens the
     // tail of the launch (the last slots to drain run the short instances); the host derives it from the iteration counts of the previous call (ce_set_dispatch_history)
-    const int tid = threadIdx.x, inst = order ? order[blockIdx.x] : blockIdx.x;
+    // order[gridDim.x] says whether the history has been PREDICTIVE (k_dispatch_order: the iteration counts of the last two calls fell into the same check interval for
+    // most instances); on unrelated batches the permutation would only scatter the instances' rows over HBM, and the workgroups keep the index order
+    const int tid = threadIdx.x, inst = (order && order[gridDim.x]) ? order[blockIdx.x] : blockIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = T.n, m = T.m, l = n + m + 1, ldg = T.ldg, nq = T.nq, z = T.z;
     const int gsz = max(max(n * ldg, 4 * L::LDP), 16 * NP);        // doubles of the G region: G itself, one 4-row panel of the S formation, the exchange

@@ -81,7 +81,8 @@ struct ce_engine {
     bool wl = false; int wl_nq = 0; int *d_row_perm = nullptr, *d_k_rowcone = nullptr, *d_k_qoff = nullptr;   // rows packed so that cones are wave-local (k_fwd2 WL)
     // longest-first dispatch (ce_set_dispatch_history): workgroup -> instance order for the next solve of the same batch size, from this solve's iteration counts
     bool dispatch_history = false; int *d_order = nullptr; int order_B = 0, order_cap = 0;
-    int *d_iters2 = nullptr; int iters2_cap = 0, order_pending_B = 0;      // engine-owned copy of the last solve's iteration counts (the caller's buffer may be gone when the order is computed)
+    int *d_iters2 = nullptr; int iters2_cap = 0, order_pending_B = 0;
+    int *d_iters_prev = nullptr; int iters_prev_cap = 0, iters_prev_B = 0;      // the iteration counts of the call before (k_dispatch_order compares: is the history predictive?)      // engine-owned copy of the last solve's iteration counts (the caller's buffer may be gone when the order is computed)
     int brt_variant = -1;                          // register-tiled backward kernel variant (-1: generic kernel)
     // two-tile plan of the register-tiled adjoint: a smaller tile serves the instances it holds, the worst-case tile re-runs the ones it flagged.  The smaller
     // tile is chosen from the LARGEST system of the previous call of the same batch size (nk_*: device maximum, copied to pinned memory behind the launch)
@@ -478,7 +479,7 @@ int ce_destroy(ce_handle h) {
     if (!h) return CE_OK;
     hipSetDevice(h->device);
     hipFree(h->d_rowidx); hipFree(h->d_colidx); hipFree(h->d_rowcone); hipFree(h->d_qoff); hipFree(h->d_soff); hipFree(h->d_sord); hipFree(h->d_pw); hipFree(h->d_idx_p); hipFree(h->d_pmap); hipFree(h->d_prow); hipFree(h->d_pcol);
-    hipFree(h->wsA); hipFree(h->wsdA); hipFree(h->gws); hipFree(h->d_idx_at); hipFree(h->d_idx_ar); hipFree(h->d_idx_b); hipFree(h->d_order); hipFree(h->d_iters2); hipFree(h->d_nkmax); if (h->h_nkmax) hipHostFree(h->h_nkmax); if (h->nk_ev) hipEventDestroy(h->nk_ev); hipFree(h->d_row_perm); hipFree(h->d_k_rowcone); hipFree(h->d_k_qoff); hipFree(h->d_csc_ptr); hipFree(h->d_csr_ptr); hipFree(h->d_csr_col); hipFree(h->d_csr_src);
+    hipFree(h->wsA); hipFree(h->wsdA); hipFree(h->gws); hipFree(h->d_idx_at); hipFree(h->d_idx_ar); hipFree(h->d_idx_b); hipFree(h->d_order); hipFree(h->d_iters2); hipFree(h->d_iters_prev); hipFree(h->d_nkmax); if (h->h_nkmax) hipHostFree(h->h_nkmax); if (h->nk_ev) hipEventDestroy(h->nk_ev); hipFree(h->d_row_perm); hipFree(h->d_k_rowcone); hipFree(h->d_k_qoff); hipFree(h->d_csc_ptr); hipFree(h->d_csr_ptr); hipFree(h->d_csr_col); hipFree(h->d_csr_src);
     hipFree(h->d_sp_drow); hipFree(h->d_sp_srow_col); hipFree(h->d_sp_scol_ptr); hipFree(h->d_sp_scol_row); hipFree(h->d_sp_rowslot); hipFree(h->d_sp_sing_i); hipFree(h->d_sp_sing_v); hipFree(h->d_sp_AdT); hipFree(h->d_sp_sval); hipFree(h->d_bpos); hipFree(h->d_aa_ws); hipFree(h->d_summary);
     for (auto &v : h->ev) for (auto &p : v) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
     for (auto &e : h->ev_pool) hipEventDestroy(e);
@@ -703,12 +704,26 @@ __global__ void __launch_bounds__(256) k_status_summary(int B, const int *__rest
         __hip_atomic_store(out + 3, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);      // out[3] = 1: "ready" -- a host that cleared it before the call may poll it instead of synchronising the stream
     }
 }
-// order[] = the instances sorted by iteration count, largest first (counting sort over check intervals; ties in arbitrary order): one workgroup
-__global__ void __launch_bounds__(256) k_dispatch_order(int B, const int *__restrict__ iters, int *__restrict__ order) {
+// order[] = the instances sorted by iteration count, largest first (counting sort over check intervals; ties in arbitrary order): one workgroup.
+// order[B] = 1 when the history is PREDICTIVE: at least 70 % of the instances stopped in the same check interval as the instance at the same position of the call
+// before (iters_prev, updated here; have_prev = 0: no such call).  Re-solved or slowly changing batches score ~1, unrelated batches of the metric configuration
+// ~0.43 (the chance that two draws of the count distribution agree): there the permutation predicts nothing and is not applied (k_fwd2 reads the flag).
+__global__ void __launch_bounds__(256) k_dispatch_order(int B, const int *__restrict__ iters, int *__restrict__ order, int *__restrict__ iters_prev, int have_prev) {
     constexpr int NB = 512;                       // buckets of CONVERGED_INTERVAL iterations; anything longer shares the last one
     __shared__ int cnt[NB], tmp[NB];
+    __shared__ int same;
+    if (threadIdx.x == 0) same = 0;
     for (int b = threadIdx.x; b < NB; b += 256) cnt[b] = 0;
     __syncthreads();
+    {
+        int mine = 0;
+        for (int i = threadIdx.x; i < B; i += 256) {
+            const int it = iters[i];
+            if (have_prev) mine += (max(it, 0) / CONVERGED_INTERVAL == max(iters_prev[i], 0) / CONVERGED_INTERVAL);
+            iters_prev[i] = it;
+        }
+        if (have_prev) atomicAdd(&same, mine);
+    }
     for (int i = threadIdx.x; i < B; i += 256) { const int b = min(max(iters[i], 0) / CONVERGED_INTERVAL, NB - 1); atomicAdd(&cnt[NB - 1 - b], 1); }      // (bucket 0 = longest)
     __syncthreads();
     // exclusive prefix sum over the buckets (two per thread, log-step scan: a serial loop over 512 LDS entries cost 13 us on the path to the status read-back)
@@ -721,6 +736,7 @@ __global__ void __launch_bounds__(256) k_dispatch_order(int B, const int *__rest
     for (int b = threadIdx.x; b < NB; b += 256) dst[b] = b > 0 ? src[b - 1] : 0;          // inclusive -> exclusive
     __syncthreads();
     for (int i = threadIdx.x; i < B; i += 256) { const int b = min(max(iters[i], 0) / CONVERGED_INTERVAL, NB - 1); order[atomicAdd(&dst[NB - 1 - b], 1)] = i; }
+    if (threadIdx.x == 0) order[B] = (have_prev && 10 * same >= 7 * B) ? 1 : 0;      // (`same` is complete: every atomicAdd above precedes the barriers of the scan)
 }
 // the order of the NEXT solve is computed off the critical path: behind the status summary (the host is busy with autograd then, the device idle), or at the
 // latest in front of the next solve / behind the next adjoint
@@ -728,8 +744,10 @@ static int flush_dispatch_order(ce_engine *h, hipStream_t st) {
     if (!h->order_pending_B) return CE_OK;
     const int B = h->order_pending_B;
     h->order_pending_B = 0;
-    if (h->order_cap < B) { hipFree(h->d_order); h->d_order = nullptr; h->order_cap = 0; HIPCHK(hipMalloc(&h->d_order, sizeof(int) * (size_t)B)); h->order_cap = B; }
-    hipLaunchKernelGGL(k_dispatch_order, dim3(1), dim3(256), 0, st, B, h->d_iters2, h->d_order);
+    if (h->order_cap < B) { hipFree(h->d_order); h->d_order = nullptr; h->order_cap = 0; HIPCHK(hipMalloc(&h->d_order, sizeof(int) * ((size_t)B + 1))); h->order_cap = B; }
+    if (h->iters_prev_cap < B) { hipFree(h->d_iters_prev); h->d_iters_prev = nullptr; h->iters_prev_cap = 0; h->iters_prev_B = 0; HIPCHK(hipMalloc(&h->d_iters_prev, sizeof(int) * (size_t)B)); h->iters_prev_cap = B; }
+    hipLaunchKernelGGL(k_dispatch_order, dim3(1), dim3(256), 0, st, B, h->d_iters2, h->d_order, h->d_iters_prev, h->iters_prev_B == B ? 1 : 0);
+    h->iters_prev_B = B;
     HIPCHK(hipGetLastError());
     h->order_B = B;
     return CE_OK;
@@ -737,7 +755,7 @@ static int flush_dispatch_order(ce_engine *h, hipStream_t st) {
 int ce_set_dispatch_history(ce_handle h, int on) {
     if (!h) { g_err = "null argument"; return CE_E_BADARG; }
     h->dispatch_history = on != 0;
-    if (!on) { h->order_B = 0; h->order_pending_B = 0; }
+    if (!on) { h->order_B = 0; h->order_pending_B = 0; h->iters_prev_B = 0; }
     return CE_OK;
 }
 

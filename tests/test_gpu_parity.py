@@ -680,9 +680,9 @@ def test_rank_tolerance_is_one_constant_across_the_adjoint_kernels(monkeypatch):
 
 
 def test_longest_first_dispatch_is_a_scheduling_hint_only():
-    """ce_set_dispatch_history: the second solve of a batch dispatches its workgroups by the first solve's iteration counts, longest first.  Every instance is
-    computed by the same code whatever workgroup index it gets: solutions, iteration counts and statuses are BIT-identical with the hint on and off, and for a
-    different batch of the same size (a stale order is still a permutation)."""
+    """ce_set_dispatch_history: once two consecutive solves of one batch size have shown the same iteration counts (the history is predictive), the next solve
+    dispatches its workgroups by the recorded counts, longest first; on unrelated batches the index order is kept.  Every instance is computed by the same code
+    whatever workgroup index it gets: solutions, iteration counts and statuses are BIT-identical with the hint on and off, applied or not."""
     from cvxpylayers_amd.interfaces.mi355_if import ConeEngine, make_settings
     cfg = P.CONFIGS["M"]; n, cones, B = cfg["n"], cfg["cones"], 777
     tpl = P.dense_template(n, cones)
@@ -696,9 +696,10 @@ def test_longest_first_dispatch_is_a_scheduling_hint_only():
         eng.set_dispatch_history(False)
         ref = [t.clone() for t in eng.solve(A_bm, q_t, st())]
         eng.set_dispatch_history(True)
-        first = [t.clone() for t in eng.solve(A_bm, q_t, st())]          # seed 0: no order yet; seed 1: the order of seed 0's batch (stale, harmless)
-        second = [t.clone() for t in eng.solve(A_bm, q_t, st())]         # dispatched by `first`'s iteration counts
-        for got in (first, second):
+        first = [t.clone() for t in eng.solve(A_bm, q_t, st())]          # seed 0: no order yet; seed 1: seed 0's order exists but did not predict this batch: not applied
+        second = [t.clone() for t in eng.solve(A_bm, q_t, st())]         # an order exists, its predictive flag is still 0
+        third = [t.clone() for t in eng.solve(A_bm, q_t, st())]          # first -> second agreed everywhere: dispatched longest-first by `second`'s counts
+        for got in (first, second, third):
             for a_, b_ in zip(got, ref):
                 assert torch.equal(a_, b_)
         assert len(torch.unique(ref[3])) > 1                              # (the batch does have instances of different length)
