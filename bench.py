@@ -168,7 +168,9 @@ def sq_limiter(kernel_short):
             if k.startswith(kernel_short) and isinstance(v, dict):
                 keep = {kk: vv for kk, vv in v.items() if kk in ("valu_busy", "wait_any", "wait_inst_any", "active_inst_any", "lds_conflict", "mfma_util")}      # shares of wave time
                 return dict(source=os.path.relpath(f, ROOT), kernel=k, counters=keep,
-                            reading="per wave: fp64 VALU busy for a fifth of the time, the rest waiting on barriers, LDS and dependent chains; per CU (three workgroups): VALU issue ~2/3 busy and the LDS pipe ~5/6 busy with operand reads (profiles/r04/n_fwd_instructions_per_wave_iteration.txt) -- bound by LDS operand delivery and the latency of one workgroup's barrier-separated phases, not by HBM or MFMA")
+                            reading="shares of wave time from the SQ counters of this file: a wave of the forward kernel has an fp64 VALU instruction in flight for about a fifth of its time and waits (barriers, LDS operand "
+                                    "reads, dependent chains) for the rest; three workgroups per CU overlap these chains but do not hide them -- the kernel is bound by the latency of one workgroup's barrier-separated "
+                                    "phases and by LDS operand delivery, not by HBM (touched once) or MFMA")
     return None
 
 
@@ -382,9 +384,10 @@ def main():
             "dispatch": {"history": bool(args.dispatch_history), "ms_per_step_rotating_with_history": ms_per_step if args.dispatch_history else other_ms,
                          "ms_per_step_rotating_index_order": other_ms if args.dispatch_history else ms_per_step,
                          "ms_per_step_replay_one_batch": replay_ms,
-                         "note": "workgroups are dispatched longest-first by the PREVIOUS call's iteration counts and the adjoint's first tile is sized by the PREVIOUS call's largest "
-                                 "system (plugin defaults, results bit-identical).  `value` is measured on rotating batches, where both are predictions from a different batch; "
-                                 "`replay` re-solves one batch (both exact) and is reported for comparison with rounds 1-4 only"},
+                         "note": "the plugin records every call's iteration counts and dispatches the next call's workgroups longest-first ONLY when the history has been predictive "
+                                 "(>= 70 % of the instances in the same check interval as the call before: decided on the device); the adjoint's first tile is sized by the previous call's "
+                                 "largest system.  `value` is measured on rotating batches: the history does not predict there and the index order runs; `replay` re-solves one batch "
+                                 "(history exact, applied from the third call on) and is reported for comparison with rounds 1-4 only"},
             "launch": eng.launch_info(),
         }
         if allgather_ms is not None:

@@ -49,6 +49,34 @@ if has frontend; then
   echo "== whole layer (frontend: parameter maps + plugin + one-launch recovery)" | tee -a "$OUT/summary.txt"
   timeout 300 python scripts/bench_frontend.py "$OUT/frontend_layer.json" 2>&1 | grep -v amdgpu.ids | tail -4 | tee -a "$OUT/summary.txt"
 fi
+if has c3prof; then
+  echo "== C3 (SOCP n=100, 10 x SOC(11), B=4096): kernel trace, SQ counters, in-kernel phase cycles" | tee -a "$OUT/summary.txt"
+  (cd /tmp && CONFIGS=C3 timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/c3_prof" -o trace --output-format csv -- python "$OLDPWD/scripts/bench_configs.py" "$OUT/c3_configs.json" > "$OUT/c3_prof.log" 2>&1)
+  find "$OUT/c3_prof" -name "*kernel_stats.csv" | head -1 | xargs -r head -6 | cut -c1-260 | tee -a "$OUT/summary.txt"
+  (cd /tmp && CONFIGS=C3 timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT -d "$OUT/c3_sq1" -o p --output-format csv -- python "$OLDPWD/scripts/bench_configs.py" "$OUT/c3_configs_sq.json" > "$OUT/c3_sq1.log" 2>&1)
+  python - "$OUT" <<'PY' | tee -a "$OUT/summary.txt"
+import csv, glob, collections, json, os, re, sys
+out = sys.argv[1]
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(os.path.join(out, "c3_sq1", "**", "*counter_collection.csv"), recursive=True):
+    per = collections.defaultdict(lambda: collections.defaultdict(float)); names = {}
+    for r in csv.DictReader(open(f)):
+        per[r["Dispatch_Id"]][r["Counter_Name"]] += float(r["Counter_Value"]); mm = re.search(r"\bk_\w+", r["Kernel_Name"]); names[r["Dispatch_Id"]] = mm.group(0) if mm else r["Kernel_Name"][:40]
+    for d, cs in per.items():
+        for c, v in cs.items(): agg[names[d]][c].append(v)
+res = {}
+for k, cs in agg.items():
+    if not any(t in k for t in ("k_fwd2", "k_backward")): continue
+    s = {c: sum(v) / len(v) for c, v in cs.items()}
+    s["launches"] = max(len(v) for v in cs.values())
+    if s.get("SQ_WAVE_CYCLES"):
+        s["valu_busy"] = s.get("SQ_ACTIVE_INST_VALU", 0.0) / s["SQ_WAVE_CYCLES"]; s["wait_any"] = s.get("SQ_WAIT_ANY", 0.0) / s["SQ_WAVE_CYCLES"]
+    res[k] = s
+print(json.dumps(res, indent=1))
+json.dump(res, open(os.path.join(out, "c3_sq_summary.json"), "w"), indent=1)
+PY
+  CE_ENGINE_SO=$PWD/cvxpylayers_amd/csrc/libcone_engine_timing.so timeout 300 python scripts/timing_probe.py C3 4096 2>&1 | grep -v amdgpu.ids | head -40 | tee "$OUT/c3_phase_cycles.log" | head -30 | tee -a "$OUT/summary.txt"
+fi
 if has c5prof; then
   echo "== C5 (portfolio n=501, shared A, B=16384): kernel trace" | tee -a "$OUT/summary.txt"
   (cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats -d "$OUT/c5_prof" -o trace --output-format csv -- python "$OLDPWD/scripts/shared_a_probe.py" C5 16384 default > "$OUT/c5_prof.log" 2>&1)
