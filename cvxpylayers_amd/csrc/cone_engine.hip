@@ -94,7 +94,7 @@ struct ce_engine {
     std::vector<int> p_rows, p_cols;               // host copy of the P structure (entry -> (row, col))
     int *d_idx_p = nullptr, *d_pmap = nullptr, *d_prow = nullptr, *d_pcol = nullptr;
     // profiling
-    bool prof = false;
+    int prof = 0;      // bit w: launches of kind w (0 forward, 1 adjoint, 2 layout passes) are bracketed by HIP events
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[3];
     std::vector<hipEvent_t> ev_pool;
 };
@@ -514,7 +514,7 @@ static int ensure(double **ptr, size_t *have, size_t need) {
 
 struct ProfScope {
     ce_engine *h; int which; hipStream_t st; hipEvent_t a{}, b{}; bool on;
-    ProfScope(ce_engine *h_, int w, hipStream_t s) : h(h_), which(w), st(s), on(h_->prof) {
+    ProfScope(ce_engine *h_, int w, hipStream_t s) : h(h_), which(w), st(s), on(((h_->prof >> w) & 1) != 0) {
         // events come from a pool filled by earlier scopes (ce_reset_profile returns them): creating a pair per launch cost host time in front of every
         // kernel of a profiled run -- bench.py's timed region is one
         if (on) {
@@ -1004,7 +1004,7 @@ int ce_parammap_apply2(int device, int B, int rows, int cols, int accumulate, co
 
 int ce_set_profiling(ce_handle h, int enable) {
     if (!h) return CE_E_BADARG;
-    h->prof = enable != 0;
+    h->prof = enable == 1 ? 7 : (enable > 1 ? (enable >> 1) & 7 : 0);      // 1: every kind; 2 / 4 / 8 (or sums): forward / adjoint / layout launches only
     if (h->prof) { while (h->ev_pool.size() < 2048) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) break; h->ev_pool.push_back(e); } }      // (created HERE, not in front of the timed launches)
     return CE_OK;
 }

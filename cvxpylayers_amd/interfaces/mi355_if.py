@@ -353,7 +353,8 @@ class ConeEngine:
         return (dA if batch_minor_out else dA.t()), dq, adj
 
     # introspection (bench / tests)
-    def set_profiling(self, on: bool):
+    def set_profiling(self, on):
+        """False / True, or a sum of 2 (forward), 4 (adjoint), 8 (layout passes): which launches are bracketed by HIP events (include/cone_engine.h)"""
         _lib.lib().ce_set_profiling(self._h, int(on))
 
     def reset_profile(self):

@@ -273,7 +273,8 @@ int ce_vjp_shared_a(ce_handle h, int B, const double *A_vals0, long sA_b, const 
  * Register-tiled forward kernels only (fwd_mode 4).  Off by default at the C ABI. */
 int ce_set_dispatch_history(ce_handle h, int on);
 
-/* Introspection used by bench.py / tests: per-kernel HIP-event timing on the launch stream. */
+/* Introspection used by bench.py / tests: per-kernel HIP-event timing on the launch stream.  enable: 0 off, 1 every launch, or a sum of 2 (forward launches),
+ * 4 (adjoint launches), 8 (layout passes) to bracket only those kinds (two event records per bracketed launch are host work in front of the launch). */
 int ce_set_profiling(ce_handle h, int enable);
 /* which: 0 forward kernel, 1 backward kernel, 2 layout (transpose) kernels.  Returns the mean ms per launch
  * since the last ce_reset_profile and the launch count; synchronises the recorded events. */
