@@ -146,18 +146,15 @@ __device__ __forceinline__ void for_each_idx(const int *__restrict__ base, int t
 #ifndef F2_GATHER_CHUNK
 #define F2_GATHER_CHUNK 14
 #endif
-// the gather map row of thread t (idx_stride<TT> ints, 16-byte loads off one base)
-template <int TT>
-__device__ __forceinline__ void gather_idx(const int *__restrict__ base, int t, int4 (&ix4)[idx_stride<TT> / 4]) {
+template <int TT, class F>
+__device__ __forceinline__ void gather_tile(const int *__restrict__ base, int t, const double *__restrict__ vals, F &&f) {
     const int4 *ip = reinterpret_cast<const int4 *>(reinterpret_cast<const char *>(base) + (unsigned)t * (unsigned)(idx_stride<TT> * sizeof(int)));
+    int4 ix4[idx_stride<TT> / 4];
 #pragma unroll
     for (int c4 = 0; c4 < idx_stride<TT> / 4; c4++) ix4[c4] = ip[c4];
-}
-// the values behind a map row, in chunks of CHK_ entries: one global round trip per chunk, and a register peak of one chunk (the whole fp64 tile at once pushed
-// loop-carried values of the iteration into scratch; the FP32 gathers of the equilibration, where nothing else is live, take the whole tile in one chunk)
-template <int TT, int CHK_, class F>
-__device__ __forceinline__ void gather_vals(const int4 (&ix4)[idx_stride<TT> / 4], const double *__restrict__ vals, F &&f) {
-    constexpr int CHK = CHK_ < TT ? CHK_ : TT;
+    // in chunks of F2_GATHER_CHUNK entries: one global round trip per chunk, and a register peak of one chunk (the whole tile at once pushed loop-carried
+    // values of the iteration into scratch)
+    constexpr int CHK = F2_GATHER_CHUNK < TT ? F2_GATHER_CHUNK : TT;
 #pragma unroll
     for (int k0 = 0; k0 < TT; k0 += CHK) {
         double raw[CHK];
@@ -180,12 +177,6 @@ __device__ __forceinline__ void gather_vals(const int4 (&ix4)[idx_stride<TT> / 4
         }
         __builtin_amdgcn_sched_barrier(0);
     }
-}
-template <int TT, class F>
-__device__ __forceinline__ void gather_tile(const int *__restrict__ base, int t, const double *__restrict__ vals, F &&f) {
-    int4 ix4[idx_stride<TT> / 4];
-    gather_idx<TT>(base, t, ix4);
-    gather_vals<TT, F2_GATHER_CHUNK>(ix4, vals, f);
 }
 
 // Orders LDS writes of this wave before LDS reads of this wave (other lanes' data).  LDS instructions of one wave execute in order,
@@ -449,13 +440,8 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
         float *const fPn = reinterpret_cast<float *>(sm + L::O_S3);          // column norms of P-hat (= row norms: symmetric)
         // (every gather below loads UNCONDITIONALLY through a clamped index and selects afterwards: a guarded load `ix >= 0 ? vals[ix] : 0` is a branch around the load with
         //  its own `s_waitcnt vmcnt(0)` -- 26 or 52 global round trips IN SERIES per gather, 25-36 k cycles each: profiles/r05/c_gather_serialised.txt)
-        {   // both map rows first (one round trip), then each tile's values in one chunk: three global round trips for the first touch of the instance's values
-            int4 ixa[idx_stride<T1> / 4], ixr[idx_stride<T2> / 4];
-            gather_idx<T1>(idx_at, tid, ixa);
-            gather_idx<T2>(idx_ar, tid, ixr);
-            gather_vals<T1, T1>(ixa, vals, [&](int k, int ix, double v) { atv[k >> 1][k & 1] = ix >= 0 ? (float)(-v) : 0.0f; });   // A = -A_cvx (diffcp_if.py:65)
-            gather_vals<T2, T2>(ixr, vals, [&](int k, int ix, double v) { arv[k >> 1][k & 1] = ix >= 0 ? (float)(-v) : 0.0f; });
-        }
+        gather_tile<T1>(idx_at, tid, vals, [&](int k, int ix, double v) { atv[k >> 1][k & 1] = ix >= 0 ? (float)(-v) : 0.0f; });   // A = -A_cvx (diffcp_if.py:65)
+        gather_tile<T2>(idx_ar, tid, vals, [&](int k, int ix, double v) { arv[k >> 1][k & 1] = ix >= 0 ? (float)(-v) : 0.0f; });
         float *const fEt0 = reinterpret_cast<float *>(sm + L::O_S1), *const fEt1 = reinterpret_cast<float *>(sm + L::O_S2);
         float *const fDt0 = reinterpret_cast<float *>(sm + L::O_U + OY), *const fDt1 = reinterpret_cast<float *>(sm + L::O_UT + OY);
         float *const fRn = reinterpret_cast<float *>(sm + L::O_ZB + OY);
