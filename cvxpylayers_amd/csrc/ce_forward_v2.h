@@ -1154,6 +1154,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
         const bool ev = e < l;
         const bool check = chk_ph == 0;
         const bool last = iter + 1 >= S.max_iters;
+        F2_ACC(6);      // loop bookkeeping, thread coordinates
         if (aa_on) {      // (uniform)
             if (aa_pending) {      // safeguard: residual of the map at the accelerated point against the residual before the step
                 const double dd = ev ? aaWP[ve] - sm[L::O_W + ve] : 0.0;
@@ -1485,6 +1486,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
         if (rescale) { resume = true; break; }      // -> refactor() with the new scale, then finish this iteration
         if (ev) sm[L::O_W + ve] += alpha * (sm[L::O_U + ve] - sm[L::O_UT + ve]);
         __syncthreads();
+        F2_ACC(7);      // the slow path of a check iteration (residual products, reductions, termination / rescale logic, relaxed update)
         next_iter();
     }
     }

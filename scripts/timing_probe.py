@@ -23,9 +23,10 @@ itn = it.float().cpu().numpy()
 acc = ts[:, 16:24]
 if acc.sum() > 0:
     print("iteration phases of k_fwd2 (cycles per iteration, wave 0's clock; fast-path iterations only are complete):")
-    for k, nm in enumerate(("top of the iteration", "P1a  A^T w_y up to its barrier", "the three barriers", "P1b  G t up to its barrier", "fused: A p_x, tau, cone input", "fused: projection, update")):
-        print(f"  {nm:38s} {(acc[:, k] / itn).mean():10.1f}")
-    print(f"  {'sum':38s} {(acc[:, :6].sum(1) / itn).mean():10.1f}")
+    for k, nm in enumerate(("acceleration step / safeguard / renormalisation (amortised)", "P1a  A^T w_y up to its barrier", "the three barriers", "P1b  G t up to its barrier", "fused: A p_x, tau, cone input", "fused: projection, update",
+                            "loop bookkeeping, thread coordinates", "slow path of the check iterations (amortised)")):
+        print(f"  {nm:62s} {(acc[:, k] / itn).mean():10.1f}")
+    print(f"  {'sum':62s} {(acc[:, :8].sum(1) / itn).mean():10.1f}")
 ea = ts[:, 24:32]
 if ea.sum() > 0:
     print("equilibration pass (cycles per pass, 26 passes):   " + "  ".join(f"{nm} {ea[:, k].mean() / 26:7.1f}" for k, nm in enumerate(("norms+column factor", "block sums+row factor", "barrier", "factor reads+scaling"))))
