@@ -181,19 +181,27 @@ def dry_run_ranks(args):
     world = int(os.environ["WORLD_SIZE"]); rank = int(os.environ["RANK"])
     dist.init_process_group("gloo")
     cfg = P.CONFIGS[args.config]; n = cfg["n"]; m = P.cone_rows(cfg["cones"]); B = min(args.batch, 64)
-    x = torch.full((B, n), float(rank + 1), dtype=torch.float64, requires_grad=True)
+    # K rotating batches per rank, as in the real run (slot k of rank r is seeded r + world * k there; here it is FILLED with that number + 1): every rank must
+    # visit the same slot at the same step, or the gathered batch would mix slots
+    K_rot = max(1, args.rotate)
+    xs = [torch.full((B, n), float(rank + world * k + 1), dtype=torch.float64, requires_grad=True) for k in range(K_rot)]
     y = torch.zeros((B, m), dtype=torch.float64)
+    ok = True
     dist.barrier(); t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for step_no in range(args.steps):
+        slot = step_no % K_rot
+        x = xs[slot]
         x.grad = None
         primal, dual = gather_solution(x * 1.0, y)
         primal.sum().backward()
+        want = B * n * sum(r + world * slot + 1 for r in range(world))          # every rank contributed the SAME slot
+        ok = ok and tuple(primal.shape) == (world * B, n) and float(primal.sum()) == want and bool((x.grad == 1.0).all())
     dist.barrier(); dt = time.perf_counter() - t0
     tdt = torch.tensor([dt], dtype=torch.float64); dist.all_reduce(tdt, op=dist.ReduceOp.MAX)
-    ok = tuple(primal.shape) == (world * B, n) and float(primal.sum()) == B * n * world * (world + 1) / 2 and bool((x.grad == 1.0).all())
+    okt = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64); dist.all_reduce(okt, op=dist.ReduceOp.MIN); ok = bool(okt.item() == 1.0)
     if rank == 0:
         print(json.dumps({"metric": "dry run of the multi-rank plumbing (no solver)", "value": None, "unit": "problems/s", "n_gpus": 0, "ranks": world, "backend": "gloo",
-                          "steps": args.steps, "ms_per_step": 1e3 * float(tdt.item()) / max(args.steps, 1), "dry_run": True, "gather_ok": bool(ok),
+                          "steps": args.steps, "rotating_batches": K_rot, "ms_per_step": 1e3 * float(tdt.item()) / max(args.steps, 1), "dry_run": True, "gather_ok": bool(ok),
                           "local_rank_env": os.environ.get("LOCAL_RANK"), "master_addr": os.environ.get("MASTER_ADDR")}))
     dist.destroy_process_group()
     if not ok:

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.environ.get("CE_ENGINE_SO") or os.path.join(_HERE, "csrc", "libcone_engine.so")     # CE_ENGINE_SO: a debug build (csrc: make timing)
 
 # every symbol include/cone_engine.h declares
-SYMBOLS = ["ce_abi_version", "ce_struct_size", "ce_acceleration_available", "ce_default_settings", "ce_create", "ce_destroy", "ce_last_error", "ce_solve", "ce_vjp", "ce_solve_shared_a", "ce_vjp_shared_a", "ce_qp_native", "ce_solve_qp", "ce_vjp_qp",
+SYMBOLS = ["ce_abi_version", "ce_struct_size", "ce_acceleration_available", "ce_default_settings", "ce_create", "ce_destroy", "ce_last_error", "ce_solve", "ce_vjp", "ce_solve_shared_a", "ce_vjp_shared_a", "ce_vjp_lsqr", "ce_qp_native", "ce_solve_qp", "ce_vjp_qp",
            "ce_transpose", "ce_status_summary", "ce_parammap_apply", "ce_parammap_apply2", "ce_ca_step", "ce_ca_check", "ce_ca_psd", "ce_ca_psd_mfma", "ce_ca_triples", "ce_ca_triple_jac", "ce_ca_update", "ce_ca_finish", "ce_set_profiling", "ce_get_profile", "ce_reset_profile", "ce_get_launch_info", "ce_set_dispatch_history"]
 
 
@@ -31,7 +31,7 @@ class CeSettings(C.Structure):
                 ("acceleration_lookback", C.c_int), ("acceleration_interval", C.c_int)]
 
 
-ABI_VERSION = 9          # include/cone_engine.h CE_ABI_VERSION this binding was written against
+ABI_VERSION = 10         # include/cone_engine.h CE_ABI_VERSION this binding was written against
 
 
 def build(force: bool = False) -> str:
@@ -75,6 +75,7 @@ def lib():
     L.ce_solve_shared_a.argtypes = [vp, C.c_int, C.c_int, C.c_int, dp, ip, ip, dp, ip, ip, dp, dp, dp, dp, dp, dp, dp, dp, C.POINTER(CeSettings),
                                     dp, dp, dp, dp, dp, dp, ip, ip, dp, vp]
     L.ce_vjp_shared_a.argtypes = [vp, C.c_int, dp, lg, dp, lg, lg, dp, dp, dp, dp, dp, dp, dp, lg, lg, ip, ip, C.c_double, C.c_double, C.c_double, C.c_int, vp]
+    L.ce_vjp_lsqr.argtypes = [vp, C.c_int, dp, lg, dp, lg, lg, dp, dp, dp, dp, dp, dp, dp, lg, lg, ip, ip, C.c_double, C.c_double, C.c_double, C.c_int, vp]
     L.ce_qp_native.argtypes = [vp]
     L.ce_acceleration_available.argtypes = [vp]
     L.ce_solve_qp.argtypes = [vp, C.c_int, dp, lg, lg, dp, lg, lg, dp, C.POINTER(CeSettings), dp, dp, dp, ip, ip, dp, vp]

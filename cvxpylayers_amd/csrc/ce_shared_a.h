@@ -62,7 +62,7 @@ __host__ __device__ inline size_t sa_lsqr_lds_doubles(int n, int m, int nq, int 
 // the CSR / CSC structure (any sparsity pattern, but rows of very different lengths serialise on the longest).
 template <int RP>
 __global__ void __launch_bounds__(NT, 3)
-k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, long sAb, const double *__restrict__ qg, long sqk, long sqb, const double *__restrict__ xg, const double *__restrict__ yg,
+k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, long sAb, int per_inst, const double *__restrict__ qg, long sqk, long sqb, const double *__restrict__ xg, const double *__restrict__ yg,
           const double *__restrict__ sg, const double *__restrict__ dxg, const double *__restrict__ dyg, double *__restrict__ dAo,
           double *__restrict__ dqo, long sdqk, long sdqb, int *__restrict__ adj_status, int *__restrict__ iters_o, double atol, double btol, double conlim, int itn_lim) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -93,6 +93,9 @@ k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, long
     const bool TAU = qg != nullptr;
     const double *cq = TAU ? qg + (size_t)inst * sqb : nullptr;
     const double *Ab = Avals0 + (size_t)inst * sAb;
+    // per_inst (RP == 0 only): the A part differs between instances too -- the products read this instance's value row (diffcp's LSQR adjoint for per-instance
+    // templates, solver_args mode="lsqr": ce_vjp_lsqr); else instance 0's values serve every workgroup and stay L2-resident
+    const double *Aprod = per_inst ? Ab : Avals0;
     auto bval = [&](int i) -> double { if (!TAU) return 0.0; const int pb = S.bpos[i]; return pb >= 0 ? Ab[pb] : 0.0; };
 
     for (int i = tid; i < psd_first; i += NT) vv[i] = y[i] - s[i];
@@ -245,8 +248,8 @@ k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, long
             }
             __syncthreads();
         } else {
-            sa_spmv(S.csc_ptr, S.csc_row, (const int *)nullptr, Avals0, n, [&](int i) { return yin[i]; }, [&](int j, double a) { fx(j, -a, TAU ? cq[(size_t)j * sqk] : 0.0); });
-            sa_spmv(S.csr_ptr, S.csr_col, S.csr_src, Avals0, m, [&](int j) { return xin[j]; }, [&](int i, double a) { fy(i, -a, bval(i)); });
+            sa_spmv(S.csc_ptr, S.csc_row, (const int *)nullptr, Aprod, n, [&](int i) { return yin[i]; }, [&](int j, double a) { fx(j, -a, TAU ? cq[(size_t)j * sqk] : 0.0); });
+            sa_spmv(S.csr_ptr, S.csr_col, S.csr_src, Aprod, m, [&](int j) { return xin[j]; }, [&](int i, double a) { fy(i, -a, bval(i)); });
             __syncthreads();
         }
     };

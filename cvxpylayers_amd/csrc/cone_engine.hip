@@ -895,14 +895,15 @@ int ce_solve_shared_a(ce_handle h, int B, int r, int RP, const double *AdT, cons
     HIPCHK(hipGetLastError());
     return CE_OK;
 }
-int ce_vjp_shared_a(ce_handle h, int B, const double *A_vals0, long sA_b, const double *q_vals, long sq_k, long sq_b,
-                    const double *x, const double *y, const double *s, const double *dx, const double *dy,
-                    double *dA_bm, double *dq_vals, long sdq_k, long sdq_b, int *adj_status, int *lsqr_iters, double atol, double btol, double conlim, int iter_lim, void *stream) {
+static int vjp_lsqr_launch(ce_handle h, int B, const double *A_vals0, long sA_b, int per_inst, const double *q_vals, long sq_k, long sq_b,
+                           const double *x, const double *y, const double *s, const double *dx, const double *dy,
+                           double *dA_bm, double *dq_vals, long sdq_k, long sdq_b, int *adj_status, int *lsqr_iters, double atol, double btol, double conlim, int iter_lim, void *stream) {
     if (!h || B <= 0 || !A_vals0 || !x || !y || !s || !dx || !dy || !dA_bm || !dq_vals) { g_err = "null argument"; return CE_E_BADARG; }
     const DevT &T = h->T;
     // products through the singleton / dense-row split when the template has one (CE_SA_SPLIT=0: CSR / CSC products)
     int RP = h->sp_RP;
     if (const char *e = getenv("CE_SA_SPLIT")) { if (atoi(e) == 0) RP = 0; }
+    if (per_inst) RP = 0;      // the split's dense rows are ONE matrix (instance 0's values); per-instance values go through the CSR / CSC products
     if (RP > 0 && sa_lsqr_lds_doubles(T.n, T.m, T.nq, T.ns, T.maxs, RP, h->psd_first, T.nep + T.np) * 8 > LDS_LIMIT) RP = 0;
     const size_t lds = sa_lsqr_lds_doubles(T.n, T.m, T.nq, T.ns, T.maxs, RP, h->psd_first, T.nep + T.np) * 8;
     if (lds > LDS_LIMIT) { g_err = "shared-A adjoint kernel: the LSQR vectors of one instance do not fit LDS"; return CE_E_TOO_LARGE; }
@@ -923,12 +924,23 @@ int ce_vjp_shared_a(ce_handle h, int B, const double *A_vals0, long sA_b, const 
     }
     {
         ProfScope ps(h, 1, (hipStream_t)stream);
-#define LAUNCH_SAL(RPV) hipLaunchKernelGGL(k_sa_lsqr<RPV>, dim3(B), dim3(NT), lds, (hipStream_t)stream, T, S, F, A_vals0, sA_b, q_vals, sq_k, sq_b, x, y, s, dx, dy, dA_bm, dq_vals, sdq_k, sdq_b, adj_status, lsqr_iters, atol, btol, conlim, iter_lim > 0 ? iter_lim : 2 * (T.n + T.m + 1))
+#define LAUNCH_SAL(RPV) hipLaunchKernelGGL(k_sa_lsqr<RPV>, dim3(B), dim3(NT), lds, (hipStream_t)stream, T, S, F, A_vals0, sA_b, per_inst, q_vals, sq_k, sq_b, x, y, s, dx, dy, dA_bm, dq_vals, sdq_k, sdq_b, adj_status, lsqr_iters, atol, btol, conlim, iter_lim > 0 ? iter_lim : 2 * (T.n + T.m + 1))
         if (RP == 0) LAUNCH_SAL(0); else if (RP == 16) LAUNCH_SAL(16); else if (RP == 32) LAUNCH_SAL(32); else LAUNCH_SAL(64);
 #undef LAUNCH_SAL
     }
     HIPCHK(hipGetLastError());
     return CE_OK;
+}
+int ce_vjp_shared_a(ce_handle h, int B, const double *A_vals0, long sA_b, const double *q_vals, long sq_k, long sq_b,
+                    const double *x, const double *y, const double *s, const double *dx, const double *dy,
+                    double *dA_bm, double *dq_vals, long sdq_k, long sdq_b, int *adj_status, int *lsqr_iters, double atol, double btol, double conlim, int iter_lim, void *stream) {
+    return vjp_lsqr_launch(h, B, A_vals0, sA_b, 0, q_vals, sq_k, sq_b, x, y, s, dx, dy, dA_bm, dq_vals, sdq_k, sdq_b, adj_status, lsqr_iters, atol, btol, conlim, iter_lim, stream);
+}
+int ce_vjp_lsqr(ce_handle h, int B, const double *A_vals_bm, long sA_b, const double *q_vals, long sq_k, long sq_b,
+                const double *x, const double *y, const double *s, const double *dx, const double *dy,
+                double *dA_bm, double *dq_vals, long sdq_k, long sdq_b, int *adj_status, int *lsqr_iters, double atol, double btol, double conlim, int iter_lim, void *stream) {
+    if (sA_b == 0 && B > 1) { g_err = "ce_vjp_lsqr: per-instance values need a batch stride"; return CE_E_BADARG; }
+    return vjp_lsqr_launch(h, B, A_vals_bm, sA_b, 1, q_vals, sq_k, sq_b, x, y, s, dx, dy, dA_bm, dq_vals, sdq_k, sdq_b, adj_status, lsqr_iters, atol, btol, conlim, iter_lim, stream);
 }
 int ce_ca_triples(ce_handle h, int B, int lp, double *U, double *roots, const int *active, void *stream) {
     if (!h || B <= 0 || !U || !roots || !active) { g_err = "null argument"; return CE_E_BADARG; }

@@ -59,6 +59,15 @@ def lsqr_rule(merged_args: dict, n: int, m: int) -> tuple:
             int(lim) if lim not in (None, 0) else 2 * (n + m + 1), system)
 
 
+
+def adjoint_mode(merged_args: dict) -> str:
+    """diffcp's `mode` (adj_batch / solve_and_derivative_batch; diffcp_if.py:86 runs its default "lsqr") for PER-INSTANCE-A templates:
+    absent / "dense" -> the direct, rank-revealing elimination (k_backward_rt / k_backward: the same gradients as LSQR wherever the adjoint system is regular,
+    a basic solution on rank-deficient ones);  "lsqr" -> diffcp's LSQR on the full (n + m + 1) system with its stopping rule (ce_vjp_lsqr: the minimum-norm
+    solution on rank-deficient systems, like the reference).  Shared-A templates run LSQR whatever the mode says."""
+    return "lsqr" if str(merged_args.get("mode", "")) == "lsqr" else "direct"
+
+
 _WARNED: set = set()
 
 
@@ -72,14 +81,16 @@ def _warn_once(key: str, msg: str):
 def note_ignored_args(merged_args: dict, explicit_lookback: bool):
     """The reference's solver arguments this plugin ACCEPTS but does not act on, said once instead of swallowed silently (diffcp_if.py:356-367 forwards them to
     diffcp / SCS):  acceleration_lookback > 1 -- the kernels keep ONE secant pair whatever the lookback (SCS keeps `lookback` pairs; same fixed point,
-    iteration counts within 2.5 % on the BASELINE configurations);  mode / solve_method -- the adjoint is a rank-revealing direct elimination for per-instance
-    templates and LSQR for shared-A templates, not selectable;  n_jobs_forward / n_jobs_backward -- the batch runs on the GPU."""
+    iteration counts within 2.5 % on the BASELINE configurations);  mode other than "lsqr" / "dense" (diffcp's "lsmr") and solve_method -- see adjoint_mode();
+    n_jobs_forward / n_jobs_backward -- the batch runs on the GPU."""
     lb = merged_args.get("acceleration_lookback")
     if explicit_lookback and lb is not None and int(lb) > 1:      # (the DEFAULT configuration stays silent -- valid calls must survive `-W error`; info["acceleration"] and the docs carry the one-pair fact)
         _warn_once("lookback", f"MI355 solver: acceleration_lookback={int(lb)}" + ("" if explicit_lookback else " (SCS's default, which the reference forwards)") +
                    " runs as type-I Anderson acceleration with a ONE-pair history (memory 1), not a " + str(int(lb)) + "-pair history; "
                    "pass acceleration_lookback=1 to say so explicitly, 0 to iterate plainly")
     for k in ("mode", "solve_method", "n_jobs_forward", "n_jobs_backward"):
+        if k == "mode" and str(merged_args.get(k)) in ("lsqr", "dense"):          # acted on: adjoint_mode()
+            continue
         if k in merged_args:
             _warn_once(k, f"MI355 solver: solver_args[{k!r}]={merged_args[k]!r} is accepted for compatibility with the DIFFCP plugin and ignored "
                           "(the adjoint method is fixed per template, the batch is solved on the GPU)")
@@ -331,6 +342,14 @@ class ConeEngine:
             if system == "reduced":
                 q_eval = None
             return vjp_const_a(self, A_bm, x, y, s, dx, dy, batch_minor_out=batch_minor_out, atol=atol, btol=btol, iter_lim=lim, q_eval=q_eval)
+        if path == "per_instance_lsqr":      # solver_args mode="lsqr" on a per-instance-A template: diffcp's LSQR instead of the direct elimination
+            if P_bm is not None:
+                raise ValueError("MI355 solver: mode='lsqr' is not available with a quadratic objective inside the kernels (CE_QP_EPIGRAPH=1 brings the problem to cone form)")
+            atol, btol, lim, system = (tuple(lsqr) + ("full",))[:4] if lsqr is not None else lsqr_rule({}, self.n, self.m)
+            if q_eval is None and system != "reduced":
+                lq = getattr(self, "_last_q", None)
+                q_eval = lq if (lq is not None and lq.dim() == 2 and lq.shape[1] == B) else None
+            return self._vjp_lsqr(A_bm, x, y, s, dx, dy, batch_minor_out, atol, btol, lim, None if system == "reduced" else q_eval)
         dq = torch.empty((self.n + 1, B), dtype=torch.float64, device=dev)
         adj = torch.empty((B,), dtype=torch.int32, device=dev)
         if batch_minor_out:
@@ -351,6 +370,25 @@ class ConeEngine:
                                dq.data_ptr(), B, 1, adj.data_ptr(), self._stream())
         _lib.check(rc, "ce_vjp")
         return (dA if batch_minor_out else dA.t()), dq, adj
+
+    def _vjp_lsqr(self, A_bm, x, y, s, dx, dy, batch_minor_out, atol, btol, iter_lim, q_eval, conlim=1e8):
+        """ce_vjp_lsqr: one workgroup per instance runs Paige & Saunders' LSQR on diffcp's adjoint system M^T r = dz with THIS instance's A (include/cone_engine.h)"""
+        dev, B = self.device, A_bm.shape[0]
+        f64 = dict(dtype=torch.float64, device=dev)
+        dA_bm = torch.empty((B, self.nnz_aug), **f64); dq = torch.empty((self.n + 1, B), **f64)
+        adj = torch.empty((B,), dtype=torch.int32, device=dev); its = torch.empty((B,), dtype=torch.int32, device=dev)
+        A_c = A_bm if (A_bm.stride(1) == 1 and (B == 1 or A_bm.stride(0) >= self.nnz_aug)) else A_bm.contiguous()
+        xc, yc, sc_, dxc, dyc = (t.to(torch.float64).contiguous() for t in (x, y, s, dx, dy))
+        if q_eval is not None:
+            qd = q_eval.detach().to(**f64)
+            q_args = (qd.data_ptr(), qd.stride(0), qd.stride(1))
+        else:
+            q_args = (None, 0, 0)
+        rc = _lib.lib().ce_vjp_lsqr(self._h, B, A_c.data_ptr(), A_c.stride(0), *q_args, xc.data_ptr(), yc.data_ptr(), sc_.data_ptr(), dxc.data_ptr(), dyc.data_ptr(),
+                                    dA_bm.data_ptr(), dq.data_ptr(), B, 1, adj.data_ptr(), its.data_ptr(), float(atol), float(btol), float(conlim), int(iter_lim), self._stream())
+        _lib.check(rc, "ce_vjp_lsqr")
+        self.last_lsqr_iters = its
+        return (dA_bm.t().contiguous() if batch_minor_out else dA_bm.t()), dq, adj
 
     # introspection (bench / tests)
     def set_profiling(self, on):
@@ -614,6 +652,8 @@ class _ConeLayer(torch.autograd.Function):
                 warm = tuple(t if t.dim() == 2 else t.unsqueeze(0) for t in warm_start)     # (x, y, s) tensors
             x, y, s, iters, status, resid = eng.solve(A_bm, q_dev, settings, warm=warm, P_bm=P_bm)
             path = eng.last_path          # recorded per call: the backward of THIS node must not follow a later solve's path
+            if path == "per_instance" and P_bm is None and adjoint_mode(merged_args) == "lsqr":
+                path = "per_instance_lsqr"          # (the adjoint of this node: diffcp's LSQR instead of the direct elimination)
             eng._last_solution = (x.detach(), y.detach(), s)
             # The reference raises from forward() when an instance fails (diffcp_if.py:365-372), so the host has to learn the outcome here: one tiny
             # reduction kernel + 8 bytes into pinned memory behind the solve (ce_status_summary) and ONE stream synchronisation -- not the status
@@ -626,7 +666,7 @@ class _ConeLayer(torch.autograd.Function):
             dual = y.to(in_device)
             info = dict(iters=iters, status=status, resid=resid, acceleration=getattr(eng, "last_acceleration", False))
             lsqr = lsqr_rule(merged_args, eng.n, eng.m)
-            saved = (eng, A_bm, x.detach(), y.detach(), s, batch_minor_in, P_bm, path, None, lsqr, q_dev if path == "const_a" else None) if needs_grad else None
+            saved = (eng, A_bm, x.detach(), y.detach(), s, batch_minor_in, P_bm, path, None, lsqr, q_dev if path in ("const_a", "per_instance_lsqr") else None) if needs_grad else None
             if status.numel():
                 summ = eng.read_summaries()
                 min_status, n_inaccurate = int(summ[0][0]), int(summ[0][1])
@@ -651,7 +691,7 @@ class _ConeLayer(torch.autograd.Function):
             y = torch.where(failed[:, None], torch.full_like(y, float("nan")), y)
             primal = x.to(in_device)
             dual = y.to(in_device)
-            saved = (eng, A_bm, x.detach(), y.detach(), s, batch_minor_in, P_bm, path, failed, lsqr, q_dev if path == "const_a" else None) if needs_grad else None
+            saved = (eng, A_bm, x.detach(), y.detach(), s, batch_minor_in, P_bm, path, failed, lsqr, q_dev if path in ("const_a", "per_instance_lsqr") else None) if needs_grad else None
         # x / y are handed back as `primal` / `dual` (same objects when the input lives on the engine's device), and autograd
         # attaches this node to them: keeping the SAME objects on the node would form a reference cycle (node -> saved ->
         # primal -> grad_fn -> node) that only the cyclic GC breaks, i.e. 167 MB buffers pile up for many steps and the

@@ -91,8 +91,8 @@ void ce_default_settings(ce_settings *s);
  * library short structs.  Bindings must check  ce_abi_version() == CE_ABI_VERSION  and  ce_struct_size(which) == sizeof(their
  * struct)  (which: 0 ce_template, 1 ce_settings) once at load time and refuse to continue otherwise (cvxpylayers_amd/_lib.py
  * does; tests/test_cabi.py checks the stub printed in INTEGRATION.md the same way).  CE_ABI_VERSION is bumped whenever a struct
- * layout, an entry point's signature or the meaning of an argument changes (9: ce_vjp_shared_a takes sA_b and q_vals -- the adjoint system gains diffcp's tau row and column --, its iter_lim default is diffcp's 2 (n + m + 1); 8: ce_set_dispatch_history added, ce_status_summary writes a fourth "ready" int; 7: ce_status_summary added; 6: ce_default_settings = SCS defaults incl. acceleration_lookback 10, ce_acceleration_available). */
-#define CE_ABI_VERSION 9
+ * layout, an entry point's signature or the meaning of an argument changes (10: ce_vjp_lsqr added; 9: ce_vjp_shared_a takes sA_b and q_vals -- the adjoint system gains diffcp's tau row and column --, its iter_lim default is diffcp's 2 (n + m + 1); 8: ce_set_dispatch_history added, ce_status_summary writes a fourth "ready" int; 7: ce_status_summary added; 6: ce_default_settings = SCS defaults incl. acceleration_lookback 10, ce_acceleration_available). */
+#define CE_ABI_VERSION 10
 int ce_abi_version(void);
 int ce_struct_size(int which);
 /* 1 when ce_solve / ce_solve_qp on this engine honour ce_settings.acceleration_lookback > 0 (second-generation forward kernel with
@@ -261,6 +261,17 @@ int ce_solve_shared_a(ce_handle h, int B, int r, int RP, const double *AdT, cons
 int ce_vjp_shared_a(ce_handle h, int B, const double *A_vals0, long sA_b, const double *q_vals, long sq_k, long sq_b,
                     const double *x, const double *y, const double *s, const double *dx, const double *dy,
                     double *dA_bm, double *dq_vals, long sdq_k, long sdq_b, int *adj_status, int *lsqr_iters, double atol, double btol, double conlim, int iter_lim, void *stream);
+
+/*
+ * diffcp's LSQR adjoint for templates whose A DOES depend on the parameters  <- adj_batch(..., mode="lsqr"), the mode diffcp_if.py:86 runs by default.
+ * ce_vjp solves the adjoint system by a rank-revealing direct elimination (the same gradients wherever the system is regular: every BASELINE configuration);
+ * on a rank-deficient system it returns a basic solution where diffcp's LSQR returns the minimum-norm one.  This entry runs ce_vjp_shared_a's LSQR kernel with
+ * the A part read per instance: A_vals_bm (B, nnz_aug) batch-major (sA_b = nnz_aug), every other argument as ce_vjp_shared_a.  The plugin selects it with
+ * solver_args mode="lsqr".  A is streamed from L2 / HBM twice per LSQR iteration: the direct elimination stays the default for speed.
+ */
+int ce_vjp_lsqr(ce_handle h, int B, const double *A_vals_bm, long sA_b, const double *q_vals, long sq_k, long sq_b,
+                const double *x, const double *y, const double *s, const double *dx, const double *dy,
+                double *dA_bm, double *dq_vals, long sdq_k, long sdq_b, int *adj_status, int *lsqr_iters, double atol, double btol, double conlim, int iter_lim, void *stream);
 
 /* Longest-first dispatch.  Workgroups are dispatched in index order and one workgroup owns one instance, so the tail of a forward launch is set by the
  * instances that happen to start last: when they are long ones the last slots drain slowly (13 % of the metric configuration's kernel time).  With the switch

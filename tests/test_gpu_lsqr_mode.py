@@ -1,0 +1,116 @@
+"""solver_args mode="lsqr" on per-instance-A templates: diffcp's own adjoint method (diffcp_if.py:86 -> adj_batch, default mode "lsqr") instead of the engine's
+direct elimination.  ce_vjp_lsqr runs Paige & Saunders' LSQR on the full (n + m + 1) system M^T r = dz, one workgroup per instance, with the instance's own A.
+Checked against the oracle's LSQR mode (oracle/cone_oracle.c lsqr_MT) at matched tolerances:
+  * a regular system: LSQR (tight) = the direct elimination = the oracle, to 1e-6; at diffcp's 1e-8 rule the iteration counts are the oracle's;
+  * a RANK-DEFICIENT system (a duplicated equality row): LSQR returns the minimum-norm solution -- db equal on the two copies, as diffcp does -- where the direct
+    elimination returns a basic one; the engine's LSQR still matches the oracle's to 1e-6;
+  * through the plugin: `_CvxpyLayer.apply(..., solver_args={"mode": "lsqr"})` reaches it, silently (no "ignored" warning)."""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+from cvxpylayers_amd import problems as P
+from kit import TIGHT_LSQR
+from test_gpu_parity import gpu_solve
+
+pytestmark = pytest.mark.gpu
+
+
+def _want(tpl, g, n):
+    cols = np.repeat(np.arange(n + 1), np.diff(tpl.indptr))
+    B = g["dA"].shape[0]
+    want = np.empty((tpl.nnz_aug, B))
+    for k in range(tpl.nnz_aug):
+        i, j = tpl.indices[k], cols[k]
+        want[k] = -g["dA"][:, i, j] if j < n else g["db"][:, i]          # boundary convention (diffcp_if.py:91-92)
+    return want
+
+
+def _setup(n, cones, B, seed, eps, dup_rows=None, max_iters=200000):
+    from oracle import oracle
+    tpl = P.dense_template(n, cones)
+    A, b, c = P.generate(n, cones, B, seed=seed)
+    if dup_rows is not None:
+        src, dst = dup_rows
+        A[:, dst, :] = A[:, src, :]; b[:, dst] = b[:, src]
+    ref = oracle.solve_batch(A, b, c, cones, eps=eps, max_iters=max_iters)
+    assert (ref["status"] == 1).all()
+    eng, A_bm, x, y, s, iters, status, resid = gpu_solve(tpl, A, b, c, eps=eps, max_iters=max_iters)
+    assert (status == 1).all()
+    rng = np.random.default_rng(seed + 100)
+    dx = rng.standard_normal(ref["x"].shape); dy = rng.standard_normal(ref["y"].shape)
+    pt = tuple(torch.from_numpy(ref[k]).cuda() for k in ("x", "y", "s"))          # differentiate at the oracle's point
+    _, q_eval = tpl.values_from_dense(A, b, c)
+    return oracle, tpl, (A, b, c), ref, eng, A_bm, pt, dx, dy, torch.from_numpy(q_eval).cuda()
+
+
+def test_lsqr_mode_equals_direct_and_oracle_on_a_regular_system():
+    cfg = P.CONFIGS["M"]; n, cones = cfg["n"], cfg["cones"]
+    oracle, tpl, (A, b, c), ref, eng, A_bm, (xr, yr, sr), dx, dy, q_t = _setup(n, cones, 48, 0, 1e-9)
+    dxt, dyt = torch.from_numpy(dx).cuda(), torch.from_numpy(dy).cuda()
+    dA_d, dq_d, _ = eng.vjp(A_bm, xr, yr, sr, dxt, dyt, path="per_instance")
+    dA_l, dq_l, adj = eng.vjp(A_bm, xr, yr, sr, dxt, dyt, path="per_instance_lsqr", lsqr=TIGHT_LSQR, q_eval=q_t)
+    torch.cuda.synchronize()
+    assert (adj.cpu().numpy() == 0).all()
+    g = oracle.adjoint_batch(A, b, c, cones, ref["x"], ref["y"], ref["s"], dx, dy, mode="lsqr", lsqr_atol=TIGHT_LSQR[0], lsqr_btol=TIGHT_LSQR[1], lsqr_iter_lim=TIGHT_LSQR[2])
+    want = _want(tpl, g, n)
+    scale = 1 + np.abs(want).max()
+    assert np.abs(dA_l.cpu().numpy() - want).max() < 1e-6 * scale
+    assert np.abs(dA_l.cpu().numpy() - dA_d.cpu().numpy()).max() < 1e-5 * scale          # regular system: one solution
+    assert np.abs(dq_l.cpu().numpy()[:n] - g["dc"].T).max() < 1e-6 * (1 + np.abs(g["dc"]).max())
+    # diffcp's stopping rule (1e-8 / 1e-8 / 1e8 / 2 N): the iteration counts are the oracle's
+    dA_r, dq_r, adj_r = eng.vjp(A_bm, xr, yr, sr, dxt, dyt, path="per_instance_lsqr", q_eval=q_t)
+    torch.cuda.synchronize()
+    g_r = oracle.adjoint_batch(A, b, c, cones, ref["x"], ref["y"], ref["s"], dx, dy, mode="lsqr")
+    it_e, it_o = eng.last_lsqr_iters.cpu().numpy(), g_r["lsqr_iters"]
+    assert np.abs(it_e - it_o).max() <= 3 + 0.05 * it_o.max(), (it_e, it_o)
+    assert np.abs(dA_r.cpu().numpy() - _want(tpl, g_r, n)).max() < 1e-5 * scale
+
+
+def test_lsqr_mode_returns_diffcps_minimum_norm_solution_on_a_rank_deficient_system():
+    n, cones = 8, {"z": 4, "l": 6, "q": [4]}
+    oracle, tpl, (A, b, c), ref, eng, A_bm, (xr, yr, sr), dx, dy, q_t = _setup(n, cones, 6, 2, 1e-10, dup_rows=(0, 1))
+    dxt, dyt = torch.from_numpy(dx).cuda(), torch.from_numpy(dy).cuda()
+    dA_l, dq_l, adj = eng.vjp(A_bm, xr, yr, sr, dxt, dyt, path="per_instance_lsqr", lsqr=TIGHT_LSQR, q_eval=q_t)
+    dA_d, dq_d, _ = eng.vjp(A_bm, xr, yr, sr, dxt, dyt, path="per_instance")
+    torch.cuda.synchronize()
+    g = oracle.adjoint_batch(A, b, c, cones, ref["x"], ref["y"], ref["s"], dx, dy, mode="lsqr", lsqr_atol=TIGHT_LSQR[0], lsqr_btol=TIGHT_LSQR[1], lsqr_iter_lim=TIGHT_LSQR[2])
+    want = _want(tpl, g, n)
+    scale = 1 + np.abs(want).max()
+    got = dA_l.cpu().numpy()
+    assert np.abs(got - want).max() < 1e-6 * scale, np.abs(got - want).max() / scale
+    assert np.abs(dq_l.cpu().numpy()[:n] - g["dc"].T).max() < 1e-6 * (1 + np.abs(g["dc"]).max())
+    # the two copies of the equality receive the same db from the minimum-norm solution (b entries: the last column of the value order) ...
+    cols = np.repeat(np.arange(n + 1), np.diff(tpl.indptr))
+    kb = {int(tpl.indices[k]): k for k in range(tpl.nnz_aug) if cols[k] == n}
+    assert np.abs(got[kb[0]] - got[kb[1]]).max() < 1e-8 * scale
+    # ... and not from the direct elimination's basic solution: the two methods differ here, which is why the mode exists
+    direct = dA_d.cpu().numpy()
+    assert np.abs(direct[kb[0]] - direct[kb[1]]).max() > 1e-3
+    assert np.isfinite(direct).all()
+
+
+def test_mode_lsqr_through_the_plugin_is_silent_and_reaches_the_lsqr_kernel():
+    from cvxpylayers_amd.interfaces.mi355_if import MI355_ctx, _CvxpyLayer
+    n, cones = 8, {"z": 4, "l": 6, "q": [4]}
+    tpl = P.dense_template(n, cones)
+    A, b, c = P.generate(n, cones, 6, seed=2)
+    A[:, 1, :] = A[:, 0, :]; b[:, 1] = b[:, 0]
+    A_eval, q_eval = tpl.values_from_dense(A, b, c)
+    ctx = MI355_ctx(None, tpl.problem_data_index, cones, options={"eps": 1e-10, "max_iters": 200000})
+    grads = {}
+    for mode in ("lsqr", "dense"):
+        A_t = torch.from_numpy(A_eval).cuda().requires_grad_(); q_t = torch.from_numpy(q_eval).cuda().requires_grad_()
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")          # an "accepted and ignored" warning would fail the call
+            primal, dual, info, _ = _CvxpyLayer.apply(None, q_t, A_t, ctx, {"mode": mode, "lsqr_atol": 1e-12, "lsqr_btol": 1e-12, "lsqr_iter_lim": 20000}, True, None)
+            (primal * torch.arange(1, n + 1, device="cuda", dtype=torch.float64)).sum().backward()
+        grads[mode] = A_t.grad.cpu().numpy()
+    eng = ctx.engine(torch.device("cuda", 0))
+    assert eng.last_lsqr_iters is not None and int(eng.last_lsqr_iters.max()) > 0
+    cols = np.repeat(np.arange(n + 1), np.diff(tpl.indptr))
+    kb = {int(tpl.indices[k]): k for k in range(tpl.nnz_aug) if cols[k] == n}
+    assert np.abs(grads["lsqr"][kb[0]] - grads["lsqr"][kb[1]]).max() < 1e-7 * (1 + np.abs(grads["lsqr"]).max())
+    assert np.abs(grads["dense"][kb[0]] - grads["dense"][kb[1]]).max() > 1e-3

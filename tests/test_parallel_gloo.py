@@ -190,9 +190,10 @@ def test_world_size_2_gloo_through_the_frontend_with_a_broadcast_parameter():
 def test_bench_dry_run_ranks_exercises_the_self_spawn_plumbing():
     import json
     import subprocess
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run-ranks", "2", "--steps", "2"], capture_output=True, text=True, timeout=300,
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run-ranks", "2", "--steps", "6", "--rotate", "4"], capture_output=True, text=True, timeout=300,
                          env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")})
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert out.returncode == 0 and len(lines) == 1, (out.stdout[-400:], out.stderr[-800:])
     rec = json.loads(lines[0])
     assert rec["dry_run"] and rec["ranks"] == 2 and rec["gather_ok"] and rec["backend"] == "gloo" and rec["master_addr"] == "127.0.0.1"
+    assert rec["rotating_batches"] == 4          # every rank visits the same slot of its K rotating batches at the same step (gather_ok checks the gathered sums per slot)

@@ -1,5 +1,5 @@
 """Solver arguments the plugin accepts for compatibility with the DIFFCP plugin (diffcp_if.py:356-367) but does not act on are SAID, once per
-process and topic, not swallowed: an EXPLICIT acceleration_lookback > 1 (one-pair history), mode / solve_method / n_jobs_*.
+process and topic, not swallowed: an EXPLICIT acceleration_lookback > 1 (one-pair history), mode other than lsqr / dense, solve_method, n_jobs_*.
 The default configuration stays silent (a call that is valid for the reference must survive `-W error`)."""
 import warnings
 
@@ -32,14 +32,16 @@ def test_lookback_zero_and_one_are_exactly_what_runs(lb):
     assert not w
 
 
-def test_mode_and_n_jobs_are_accepted_and_reported():
+def test_mode_lsqr_and_dense_are_acted_on_other_modes_and_n_jobs_are_reported():
     m = _fresh()
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
-        m.note_ignored_args({"acceleration_lookback": 0, "mode": "lsqr", "n_jobs_forward": 4}, explicit_lookback=True)
-        m.note_ignored_args({"acceleration_lookback": 0, "mode": "dense", "n_jobs_backward": -1}, explicit_lookback=True)
+        m.note_ignored_args({"acceleration_lookback": 0, "mode": "lsqr", "n_jobs_forward": 4}, explicit_lookback=True)          # mode="lsqr": diffcp's LSQR adjoint (ce_vjp_lsqr)
+        m.note_ignored_args({"acceleration_lookback": 0, "mode": "dense", "n_jobs_backward": -1}, explicit_lookback=True)       # mode="dense": the direct elimination
+        m.note_ignored_args({"acceleration_lookback": 0, "mode": "lsmr"}, explicit_lookback=True)
     msgs = [str(x.message) for x in w]
-    assert len(msgs) == 3 and any("'mode'" in t for t in msgs) and any("n_jobs_forward" in t for t in msgs) and any("n_jobs_backward" in t for t in msgs)
+    assert len(msgs) == 3 and any("'mode'" in t and "lsmr" in t for t in msgs) and any("n_jobs_forward" in t for t in msgs) and any("n_jobs_backward" in t for t in msgs)
+    assert m.adjoint_mode({"mode": "lsqr"}) == "lsqr" and m.adjoint_mode({"mode": "dense"}) == "direct" and m.adjoint_mode({}) == "direct"
     # and they still pass validation (unknown names do not)
     m.make_settings({"mode": "lsqr", "n_jobs_forward": 4, "eps": 1e-6})
     with pytest.raises(ValueError):
