@@ -166,11 +166,12 @@ def sq_limiter(kernel_short):
             continue
         for k, v in d.items():
             if k.startswith(kernel_short) and isinstance(v, dict):
-                keep = {kk: vv for kk, vv in v.items() if kk in ("valu_busy", "wait_any", "wait_inst_any", "active_inst_any", "lds_conflict", "mfma_util")}      # shares of wave time
+                keep = {kk: vv for kk, vv in v.items() if kk in ("valu_busy", "wait_any", "wait_inst_any", "active_inst_any", "lds_conflict", "mfma_util", "simd_valu_util", "cu_lds_inst_util", "cu_lds_array_util", "resident_waves_per_cu")}      # shares of wave time
                 return dict(source=os.path.relpath(f, ROOT), kernel=k, counters=keep,
-                            reading="shares of wave time from the SQ counters of this file: a wave of the forward kernel has an fp64 VALU instruction in flight for about a fifth of its time and waits (barriers, LDS operand "
-                                    "reads, dependent chains) for the rest; three workgroups per CU overlap these chains but do not hide them -- the kernel is bound by the latency of one workgroup's barrier-separated "
-                                    "phases and by LDS operand delivery, not by HBM (touched once) or MFMA")
+                            reading="SQ counters of this file. Per unit (simd_valu_util, cu_lds_*_util; scripts/sq_summary.py): a SIMD has a VALU instruction in its pipe for about half of the launch, a CU's LDS is busy "
+                                    "for about half of it, with ~10 of 12 wave slots occupied on average (tail of the launch) -- neither pipe is saturated. Per wave (valu_busy, wait_*): a wave issues VALU work for a fifth of its "
+                                    "time and waits (barriers, LDS operand reads, dependent chains) for most of the rest; three workgroups per CU overlap these chains but do not hide them. The kernel is bound by the latency of "
+                                    "one workgroup's barrier-separated phases together with the two half-loaded pipes they share, not by HBM (touched once) or MFMA; about a sixth of its VALU instructions are the fp64 FMAs the flop count knows, hence the fp64 fraction")
     return None
 
 
