@@ -265,10 +265,31 @@ class ConeEngine:
         if getattr(self, "_summary_host", None) is None:
             self._summary_host = torch.zeros((3, 4), dtype=torch.int32).pin_memory()          # slot 0: status of a forward; slots 1, 2: adjoint flags of backward calls, alternating
             self._summary_np = self._summary_host.numpy()          # (shares the pinned memory)
+            self._summary_vec = [None, None, None]
         self._summary_np[slot, 3] = 0                               # "ready" flag, set by the device after the three values
         self._summary_last_slot = slot
+        self._summary_vec[slot] = vec                               # (kept for ensure_summary: the counts can be recomputed from the vector if the device's stores never arrive)
         stream = torch.cuda.current_stream(self.device)
         _lib.check(_lib.lib().ce_status_summary(self._h, int(vec.numel()), vec.data_ptr(), self._summary_host[slot].data_ptr(), C.c_void_p(stream.cuda_stream)), "ce_status_summary")
+
+    def ensure_summary(self, slot: int):
+        """Call with the stream drained.  The three counts of a slot are only valid once its ready flag is set; a flag that is still clear AFTER a synchronisation
+        means the device's stores did not reach this buffer (a mapping of the pinned buffer that went stale, a box misbehaving): then the counts are recomputed
+        from the device vector itself -- correctness does not hang on the fast path -- and the spin-poll is switched off for this engine (every later call would
+        otherwise burn its full 0.25 s guard)."""
+        arr = self._summary_np
+        if arr[slot, 3] != 0:
+            return
+        vec = self._summary_vec[slot]
+        if vec is None:
+            return
+        v = vec.detach().to("cpu").numpy()
+        arr[slot, 0] = int(v.min()) if v.size else 0
+        arr[slot, 1] = int((v == 2).sum()); arr[slot, 2] = int(((v & 3) != 0).sum()); arr[slot, 3] = 1
+        if not getattr(self, "_summary_no_spin", False):
+            self._summary_no_spin = True
+            warnings.warn("MI355 solver: the status summary written by the device did not arrive in pinned host memory; recomputed from the status vector, "
+                          "polling disabled for this engine (stream synchronisation from now on)")
 
     def read_summaries(self):
         """Waits for the summaries enqueued on this stream and returns them.  The last one enqueued carries a ready flag in pinned memory: polling it
@@ -277,14 +298,17 @@ class ConeEngine:
         import os
         import time
         slot = getattr(self, "_summary_last_slot", None)
-        if slot is not None and os.environ.get("CE_SPIN_WAIT") != "0":
+        if slot is not None and os.environ.get("CE_SPIN_WAIT") != "0" and not getattr(self, "_summary_no_spin", False):
             arr, t0 = self._summary_np, time.perf_counter()
             while arr[slot, 3] == 0:
                 if time.perf_counter() - t0 > 0.25:                 # long solves: hand the core back
                     torch.cuda.current_stream(self.device).synchronize()
+                    self.ensure_summary(slot)
                     break
         else:
             torch.cuda.current_stream(self.device).synchronize()
+            if slot is not None:
+                self.ensure_summary(slot)
         return self._summary_np.tolist()
 
     def status_summary(self, status: torch.Tensor) -> tuple[int, int]:
@@ -576,6 +600,7 @@ def _fold_adjoint(eng, entry):
     # was just read is not ordered by that read
     if getattr(eng, "_summary_np", None) is not None and eng._summary_np[slot, 3] == 0:
         torch.cuda.synchronize(eng.device)
+        eng.ensure_summary(slot)
     eng._adj_count += int(eng._summary_np[slot, 2])     # bits 0-1; bit 2 (4) = rank-deficient system, basic solution returned like the reference's LSQR does -- not a failure
     eng._adj_total += bs
 

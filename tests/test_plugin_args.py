@@ -46,3 +46,26 @@ def test_mode_lsqr_and_dense_are_acted_on_other_modes_and_n_jobs_are_reported():
     m.make_settings({"mode": "lsqr", "n_jobs_forward": 4, "eps": 1e-6})
     with pytest.raises(ValueError):
         m.make_settings({"lookback": 3})
+
+
+def test_status_counts_are_recomputed_when_the_device_summary_never_arrives():
+    """ensure_summary (mi355_if.ConeEngine): a ready flag still clear AFTER the stream was drained means the device's stores did not reach the pinned buffer;
+    the counts then come from the status vector itself (min, #inaccurate, #flagged) and the engine stops spin-polling -- said once."""
+    import numpy as np
+    import torch
+    m = _fresh()
+    eng = object.__new__(m.ConeEngine)
+    eng._summary_np = np.zeros((3, 4), dtype=np.int32)
+    eng._summary_vec = [torch.tensor([1, 2, 1, -2, 2], dtype=torch.int32), None, torch.tensor([0, 4, 1, 0], dtype=torch.int32)]
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        eng.ensure_summary(0)
+        eng.ensure_summary(2)
+        eng.ensure_summary(1)            # nothing enqueued in that slot: left alone
+    assert eng._summary_np[0].tolist() == [-2, 2, 5, 1]          # min status, two "solved, inaccurate", five with (v & 3) != 0
+    assert eng._summary_np[2].tolist() == [0, 0, 1, 1]           # adjoint flags: bit 2 (rank-deficient, 4) is not a failure, bits 0-1 are
+    assert eng._summary_np[1].tolist() == [0, 0, 0, 0]
+    assert eng._summary_no_spin and len(w) == 1 and "did not arrive" in str(w[0].message)
+    eng._summary_np[0] = [1, 0, 0, 1]                            # a slot whose flag IS set is never touched
+    eng.ensure_summary(0)
+    assert eng._summary_np[0].tolist() == [1, 0, 0, 1]
