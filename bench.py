@@ -288,7 +288,7 @@ def main():
         last_info[slot] = info
         return info
 
-    # clock ramp: a run as short as the driver's (--steps 20 --warmup 5: 60 ms of GPU work) would be timed on a GPU that has not reached its steady clocks yet (ROUND_NOTES.md: short measurements right
+    # clock ramp: a run as short as the driver's (--steps 20 --warmup 5: 60 ms of GPU work) would be timed on a GPU that has not reached its steady clocks yet (docs/ROUND_NOTES_r3_r4.md: short measurements right
     # after process start see the ramp).  Untimed steps until 0.3 s have passed, in ADDITION to the W warm-up steps of the contract; reported as `prewarm_steps`.
     prewarm_steps = 0
     t_pw = time.perf_counter()

@@ -1,6 +1,6 @@
 """usage: asm_serial_chains.py <asm file> <mangled kernel prefix> [min_run]
 Heuristic scan of a kernel's ISA for SERIALISED memory round trips: runs of >= min_run (default 3) consecutive "one or two loads, then s_waitcnt ...cnt(0)"
-groups with no other load in flight -- the pattern that cost k_fwd2 ten LDS round trips in its A p_x phase (ROUND_NOTES.md).  Prints the basic blocks with
+groups with no other load in flight -- the pattern that cost k_fwd2 ten LDS round trips in its A p_x phase (docs/ROUND_NOTES_r3_r4.md).  Prints the basic blocks with
 such runs, their loop depth and the first instructions of the run; use scripts/asm_loops.py <asm> <kernel> <block> to read the block."""
 import re, sys
 src = open(sys.argv[1]).read().split('\n')
