@@ -44,6 +44,20 @@ def lib():
     return _LIB
 
 
+def default_threads() -> int:
+    """OpenMP threads of a batch call with nthreads = 0: the runtime's own maximum capped by what this process may use (affinity mask, cgroup CPU quota).  On a box
+    with 256 CPUs visible and a quota of 16 the runtime's default is 256 threads whose spinning gets the whole cgroup throttled."""
+    import os
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(per))))
+    except Exception:
+        pass
+    return max(1, min(n, int(lib().oc_num_threads())))
+
+
 def make_opts(**kw) -> Opts:
     """Accepts the reference's solver_args keys (eps, max_iters, ...; diffcp maps eps -> eps_abs & eps_rel)."""
     o = Opts()
@@ -98,7 +112,7 @@ def solve_batch(A, b, c, cones, nthreads=0, warm=None, P=None, **opts):
         P = np.ascontiguousarray(P, dtype=np.float64); Pp = _p(P)
     rc = lib().oc_solve_batch_qp(B, n, m, _p(A), _p(b), _p(c), Pp, z, l, len(q), _p(q, C.c_int), len(s), _p(s, C.c_int), nep[0], len(nep[1]), _p(nep[1]),
                               C.byref(o), _p(x), _p(y), _p(sv), _p(iters, C.c_int), _p(status, C.c_int), _p(resid),
-                              int(nthreads))
+                              int(nthreads) if int(nthreads) > 0 else default_threads())
     if rc != 0:
         raise ValueError("cone dims do not match m")
     return dict(x=x, y=y, s=sv, iters=iters, status=status, resid=resid)
@@ -126,7 +140,7 @@ def adjoint_batch(A, b, c, cones, x, y, s, dx, dy, ds=None, nthreads=0, P=None, 
         dP = np.empty((B, n, n)); dPp = _p(dP)
     rc = lib().oc_adjoint_batch_qp(B, n, m, _p(A), _p(b), _p(c), Pp, z, l, len(q), _p(q, C.c_int), len(sd), _p(sd, C.c_int), nep[0], len(nep[1]), _p(nep[1]),
                                 C.byref(o), _p(x), _p(y), _p(s), _p(dx), _p(dy), dsp, _p(dA), _p(db), _p(dc), dPp,
-                                   _p(it, C.c_int), int(nthreads))
+                                   _p(it, C.c_int), int(nthreads) if int(nthreads) > 0 else default_threads())
     if rc != 0:
         raise ValueError("cone dims do not match m")
     out = dict(dA=dA, db=db, dc=dc, lsqr_iters=it)

@@ -18,6 +18,8 @@ def rccl_one_rank():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(29600 + os.getpid() % 2000)
+    os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")          # one node, rendezvous on 127.0.0.1: no interface probing (RCCL's bootstrap took 31 s on one box of round 5)
+    os.environ.setdefault("NCCL_IB_DISABLE", "1")
     torch.cuda.set_device(0)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     yield
