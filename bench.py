@@ -251,6 +251,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost"):      # one node (the contract): bootstrap on the loopback interface, no interface / IB probing
+            os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")                            # (RCCL's one-rank bootstrap took 3 s or 31 s depending on the box without it; data moves over xGMI P2P either way)
+            os.environ.setdefault("NCCL_IB_DISABLE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
