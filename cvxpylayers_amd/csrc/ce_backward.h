@@ -11,7 +11,7 @@ __global__ void __launch_bounds__(NT)
 k_backward(DevT T, int nkcap, int ldk, const double *__restrict__ Avals, const double *__restrict__ xg,
            const double *__restrict__ yg, const double *__restrict__ sg, const double *__restrict__ dxg,
            const double *__restrict__ dyg, double *__restrict__ dAo, double *__restrict__ dqo, long sdqk, long sdqb,
-           int *__restrict__ adj_status, double *gwsA, double *gwsK) {
+           int *__restrict__ adj_status, double *gwsA, double *gwsK, int *__restrict__ fix = nullptr) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int tid = threadIdx.x, inst = blockIdx.x;
     const int n = T.n, m = T.m, lda = T.lda, nq = T.nq, z = T.z;
@@ -163,6 +163,7 @@ k_backward(DevT T, int nkcap, int ldk, const double *__restrict__ Avals, const d
         for (int k = tid; k < T.nnz_aug; k += NT) dAo[(size_t)inst * T.nnz_aug + k] = 0.0;
         for (int j = tid; j <= n; j += NT) dqo[j * sdqk + inst * sdqb] = 0.0;
         if (tid == 0 && adj_status) adj_status[inst] = 2;
+        if (tid == 0 && fix) fix[1 + atomicAdd(fix, 1)] = inst;
         return;
     }
     // ---- d = DPi(v) dy   (symmetric), per-cone scalars e_y.d, e_s.d
@@ -566,6 +567,7 @@ k_backward(DevT T, int nkcap, int ldk, const double *__restrict__ Avals, const d
     }
     for (int j = tid; j <= n; j += NT) dqo[j * sdqk + inst * sdqb] = (j < n) ? -rx[j] : 0.0;
     if (tid == 0 && adj_status) adj_status[inst] = misc[2];
+    if (tid == 0 && fix && (misc[2] & 4)) fix[1 + atomicAdd(fix, 1)] = inst;      // rank-deficient: re-solved by the LSQR launch behind this kernel (ce_vjp_qp)
 }
 
 // ================================================================================================

@@ -45,7 +45,7 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
               double *__restrict__ dAo, double *__restrict__ dqo, long sdqk, long sdqb, int *__restrict__ adj_status,
               const double *__restrict__ Pvals_g = nullptr, int nnzP = 0, const int *__restrict__ pmap = nullptr,
               const int *__restrict__ prow = nullptr, const int *__restrict__ pcol = nullptr, int p_tri = 0,
-              double *__restrict__ dPo = nullptr, int retry = 0, int *__restrict__ nk_max = nullptr) {
+              double *__restrict__ dPo = nullptr, int retry = 0, int *__restrict__ nk_max = nullptr, int *__restrict__ fix = nullptr, int nonfinal = 0) {
     // retry: second launch of a two-tile plan (cone_engine.hip ce_vjp_qp): a SMALLER tile variant has already served every instance whose system fits it
     // and flagged the others (adj_status 2, zero gradient); this launch -- the template's worst-case tile -- recomputes the flagged ones only.
     if (retry && adj_status[blockIdx.x] != 2) return;
@@ -241,6 +241,7 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
         for (int j = tid; j <= n; j += NTB) dqo[j * sdqk + inst * sdqb] = 0.0;
         if (dPo) for (int k = tid; k < nnzP; k += NTB) dPo[(size_t)inst * nnzP + k] = 0.0;
         if (tid == 0 && adj_status) adj_status[inst] = 2;
+        if (tid == 0 && fix && !nonfinal) fix[1 + atomicAdd(fix, 1)] = inst;      // (the LSQR launch behind this kernel serves it)
         return;
     }
     CE_STAMP(2);
@@ -734,6 +735,7 @@ k_backward_rt(DevT T, const double *__restrict__ Avals, const double *__restrict
         }
     }
     if (tid == 0 && adj_status) adj_status[inst] = misc[2];
+    if (tid == 0 && fix && (misc[2] & 4)) fix[1 + atomicAdd(fix, 1)] = inst;      // rank-deficient system: diffcp's LSQR element replaces this basic solution (ce_vjp_qp)
 #ifdef CE_TIMING
     CE_STAMP(7);
     if (tid < 7) dAo[(size_t)inst * T.nnz_aug + tid] = (double)(tstamp[tid + 1] - tstamp[tid]);

@@ -172,7 +172,10 @@ __device__ __forceinline__ void gather_tile(const int *__restrict__ base, int t,
             if (k < TT) {
                 const int4 q = ix4[k >> 2];
                 const int ix = (k & 3) == 0 ? q.x : ((k & 3) == 1 ? q.y : ((k & 3) == 2 ? q.z : q.w));
-                f(k, ix, raw[u]);
+                // a structural zero read entry 0 through the clamped index: its bits are cleared here (two v_and_b32 with the index's sign mask -- integer
+                // operations cannot be turned back into a branch around the load, and a non-finite entry 0 cannot leak into the tile as Inf * 0 = NaN)
+                const int msk = ~(ix >> 31);
+                f(k, ix, __hiloint2double(__double2hiint(raw[u]) & msk, __double2loint(raw[u]) & msk));
             }
         }
         __builtin_amdgcn_sched_barrier(0);

@@ -64,9 +64,13 @@ template <int RP>
 __global__ void __launch_bounds__(NT, 3)
 k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, long sAb, int per_inst, const double *__restrict__ qg, long sqk, long sqb, const double *__restrict__ xg, const double *__restrict__ yg,
           const double *__restrict__ sg, const double *__restrict__ dxg, const double *__restrict__ dyg, double *__restrict__ dAo,
-          double *__restrict__ dqo, long sdqk, long sdqb, int *__restrict__ adj_status, int *__restrict__ iters_o, double atol, double btol, double conlim, int itn_lim) {
+          double *__restrict__ dqo, long sdqk, long sdqb, int *__restrict__ adj_status, int *__restrict__ iters_o, double atol, double btol, double conlim, int itn_lim,
+          const int *__restrict__ sel = nullptr, int status_or = 0) {
+    // sel != nullptr (ce_vjp's re-solve of the instances its direct elimination flagged rank-deficient): sel[0] instances are listed in sel[1 ...] (appended by
+    // the elimination kernel on the same stream); the grid is a fixed number of workgroups that walk the list -- the host never learns the count.  status_or is
+    // OR-ed into the adj_status of every instance served (ce_vjp: 4 | 8 = "rank-deficient, re-solved by LSQR").
     extern __shared__ __attribute__((aligned(16))) double sm[];
-    const int tid = threadIdx.x, inst = blockIdx.x;
+    const int tid = threadIdx.x;
     const int n = T.n, m = T.m, z = T.z, nl = T.l, nq = T.nq, ns = T.ns;
     const int KP = ns > 0 ? psd_mfma_kp(T.maxs) : 0, P = KP + 1, PM = KP * P;
     const float rKP = KP > 0 ? 1.0f / (float)KP : 1.0f;
@@ -87,6 +91,9 @@ k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, long
     double *socs = p; p += 5 * (nq > 0 ? nq : 1);          // per cone: t, |z|, case, z.h ; then h_0 per cone
     p += (size_t)(p - sm) & 1;
     double *Jt = p; p += 9 * (size_t)ntri;                    // exponential / power triples: symmetrised 3 x 3 derivative of the dual-cone projection
+  for (int li = blockIdx.x;; li += gridDim.x) {              // (one pass without a list: instance = workgroup)
+    int inst = li;
+    if (sel) { if (li >= sel[0]) break; inst = sel[1 + li]; } else if (li != (int)blockIdx.x) break;
     const double *x = xg + (size_t)inst * n, *y = yg + (size_t)inst * m, *s = sg + (size_t)inst * m;
     // the tau row / column of the operator: c_j from the boundary's q values, b_i from this instance's value row (both stay in global memory: L2-resident, read
     // with the loads of the products they join; LDS has no room for two more vectors at three workgroups per CU).  qg == null: r_tau pinned to 0.
@@ -370,5 +377,7 @@ k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, long
     __syncthreads();
     if (tid == 0) for (int k = 0; k < 8; k++) dA[k] = (double)ls_tacc[k];
 #endif
-    if (tid == 0) { if (adj_status) adj_status[inst] = live ? 1 : 0; if (iters_o) iters_o[inst] = itn; }
+    if (tid == 0) { if (adj_status) adj_status[inst] = (live ? 1 : 0) | status_or; if (iters_o) iters_o[inst] = itn; }
+    __syncthreads();          // (the next listed instance reuses every LDS vector)
+  }
 }

@@ -10,7 +10,7 @@ namespace {
 }  // namespace
 
 int ce_launch_bwd_generic(int mode, int B, size_t lds, hipStream_t st, const CeBwdArgs &a) {
-#define LAUNCH_B(AL, KL) hipLaunchKernelGGL((k_backward<AL, KL>), dim3(B), dim3(NT), lds, st, a.T, a.nkcap, a.ldk, a.Abm, a.x, a.y, a.s, a.dx, a.dy, a.dA, a.dq, a.sdqk, a.sdqb, a.adj, a.gA, a.gK)
+#define LAUNCH_B(AL, KL) hipLaunchKernelGGL((k_backward<AL, KL>), dim3(B), dim3(NT), lds, st, a.T, a.nkcap, a.ldk, a.Abm, a.x, a.y, a.s, a.dx, a.dy, a.dA, a.dq, a.sdqk, a.sdqb, a.adj, a.gA, a.gK, a.fix)
     switch (mode) {
     case 0: LAUNCH_B(true, true); break;
     case 1: LAUNCH_B(true, false); break;

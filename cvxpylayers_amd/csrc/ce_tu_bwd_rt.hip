@@ -14,7 +14,7 @@ namespace {
 #ifndef CE_BRT_PSD
 #error "compile with -DCE_BRT_PSD=0|1"
 #endif
-#define BRT_ARGS a.T, a.Abm, a.x, a.y, a.s, a.dx, a.dy, a.dA, a.dq, a.sdqk, a.sdqb, a.adj, a.P, a.nnz_p, a.pmap, a.prow, a.pcol, a.p_tri, a.dP, a.retry, a.nk_max
+#define BRT_ARGS a.T, a.Abm, a.x, a.y, a.s, a.dx, a.dy, a.dA, a.dq, a.sdqk, a.sdqb, a.adj, a.P, a.nnz_p, a.pmap, a.prow, a.pcol, a.p_tri, a.dP, a.retry, a.nk_max, a.fix, a.nonfinal
 #define LAUNCH_BRT(NTHREADS, ...) hipLaunchKernelGGL((k_backward_rt<__VA_ARGS__>), dim3(B), dim3(NTHREADS), lds, st, BRT_ARGS)
 #define SETATTR(...) do { hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_backward_rt<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes); if (e_ != hipSuccess) return e_; } while (0)
 

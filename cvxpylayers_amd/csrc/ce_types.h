@@ -42,6 +42,9 @@ struct CeBwdArgs {
     double *gA, *gK;
     int retry;                  // k_backward_rt: 1 = recompute only the instances an earlier launch flagged (adj == 2)
     int *nk_max;                // k_backward_rt: device maximum of the systems' order NK over the batch (NULL: not wanted)
+    int *fix;                   // fix[0]: counter, fix[1 ...]: instances whose adjoint system the elimination found rank deficient (or too large for the tile), appended
+                                // by the kernels for the LSQR re-solve behind them (cone_engine.hip ce_vjp_qp); NULL: not wanted
+    int nonfinal;               // k_backward_rt: 1 = first launch of a two-tile plan (an instance this tile does not hold is not listed: the retry launch serves it)
 };
 
 // launchers (one per kernel object file): 0 on success, -1 unknown variant

@@ -88,6 +88,10 @@ struct ce_engine {
     // tile is chosen from the LARGEST system of the previous call of the same batch size (nk_*: device maximum, copied to pinned memory behind the launch)
     bool two_tile = false; int fast_forced = -1;
     int *d_nkmax = nullptr, *h_nkmax = nullptr; hipEvent_t nk_ev = nullptr; bool nk_pending = false, nk_have = false, nk_zeroed = false; int nk_last = 0, nk_B = 0;
+    // re-solve of rank-deficient adjoint systems by LSQR (ce_set_adjoint_resolve): fix[0] = number of listed instances, fix[1 ...] = the instances the elimination
+    // kernels flagged (appended on the device); diffcp's LSQR rule
+    const double *call_q = nullptr; long call_sqk = 0, call_sqb = 0;      // (ce_vjp -> ce_vjp_qp: the objective values of the call in flight)
+    bool resolve = true; int *d_fix = nullptr; int fix_cap = 0; double rs_atol = 1e-8, rs_btol = 1e-8, rs_conlim = 1e8; int rs_iter_lim = 0;
     // quadratic objective
     int nnz_p = 0, p_tri = 0; bool qp_native = false;
     bool aa_ok = false;                            // the forward launch carries the LDS for the Anderson-acceleration vectors
@@ -475,6 +479,12 @@ int ce_create(const ce_template *tpl, int device, ce_handle *out) {
     return CE_OK;
 }
 
+int ce_set_adjoint_resolve(ce_handle h, int enable, double atol, double btol, double conlim, int iter_lim) {
+    if (!h) { g_err = "null argument"; return CE_E_BADARG; }
+    h->resolve = enable != 0;
+    h->rs_atol = atol > 0 ? atol : 1e-8; h->rs_btol = btol > 0 ? btol : 1e-8; h->rs_conlim = conlim; h->rs_iter_lim = iter_lim > 0 ? iter_lim : 0;
+    return CE_OK;
+}
 int ce_destroy(ce_handle h) {
     if (!h) return CE_OK;
     hipSetDevice(h->device);
@@ -610,10 +620,19 @@ int ce_solve_qp(ce_handle h, int B, const double *A_vals, long sA_k, long sA_b, 
 int ce_vjp(ce_handle h, int B, const double *A_vals, long sA_k, long sA_b, const double *q_vals, long sq_k, long sq_b,
            const double *x, const double *y, const double *s, const double *dx, const double *dy,
            double *dA_vals, long sdA_k, long sdA_b, double *dq_vals, long sdq_k, long sdq_b, int *adj_status, void *stream) {
-    (void)q_vals; (void)sq_k; (void)sq_b;   // b, c do not enter the adjoint system once r_tau is pinned
-    return ce_vjp_qp(h, B, A_vals, sA_k, sA_b, nullptr, x, y, s, dx, dy, dA_vals, sdA_k, sdA_b, dq_vals, sdq_k, sdq_b, nullptr, adj_status, stream);
+    // b, c do not enter the elimination (r_tau pinned to 0); they do enter diffcp's full system, which the instances the elimination flags as rank deficient
+    // are re-solved on (ce_set_adjoint_resolve): q_vals == NULL switches the re-solve off for this call
+    if (!h) { g_err = "null argument"; return CE_E_BADARG; }
+    h->call_q = q_vals; h->call_sqk = sq_k; h->call_sqb = sq_b;
+    const int rc = ce_vjp_qp(h, B, A_vals, sA_k, sA_b, nullptr, x, y, s, dx, dy, dA_vals, sdA_k, sdA_b, dq_vals, sdq_k, sdq_b, nullptr, adj_status, stream);
+    h->call_q = nullptr;
+    return rc;
 }
 
+static int vjp_lsqr_launch(ce_handle h, int B, const double *A_vals0, long sA_b, int per_inst, const double *q_vals, long sq_k, long sq_b,
+                           const double *x, const double *y, const double *s, const double *dx, const double *dy,
+                           double *dA_bm, double *dq_vals, long sdq_k, long sdq_b, int *adj_status, int *lsqr_iters, double atol, double btol, double conlim, int iter_lim, void *stream,
+                           const int *sel = nullptr, int status_or = 0);
 int ce_vjp_qp(ce_handle h, int B, const double *A_vals, long sA_k, long sA_b, const double *P_vals,
               const double *x, const double *y, const double *s, const double *dx, const double *dy,
               double *dA_vals, long sdA_k, long sdA_b, double *dq_vals, long sdq_k, long sdq_b, double *dP_vals, int *adj_status, void *stream) {
@@ -639,9 +658,22 @@ int ce_vjp_qp(ce_handle h, int B, const double *A_vals, long sA_k, long sA_b, co
         if (rc) return rc;
         gK = h->gws; gA = h->gws + (size_t)B * perK;
     }
+    // Rank-deficient adjoint systems (redundant equality rows, degenerate active sets): the elimination kernels set the free variables to zero -- a BASIC
+    // solution -- where the reference's LSQR (diffcp_if.py:86 -> adj_batch) returns the minimum-norm one.  The kernels append such instances (and the ones whose
+    // system exceeds the register tile) to a device-side list; a fixed grid of LSQR workgroups behind them walks the list and overwrites those instances'
+    // gradients with diffcp's answer (k_sa_lsqr with the instance's own A, full (n + m + 1) system, diffcp's stopping rule).  No host round trip; an empty list
+    // costs one launch of workgroups that return at once.
+    bool do_fix = h->resolve && h->call_q && !P_vals &&
+                  sa_lsqr_lds_doubles(T.n, T.m, T.nq, T.ns, T.maxs, 0, h->psd_first, T.nep + T.np) * 8 <= LDS_LIMIT;
+    if (do_fix && h->fix_cap < B) {
+        if (h->d_fix) { hipFree(h->d_fix); h->d_fix = nullptr; h->fix_cap = 0; }
+        HIPCHK(hipMalloc(&h->d_fix, sizeof(int) * ((size_t)B + 1))); h->fix_cap = B;
+        HIPCHK(hipMemsetAsync(h->d_fix, 0, sizeof(int), st));      // (afterwards the counter is reset behind the LSQR launch of every call)
+    }
     {
         ProfScope ps(h, 1, st);
         CeBwdArgs ba{};
+        ba.fix = do_fix ? h->d_fix : nullptr;
         ba.T = T; ba.nkcap = h->nkcap; ba.ldk = h->ldk; ba.Abm = Abm; ba.x = x; ba.y = y; ba.s = s; ba.dx = dx; ba.dy = dy; ba.dA = dAbm; ba.dq = dq_vals;
         ba.sdqk = sdq_k; ba.sdqb = sdq_b; ba.adj = adj_status; ba.P = P_vals; ba.nnz_p = h->nnz_p; ba.pmap = h->d_pmap; ba.prow = h->d_prow; ba.pcol = h->d_pcol;
         ba.p_tri = h->p_tri; ba.dP = dP_vals; ba.gA = gA; ba.gK = gK;
@@ -666,13 +698,23 @@ int ce_vjp_qp(ce_handle h, int B, const double *A_vals, long sA_k, long sA_b, co
                 ba.nk_max = h->d_nkmax;
             }
             if (fast >= 0) {
+                ba.nonfinal = 1;      // (an instance this tile does not hold is the retry launch's business, not yet the list's)
                 lrc = ce_launch_bwd_rt_plain(fast, B, fast_lds, st, ba);
-                ba.retry = 1;
+                ba.retry = 1; ba.nonfinal = 0;
                 if (!lrc) lrc = ce_launch_bwd_rt_plain(h->brt_variant, B, h->bwd_lds, st, ba);
             } else
             lrc = (T.ns > 0 || T.nep + T.np > 0) ? ce_launch_bwd_rt_psd(h->brt_variant, B, h->bwd_lds, st, ba) : ce_launch_bwd_rt_plain(h->brt_variant, B, h->bwd_lds, st, ba);
         } else lrc = ce_launch_bwd_generic(h->bwd_mode, B, h->bwd_lds, st, ba);
         if (lrc) { g_err = "internal: no backward kernel for the planned variant"; return CE_E_BADARG; }
+        if (do_fix) {
+            const int grid = B < 1024 ? B : 1024;
+            const int prof_keep = h->prof; h->prof = 0;          // (inside this scope's bracket already)
+            rc = vjp_lsqr_launch(h, grid, Abm, K, 1, h->call_q, h->call_sqk, h->call_sqb, x, y, s, dx, dy, dAbm, dq_vals, sdq_k, sdq_b, adj_status, nullptr,
+                                 h->rs_atol, h->rs_btol, h->rs_conlim, h->rs_iter_lim, stream, h->d_fix, 4 | 8);
+            h->prof = prof_keep;
+            if (rc) return rc;
+            HIPCHK(hipMemsetAsync(h->d_fix, 0, sizeof(int), st));          // for the next call (kept off the path in front of its kernels)
+        }
         if (ba.nk_max) {      // the largest system of this call, for the tile choice of the next one (read once the copy has landed: no synchronisation here)
             HIPCHK(hipMemcpyAsync(h->h_nkmax, h->d_nkmax, sizeof(int), hipMemcpyDeviceToHost, st));
             HIPCHK(hipEventRecord(h->nk_ev, st));
@@ -897,7 +939,8 @@ int ce_solve_shared_a(ce_handle h, int B, int r, int RP, const double *AdT, cons
 }
 static int vjp_lsqr_launch(ce_handle h, int B, const double *A_vals0, long sA_b, int per_inst, const double *q_vals, long sq_k, long sq_b,
                            const double *x, const double *y, const double *s, const double *dx, const double *dy,
-                           double *dA_bm, double *dq_vals, long sdq_k, long sdq_b, int *adj_status, int *lsqr_iters, double atol, double btol, double conlim, int iter_lim, void *stream) {
+                           double *dA_bm, double *dq_vals, long sdq_k, long sdq_b, int *adj_status, int *lsqr_iters, double atol, double btol, double conlim, int iter_lim, void *stream,
+                           const int *sel, int status_or) {
     if (!h || B <= 0 || !A_vals0 || !x || !y || !s || !dx || !dy || !dA_bm || !dq_vals) { g_err = "null argument"; return CE_E_BADARG; }
     const DevT &T = h->T;
     // products through the singleton / dense-row split when the template has one (CE_SA_SPLIT=0: CSR / CSC products)
@@ -924,7 +967,7 @@ static int vjp_lsqr_launch(ce_handle h, int B, const double *A_vals0, long sA_b,
     }
     {
         ProfScope ps(h, 1, (hipStream_t)stream);
-#define LAUNCH_SAL(RPV) hipLaunchKernelGGL(k_sa_lsqr<RPV>, dim3(B), dim3(NT), lds, (hipStream_t)stream, T, S, F, A_vals0, sA_b, per_inst, q_vals, sq_k, sq_b, x, y, s, dx, dy, dA_bm, dq_vals, sdq_k, sdq_b, adj_status, lsqr_iters, atol, btol, conlim, iter_lim > 0 ? iter_lim : 2 * (T.n + T.m + 1))
+#define LAUNCH_SAL(RPV) hipLaunchKernelGGL(k_sa_lsqr<RPV>, dim3(B), dim3(NT), lds, (hipStream_t)stream, T, S, F, A_vals0, sA_b, per_inst, q_vals, sq_k, sq_b, x, y, s, dx, dy, dA_bm, dq_vals, sdq_k, sdq_b, adj_status, lsqr_iters, atol, btol, conlim, iter_lim > 0 ? iter_lim : 2 * (T.n + T.m + 1), sel, status_or)
         if (RP == 0) LAUNCH_SAL(0); else if (RP == 16) LAUNCH_SAL(16); else if (RP == 32) LAUNCH_SAL(32); else LAUNCH_SAL(64);
 #undef LAUNCH_SAL
     }

@@ -488,65 +488,86 @@ def vjp_const_a(eng, A_bm, x, y, s, dx, dy, batch_minor_out=False, atol=1e-8, bt
                                                C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "ce_ca_triple_jac")
         tri = (m - 3 * ntri, 0.5 * (J + J.transpose(2, 3)))
 
-    def N(rx, ry):          # (B,n),(B,m) -> (B,n),(B,m)
-        return -(ry @ A), _dproj(v, rx @ At - ry, z, nl, qs, psd, peig, tri) + ry
+    # diffcp's FULL (n + m + 1) system when the call's q_eval is at hand (tau row and column: c from q_eval, b from the value rows), like the one-kernel LSQR above
+    # (round 6, ADVICE: this fallback used to drop them and to stop without the conlim / machine-precision tests -- the answer depended on which path ran);
+    # q_eval None: r_tau pinned to 0 (adjoint_system="reduced")
+    TAU = q_eval is not None
+    if TAU:
+        cvec = q_eval.detach().to(**f64)[:n].t().contiguous()                       # (B, n)
+        bvec = torch.zeros((B, m), **f64)
+        if eng.nnz_aug > nnzA:
+            bvec[:, rows_t[nnzA:]] = A_bm[:, nnzA:].to(torch.float64)
+    else:
+        cvec, bvec = torch.zeros((B, n), **f64), torch.zeros((B, m), **f64)
 
-    def NT(px, py):
+    def N(rx, ry, rt):          # (B,n),(B,m),(B,) -> same
+        return (-(ry @ A) - cvec * rt[:, None], _dproj(v, rx @ At - bvec * rt[:, None] - ry, z, nl, qs, psd, peig, tri) + ry,
+                (cvec * rx).sum(dim=1) + (bvec * ry).sum(dim=1))
+
+    def NT(px, py, pt):
         q = _dproj(v, py, z, nl, qs, psd, peig, tri)
-        return q @ A, -(px @ At) - q + py
+        return q @ A + cvec * pt[:, None], -(px @ At) + bvec * pt[:, None] - q + py, -(cvec * px).sum(dim=1) - (bvec * q).sum(dim=1)
 
-    def nrm(a, b_):
-        return torch.sqrt((a * a).sum(dim=1) + (b_ * b_).sum(dim=1))
+    def nrm(a, b_, t_):
+        return torch.sqrt((a * a).sum(dim=1) + (b_ * b_).sum(dim=1) + t_ * t_)
 
+    x64, y64 = x.to(torch.float64), y.to(torch.float64)
     bx, by = dx.to(torch.float64), _dproj(v, dy.to(torch.float64), z, nl, qs, psd, peig, tri)
+    bt = -((x64 * bx).sum(dim=1) + (y64 * dy.to(torch.float64)).sum(dim=1)) if TAU else torch.zeros(B, **f64)      # dz_tau = -(x.dx + y.dy)
     # LSQR (Paige & Saunders), batched; rows that met a stopping test are frozen
-    bnorm = nrm(bx, by)
+    bnorm = nrm(bx, by, bt)
     live = bnorm > 0
     safe = lambda t: torch.where(t > 0, t, torch.ones_like(t))
     beta = bnorm.clone()
-    ux, uy = bx / safe(beta)[:, None], by / safe(beta)[:, None]
-    vx, vy = NT(ux, uy)
-    alfa = nrm(vx, vy)
-    vx, vy = vx / safe(alfa)[:, None], vy / safe(alfa)[:, None]
-    wx, wy = vx.clone(), vy.clone()
-    rx, ry = torch.zeros_like(bx), torch.zeros_like(by)
+    ux, uy, ut = bx / safe(beta)[:, None], by / safe(beta)[:, None], bt / safe(beta)
+    vx, vy, vt = NT(ux, uy, ut)
+    if not TAU:
+        vt = torch.zeros_like(vt)
+    alfa = nrm(vx, vy, vt)
+    vx, vy, vt = vx / safe(alfa)[:, None], vy / safe(alfa)[:, None], vt / safe(alfa)
+    wx, wy, wt = vx.clone(), vy.clone(), vt.clone()
+    rx, ry, rt = torch.zeros_like(bx), torch.zeros_like(by), torch.zeros(B, **f64)
     rhobar, phibar = alfa.clone(), beta.clone()
     anorm = torch.zeros(B, **f64); ddnorm = torch.zeros(B, **f64); xxnorm = torch.zeros(B, **f64)
     zz = torch.zeros(B, **f64); cs2 = -torch.ones(B, **f64); sn2 = torch.zeros(B, **f64)
     live = live & (alfa * beta > 0)
     itn_lim = int(iter_lim)
+    ctol = 1.0 / conlim if conlim and conlim > 0 else 0.0
+    tau_on = 1.0 if TAU else 0.0
 
     def lsqr_iter(st):
-        """one LSQR iteration as a pure function of the state tuple (so that a block of them can be captured in a HIP graph)"""
-        ux, uy, vx, vy, wx, wy, rx, ry, alfa, rhobar, phibar, anorm, ddnorm, xxnorm, zz, cs2, sn2, live = st
-        tx, ty = N(vx, vy)
-        ux, uy = tx - alfa[:, None] * ux, ty - alfa[:, None] * uy
-        beta = nrm(ux, uy)
-        ux, uy = ux / safe(beta)[:, None], uy / safe(beta)[:, None]
+        """one LSQR iteration as a pure function of the state tuple (so that a block of them can be captured in a HIP graph); stopping tests as in
+        oracle/cone_oracle.c lsqr_MT / scipy: atol, btol, conlim and the three machine-precision tests"""
+        ux, uy, ut, vx, vy, vt, wx, wy, wt, rx, ry, rt, alfa, rhobar, phibar, anorm, ddnorm, xxnorm, zz, cs2, sn2, live = st
+        tx, ty, tt = N(vx, vy, vt)
+        ux, uy, ut = tx - alfa[:, None] * ux, ty - alfa[:, None] * uy, tau_on * (tt - alfa * ut)
+        beta = nrm(ux, uy, ut)
+        ux, uy, ut = ux / safe(beta)[:, None], uy / safe(beta)[:, None], ut / safe(beta)
         anorm = torch.sqrt(anorm * anorm + alfa * alfa + beta * beta)
-        tx, ty = NT(ux, uy)
-        vx, vy = tx - beta[:, None] * vx, ty - beta[:, None] * vy
-        alfa = nrm(vx, vy)
-        vx, vy = vx / safe(alfa)[:, None], vy / safe(alfa)[:, None]
+        tx, ty, tt = NT(ux, uy, ut)
+        vx, vy, vt = tx - beta[:, None] * vx, ty - beta[:, None] * vy, tau_on * (tt - beta * vt)
+        alfa = nrm(vx, vy, vt)
+        vx, vy, vt = vx / safe(alfa)[:, None], vy / safe(alfa)[:, None], vt / safe(alfa)
         rho = torch.sqrt(rhobar * rhobar + beta * beta)
         cs, sn = rhobar / safe(rho), beta / safe(rho)
         theta = sn * alfa; rhobar = -cs * alfa; phi = cs * phibar; phibar = sn * phibar; tau = sn * phi
         t1, t2 = phi / safe(rho), -theta / safe(rho)
-        lm = live.to(torch.float64)[:, None]
-        ddnorm = ddnorm + ((wx * wx).sum(dim=1) + (wy * wy).sum(dim=1)) / safe(rho * rho)
-        rx = rx + lm * t1[:, None] * wx; ry = ry + lm * t1[:, None] * wy
-        wx, wy = vx + t2[:, None] * wx, vy + t2[:, None] * wy
+        lm = live.to(torch.float64)
+        ddnorm = ddnorm + ((wx * wx).sum(dim=1) + (wy * wy).sum(dim=1) + wt * wt) / safe(rho * rho)
+        rx = rx + (lm * t1)[:, None] * wx; ry = ry + (lm * t1)[:, None] * wy; rt = rt + lm * t1 * wt
+        wx, wy, wt = vx + t2[:, None] * wx, vy + t2[:, None] * wy, vt + t2 * wt
         delta = sn2 * rho; gambar = -cs2 * rho; rhs = phi - delta * zz; zbar = rhs / safe(gambar.abs()) * torch.sign(gambar)
         xnorm = torch.sqrt(xxnorm + zbar * zbar)
         gamma = torch.sqrt(gambar * gambar + theta * theta); cs2 = gambar / safe(gamma); sn2 = theta / safe(gamma); zz = rhs / safe(gamma); xxnorm = xxnorm + zz * zz
         rnorm = phibar
         arnorm = alfa * tau.abs()
         test1 = rnorm / safe(bnorm); test2 = arnorm / (anorm * rnorm + 1e-300)
+        test3 = 1.0 / (anorm * torch.sqrt(ddnorm) + 1e-300); tt1 = test1 / (1.0 + anorm * xnorm / safe(bnorm))
         rtol = btol + atol * anorm * xnorm / safe(bnorm)
-        live = live & ~((test1 <= rtol) | (test2 <= atol))
-        return (ux, uy, vx, vy, wx, wy, rx, ry, alfa, rhobar, phibar, anorm, ddnorm, xxnorm, zz, cs2, sn2, live)
+        live = live & ~((test1 <= rtol) | (test2 <= atol) | (test3 <= ctol) | (1.0 + test3 <= 1.0) | (1.0 + test2 <= 1.0) | (1.0 + tt1 <= 1.0))
+        return (ux, uy, ut, vx, vy, vt, wx, wy, wt, rx, ry, rt, alfa, rhobar, phibar, anorm, ddnorm, xxnorm, zz, cs2, sn2, live)
 
-    state = [ux, uy, vx, vy, wx, wy, rx, ry, alfa, rhobar, phibar, anorm, ddnorm, xxnorm, zz, cs2, sn2, live]
+    state = [ux, uy, ut, vx, vy, vt, wx, wy, wt, rx, ry, rt, alfa, rhobar, phibar, anorm, ddnorm, xxnorm, zz, cs2, sn2, live]
     BLK = 16
     import os
     graph = None
@@ -572,16 +593,17 @@ def vjp_const_a(eng, A_bm, x, y, s, dx, dy, batch_minor_out=False, atol=1e-8, bt
         itn += BLK
         if not bool(state[-1].any().item()):
             break
-    rx, ry, live = state[6], state[7], state[-1]
+    rx, ry, rt, live = state[9], state[10], state[11], state[-1]
     adj = live.to(torch.int32)           # 1: LSQR hit its iteration limit for this instance
-    # outputs: dA_ij = x_j r_y,i - y_i r_x,j ; db = -r_y ; dc = -r_x   (r_tau = 0), packed as [-dA.data, db[b_idx]], [dc, 0]
+    # outputs: dA_ij = x_j r_y,i - y_i r_x,j ; db = y r_tau - r_y ; dc = x r_tau - r_x, packed as [-dA.data, db[b_idx]], [dc, 0]  (cone_oracle.c adjoint_one)
     K = eng.nnz_aug
     dA_bm = torch.empty((B, K), **f64)
     ra, ca = rows_t[:nnzA], cols_t[:nnzA]
-    dA_bm[:, :nnzA] = -(x[:, ca] * ry[:, ra] - y[:, ra] * rx[:, ca])
+    dA_bm[:, :nnzA] = -(x64[:, ca] * ry[:, ra] - y64[:, ra] * rx[:, ca])
     if K > nnzA:
-        dA_bm[:, nnzA:] = -ry[:, rows_t[nnzA:]]
+        rb = rows_t[nnzA:]
+        dA_bm[:, nnzA:] = y64[:, rb] * rt[:, None] - ry[:, rb]
     dq = torch.zeros((n + 1, B), **f64)
-    dq[:n] = -rx.t()
+    dq[:n] = (x64 * rt[:, None] - rx).t()
     dA = dA_bm.t().contiguous() if batch_minor_out else dA_bm.t()
     return dA, dq, adj

@@ -62,10 +62,13 @@ def lsqr_rule(merged_args: dict, n: int, m: int) -> tuple:
 
 def adjoint_mode(merged_args: dict) -> str:
     """diffcp's `mode` (adj_batch / solve_and_derivative_batch; diffcp_if.py:86 runs its default "lsqr") for PER-INSTANCE-A templates:
-    absent / "dense" -> the direct, rank-revealing elimination (k_backward_rt / k_backward: the same gradients as LSQR wherever the adjoint system is regular,
-    a basic solution on rank-deficient ones);  "lsqr" -> diffcp's LSQR on the full (n + m + 1) system with its stopping rule (ce_vjp_lsqr: the minimum-norm
-    solution on rank-deficient systems, like the reference).  Shared-A templates run LSQR whatever the mode says."""
-    return "lsqr" if str(merged_args.get("mode", "")) == "lsqr" else "direct"
+    absent -> "direct": the rank-revealing elimination (k_backward_rt / k_backward: the same gradients as LSQR wherever the adjoint system is regular) and,
+    behind it on the device, diffcp's LSQR for exactly the instances the elimination found RANK DEFICIENT (ce_vjp with q_vals; include/cone_engine.h) -- the
+    default answer is diffcp's minimum-norm element everywhere, regular instances pay nothing;
+    "dense" -> "dense": the elimination alone (a basic solution on rank-deficient systems);
+    "lsqr" -> diffcp's LSQR on the full (n + m + 1) system with its stopping rule for every instance (ce_vjp_lsqr).  Shared-A templates run LSQR whatever the mode says."""
+    mode = str(merged_args.get("mode", ""))
+    return "lsqr" if mode == "lsqr" else ("dense" if mode == "dense" else "direct")
 
 
 _WARNED: set = set()
@@ -219,7 +222,9 @@ class ConeEngine:
                                  f"{tuple(warm[0].shape)}, {tuple(warm[1].shape)}, {tuple(warm[2].shape)}")
         if P_bm is not None and not self.qp_native:
             raise RuntimeError("quadratic objective on an engine without native P support (use the epigraph form)")
-        self._last_q = q_eval          # (direct engine users: vjp() without q_eval differentiates the most recent solve)
+        # direct engine users (tests, probes): vjp() without q_eval may use the objective of the most recent solve() -- but only for the SAME value buffer
+        # (the plugin always passes q_eval explicitly; a q paired with another call's A would silently change the full adjoint system: ADVICE round 5)
+        self._last_q, self._last_q_key = q_eval.detach(), (A_bm.data_ptr(), B)
         if P_bm is None and self._use_const_a(A_bm):
             from cvxpylayers_amd.interfaces.const_a import solve_const_a
             self.last_path = "const_a"
@@ -247,6 +252,10 @@ class ConeEngine:
                                      iters.data_ptr(), status.data_ptr(), resid.data_ptr(), self._stream())
         _lib.check(rc, "ce_solve")
         return x, y, s, iters, status, resid
+
+    def _recent_q(self, A_bm):
+        lq, key = getattr(self, "_last_q", None), getattr(self, "_last_q_key", None)
+        return lq if (lq is not None and key == (A_bm.data_ptr(), A_bm.shape[0])) else None
 
     def zeros_like_cached(self, t: torch.Tensor) -> torch.Tensor:
         """A read-only zero tensor of t's shape on this engine's device, allocated once per shape (the cotangent of an output the loss does not use)."""
@@ -359,9 +368,8 @@ class ConeEngine:
             path = getattr(self, "last_path", None)
         if path == "const_a" and (self.launch_info()["bwd_mode"] in (1, 2) or __import__("os").environ.get("CE_CONST_A") == "1"):
             from cvxpylayers_amd.interfaces.const_a import vjp_const_a      # shared A: batched LSQR with GEMMs over the batch
-            if q_eval is None:          # direct engine users with one solve in flight: the objective of the most recent solve() of this batch size
-                lq = getattr(self, "_last_q", None)
-                q_eval = lq if (lq is not None and lq.dim() == 2 and lq.shape[1] == B) else None
+            if q_eval is None:          # direct engine users: the objective of the most recent solve() of this very value buffer, else the reduced system
+                q_eval = self._recent_q(A_bm)
             atol, btol, lim, system = (tuple(lsqr) + ("full",))[:4] if lsqr is not None else lsqr_rule({}, self.n, self.m)
             if system == "reduced":
                 q_eval = None
@@ -371,11 +379,23 @@ class ConeEngine:
                 raise ValueError("MI355 solver: mode='lsqr' is not available with a quadratic objective inside the kernels (CE_QP_EPIGRAPH=1 brings the problem to cone form)")
             atol, btol, lim, system = (tuple(lsqr) + ("full",))[:4] if lsqr is not None else lsqr_rule({}, self.n, self.m)
             if q_eval is None and system != "reduced":
-                lq = getattr(self, "_last_q", None)
-                q_eval = lq if (lq is not None and lq.dim() == 2 and lq.shape[1] == B) else None
-            return self._vjp_lsqr(A_bm, x, y, s, dx, dy, batch_minor_out, atol, btol, lim, None if system == "reduced" else q_eval)
+                q_eval = self._recent_q(A_bm)
+            out = self._vjp_lsqr(A_bm, x, y, s, dx, dy, batch_minor_out, atol, btol, lim, None if system == "reduced" else q_eval)
+            if out is not None:
+                return out
+            path = "per_instance"          # (the LSQR vectors of one instance exceed LDS: warned once, the direct elimination + re-solve serves the call)
         dq = torch.empty((self.n + 1, B), dtype=torch.float64, device=dev)
         adj = torch.empty((B,), dtype=torch.int32, device=dev)
+        # rank-deficient instances are re-solved on the device by diffcp's LSQR when the call's q_eval is at hand (ce_vjp); path "per_instance_dense" (solver_args
+        # mode="dense") keeps the elimination's basic solution
+        q_args = (None, 0, 0)
+        if P_bm is None and q_eval is not None and path != "per_instance_dense":          # (q_eval must be given explicitly here: without it, the elimination alone)
+            qd = q_eval.detach().to(dtype=torch.float64, device=dev)
+            q_args = (qd.data_ptr(), qd.stride(0), qd.stride(1))
+            rule = (tuple(lsqr) + ("full",))[:4] if lsqr is not None else lsqr_rule({}, self.n, self.m)
+            if rule[:3] != getattr(self, "_resolve_rule", None):
+                _lib.check(_lib.lib().ce_set_adjoint_resolve(self._h, 1, float(rule[0]), float(rule[1]), 1e8, int(rule[2])), "ce_set_adjoint_resolve")
+                self._resolve_rule = rule[:3]
         if batch_minor_out:
             dA = torch.empty((self.nnz_aug, B), dtype=torch.float64, device=dev)
             sk, sb = B, 1
@@ -389,7 +409,7 @@ class ConeEngine:
                                       dq.data_ptr(), B, 1, dP.data_ptr(), adj.data_ptr(), self._stream())
             _lib.check(rc, "ce_vjp_qp")
             return (dA if batch_minor_out else dA.t()), dq, adj, dP
-        rc = _lib.lib().ce_vjp(self._h, B, A_bm.data_ptr(), 1, self.nnz_aug, None, 0, 0, x.data_ptr(), y.data_ptr(),
+        rc = _lib.lib().ce_vjp(self._h, B, A_bm.data_ptr(), 1, self.nnz_aug, *q_args, x.data_ptr(), y.data_ptr(),
                                s.data_ptr(), dx.data_ptr(), dy.data_ptr(), dA.data_ptr(), sk, sb,
                                dq.data_ptr(), B, 1, adj.data_ptr(), self._stream())
         _lib.check(rc, "ce_vjp")
@@ -410,6 +430,10 @@ class ConeEngine:
             q_args = (None, 0, 0)
         rc = _lib.lib().ce_vjp_lsqr(self._h, B, A_c.data_ptr(), A_c.stride(0), *q_args, xc.data_ptr(), yc.data_ptr(), sc_.data_ptr(), dxc.data_ptr(), dyc.data_ptr(),
                                     dA_bm.data_ptr(), dq.data_ptr(), B, 1, adj.data_ptr(), its.data_ptr(), float(atol), float(btol), float(conlim), int(iter_lim), self._stream())
+        if rc == -3:          # CE_E_TOO_LARGE: mode="lsqr" cannot be honoured for this template
+            _warn_once("lsqr_too_large", "MI355 solver: solver_args mode='lsqr' needs the LSQR vectors of one instance in LDS, which this template exceeds; "
+                                         "falling back to the direct elimination (rank-deficient instances are flagged in info['adjoint'])")
+            return None
         _lib.check(rc, "ce_vjp_lsqr")
         self.last_lsqr_iters = its
         return (dA_bm.t().contiguous() if batch_minor_out else dA_bm.t()), dq, adj
@@ -619,6 +643,17 @@ def _report_flagged_adjoints(eng):
                       "set or iteration limit); their gradients are unreliable")
 
 
+def adjoint_report(info: dict) -> dict:
+    """Counts of the last backward through the node that returned `info` (synchronises): instances whose adjoint system was rank deficient, how many of them
+    were re-solved by diffcp's LSQR on the device, how many LSQR runs stopped at the iteration limit / were left without gradient."""
+    adj = (info.get("adjoint") or {}).get("status")
+    if adj is None:
+        return dict(rank_deficient=0, lsqr_resolved=0, lsqr_iteration_limit=0, no_gradient=0, backward_ran=False)
+    a = adj.detach().cpu().numpy()
+    return dict(rank_deficient=int(((a & 4) != 0).sum()), lsqr_resolved=int(((a & 8) != 0).sum()), lsqr_iteration_limit=int(((a & 1) != 0).sum()),
+                no_gradient=int(((a & 2) != 0).sum()), backward_ran=True)
+
+
 def _detect_batch_size(con_values) -> tuple[int, bool]:
     """diffcp_if.py:34-43"""
     if con_values.dim() == 1:
@@ -679,6 +714,11 @@ class _ConeLayer(torch.autograd.Function):
             path = eng.last_path          # recorded per call: the backward of THIS node must not follow a later solve's path
             if path == "per_instance" and P_bm is None and adjoint_mode(merged_args) == "lsqr":
                 path = "per_instance_lsqr"          # (the adjoint of this node: diffcp's LSQR instead of the direct elimination)
+            elif path == "per_instance" and P_bm is not None and adjoint_mode(merged_args) == "lsqr":
+                _warn_once("lsqr_qp", "MI355 solver: solver_args mode='lsqr' is not available with a quadratic objective inside the kernels; the direct elimination "
+                                      "differentiates this layer (CE_QP_EPIGRAPH=1 brings the problem to cone form, where mode='lsqr' applies)")
+            elif path == "per_instance" and adjoint_mode(merged_args) == "dense":
+                path = "per_instance_dense"         # (the elimination alone: no LSQR re-solve of rank-deficient instances)
             eng._last_solution = (x.detach(), y.detach(), s)
             # The reference raises from forward() when an instance fails (diffcp_if.py:365-372), so the host has to learn the outcome here: one tiny
             # reduction kernel + 8 bytes into pinned memory behind the solve (ce_status_summary) and ONE stream synchronisation -- not the status
@@ -689,9 +729,11 @@ class _ConeLayer(torch.autograd.Function):
             # end of the solve until the caller's backward reaches it, so host work placed behind the wait is added to that gap
             primal = x.to(in_device)
             dual = y.to(in_device)
-            info = dict(iters=iters, status=status, resid=resid, acceleration=getattr(eng, "last_acceleration", False))
+            # info["adjoint"] is filled by backward(): "status" = the per-instance bit field of include/cone_engine.h ce_vjp (4: rank-deficient system, 8: gradients
+            # are diffcp's LSQR element from the device-side re-solve); adjoint_report(info) counts them
+            info = dict(iters=iters, status=status, resid=resid, acceleration=getattr(eng, "last_acceleration", False), adjoint={"status": None, "path": path})
             lsqr = lsqr_rule(merged_args, eng.n, eng.m)
-            saved = (eng, A_bm, x.detach(), y.detach(), s, batch_minor_in, P_bm, path, None, lsqr, q_dev if path in ("const_a", "per_instance_lsqr") else None) if needs_grad else None
+            saved = (eng, A_bm, x.detach(), y.detach(), s, batch_minor_in, P_bm, path, None, lsqr, q_dev if P_bm is None else None) if needs_grad else None
             if status.numel():
                 summ = eng.read_summaries()
                 min_status, n_inaccurate = int(summ[0][0]), int(summ[0][1])
@@ -716,7 +758,7 @@ class _ConeLayer(torch.autograd.Function):
             y = torch.where(failed[:, None], torch.full_like(y, float("nan")), y)
             primal = x.to(in_device)
             dual = y.to(in_device)
-            saved = (eng, A_bm, x.detach(), y.detach(), s, batch_minor_in, P_bm, path, failed, lsqr, q_dev if path in ("const_a", "per_instance_lsqr") else None) if needs_grad else None
+            saved = (eng, A_bm, x.detach(), y.detach(), s, batch_minor_in, P_bm, path, failed, lsqr, q_dev if P_bm is None else None) if needs_grad else None
         # x / y are handed back as `primal` / `dual` (same objects when the input lives on the engine's device), and autograd
         # attaches this node to them: keeping the SAME objects on the node would form a reference cycle (node -> saved ->
         # primal -> grad_fn -> node) that only the cyclic GC breaks, i.e. 167 MB buffers pile up for many steps and the
@@ -757,6 +799,8 @@ class _ConeLayer(torch.autograd.Function):
             if P_bm is not None:
                 dP = torch.where(failed[None, :].to(dP.device), torch.zeros_like(dP), dP)
         ctx.adj_status = adj
+        if isinstance(ctx.info, dict) and isinstance(ctx.info.get("adjoint"), dict):
+            ctx.info["adjoint"]["status"] = adj
         with torch.cuda.device(eng.device):
             _note_adjoint_flags(eng, adj, batch_size)            # reported by the next forward call (no host sync on the backward path)
         dA = dA.to(in_device)

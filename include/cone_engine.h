@@ -91,8 +91,8 @@ void ce_default_settings(ce_settings *s);
  * library short structs.  Bindings must check  ce_abi_version() == CE_ABI_VERSION  and  ce_struct_size(which) == sizeof(their
  * struct)  (which: 0 ce_template, 1 ce_settings) once at load time and refuse to continue otherwise (cvxpylayers_amd/_lib.py
  * does; tests/test_cabi.py checks the stub printed in INTEGRATION.md the same way).  CE_ABI_VERSION is bumped whenever a struct
- * layout, an entry point's signature or the meaning of an argument changes (10: ce_vjp_lsqr added; 9: ce_vjp_shared_a takes sA_b and q_vals -- the adjoint system gains diffcp's tau row and column --, its iter_lim default is diffcp's 2 (n + m + 1); 8: ce_set_dispatch_history added, ce_status_summary writes a fourth "ready" int; 7: ce_status_summary added; 6: ce_default_settings = SCS defaults incl. acceleration_lookback 10, ce_acceleration_available). */
-#define CE_ABI_VERSION 10
+ * layout, an entry point's signature or the meaning of an argument changes (11: ce_vjp re-solves rank-deficient instances by LSQR when q_vals is given, adj_status is a bit field, ce_set_adjoint_resolve added; 10: ce_vjp_lsqr added; 9: ce_vjp_shared_a takes sA_b and q_vals -- the adjoint system gains diffcp's tau row and column --, its iter_lim default is diffcp's 2 (n + m + 1); 8: ce_set_dispatch_history added, ce_status_summary writes a fourth "ready" int; 7: ce_status_summary added; 6: ce_default_settings = SCS defaults incl. acceleration_lookback 10, ce_acceleration_available). */
+#define CE_ABI_VERSION 11
 int ce_abi_version(void);
 int ce_struct_size(int which);
 /* 1 when ce_solve / ce_solve_qp on this engine honour ce_settings.acceleration_lookback > 0 (second-generation forward kernel with
@@ -124,7 +124,14 @@ int ce_solve(ce_handle h, int B,
  * dx [B][n], dy [B][m] contiguous.  Gradients are written in the *boundary* convention
  * dA_vals (k, i) at [k*sdA_k + i*sdA_b] = [-dA.data, db[b_idx]],  dq_vals (k,i) at [k*sdq_k + i*sdq_b] = [dc, 0].
  * If A_vals == NULL the batch-major copy retained by the last ce_solve on this handle is used.
- * adj_status [B] (or NULL): 0 ok, 1 = active set larger than the direct solve supports / singular pivot.
+ * The system M^T r = dz is reduced cone block by cone block and eliminated directly with r_tau pinned to 0 (the same gradients as diffcp's LSQR wherever it is
+ * regular).  Where it is RANK DEFICIENT (redundant equality rows, degenerate active sets) the elimination only has a basic solution to offer while diffcp's LSQR
+ * (diffcp_if.py:86 -> adj_batch) returns the minimum-norm one: with q_vals given (the call's q_eval, as ce_solve; c and b enter diffcp's full (n + m + 1)
+ * system through it) such instances -- and instances whose active set exceeds the kernel's tile -- are listed on the device by the elimination kernel and
+ * re-solved behind it by the LSQR kernel of ce_vjp_lsqr (one more launch whose workgroups walk the list; no host round trip), so the DEFAULT answer is
+ * diffcp's on every instance.  q_vals == NULL, ce_set_adjoint_resolve(h, 0, ...) or a quadratic objective: no re-solve.
+ * adj_status [B] (or NULL), bit field: 1 = LSQR re-solve stopped at its iteration limit; 2 = active set larger than the direct solve holds and no re-solve
+ * (zero gradient); 4 = rank-deficient system (free variables set to zero by the elimination); 8 = gradients replaced by the LSQR re-solve.
  */
 int ce_vjp(ce_handle h, int B,
            const double *A_vals, long sA_k, long sA_b,
@@ -283,6 +290,10 @@ int ce_vjp_lsqr(ce_handle h, int B, const double *A_vals_bm, long sA_b, const do
  * the instances' rows over HBM: 1.5 % slower on the metric configuration).  A scheduling hint only: results are bit-identical in any order.
  * Register-tiled forward kernels only (fwd_mode 4).  Off by default at the C ABI. */
 int ce_set_dispatch_history(ce_handle h, int on);
+
+/* The LSQR re-solve of ce_vjp (see there): enable (default 1) and its stopping rule -- Paige & Saunders' atol / btol / conlim and the iteration limit
+ * (0: diffcp's 2 (n + m + 1)); defaults = diffcp's adj_batch(mode="lsqr"): 1e-8, 1e-8, 1e8, 0.  <- diffcp_if.py:86. */
+int ce_set_adjoint_resolve(ce_handle h, int enable, double atol, double btol, double conlim, int iter_lim);
 
 /* Introspection used by bench.py / tests: per-kernel HIP-event timing on the launch stream.  enable: 0 off, 1 every launch, or a sum of 2 (forward launches),
  * 4 (adjoint launches), 8 (layout passes) to bracket only those kinds (two event records per bracketed launch are host work in front of the launch). */

@@ -174,3 +174,18 @@ def geo_mean_max(w, total, alpha=0.5):
 # The shared-A adjoint stops like diffcp's LSQR by default (atol = btol = 1e-8, 2 N iterations: mi355_if.lsqr_rule).  Tests that compare its gradients with a
 # DIRECT elimination to 1e-5 ask for a tight solve explicitly -- the same triple as solver_args lsqr_atol / lsqr_btol / lsqr_iter_lim.
 TIGHT_LSQR = (1e-12, 1e-12, 20000)
+
+
+TIGHTER_LSQR = (1e-14, 1e-14, 40000)
+
+
+def assert_lsqr_agreement_per_instance(el, own_move, strict=1e-5, factor=3.0, floor=0.7):
+    """The per-instance rule for comparing two LSQR implementations on the same adjoint system (round 6; it replaces "95 % of the instances below 5e-3"):
+    EVERY instance must be within `strict` of the oracle's LSQR answer, or no further from it than `factor` x the distance the ORACLE'S OWN answer moves when its
+    stopping rule is tightened once more (TIGHT_LSQR -> TIGHTER_LSQR) -- i.e. the difference must be explained, instance by instance, by LSQR's own accuracy on a
+    near-singular system (the components along near-null directions converge on neither side).  At least `floor` of the instances must meet `strict` outright."""
+    import numpy as np
+    el, own_move = np.asarray(el), np.asarray(own_move)
+    ok = (el <= strict) | (el <= factor * own_move)
+    assert ok.all(), [(int(i), float(el[i]), float(own_move[i])) for i in np.nonzero(~ok)[0]]
+    assert (el <= strict).mean() >= floor, (float((el <= strict).mean()), el)

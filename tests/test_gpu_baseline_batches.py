@@ -14,7 +14,7 @@ import pytest
 import torch
 
 from cvxpylayers_amd import problems as P
-from kit import TIGHT_LSQR
+from kit import TIGHT_LSQR, TIGHTER_LSQR, assert_lsqr_agreement_per_instance
 
 pytestmark = pytest.mark.gpu
 
@@ -333,8 +333,13 @@ def test_C5_portfolio_n501_at_B16384():
     el = err_against(gl)
     # Same recurrences on the same system: rounding-level agreement (1e-15) on most instances; on ill-conditioned ones (near-degenerate faces) the components along
     # near-null directions converge on neither side and the implementations' summation orders separate them -- LSQR's own accuracy there (tests/test_gpu_atsize.py)
-    # (a single instance of the 48 can sit 5e-2 apart: there the oracle's own answer moves by as much when its tolerances are tightened once more)
-    assert np.median(el) < 1e-9 and (el < 1e-5).mean() >= 0.7 and (el < 5e-3).mean() >= 0.95, (el, regular)
+    # PER-INSTANCE rule (round 6; was "95 % below 5e-3"): every instance is within 1e-5 of the oracle, or no further from it than 3 x what the oracle's OWN answer
+    # moves when its stopping rule is tightened once more (kit.assert_lsqr_agreement_per_instance)
+    gl2 = oracle.adjoint_batch(Ab, bb, c[idx], cones, ref["x"], ref["y"], ref["s"], ones, zeros, mode="lsqr", lsqr_atol=TIGHTER_LSQR[0], lsqr_btol=TIGHTER_LSQR[1], lsqr_iter_lim=TIGHTER_LSQR[2])
+    own = np.maximum(np.abs(gl["dc"] - gl2["dc"]).max(axis=1) / (1 + np.abs(gl2["dc"]).max(axis=1)),
+                     np.abs(gl["db"][:, brows] - gl2["db"][:, brows]).max(axis=1) / (1 + np.abs(gl2["db"]).max(axis=1)))
+    assert np.median(el) < 1e-9, el
+    assert_lsqr_agreement_per_instance(el, own)
     gd = oracle.adjoint_batch(Ab, bb, c[idx], cones, ref["x"], ref["y"], ref["s"], ones, zeros, mode="dense")
     assert err_against(gd)[regular].max() < 5e-4, (regular.mean(), err_against(gd)[regular].max())
     # diffcp's own stopping rule (the plugin's default: atol = btol = 1e-8, 2 (n + m + 1) iterations) on both sides: the same element to LSQR's accuracy at that rule

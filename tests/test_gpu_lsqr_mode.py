@@ -4,7 +4,10 @@ Checked against the oracle's LSQR mode (oracle/cone_oracle.c lsqr_MT) at matched
   * a regular system: LSQR (tight) = the direct elimination = the oracle, to 1e-6; at diffcp's 1e-8 rule the iteration counts are the oracle's;
   * a RANK-DEFICIENT system (a duplicated equality row): LSQR returns the minimum-norm solution -- db equal on the two copies, as diffcp does -- where the direct
     elimination returns a basic one; the engine's LSQR still matches the oracle's to 1e-6;
-  * through the plugin: `_CvxpyLayer.apply(..., solver_args={"mode": "lsqr"})` reaches it, silently (no "ignored" warning)."""
+  * through the plugin: `_CvxpyLayer.apply(..., solver_args={"mode": "lsqr"})` reaches it, silently (no "ignored" warning);
+  * the DEFAULT path (round 6): the elimination kernel lists the instances whose system it found rank deficient and the LSQR kernel re-solves exactly those behind it
+    on the device (ce_vjp with q_vals) -- default solver_args give diffcp's minimum-norm element on the degenerate instances, the regular instances of the same
+    batch keep the elimination's answer bit for bit, and info["adjoint"] says which is which."""
 import warnings
 
 import numpy as np
@@ -114,3 +117,69 @@ def test_mode_lsqr_through_the_plugin_is_silent_and_reaches_the_lsqr_kernel():
     kb = {int(tpl.indices[k]): k for k in range(tpl.nnz_aug) if cols[k] == n}
     assert np.abs(grads["lsqr"][kb[0]] - grads["lsqr"][kb[1]]).max() < 1e-7 * (1 + np.abs(grads["lsqr"]).max())
     assert np.abs(grads["dense"][kb[0]] - grads["dense"][kb[1]]).max() > 1e-3
+
+
+def test_default_path_resolves_exactly_the_rank_deficient_instances_by_lsqr():
+    from oracle import oracle
+    n, cones, B = 8, {"z": 4, "l": 6, "q": [4]}, 12
+    tpl = P.dense_template(n, cones)
+    A, b, c = P.generate(n, cones, B, seed=5)
+    deg = np.arange(B) % 3 == 0                      # every third instance gets a duplicated equality row
+    A[deg, 1, :] = A[deg, 0, :]; b[deg, 1] = b[deg, 0]
+    ref = oracle.solve_batch(A, b, c, cones, eps=1e-10, max_iters=200000)
+    assert (ref["status"] == 1).all()
+    eng, A_bm, *_ = gpu_solve(tpl, A, b, c, eps=1e-10, max_iters=200000)
+    rng = np.random.default_rng(7)
+    dx = rng.standard_normal(ref["x"].shape); dy = rng.standard_normal(ref["y"].shape)
+    xr, yr, sr = (torch.from_numpy(ref[k]).cuda() for k in ("x", "y", "s"))
+    dxt, dyt = torch.from_numpy(dx).cuda(), torch.from_numpy(dy).cuda()
+    _, q_eval = tpl.values_from_dense(A, b, c); q_t = torch.from_numpy(q_eval).cuda()
+    dA_basic, dq_basic, adj_basic = eng.vjp(A_bm, xr, yr, sr, dxt, dyt, path="per_instance")                                  # no q_eval: the elimination alone
+    dA_def, dq_def, adj_def = eng.vjp(A_bm, xr, yr, sr, dxt, dyt, path="per_instance", lsqr=TIGHT_LSQR, q_eval=q_t)           # the default route of the plugin
+    dA_def2, _, adj_def2 = eng.vjp(A_bm, xr, yr, sr, dxt, dyt, path="per_instance", lsqr=TIGHT_LSQR, q_eval=q_t)              # (the device-side list is reset between calls)
+    dA_l, dq_l, _ = eng.vjp(A_bm, xr, yr, sr, dxt, dyt, path="per_instance_lsqr", lsqr=TIGHT_LSQR, q_eval=q_t)
+    torch.cuda.synchronize()
+    a0, a1 = adj_basic.cpu().numpy(), adj_def.cpu().numpy()
+    assert ((a0 & 4) != 0).tolist() == deg.tolist(), a0                  # the elimination flags exactly the duplicated-row instances ...
+    assert (a1[deg] == 12).all() and (a1[~deg] == 0).all(), a1           # ... and exactly those are re-solved (4 | 8), converged (bit 0 clear)
+    assert (adj_def2.cpu().numpy() == a1).all()
+    got, basic, lsq = dA_def.cpu().numpy(), dA_basic.cpu().numpy(), dA_l.cpu().numpy()
+    assert np.array_equal(got[:, ~deg], basic[:, ~deg])                  # regular instances: untouched
+    assert np.array_equal(got[:, deg], lsq[:, deg])                      # degenerate instances: the LSQR kernel's answer
+    assert np.array_equal(dA_def2.cpu().numpy(), got)
+    assert np.array_equal(dq_def.cpu().numpy()[:, deg], dq_l.cpu().numpy()[:, deg])
+    g = oracle.adjoint_batch(A, b, c, cones, ref["x"], ref["y"], ref["s"], dx, dy, mode="lsqr", lsqr_atol=TIGHT_LSQR[0], lsqr_btol=TIGHT_LSQR[1], lsqr_iter_lim=TIGHT_LSQR[2])
+    want = _want(tpl, g, n)
+    assert np.abs(got - want).max() < 1e-6 * (1 + np.abs(want).max())  # every instance = the oracle's LSQR mode = diffcp's element
+    cols = np.repeat(np.arange(n + 1), np.diff(tpl.indptr))
+    kb = {int(tpl.indices[k]): k for k in range(tpl.nnz_aug) if cols[k] == n}
+    assert np.abs(got[kb[0]][deg] - got[kb[1]][deg]).max() < 1e-8 * (1 + np.abs(want).max())
+    assert np.abs(basic[kb[0]][deg] - basic[kb[1]][deg]).max() > 1e-3
+
+
+def test_default_solver_args_through_the_plugin_give_diffcps_element_and_report_it():
+    from cvxpylayers_amd.interfaces.mi355_if import MI355_ctx, _CvxpyLayer, adjoint_report
+    n, cones = 8, {"z": 4, "l": 6, "q": [4]}
+    tpl = P.dense_template(n, cones)
+    A, b, c = P.generate(n, cones, 6, seed=2)
+    A[:3, 1, :] = A[:3, 0, :]; b[:3, 1] = b[:3, 0]
+    A_eval, q_eval = tpl.values_from_dense(A, b, c)
+    ctx = MI355_ctx(None, tpl.problem_data_index, cones, options={"eps": 1e-10, "max_iters": 200000})
+    grads, reports = {}, {}
+    for name, args in (("default", {}), ("lsqr", {"mode": "lsqr"}), ("dense", {"mode": "dense"})):
+        A_t = torch.from_numpy(A_eval).cuda().requires_grad_(); q_t = torch.from_numpy(q_eval).cuda().requires_grad_()
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")
+            primal, dual, info, _ = _CvxpyLayer.apply(None, q_t, A_t, ctx, args, True, None)
+            (primal * torch.arange(1, n + 1, device="cuda", dtype=torch.float64)).sum().backward()
+        grads[name] = A_t.grad.cpu().numpy(); reports[name] = adjoint_report(info)
+    assert reports["default"] == dict(rank_deficient=3, lsqr_resolved=3, lsqr_iteration_limit=0, no_gradient=0, backward_ran=True), reports
+    assert reports["dense"]["rank_deficient"] == 3 and reports["dense"]["lsqr_resolved"] == 0
+    scale = 1 + np.abs(grads["lsqr"]).max()
+    assert np.abs(grads["default"][:, :3] - grads["lsqr"][:, :3]).max() < 1e-12 * scale          # the same kernel, the same rule
+    assert np.abs(grads["default"][:, 3:] - grads["dense"][:, 3:]).max() == 0.0
+    assert np.abs(grads["default"][:, 3:] - grads["lsqr"][:, 3:]).max() < 1e-5 * scale           # regular instances: elimination = LSQR at diffcp's rule
+    cols = np.repeat(np.arange(n + 1), np.diff(tpl.indptr))
+    kb = {int(tpl.indices[k]): k for k in range(tpl.nnz_aug) if cols[k] == n}
+    assert np.abs(grads["default"][kb[0]][:3] - grads["default"][kb[1]][:3]).max() < 1e-6 * scale
+    assert np.abs(grads["dense"][kb[0]][:3] - grads["dense"][kb[1]][:3]).max() > 1e-3

@@ -41,7 +41,7 @@ def test_mode_lsqr_and_dense_are_acted_on_other_modes_and_n_jobs_are_reported():
         m.note_ignored_args({"acceleration_lookback": 0, "mode": "lsmr"}, explicit_lookback=True)
     msgs = [str(x.message) for x in w]
     assert len(msgs) == 3 and any("'mode'" in t and "lsmr" in t for t in msgs) and any("n_jobs_forward" in t for t in msgs) and any("n_jobs_backward" in t for t in msgs)
-    assert m.adjoint_mode({"mode": "lsqr"}) == "lsqr" and m.adjoint_mode({"mode": "dense"}) == "direct" and m.adjoint_mode({}) == "direct"
+    assert m.adjoint_mode({"mode": "lsqr"}) == "lsqr" and m.adjoint_mode({"mode": "dense"}) == "dense" and m.adjoint_mode({}) == "direct"      # (default: elimination + device-side LSQR re-solve of rank-deficient instances; "dense": the elimination alone)
     # and they still pass validation (unknown names do not)
     m.make_settings({"mode": "lsqr", "n_jobs_forward": 4, "eps": 1e-6})
     with pytest.raises(ValueError):
