@@ -9,6 +9,9 @@ namespace {
 #include "ce_global_mv.h"
 #include "ce_backward.h"
 #include "ce_backward_rt.h"
+#if CE_BRT_PSD == 0
+#include "ce_backward_ns.h"
+#endif
 }  // namespace
 
 #ifndef CE_BRT_PSD
@@ -31,6 +34,27 @@ int ce_launch_bwd_rt_plain(int variant, int B, size_t lds, hipStream_t st, const
     default: return -1;
     }
     return 0;
+}
+// search-free null-space adjoint (ce_backward_ns.h): variant -> {tiles of 16 reduced columns, threads}
+#define NS_ARGS a.T, a.Abm, a.x, a.y, a.s, a.dx, a.dy, a.dA, a.dq, a.sdqk, a.sdqb, a.adj, a.fix
+int ce_launch_bwd_ns(int variant, int B, size_t lds, hipStream_t st, const CeBwdArgs &a) {
+    switch (variant) {
+    case 0: hipLaunchKernelGGL((k_backward_ns<2, 256>), dim3(B), dim3(256), lds, st, NS_ARGS); break;
+    case 1: hipLaunchKernelGGL((k_backward_ns<4, 256>), dim3(B), dim3(256), lds, st, NS_ARGS); break;
+    case 2: hipLaunchKernelGGL((k_backward_ns<7, 512>), dim3(B), dim3(512), lds, st, NS_ARGS); break;
+    default: return -1;
+    }
+    return 0;
+}
+hipError_t ce_setattr_bwd_ns(int bytes) {
+#define SETATTR_NS(...) do { hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_backward_ns<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes); if (e_ != hipSuccess) return e_; } while (0)
+    SETATTR_NS(2, 256); SETATTR_NS(4, 256); SETATTR_NS(7, 512);
+#undef SETATTR_NS
+    return hipSuccess;
+}
+size_t ce_bwd_ns_lds_bytes(int n, int m, int nq, int variant) {
+    static const int V[3][2] = {{2, 256}, {4, 256}, {7, 512}};
+    return bwd_ns_lds_bytes_of(n, m, nq, V[variant][0], V[variant][1]);
 }
 hipError_t ce_setattr_bwd_rt_plain(int bytes) {
     SETATTR(4, 4, 4); SETATTR(5, 5, 4); SETATTR(6, 6, 4); SETATTR(7, 7, 4); SETATTR(7, 7, 7); SETATTR(5, 9, 7, false, 32); SETATTR(7, 13, 7, false, 32);

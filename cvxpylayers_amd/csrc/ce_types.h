@@ -54,6 +54,9 @@ int ce_launch_fwd2_qp(int variant, int B, size_t lds, hipStream_t st, const CeFw
 int ce_launch_fwd_rt(int variant, int B, size_t lds, hipStream_t st, const CeFwdArgs &a);
 int ce_launch_fwd_generic(int mode, int B, size_t lds, hipStream_t st, const CeFwdArgs &a);
 int ce_launch_bwd_rt_plain(int variant, int B, size_t lds, hipStream_t st, const CeBwdArgs &a);
+int ce_launch_bwd_ns(int variant, int B, size_t lds, hipStream_t st, const CeBwdArgs &a);       // search-free null-space adjoint (plain cones), variants {2|256, 4|256, 7|512}
+size_t ce_bwd_ns_lds_bytes(int n, int m, int nq, int variant);
+hipError_t ce_setattr_bwd_ns(int bytes);
 int ce_launch_bwd_rt_psd(int variant, int B, size_t lds, hipStream_t st, const CeBwdArgs &a);
 int ce_launch_bwd_generic(int mode, int B, size_t lds, hipStream_t st, const CeBwdArgs &a);
 // raise the dynamic-LDS limit of every kernel of the family

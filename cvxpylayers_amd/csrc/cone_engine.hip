@@ -84,6 +84,7 @@ struct ce_engine {
     int *d_iters2 = nullptr; int iters2_cap = 0, order_pending_B = 0;
     int *d_iters_prev = nullptr; int iters_prev_cap = 0, iters_prev_B = 0;      // the iteration counts of the call before (k_dispatch_order compares: is the history predictive?)      // engine-owned copy of the last solve's iteration counts (the caller's buffer may be gone when the order is computed)
     int brt_variant = -1;                          // register-tiled backward kernel variant (-1: generic kernel)
+    int ns_variant = -1; size_t ns_lds = 0;       // search-free null-space adjoint (ce_backward_ns.h), -1: not applicable
     // two-tile plan of the register-tiled adjoint: a smaller tile serves the instances it holds, the worst-case tile re-runs the ones it flagged.  The smaller
     // tile is chosen from the LARGEST system of the previous call of the same batch size (nk_*: device maximum, copied to pinned memory behind the launch)
     bool two_tile = false; int fast_forced = -1;
@@ -471,6 +472,19 @@ int ce_create(const ce_template *tpl, int device, ce_handle *out) {
         h->two_tile = h->bwd_mode == 3 && plain && h->nnz_p == 0 && h->brt_variant > 0 && !(tt && !strcmp(tt, "0"));
         h->fast_forced = fv ? atoi(fv) : -1;
     }
+    // Search-free null-space adjoint (ce_backward_ns.h): plain cones, linear objective, 4 ceil(n / 4) + 1 columns in the variant's tiles.  It serves ce_vjp calls
+    // whose LSQR re-solve is armed (rank-deficient instances are detected, flagged and handed to LSQR, not resolved by the elimination).  CE_BWD_NS=0 disables.
+    {
+        static const int NSV[3][2] = {{2, 256}, {4, 256}, {7, 512}};
+        const char *e = getenv("CE_BWD_NS");
+        const bool plain = T.ns == 0 && T.nep + T.np == 0;
+        if (plain && h->nnz_p == 0 && !(e && atoi(e) == 0) && !getenv("CE_FORCE_GENERIC")) {
+            for (int v = 0; v < 3; v++) {
+                if (4 * ((T.n + 3) / 4) + 1 <= 16 * NSV[v][0] && ce_bwd_ns_lds_bytes(T.n, T.m, T.nq, v) <= LDS_LIMIT) { h->ns_variant = v; h->ns_lds = ce_bwd_ns_lds_bytes(T.n, T.m, T.nq, v); break; }
+            }
+        }
+        HIPCHK(ce_setattr_bwd_ns((int)LDS_LIMIT));
+    }
     if (h->qp_native && h->bwd_mode != 3) h->qp_native = false;      // the adjoint with P lives in the register-tiled backward kernel
     HIPCHK(ce_setattr_fwd_generic((int)LDS_LIMIT)); HIPCHK(ce_setattr_fwd_rt((int)LDS_LIMIT));
     HIPCHK(ce_setattr_fwd2_plain((int)LDS_LIMIT)); HIPCHK(ce_setattr_fwd2_psd((int)LDS_LIMIT)); HIPCHK(ce_setattr_fwd2_qp((int)LDS_LIMIT));
@@ -479,6 +493,7 @@ int ce_create(const ce_template *tpl, int device, ce_handle *out) {
     return CE_OK;
 }
 
+int ce_adjoint_ns_variant(ce_handle h) { return h ? h->ns_variant : -1; }
 int ce_set_adjoint_resolve(ce_handle h, int enable, double atol, double btol, double conlim, int iter_lim) {
     if (!h) { g_err = "null argument"; return CE_E_BADARG; }
     h->resolve = enable != 0;
@@ -678,7 +693,10 @@ int ce_vjp_qp(ce_handle h, int B, const double *A_vals, long sA_k, long sA_b, co
         ba.sdqk = sdq_k; ba.sdqb = sdq_b; ba.adj = adj_status; ba.P = P_vals; ba.nnz_p = h->nnz_p; ba.pmap = h->d_pmap; ba.prow = h->d_prow; ba.pcol = h->d_pcol;
         ba.p_tri = h->p_tri; ba.dP = dP_vals; ba.gA = gA; ba.gK = gK;
         int lrc;
-        if (h->bwd_mode == 3) {
+        if (do_fix && h->ns_variant >= 0) {
+            ba.T.lda = T.n;
+            lrc = ce_launch_bwd_ns(h->ns_variant, B, h->ns_lds, st, ba);
+        } else if (h->bwd_mode == 3) {
             ba.T.lda = T.n;
             int fast = -1; size_t fast_lds = 0;
             if (h->two_tile && adj_status && !P_vals) {

@@ -294,6 +294,11 @@ int ce_set_dispatch_history(ce_handle h, int on);
 /* The LSQR re-solve of ce_vjp (see there): enable (default 1) and its stopping rule -- Paige & Saunders' atol / btol / conlim and the iteration limit
  * (0: diffcp's 2 (n + m + 1)); defaults = diffcp's adj_batch(mode="lsqr"): 1e-8, 1e-8, 1e8, 0.  <- diffcp_if.py:86. */
 int ce_set_adjoint_resolve(ce_handle h, int enable, double atol, double btol, double conlim, int iter_lim);
+/* >= 0: ce_vjp calls with the re-solve armed (q_vals given, enabled) run the SEARCH-FREE elimination kernel k_backward_ns (csrc/ce_backward_ns.h: the equality rows
+ * are eliminated by one wave with column pivoting, the reduced Hessian on the null space is formed and swept on the matrix cores without a pivot search; a
+ * vanishing pivot flags the instance for the LSQR re-solve) -- plain-cone templates with a linear objective and n <= 108; the value is the tile variant.
+ * -1: the pivoting elimination kernels (k_backward_rt / k_backward) serve every call.  Introspection for tests / bench. */
+int ce_adjoint_ns_variant(ce_handle h);
 
 /* Introspection used by bench.py / tests: per-kernel HIP-event timing on the launch stream.  enable: 0 off, 1 every launch, or a sum of 2 (forward launches),
  * 4 (adjoint launches), 8 (layout passes) to bracket only those kinds (two event records per bracketed launch are host work in front of the launch). */

@@ -1,0 +1,25 @@
+"""Debug-build probe (-DCE_TIMING; CE_ENGINE_SO=.../libcone_engine_timing.so): mean per-phase shader cycles of the search-free adjoint kernel k_backward_ns.
+usage: ns_timing_probe.py [config] [B]"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from cvxpylayers_amd import problems as P
+from cvxpylayers_amd.interfaces.mi355_if import ConeEngine, make_settings
+cfg = P.CONFIGS[sys.argv[1] if len(sys.argv) > 1 else "M"]; n, cones = cfg["n"], cfg["cones"]; B = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+tpl = P.dense_template(n, cones)
+A, b, c = P.generate(n, cones, B, seed=0)
+A_eval, q_eval = tpl.values_from_dense(A, b, c)
+dev = torch.device("cuda", 0)
+eng = ConeEngine(tpl.indices, tpl.indptr, tpl.n, tpl.m, cones, dev)
+A_bm = torch.from_numpy(A_eval).to(dev).t().contiguous(); q_t = torch.from_numpy(q_eval).to(dev)
+x, y, s, it, st, res = eng.solve(A_bm, q_t, make_settings(dict(eps=1e-4, max_iters=10000)))
+dx = torch.ones_like(x); dy = torch.zeros_like(y)
+for _ in range(2):
+    dA, dq, adj = eng.vjp(A_bm, x, y, s, dx, dy, path="per_instance", q_eval=q_t)
+torch.cuda.synchronize()
+t = dA.t()[:, :12].cpu().numpy()
+names = ["load", "classify + numbering", "d, a_z, f, lists", "row elimination of B (one wave)", "null-space transform of the rows", "reduced Hessian on the matrix cores", "sweep", "x, q, g, mu", "r_y", "outputs"]
+for k, nm in enumerate(names):
+    print(f"{nm:40s} mean {t[:, k].mean():12.1f}  max {t[:, k].max():12.1f}")
+print(f"{'sum of phases':40s} {t[:, :10].sum(1).mean():12.1f}")
+print("mean NK = n + neq %.1f, mean nf %.1f (sweep blocks %.1f)" % (t[:, 10].mean(), t[:, 11].mean(), np.ceil(t[:, 11] / 4).mean()))

@@ -177,13 +177,29 @@ TIGHT_LSQR = (1e-12, 1e-12, 20000)
 
 
 TIGHTER_LSQR = (1e-14, 1e-14, 40000)
+# The rules under which the ORACLE's own LSQR answer is re-computed to measure LSQR's accuracy on an instance: tighter atol / btol, and -- for the ill-conditioned
+# instances, which stop on the condition-estimate test long before atol / btol matter -- the same tolerances with conlim relaxed (1e8 -> 3e8, 1e9)
+LSQR_OWN_RULES = (dict(lsqr_atol=1e-14, lsqr_btol=1e-14, lsqr_iter_lim=40000), dict(lsqr_atol=1e-12, lsqr_btol=1e-12, lsqr_iter_lim=20000, lsqr_conlim=3e8),
+                  dict(lsqr_atol=1e-12, lsqr_btol=1e-12, lsqr_iter_lim=20000, lsqr_conlim=1e9))
+
+
+def lsqr_own_movement(run, base, dist):
+    """max over LSQR_OWN_RULES of dist(base, run(**rule)): how far the oracle's own answer moves, per instance, when the stopping test that fired is pushed out"""
+    import numpy as np
+    own = None
+    for rule in LSQR_OWN_RULES:
+        d = dist(base, run(**rule))
+        own = d if own is None else np.maximum(own, d)
+    return own
 
 
 def assert_lsqr_agreement_per_instance(el, own_move, strict=1e-5, factor=3.0, floor=0.7):
     """The per-instance rule for comparing two LSQR implementations on the same adjoint system (round 6; it replaces "95 % of the instances below 5e-3"):
     EVERY instance must be within `strict` of the oracle's LSQR answer, or no further from it than `factor` x the distance the ORACLE'S OWN answer moves when its
-    stopping rule is tightened once more (TIGHT_LSQR -> TIGHTER_LSQR) -- i.e. the difference must be explained, instance by instance, by LSQR's own accuracy on a
-    near-singular system (the components along near-null directions converge on neither side).  At least `floor` of the instances must meet `strict` outright."""
+    stopping rule is pushed out (lsqr_own_movement) -- i.e. the difference must be explained, instance by instance, by LSQR's own accuracy on a near-singular
+    system (the components along near-null directions converge on neither side; such instances stop on LSQR's condition-estimate test, conlim = 1e8, and the
+    answer at that point depends on the summation order to about the amount it still moves over the following iterations).  At least `floor` of the instances
+    must meet `strict` outright."""
     import numpy as np
     el, own_move = np.asarray(el), np.asarray(own_move)
     ok = (el <= strict) | (el <= factor * own_move)

@@ -144,7 +144,8 @@ def test_default_path_resolves_exactly_the_rank_deficient_instances_by_lsqr():
     assert (a1[deg] == 12).all() and (a1[~deg] == 0).all(), a1           # ... and exactly those are re-solved (4 | 8), converged (bit 0 clear)
     assert (adj_def2.cpu().numpy() == a1).all()
     got, basic, lsq = dA_def.cpu().numpy(), dA_basic.cpu().numpy(), dA_l.cpu().numpy()
-    assert np.array_equal(got[:, ~deg], basic[:, ~deg])                  # regular instances: untouched
+    sc0 = 1 + np.abs(basic).max()
+    assert np.abs(got[:, ~deg] - basic[:, ~deg]).max() < 1e-9 * sc0      # regular instances: the elimination's answer (search-free kernel here, pivoting kernel there: one solution)
     assert np.array_equal(got[:, deg], lsq[:, deg])                      # degenerate instances: the LSQR kernel's answer
     assert np.array_equal(dA_def2.cpu().numpy(), got)
     assert np.array_equal(dq_def.cpu().numpy()[:, deg], dq_l.cpu().numpy()[:, deg])
@@ -177,7 +178,7 @@ def test_default_solver_args_through_the_plugin_give_diffcps_element_and_report_
     assert reports["dense"]["rank_deficient"] == 3 and reports["dense"]["lsqr_resolved"] == 0
     scale = 1 + np.abs(grads["lsqr"]).max()
     assert np.abs(grads["default"][:, :3] - grads["lsqr"][:, :3]).max() < 1e-12 * scale          # the same kernel, the same rule
-    assert np.abs(grads["default"][:, 3:] - grads["dense"][:, 3:]).max() == 0.0
+    assert np.abs(grads["default"][:, 3:] - grads["dense"][:, 3:]).max() < 1e-9 * scale          # (two elimination kernels, one solution)
     assert np.abs(grads["default"][:, 3:] - grads["lsqr"][:, 3:]).max() < 1e-5 * scale           # regular instances: elimination = LSQR at diffcp's rule
     cols = np.repeat(np.arange(n + 1), np.diff(tpl.indptr))
     kb = {int(tpl.indices[k]): k for k in range(tpl.nnz_aug) if cols[k] == n}

@@ -9,7 +9,7 @@ import torch
 
 import kit
 from cvxpylayers_amd import problems as P
-from kit import TIGHT_LSQR, TIGHTER_LSQR, assert_lsqr_agreement_per_instance
+from kit import TIGHT_LSQR, lsqr_own_movement, assert_lsqr_agreement_per_instance
 
 pytestmark = pytest.mark.gpu
 
@@ -306,8 +306,8 @@ def test_constant_A_path_is_selected_for_large_shared_templates():
     dA, dq, adj = eng.vjp(A_bm, xr, yr, sr, torch.from_numpy(dx).cuda(), torch.zeros_like(yr), lsqr=TIGHT_LSQR)
     assert (adj.cpu().numpy() == 0).all()
     el = np.abs(dq.cpu().numpy()[:n].T - g["dc"]).max(axis=1) / (1 + np.abs(g["dc"]).max(axis=1))
-    g2 = oracle.adjoint_batch(Ab, bb, c, cones, ref["x"], ref["y"], ref["s"], dx, np.zeros_like(ref["y"]), mode="lsqr", lsqr_atol=TIGHTER_LSQR[0], lsqr_btol=TIGHTER_LSQR[1], lsqr_iter_lim=TIGHTER_LSQR[2])
-    own = np.abs(g["dc"] - g2["dc"]).max(axis=1) / (1 + np.abs(g2["dc"]).max(axis=1))
+    own = lsqr_own_movement(lambda **kw: oracle.adjoint_batch(Ab, bb, c, cones, ref["x"], ref["y"], ref["s"], dx, np.zeros_like(ref["y"]), mode="lsqr", **kw), g,
+                            lambda g1, g2: np.abs(g1["dc"] - g2["dc"]).max(axis=1) / (1 + np.abs(g2["dc"]).max(axis=1)))
     assert np.median(el) < 1e-9, el
     assert_lsqr_agreement_per_instance(el, own)          # (rounding-level agreement; on ill-conditioned instances: within the oracle's own movement under a tighter rule)
 
