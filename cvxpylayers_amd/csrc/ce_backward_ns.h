@@ -22,7 +22,9 @@
 // Plain cones (zero / nonnegative / second-order), linear objective.  PSD / exponential / power cones and quadratic objectives keep k_backward_rt.
 #pragma once
 
-__host__ __device__ constexpr int bwd_ns_ldp(int NTILE) { return (16 * NTILE) % 32 == 16 ? 16 * NTILE : 16 * NTILE + 16; }      // pitch of the sweep's row buffers: 16 mod 32 doubles (conflict-free)
+// pitch of the sweep's row buffers: 16 mod 32 doubles (conflict-free) with at least 16 doubles of gap behind the 16 NTILE entries of a row (the gaps of the
+// eight buffer rows hold the ORIGINAL diagonal of the reduced Hessian: the rank tolerance of a pivot is relative to its own diagonal entry)
+__host__ __device__ constexpr int bwd_ns_ldp(int NTILE) { return (16 * NTILE + 16) % 32 == 16 ? 16 * NTILE + 16 : 16 * NTILE + 32; }
 __host__ __device__ inline int bwd_ns_kwmax(int m) { return ((m + 4) & ~3) + 4; }                                            // capacity of the weighted-row list (<= m entries + at least one pad, a multiple of 4)
 __host__ __device__ constexpr int bwd_ns_nsl(int NTILE) { return (16 * NTILE - 3 + 63) / 64; }                               // 64-lane slots that hold the columns 0 .. n (n = right-hand side)
 __host__ __device__ inline int bwd_ns_union_doubles(int n, int m, int nqs, int NTILE) {
@@ -41,8 +43,10 @@ __host__ __device__ inline size_t bwd_ns_lds_bytes_of(int n, int m, int nq, int 
 
 #ifdef CE_TIMING
 #define NS_STAMP(i) do { __syncthreads(); if (threadIdx.x == 0) tstamp[i] = __builtin_readcyclecounter(); } while (0)
+#define NS_SUB(i) do { if (threadIdx.x == 0) tsub[i] = __builtin_readcyclecounter(); } while (0)          // thread 0's clock, no barrier
 #else
 #define NS_STAMP(i) do { } while (0)
+#define NS_SUB(i) do { } while (0)
 #endif
 
 template <int NTILE, int NTHR>
@@ -97,7 +101,7 @@ k_backward_ns(DevT T, const double *__restrict__ Avals, const double *__restrict
     int *misc = ip; ip += 8;         // [0] n_eq, [1] nf, [2] flags, [3] KW
 
 #ifdef CE_TIMING
-    __shared__ long long tstamp[16];
+    __shared__ long long tstamp[16], tsub[16];
 #endif
     NS_STAMP(0);
     // ---- load: the instance's values scattered into dense solver form A = -A_cvx (b is not needed: r_tau is pinned)
@@ -123,29 +127,60 @@ k_backward_ns(DevT T, const double *__restrict__ Avals, const double *__restrict
         __syncthreads();
     }
     NS_STAMP(1);
-    // ---- classify (as k_backward_rt)
-    for (int i = tid; i < z + T.l; i += NTHR) rkind[i] = (i < z || vv[i] > 0) ? RK_EQ : RK_FREE;
-    for (int c = tid; c < nq; c += NTHR) {
-        const int r0 = T.qoff[c], r1 = T.qoff[c + 1], d = r1 - r0;
-        int kind; double lam = 0, nz = 0;
-        if (d == 1) kind = vv[r0] >= 0 ? 0 : 1;
-        else {
-            double nz1 = 0;
-            for (int i = r0 + 1; i < r1; i += 4) {
-                double w[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) w[u] = vv[min(i + u, r1 - 1)];
-#pragma unroll
-                for (int u = 0; u < 4; u++) { const double t = (i + u < r1) ? w[u] : 0.0; if (u & 1) nz1 = fma(t, t, nz1); else nz = fma(t, t, nz); }
-            }
-            nz = sqrt(nz + nz1);
-            const double t0 = vv[r0];
-            if (nz <= t0) kind = 0; else if (nz <= -t0) kind = 1; else { kind = 2; lam = (t0 + nz) / (2 * nz); }
+    // ---- classify + d = DPi(v) dy in ONE pass: 16 lanes per cone (a row per lane, sums by DPP butterflies inside the 16-lane row), nonnegative rows beside them.
+    //      (One thread per cone walked its rows in dependent loops: 8 of 256 threads busy, ~25 k cycles for the two phases.)  dv holds dy: transformed in place.
+    for (int i = tid; i < z + T.l; i += NTHR) { const bool eq = (i < z || vv[i] > 0); rkind[i] = eq ? RK_EQ : RK_FREE; if (!eq) dv[i] = 0.0; }
+    for (int c0 = 0; c0 < nq; c0 += NTHR / 16) {
+        const int c = c0 + (tid >> 4), l16 = tid & 15;
+        const bool cv = c < nq;
+        const int r0 = cv ? T.qoff[c] : 0, r1 = cv ? T.qoff[c + 1] : 0, d = r1 - r0;
+        const double t0 = cv ? vv[r0] : 0.0, h0 = cv ? dv[r0] : 0.0;
+        double nz2 = 0.0, zh = 0.0;
+        for (int i = r0 + 1 + l16; i < r1; i += 16) { const double w = vv[i]; nz2 = fma(w, w, nz2); zh = fma(w, dv[i], zh); }
+        nz2 = group_reduce<16, false>(nz2); zh = group_reduce<16, false>(zh);
+        const double nz = sqrt(nz2);
+        int kind; double lam = 0.0;
+        if (d == 1) kind = t0 >= 0 ? 0 : 1;
+        else if (nz <= t0) kind = 0; else if (nz <= -t0) kind = 1; else { kind = 2; lam = (t0 + nz) / (2 * nz); }
+        double zd = 0.0;
+        const double i2n = kind == 2 ? 1.0 / (2 * nz) : 0.0, cz = kind == 2 ? t0 * zh / (nz * nz) : 0.0;
+        const int rk = kind == 0 ? RK_EQ : (kind == 1 ? RK_FREE : RK_SOCB);
+        for (int i = r0 + 1 + l16; i < r1; i += 16) {
+            rkind[i] = rk;
+            if (kind == 1) dv[i] = 0.0;
+            else if (kind == 2) { const double w = vv[i]; const double di = (w * h0 + (t0 + nz) * dv[i] - w * cz) * i2n; dv[i] = di; zd = fma(w, di, zd); }
         }
-        ckind[c] = kind; cinfo[5 * c] = lam; cinfo[5 * c + 1] = nz; cinfo[5 * c + 4] = lam / (1 - lam);
-        for (int i = r0; i < r1; i++) rkind[i] = kind == 0 ? RK_EQ : (kind == 1 ? RK_FREE : RK_SOCB);
+        zd = group_reduce<16, false>(zd);
+        if (cv && l16 == 0) {
+            rkind[r0] = rk; ckind[c] = kind; cinfo[5 * c] = lam; cinfo[5 * c + 1] = nz; cinfo[5 * c + 4] = lam / (1 - lam);
+            if (kind == 1) dv[r0] = 0.0;
+            else if (kind == 2) {
+                const double d0 = (nz * h0 + zh) * i2n;
+                dv[r0] = d0;
+                const double zdn = zd / nz;
+                cinfo[5 * c + 2] = (d0 + zdn) * M_SQRT1_2;   // e_y . d
+                cinfo[5 * c + 3] = (d0 - zdn) * M_SQRT1_2;   // e_s . d
+            }
+        }
     }
     __syncthreads();
+    NS_STAMP(2);
+    // ---- a_z = A_z^T z-hat for boundary cones  (a_y = (a_0 + a_z) / sqrt 2,  a_s = (a_0 - a_z) / sqrt 2); published by the barriers of the numbering below
+    for (int idx = tid; idx < nq * n; idx += NTHR) {
+        const int c = idx / n, j = idx - c * n;
+        if (ckind[c] != 2) continue;
+        const int r0 = T.qoff[c], r1 = T.qoff[c + 1];
+        const double inz = 1.0 / cinfo[5 * c + 1];
+        double a = 0, a1 = 0;
+        for (int i = r0 + 1; i < r1; i += 4) {
+            double av[4], wv[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int iu = min(i + u, r1 - 1); av[u] = A[iu * lda + j]; wv[u] = vv[iu]; }
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const double w = (i + u < r1) ? wv[u] : 0.0; if (u & 1) a1 = fma(av[u], w, a1); else a = fma(av[u], w, a); }
+        }
+        az[c * npad + j] = (a + a1) * inz;
+    }
     // ---- equality numbering: ballot prefix sums (rows in order, then one e_y row per boundary cone); weighted-row list offsets
     {
         int base = 0;
@@ -167,17 +202,18 @@ k_backward_ns(DevT T, const double *__restrict__ Avals, const double *__restrict
             base += tot;
             __syncthreads();
         }
-        if (tid == 0) {
+        // one lane per cone: the boundary cones before it give its equality index and the start of its weighted rows
+        for (int c = tid; c < nq; c += NTHR) {
             int ne = base, kw = 0;
-            for (int c = 0; c < nq; c++) {
-                if (ckind[c] == 2) {
-                    if (ne < n) { esrc[ne] = -1 - c; erow[ne] = (int)(A - sm) + T.qoff[c] * lda; }      // (the cone's t-row will hold a_y)
-                    ceq[c] = ne++;
-                    cbase[c] = kw; kw += T.qoff[c + 1] - T.qoff[c];                                      // its z-rows, then a_z
-                } else { ceq[c] = -1; cbase[c] = -1; }
-            }
-            misc[0] = ne; misc[3] = kw;
+            for (int c2 = 0; c2 < c; c2++) { if (ckind[c2] == 2) { ne++; kw += T.qoff[c2 + 1] - T.qoff[c2]; } }
+            if (ckind[c] == 2) {
+                if (ne < n) { esrc[ne] = -1 - c; erow[ne] = (int)(A - sm) + T.qoff[c] * lda; }      // (the cone's t-row will hold a_y)
+                ceq[c] = ne; cbase[c] = kw;
+                ne++; kw += T.qoff[c + 1] - T.qoff[c];
+            } else { ceq[c] = -1; cbase[c] = -1; }
+            if (c == nq - 1) { misc[0] = ne; misc[3] = kw; }
         }
+        if (nq == 0 && tid == 0) { misc[0] = base; misc[3] = 0; }
         __syncthreads();
     }
     const int neq = misc[0], KW = misc[3], KW4 = (KW + 4) & ~3;          // (at least one pad entry: entry KW stands for f in the null-space transform)
@@ -187,64 +223,6 @@ k_backward_ns(DevT T, const double *__restrict__ Avals, const double *__restrict
         if (tid == 0) { if (adj_status) adj_status[inst] = 2; if (fix) fix[1 + atomicAdd(fix, 1)] = inst; }
         return;
     }
-    NS_STAMP(2);
-    // ---- d = DPi(v) dy, per-cone scalars (dv holds dy: transformed in place)
-    for (int i = tid; i < z + T.l; i += NTHR) { if (rkind[i] != RK_EQ) dv[i] = 0.0; }
-    for (int c = tid; c < nq; c += NTHR) {
-        const int r0 = T.qoff[c], r1 = T.qoff[c + 1];
-        if (ckind[c] == 0) { /* dv = dy */ }
-        else if (ckind[c] == 1) { for (int i = r0; i < r1; i++) dv[i] = 0.0; }
-        else {
-            const double t0 = vv[r0], nz = cinfo[5 * c + 1], h0 = dv[r0];
-            double zh = 0, zh1 = 0;
-            for (int i = r0 + 1; i < r1; i += 4) {
-                double w[4], hh[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) { const int iu = min(i + u, r1 - 1); w[u] = vv[iu]; hh[u] = dv[iu]; }
-#pragma unroll
-                for (int u = 0; u < 4; u++) { const double t = (i + u < r1) ? w[u] : 0.0; if (u & 1) zh1 = fma(t, hh[u], zh1); else zh = fma(t, hh[u], zh); }
-            }
-            zh += zh1;
-            const double i2n = 1.0 / (2 * nz), cz = t0 * zh / (nz * nz);
-            const double d0 = (nz * h0 + zh) * i2n;
-            double zd = 0, zd1 = 0;
-            for (int i = r0 + 1; i < r1; i += 4) {
-                double w[4], hh[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) { const int iu = min(i + u, r1 - 1); w[u] = vv[iu]; hh[u] = dv[iu]; }
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    if (i + u < r1) {
-                        const double di = (w[u] * h0 + (t0 + nz) * hh[u] - w[u] * cz) * i2n;
-                        dv[i + u] = di;
-                        if (u & 1) zd1 = fma(w[u], di, zd1); else zd = fma(w[u], di, zd);
-                    }
-                }
-            }
-            dv[r0] = d0;
-            zd = (zd + zd1) / nz;
-            cinfo[5 * c + 2] = (d0 + zd) * M_SQRT1_2;   // e_y . d
-            cinfo[5 * c + 3] = (d0 - zd) * M_SQRT1_2;   // e_s . d
-        }
-    }
-    __syncthreads();
-    // ---- a_z = A_z^T z-hat for boundary cones  (a_y = (a_0 + a_z) / sqrt 2,  a_s = (a_0 - a_z) / sqrt 2)
-    for (int idx = tid; idx < nq * n; idx += NTHR) {
-        const int c = idx / n, j = idx - c * n;
-        if (ckind[c] != 2) continue;
-        const int r0 = T.qoff[c], r1 = T.qoff[c + 1];
-        const double inz = 1.0 / cinfo[5 * c + 1];
-        double a = 0, a1 = 0;
-        for (int i = r0 + 1; i < r1; i += 4) {
-            double av[4], wv[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) { const int iu = min(i + u, r1 - 1); av[u] = A[iu * lda + j]; wv[u] = vv[iu]; }
-#pragma unroll
-            for (int u = 0; u < 4; u++) { const double w = (i + u < r1) ? wv[u] : 0.0; if (u & 1) a1 = fma(av[u], w, a1); else a = fma(av[u], w, a); }
-        }
-        az[c * npad + j] = (a + a1) * inz;
-    }
-    __syncthreads();
     // ---- f[j] = dx[j] + sum_c [ a_s (e_s.d) + (A_c^T d - a_y (e_y.d) - a_s (e_s.d)) / (1 - lam) ]     (4 lanes per column, fixed summation order)
     for (int j0 = 0; j0 < n; j0 += NTHR / 4) {
         const int j = j0 + (tid >> 2), part = tid & 3;
@@ -299,36 +277,87 @@ k_backward_ns(DevT T, const double *__restrict__ Avals, const double *__restrict
     //      column n = the right-hand side); per pivot the owner of the row finds the pivot column (DPP butterfly on |value| keys), publishes the scaled row, and
     //      after ONE barrier every wave updates its rows (multipliers by v_readlane from the pivot column's lane).  The pivot column keeps the multipliers and is
     //      carried through the later steps like any other column: it ends as column e of B_1^-1 (in-place Gauss-Jordan inversion), which mu needs.
-    {
+    constexpr int NR1 = 16;          // equality rows one wave holds in registers (single-wave elimination: no barrier, no LDS traffic per pivot)
+    if (NSL == 1 && neq <= NR1) {
+        // Few equalities (the common case: ~9 at the metric configuration): wave 0 keeps ALL rows in registers and runs the whole elimination alone -- per pivot a
+        // DPP butterfly, one reciprocal and a v_readlane + FMA per row, nothing else; the other waves wait at the barrier behind it.
+        if (wave == 0) {
+            double c1[NR1], rt1[NR1];
+            static_for<NR1>([&](auto kc) {
+                constexpr int kk = decltype(kc)::value;
+                const double *ptr = sm + (kk < neq ? erow[kk < neq ? kk : 0] : 0);
+                const double v = (kk < neq && lane < n) ? ptr[lane < n ? lane : 0] : 0.0;
+                c1[kk] = (kk < neq && lane == n) ? dB[kk < neq ? kk : 0] : v;
+                rt1[kk] = fabs(v);
+            });
+            static_for<NR1>([&](auto kc) {
+                constexpr int kk = decltype(kc)::value;
+                if (kk < neq) { const double rmax = wave_reduce_dpp<true>(rt1[kk]); rt1[kk] = CE_RANK_TOL * (rmax > 0 ? rmax : 1.0); }      // (uniform)
+            });
+            bool cfr = true;
+            static_for<NR1>([&](auto ec) {
+                constexpr int e = decltype(ec)::value;
+                if (e < neq) {          // (uniform)
+                    const double rv = c1[e];
+                    const double key = __hiloint2double(__double2hiint(rv) & 0x7fffffff, (__double2loint(rv) & ~0xFF) | (255 - lane));
+                    const double best = wave_reduce_dpp<true>((lane < n && cfr) ? key : 0.0);
+                    const int jb = 255 - (__double2loint(best) & 0xFF);
+                    const bool ok = best >= rt1[e] && jb < n;
+                    if (ok) {
+                        const double pv = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(rv), jb), __builtin_amdgcn_readlane(__double2loint(rv), jb));
+                        double inv = __builtin_amdgcn_rcp(pv);
+                        inv = fma(fma(-pv, inv, 1.0), inv, inv);
+                        inv = fma(fma(-pv, inv, 1.0), inv, inv);
+                        const double re = rv * inv;
+                        static_for<NR1>([&](auto ic) {
+                            constexpr int i = decltype(ic)::value;
+                            if (i != e && i < neq) {
+                                const double mlt = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(c1[i]), jb), __builtin_amdgcn_readlane(__double2loint(c1[i]), jb));
+                                c1[i] = (lane == jb) ? -mlt * inv : fma(-mlt, re, c1[i]);          // the pivot column keeps the multiplier (-> column e of B_1^-1)
+                            }
+                        });
+                        c1[e] = (lane == jb) ? inv : re;
+                        cfr = cfr && lane != jb;
+                        if (lane == 0) pcol[e] = jb;
+                    } else if (lane == 0) { pcol[e] = -1; misc[2] |= 4; }          // redundant equality row: dropped (mu_e = 0), the instance is flagged
+                }
+            });
+            static_for<NR1>([&](auto kc) {
+                constexpr int kk = decltype(kc)::value;
+                if (kk < neq) { double *ptr = sm + erow[kk]; if (lane < n) ptr[lane] = c1[kk]; else if (lane == n) dB[kk] = c1[kk]; }
+            });
+            const bool fr = lane < n && cfr;
+            const unsigned long long bal = __ballot(fr);
+            if (lane < n) { if (fr) { const int f = __popcll(bal & ((1ull << lane) - 1ull)); cmap[lane] = f; fcol[f] = lane; } else cmap[lane] = -1; }
+            if (lane == 0) misc[1] = __popcll(bal);
+        }
+    } else {
         double col[NLOC][NSL];
+        double rtol[NLOC];          // rank tolerance of a row: CE_RANK_TOL x its largest entry as loaded (scale-invariant per row; a redundant row ends at rounding level of that)
         bool cfree[NSL];
-        double bmax = 0.0;
-#pragma unroll
-        for (int kk = 0; kk < NLOC; kk++) {
+        static_for<NLOC>([&](auto kc) {          // (a compile-time loop: a plain unroll of this body stayed rolled and put the rows in scratch)
+            constexpr int kk = decltype(kc)::value;
             const int e = wave + NWB * kk;
             const double *ptr = sm + (e < neq ? erow[e] : 0);
             const double de = e < neq ? dB[e] : 0.0;
+            double rmax = 0.0;
 #pragma unroll
             for (int s2 = 0; s2 < NSL; s2++) {
                 const int j = lane + 64 * s2;
                 const double v = (e < neq && j < n) ? ptr[j < n ? j : 0] : 0.0;
-                bmax = fmax(bmax, fabs(v));
+                rmax = fmax(rmax, fabs(v));
                 col[kk][s2] = (e < neq && j == n) ? de : v;
             }
-        }
+            rmax = wave_reduce_dpp<true>(rmax);
+            rtol[kk] = CE_RANK_TOL * (rmax > 0 ? rmax : 1.0);
+        });
 #pragma unroll
         for (int s2 = 0; s2 < NSL; s2++) cfree[s2] = true;
-        {
-            double r1[1] = {bmax};
-            block_reduce_n<1, NWB>(r1, 1u, red);
-            bmax = r1[0];
-        }
-        const double ptolB = CE_RANK_TOL * (bmax > 0 ? bmax : 1.0);
         for (int e = 0; e < neq; e++) {
             const int wo = e % NWB, k = e / NWB;
             double *pb = pub + (e & 1) * PUBP;
             if (wave == wo) {
-                double re[NSL];
+                double re[NSL], ptolB = 0.0;
 #pragma unroll
                 for (int s2 = 0; s2 < NSL; s2++) re[s2] = 0.0;
                 static_for<NLOC>([&](auto kc) {
@@ -336,6 +365,7 @@ k_backward_ns(DevT T, const double *__restrict__ Avals, const double *__restrict
                     if (k == kk) {
 #pragma unroll
                         for (int s2 = 0; s2 < NSL; s2++) re[s2] = col[kk][s2];
+                        ptolB = rtol[kk];
                     }
                 });
                 double best = 0.0;
@@ -351,7 +381,11 @@ k_backward_ns(DevT T, const double *__restrict__ Avals, const double *__restrict
                 const int jl = ok ? (jb & 63) : 0;
                 double pv = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(re[0]), jl), __builtin_amdgcn_readlane(__double2loint(re[0]), jl));
                 if constexpr (NSL > 1) { if (jb >= 64) pv = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(re[NSL - 1]), jl), __builtin_amdgcn_readlane(__double2loint(re[NSL - 1]), jl)); }
-                const double inv = ok ? 1.0 / pv : 0.0;
+                const double pvs = ok ? pv : 1.0;
+                double inv = __builtin_amdgcn_rcp(pvs);          // hardware seed + two Newton steps (the IEEE divide expansion sits on the path every wave waits for)
+                inv = fma(fma(-pvs, inv, 1.0), inv, inv);
+                inv = fma(fma(-pvs, inv, 1.0), inv, inv);
+                inv = ok ? inv : 0.0;
 #pragma unroll
                 for (int s2 = 0; s2 < NSL; s2++) pb[lane + 64 * s2] = re[s2] * inv;
                 if (lane == 0) {
@@ -361,12 +395,14 @@ k_backward_ns(DevT T, const double *__restrict__ Avals, const double *__restrict
                 }
             }
             __syncthreads();
-            const int jb = __builtin_amdgcn_readfirstlane(reinterpret_cast<const int *>(pb + NCOLP + 1)[0]);
-            if (jb < 0) continue;
+            // header, inverse pivot and this lane's entries of the scaled row in ONE round trip (requested together, before the header is looked at)
+            const int jbv = reinterpret_cast<const int *>(pb + NCOLP + 1)[0];
             const double inv = pb[NCOLP];
             double r[NSL];
 #pragma unroll
             for (int s2 = 0; s2 < NSL; s2++) r[s2] = pb[lane + 64 * s2];
+            const int jb = __builtin_amdgcn_readfirstlane(jbv);
+            if (jb < 0) continue;
             const int jl = jb & 63;
             static_for<NLOC>([&](auto kc) {
                 constexpr int kk = decltype(kc)::value;
@@ -387,15 +423,15 @@ k_backward_ns(DevT T, const double *__restrict__ Avals, const double *__restrict
             for (int s2 = 0; s2 < NSL; s2++) if (lane + 64 * s2 == jb) cfree[s2] = false;
         }
         // rows back to LDS (in place: R in the free columns, B_1^-1 in the pivot columns), d~ -> dB
-#pragma unroll
-        for (int kk = 0; kk < NLOC; kk++) {
+        static_for<NLOC>([&](auto kc) {
+            constexpr int kk = decltype(kc)::value;
             const int e = wave + NWB * kk;
             if (e < neq) {
                 double *ptr = sm + erow[e];
 #pragma unroll
                 for (int s2 = 0; s2 < NSL; s2++) { const int j = lane + 64 * s2; if (j < n) ptr[j] = col[kk][s2]; else if (j == n) dB[e] = col[kk][s2]; }
             }
-        }
+        });
         if (wave == 0) {          // free columns numbered in increasing order (cfree is the same in every wave)
             int basef = 0;
 #pragma unroll
@@ -424,6 +460,7 @@ k_backward_ns(DevT T, const double *__restrict__ Avals, const double *__restrict
         if (wave < NCT) {
             const int colj = 16 * wave + lc;
             for (int g0 = 0; g0 <= KW; g0 += 64) {
+                const int ng = min(4, (KW - g0 + 16) >> 4);          // row groups of this pass that hold a list row <= KW (uniform)
                 v4d tacc[4];
                 int wr[4];
 #pragma unroll
@@ -437,17 +474,31 @@ k_backward_ns(DevT T, const double *__restrict__ Avals, const double *__restrict
 #pragma unroll
                     for (int g = 0; g < 4; g++) aop[g] = sm[wr[g] + pcs];
 #pragma unroll
-                    for (int g = 0; g < 4; g++) tacc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(pc >= 0 ? aop[g] : 0.0, bop, tacc[g], 0, 0, 0);
+                    for (int g = 0; g < 4; g++) if (g < ng) tacc[g] = __builtin_amdgcn_mfma_f64_16x16x4f64(pc >= 0 ? aop[g] : 0.0, bop, tacc[g], 0, 0, 0);
                 }
-                const bool wcol = colj < n && cmap[colj < n ? colj : 0] >= 0;
+                // write-back in three fenced stages (list offsets, old values, stores): sixteen dependent read-modify-writes in series otherwise
+                const bool wcol = colj < n && cmap[colj < n ? colj : 0] >= 0, tcol = colj == n;
+                int wq[4][4];
+#pragma unroll
+                for (int g = 0; g < 4; g++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) wq[g][r] = wrow[min(g0 + 16 * g + lg + 4 * r, KW4 - 1)];
+                __builtin_amdgcn_sched_barrier(0);
+                double ov[4][4];
+                const int cj = colj < n ? colj : 0;
+#pragma unroll
+                for (int g = 0; g < 4; g++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) ov[g][r] = sm[wq[g][r] + cj];
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int g = 0; g < 4; g++)
 #pragma unroll
                     for (int r = 0; r < 4; r++) {
                         const int q = g0 + 16 * g + lg + 4 * r;
                         if (q <= KW) {
-                            if (wcol) sm[wrow[q] + colj] -= tacc[g][r];
-                            else if (colj == n && q < KW) tvec[q] = tacc[g][r];
+                            if (wcol) sm[wq[g][r] + cj] = ov[g][r] - tacc[g][r];
+                            else if (tcol && q < KW) tvec[q] = tacc[g][r];
                         }
                     }
             }
@@ -460,7 +511,6 @@ k_backward_ns(DevT T, const double *__restrict__ Avals, const double *__restrict
     v4d acc[NTILE];
 #pragma unroll
     for (int J = 0; J < NTILE; J++) acc[J] = v4d{0.0, 0.0, 0.0, 0.0};
-    double dmax = 0.0;
     const int jmax = (cr >> 4) + 1;                     // tiles / strips that hold a row or column <= cr
     if (wave < jmax) {
         int oc[NTILE]; double msk[NTILE], tsel[NTILE];      // per tile: original column of this lane's reduced column (0 when masked), 0/1 mask, -1 on the right-hand-side column
@@ -471,6 +521,10 @@ k_backward_ns(DevT T, const double *__restrict__ Avals, const double *__restrict
         }
         int ocw = 0; double mskw = 0.0, tselw = 0.0;
         static_for<NTILE>([&](auto Jc) { constexpr int J = decltype(Jc)::value; if (wave == J) { ocw = oc[J]; mskw = msk[J]; tselw = tsel[J]; } });
+        double frhs[4];          // (Z^T f)[row] of this lane's four strip rows: requested now, added behind the loop
+#pragma unroll
+        for (int r = 0; r < 4; r++) { const int rowi = 16 * wave + lg + 4 * r; frhs[r] = fvec[fcol[rowi < nf ? rowi : 0]]; }
+        NS_SUB(0);
         // stage A (list entry) of steps 0, 1; stage B (row values) of step 0
         int wrA = wrow[lg], wrA2 = wrow[min(4 + lg, KW4 - 1)];
         double wA = wgt[lg], tA = tvec[lg], wA2 = wgt[min(4 + lg, KW4 - 1)], tA2 = tvec[min(4 + lg, KW4 - 1)];
@@ -492,23 +546,32 @@ k_backward_ns(DevT T, const double *__restrict__ Avals, const double *__restrict
 #pragma unroll
             for (int J = 0; J < NTILE; J++) if (J < jmax) acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[J], acc[J], 0, 0, 0);
         }
-        // + Z^T f on the right-hand-side column; identity on the padding rows of the last block; the largest diagonal entry (rank tolerance)
+        NS_SUB(1);
+        // + Z^T f on the right-hand-side column; identity on the padding rows of the last block
         static_for<NTILE>([&](auto Jc) {
             constexpr int J = decltype(Jc)::value;
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
+            static_for<4>([&](auto rc) {          // (compile-time indices into the accumulators: a rolled loop here puts them in scratch)
+                constexpr int r = decltype(rc)::value;
                 const int rowi = 16 * wave + lg + 4 * r;
-                if (16 * J + lc == cr && rowi < nf) acc[J][r] += fvec[fcol[rowi]];
-                if (wave == J && lc == lg + 4 * r) { if (rowi < nf) dmax = fmax(dmax, acc[J][r]); else if (rowi < cr) acc[J][r] = 1.0; }
+                const double add = (16 * J + lc == cr && rowi < nf) ? frhs[r] : 0.0;
+                const bool pad = wave == J && lc == lg + 4 * r && rowi >= nf && rowi < cr;
+                acc[J][r] = pad ? 1.0 : acc[J][r] + add;
+            });
+        });
+    }
+    NS_SUB(2);
+    __syncthreads();          // the Gram's reads of a_z are complete: the union region becomes the sweep's row buffers
+    // the ORIGINAL diagonal of the reduced Hessian -> the gaps behind the buffer rows (entry k at row k >> 4 of the buffers, 16 NTILE + (k & 15)); rows 0 .. 3 -> buffer 0
+    if (wave < NTILE) {
+        static_for<NTILE>([&](auto Jc) {
+            constexpr int J = decltype(Jc)::value;
+            if (wave == J) {
+                double dsel = 0.0;
+                static_for<4>([&](auto rc) { constexpr int r = decltype(rc)::value; dsel = (lc == lg + 4 * r) ? acc[J][r] : dsel; });
+                if ((lc & 3) == lg) Rbuf[J * LDP + 16 * NTILE + lc] = dsel;          // (the diagonal lanes: lc = lg + 4 r)
             }
         });
     }
-    {
-        double r1[1] = {dmax};
-        block_reduce_n<1, NWB>(r1, 1u, red);          // (its barriers also end the Gram's reads of a_z: the union region becomes the sweep's row buffers)
-        dmax = r1[0];
-    }
-    const double ptolH = CE_RANK_TOL * dmax;
     NS_STAMP(6);
     // ---- 4. blocked sweep on the matrix cores (ce_forward_v2.h, S inversion): after block b the rows K = {4b .. 4b+3} hold P R, the others S - C P R;
     //      the right-hand-side column ends as (Z^T H Z)^-1 rhs.  A pivot that is not positive against the tolerance drops its variable (pivot inverse 0) and flags.
@@ -539,6 +602,11 @@ k_backward_ns(DevT T, const double *__restrict__ Avals, const double *__restrict
                     const double2 v0 = *reinterpret_cast<const double2 *>(Rb + q * LDP + k0), v1 = *reinterpret_cast<const double2 *>(Rb + q * LDP + k0 + 2);
                     a[q][0] = v0.x; a[q][1] = v0.y; a[q][2] = v1.x; a[q][3] = v1.y;
                 }
+                double dg[4];          // the block's original diagonal entries (rank tolerance relative to each)
+                {
+                    const double2 d0 = *reinterpret_cast<const double2 *>(Rbuf + wo * LDP + 16 * NTILE + c0), d1 = *reinterpret_cast<const double2 *>(Rbuf + wo * LDP + 16 * NTILE + c0 + 2);
+                    dg[0] = d0.x; dg[1] = d0.y; dg[2] = d1.x; dg[3] = d1.y;
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 double e[4];
 #pragma unroll
@@ -547,7 +615,7 @@ k_backward_ns(DevT T, const double *__restrict__ Avals, const double *__restrict
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const double pv = a[k][k];
-                    const bool ok = pv > ptolH;
+                    const bool ok = pv > CE_RANK_TOL * dg[k];
                     tiny |= !ok;
                     const double pvs = ok ? pv : 1.0;
                     double pi_ = __builtin_amdgcn_rcp(pvs);
@@ -599,8 +667,7 @@ k_backward_ns(DevT T, const double *__restrict__ Avals, const double *__restrict
     if (wave < NTILE) {
         static_for<NTILE>([&](auto Jc) {
             constexpr int J = decltype(Jc)::value;
-#pragma unroll
-            for (int r = 0; r < 4; r++) { const int rowi = 16 * wave + lg + 4 * r; if (16 * J + lc == cr && rowi < nf) rx[fcol[rowi]] = acc[J][r]; }
+            static_for<4>([&](auto rc) { constexpr int r = decltype(rc)::value; const int rowi = 16 * wave + lg + 4 * r; if (16 * J + lc == cr && rowi < nf) rx[fcol[rowi]] = acc[J][r]; });
         });
     }
     __syncthreads();
@@ -721,5 +788,6 @@ k_backward_ns(DevT T, const double *__restrict__ Avals, const double *__restrict
     if (tid < 10) dAo[(size_t)inst * T.nnz_aug + tid] = (double)(tstamp[tid + 1] - tstamp[tid]);
     if (tid == 10) dAo[(size_t)inst * T.nnz_aug + 10] = (double)(n + neq);
     if (tid == 11) dAo[(size_t)inst * T.nnz_aug + 11] = (double)nf;
+    if (tid == 12) { dAo[(size_t)inst * T.nnz_aug + 12] = (double)(tsub[0] - tstamp[5]); dAo[(size_t)inst * T.nnz_aug + 13] = (double)(tsub[1] - tsub[0]); dAo[(size_t)inst * T.nnz_aug + 14] = (double)(tsub[2] - tsub[1]); dAo[(size_t)inst * T.nnz_aug + 15] = (double)KW; }
 #endif
 }

@@ -17,9 +17,10 @@ dx = torch.ones_like(x); dy = torch.zeros_like(y)
 for _ in range(2):
     dA, dq, adj = eng.vjp(A_bm, x, y, s, dx, dy, path="per_instance", q_eval=q_t)
 torch.cuda.synchronize()
-t = dA.t()[:, :12].cpu().numpy()
-names = ["load", "classify + numbering", "d, a_z, f, lists", "row elimination of B (one wave)", "null-space transform of the rows", "reduced Hessian on the matrix cores", "sweep", "x, q, g, mu", "r_y", "outputs"]
+t = dA.t()[:, :16].cpu().numpy()
+names = ["load", "classify + d (16 lanes per cone)", "a_z, numbering, f, lists", "row elimination of B (registers, one barrier per pivot)", "null-space transform of the rows", "reduced Hessian on the matrix cores", "sweep", "x, q, g, mu", "r_y", "outputs"]
 for k, nm in enumerate(names):
     print(f"{nm:40s} mean {t[:, k].mean():12.1f}  max {t[:, k].max():12.1f}")
 print(f"{'sum of phases':40s} {t[:, :10].sum(1).mean():12.1f}")
 print("mean NK = n + neq %.1f, mean nf %.1f (sweep blocks %.1f)" % (t[:, 10].mean(), t[:, 11].mean(), np.ceil(t[:, 11] / 4).mean()))
+print("reduced Hessian, thread 0: set-up (columns, masks, Z^T f requests) %.0f, the loop %.0f (%.1f list rows = %.1f steps of four), epilogue %.0f" % (t[:, 12].mean(), t[:, 13].mean(), t[:, 15].mean(), np.ceil((t[:, 15] + 1) / 4).mean(), t[:, 14].mean()))
