@@ -629,11 +629,34 @@ def _fold_adjoint(eng, entry):
     eng._adj_total += bs
 
 
-def _report_flagged_adjoints(eng):
-    """forward side: every backward enqueued before this forward's status summary has finished by the time that summary is read"""
+def _report_previous_async(eng):
+    """raise_on_error=False: the outcome of the PREVIOUS asynchronous forward, if its summary has landed in the pinned slot (never waits)"""
+    bs = getattr(eng, "_async_pending", None)
+    arr = getattr(eng, "_summary_np", None)
+    if not bs or arr is None or arr[0, 3] == 0:
+        return
+    eng._async_pending = None
+    mn, n_inacc = int(arr[0, 0]), int(arr[0, 1])
+    if mn < 0:
+        warnings.warn(f"MI355 solver: instances of the previous forward call (batch of {bs}) failed (worst status {STATUS_NAMES.get(mn, mn)}); their rows were returned as NaN "
+                      "with zero gradients (raise_on_error=False); info['status'] of that call says which")
+    if n_inacc:
+        warnings.warn("Solved/Inaccurate.")
+
+
+def _report_flagged_adjoints(eng, block: bool = True):
+    """forward side: every backward enqueued before this forward's status summary has finished by the time that summary is read
+    (block=False -- the asynchronous forward of raise_on_error=False: only the slots whose ready flag is already set are folded)"""
     pend = getattr(eng, "_adj_pending", None)
     if not pend and not getattr(eng, "_adj_total", 0):
         return
+    if not block:
+        arr = getattr(eng, "_summary_np", None)
+        ready = [k for k, (sl, _) in enumerate(pend or []) if arr is not None and arr[sl, 3] != 0]
+        for k in reversed(ready):
+            _fold_adjoint(eng, pend.pop(k))
+        if pend:
+            return
     while pend:
         _fold_adjoint(eng, pend.pop())
     nbad, bs = eng._adj_count, eng._adj_total
@@ -723,6 +746,9 @@ class _ConeLayer(torch.autograd.Function):
             # The reference raises from forward() when an instance fails (diffcp_if.py:365-372), so the host has to learn the outcome here: one tiny
             # reduction kernel + 8 bytes into pinned memory behind the solve (ce_status_summary) and ONE stream synchronisation -- not the status
             # vector through a pageable copy plus host-side reductions.  Per-instance inspection happens only on the failure path.
+            raise_on = bool(merged_args.get("raise_on_error", True))
+            if not raise_on:
+                _report_previous_async(eng)          # (what the previous asynchronous forward left in the pinned slot, if it has landed: warnings only, never a wait)
             if status.numel():
                 eng.enqueue_summary(status, 0)
             # everything the host can prepare without knowing the outcome happens BEFORE the one synchronisation of this call: the GPU is idle from the
@@ -734,6 +760,18 @@ class _ConeLayer(torch.autograd.Function):
             info = dict(iters=iters, status=status, resid=resid, acceleration=getattr(eng, "last_acceleration", False), adjoint={"status": None, "path": path})
             lsqr = lsqr_rule(merged_args, eng.n, eng.m)
             saved = (eng, A_bm, x.detach(), y.detach(), s, batch_minor_in, P_bm, path, None, lsqr, q_dev if P_bm is None else None) if needs_grad else None
+            if status.numel() and not raise_on:
+                # raise_on_error=False: the caller has waived the reference's "raise from forward()" contract, so NOTHING forces a host round trip here.  Failed
+                # instances are masked ON THE DEVICE (two small elementwise launches, unconditionally), the outcome summary lands in pinned memory behind the
+                # solve and is reported -- as warnings -- by the next call that finds it there.  The GPU never waits for the host between the forward and the
+                # adjoint kernel (bench.py `async_forward`: the host gap of the step disappears).
+                failed = (status < 0)
+                nanv = float("nan")
+                x = torch.where(failed[:, None], nanv, x); y = torch.where(failed[:, None], nanv, y)
+                eng._async_pending = batch_size
+                saved = (eng, A_bm, x.detach(), y.detach(), s, batch_minor_in, P_bm, path, failed, lsqr, q_dev if P_bm is None else None) if needs_grad else None
+                _report_flagged_adjoints(eng, block=False)
+                return x.to(in_device), y.to(in_device), info, (saved, batch_size, originally_unbatched, in_device)
             if status.numel():
                 summ = eng.read_summaries()
                 min_status, n_inaccurate = int(summ[0][0]), int(summ[0][1])
@@ -741,24 +779,14 @@ class _ConeLayer(torch.autograd.Function):
             else:
                 min_status, n_inaccurate = 1, 0
         any_failed = min_status < 0
-        if any_failed and merged_args.get("raise_on_error", True):
+        if any_failed and raise_on:
             st = status.cpu()
             bad = int((st < 0).nonzero()[0])
             raise SolverError(f"Solver mi355 returned status {STATUS_NAMES.get(int(st[bad]), int(st[bad]))} "
                               f"for instance {bad} ({int((st < 0).sum())} of {batch_size} instances failed)")
         if n_inaccurate:
             warnings.warn("Solved/Inaccurate.")
-        failed = None
-        if any_failed:
-            # raise_on_error=False: per-instance failure masking.  Rows of failed instances (infeasible / unbounded /
-            # failed) come back as NaN -- never a half-converged iterate -- and their parameter gradients as zero (backward), so that one
-            # bad instance of a training batch neither poisons nor silently steers the others.  info["status"] says which.
-            failed = (status < 0)
-            x = torch.where(failed[:, None], torch.full_like(x, float("nan")), x)
-            y = torch.where(failed[:, None], torch.full_like(y, float("nan")), y)
-            primal = x.to(in_device)
-            dual = y.to(in_device)
-            saved = (eng, A_bm, x.detach(), y.detach(), s, batch_minor_in, P_bm, path, failed, lsqr, q_dev if P_bm is None else None) if needs_grad else None
+        # (raise_on_error=False never reaches this point: its failure masking happens on the device, above)
         # x / y are handed back as `primal` / `dual` (same objects when the input lives on the engine's device), and autograd
         # attaches this node to them: keeping the SAME objects on the node would form a reference cycle (node -> saved ->
         # primal -> grad_fn -> node) that only the cyclic GC breaks, i.e. 167 MB buffers pile up for many steps and the
@@ -794,10 +822,7 @@ class _ConeLayer(torch.autograd.Function):
                 dP = dP_bm.t().to(in_device)
             else:
                 dA, dq, adj = eng.vjp(A_bm, x, y, s, dx, dy, batch_minor_out=batch_minor_in, path=path, lsqr=lsqr, q_eval=q_saved)
-        if failed is not None:
-            dA = torch.where(failed[None, :], torch.zeros_like(dA), dA); dq = torch.where(failed[None, :], torch.zeros_like(dq), dq)
-            if P_bm is not None:
-                dP = torch.where(failed[None, :].to(dP.device), torch.zeros_like(dP), dP)
+        # (masked instances: zero cotangents at a zero point give exactly zero dA / dq / dP rows from every adjoint kernel -- r = 0 --, no pass over the gradients needed)
         ctx.adj_status = adj
         if isinstance(ctx.info, dict) and isinstance(ctx.info.get("adjoint"), dict):
             ctx.info["adjoint"]["status"] = adj

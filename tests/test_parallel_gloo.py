@@ -197,3 +197,19 @@ def test_bench_dry_run_ranks_exercises_the_self_spawn_plumbing():
     rec = json.loads(lines[0])
     assert rec["dry_run"] and rec["ranks"] == 2 and rec["gather_ok"] and rec["backend"] == "gloo" and rec["master_addr"] == "127.0.0.1"
     assert rec["rotating_batches"] == 4          # every rank visits the same slot of its K rotating batches at the same step (gather_ok checks the gathered sums per slot)
+
+
+@pytest.mark.parametrize("scaling,config,batch,want_sizes", [("weak", "C3", 4096, [64] * 8), ("strong", "C5", 100, [13, 13, 13, 13, 12, 12, 12, 12])])      # (8 ranks x one torch import each: two cases keep the CPU suite short)
+def test_bench_dry_run_eight_ranks_in_both_scaling_modes(scaling, config, batch, want_sizes):
+    """`bench.py --scaling strong|weak --config C3|C5` under ranks.  BASELINE.json's "SOCP n=100, batch=4096, 1->8 GPU batch shard" is
+    `--config C3 --scaling strong`, "portfolio n=500, batch=16384 sharded across 8 GPUs" is `--config C5 --batch 16384 --scaling strong`; eight CPU ranks over gloo
+    run the script's own launch / shard / gather / timing plumbing (ragged shards included: 100 instances over 8 ranks).  No RCCL run with more than one rank exists."""
+    import json
+    import subprocess
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run-ranks", "8", "--steps", "3", "--rotate", "2", "--scaling", scaling, "--config", config, "--batch", str(batch)],
+                         capture_output=True, text=True, timeout=600, env={**{k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}, "OMP_NUM_THREADS": "1"})
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, (out.stdout[-400:], out.stderr[-800:])
+    rec = json.loads(lines[0])
+    assert rec["dry_run"] and rec["ranks"] == 8 and rec["gather_ok"] and rec["scaling"] == scaling and rec["config"] == config
+    assert rec["shard_sizes"] == want_sizes
