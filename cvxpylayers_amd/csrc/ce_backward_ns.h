@@ -102,6 +102,7 @@ k_backward_ns(DevT T, const double *__restrict__ Avals, const double *__restrict
 
 #ifdef CE_TIMING
     __shared__ long long tstamp[16], tsub[16];
+    if (threadIdx.x < 16) tsub[threadIdx.x] = 0;
 #endif
     NS_STAMP(0);
     // ---- load: the instance's values scattered into dense solver form A = -A_cvx (b is not needed: r_tau is pinned)
@@ -277,48 +278,78 @@ k_backward_ns(DevT T, const double *__restrict__ Avals, const double *__restrict
     //      column n = the right-hand side); per pivot the owner of the row finds the pivot column (DPP butterfly on |value| keys), publishes the scaled row, and
     //      after ONE barrier every wave updates its rows (multipliers by v_readlane from the pivot column's lane).  The pivot column keeps the multipliers and is
     //      carried through the later steps like any other column: it ends as column e of B_1^-1 (in-place Gauss-Jordan inversion), which mu needs.
-    constexpr int NR1 = 16;          // equality rows one wave holds in registers (single-wave elimination: no barrier, no LDS traffic per pivot)
+    constexpr int NR1 = 24;          // equality rows one wave holds in registers (single-wave elimination: no barrier, no LDS traffic per pivot)
     if (NSL == 1 && neq <= NR1) {
-        // Few equalities (the common case: ~9 at the metric configuration): wave 0 keeps ALL rows in registers and runs the whole elimination alone -- per pivot a
-        // DPP butterfly, one reciprocal and a v_readlane + FMA per row, nothing else; the other waves wait at the barrier behind it.
-        if (wave == 0) {
-            double c1[NR1], rt1[NR1];
+        // Up to 24 equalities (metric configuration: ~17, i.e. ~9 active bounds + one e_y row per boundary cone): wave 0 keeps ALL rows in registers and runs the
+        // whole elimination alone -- per pivot a DPP butterfly, one reciprocal and two v_readlane + one FMA per row; the other waves wait at the barrier behind it.
+        // Rows are updated in groups of eight behind ONE uniform test (rows past neq hold zeros and are harmless to update): a scalar branch per row made a pivot
+        // cost 2.8 k cycles, mostly branch latency.
+        if (wave == 0) {          // (spreading this phase over the SIMDs by hardware wave slot was measured: no change -- it is bound by its own dependent chain, ~1.1 k cycles per pivot)
+            double c1[NR1]; float rt1[NR1];
             static_for<NR1>([&](auto kc) {
                 constexpr int kk = decltype(kc)::value;
                 const double *ptr = sm + (kk < neq ? erow[kk < neq ? kk : 0] : 0);
                 const double v = (kk < neq && lane < n) ? ptr[lane < n ? lane : 0] : 0.0;
                 c1[kk] = (kk < neq && lane == n) ? dB[kk < neq ? kk : 0] : v;
-                rt1[kk] = fabs(v);
+                rt1[kk] = (float)fabs(v);
             });
-            static_for<NR1>([&](auto kc) {
-                constexpr int kk = decltype(kc)::value;
-                if (kk < neq) { const double rmax = wave_reduce_dpp<true>(rt1[kk]); rt1[kk] = CE_RANK_TOL * (rmax > 0 ? rmax : 1.0); }      // (uniform)
+            static_for<NR1 / 8>([&](auto gc) {          // rank tolerance of a row: CE_RANK_TOL x its largest entry as loaded (kept in single precision: a threshold)
+                constexpr int g = decltype(gc)::value;
+                if (8 * g < neq) {
+                    static_for<8>([&](auto kc) {
+                        constexpr int kk = 8 * g + decltype(kc)::value;
+                        const double rmax = wave_reduce_dpp<true>((double)rt1[kk]);
+                        rt1[kk] = (float)(CE_RANK_TOL * (rmax > 0 ? rmax : 1.0));
+                    });
+                }
             });
             bool cfr = true;
+#ifdef CE_TIMING
+            long long pacc[4] = {0, 0, 0, 0}, pt0 = __builtin_readcyclecounter();
+#define NS_PACC(k) do { const long long t1_ = __builtin_readcyclecounter(); pacc[k] += t1_ - pt0; pt0 = t1_; } while (0)
+#else
+#define NS_PACC(k) do { } while (0)
+#endif
             static_for<NR1>([&](auto ec) {
                 constexpr int e = decltype(ec)::value;
                 if (e < neq) {          // (uniform)
+                    NS_PACC(3);
                     const double rv = c1[e];
                     const double key = __hiloint2double(__double2hiint(rv) & 0x7fffffff, (__double2loint(rv) & ~0xFF) | (255 - lane));
                     const double best = wave_reduce_dpp<true>((lane < n && cfr) ? key : 0.0);
                     const int jb = 255 - (__double2loint(best) & 0xFF);
-                    const bool ok = best >= rt1[e] && jb < n;
+                    const bool ok = best >= (double)rt1[e] && jb < n;
+                    NS_PACC(0);
                     if (ok) {
                         const double pv = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(rv), jb), __builtin_amdgcn_readlane(__double2loint(rv), jb));
                         double inv = __builtin_amdgcn_rcp(pv);
                         inv = fma(fma(-pv, inv, 1.0), inv, inv);
                         inv = fma(fma(-pv, inv, 1.0), inv, inv);
-                        const double re = rv * inv;
-                        static_for<NR1>([&](auto ic) {
-                            constexpr int i = decltype(ic)::value;
-                            if (i != e && i < neq) {
-                                const double mlt = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(c1[i]), jb), __builtin_amdgcn_readlane(__double2loint(c1[i]), jb));
-                                c1[i] = (lane == jb) ? -mlt * inv : fma(-mlt, re, c1[i]);          // the pivot column keeps the multiplier (-> column e of B_1^-1)
+                        const bool isj = lane == jb;
+                        // The scaled pivot row carries 1 + 1/p (instead of 1) in the pivot column: the ONE fused update c <- c - m re of another row then leaves
+                        // m - m (1 + 1/p) = -m / p there -- the multiplier the in-place inverse keeps in that column -- with no blend per row (two v_cndmask and a
+                        // multiply per row and pivot were half of the elimination's instructions).  Error of that entry: |m| (1 + |1/p|) ulp, i.e. relative
+                        // (1 + |p|) ulp -- p is the largest entry of its row.
+                        const double re = isj ? 1.0 + inv : rv * inv;
+                        NS_PACC(1);
+                        static_for<NR1 / 8>([&](auto gc) {
+                            constexpr int g = decltype(gc)::value;
+                            if (8 * g < neq) {          // (uniform; one test per eight rows)
+                                double ml[8];
+                                static_for<8>([&](auto kc) {          // the eight multipliers first (v_readlane pairs back to back), then the eight updates
+                                    constexpr int i = 8 * g + decltype(kc)::value;
+                                    ml[decltype(kc)::value] = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(c1[i]), jb), __builtin_amdgcn_readlane(__double2loint(c1[i]), jb));
+                                });
+                                static_for<8>([&](auto kc) {
+                                    constexpr int i = 8 * g + decltype(kc)::value;
+                                    if constexpr (i != e) c1[i] = fma(-ml[decltype(kc)::value], re, c1[i]);          // (the pivot column keeps the multiplier -> column e of B_1^-1)
+                                });
                             }
                         });
-                        c1[e] = (lane == jb) ? inv : re;
-                        cfr = cfr && lane != jb;
+                        c1[e] = isj ? inv : re;          // (the pivot row itself: 1/p in the pivot column)
+                        cfr = cfr && !isj;
                         if (lane == 0) pcol[e] = jb;
+                        NS_PACC(2);
                     } else if (lane == 0) { pcol[e] = -1; misc[2] |= 4; }          // redundant equality row: dropped (mu_e = 0), the instance is flagged
                 }
             });
@@ -330,6 +361,9 @@ k_backward_ns(DevT T, const double *__restrict__ Avals, const double *__restrict
             const unsigned long long bal = __ballot(fr);
             if (lane < n) { if (fr) { const int f = __popcll(bal & ((1ull << lane) - 1ull)); cmap[lane] = f; fcol[f] = lane; } else cmap[lane] = -1; }
             if (lane == 0) misc[1] = __popcll(bal);
+#ifdef CE_TIMING
+            if (lane == 0) for (int k = 0; k < 4; k++) tsub[8 + k] = pacc[k];
+#endif
         }
     } else {
         double col[NLOC][NSL];
@@ -387,7 +421,7 @@ k_backward_ns(DevT T, const double *__restrict__ Avals, const double *__restrict
                 inv = fma(fma(-pvs, inv, 1.0), inv, inv);
                 inv = ok ? inv : 0.0;
 #pragma unroll
-                for (int s2 = 0; s2 < NSL; s2++) pb[lane + 64 * s2] = re[s2] * inv;
+                for (int s2 = 0; s2 < NSL; s2++) pb[lane + 64 * s2] = (lane + 64 * s2 == jb) ? 1.0 + inv : re[s2] * inv;      // (1 + 1/p in the pivot column: see the single-wave path)
                 if (lane == 0) {
                     pb[NCOLP] = inv; reinterpret_cast<int *>(pb + NCOLP + 1)[0] = ok ? jb : -1;
                     pcol[e] = ok ? jb : -1;
@@ -404,19 +438,23 @@ k_backward_ns(DevT T, const double *__restrict__ Avals, const double *__restrict
             const int jb = __builtin_amdgcn_readfirstlane(jbv);
             if (jb < 0) continue;
             const int jl = jb & 63;
-            static_for<NLOC>([&](auto kc) {
-                constexpr int kk = decltype(kc)::value;
-                const int ei = wave + NWB * kk;
-                if (ei < neq) {          // (uniform)
-                    double mlt = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(col[kk][0]), jl), __builtin_amdgcn_readlane(__double2loint(col[kk][0]), jl));
-                    if constexpr (NSL > 1) { if (jb >= 64) mlt = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(col[kk][NSL - 1]), jl), __builtin_amdgcn_readlane(__double2loint(col[kk][NSL - 1]), jl)); }
-                    const bool isp = ei == e;
+            static_for<(NLOC + 3) / 4>([&](auto gc) {
+                constexpr int g = decltype(gc)::value;
+                if (NWB * 4 * g < neq) {          // (uniform; one test per four local rows: rows past neq hold zeros and are harmless to update)
+                    static_for<4>([&](auto kc) {
+                        constexpr int kk = 4 * g + decltype(kc)::value;
+                        if constexpr (kk < NLOC) {
+                            const int ei = wave + NWB * kk;
+                            double mlt = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(col[kk][0]), jl), __builtin_amdgcn_readlane(__double2loint(col[kk][0]), jl));
+                            if constexpr (NSL > 1) { if (jb >= 64) mlt = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(col[kk][NSL - 1]), jl), __builtin_amdgcn_readlane(__double2loint(col[kk][NSL - 1]), jl)); }
+                            const bool isp = ei == e;          // (uniform: the pivot row itself becomes the scaled row, 1/p in the pivot column)
 #pragma unroll
-                    for (int s2 = 0; s2 < NSL; s2++) {
-                        const int j = lane + 64 * s2;
-                        const double upd = isp ? r[s2] : fma(-mlt, r[s2], col[kk][s2]);
-                        col[kk][s2] = (j == jb) ? (isp ? inv : -mlt * inv) : upd;          // the pivot column keeps the multiplier (-> column e of B_1^-1)
-                    }
+                            for (int s2 = 0; s2 < NSL; s2++) {
+                                const int j = lane + 64 * s2;
+                                col[kk][s2] = isp ? ((j == jb) ? inv : r[s2]) : fma(-mlt, r[s2], col[kk][s2]);          // the pivot column keeps the multiplier (-> column e of B_1^-1)
+                            }
+                        }
+                    });
                 }
             });
 #pragma unroll
@@ -789,5 +827,6 @@ k_backward_ns(DevT T, const double *__restrict__ Avals, const double *__restrict
     if (tid == 10) dAo[(size_t)inst * T.nnz_aug + 10] = (double)(n + neq);
     if (tid == 11) dAo[(size_t)inst * T.nnz_aug + 11] = (double)nf;
     if (tid == 12) { dAo[(size_t)inst * T.nnz_aug + 12] = (double)(tsub[0] - tstamp[5]); dAo[(size_t)inst * T.nnz_aug + 13] = (double)(tsub[1] - tsub[0]); dAo[(size_t)inst * T.nnz_aug + 14] = (double)(tsub[2] - tsub[1]); dAo[(size_t)inst * T.nnz_aug + 15] = (double)KW; }
+    if (tid >= 16 && tid < 20) dAo[(size_t)inst * T.nnz_aug + tid] = (double)tsub[8 + tid - 16];
 #endif
 }
