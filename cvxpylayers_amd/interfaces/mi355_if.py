@@ -612,6 +612,9 @@ def _note_adjoint_flags(eng, adj, bs):
     eng._adj_seq += 1
     for k in [k for k, (sl, _) in enumerate(pend) if sl == slot]:          # written two backward calls ago: long complete, but make sure before it is overwritten
         if getattr(eng, "_summary_np", None) is not None and eng._summary_np[slot, 3] == 0:
+            if getattr(eng, "_async_mode", False):      # asynchronous forward (raise_on_error=False): the host runs ahead of the device and must never wait -- this call's flags go unreported
+                eng._adj_seq -= 1
+                return
             torch.cuda.current_stream(eng.device).synchronize()
         _fold_adjoint(eng, pend.pop(k))
     eng.enqueue_summary(adj, slot)
@@ -747,6 +750,7 @@ class _ConeLayer(torch.autograd.Function):
             # reduction kernel + 8 bytes into pinned memory behind the solve (ce_status_summary) and ONE stream synchronisation -- not the status
             # vector through a pageable copy plus host-side reductions.  Per-instance inspection happens only on the failure path.
             raise_on = bool(merged_args.get("raise_on_error", True))
+            eng._async_mode = not raise_on
             if not raise_on:
                 _report_previous_async(eng)          # (what the previous asynchronous forward left in the pinned slot, if it has landed: warnings only, never a wait)
             if status.numel():
