@@ -17,6 +17,7 @@ def get_solver_ctx(solver, param_prob, cone_dims, data, kwargs, verbose=False):
             data.get("lower_bound") if data else None,
             data.get("upper_bound") if data else None,
             options,
+            reduced_A_mat=getattr(param_prob.reduced_A, "reduced_mat", None),          # the parameter map: constant-A is decided structurally, once (moreau_if.py:234-256)
         )
     raise RuntimeError("Unknown solver. Check if your solver is supported by CVXPYlayers")
 

@@ -348,6 +348,9 @@ class ConeEngine:
             return False
         if env != "1" and self.launch_info()["fwd_mode"] not in (1, 2):
             return False
+        known = getattr(self, "A_is_constant", None)          # structural answer of MI355_ctx (parameter map), when the layer supplied it
+        if known is not None:
+            return bool(known)
         return is_constant_A(A_bm, self.nnzA)
 
     def vjp(self, A_bm, x, y, s, dx, dy, batch_minor_out: bool = False, P_bm=None, path: str | None = None, lsqr: tuple | None = None, q_eval=None):
@@ -560,7 +563,10 @@ class MI355_ctx:
     (diffcp_if.py:105-120): constraint_structure = (indices, indptr, (m, n+1)) is the CSC structure of the
     augmented matrix [A_cvx | b_cvx]."""
 
-    def __init__(self, objective_structure, constraint_structure, dims, lower_bounds=None, upper_bounds=None, options=None):
+    def __init__(self, objective_structure, constraint_structure, dims, lower_bounds=None, upper_bounds=None, options=None, reduced_A_mat=None):
+        """reduced_A_mat (optional; the keyword MOREAU_ctx takes, moreau_if.py:159-256): the parameter map of the constraint values, (nnz_aug, P + 1) with the
+        constant column last.  When given, whether the A part is batch-invariant is decided HERE, once, from the map's structure -- rows of A entries with no
+        parameter column (the reference's PA_is_constant test, moreau_if.py:234-256, restricted to the A rows: b may vary) -- and no call compares values."""
         con_indices, con_ptr, (m, np1) = constraint_structure
         self.A_structure = (np.asarray(con_indices), np.asarray(con_ptr))
         self.A_shape = (int(m), int(np1))
@@ -570,6 +576,10 @@ class MI355_ctx:
         self.options = options or {}
         self.default_device = torch.device("cuda", 0)
         self._engines: dict[int, ConeEngine] = {}
+        self.A_is_constant = None          # None: unknown (decided per call from the values, one compare + one host sync); True / False: structural
+        if reduced_A_mat is not None:
+            nnzA = int(np.asarray(con_ptr)[int(np1) - 1])
+            self.A_is_constant = bool(reduced_A_mat[:nnzA, :-1].nnz == 0) if nnzA > 0 else True
         # Quadratic objective 1/2 x^T P x (plugins registered in SUPPORTS_QUAD_OBJ receive P_eval, _quad_form_dpp.py:32,
         # interfaces/__init__.py:35-42): handled as an epigraph SOC block over the Cholesky factor of P (see QuadEpigraph).
         self.quad = QuadEpigraph(objective_structure, self.A_structure, self.A_shape, self.cone_dict) if objective_structure is not None else None
@@ -580,6 +590,7 @@ class MI355_ctx:
         if self._aug_ctx is None:
             q = self.quad
             self._aug_ctx = MI355_ctx(None, (q.aug_indices, q.aug_indptr, (q.m_aug, q.n + 2)), q.aug_cones, None, None, self.options)
+            self._aug_ctx.A_is_constant = False if self.A_is_constant is False else None      # (the Cholesky factor of P enters A: constant only if P is, which the values decide)
             self._aug_ctx.default_device = self.default_device
         return self._aug_ctx
 
@@ -592,6 +603,7 @@ class MI355_ctx:
             # A layer is called again and again on related batches (training steps, sweeps): dispatch the instances that ran longest last time first
             # (options={"dispatch_history": False} or CE_DISPATCH_HISTORY=0 switch it off; see include/cone_engine.h)
             import os
+            self._engines[idx].A_is_constant = self.A_is_constant
             self._engines[idx].set_dispatch_history(bool(self.options.get("dispatch_history", True)) and os.environ.get("CE_DISPATCH_HISTORY") != "0")
         return self._engines[idx]
 

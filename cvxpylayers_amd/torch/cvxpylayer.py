@@ -277,11 +277,12 @@ class _ParamProbView:
     """Minimal stand-in for CVXPY's ParamConeProg as far as interfaces.get_solver_ctx reads it."""
 
     class _Red:
-        def __init__(self, pdi):
+        def __init__(self, pdi, mat=None):
             self.problem_data_index = pdi
+            self.reduced_mat = mat          # the parameter map (ParamConeProg.reduced_A.reduced_mat): lets the plugin decide structurally whether A is batch-invariant
 
-    def __init__(self, a_structure, p_structure=None):
-        self.reduced_A = self._Red(a_structure)
+    def __init__(self, a_structure, p_structure=None, a_map=None):
+        self.reduced_A = self._Red(a_structure, a_map)
         self.reduced_P = self._Red(p_structure) if p_structure is not None else None
 
 
@@ -306,7 +307,7 @@ class CvxpyLayer(torch.nn.Module):
         self.template = template
         self.solver = solver
         opts = dict(solver_args or {})
-        solver_ctx = get_solver_ctx(solver, _ParamProbView(template.A_structure, template.P_structure if template.P_map is not None else None),
+        solver_ctx = get_solver_ctx(solver, _ParamProbView(template.A_structure, template.P_structure if template.P_map is not None else None, template.A_map),
                                     template.cone_dims, {}, opts, verbose)
         self.ctx = _Ctx(solver_ctx, solver)
         # The maps address parameters Fortran-flattened (the reference's p_stack); the device copies are re-indexed once to the

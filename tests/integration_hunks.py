@@ -27,6 +27,7 @@ HUNKS = [
             data.get("lower_bound"),
             data.get("upper_bound"),
             options,
+            reduced_A_mat=param_prob.reduced_A.reduced_mat,      # constant-A decided once from the parameter map (as MOREAU_ctx does)
         )
 
     if solver == "DIFFCP":''', 1),

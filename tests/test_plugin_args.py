@@ -69,3 +69,20 @@ def test_status_counts_are_recomputed_when_the_device_summary_never_arrives():
     eng._summary_np[0] = [1, 0, 0, 1]                            # a slot whose flag IS set is never touched
     eng.ensure_summary(0)
     assert eng._summary_np[0].tolist() == [1, 0, 0, 1]
+
+
+def test_constant_A_is_decided_structurally_from_the_parameter_map():
+    """MI355_ctx(reduced_A_mat=...) (the keyword MOREAU_ctx takes; /root/reference moreau_if.py:234-256): the A part of the value vector is batch-invariant
+    exactly when no A entry has a parameter column in the map -- decided once at construction, no per-call compare of B x nnzA values and no host sync.
+    b may depend on parameters (unlike Moreau's PA_is_constant, which also wants b constant).  Without the map the answer stays None (decided per call)."""
+    import numpy as np
+    import scipy.sparse as sp
+    m = _fresh()
+    # 2 x 2 template, CSC of [A | b]: column 0 {rows 0, 1}, column 1 {row 1}, b column {rows 0, 1}  ->  nnz_aug = 5, nnzA = 3
+    structure = (np.array([0, 1, 1, 0, 1]), np.array([0, 2, 3, 5]), (2, 3))
+    P = 2          # two parameters + the constant column
+    only_b = sp.csr_array((np.ones(5), (np.array([0, 1, 2, 3, 4]), np.array([2, 2, 2, 0, 1]))), shape=(5, P + 1))        # A entries constant, b depends on the parameters
+    a_too = sp.csr_array((np.ones(5), (np.array([0, 1, 2, 3, 4]), np.array([2, 0, 2, 0, 1]))), shape=(5, P + 1))         # A entry 1 depends on parameter 0
+    assert m.MI355_ctx(None, structure, {"z": 0, "l": 2, "q": []}).A_is_constant is None
+    assert m.MI355_ctx(None, structure, {"z": 0, "l": 2, "q": []}, reduced_A_mat=only_b).A_is_constant is True
+    assert m.MI355_ctx(None, structure, {"z": 0, "l": 2, "q": []}, reduced_A_mat=a_too).A_is_constant is False
