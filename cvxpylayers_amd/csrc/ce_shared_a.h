@@ -65,7 +65,7 @@ __global__ void __launch_bounds__(NT, 3)
 k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, long sAb, int per_inst, const double *__restrict__ qg, long sqk, long sqb, const double *__restrict__ xg, const double *__restrict__ yg,
           const double *__restrict__ sg, const double *__restrict__ dxg, const double *__restrict__ dyg, double *__restrict__ dAo,
           double *__restrict__ dqo, long sdqk, long sdqb, int *__restrict__ adj_status, int *__restrict__ iters_o, double atol, double btol, double conlim, int itn_lim,
-          const int *__restrict__ sel = nullptr, int status_or = 0) {
+          const int *__restrict__ sel = nullptr, int status_or = 0, int a_lds = 0) {
     // sel != nullptr (ce_vjp's re-solve of the instances its direct elimination flagged rank-deficient): sel[0] instances are listed in sel[1 ...] (appended by
     // the elimination kernel on the same stream); the grid is a fixed number of workgroups that walk the list -- the host never learns the count.  status_or is
     // OR-ed into the adj_status of every instance served (ce_vjp: 4 | 8 = "rank-deficient, re-solved by LSQR").
@@ -91,6 +91,11 @@ k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, long
     double *socs = p; p += 5 * (nq > 0 ? nq : 1);          // per cone: t, |z|, case, z.h ; then h_0 per cone
     p += (size_t)(p - sm) & 1;
     double *Jt = p; p += 9 * (size_t)ntri;                    // exponential / power triples: symmetrised 3 x 3 derivative of the dual-cone projection
+    // a_lds (per-instance A only; the host grants it when m n doubles fit behind the vectors): the instance's A is staged DENSE in LDS once and both products of
+    // every LSQR iteration read it there -- the CSR / CSC products stream the instance's 8 (nnzA) bytes from L2 / HBM twice per iteration, which is what an
+    // instance of the re-solve list costs when it runs alone on its CU (302 iterations x ~35 k cycles at the metric shape).
+    p += (size_t)(p - sm) & 1;
+    double *Ad = p;                                          // [m][n], boundary sign (the products negate)
   for (int li = blockIdx.x;; li += gridDim.x) {              // (one pass without a list: instance = workgroup)
     int inst = li;
     if (sel) { if (li >= sel[0]) break; inst = sel[1 + li]; } else if (li != (int)blockIdx.x) break;
@@ -104,6 +109,11 @@ k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, long
     // templates, solver_args mode="lsqr": ce_vjp_lsqr); else instance 0's values serve every workgroup and stay L2-resident
     const double *Aprod = per_inst ? Ab : Avals0;
     auto bval = [&](int i) -> double { if (!TAU) return 0.0; const int pb = S.bpos[i]; return pb >= 0 ? Ab[pb] : 0.0; };
+    if (a_lds) {
+        for (int i = tid; i < m * n; i += NT) Ad[i] = 0.0;
+        __syncthreads();
+        for (int k = tid; k < S.nnzA; k += NT) Ad[T.rowidx[k] * n + T.colidx[k]] = Aprod[k];
+    }
 
     for (int i = tid; i < psd_first; i += NT) vv[i] = y[i] - s[i];
     __syncthreads();
@@ -252,6 +262,37 @@ k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, long
                         fy(i, s_, bb[u]);
                     }
                 }
+            }
+            __syncthreads();
+        } else if (a_lds) {
+            // dense products from the LDS copy: eight lanes per output, four entries per lane and step in flight, DPP butterfly over the eight
+            const int g = tid >> 3, c8 = tid & 7;
+            for (int j0 = 0; j0 < n; j0 += NT / 8) {          // (A^T yin)_j
+                const int j = j0 + g, jc = j < n ? j : n - 1;
+                double a0 = 0, a1 = 0;
+                for (int i = c8; i < m; i += 32) {
+                    double av[4], yv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) { const int iu = min(i + 8 * u, m - 1); av[u] = Ad[iu * n + jc]; yv[u] = yin[iu]; }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) { const double w = (i + 8 * u < m) ? yv[u] : 0.0; if (u & 1) a1 = fma(av[u], w, a1); else a0 = fma(av[u], w, a0); }
+                }
+                const double a = group_reduce<8, false>(a0 + a1);
+                if (j < n && c8 == 0) fx(j, -a, TAU ? cq[(size_t)j * sqk] : 0.0);
+            }
+            for (int i0 = 0; i0 < m; i0 += NT / 8) {          // (A xin)_i
+                const int i = i0 + g, ic = i < m ? i : m - 1;
+                const double *row = Ad + ic * n;
+                double a0 = 0, a1 = 0;
+                for (int j = c8; j < n; j += 32) {
+                    double av[4], xv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) { const int ju = min(j + 8 * u, n - 1); av[u] = row[ju]; xv[u] = xin[ju]; }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) { const double w = (j + 8 * u < n) ? xv[u] : 0.0; if (u & 1) a1 = fma(av[u], w, a1); else a0 = fma(av[u], w, a0); }
+                }
+                const double a = group_reduce<8, false>(a0 + a1);
+                if (i < m && c8 == 0) fy(i, -a, bval(i));
             }
             __syncthreads();
         } else {

@@ -966,8 +966,15 @@ static int vjp_lsqr_launch(ce_handle h, int B, const double *A_vals0, long sA_b,
     if (const char *e = getenv("CE_SA_SPLIT")) { if (atoi(e) == 0) RP = 0; }
     if (per_inst) RP = 0;      // the split's dense rows are ONE matrix (instance 0's values); per-instance values go through the CSR / CSC products
     if (RP > 0 && sa_lsqr_lds_doubles(T.n, T.m, T.nq, T.ns, T.maxs, RP, h->psd_first, T.nep + T.np) * 8 > LDS_LIMIT) RP = 0;
-    const size_t lds = sa_lsqr_lds_doubles(T.n, T.m, T.nq, T.ns, T.maxs, RP, h->psd_first, T.nep + T.np) * 8;
+    size_t lds = sa_lsqr_lds_doubles(T.n, T.m, T.nq, T.ns, T.maxs, RP, h->psd_first, T.nep + T.np) * 8;
     if (lds > LDS_LIMIT) { g_err = "shared-A adjoint kernel: the LSQR vectors of one instance do not fit LDS"; return CE_E_TOO_LARGE; }
+    // per-instance A: staged dense in LDS when it fits behind the vectors with three workgroups per CU to spare (CE_LSQR_A_LDS=0 disables)
+    int a_lds = 0;
+    if (per_inst && RP == 0) {
+        const char *e = getenv("CE_LSQR_A_LDS");
+        const size_t with = lds + 8 + sizeof(double) * (size_t)T.m * T.n;
+        if (!(e && atoi(e) == 0) && with <= LDS_LIMIT / 3) { a_lds = 1; lds = with; }
+    }
     HIPCHK(hipSetDevice(h->device));
     if (!h->sa_lsqr_attr) {
 #define SA_ATTR(RPV) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sa_lsqr<RPV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT))
@@ -985,7 +992,7 @@ static int vjp_lsqr_launch(ce_handle h, int B, const double *A_vals0, long sA_b,
     }
     {
         ProfScope ps(h, 1, (hipStream_t)stream);
-#define LAUNCH_SAL(RPV) hipLaunchKernelGGL(k_sa_lsqr<RPV>, dim3(B), dim3(NT), lds, (hipStream_t)stream, T, S, F, A_vals0, sA_b, per_inst, q_vals, sq_k, sq_b, x, y, s, dx, dy, dA_bm, dq_vals, sdq_k, sdq_b, adj_status, lsqr_iters, atol, btol, conlim, iter_lim > 0 ? iter_lim : 2 * (T.n + T.m + 1), sel, status_or)
+#define LAUNCH_SAL(RPV) hipLaunchKernelGGL(k_sa_lsqr<RPV>, dim3(B), dim3(NT), lds, (hipStream_t)stream, T, S, F, A_vals0, sA_b, per_inst, q_vals, sq_k, sq_b, x, y, s, dx, dy, dA_bm, dq_vals, sdq_k, sdq_b, adj_status, lsqr_iters, atol, btol, conlim, iter_lim > 0 ? iter_lim : 2 * (T.n + T.m + 1), sel, status_or, a_lds)
         if (RP == 0) LAUNCH_SAL(0); else if (RP == 16) LAUNCH_SAL(16); else if (RP == 32) LAUNCH_SAL(32); else LAUNCH_SAL(64);
 #undef LAUNCH_SAL
     }
