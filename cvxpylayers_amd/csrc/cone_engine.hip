@@ -725,7 +725,7 @@ int ce_vjp_qp(ce_handle h, int B, const double *A_vals, long sA_k, long sA_b, co
         } else lrc = ce_launch_bwd_generic(h->bwd_mode, B, h->bwd_lds, st, ba);
         if (lrc) { g_err = "internal: no backward kernel for the planned variant"; return CE_E_BADARG; }
         if (do_fix) {
-            const int grid = B < 1024 ? B : 1024;
+            const int grid = B < 768 ? B : 768;          // three workgroups per CU: what the LSQR kernel's LDS allows; an empty list costs one pass of workgroups that return at once
             const int prof_keep = h->prof; h->prof = 0;          // (inside this scope's bracket already)
             rc = vjp_lsqr_launch(h, grid, Abm, K, 1, h->call_q, h->call_sqk, h->call_sqb, x, y, s, dx, dy, dAbm, dq_vals, sdq_k, sdq_b, adj_status, nullptr,
                                  h->rs_atol, h->rs_btol, h->rs_conlim, h->rs_iter_lim, stream, h->d_fix, 4 | 8);
@@ -768,34 +768,34 @@ __global__ void __launch_bounds__(256) k_status_summary(int B, const int *__rest
 // order[B] = 1 when the history is PREDICTIVE: at least 70 % of the instances stopped in the same check interval as the instance at the same position of the call
 // before (iters_prev, updated here; have_prev = 0: no such call).  Re-solved or slowly changing batches score ~1, unrelated batches of the metric configuration
 // ~0.43 (the chance that two draws of the count distribution agree): there the permutation predicts nothing and is not applied (k_fwd2 reads the flag).
-__global__ void __launch_bounds__(256) k_dispatch_order(int B, const int *__restrict__ iters, int *__restrict__ order, int *__restrict__ iters_prev, int have_prev) {
+__global__ void __launch_bounds__(1024) k_dispatch_order(int B, const int *__restrict__ iters, int *__restrict__ order, int *__restrict__ iters_prev, int have_prev) {
     constexpr int NB = 512;                       // buckets of CONVERGED_INTERVAL iterations; anything longer shares the last one
     __shared__ int cnt[NB], tmp[NB];
     __shared__ int same;
     if (threadIdx.x == 0) same = 0;
-    for (int b = threadIdx.x; b < NB; b += 256) cnt[b] = 0;
+    for (int b = threadIdx.x; b < NB; b += 1024) cnt[b] = 0;
     __syncthreads();
     {
         int mine = 0;
-        for (int i = threadIdx.x; i < B; i += 256) {
+        for (int i = threadIdx.x; i < B; i += 1024) {
             const int it = iters[i];
             if (have_prev) mine += (max(it, 0) / CONVERGED_INTERVAL == max(iters_prev[i], 0) / CONVERGED_INTERVAL);
             iters_prev[i] = it;
         }
         if (have_prev) atomicAdd(&same, mine);
     }
-    for (int i = threadIdx.x; i < B; i += 256) { const int b = min(max(iters[i], 0) / CONVERGED_INTERVAL, NB - 1); atomicAdd(&cnt[NB - 1 - b], 1); }      // (bucket 0 = longest)
+    for (int i = threadIdx.x; i < B; i += 1024) { const int b = min(max(iters[i], 0) / CONVERGED_INTERVAL, NB - 1); atomicAdd(&cnt[NB - 1 - b], 1); }      // (bucket 0 = longest)
     __syncthreads();
     // exclusive prefix sum over the buckets (two per thread, log-step scan: a serial loop over 512 LDS entries cost 13 us on the path to the status read-back)
     int *src = cnt, *dst = tmp;
     for (int off = 1; off < NB; off <<= 1) {
-        for (int b = threadIdx.x; b < NB; b += 256) dst[b] = src[b] + (b >= off ? src[b - off] : 0);
+        for (int b = threadIdx.x; b < NB; b += 1024) dst[b] = src[b] + (b >= off ? src[b - off] : 0);
         __syncthreads();
         int *t = src; src = dst; dst = t;
     }
-    for (int b = threadIdx.x; b < NB; b += 256) dst[b] = b > 0 ? src[b - 1] : 0;          // inclusive -> exclusive
+    for (int b = threadIdx.x; b < NB; b += 1024) dst[b] = b > 0 ? src[b - 1] : 0;          // inclusive -> exclusive
     __syncthreads();
-    for (int i = threadIdx.x; i < B; i += 256) { const int b = min(max(iters[i], 0) / CONVERGED_INTERVAL, NB - 1); order[atomicAdd(&dst[NB - 1 - b], 1)] = i; }
+    for (int i = threadIdx.x; i < B; i += 1024) { const int b = min(max(iters[i], 0) / CONVERGED_INTERVAL, NB - 1); order[atomicAdd(&dst[NB - 1 - b], 1)] = i; }
     if (threadIdx.x == 0) order[B] = (have_prev && 10 * same >= 7 * B) ? 1 : 0;      // (`same` is complete: every atomicAdd above precedes the barriers of the scan)
 }
 // the order of the NEXT solve is computed off the critical path: behind the status summary (the host is busy with autograd then, the device idle), or at the
@@ -806,7 +806,7 @@ static int flush_dispatch_order(ce_engine *h, hipStream_t st) {
     h->order_pending_B = 0;
     if (h->order_cap < B) { hipFree(h->d_order); h->d_order = nullptr; h->order_cap = 0; HIPCHK(hipMalloc(&h->d_order, sizeof(int) * ((size_t)B + 1))); h->order_cap = B; }
     if (h->iters_prev_cap < B) { hipFree(h->d_iters_prev); h->d_iters_prev = nullptr; h->iters_prev_cap = 0; h->iters_prev_B = 0; HIPCHK(hipMalloc(&h->d_iters_prev, sizeof(int) * (size_t)B)); h->iters_prev_cap = B; }
-    hipLaunchKernelGGL(k_dispatch_order, dim3(1), dim3(256), 0, st, B, h->d_iters2, h->d_order, h->d_iters_prev, h->iters_prev_B == B ? 1 : 0);
+    hipLaunchKernelGGL(k_dispatch_order, dim3(1), dim3(1024), 0, st, B, h->d_iters2, h->d_order, h->d_iters_prev, h->iters_prev_B == B ? 1 : 0);
     h->iters_prev_B = B;
     HIPCHK(hipGetLastError());
     h->order_B = B;
