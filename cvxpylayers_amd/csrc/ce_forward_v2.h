@@ -83,7 +83,11 @@ __device__ __forceinline__ double seg_dot(const double (&tile)[TT], const double
     for (int p = 0; p < PARTS; p++) {
 #pragma unroll
         for (int k = p * H; k < (p + 1) * H && k < NB; k++) {
+#ifdef F2_PROBE_HALFVEC      // (timing probe only, WRONG results: what the iteration would cost if a thread's vector operand were half as long -- a 2 x 13 tile instead of 1 x 26)
+            const double2 v = v2[NB > 8 ? k % ((NB + 1) / 2) : k];
+#else
             const double2 v = v2[k];
+#endif
             a0 = fma(tile[2 * k], v.x, a0);
             a1 = fma(tile[2 * k + 1], v.y, a1);
         }
