@@ -152,6 +152,15 @@ k_backward_ns(DevT T, const double *__restrict__ Avals, const double *__restrict
             else if (kind == 2) { const double w = vv[i]; const double di = (w * h0 + (t0 + nz) * dv[i] - w * cz) * i2n; dv[i] = di; zd = fma(w, di, zd); }
         }
         zd = group_reduce<16, false>(zd);
+        if (kind == 2) {
+            // u_i: the weight of row i of this cone in  f - dx = sum_c [ a_s (e_s.d) + (A_c^T d - a_y (e_y.d) - a_s (e_s.d)) / (1 - lam) ] = A^T u  (a_y, a_s are
+            // combinations of the cone's rows: a_y = (a_0 + a_z) / sqrt 2, a_s = (a_0 - a_z) / sqrt 2, a_z = A_z^T z-hat), so that f is ONE pass over the rows
+            // together with a_z, not a pass of its own behind a_z and a barrier
+            const double d0 = (nz * h0 + zh) * i2n, zdn = zd / nz, eyd = (d0 + zdn) * M_SQRT1_2, esd = (d0 - zdn) * M_SQRT1_2;
+            const double il = 1.0 / (1 - lam), k0c = (esd * (1 - il) - eyd * il) * M_SQRT1_2, kzc = (-esd * (1 - il) - eyd * il) * M_SQRT1_2, inz = 1.0 / nz;
+            for (int i = r0 + 1 + l16; i < r1; i += 16) tvec[i] = fma(il, dv[i], vv[i] * inz * kzc);
+            if (l16 == 0) tvec[r0] = fma(il, d0, k0c);
+        }
         if (cv && l16 == 0) {
             rkind[r0] = rk; ckind[c] = kind; cinfo[5 * c] = lam; cinfo[5 * c + 1] = nz; cinfo[5 * c + 4] = lam / (1 - lam);
             if (kind == 1) dv[r0] = 0.0;
@@ -166,22 +175,6 @@ k_backward_ns(DevT T, const double *__restrict__ Avals, const double *__restrict
     }
     __syncthreads();
     NS_STAMP(2);
-    // ---- a_z = A_z^T z-hat for boundary cones  (a_y = (a_0 + a_z) / sqrt 2,  a_s = (a_0 - a_z) / sqrt 2); published by the barriers of the numbering below
-    for (int idx = tid; idx < nq * n; idx += NTHR) {
-        const int c = idx / n, j = idx - c * n;
-        if (ckind[c] != 2) continue;
-        const int r0 = T.qoff[c], r1 = T.qoff[c + 1];
-        const double inz = 1.0 / cinfo[5 * c + 1];
-        double a = 0, a1 = 0;
-        for (int i = r0 + 1; i < r1; i += 4) {
-            double av[4], wv[4];
-#pragma unroll
-            for (int u = 0; u < 4; u++) { const int iu = min(i + u, r1 - 1); av[u] = A[iu * lda + j]; wv[u] = vv[iu]; }
-#pragma unroll
-            for (int u = 0; u < 4; u++) { const double w = (i + u < r1) ? wv[u] : 0.0; if (u & 1) a1 = fma(av[u], w, a1); else a = fma(av[u], w, a); }
-        }
-        az[c * npad + j] = (a + a1) * inz;
-    }
     // ---- equality numbering: ballot prefix sums (rows in order, then one e_y row per boundary cone); weighted-row list offsets
     {
         int base = 0;
@@ -224,7 +217,7 @@ k_backward_ns(DevT T, const double *__restrict__ Avals, const double *__restrict
         if (tid == 0) { if (adj_status) adj_status[inst] = 2; if (fix) fix[1 + atomicAdd(fix, 1)] = inst; }
         return;
     }
-    // ---- f[j] = dx[j] + sum_c [ a_s (e_s.d) + (A_c^T d - a_y (e_y.d) - a_s (e_s.d)) / (1 - lam) ]     (4 lanes per column, fixed summation order)
+    // ---- f = dx + A^T u  and  a_z = A_z^T z-hat  in ONE pass over the rows of the boundary cones (4 lanes per column, each takes every 4th cone; fixed summation order)
     for (int j0 = 0; j0 < n; j0 += NTHR / 4) {
         const int j = j0 + (tid >> 2), part = tid & 3;
         double acc = 0;
@@ -232,20 +225,20 @@ k_backward_ns(DevT T, const double *__restrict__ Avals, const double *__restrict
             for (int c = part; c < nq; c += 4) {
                 if (ckind[c] != 2) continue;
                 const int r0 = T.qoff[c], r1 = T.qoff[c + 1];
-                const double lam = cinfo[5 * c], eyd = cinfo[5 * c + 2], esd = cinfo[5 * c + 3];
-                double g = 0, g1 = 0;
-                const double a0j = A[r0 * lda + j], azj = az[c * npad + j];
-                const double ayj = (a0j + azj) * M_SQRT1_2, asj = (a0j - azj) * M_SQRT1_2;
+                double g = 0, g1 = 0, a = 0, a1 = 0;
                 for (int i = r0; i < r1; i += 4) {
-                    double av[4], wv[4];
+                    double av[4], uv[4], wv[4];
 #pragma unroll
-                    for (int u = 0; u < 4; u++) { const int iu = min(i + u, r1 - 1); av[u] = A[iu * lda + j]; wv[u] = dv[iu]; }
+                    for (int u = 0; u < 4; u++) { const int iu = min(i + u, r1 - 1); av[u] = A[iu * lda + j]; uv[u] = tvec[iu]; wv[u] = vv[iu]; }
 #pragma unroll
-                    for (int u = 0; u < 4; u++) { const double w = (i + u < r1) ? wv[u] : 0.0; if (u & 1) g1 = fma(av[u], w, g1); else g = fma(av[u], w, g); }
+                    for (int u = 0; u < 4; u++) {
+                        const bool in = i + u < r1;
+                        const double uu = in ? uv[u] : 0.0, ww = (in && i + u > r0) ? wv[u] : 0.0;
+                        if (u & 1) { g1 = fma(av[u], uu, g1); a1 = fma(av[u], ww, a1); } else { g = fma(av[u], uu, g); a = fma(av[u], ww, a); }
+                    }
                 }
-                g += g1;
-                const double a = g - ayj * eyd - asj * esd;      // A_c^T P d
-                acc += asj * esd + a / (1 - lam);
+                az[c * npad + j] = (a + a1) / cinfo[5 * c + 1];
+                acc += g + g1;
             }
         }
         acc = group_reduce<4, false>(acc);
@@ -551,38 +544,52 @@ k_backward_ns(DevT T, const double *__restrict__ Avals, const double *__restrict
     for (int J = 0; J < NTILE; J++) acc[J] = v4d{0.0, 0.0, 0.0, 0.0};
     const int jmax = (cr >> 4) + 1;                     // tiles / strips that hold a row or column <= cr
     if (wave < jmax) {
-        int oc[NTILE]; double msk[NTILE], tsel[NTILE];      // per tile: original column of this lane's reduced column (0 when masked), 0/1 mask, -1 on the right-hand-side column
+        // Operand addresses, not operand arithmetic: a lane whose reduced column does not exist reads a ZERO (a pad entry of tvec), the lane of the right-hand-side
+        // column reads t_q itself (the column is negated behind the loop), every other lane reads the row's entry of its original column -- so the B operands go
+        // from LDS straight into the matrix cores and the A operand takes ONE multiply (the weight).  With fp64 multiplies and blends between the MFMAs the loop
+        // ran at ~200 cycles per MFMA (the fp64 vector operations queue behind the matrix instruction in flight); requested in batches of four steps.
+        const int tvoff = (int)(tvec - sm), zoff = tvoff + KW;          // (tvec[KW] is a pad entry: 0.0)
+        int oc[NTILE], kd[NTILE];          // per tile: original column of this lane's reduced column; kind 0 row entry, 1 the step's t_q, 2 zero
 #pragma unroll
         for (int J = 0; J < NTILE; J++) {
             const int colr = 16 * J + lc;
-            oc[J] = colr < nf ? fcol[colr < nf ? colr : 0] : 0; msk[J] = colr < nf ? 1.0 : 0.0; tsel[J] = colr == cr ? -1.0 : 0.0;
+            oc[J] = colr < nf ? fcol[colr < nf ? colr : 0] : 0; kd[J] = colr < nf ? 0 : (colr == cr ? 1 : 2);
         }
-        int ocw = 0; double mskw = 0.0, tselw = 0.0;
-        static_for<NTILE>([&](auto Jc) { constexpr int J = decltype(Jc)::value; if (wave == J) { ocw = oc[J]; mskw = msk[J]; tselw = tsel[J]; } });
-        double frhs[4];          // (Z^T f)[row] of this lane's four strip rows: requested now, added behind the loop
+        int ocw = 0, kdw = 2;
+        static_for<NTILE>([&](auto Jc) { constexpr int J = decltype(Jc)::value; if (wave == J) { ocw = oc[J]; kdw = kd[J]; } });
+        double frhs[4];          // (Z^T f)[row] of this lane's four strip rows: requested now, used behind the loop
 #pragma unroll
         for (int r = 0; r < 4; r++) { const int rowi = 16 * wave + lg + 4 * r; frhs[r] = fvec[fcol[rowi < nf ? rowi : 0]]; }
         NS_SUB(0);
-        // stage A (list entry) of steps 0, 1; stage B (row values) of step 0
-        int wrA = wrow[lg], wrA2 = wrow[min(4 + lg, KW4 - 1)];
-        double wA = wgt[lg], tA = tvec[lg], wA2 = wgt[min(4 + lg, KW4 - 1)], tA2 = tvec[min(4 + lg, KW4 - 1)];
-        double aB = sm[wrA + ocw], bB[NTILE], wB = wA, tB = tA;
+        constexpr int UB = 4;
+        int wr[UB]; double ww[UB];
 #pragma unroll
-        for (int J = 0; J < NTILE; J++) bB[J] = sm[wrA + oc[J]];
-        for (int k0 = 0; k0 < KW4; k0 += 4) {
-            const double a = wB * fma(aB, mskw, tB * tselw);
-            double b[NTILE];
+        for (int u = 0; u < UB; u++) { const int q = min(4 * u + lg, KW4 - 1); wr[u] = wrow[q]; ww[u] = wgt[q]; }
+        for (int k0 = 0; k0 < KW4; k0 += 4 * UB) {
+            double aB[UB], bB[UB][NTILE];
 #pragma unroll
-            for (int J = 0; J < NTILE; J++) b[J] = fma(bB[J], msk[J], tB * tsel[J]);
-            // stage B of the next step, stage A of the one after it (clamped past the end: harmless reads)
-            aB = sm[wrA2 + ocw];
+            for (int u = 0; u < UB; u++) {
+                const int tq = tvoff + min(k0 + 4 * u + lg, KW4 - 1);
+                aB[u] = sm[kdw == 0 ? wr[u] + ocw : (kdw == 1 ? tq : zoff)];
 #pragma unroll
-            for (int J = 0; J < NTILE; J++) bB[J] = sm[wrA2 + oc[J]];
-            wB = wA2; tB = tA2;
-            const int qn = min(k0 + 8 + lg, KW4 - 1);
-            wrA2 = wrow[qn]; wA2 = wgt[qn]; tA2 = tvec[qn];
+                for (int J = 0; J < NTILE; J++) bB[u][J] = sm[kd[J] == 0 ? wr[u] + oc[J] : (kd[J] == 1 ? tq : zoff)];
+            }
+            double wc[UB];
 #pragma unroll
-            for (int J = 0; J < NTILE; J++) if (J < jmax) acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[J], acc[J], 0, 0, 0);
+            for (int u = 0; u < UB; u++) wc[u] = ww[u];
+#pragma unroll
+            for (int u = 0; u < UB; u++) { const int q = min(k0 + 4 * UB + 4 * u + lg, KW4 - 1); wr[u] = wrow[q]; ww[u] = wgt[q]; }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < UB; u++) aB[u] *= wc[u];          // the four weighted A operands first, then nothing but matrix instructions
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < UB; u++) {
+                if (k0 + 4 * u < KW4) {          // (uniform: the last batch may be short)
+#pragma unroll
+                    for (int J = 0; J < NTILE; J++) if (J < jmax) acc[J] = __builtin_amdgcn_mfma_f64_16x16x4f64(aB[u], bB[u][J], acc[J], 0, 0, 0);
+                }
+            }
         }
         NS_SUB(1);
         // + Z^T f on the right-hand-side column; identity on the padding rows of the last block
@@ -591,9 +598,9 @@ k_backward_ns(DevT T, const double *__restrict__ Avals, const double *__restrict
             static_for<4>([&](auto rc) {          // (compile-time indices into the accumulators: a rolled loop here puts them in scratch)
                 constexpr int r = decltype(rc)::value;
                 const int rowi = 16 * wave + lg + 4 * r;
-                const double add = (16 * J + lc == cr && rowi < nf) ? frhs[r] : 0.0;
+                const bool rhs = 16 * J + lc == cr;          // the right-hand-side column: Z^T f - sum_k w_k t_k a~_k (the loop accumulated + sum w t a~ there)
                 const bool pad = wave == J && lc == lg + 4 * r && rowi >= nf && rowi < cr;
-                acc[J][r] = pad ? 1.0 : acc[J][r] + add;
+                acc[J][r] = pad ? 1.0 : (rhs ? (rowi < nf ? frhs[r] : 0.0) - acc[J][r] : acc[J][r]);
             });
         });
     }
