@@ -72,24 +72,6 @@ __device__ __forceinline__ void sqrt_rsqrt(double q, double &s, double &rinv) {
 #ifndef F2_SEG_PARTS
 #define F2_SEG_PARTS 1
 #endif
-#ifndef F2_MERGE
-#define F2_MERGE 1
-#endif
-#ifndef F2_DBG_NOP1
-#define F2_DBG_NOP1 0
-#endif
-#ifndef F2_DBG_NOCHECK
-#define F2_DBG_NOCHECK 0
-#endif
-#ifndef F2_DBG_NOW
-#define F2_DBG_NOW 0
-#endif
-#ifndef F2_CSN
-#define F2_CSN 4
-#endif
-#ifndef F2_WKCH
-#define F2_WKCH 4
-#endif
 template <int CH, int TT, int PARTS_ = F2_SEG_PARTS, bool REDUCE = true>
 __device__ __forceinline__ double seg_dot(const double (&tile)[TT], const double *vec) {
     const double2 *v2 = reinterpret_cast<const double2 *>(vec);
@@ -389,14 +371,6 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
        const int *__restrict__ row_perm = nullptr, const int *__restrict__ order = nullptr, int *__restrict__ iters2 = nullptr) {
     static_assert(!(WL && (PSD || HASP)), "wave-local cone exchange: plain cones only");
     constexpr int NT = NTH, NW = NTH / 64;        // threads / waves per workgroup of this instantiation (shadow the file-level defaults)
-    // MG: the column tile holds W = G A-hat^T instead of A-hat^T after every (re)factorisation, and the iteration's first two products become ONE phase
-    //     p_x = rho_x G w_x - W w_y      (was: t = rho_x w_x - A-hat^T w_y | barrier | p_x = G t)
-    // -- one barrier and one chain of dependent LDS round trips less per iteration.  W is formed on the matrix cores (form_w below); the check iterations take
-    // A-hat^T y from the ROW tile (cols_from_rows).  Wave-local plain-cone instantiations with four lanes per column (the lane group of a column = the four
-    // row groups of an MFMA accumulator).  -DF2_MERGE=0 builds the two-phase form everywhere (A/B switch).
-    constexpr bool MG = F2_MERGE && WL && !PSD && !HASP && NTH == 256 && CHT == 4 && CHG == 4 && CHA == 2;
-    constexpr int PW = CHA * T2 + 2;               // pitch of a staged row panel of A-hat (form_w): 54 doubles -> the 32 lanes of an LDS pass read 32 distinct bank pairs
-    constexpr int NWT = (T1 + 3) / 4;              // 16-row tiles of W^T per column strip
     using L = F2<CHT, T1, CHA, T2, CHG, TG, NW>;
     using Co = F2Co<CHT, CHA, CHG>;
     constexpr int MP = L::MP, NP = L::NP, VP = L::VP, OY = L::OY, OX = L::OX, OT = L::OT;
@@ -1081,58 +1055,6 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
         block_reduce_w<1, NW>(r, 0u, red, wave);
         hg = uniform_d(r[0]);
         inv_den = uniform_d(1.0 / (rtau + hg));
-        if constexpr (MG && !F2_DBG_NOW) {
-            // W = G A-hat^T into the column tile, on the matrix cores.  Wave w forms W^T = A-hat G for ITS 16 columns j = 16 w + lc, 16 rows of A-hat per tile:
-            //     D[M][N] += sum_K A[M][K] B[K][N],   A[M][K] = A-hat[row(t, M)][4 s + K],   B[K][N] = G[4 s + K][16 w + N]          (13 steps s per tile)
-            // with the tile's rows chosen as  row(t, M) = T1 (M & 3) + 4 t + (M >> 2):  accumulator register r of lane (lg, lc) holds D[lg + 4 r][lc], i.e. the entry
-            // W[16 w + lc][T1 lg + 4 t + r] -- slot k = 4 t + r of the column thread (j1 = 16 w + lc, c1 = lg).  Register indices are static; what is left is the lane
-            // permutation (16 lg + lc) -> (4 lc + lg), one ds_bpermute pair per entry.  The tiles' rows come from the ROW tile, staged as 16-row panels (pitch PW,
-            // double buffered: one barrier per tile) in the dynamic tail of the LDS carve -- the acceleration history that lives there is dead across a (re)factorisation.
-            double *const pan = Gm + gsz;
-            const int lane = tid & 63, lg = lane >> 4, lc = lane & 15;
-            const int rc = i2 / T1, rk = i2 - T1 * rc;               // this thread's row: block rc, slot rk -> tile rk >> 2, tile row rc + 4 (rk & 3)
-            auto stage = [&](int t) {
-                if (i2 < MP && (rk >> 2) == t) {
-                    double2 *dst = reinterpret_cast<double2 *>(pan + (t & 1) * (16 * PW) + (rc + 4 * (rk & 3)) * PW + T2 * c2);
-#pragma unroll
-                    for (int k = 0; k < T2 / 2; k++) dst[k] = make_double2(ar[2 * k], ar[2 * k + 1]);
-                }
-            };
-            constexpr int NKS = (L::NPa + 3) / 4;                     // contraction steps (columns of A-hat beyond n are structural zeros)
-            constexpr int KCH = F2_WKCH;                              // ... in batches of F2_WKCH operand pairs (register peak: both tiles are live)
-            const int gc = min(16 * wave + lc, n - 1);                // (columns beyond n: finite values, the results are not used)
-            const int src = (16 * (lane & 3) + (lane >> 2)) << 2;     // byte address of the accumulator lane whose entries belong to this column thread
-            stage(0);
-            __syncthreads();
-            static_for<NWT>([&](auto tc) {
-                constexpr int t = decltype(tc)::value;
-                if constexpr (t + 1 < NWT) stage(t + 1);
-                typedef double v4d __attribute__((ext_vector_type(4)));
-                v4d acc = v4d{0.0, 0.0, 0.0, 0.0};
-                const double *prow = pan + (t & 1) * (16 * PW) + lc * PW + lg;
-#pragma unroll
-                for (int s0 = 0; s0 < NKS; s0 += KCH) {
-                    double aop[KCH], bop[KCH];
-#pragma unroll
-                    for (int u = 0; u < KCH; u++) {
-                        const int s4 = s0 + u < NKS ? s0 + u : NKS - 1;
-                        aop[u] = prow[4 * s4]; bop[u] = Gm[__mul24(min(4 * s4 + lg, n - 1), ldg) + gc];
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int u = 0; u < KCH; u++) if (s0 + u < NKS) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[u], bop[u], acc, 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                static_for<4>([&](auto rc4) {
-                    constexpr int r4 = decltype(rc4)::value;
-                    if constexpr (4 * t + r4 < T1) {
-                        const int lo = __builtin_amdgcn_ds_bpermute(src, __double2loint(acc[r4])), hi = __builtin_amdgcn_ds_bpermute(src, __double2hiint(acc[r4]));
-                        at[4 * t + r4] = __hiloint2double(hi, lo);
-                    }
-                });
-                __syncthreads();
-            });
-        }
         load_phi_tile(co);
         for (int i = tid; i < NP; i += NT) { sm[L::O_S1 + i] = 0.0; sm[L::O_S2 + i] = 0.0; sm[L::O_PX + i] = 0.0; }
         for (int i = tid; i < m; i += NT) sm[L::O_ZB + OY + i] = 0.0;
@@ -1301,21 +1223,6 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
         }
         if (aa_on && (aa_pending || aa_ph + 1 == aa_int)) { aa_stale = false; if (ev) aaWP[ve] = sm[L::O_W + ve]; }      // input of this iteration, kept where the top of the next one reads it (the safeguard after a step, the step itself every aa_int iterations)
         F2_ACC(0);      // top of the iteration (acceleration bookkeeping, coordinates)
-        if constexpr (MG && !F2_DBG_NOP1) {
-            // P1 (merged): p_x = rho_x G w_x - W w_y,  W = G A-hat^T in the column tile  (+ phi . w from the two spare column groups).  The row segment of G is the
-            // (jg, cg) = (j1, c1) segment of the two-phase form; both partial sums share ONE butterfly.
-            const double *wvec = sm + L::O_W + ((j1 == n + 1 && T1 * c1 < n) ? OX : OY) + T1 * c1;
-            const double a = seg_dot<CHT, T1, F2_SEG_PARTS, false>(at, wvec);
-            __builtin_amdgcn_sched_barrier(0);
-            const double b = seg_dot_lds<CHG, TG, false>(Gm + __mul24(j1 < n ? j1 : 0, ldg) + TG * c1, sm + L::O_W + OX + TG * c1);      // (24-bit multiply: full rate)
-            const double r = group_reduce<CHT, false>(j1 < n ? fma(rho_x, b, -a) : a);
-            if (own1) sm[L::O_PX + j1] = r;
-            else if (c1 == 0 && j1 <= n + 1) sm[L::O_WP + (j1 - n)] = r;          // phi_y . w_y , phi_x . w_x
-            if (Co::thread_id(wave) == 0) sm[L::O_WP + 2] = sm[L::O_W + OT];       // snapshot of w_tau: the fused phase below rewrites it while other waves still need it
-            F2_ACC(1);
-            __syncthreads();
-            F2_ACC(2);
-        } else {
         // P1a: t = rho_x w_x - A^T w_y   (+ phi . w from the two spare column groups)
         {
             const double *wvec = sm + L::O_W + ((j1 == n + 1 && T1 * c1 < n) ? OX : OY) + T1 * c1;
@@ -1335,7 +1242,6 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
         F2_ACC(3);      // P1b up to its barrier
         __syncthreads();
         F2_ACC(2);
-        }
         if constexpr (WL) {
             // P2 + P3 fused: q = A p_x ; tau-tilde ; u-tilde ; cone projection ; relaxed update.  The cone blocks of y are wave-local.
             // Latency is what this phase costs (three workgroups per CU hide some of it, not all): every LDS round trip that can be issued early is.
@@ -1513,29 +1419,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
                 if (own2) sm[L::O_ZB + OY + i2] = ax_raw;
             }
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (MG && !F2_DBG_NOCHECK) {
-                // A-hat^T y-hat from the ROW tile (the column tile holds G A-hat^T): every lane scales its row segment by y_i; the 8 rows of a DPP row that share a
-                // column half are added in three DPP stages that keep the lane's parity (= its column half): quad_perm [2,3,0,1], row_ror:4, row_ror:8; the 16 partial
-                // rows per column (4 waves x 4 DPP rows) are added by the column's owner in the residual phase below.  Parked behind the acceleration history.
-                double *const part = Gm + gsz + 5 * VP;               // [16][NPa]
-                const double yi = sm[L::O_U + OY + (i2 < MP ? i2 : 0)];      // (rows beyond MP: the tile is zero)
-                const int lane = co.t & 63;
-                double2 *dst = reinterpret_cast<double2 *>(part + (4 * wave + (lane >> 4)) * L::NPa + T2 * c2);
-                constexpr int CSN = F2_CSN;        // partial sums live at a time (even)
-                static_for<(T2 + CSN - 1) / CSN>([&](auto hc) {
-                    constexpr int k0 = decltype(hc)::value * CSN, k1 = k0 + CSN < T2 ? k0 + CSN : T2;
-                    double cs[k1 - k0];
-#pragma unroll
-                    for (int k = k0; k < k1; k++) cs[k - k0] = ar[k] * yi;
-#pragma unroll
-                    for (int k = 0; k < k1 - k0; k++) { cs[k] += dpp_mov<0x4E>(cs[k]); cs[k] += dpp_mov<0x124>(cs[k]); cs[k] += dpp_mov<0x128>(cs[k]); }
-                    if ((lane & 14) == 0) {
-#pragma unroll
-                        for (int k = 0; k < (k1 - k0) / 2; k++) dst[k0 / 2 + k] = make_double2(cs[2 * k], cs[2 * k + 1]);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                });
-            } else {
+            {
                 const double aty_raw = seg_dot<CHT, T1>(at, sm + L::O_U + OY + T1 * c1);      // A-hat^T y-hat
                 if (own1) sm[L::O_ZB + OX + j1] = aty_raw;
             }
@@ -1563,16 +1447,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
             } else if (e < m + n) {
                 const int j = e - m;
                 const double sc_ = isg / sm[L::O_EV + j];
-                double aty_raw = 0;
-                if constexpr (MG && !F2_DBG_NOCHECK) {
-                    const double *part = Gm + gsz + 5 * VP + j;
-                    double pv[16];
-#pragma unroll
-                    for (int q = 0; q < 16; q++) pv[q] = part[q * L::NPa];
-#pragma unroll
-                    for (int q = 0; q < 16; q++) aty_raw += pv[q];
-                } else aty_raw = sm[L::O_ZB + OX + j];
-                const double aty = aty_raw * sc_;
+                const double aty = sm[L::O_ZB + OX + j] * sc_;
                 const double cj = sm[L::O_CV + j];
                 double pxj = 0;
                 if constexpr (HASP) { pxj = sm[L::O_TV + j] * sc_; rP[0] = fabs(pxj); rP[1] = sm[L::O_TV + j] * sm[L::O_U + OX + j] * isg * isg; }

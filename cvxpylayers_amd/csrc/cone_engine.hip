@@ -414,12 +414,6 @@ int ce_create(const ce_template *tpl, int device, ce_handle *out) {
             {   // five more vectors (w_prev, x_prev, f_prev, f_save, x_save) when they fit: Anderson acceleration available
                 const F2Dims dd = f2_dims(v);
                 size_t tail = 5 * (size_t)dd.VP;
-                // the merged-operand instantiation of k_fwd2 (ce_forward_v2.h `MG`: wave-local rows, four lanes per column, 256 threads) stages row panels of A-hat
-                // in the same tail while it forms W = G A-hat^T (2 x 16 rows of NPa + 2 doubles) and parks the check iterations' partial column sums behind the history
-#ifndef F2_MERGE
-#define F2_MERGE 1
-#endif
-                if (F2_MERGE && h->wl && !has_p && V[0] == 4 && V[4] == 4 && V[2] == 2 && NTH == 256) tail = std::max((size_t)2 * 16 * (dd.NPa + 2), tail + (size_t)16 * dd.NPa);
                 const size_t by_aa = by + tail * 8;
                 if (by_aa <= LDS_LIMIT) { h->fwd_lds = by_aa; h->aa_ok = true; }
             }
