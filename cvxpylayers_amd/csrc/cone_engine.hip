@@ -81,7 +81,7 @@ struct ce_engine {
     bool wl = false; int wl_nq = 0; int *d_row_perm = nullptr, *d_k_rowcone = nullptr, *d_k_qoff = nullptr;   // rows packed so that cones are wave-local (k_fwd2 WL)
     // longest-first dispatch (ce_set_dispatch_history): workgroup -> instance order for the next solve of the same batch size, from this solve's iteration counts
     bool dispatch_history = false; int *d_order = nullptr; int order_B = 0, order_cap = 0;
-    int *d_iters2 = nullptr; int iters2_cap = 0, order_pending_B = 0;
+    int *d_iters2 = nullptr; int iters2_cap = 0, order_pending_B = 0; const int *last_status = nullptr;      // last_status: the status vector of the solve whose order is pending
     int *d_iters_prev = nullptr; int iters_prev_cap = 0, iters_prev_B = 0;      // the iteration counts of the call before (k_dispatch_order compares: is the history predictive?)      // engine-owned copy of the last solve's iteration counts (the caller's buffer may be gone when the order is computed)
     int brt_variant = -1;                          // register-tiled backward kernel variant (-1: generic kernel)
     int ns_variant = -1; size_t ns_lds = 0;       // search-free null-space adjoint (ce_backward_ns.h), -1: not applicable
@@ -568,7 +568,7 @@ static int to_batch_major(ce_engine *h, int B, const double *vals, long sk, long
 }
 
 struct ce_engine;
-static int flush_dispatch_order(ce_engine *h, hipStream_t st);      // (defined next to ce_set_dispatch_history)
+static int flush_dispatch_order(ce_engine *h, hipStream_t st, const int *sum_status, int *sum_out);      // (defined next to ce_set_dispatch_history)
 
 int ce_qp_native(ce_handle h) { return (h && h->qp_native) ? 1 : 0; }
 
@@ -609,7 +609,7 @@ int ce_solve_qp(ce_handle h, int B, const double *A_vals, long sA_k, long sA_b, 
         fa.x = x; fa.y = y; fa.s = s; fa.iters = iters; fa.status = status; fa.resid = resid; fa.P = P_vals; fa.nnz_p = h->nnz_p; fa.idx_p = h->d_idx_p; fa.gA = gA; fa.gG = gG;
         int lrc;
         if (h->dispatch_history && h->fwd_mode == 4) {
-            rc = flush_dispatch_order(h, st); if (rc) return rc;          // (a solve whose status was never summarised: the order is still owed)
+            rc = flush_dispatch_order(h, st, nullptr, nullptr); if (rc) return rc;          // (a solve whose status was never summarised: the order is still owed)
             if (h->iters2_cap < B) { hipFree(h->d_iters2); h->d_iters2 = nullptr; h->iters2_cap = 0; HIPCHK(hipMalloc(&h->d_iters2, sizeof(int) * (size_t)B)); h->iters2_cap = B; }
             fa.iters2 = h->d_iters2; fa_iters2 = true;
         }
@@ -629,7 +629,7 @@ int ce_solve_qp(ce_handle h, int B, const double *A_vals, long sA_k, long sA_b, 
         if (lrc) { g_err = "internal: no forward kernel for the planned variant"; return CE_E_BADARG; }
     }
     HIPCHK(hipGetLastError());
-    if (fa_iters2) h->order_pending_B = B;          // (computed by flush_dispatch_order, off the critical path)
+    if (fa_iters2) { h->order_pending_B = B; h->last_status = status; }          // (computed by flush_dispatch_order, off the critical path)
     return CE_OK;
 }
 
@@ -648,7 +648,7 @@ int ce_vjp(ce_handle h, int B, const double *A_vals, long sA_k, long sA_b, const
 static int vjp_lsqr_launch(ce_handle h, int B, const double *A_vals0, long sA_b, int per_inst, const double *q_vals, long sq_k, long sq_b,
                            const double *x, const double *y, const double *s, const double *dx, const double *dy,
                            double *dA_bm, double *dq_vals, long sdq_k, long sdq_b, int *adj_status, int *lsqr_iters, double atol, double btol, double conlim, int iter_lim, void *stream,
-                           const int *sel = nullptr, int status_or = 0);
+                           int *sel = nullptr, int status_or = 0, int *sel_done = nullptr);
 int ce_vjp_qp(ce_handle h, int B, const double *A_vals, long sA_k, long sA_b, const double *P_vals,
               const double *x, const double *y, const double *s, const double *dx, const double *dy,
               double *dA_vals, long sdA_k, long sdA_b, double *dq_vals, long sdq_k, long sdq_b, double *dP_vals, int *adj_status, void *stream) {
@@ -683,8 +683,8 @@ int ce_vjp_qp(ce_handle h, int B, const double *A_vals, long sA_k, long sA_b, co
                   sa_lsqr_lds_doubles(T.n, T.m, T.nq, T.ns, T.maxs, 0, h->psd_first, T.nep + T.np) * 8 <= LDS_LIMIT;
     if (do_fix && h->fix_cap < B) {
         if (h->d_fix) { hipFree(h->d_fix); h->d_fix = nullptr; h->fix_cap = 0; }
-        HIPCHK(hipMalloc(&h->d_fix, sizeof(int) * ((size_t)B + 1))); h->fix_cap = B;
-        HIPCHK(hipMemsetAsync(h->d_fix, 0, sizeof(int), st));      // (afterwards the counter is reset behind the LSQR launch of every call)
+        HIPCHK(hipMalloc(&h->d_fix, sizeof(int) * ((size_t)B + 2))); h->fix_cap = B;
+        HIPCHK(hipMemsetAsync(h->d_fix, 0, sizeof(int) * ((size_t)B + 2), st));      // count | entries | exit ticket of the LSQR launch (afterwards the LAST workgroup of every LSQR launch resets the two counters)
     }
     {
         ProfScope ps(h, 1, st);
@@ -729,10 +729,9 @@ int ce_vjp_qp(ce_handle h, int B, const double *A_vals, long sA_k, long sA_b, co
             const int grid = B < 768 ? B : 768;          // three workgroups per CU: what the LSQR kernel's LDS allows; an empty list costs one pass of workgroups that return at once
             const int prof_keep = h->prof; h->prof = 0;          // (inside this scope's bracket already)
             rc = vjp_lsqr_launch(h, grid, Abm, K, 1, h->call_q, h->call_sqk, h->call_sqb, x, y, s, dx, dy, dAbm, dq_vals, sdq_k, sdq_b, adj_status, nullptr,
-                                 h->rs_atol, h->rs_btol, h->rs_conlim, h->rs_iter_lim, stream, h->d_fix, 4 | 8);
+                                 h->rs_atol, h->rs_btol, h->rs_conlim, h->rs_iter_lim, stream, h->d_fix, 4 | 8, h->d_fix + h->fix_cap + 1);
             h->prof = prof_keep;
             if (rc) return rc;
-            HIPCHK(hipMemsetAsync(h->d_fix, 0, sizeof(int), st));          // for the next call (kept off the path in front of its kernels)
         }
         if (ba.nk_max) {      // the largest system of this call, for the tile choice of the next one (read once the copy has landed: no synchronisation here)
             HIPCHK(hipMemcpyAsync(h->h_nkmax, h->d_nkmax, sizeof(int), hipMemcpyDeviceToHost, st));
@@ -746,7 +745,7 @@ int ce_vjp_qp(ce_handle h, int B, const double *A_vals, long sA_k, long sA_b, co
         launch_transpose(st, dAbm, dA_vals, B, K);
     }
     HIPCHK(hipGetLastError());
-    return flush_dispatch_order(h, st);
+    return flush_dispatch_order(h, st, nullptr, nullptr);
 }
 
 // summary of an int32 vector v[B] (status of a forward call, or adj_status of a backward call): out[0] = min v, out[1] = #{v == 2} ("solved,
@@ -769,10 +768,27 @@ __global__ void __launch_bounds__(256) k_status_summary(int B, const int *__rest
 // order[B] = 1 when the history is PREDICTIVE: at least 70 % of the instances stopped in the same check interval as the instance at the same position of the call
 // before (iters_prev, updated here; have_prev = 0: no such call).  Re-solved or slowly changing batches score ~1, unrelated batches of the metric configuration
 // ~0.43 (the chance that two draws of the count distribution agree): there the permutation predicts nothing and is not applied (k_fwd2 reads the flag).
-__global__ void __launch_bounds__(1024) k_dispatch_order(int B, const int *__restrict__ iters, int *__restrict__ order, int *__restrict__ iters_prev, int have_prev) {
+// sum_status / sum_out given: the status summary of k_status_summary comes FIRST (its ready flag is what the host polls), the sort behind it in the same launch
+__global__ void __launch_bounds__(1024) k_dispatch_order(int B, const int *__restrict__ iters, int *__restrict__ order, int *__restrict__ iters_prev, int have_prev,
+                                                         const int *__restrict__ sum_status = nullptr, int *__restrict__ sum_out = nullptr) {
     constexpr int NB = 512;                       // buckets of CONVERGED_INTERVAL iterations; anything longer shares the last one
     __shared__ int cnt[NB], tmp[NB];
     __shared__ int same;
+    if (sum_out) {
+        int mn = 0x7fffffff, n2 = 0, nf = 0;
+        for (int i = threadIdx.x; i < B; i += 1024) { const int s = sum_status[i]; mn = min(mn, s); n2 += (s == 2); nf += ((s & 3) != 0); }
+        for (int o = 32; o > 0; o >>= 1) { mn = min(mn, __shfl_xor(mn, o)); n2 += __shfl_xor(n2, o); nf += __shfl_xor(nf, o); }
+        if ((threadIdx.x & 63) == 0) { tmp[threadIdx.x >> 6] = mn; tmp[16 + (threadIdx.x >> 6)] = n2; tmp[32 + (threadIdx.x >> 6)] = nf; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int a = tmp[0], b2 = 0, c = 0;
+            for (int w = 0; w < 16; w++) { a = min(a, tmp[w]); b2 += tmp[16 + w]; c += tmp[32 + w]; }
+            sum_out[0] = a; sum_out[1] = b2; sum_out[2] = c;
+            __threadfence_system();
+            __hip_atomic_store(sum_out + 3, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        __syncthreads();
+    }
     if (threadIdx.x == 0) same = 0;
     for (int b = threadIdx.x; b < NB; b += 1024) cnt[b] = 0;
     __syncthreads();
@@ -801,13 +817,15 @@ __global__ void __launch_bounds__(1024) k_dispatch_order(int B, const int *__res
 }
 // the order of the NEXT solve is computed off the critical path: behind the status summary (the host is busy with autograd then, the device idle), or at the
 // latest in front of the next solve / behind the next adjoint
-static int flush_dispatch_order(ce_engine *h, hipStream_t st) {
+static int flush_dispatch_order(ce_engine *h, hipStream_t st, const int *sum_status = nullptr, int *sum_out = nullptr) {
     if (!h->order_pending_B) return CE_OK;
     const int B = h->order_pending_B;
     h->order_pending_B = 0;
     if (h->order_cap < B) { hipFree(h->d_order); h->d_order = nullptr; h->order_cap = 0; HIPCHK(hipMalloc(&h->d_order, sizeof(int) * ((size_t)B + 1))); h->order_cap = B; }
     if (h->iters_prev_cap < B) { hipFree(h->d_iters_prev); h->d_iters_prev = nullptr; h->iters_prev_cap = 0; h->iters_prev_B = 0; HIPCHK(hipMalloc(&h->d_iters_prev, sizeof(int) * (size_t)B)); h->iters_prev_cap = B; }
-    hipLaunchKernelGGL(k_dispatch_order, dim3(1), dim3(1024), 0, st, B, h->d_iters2, h->d_order, h->d_iters_prev, h->iters_prev_B == B ? 1 : 0);
+    // (on a stream of the engine's own, ordered by two events, this kernel was measured SLOWER: a cross-queue dependency costs more than the 10 us it would hide -- 2.13 against 2.05 ms
+    //  per replayed step, no change on rotating batches)
+    hipLaunchKernelGGL(k_dispatch_order, dim3(1), dim3(1024), 0, st, B, h->d_iters2, h->d_order, h->d_iters_prev, h->iters_prev_B == B ? 1 : 0, sum_status, sum_out);
     h->iters_prev_B = B;
     HIPCHK(hipGetLastError());
     h->order_B = B;
@@ -836,15 +854,17 @@ int ce_status_summary(ce_handle h, int B, const int *status, int *summary_host, 
     }
     if (h->summary_host_dev) {
         int *out = reinterpret_cast<int *>(h->summary_host_dev + ((uintptr_t)summary_host - page));
+        // a solve whose dispatch order is still owed and whose status this is: ONE launch does both, the summary (and its ready flag) first
+        if (h->order_pending_B == B && status == h->last_status) return flush_dispatch_order(h, (hipStream_t)stream, status, out);
         hipLaunchKernelGGL(k_status_summary, dim3(1), dim3(256), 0, (hipStream_t)stream, B, status, out);
         HIPCHK(hipGetLastError());
-        return flush_dispatch_order(h, (hipStream_t)stream);          // (behind the summary: the host reads the flag while this runs)
+        return flush_dispatch_order(h, (hipStream_t)stream, nullptr, nullptr);          // (behind the summary: the host reads the flag while this runs)
     }
     int *slot = h->d_summary + 4 * (h->summary_next++ & 7);      // a few calls may be in flight on the stream before the caller synchronises
     hipLaunchKernelGGL(k_status_summary, dim3(1), dim3(256), 0, (hipStream_t)stream, B, status, slot);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(summary_host, slot, 4 * sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));      // (three values + the ready flag)
-    return flush_dispatch_order(h, (hipStream_t)stream);
+    return flush_dispatch_order(h, (hipStream_t)stream, nullptr, nullptr);
 }
 
 int ce_transpose(ce_handle h, int rows, int cols, const double *in, double *out, void *stream) {
@@ -959,7 +979,7 @@ int ce_solve_shared_a(ce_handle h, int B, int r, int RP, const double *AdT, cons
 static int vjp_lsqr_launch(ce_handle h, int B, const double *A_vals0, long sA_b, int per_inst, const double *q_vals, long sq_k, long sq_b,
                            const double *x, const double *y, const double *s, const double *dx, const double *dy,
                            double *dA_bm, double *dq_vals, long sdq_k, long sdq_b, int *adj_status, int *lsqr_iters, double atol, double btol, double conlim, int iter_lim, void *stream,
-                           const int *sel, int status_or) {
+                           int *sel, int status_or, int *sel_done) {
     if (!h || B <= 0 || !A_vals0 || !x || !y || !s || !dx || !dy || !dA_bm || !dq_vals) { g_err = "null argument"; return CE_E_BADARG; }
     const DevT &T = h->T;
     // products through the singleton / dense-row split when the template has one (CE_SA_SPLIT=0: CSR / CSC products)
@@ -993,7 +1013,7 @@ static int vjp_lsqr_launch(ce_handle h, int B, const double *A_vals0, long sA_b,
     }
     {
         ProfScope ps(h, 1, (hipStream_t)stream);
-#define LAUNCH_SAL(RPV) hipLaunchKernelGGL(k_sa_lsqr<RPV>, dim3(B), dim3(NT), lds, (hipStream_t)stream, T, S, F, A_vals0, sA_b, per_inst, q_vals, sq_k, sq_b, x, y, s, dx, dy, dA_bm, dq_vals, sdq_k, sdq_b, adj_status, lsqr_iters, atol, btol, conlim, iter_lim > 0 ? iter_lim : 2 * (T.n + T.m + 1), sel, status_or, a_lds)
+#define LAUNCH_SAL(RPV) hipLaunchKernelGGL(k_sa_lsqr<RPV>, dim3(B), dim3(NT), lds, (hipStream_t)stream, T, S, F, A_vals0, sA_b, per_inst, q_vals, sq_k, sq_b, x, y, s, dx, dy, dA_bm, dq_vals, sdq_k, sdq_b, adj_status, lsqr_iters, atol, btol, conlim, iter_lim > 0 ? iter_lim : 2 * (T.n + T.m + 1), sel, status_or, a_lds, sel_done)
         if (RP == 0) LAUNCH_SAL(0); else if (RP == 16) LAUNCH_SAL(16); else if (RP == 32) LAUNCH_SAL(32); else LAUNCH_SAL(64);
 #undef LAUNCH_SAL
     }
