@@ -65,12 +65,15 @@ __global__ void __launch_bounds__(NT, 3)
 k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, long sAb, int per_inst, const double *__restrict__ qg, long sqk, long sqb, const double *__restrict__ xg, const double *__restrict__ yg,
           const double *__restrict__ sg, const double *__restrict__ dxg, const double *__restrict__ dyg, double *__restrict__ dAo,
           double *__restrict__ dqo, long sdqk, long sdqb, int *__restrict__ adj_status, int *__restrict__ iters_o, double atol, double btol, double conlim, int itn_lim,
-          int *sel = nullptr, int status_or = 0, int a_lds = 0, int *sel_done = nullptr) {
+          const int *__restrict__ sel = nullptr, int status_or = 0, int a_lds = 0, int *__restrict__ sel_reset = nullptr) {
     // sel != nullptr (ce_vjp's re-solve of the instances its direct elimination flagged rank-deficient): sel[0] instances are listed in sel[1 ...] (appended by
     // the elimination kernel on the same stream); the grid is a fixed number of workgroups that walk the list -- the host never learns the count.  status_or is
     // OR-ed into the adj_status of every instance served (ce_vjp: 4 | 8 = "rank-deficient, re-solved by LSQR").
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int tid = threadIdx.x;
+    // ce_vjp alternates TWO lists: while this launch walks `sel`, it empties the other one (walked by the previous call's launch, appended to by the next call's
+    // elimination kernel) -- no memset launch per call, and no exit ticket (768 atomics on one address cost 7 us: measured)
+    if (sel_reset && blockIdx.x == 0 && tid == 0) *sel_reset = 0;
     const int n = T.n, m = T.m, z = T.z, nl = T.l, nq = T.nq, ns = T.ns;
     const int KP = ns > 0 ? psd_mfma_kp(T.maxs) : 0, P = KP + 1, PM = KP * P;
     const float rKP = KP > 0 ? 1.0f / (float)KP : 1.0f;
@@ -421,8 +424,4 @@ k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, long
     if (tid == 0) { if (adj_status) adj_status[inst] = (live ? 1 : 0) | status_or; if (iters_o) iters_o[inst] = itn; }
     __syncthreads();          // (the next listed instance reuses every LDS vector)
   }
-    // the list is emptied for the next call by the LAST workgroup to leave (every other one has read the count by then): no memset launch behind this kernel
-    if (sel && sel_done && tid == 0) {
-        if (atomicAdd(sel_done, 1) == (int)gridDim.x - 1) { sel[0] = 0; *sel_done = 0; }
-    }
 }

@@ -92,7 +92,7 @@ struct ce_engine {
     // re-solve of rank-deficient adjoint systems by LSQR (ce_set_adjoint_resolve): fix[0] = number of listed instances, fix[1 ...] = the instances the elimination
     // kernels flagged (appended on the device); diffcp's LSQR rule
     const double *call_q = nullptr; long call_sqk = 0, call_sqb = 0;      // (ce_vjp -> ce_vjp_qp: the objective values of the call in flight)
-    bool resolve = true; int *d_fix = nullptr; int fix_cap = 0; double rs_atol = 1e-8, rs_btol = 1e-8, rs_conlim = 1e8; int rs_iter_lim = 0;
+    bool resolve = true; int *d_fix = nullptr; int fix_cap = 0, fix_par = 0; double rs_atol = 1e-8, rs_btol = 1e-8, rs_conlim = 1e8; int rs_iter_lim = 0;
     // quadratic objective
     int nnz_p = 0, p_tri = 0; bool qp_native = false;
     bool aa_ok = false;                            // the forward launch carries the LDS for the Anderson-acceleration vectors
@@ -648,7 +648,7 @@ int ce_vjp(ce_handle h, int B, const double *A_vals, long sA_k, long sA_b, const
 static int vjp_lsqr_launch(ce_handle h, int B, const double *A_vals0, long sA_b, int per_inst, const double *q_vals, long sq_k, long sq_b,
                            const double *x, const double *y, const double *s, const double *dx, const double *dy,
                            double *dA_bm, double *dq_vals, long sdq_k, long sdq_b, int *adj_status, int *lsqr_iters, double atol, double btol, double conlim, int iter_lim, void *stream,
-                           int *sel = nullptr, int status_or = 0, int *sel_done = nullptr);
+                           const int *sel = nullptr, int status_or = 0, int *sel_reset = nullptr);
 int ce_vjp_qp(ce_handle h, int B, const double *A_vals, long sA_k, long sA_b, const double *P_vals,
               const double *x, const double *y, const double *s, const double *dx, const double *dy,
               double *dA_vals, long sdA_k, long sdA_b, double *dq_vals, long sdq_k, long sdq_b, double *dP_vals, int *adj_status, void *stream) {
@@ -683,13 +683,14 @@ int ce_vjp_qp(ce_handle h, int B, const double *A_vals, long sA_k, long sA_b, co
                   sa_lsqr_lds_doubles(T.n, T.m, T.nq, T.ns, T.maxs, 0, h->psd_first, T.nep + T.np) * 8 <= LDS_LIMIT;
     if (do_fix && h->fix_cap < B) {
         if (h->d_fix) { hipFree(h->d_fix); h->d_fix = nullptr; h->fix_cap = 0; }
-        HIPCHK(hipMalloc(&h->d_fix, sizeof(int) * ((size_t)B + 2))); h->fix_cap = B;
-        HIPCHK(hipMemsetAsync(h->d_fix, 0, sizeof(int) * ((size_t)B + 2), st));      // count | entries | exit ticket of the LSQR launch (afterwards the LAST workgroup of every LSQR launch resets the two counters)
+        HIPCHK(hipMalloc(&h->d_fix, sizeof(int) * 2 * ((size_t)B + 1))); h->fix_cap = B; h->fix_par = 0;
+        HIPCHK(hipMemsetAsync(h->d_fix, 0, sizeof(int) * 2 * ((size_t)B + 1), st));      // TWO lists (count | entries), used alternately: the LSQR launch of a call empties the list of the call before
     }
     {
         ProfScope ps(h, 1, st);
         CeBwdArgs ba{};
-        ba.fix = do_fix ? h->d_fix : nullptr;
+        int *const fix_cur = do_fix ? h->d_fix + (size_t)h->fix_par * (h->fix_cap + 1) : nullptr, *const fix_oth = do_fix ? h->d_fix + (size_t)(1 - h->fix_par) * (h->fix_cap + 1) : nullptr;
+        ba.fix = fix_cur;
         ba.T = T; ba.nkcap = h->nkcap; ba.ldk = h->ldk; ba.Abm = Abm; ba.x = x; ba.y = y; ba.s = s; ba.dx = dx; ba.dy = dy; ba.dA = dAbm; ba.dq = dq_vals;
         ba.sdqk = sdq_k; ba.sdqb = sdq_b; ba.adj = adj_status; ba.P = P_vals; ba.nnz_p = h->nnz_p; ba.pmap = h->d_pmap; ba.prow = h->d_prow; ba.pcol = h->d_pcol;
         ba.p_tri = h->p_tri; ba.dP = dP_vals; ba.gA = gA; ba.gK = gK;
@@ -729,7 +730,8 @@ int ce_vjp_qp(ce_handle h, int B, const double *A_vals, long sA_k, long sA_b, co
             const int grid = B < 768 ? B : 768;          // three workgroups per CU: what the LSQR kernel's LDS allows; an empty list costs one pass of workgroups that return at once
             const int prof_keep = h->prof; h->prof = 0;          // (inside this scope's bracket already)
             rc = vjp_lsqr_launch(h, grid, Abm, K, 1, h->call_q, h->call_sqk, h->call_sqb, x, y, s, dx, dy, dAbm, dq_vals, sdq_k, sdq_b, adj_status, nullptr,
-                                 h->rs_atol, h->rs_btol, h->rs_conlim, h->rs_iter_lim, stream, h->d_fix, 4 | 8, h->d_fix + h->fix_cap + 1);
+                                 h->rs_atol, h->rs_btol, h->rs_conlim, h->rs_iter_lim, stream, fix_cur, 4 | 8, fix_oth);
+            h->fix_par ^= 1;
             h->prof = prof_keep;
             if (rc) return rc;
         }
@@ -799,8 +801,11 @@ __global__ void __launch_bounds__(1024) k_dispatch_order(int B, const int *__res
             if (have_prev) mine += (max(it, 0) / CONVERGED_INTERVAL == max(iters_prev[i], 0) / CONVERGED_INTERVAL);
             iters_prev[i] = it;
         }
-        if (have_prev) atomicAdd(&same, mine);
+        if (have_prev && mine) atomicAdd(&same, mine);
     }
+    __syncthreads();
+    // not predictive (unrelated batches, the first call): the order would not be applied -- the sort is skipped, the kernel is ~5 us shorter on the path to the caller's next launch
+    if (!(have_prev && 10 * same >= 7 * B)) { if (threadIdx.x == 0) order[B] = 0; return; }
     for (int i = threadIdx.x; i < B; i += 1024) { const int b = min(max(iters[i], 0) / CONVERGED_INTERVAL, NB - 1); atomicAdd(&cnt[NB - 1 - b], 1); }      // (bucket 0 = longest)
     __syncthreads();
     // exclusive prefix sum over the buckets (two per thread, log-step scan: a serial loop over 512 LDS entries cost 13 us on the path to the status read-back)
@@ -813,7 +818,7 @@ __global__ void __launch_bounds__(1024) k_dispatch_order(int B, const int *__res
     for (int b = threadIdx.x; b < NB; b += 1024) dst[b] = b > 0 ? src[b - 1] : 0;          // inclusive -> exclusive
     __syncthreads();
     for (int i = threadIdx.x; i < B; i += 1024) { const int b = min(max(iters[i], 0) / CONVERGED_INTERVAL, NB - 1); order[atomicAdd(&dst[NB - 1 - b], 1)] = i; }
-    if (threadIdx.x == 0) order[B] = (have_prev && 10 * same >= 7 * B) ? 1 : 0;      // (`same` is complete: every atomicAdd above precedes the barriers of the scan)
+    if (threadIdx.x == 0) order[B] = 1;
 }
 // the order of the NEXT solve is computed off the critical path: behind the status summary (the host is busy with autograd then, the device idle), or at the
 // latest in front of the next solve / behind the next adjoint
@@ -979,7 +984,7 @@ int ce_solve_shared_a(ce_handle h, int B, int r, int RP, const double *AdT, cons
 static int vjp_lsqr_launch(ce_handle h, int B, const double *A_vals0, long sA_b, int per_inst, const double *q_vals, long sq_k, long sq_b,
                            const double *x, const double *y, const double *s, const double *dx, const double *dy,
                            double *dA_bm, double *dq_vals, long sdq_k, long sdq_b, int *adj_status, int *lsqr_iters, double atol, double btol, double conlim, int iter_lim, void *stream,
-                           int *sel, int status_or, int *sel_done) {
+                           const int *sel, int status_or, int *sel_reset) {
     if (!h || B <= 0 || !A_vals0 || !x || !y || !s || !dx || !dy || !dA_bm || !dq_vals) { g_err = "null argument"; return CE_E_BADARG; }
     const DevT &T = h->T;
     // products through the singleton / dense-row split when the template has one (CE_SA_SPLIT=0: CSR / CSC products)
@@ -1013,7 +1018,7 @@ static int vjp_lsqr_launch(ce_handle h, int B, const double *A_vals0, long sA_b,
     }
     {
         ProfScope ps(h, 1, (hipStream_t)stream);
-#define LAUNCH_SAL(RPV) hipLaunchKernelGGL(k_sa_lsqr<RPV>, dim3(B), dim3(NT), lds, (hipStream_t)stream, T, S, F, A_vals0, sA_b, per_inst, q_vals, sq_k, sq_b, x, y, s, dx, dy, dA_bm, dq_vals, sdq_k, sdq_b, adj_status, lsqr_iters, atol, btol, conlim, iter_lim > 0 ? iter_lim : 2 * (T.n + T.m + 1), sel, status_or, a_lds, sel_done)
+#define LAUNCH_SAL(RPV) hipLaunchKernelGGL(k_sa_lsqr<RPV>, dim3(B), dim3(NT), lds, (hipStream_t)stream, T, S, F, A_vals0, sA_b, per_inst, q_vals, sq_k, sq_b, x, y, s, dx, dy, dA_bm, dq_vals, sdq_k, sdq_b, adj_status, lsqr_iters, atol, btol, conlim, iter_lim > 0 ? iter_lim : 2 * (T.n + T.m + 1), sel, status_or, a_lds, sel_reset)
         if (RP == 0) LAUNCH_SAL(0); else if (RP == 16) LAUNCH_SAL(16); else if (RP == 32) LAUNCH_SAL(32); else LAUNCH_SAL(64);
 #undef LAUNCH_SAL
     }
