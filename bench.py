@@ -237,7 +237,7 @@ def build_workload(config, B, seeds, dev):
             if A1t is None:
                 A1, _ = tpl.values_from_dense(A[None], b[None], c[:1])
                 A1t = torch.from_numpy(A1[:, 0]).to(dev)[None, :].repeat(B, 1).contiguous().t().requires_grad_()      # (nnz_aug, B) view of batch-major storage: what the frontend hands over
-            q = torch.from_numpy(np.concatenate([c.T, np.zeros((1, B))], axis=0)).to(dev).requires_grad_()
+            q = torch.from_numpy(np.ascontiguousarray(np.concatenate([c.T, np.zeros((1, B))], axis=0))).to(dev).requires_grad_()
             batches.append((A1t, q))
         return tpl, cones, batches, f"config C5: portfolio n={tpl.n} m={tpl.m} (1 zero + 500 nonneg + SOC(51)), A and b shared, mu batched"
     cfg = P.CONFIGS[config]

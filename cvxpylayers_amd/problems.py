@@ -66,7 +66,7 @@ class ConeTemplate:
         aug = np.concatenate([-A, b[:, :, None]], axis=2)
         cols = np.repeat(np.arange(self.n + 1), np.diff(self.indptr))
         A_eval = aug[:, self.indices, cols].T.copy()
-        q_eval = np.concatenate([c.T, np.zeros((1, B))], axis=0)
+        q_eval = np.ascontiguousarray(np.concatenate([c.T, np.zeros((1, B))], axis=0))      # (n+1, B) row-major like the reference's q_map product (np.concatenate of a transposed view comes out column-major: autograd then copies every dq into that layout)
         return A_eval, q_eval
 
 
