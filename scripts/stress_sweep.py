@@ -1,5 +1,5 @@
 """Randomised sweep of the engine against the CPU oracle: tests/stress_kit.py (what it checks) run for as many shapes / seeds as asked.
-usage: stress_sweep.py [n_shapes] [seed] [B]      (GPU box; exit code 1 when a check fails)"""
+usage: stress_sweep.py [n_shapes] [seed] [B] [ext]      (GPU box; exit code 1 when a check fails)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -8,7 +8,8 @@ from stress_kit import sweep
 n_shapes = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 B = int(sys.argv[3]) if len(sys.argv) > 3 else 16
+ext = len(sys.argv) > 4 and sys.argv[4] == "ext"          # PSD / exponential / power cones too
 t0 = time.time()
-fails, notes, _ = sweep(n_shapes, seed0, B)
+fails, notes, _ = sweep(n_shapes, seed0, B, ext=ext)
 print(f"{n_shapes} shapes (seed {seed0}, B {B}): {len(fails)} failed, {len(notes)} with notes (iteration counts / inaccurate statuses), {time.time() - t0:.0f} s")
 sys.exit(1 if fails else 0)

@@ -23,9 +23,15 @@ def boundary(tpl, g, n):
     return want
 
 
-def random_shape(rng):
+def random_shape(rng, ext=False):
     n = int(rng.choice([1, 2, 3, 5, 8, 13, 14, 15, 22, 30, 31, 40, 50, 51, 62, 75, 98, 104, 110]))
     cones = {"z": 0, "l": 0, "q": []}
+    if ext:      # PSD blocks / exponential / power triples too (smaller n: the eigen-solves of the oracle are slow)
+        n = int(rng.choice([2, 3, 5, 8, 13, 14, 20, 30, 40, 55]))
+        kind = rng.integers(0, 3)
+        if kind != 1: cones["s"] = [int(k) for k in rng.integers(2, 7, size=int(rng.integers(1, 3)))]
+        if kind != 0: cones["ep"] = int(rng.integers(1, 5))
+        if kind == 2 and rng.random() < 0.5: cones["p"] = [float(rng.choice([0.3, 0.5, -0.6]))]
     budget = int(rng.integers(max(n, 2), 2 * n + 12))          # rows: m >= n mostly (bounded problems)
     if rng.random() < 0.4:
         cones["z"] = int(rng.integers(1, max(2, n // 3 + 1)))
@@ -35,17 +41,18 @@ def random_shape(rng):
         d = int(rng.integers(2, max(3, min(n + 1, 26))))
         if rows + d > budget: break
         cones["q"].append(d); rows += d
+    rows += P.cone_rows({k: v for k, v in cones.items() if k in ("s", "ep", "p")})
     cones["l"] = max(budget - rows, 1 if not cones["q"] else 0)
     dens = float(rng.choice([1.0, 1.0, 0.6, 0.3]))
     return n, cones, dens
 
 
-def sweep(n_shapes=40, seed0=1, B=16, verbose=True):
+def sweep(n_shapes=40, seed0=1, B=16, verbose=True, ext=False):
     rng = np.random.default_rng(seed0)
     dev = torch.device("cuda", 0)
     fails, notes, lines = [], [], []
     for it in range(n_shapes):
-        n, cones, dens = random_shape(rng)
+        n, cones, dens = random_shape(rng, ext)
         m = P.cone_rows(cones)
         pat = rng.random((m, n)) < dens
         pat[np.arange(m), rng.integers(0, n, m)] = True

@@ -11,3 +11,10 @@ def test_random_templates_forward_and_default_adjoint_against_the_oracle():
     from stress_kit import sweep
     fails, notes, lines = sweep(48, 11, 12, verbose=False)
     assert not fails, "\n".join(l for l in lines if l.startswith("FAIL"))
+
+
+def test_random_templates_with_psd_exponential_and_power_cones():
+    """the same sweep with PSD blocks, exponential and power triples in the mix (pivoting adjoint kernels + LSQR re-solve)"""
+    from stress_kit import sweep
+    fails, notes, lines = sweep(36, 5, 10, verbose=False, ext=True)
+    assert not fails, "\n".join(l for l in lines if l.startswith("FAIL"))
