@@ -135,3 +135,88 @@ def sweep(n_shapes=40, seed0=1, B=16, verbose=True, ext=False):
         if info_msgs: notes.append(tag)
         del eng
     return fails, notes, lines
+
+
+def sweep_shared(n_shapes=20, seed0=1, B=12, verbose=True):
+    """Shared-A templates (only b, c vary over the batch: the persistent kernels k_sa_fwd / k_sa_lsqr, or the batch-GEMM fallback when a column has no
+    single-entry row): canonicalisation-shaped structure -- a few dense rows (equalities / inequalities), a bound on every variable, second-order and PSD blocks
+    made of single-entry rows.  Forward against the oracle at eps 1e-9; the adjoint (diffcp's LSQR on the full system) against the oracle's LSQR mode under the
+    same tight rule.  CE_CONST_A=1 must be in the environment BEFORE the first engine is built (the caller sets it)."""
+    rng = np.random.default_rng(seed0)
+    dev = torch.device("cuda", 0)
+    fails, notes, lines = [], [], []
+    for it in range(n_shapes):
+        n = int(rng.choice([6, 10, 16, 24, 40, 64, 100, 150]))
+        rz, rl = int(rng.integers(0, 4)), int(rng.integers(0, 5))
+        bounded = rng.random() < 0.8                      # a bound row on every variable (else some columns have no single-entry row: fallback path)
+        qdims, sdims, used = [], [], 0
+        for _ in range(int(rng.integers(0, 4))):
+            d = int(rng.integers(2, 9))
+            if used + d <= n: qdims.append(d); used += d
+        if n - used >= 6 and rng.random() < 0.4:
+            k = int(rng.choice([2, 3])); sdims.append(k); used += k * (k + 1) // 2
+        nb = n if bounded else max(n // 2, 1)
+        cones = {"z": rz, "l": rl + nb, "q": qdims, "s": sdims}
+        m = P.cone_rows(cones)
+        A0 = np.zeros((m, n)); r = 0
+        for _ in range(rz + rl):
+            cols = rng.random(n) < rng.choice([1.0, 0.5]); cols[rng.integers(0, n)] = True
+            A0[r, cols] = rng.standard_normal(int(cols.sum())) / np.sqrt(n); r += 1
+        bcols = np.arange(n) if bounded else rng.choice(n, nb, replace=False)
+        for j in bcols: A0[r, j] = -(0.5 + rng.random()); r += 1
+        var = 0
+        for d in qdims:
+            for _ in range(d): A0[r, var] = -(0.5 + rng.random()); r += 1; var += 1
+        for k in sdims:
+            for _ in range(k * (k + 1) // 2): A0[r, var] = -1.0; r += 1; var += 1
+        assert r == m
+        seed = int(rng.integers(1 << 30))
+        tag = f"shared shape {it}: n={n} m={m} cones={cones} bounded={bounded} seed={seed}"
+        msgs, info_msgs = [], []
+        r2 = np.random.default_rng(seed)
+        x0 = r2.standard_normal((B, n)) * 0.5; s0, y0 = P._interior_point(r2, cones, B)
+        A = np.broadcast_to(A0, (B,) + A0.shape).copy()
+        b = x0 @ A0.T + s0; c = -(y0 @ A0)
+        tpl = P.dense_template(n, cones, pattern=(A0 != 0))
+        rank_A = int(np.linalg.matrix_rank(A0))
+        if rank_A < n: tag += f" rank(A)={rank_A}"
+        ref = oracle.solve_batch(A, b, c, cones, eps=1e-9, max_iters=200000)
+        eng = ConeEngine(tpl.indices, tpl.indptr, tpl.n, tpl.m, tpl.cones, dev)
+        A_eval, q_eval = tpl.values_from_dense(A, b, c)
+        A_bm = eng.to_batch_major(torch.from_numpy(A_eval).to(dev)); q_t = torch.from_numpy(q_eval).to(dev)
+        x, y, s, iters, status, resid = eng.solve(A_bm, q_t, make_settings(dict(eps=1e-9, max_iters=200000, acceleration_lookback=0)))
+        torch.cuda.synchronize()
+        path = f"{eng.last_path}/{getattr(eng, 'last_const_a_kernel', None)}"
+        st = status.cpu().numpy()
+        if eng.last_path != "const_a": msgs.append(f"path {eng.last_path}")
+        if not np.isin(st[ref["status"] == 1], (1, 2)).all(): msgs.append(f"status {st} vs {ref['status']}")
+        elif not (st == ref["status"]).all(): info_msgs.append(f"status {st} vs {ref['status']}")
+        ok = (st == 1) & (ref["status"] == 1)
+        if ok.any():
+            for nm, got, want in (("x", x, ref["x"]), ("y", y, ref["y"]), ("s", s, ref["s"])):
+                if nm == "x" and rank_A < n: continue          # (columns that only meet a few dense rows: A has a null space, the primal solution is not unique)
+                err = (np.abs(got.cpu().numpy() - want).max(axis=1) / (1 + np.abs(want).max(axis=1)))[ok]
+                if err.max() > 2e-6: msgs.append(f"{nm} err {err.max():.2e}")
+        if ok.sum() >= 2:
+            idx = np.nonzero(ok)[0]
+            dx = rng.standard_normal((len(idx), n)); dy = rng.standard_normal((len(idx), m))
+            xr, yr, sr = (torch.from_numpy(np.ascontiguousarray(ref[k][idx])).to(dev) for k in ("x", "y", "s"))
+            A_sub = A_bm[torch.from_numpy(idx).to(dev)].contiguous(); q_sub = q_t[:, torch.from_numpy(idx).to(dev)].contiguous()
+            dA, dq, adj = eng.vjp(A_sub, xr, yr, sr, torch.from_numpy(dx).to(dev), torch.from_numpy(dy).to(dev), path="const_a", lsqr=TIGHT_LSQR, q_eval=q_sub)
+            torch.cuda.synchronize()
+            a = adj.cpu().numpy(); got = dA.cpu().numpy(); gq = dq.cpu().numpy()
+            if not (np.isfinite(got).all() and np.isfinite(gq).all()): msgs.append("non-finite gradients")
+            gl = oracle.adjoint_batch(A[idx], b[idx], c[idx], cones, ref["x"][idx], ref["y"][idx], ref["s"][idx], dx, dy, mode="lsqr",
+                                      lsqr_atol=TIGHT_LSQR[0], lsqr_btol=TIGHT_LSQR[1], lsqr_iter_lim=TIGHT_LSQR[2])
+            wl = boundary(tpl, gl, n)
+            el = np.maximum(np.abs(got - wl).max(axis=0) / (1 + np.abs(wl).max(axis=0)), np.abs(gq[:n] - gl["dc"].T).max(axis=0) / (1 + np.abs(gl["dc"]).max(axis=1)))
+            conv = (a & 1) == 0                               # (LSQR runs that stopped at the iteration limit are reported, not compared)
+            if conv.any() and (el[conv].max() > 5e-3 or np.median(el[conv]) > 1e-5): msgs.append(f"adjoint err max {el[conv].max():.2e} median {np.median(el[conv]):.2e}")
+            if not conv.all(): info_msgs.append(f"{int((~conv).sum())} LSQR runs at the iteration limit")
+        line = (("FAIL " if msgs else "ok   ") + tag + f" | solved {int(ok.sum())}/{B} path {path}" + "".join(" | " + mm for mm in msgs) + "".join(" | note: " + mm[:160] for mm in info_msgs))
+        lines.append(line)
+        if verbose: print(line, flush=True)
+        if msgs: fails.append(tag)
+        if info_msgs: notes.append(tag)
+        del eng
+    return fails, notes, lines

@@ -18,3 +18,12 @@ def test_random_templates_with_psd_exponential_and_power_cones():
     from stress_kit import sweep
     fails, notes, lines = sweep(36, 5, 10, verbose=False, ext=True)
     assert not fails, "\n".join(l for l in lines if l.startswith("FAIL"))
+
+
+def test_random_shared_A_templates(monkeypatch):
+    """shared-A templates in the shape canonicalisation produces (dense rows + bounds + cone blocks of single-entry rows): the persistent kernels k_sa_fwd /
+    k_sa_lsqr and the batch-GEMM fallback against the oracle (forward at eps 1e-9, diffcp's LSQR adjoint on the full system under a tight rule)"""
+    monkeypatch.setenv("CE_CONST_A", "1")
+    from stress_kit import sweep_shared
+    fails, notes, lines = sweep_shared(30, 3, 10, verbose=False)
+    assert not fails, "\n".join(l for l in lines if l.startswith("FAIL"))
