@@ -60,7 +60,8 @@ __host__ __device__ inline size_t sa_lsqr_lds_doubles(int n, int m, int nq, int 
 
 // RP > 0: A is applied through its split into singleton rows and r <= RP dense rows (ce_shared_a_ops.h: balanced, wide loads); RP == 0: through
 // the CSR / CSC structure (any sparsity pattern, but rows of very different lengths serialise on the longest).
-template <int RP>
+// HPSD / HTRI: the template has PSD blocks / exponential-power triples (false: their code is compiled out -- the plain-cone instantiation carried 50 spilled VGPRs of it)
+template <int RP, bool HPSD = true, bool HTRI = true>
 __global__ void __launch_bounds__(NT, 3)
 k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, long sAb, int per_inst, const double *__restrict__ qg, long sqk, long sqb, const double *__restrict__ xg, const double *__restrict__ yg,
           const double *__restrict__ sg, const double *__restrict__ dxg, const double *__restrict__ dyg, double *__restrict__ dAo,
@@ -74,10 +75,10 @@ k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, long
     // ce_vjp alternates TWO lists: while this launch walks `sel`, it empties the other one (walked by the previous call's launch, appended to by the next call's
     // elimination kernel) -- no memset launch per call, and no exit ticket (768 atomics on one address cost 7 us: measured)
     if (sel_reset && blockIdx.x == 0 && tid == 0) *sel_reset = 0;
-    const int n = T.n, m = T.m, z = T.z, nl = T.l, nq = T.nq, ns = T.ns;
+    const int n = T.n, m = T.m, z = T.z, nl = T.l, nq = T.nq, ns = HPSD ? T.ns : 0;
     const int KP = ns > 0 ? psd_mfma_kp(T.maxs) : 0, P = KP + 1, PM = KP * P;
     const float rKP = KP > 0 ? 1.0f / (float)KP : 1.0f;
-    const int ntri = T.nep + T.np;
+    const int ntri = HTRI ? T.nep + T.np : 0;
     const int psd_first = ns > 0 ? T.soff[0] : T.eoff, nvv = psd_first + (psd_first & 1);      // rows in front of the PSD blocks / the triples
     double *p = sm;                                          // (everything read with 16-byte accesses sits at the start: even sizes only)
     double *wyd = p, *vd = p, *part = p;
@@ -131,7 +132,7 @@ k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, long
             socs[4 * c + 2] = (r1 - r0 == 1) ? (t >= 0 ? 0.0 : 1.0) : (nz <= t ? 0.0 : (nz <= -t ? 1.0 : 2.0));     // 0 identity, 1 zero, 2 boundary
         }
     }
-    for (int c = tid; c < ntri; c += NT) {   // D Pi_K*(v) of every triple (k_ca_triple_jac; symmetrised like the batched path does)
+    if constexpr (HTRI) for (int c = tid; c < ntri; c += NT) {   // D Pi_K*(v) of every triple (k_ca_triple_jac; symmetrised like the batched path does)
         const int e0 = T.eoff + 3 * c;
         const double v3[3] = {y[e0] - s[e0], y[e0 + 1] - s[e0 + 1], y[e0 + 2] - s[e0 + 2]};
         double w3[3] = {-v3[0], -v3[1], -v3[2]}, J[9];
@@ -143,7 +144,7 @@ k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, long
         }
         for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Jt[9 * c + 3 * i + j] = 0.5 * (J[3 * i + j] + J[3 * j + i]);
     }
-    for (int c = 0; c < ns; c++) {      // eigenvectors and divided differences of every PSD block (cold Jacobi, once)
+    if constexpr (HPSD) for (int c = 0; c < ns; c++) {      // eigenvectors and divided differences of every PSD block (cold Jacobi, once)
         const int k = T.sord[c];
         double *U = Um + (size_t)c * PM, *Bc = Bm + (size_t)c * PM;
         const double *ys = y + T.soff[c], *ss = s + T.soff[c];
@@ -202,7 +203,7 @@ k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, long
             }
             sink(i, o);
         }
-        for (int c = 0; c < ns; c++) {      // PSD block: Z = U (B o (U^T H U)) U^T on the matrix cores
+        if constexpr (HPSD) for (int c = 0; c < ns; c++) {      // PSD block: Z = U (B o (U^T H U)) U^T on the matrix cores
             const int k = T.sord[c], off = T.soff[c], KT = KP / 16;
             const double *U = Um + (size_t)c * PM, *Bc = Bm + (size_t)c * PM;
             for (int idx = tid; idx < KP * KP; idx += NT) {
@@ -228,7 +229,7 @@ k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, long
             }
             if (c + 1 < ns) __syncthreads();                       // (Hm is reused by the next block)
         }
-        for (int c = tid; c < ntri; c += NT) {     // triples: o = J h (the thread reads its three entries before it sinks them)
+        if constexpr (HTRI) for (int c = tid; c < ntri; c += NT) {     // triples: o = J h (the thread reads its three entries before it sinks them)
             const int e0 = T.eoff + 3 * c;
             const double h0 = h[e0] * hs, h1 = h[e0 + 1] * hs, h2 = h[e0 + 2] * hs;
             const double *J = Jt + 9 * c;

@@ -45,6 +45,7 @@ namespace {
 #include "ce_psd_mfma.h"
 #include "ce_const_a.h"
 #include "ce_shared_a.h"
+#include "ce_shared_a_mi.h"
 #include "ce_shared_a_fwd.h"
 }  // namespace
 
@@ -70,7 +71,7 @@ struct ce_engine {
     int *d_csc_ptr = nullptr, *d_csr_ptr = nullptr, *d_csr_col = nullptr, *d_csr_src = nullptr;   // sparse structure of the A part (shared-A kernels)
     // split of the A part into singleton rows and sp_r <= 64 dense rows (ce_shared_a_ops.h); sp_RP == 0: more than 64 rows with several entries
     int sp_r = 0, sp_RP = 0;
-    bool sa_fwd_attr = false, sa_lsqr_attr = false;
+    bool sa_fwd_attr = false, sa_lsqr_attr = false, sa_lsqr_mi_attr = false;
     int *d_summary = nullptr; unsigned summary_next = 0;   // ce_status_summary staging (8 slots of 3 ints)
     double *d_aa_ws = nullptr; size_t aa_ws_bytes = 0;   // Anderson-acceleration history of the shared-A forward kernel ([B][4][lp])
     unsigned long long *d_psd_stats = nullptr;     // CE_PSD_STATS=1: counters of the PSD projection (printed to stderr by ce_destroy)   // MaxDynamicSharedMemorySize is per device: set once per engine (an engine is bound to one device, one caller thread)
@@ -1003,8 +1004,9 @@ static int vjp_lsqr_launch(ce_handle h, int B, const double *A_vals0, long sA_b,
     }
     HIPCHK(hipSetDevice(h->device));
     if (!h->sa_lsqr_attr) {
-#define SA_ATTR(RPV) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sa_lsqr<RPV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT))
-        SA_ATTR(0); SA_ATTR(16); SA_ATTR(32); SA_ATTR(64);
+#define SA_ATTR(...) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sa_lsqr<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT))
+        SA_ATTR(0); SA_ATTR(16); SA_ATTR(32); SA_ATTR(64); SA_ATTR(0, false, false); SA_ATTR(16, false, false); SA_ATTR(32, false, false); SA_ATTR(64, false, false);
+        SA_ATTR(16, true, false); SA_ATTR(32, true, false); SA_ATTR(64, true, false);
 #undef SA_ATTR
         h->sa_lsqr_attr = true;
     }
@@ -1016,10 +1018,40 @@ static int vjp_lsqr_launch(ce_handle h, int B, const double *A_vals0, long sA_b,
         HIPCHK(hipMemsetAsync(h->d_sp_sing_v, 0, sizeof(double) * T.n, (hipStream_t)stream));
         if (T.nnzA > 0) hipLaunchKernelGGL(k_sa_fill_split, dim3((T.nnzA + 255) / 256), dim3(256), 0, (hipStream_t)stream, T.nnzA, RP, h->d_rowidx, h->d_colidx, h->d_sp_rowslot, A_vals0, h->d_sp_AdT, h->d_sp_sval, h->d_sp_sing_i, h->d_sp_sing_v);
     }
+    // Several instances per workgroup share the stream over A_d^T (ce_shared_a_mi.h) where the template allows it: plain cones, the split's products, the solution
+    // in the owners' registers, no re-solve list, and enough instances to fill the device either way.  CE_SA_LSQR_NI=1 keeps one instance per workgroup (A/B), 2 / 3 force.
+    int ni = 0;
+    if (RP > 0 && !per_inst && !sel && T.ns == 0 && T.nep + T.np == 0 && T.n <= SAMI_EL * 256 && T.m <= SAMI_EL * 256) {
+        ni = 0;      // (measured slower than one instance per workgroup at config 5: profiles/r06/n_*; opt-in)
+        if (const char *e = getenv("CE_SA_LSQR_NI")) { const int v = atoi(e); ni = (v == 2 || v == 3) ? v : 0; }
+        while (ni >= 2 && sa_lsqr_mi_lds_doubles(T.n, T.m, T.nq, RP, ni) * 8 > LDS_LIMIT) ni--;
+        if (ni < 2) ni = 0;
+    }
+    if (ni) {
+        if (!h->sa_lsqr_mi_attr) {
+#define SA_ATTR(RPV, NIV) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sa_lsqr_mi<RPV, NIV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT))
+            SA_ATTR(16, 2); SA_ATTR(32, 2); SA_ATTR(64, 2); SA_ATTR(16, 3); SA_ATTR(32, 3); SA_ATTR(64, 3);
+#undef SA_ATTR
+            h->sa_lsqr_mi_attr = true;
+        }
+        const size_t lds_mi = sa_lsqr_mi_lds_doubles(T.n, T.m, T.nq, RP, ni) * 8;
+        ProfScope ps(h, 1, (hipStream_t)stream);
+#define LAUNCH_MI(RPV, NIV) hipLaunchKernelGGL((k_sa_lsqr_mi<RPV, NIV>), dim3((B + NIV - 1) / NIV), dim3(NIV * 256), lds_mi, (hipStream_t)stream, T, S, F, A_vals0, sA_b, q_vals, sq_k, sq_b, x, y, s, dx, dy, dA_bm, dq_vals, sdq_k, sdq_b, adj_status, lsqr_iters, atol, btol, conlim, iter_lim > 0 ? iter_lim : 2 * (T.n + T.m + 1), B)
+        if (ni == 2) { if (RP == 16) LAUNCH_MI(16, 2); else if (RP == 32) LAUNCH_MI(32, 2); else LAUNCH_MI(64, 2); }
+        else { if (RP == 16) LAUNCH_MI(16, 3); else if (RP == 32) LAUNCH_MI(32, 3); else LAUNCH_MI(64, 3); }
+#undef LAUNCH_MI
+        HIPCHK(hipGetLastError());
+        return CE_OK;
+    }
     {
         ProfScope ps(h, 1, (hipStream_t)stream);
-#define LAUNCH_SAL(RPV) hipLaunchKernelGGL(k_sa_lsqr<RPV>, dim3(B), dim3(NT), lds, (hipStream_t)stream, T, S, F, A_vals0, sA_b, per_inst, q_vals, sq_k, sq_b, x, y, s, dx, dy, dA_bm, dq_vals, sdq_k, sdq_b, adj_status, lsqr_iters, atol, btol, conlim, iter_lim > 0 ? iter_lim : 2 * (T.n + T.m + 1), sel, status_or, a_lds, sel_reset)
-        if (RP == 0) LAUNCH_SAL(0); else if (RP == 16) LAUNCH_SAL(16); else if (RP == 32) LAUNCH_SAL(32); else LAUNCH_SAL(64);
+#define LAUNCH_SAL(...) hipLaunchKernelGGL((k_sa_lsqr<__VA_ARGS__>), dim3(B), dim3(NT), lds, (hipStream_t)stream, T, S, F, A_vals0, sA_b, per_inst, q_vals, sq_k, sq_b, x, y, s, dx, dy, dA_bm, dq_vals, sdq_k, sdq_b, adj_status, lsqr_iters, atol, btol, conlim, iter_lim > 0 ? iter_lim : 2 * (T.n + T.m + 1), sel, status_or, a_lds, sel_reset)
+        // plain cones / PSD without triples: instantiations without the other cones' code (CE_SA_LSQR_SPEC=0: the general kernel)
+        const bool tri = T.nep + T.np > 0, psd = T.ns > 0;
+        int spec = 1; if (const char *e = getenv("CE_SA_LSQR_SPEC")) spec = atoi(e);
+        if (spec && !tri && !psd) { if (RP == 0) LAUNCH_SAL(0, false, false); else if (RP == 16) LAUNCH_SAL(16, false, false); else if (RP == 32) LAUNCH_SAL(32, false, false); else LAUNCH_SAL(64, false, false); }
+        else if (spec && !tri && RP > 0) { if (RP == 16) LAUNCH_SAL(16, true, false); else if (RP == 32) LAUNCH_SAL(32, true, false); else LAUNCH_SAL(64, true, false); }
+        else if (RP == 0) LAUNCH_SAL(0); else if (RP == 16) LAUNCH_SAL(16); else if (RP == 32) LAUNCH_SAL(32); else LAUNCH_SAL(64);
 #undef LAUNCH_SAL
     }
     HIPCHK(hipGetLastError());

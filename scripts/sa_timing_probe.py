@@ -42,3 +42,15 @@ for k, nm in ((0, "N v: both products (fused pass over A_d^T + row loop)"), (1, 
               (3, "u scaling + q = D Pi(u_y)"), (4, "N^T u: both products"), (5, "|v-hat| (block reduce)"), (6, "v, w, r updates"), (7, "scalar recurrences / loop top")):
     print(f"  {nm:62s} {t[:, k].mean():10.1f} cycles / LSQR iteration")
 print(f"  {'sum':62s} {t.sum(axis=1).mean():10.1f}")
+
+# ---- the multi-instance adjoint kernel (k_sa_lsqr_mi, CE_SA_LSQR_NI=2|3): stamps of the workgroup's first thread, per iteration of the workgroup (= the slowest of its instances)
+ni = int(os.environ.get("CE_SA_LSQR_NI", "0") or 0)
+if ni >= 2:
+    t = dA.t()[::ni, :13].cpu().numpy()
+    lim = li[: (B // ni) * ni].reshape(-1, ni).max(axis=1)[:, None]
+    t = t[: lim.shape[0]] / lim
+    print(f"k_sa_lsqr_mi NI={ni}: workgroup iterations mean", float(lim.mean()))
+    for k, nm in enumerate(("A: dense entries of v_y", "A: streaming pass", "A: wait at the pass's barrier", "A: row loop", "D Pi (t_y) + u-hat_y", "|u-hat| (reduce)", "u scaling, q = D Pi(u_y), publish",
+                            "E: dense entries of q", "E: streaming pass", "E: wait at the pass's barrier", "E: row loop", "|v-hat| (reduce)", "v, w, r updates, stop tests, live mask")):
+        print(f"  {nm:62s} {t[:, k].mean():10.1f} cycles / iteration")
+    print(f"  {'sum':62s} {t.sum(axis=1).mean():10.1f}")

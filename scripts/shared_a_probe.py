@@ -32,10 +32,15 @@ VARIANTS = {
     "k1024":      dict(CE_SA_FWD="1", CE_SA_KERNEL="1", CE_SA_NT="1024"),
     "kcsr":       dict(CE_SA_FWD="1", CE_SA_KERNEL="1", CE_SA_SPLIT="0"),
     "default":    dict(),
+    # the adjoint kernel: one instance per workgroup (k_sa_lsqr) against NI instances sharing the stream over A_d^T (k_sa_lsqr_mi)
+    "ni1":        dict(CE_SA_LSQR_NI="1"),
+    "spec0":      dict(CE_SA_LSQR_SPEC="0"),
+    "ni2":        dict(CE_SA_LSQR_NI="2"),
+    "ni3":        dict(CE_SA_LSQR_NI="3"),
     # the adjoint's LSQR stopping rule: rounds 1-4 (atol = btol = 1e-12, 4 (n + m) iterations) against diffcp's (1e-8, 1e-8, 2 (n + m + 1): the default since round 5)
     "tight":      dict(_args=dict(lsqr_atol=1e-12, lsqr_btol=1e-12, lsqr_iter_lim=4 * (tpl.n + tpl.m))),
 }
-KEYS = ("CE_SA_FWD", "CE_SA_KERNEL", "CE_SA_NT", "CE_SA_SPLIT")
+KEYS = ("CE_SA_FWD", "CE_SA_KERNEL", "CE_SA_NT", "CE_SA_SPLIT", "CE_SA_LSQR_NI", "CE_SA_LSQR_SPEC")
 ref = None
 res = []
 wts = torch.from_numpy(np.random.default_rng(5).standard_normal((tpl.n, B))).to(dev) if True else None
@@ -62,6 +67,15 @@ for name in (want or ["torch", "k512", "k256", "default"]):
     if ref is None: ref = (x.clone(), g.clone(), gA.clone())
     else:
         out["dx_max"] = float((x - ref[0]).abs().max()); out["dgq_rel"] = float((g - ref[1]).abs().max() / (1e-300 + ref[1].abs().max())); out["dgA_rel"] = float((gA - ref[2]).abs().max() / (1e-300 + ref[2].abs().max()))
+    if getattr(eng, "last_lsqr_iters", None) is not None:
+        li = eng.last_lsqr_iters.double().cpu().numpy()
+        out["lsqr_iters_pct"] = [float(v) for v in np.percentile(li, [5, 25, 50, 75, 95])]
+        for g_ in (2, 3, 4):
+            k_ = (len(li) // g_) * g_
+            out[f"lsqr_group{g_}_max_over_mean"] = float(li[:k_].reshape(-1, g_).max(axis=1).mean() / li.mean())
+        if name.startswith("ni"):
+            if "li_ref" in globals(): out["lsqr_iters_maxdiff"] = float(np.abs(li - li_ref).max())
+            else: li_ref = li
     eng.last_lsqr_iters = None
     print(json.dumps(out), flush=True); res.append(out)
 os.makedirs("gpurun_out/sap", exist_ok=True)
