@@ -593,12 +593,12 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
     auto materialize_at = [&](const Co &co) {
         const double ej = sm[L::O_EV + (co.j1 < NP ? co.j1 : 0)];
         const double *dv = sm + L::O_DV + T1 * co.c1;
-        gather_tile<T1>(idx_at, co.t, vals, [&](int k, int ix, double v) { at[k] = (-v * (dv[k] * ej)) * (ix >= 0 ? 1.0 : 0.0); });
+        gather_tile<T1>(idx_at, co.t, vals, [&](int k, int ix, double v) { at[k] = ix >= 0 ? -v * (dv[k] * ej) : 0.0; });
     };
     auto materialize_ar = [&](const Co &co) {
         const double di = sm[L::O_DV + (co.i2 < MP ? co.i2 : 0)];
         const double *evs = sm + L::O_EV + T2 * co.c2;
-        gather_tile<T2>(idx_ar, co.t, vals, [&](int k, int ix, double v) { ar[k] = (-v * (di * evs[k])) * (ix >= 0 ? 1.0 : 0.0); });
+        gather_tile<T2>(idx_ar, co.t, vals, [&](int k, int ix, double v) { ar[k] = ix >= 0 ? -v * (di * evs[k]) : 0.0; });
     };
     // P-hat row segment of the (jg, cg) layout, re-materialised wherever it is needed (S formation, P-hat g_x, the residual check)
     double gPg = 0;                                                  // g_x^T P-hat g_x
@@ -607,7 +607,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
         const double *pv = Pvals_g + (size_t)inst * nnzP;
         const double ej = sm[L::O_EV + (co.jg < NP ? co.jg : 0)];
         const double *evs = sm + L::O_EV + TG * co.cg;
-        gather_tile<TG>(idx_p, co.t, pv, [&](int k, int ix, double v) { pg[k] = (v * (ej * evs[k])) * (ix >= 0 ? 1.0 : 0.0); });
+        gather_tile<TG>(idx_p, co.t, pv, [&](int k, int ix, double v) { pg[k] = ix >= 0 ? v * (ej * evs[k]) : 0.0; });
     };
     // The column groups j1 == n and j1 == n + 1 (idle in the A^T product) carry phi as two extra "columns", so that the
     // A^T w_y phase also yields phi_y . w_y and phi_x . w_x (the numerator of tau-tilde) without a separate reduction.

@@ -307,8 +307,10 @@ k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, long
     };
     auto safe = [](double t) -> double { return t > 0 ? t : 1.0; };
     // (sum of squares, tau-row dot product) over the workgroup in one reduction
-    auto sum_two = [&](double v, double w, double &wsum) -> double { double r[2] = {v, w}; block_reduce<2>(r, 0u, red); wsum = r[1]; return r[0]; };
-    auto sum_three = [&](double v, double w, double u3, double &wsum, double &usum) -> double { double r[3] = {v, w, u3}; block_reduce<3>(r, 0u, red); wsum = r[1]; usum = r[2]; return r[0]; };
+    // (the sums come back workgroup-uniform: through readfirstlane they and every scalar of the recurrences computed from them are known to be uniform and live in
+    // scalar registers across the phases -- ~20 loop-carried doubles that otherwise hold 40 VGPRs of a kernel that sits at its 168-VGPR ceiling)
+    auto sum_two = [&](double v, double w, double &wsum) -> double { double r[2] = {v, w}; block_reduce<2>(r, 0u, red); wsum = uniform_d(r[1]); return uniform_d(r[0]); };
+    auto sum_three = [&](double v, double w, double u3, double &wsum, double &usum) -> double { double r[3] = {v, w, u3}; block_reduce<3>(r, 0u, red); wsum = uniform_d(r[1]); usum = uniform_d(r[2]); return uniform_d(r[0]); };
 
     // ---- LSQR (Paige & Saunders) on  N r = dz,  N = M^T  (the tau components ut, vt, wt, rt are workgroup-uniform scalars in registers)
     //      N   (r_x, r_y, r_t) = ( -A^T r_y - c r_t ,  DPi(A r_x - b r_t - r_y) + r_y ,  c.r_x + b.r_y )
@@ -408,6 +410,9 @@ k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, long
         // conlim (1e8: ill-conditioned systems stop HERE, long before atol / btol are met) and the three machine-precision tests
         const double test3 = 1.0 / (anorm * sqrt(ddnorm) + 1e-300), tt1 = test1 / (1.0 + anorm * xnorm / safe(bnorm));
         if (test1 <= rtol || test2 <= atol || test3 <= ctol || 1.0 + test3 <= 1.0 || 1.0 + test2 <= 1.0 || 1.0 + tt1 <= 1.0) live = false;
+        alfa = uniform_d(alfa); beta = uniform_d(beta); ut = uniform_d(ut); vt = uniform_d(vt); wt = uniform_d(wt); rt = uniform_d(rt);
+        rhobar = uniform_d(rhobar); phibar = uniform_d(phibar); anorm = uniform_d(anorm); xxnorm = uniform_d(xxnorm); zz = uniform_d(zz);
+        cs2 = uniform_d(cs2); sn2 = uniform_d(sn2); ddnorm = uniform_d(ddnorm);
     }
     __syncthreads();
     // ---- outputs in the boundary convention: dA_eval = [-dA.data, db[b_idx]], dq_eval = [dc, 0]  (diffcp_if.py:91-92);

@@ -54,7 +54,8 @@ __host__ __device__ inline size_t sa_fwd_lds_doubles(int n, int m, int nq, int n
 // anyway: eight waves keep more loads of the shared matrix in flight and shorten every elementwise pass).
 // CIDX: the template's small index arrays (singleton structure, cone offsets) are copied to LDS once -- every iteration reads them, and from global
 // memory each dependent lookup is an exposed L2 round trip when a single workgroup owns the CU.
-template <int RP, int NTH, bool CIDX = false>
+// HTRI false: the template has no exponential / power triples (their projection code is compiled out of the instantiation BASELINE config 5 runs)
+template <int RP, int NTH, bool CIDX = false, bool HTRI = true>
 __global__ void __launch_bounds__(NTH, NTH == 256 ? 2 : 1)
 k_sa_fwd(DevT T, SaFwd F, ce_settings S, const double *__restrict__ BHg, const double *__restrict__ CHg, const double *__restrict__ sigma_g,
          const double *__restrict__ nb0_g, const double *__restrict__ nc0_g, const double *__restrict__ warm_x, const double *__restrict__ warm_y,
@@ -62,7 +63,8 @@ k_sa_fwd(DevT T, SaFwd F, ce_settings S, const double *__restrict__ BHg, const d
          int *__restrict__ iters_o, int *__restrict__ status_o, double *__restrict__ resid_o) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int tid = threadIdx.x, inst = blockIdx.x;
-    const int n = T.n, m = T.m, l = n + m + 1, lp = l + (l & 1), z = T.z, nl = T.l, nq = T.nq, ns = T.ns;
+    // (the 512-thread instantiations serve templates without PSD blocks only -- cone_engine.hip ce_solve_shared_a -- and are compiled without the projection's code)
+    const int n = T.n, m = T.m, l = n + m + 1, lp = l + (l & 1), z = T.z, nl = T.l, nq = T.nq, ns = NTH == 256 ? T.ns : 0;
     const int r = F.r, LK = RP + 1;
     constexpr int NT = NTH, NW = NTH / 64;                  // (shadow the engine-wide 256-thread constants)
     const int ne = n + (n & 1), me = m + (m & 1);           // even strides: every LDS vector below starts 16-byte aligned
@@ -83,7 +85,7 @@ k_sa_fwd(DevT T, SaFwd F, ce_settings S, const double *__restrict__ BHg, const d
     double *part = p; p += 2 * NT;                              // partial sums of the dense-row products
     double *red = p; p += NW * 8;
     double *sc = p; p += 32;
-    const int ntri = T.nep + T.np;
+    const int ntri = HTRI ? T.nep + T.np : 0;
     double *troot = p; p += ntri + (ntri & 1);              // exponential / power triples: root of the previous projection (warm start of the Newton iteration)
     double *aaW_lds = p; if (F.aa_w_lds) p += lp;           // Anderson acceleration: input of the last iteration
     const int *c_srow_col = F.srow_col, *c_rowcone = T.rowcone, *c_scol_ptr = F.scol_ptr, *c_scol_row = F.scol_row, *c_qoff = T.qoff, *c_drow = F.drow;
@@ -412,7 +414,7 @@ k_sa_fwd(DevT T, SaFwd F, ce_settings S, const double *__restrict__ BHg, const d
                     __syncthreads();
                 }
             }
-            if (ntri > 0) {    // exponential / power cone triples (after the PSD blocks): one thread per cone, in place (ce_expcone.h)
+            if constexpr (HTRI) if (ntri > 0) {    // exponential / power cone triples (after the PSD blocks): one thread per cone, in place (ce_expcone.h)
                 for (int c = tid; c < ntri; c += NT) {
                     double *zc = zb + n + T.eoff + 3 * c;
                     if (c < T.nep) exp_project_dual(zc, troot + c); else pow_project_dual_of_entry(zc, T.pw[c - T.nep], troot + c);

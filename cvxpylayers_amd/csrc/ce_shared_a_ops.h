@@ -3,6 +3,9 @@
 // the launch reads the same matrix); the singleton rows are a gather.  Both directions keep several wide, line-covering loads in flight
 // per lane: with one workgroup per instance the latency of the L2 stream, not its bandwidth, is what the products cost.
 #pragma once
+#ifndef SA_UR64
+#define SA_UR64 2
+#endif
 
 // fields the product routines read (SaFwd and SaSplit both carry them):
 //   r, AdT, drow[r], srow_col[m] (-1: not a singleton row), srow_val[m], scol_ptr[n + 1], scol_row[]
@@ -103,7 +106,7 @@ template <int NTH, int RP, class FE, class FO>
 __device__ __forceinline__ void sa_fused_pass(const double *__restrict__ AdT, int n, const double *w, const double *xin, FE &&extra, FO &&out, double *part,
                                               const int *__restrict__ sing_i = nullptr, const double *__restrict__ sing_v = nullptr, const double *yin = nullptr,
                                               const double *__restrict__ cex = nullptr, long cex_stride = 0) {
-    constexpr int NL = RP / 16, RS = NTH / 8, UR = RP == 64 ? 2 : 4;      // rows in flight per lane (RP = 64: two, the accumulators need the registers)
+    constexpr int NL = RP / 16, RS = NTH / 8, UR = RP == 64 ? SA_UR64 : 4;      // rows in flight per lane (RP = 64: two, the accumulators need the registers)
     const int tid = threadIdx.x, k8 = tid & 7;
     const double2 *w2 = reinterpret_cast<const double2 *>(w) + k8;
     double2 vacc[NL], wr[NL];          // (wr: this lane's entries of w, read once -- see sa_rows_dot)

@@ -73,6 +73,7 @@ struct ce_engine {
     int sp_r = 0, sp_RP = 0;
     bool sa_fwd_attr = false, sa_lsqr_attr = false, sa_lsqr_mi_attr = false;
     int *d_summary = nullptr; unsigned summary_next = 0;   // ce_status_summary staging (8 slots of 3 ints)
+    double *d_qT = nullptr; size_t qT_bytes = 0;         // batch-major copy of the objective values for the LSQR adjoint kernels (vjp_lsqr_launch)
     double *d_aa_ws = nullptr; size_t aa_ws_bytes = 0;   // Anderson-acceleration history of the shared-A forward kernel ([B][4][lp])
     unsigned long long *d_psd_stats = nullptr;     // CE_PSD_STATS=1: counters of the PSD projection (printed to stderr by ce_destroy)   // MaxDynamicSharedMemorySize is per device: set once per engine (an engine is bound to one device, one caller thread)
     int psd_first = 0;           // first row of the first PSD block (m when the template has none)
@@ -507,7 +508,7 @@ int ce_destroy(ce_handle h) {
     hipSetDevice(h->device);
     hipFree(h->d_rowidx); hipFree(h->d_colidx); hipFree(h->d_rowcone); hipFree(h->d_qoff); hipFree(h->d_soff); hipFree(h->d_sord); hipFree(h->d_pw); hipFree(h->d_idx_p); hipFree(h->d_pmap); hipFree(h->d_prow); hipFree(h->d_pcol);
     hipFree(h->wsA); hipFree(h->wsdA); hipFree(h->gws); hipFree(h->d_idx_at); hipFree(h->d_idx_ar); hipFree(h->d_idx_b); hipFree(h->d_order); hipFree(h->d_iters2); hipFree(h->d_iters_prev); hipFree(h->d_nkmax); if (h->h_nkmax) hipHostFree(h->h_nkmax); if (h->nk_ev) hipEventDestroy(h->nk_ev); hipFree(h->d_row_perm); hipFree(h->d_k_rowcone); hipFree(h->d_k_qoff); hipFree(h->d_csc_ptr); hipFree(h->d_csr_ptr); hipFree(h->d_csr_col); hipFree(h->d_csr_src);
-    hipFree(h->d_sp_drow); hipFree(h->d_sp_srow_col); hipFree(h->d_sp_scol_ptr); hipFree(h->d_sp_scol_row); hipFree(h->d_sp_rowslot); hipFree(h->d_sp_sing_i); hipFree(h->d_sp_sing_v); hipFree(h->d_sp_AdT); hipFree(h->d_sp_sval); hipFree(h->d_bpos); hipFree(h->d_aa_ws); hipFree(h->d_summary);
+    hipFree(h->d_sp_drow); hipFree(h->d_sp_srow_col); hipFree(h->d_sp_scol_ptr); hipFree(h->d_sp_scol_row); hipFree(h->d_sp_rowslot); hipFree(h->d_sp_sing_i); hipFree(h->d_sp_sing_v); hipFree(h->d_sp_AdT); hipFree(h->d_sp_sval); hipFree(h->d_bpos); hipFree(h->d_aa_ws); hipFree(h->d_qT); hipFree(h->d_summary);
     for (auto &v : h->ev) for (auto &p : v) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
     for (auto &e : h->ev_pool) hipEventDestroy(e);
     if (h->d_psd_stats) {
@@ -955,6 +956,7 @@ int ce_solve_shared_a(ce_handle h, int B, int r, int RP, const double *AdT, cons
     if (!h->sa_fwd_attr) {
 #define SA_ATTR(...) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sa_fwd<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT))
         SA_ATTR(16, 256); SA_ATTR(32, 256); SA_ATTR(64, 256); SA_ATTR(16, 512); SA_ATTR(32, 512); SA_ATTR(64, 512); SA_ATTR(16, 512, true); SA_ATTR(32, 512, true); SA_ATTR(64, 512, true);
+        SA_ATTR(16, 512, true, false); SA_ATTR(32, 512, true, false); SA_ATTR(64, 512, true, false);
 #undef SA_ATTR
         h->sa_fwd_attr = true;
     }
@@ -976,6 +978,7 @@ int ce_solve_shared_a(ce_handle h, int B, int r, int RP, const double *AdT, cons
 #define LAUNCH_SA(NTV, ...) hipLaunchKernelGGL((k_sa_fwd<__VA_ARGS__>), dim3(B), dim3(NTV), lds, (hipStream_t)stream, T, F, *settings, b_hat, c_hat, sigma, nrm_b0, nrm_c0, warm_x, warm_y, warm_s, x, y, s, iters, status, resid)
         if (nth == 256) { if (RP == 16) LAUNCH_SA(256, 16, 256); else if (RP == 32) LAUNCH_SA(256, 32, 256); else LAUNCH_SA(256, 64, 256); }
         else if (!cidx) { if (RP == 16) LAUNCH_SA(512, 16, 512); else if (RP == 32) LAUNCH_SA(512, 32, 512); else LAUNCH_SA(512, 64, 512); }
+        else if (T.nep + T.np == 0) { if (RP == 16) LAUNCH_SA(512, 16, 512, true, false); else if (RP == 32) LAUNCH_SA(512, 32, 512, true, false); else LAUNCH_SA(512, 64, 512, true, false); }
         else { if (RP == 16) LAUNCH_SA(512, 16, 512, true); else if (RP == 32) LAUNCH_SA(512, 32, 512, true); else LAUNCH_SA(512, 64, 512, true); }
 #undef LAUNCH_SA
     }
@@ -1009,6 +1012,16 @@ static int vjp_lsqr_launch(ce_handle h, int B, const double *A_vals0, long sA_b,
         SA_ATTR(16, true, false); SA_ATTR(32, true, false); SA_ATTR(64, true, false);
 #undef SA_ATTR
         h->sa_lsqr_attr = true;
+    }
+    // The streaming passes read c_j of their instance with every row of the matrix.  In the boundary's layout (q_eval (n + 1, B): consecutive j are B doubles apart) each of
+    // those loads is a line of its own, and the lines of all resident instances (config 5: 768 x 501 x 128 B) live in the memory-side cache, not in L2: the pass waited for
+    // THEM, not for the matrix.  One transpose per call gives every instance a contiguous c (4 KB, L2-resident for the whole solve).  Not for the re-solve list
+    // (a handful of instances; the launch sits on the metric configuration's hot path).
+    if (q_vals && !sel && sq_b == 1 && sq_k == (long)B && B > 1) {
+        int rc = ensure(&h->d_qT, &h->qT_bytes, sizeof(double) * (size_t)B * (T.n + 1));
+        if (rc) return rc;
+        launch_transpose((hipStream_t)stream, q_vals, h->d_qT, T.n + 1, B);
+        q_vals = h->d_qT; sq_k = 1; sq_b = T.n + 1;
     }
     SaStruct S{h->d_csc_ptr, h->d_rowidx, h->d_csr_ptr, h->d_csr_col, h->d_csr_src, T.nnzA, h->d_bpos};
     SaSplit F{h->sp_r, RP, h->d_sp_AdT, h->d_sp_drow, h->d_sp_srow_col, h->d_sp_sval, h->d_sp_scol_ptr, h->d_sp_scol_row, h->d_sp_rowslot, h->d_sp_sing_i, h->d_sp_sing_v};
