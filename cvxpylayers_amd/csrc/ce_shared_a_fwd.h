@@ -63,8 +63,7 @@ k_sa_fwd(DevT T, SaFwd F, ce_settings S, const double *__restrict__ BHg, const d
          int *__restrict__ iters_o, int *__restrict__ status_o, double *__restrict__ resid_o) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int tid = threadIdx.x, inst = blockIdx.x;
-    // (the 512-thread instantiations serve templates without PSD blocks only -- cone_engine.hip ce_solve_shared_a -- and are compiled without the projection's code)
-    const int n = T.n, m = T.m, l = n + m + 1, lp = l + (l & 1), z = T.z, nl = T.l, nq = T.nq, ns = NTH == 256 ? T.ns : 0;
+    const int n = T.n, m = T.m, l = n + m + 1, lp = l + (l & 1), z = T.z, nl = T.l, nq = T.nq, ns = T.ns;
     const int r = F.r, LK = RP + 1;
     constexpr int NT = NTH, NW = NTH / 64;                  // (shadow the engine-wide 256-thread constants)
     const int ne = n + (n & 1), me = m + (m & 1);           // even strides: every LDS vector below starts 16-byte aligned
