@@ -66,13 +66,12 @@ __global__ void __launch_bounds__(NT, 3)
 k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, long sAb, int per_inst, const double *__restrict__ qg, long sqk, long sqb, const double *__restrict__ xg, const double *__restrict__ yg,
           const double *__restrict__ sg, const double *__restrict__ dxg, const double *__restrict__ dyg, double *__restrict__ dAo,
           double *__restrict__ dqo, long sdqk, long sdqb, int *__restrict__ adj_status, int *__restrict__ iters_o, double atol, double btol, double conlim, int itn_lim,
-          const int *__restrict__ sel = nullptr, int status_or = 0, int a_lds_rot = 0, int *__restrict__ sel_reset = nullptr) {
+          const int *__restrict__ sel = nullptr, int status_or = 0, int a_lds = 0, int *__restrict__ sel_reset = nullptr) {
     // sel != nullptr (ce_vjp's re-solve of the instances its direct elimination flagged rank-deficient): sel[0] instances are listed in sel[1 ...] (appended by
     // the elimination kernel on the same stream); the grid is a fixed number of workgroups that walk the list -- the host never learns the count.  status_or is
     // OR-ed into the adj_status of every instance served (ce_vjp: 4 | 8 = "rank-deficient, re-solved by LSQR").
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int tid = threadIdx.x;
-    const int a_lds = a_lds_rot & 1, rot_step = a_lds_rot >> 8;
     // ce_vjp alternates TWO lists: while this launch walks `sel`, it empties the other one (walked by the previous call's launch, appended to by the next call's
     // elimination kernel) -- no memset launch per call, and no exit ticket (768 atomics on one address cost 7 us: measured)
     if (sel_reset && blockIdx.x == 0 && tid == 0) *sel_reset = 0;
@@ -239,14 +238,13 @@ k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, long
     };
     // the two products of one operator application share their barriers.  On return (synchronised): fx(j, (A^T yin)_j) was called for every
     // column and fy(i, (A xin)_i) for every row (solver-form A = -A_cvx: the stored values carry the boundary's sign).
-    const int rot = rot_step > 0 ? (int)((blockIdx.x * (unsigned)rot_step) % (unsigned)(n > 0 ? n : 1)) : 0;      // (start row of this workgroup's streaming passes: sa_fused_pass)
     auto both_products = [&](const double *yin, const double *xin, auto &&fx, auto &&fy) {
         if constexpr (RP > 0) {
             for (int a = tid; a < RP; a += NT) wyd[a] = a < F.r ? yin[F.drow[a]] : 0.0;
             __syncthreads();
             sa_fused_pass<NT, RP>(F.AdT, n, wyd, xin,
                                   [&](int j, int k8) { double acc = 0; for (int k = F.scol_ptr[j] + k8; k < F.scol_ptr[j + 1]; k += 8) { const int i = F.scol_row[k]; acc = fma(F.srow_val[i], yin[i], acc); } return acc; },
-                                  fx, part, F.sing_i, F.sing_v, yin, cq, sqk, rot);
+                                  fx, part, F.sing_i, F.sing_v, yin, cq, sqk);
             __syncthreads();
             for (int i0 = tid; i0 < m; i0 += 4 * NT) {          // four rows per step: their index / value loads (global memory) are requested together
                 int cc[4], aa[4], pb[4]; double sv4[4], bb[4];

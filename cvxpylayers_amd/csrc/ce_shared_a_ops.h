@@ -105,9 +105,7 @@ __device__ __forceinline__ void sa_rows_dot(const double *__restrict__ AdT, int 
 template <int NTH, int RP, class FE, class FO>
 __device__ __forceinline__ void sa_fused_pass(const double *__restrict__ AdT, int n, const double *w, const double *xin, FE &&extra, FO &&out, double *part,
                                               const int *__restrict__ sing_i = nullptr, const double *__restrict__ sing_v = nullptr, const double *yin = nullptr,
-                                              const double *__restrict__ cex = nullptr, long cex_stride = 0, int rot = 0) {
-    // rot: the pass starts at row `rot` and wraps -- every workgroup of a launch walks the SAME matrix, and workgroups that start together ask the same L2 channel
-    // for the same lines at the same time; a per-workgroup rotation spreads them over the matrix (the sums over rows change their order, nothing else)
+                                              const double *__restrict__ cex = nullptr, long cex_stride = 0) {
     constexpr int NL = RP / 16, RS = NTH / 8, UR = RP == 64 ? SA_UR64 : 4;      // rows in flight per lane (RP = 64: two, the accumulators need the registers)
     const int tid = threadIdx.x, k8 = tid & 7;
     const double2 *w2 = reinterpret_cast<const double2 *>(w) + k8;
@@ -119,7 +117,7 @@ __device__ __forceinline__ void sa_fused_pass(const double *__restrict__ AdT, in
         int si[UR]; double sv[UR], ce[UR];
 #pragma unroll
         for (int u = 0; u < UR; u++) {
-            const int jr = j0 + u * RS, jw = jr + rot, j = jw - (jw >= n ? n : 0), jc = jr < n ? j : 0;
+            const int j = j0 + u * RS, jc = j < n ? j : n - 1;
             const double2 *row = reinterpret_cast<const double2 *>(AdT + (size_t)jc * RP) + k8;
 #pragma unroll
             for (int i = 0; i < NL; i++) rv[u][i] = row[8 * i];
@@ -128,8 +126,8 @@ __device__ __forceinline__ void sa_fused_pass(const double *__restrict__ AdT, in
         }
 #pragma unroll
         for (int u = 0; u < UR; u++) {
-            const int jr = j0 + u * RS, jw = jr + rot, j = jw - (jw >= n ? n : 0);
-            const bool ok = jr < n;
+            const int j = j0 + u * RS;
+            const bool ok = j < n;
             const double xv = ok ? xin[j] : 0.0;
             double a0 = 0, a1 = 0;
             if (ok) { if (si[u] >= 0) a0 = (k8 == 0) ? sv[u] * yin[si[u]] : 0.0; else if (si[u] == -2) a0 = extra(j, k8); }

@@ -1056,11 +1056,10 @@ static int vjp_lsqr_launch(ce_handle h, int B, const double *A_vals0, long sA_b,
         HIPCHK(hipGetLastError());
         return CE_OK;
     }
-    int rot_step = 61; if (const char *e = getenv("CE_SA_ROT")) rot_step = atoi(e);      // per-workgroup start row of the streaming passes (0: everybody starts at row 0)
     if (const char *e = getenv("CE_SA_LSQR_PADLDS")) { const size_t want = (size_t)atoi(e) * 1024; if (want > lds && want <= LDS_LIMIT) lds = want; }      // (residency experiment: workgroups per CU)
     {
         ProfScope ps(h, 1, (hipStream_t)stream);
-#define LAUNCH_SAL(...) hipLaunchKernelGGL((k_sa_lsqr<__VA_ARGS__>), dim3(B), dim3(NT), lds, (hipStream_t)stream, T, S, F, A_vals0, sA_b, per_inst, q_vals, sq_k, sq_b, x, y, s, dx, dy, dA_bm, dq_vals, sdq_k, sdq_b, adj_status, lsqr_iters, atol, btol, conlim, iter_lim > 0 ? iter_lim : 2 * (T.n + T.m + 1), sel, status_or, a_lds | (rot_step << 8), sel_reset)
+#define LAUNCH_SAL(...) hipLaunchKernelGGL((k_sa_lsqr<__VA_ARGS__>), dim3(B), dim3(NT), lds, (hipStream_t)stream, T, S, F, A_vals0, sA_b, per_inst, q_vals, sq_k, sq_b, x, y, s, dx, dy, dA_bm, dq_vals, sdq_k, sdq_b, adj_status, lsqr_iters, atol, btol, conlim, iter_lim > 0 ? iter_lim : 2 * (T.n + T.m + 1), sel, status_or, a_lds, sel_reset)
         // plain cones / PSD without triples: instantiations without the other cones' code (CE_SA_LSQR_SPEC=0: the general kernel)
         const bool tri = T.nep + T.np > 0, psd = T.ns > 0;
         int spec = 1; if (const char *e = getenv("CE_SA_LSQR_SPEC")) spec = atoi(e);

@@ -35,7 +35,6 @@ VARIANTS = {
     # the adjoint kernel: one instance per workgroup (k_sa_lsqr) against NI instances sharing the stream over A_d^T (k_sa_lsqr_mi)
     "ni1":        dict(CE_SA_LSQR_NI="1"),
     "spec0":      dict(CE_SA_LSQR_SPEC="0"),
-    "rot0":       dict(CE_SA_ROT="0"),
     "res2":       dict(CE_SA_LSQR_PADLDS="70"),
     "res1":       dict(CE_SA_LSQR_PADLDS="120"),
     "ni2":        dict(CE_SA_LSQR_NI="2"),
@@ -43,7 +42,7 @@ VARIANTS = {
     # the adjoint's LSQR stopping rule: rounds 1-4 (atol = btol = 1e-12, 4 (n + m) iterations) against diffcp's (1e-8, 1e-8, 2 (n + m + 1): the default since round 5)
     "tight":      dict(_args=dict(lsqr_atol=1e-12, lsqr_btol=1e-12, lsqr_iter_lim=4 * (tpl.n + tpl.m))),
 }
-KEYS = ("CE_SA_FWD", "CE_SA_KERNEL", "CE_SA_NT", "CE_SA_SPLIT", "CE_SA_LSQR_NI", "CE_SA_LSQR_SPEC", "CE_SA_LSQR_PADLDS", "CE_SA_ROT")
+KEYS = ("CE_SA_FWD", "CE_SA_KERNEL", "CE_SA_NT", "CE_SA_SPLIT", "CE_SA_LSQR_NI", "CE_SA_LSQR_SPEC", "CE_SA_LSQR_PADLDS")
 ref = None
 res = []
 wts = torch.from_numpy(np.random.default_rng(5).standard_normal((tpl.n, B))).to(dev) if True else None
