@@ -129,3 +129,33 @@ def test_C5_portfolio_n501_at_size():
     regular = n_act >= tpl.n
     gd = oracle.adjoint_batch(Ab, bb, c, cones, ref["x"], ref["y"], ref["s"], ones, zeros, mode="dense")
     assert regular.mean() > 0.8 and err_against(gd)[regular].max() < 5e-4, (regular.mean(), err_against(gd)[regular].max())
+
+
+@pytest.mark.parametrize("ni", [2, 3])
+def test_lsqr_adjoint_with_several_instances_per_workgroup_equals_the_one_instance_kernel(monkeypatch, ni):
+    """k_sa_lsqr_mi (ce_shared_a_mi.h, opt-in with CE_SA_LSQR_NI: NI instances of a shared-A template per workgroup, one stream over A_d^T for all of them) runs
+    k_sa_lsqr's recurrences on the same system: same gradients, same iteration counts (up to the order of its sums).  B = 7 leaves a sub-group without an instance
+    in the last workgroup; a smaller portfolio template than config 5 keeps the oracle out of it (k_sa_lsqr itself is pinned on the oracle above)."""
+    B = 7
+    A, b, c, cones, tpl = P.portfolio_c5_batch(B, seed=3, nw=60, kf=9)
+    Ab = np.broadcast_to(A, (B,) + A.shape).copy(); bb = np.broadcast_to(b, (B,) + b.shape).copy()
+    from cvxpylayers_amd.interfaces.mi355_if import ConeEngine, make_settings
+    A_eval, q_eval = tpl.values_from_dense(Ab, bb, c)
+    monkeypatch.setenv("CE_CONST_A", "1")          # (a template this small would take the per-instance kernels)
+    eng = ConeEngine(tpl.indices, tpl.indptr, tpl.n, tpl.m, cones, torch.device("cuda", 0))
+    A_bm = torch.from_numpy(A_eval).cuda().t().contiguous(); q_t = torch.from_numpy(q_eval).cuda()
+    x, y, s, it, status, res = eng.solve(A_bm, q_t, make_settings(dict(eps=1e-7, max_iters=100000)))
+    assert eng.last_path == "const_a" and (status.cpu().numpy() == 1).all()
+    dx = torch.from_numpy(np.random.default_rng(1).standard_normal((B, tpl.n))).cuda(); dy = torch.zeros_like(y)
+    monkeypatch.delenv("CE_SA_LSQR_NI", raising=False)
+    # (at the tight rule: under diffcp's 1e-8 the two stop an iteration or two apart and differ by what LSQR still has to gain there, ~1e-6)
+    dA1, dq1, adj1 = eng.vjp(A_bm, x, y, s, dx, dy, path="const_a", q_eval=q_t, lsqr=TIGHT_LSQR)
+    it1 = eng.last_lsqr_iters.cpu().numpy().astype(int)
+    monkeypatch.setenv("CE_SA_LSQR_NI", str(ni))
+    dA2, dq2, adj2 = eng.vjp(A_bm, x, y, s, dx, dy, path="const_a", q_eval=q_t, lsqr=TIGHT_LSQR)
+    it2 = eng.last_lsqr_iters.cpu().numpy().astype(int)
+    assert (adj1.cpu().numpy() == adj2.cpu().numpy()).all()
+    assert np.abs(it1 - it2).max() <= 2 + 0.05 * it1.max(), (it1, it2)
+    for a1, a2 in ((dA1, dA2), (dq1, dq2)):
+        a1, a2 = a1.cpu().numpy(), a2.cpu().numpy()
+        assert np.abs(a1 - a2).max() <= 1e-11 * (1 + np.abs(a1).max()), np.abs(a1 - a2).max()
