@@ -70,6 +70,35 @@ __device__ __forceinline__ double wave_reduce_dpp(double v) {
     return __hiloint2double(hi, lo);
 }
 
+// sum over the lanes of a wave that share (lane % LPR), LPR in {8, 16}: the result in every one of them.  The accumulators of the streaming passes
+// (ce_shared_a_ops.h sa_fused_pass) are folded over the row groups of a wave with it.  Six to eight ds_bpermute round trips per value stood here (__shfl_xor
+// 8 / 16 / 32); row_ror:8 stays inside a row of 16 lanes, and gfx950's v_permlane16_swap / v_permlane32_swap exchange rows / halves between two registers:
+// with both operands the same value, register 0 + register 1 is v[lane] + v[lane ^ 16] (resp. ^ 32) -- no LDS crossbar, no wait.
+#ifndef SA_COLSUM_DPP
+#define SA_COLSUM_DPP 1
+#endif
+template <int LPR>
+__device__ __forceinline__ double colsum_rows(double v) {
+#if SA_COLSUM_DPP
+    if constexpr (LPR == 8) v += dpp_mov<0x128>(v);          // row_ror:8
+    {
+        const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+        const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false), b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        v = __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+    }
+    {
+        const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+        const auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false), b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        v = __hiloint2double((int)b[0], (int)a[0]) + __hiloint2double((int)b[1], (int)a[1]);
+    }
+    return v;
+#else
+    if constexpr (LPR == 8) v += __shfl_xor(v, 8);
+    v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+    return v;
+#endif
+}
+
 // sum over the wave, the same value in every lane.  Six ds_bpermute round trips (__shfl_xor) used to stand here: ~0.8 k cycles of LDS latency per reduction,
 // several times per LSQR iteration of the shared-A adjoint kernel; the DPP form stays in the vector registers.
 __device__ __forceinline__ double wave_sum(double v) { return wave_reduce_dpp<false>(v); }

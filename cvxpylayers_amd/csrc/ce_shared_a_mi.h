@@ -148,7 +148,7 @@ k_sa_lsqr_mi(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, l
             double t[SNW];
 #pragma unroll
             for (int w = 0; w < SNW; w++) t[w] = rb[w * 4 + k];
-            v[k] = (t[0] + t[1]) + (t[2] + t[3]);
+            v[k] = uniform_d((t[0] + t[1]) + (t[2] + t[3]));      // (sub-group = whole waves: the sums and every scalar of the recurrences derived from them live in scalar registers)
         }
     };
 
@@ -215,16 +215,11 @@ k_sa_lsqr_mi(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, l
                 constexpr int qq = decltype(Q)::value;
 #pragma unroll
                 for (int i = 0; i < NL; i++) {
-                    double vx_ = vacc[qq][i].x, vy_ = vacc[qq][i].y;
-                    if constexpr (LPR == 8) { vx_ += __shfl_xor(vx_, 8); vy_ += __shfl_xor(vy_, 8); }
-                    vx_ += __shfl_xor(vx_, 16); vy_ += __shfl_xor(vy_, 16);
-                    vx_ += __shfl_xor(vx_, 32); vy_ += __shfl_xor(vy_, 32);
+                    const double vx_ = colsum_rows<LPR>(vacc[qq][i].x), vy_ = colsum_rows<LPR>(vacc[qq][i].y);
                     if ((tid & 63) < LPR) reinterpret_cast<double2 *>(part + ((size_t)qq * NWT + wv) * RP)[LPR * i + k8] = double2{vx_, vy_};
                 }
             });
-            if constexpr (LPR == 8) { pa += __shfl_xor(pa, 8); pt += __shfl_xor(pt, 8); }
-            pa += __shfl_xor(pa, 16); pt += __shfl_xor(pt, 16);
-            pa += __shfl_xor(pa, 32); pt += __shfl_xor(pt, 32);
+            pa = colsum_rows<LPR>(pa); pt = colsum_rows<LPR>(pt);
             if ((tid & 63) < LPR) { pacc[(wv * 16 + k8) * 2] = pa; pacc[(wv * 16 + k8) * 2 + 1] = pt; }
         }
         MI_T(tb + 1);
@@ -376,6 +371,9 @@ k_sa_lsqr_mi(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, l
         const double test3 = 1.0 / (anorm * sqrt(ddnorm) + 1e-300), tt1 = test1 / (1.0 + anorm * xnorm / safe(bnorm));
         if (run && (test1 <= rtol || test2 <= atol || test3 <= ctol || 1.0 + test3 <= 1.0 || 1.0 + test2 <= 1.0 || 1.0 + tt1 <= 1.0)) live = false;
         run = run && live && itn < itn_lim;
+        alfa = uniform_d(alfa); beta = uniform_d(beta); ut = uniform_d(ut); vt = uniform_d(vt); wt = uniform_d(wt); rt = uniform_d(rt);
+        rhobar = uniform_d(rhobar); phibar = uniform_d(phibar); anorm = uniform_d(anorm); xxnorm = uniform_d(xxnorm); zz = uniform_d(zz);
+        cs2 = uniform_d(cs2); sn2 = uniform_d(sn2); ddnorm = uniform_d(ddnorm);
         publish(vt, alfa, run);
         __syncthreads();
         lm = livemask_of();

@@ -143,10 +143,7 @@ __device__ __forceinline__ void sa_fused_pass(const double *__restrict__ AdT, in
     }
 #pragma unroll
     for (int i = 0; i < NL; i++) {
-        double vx = vacc[i].x, vy = vacc[i].y;
-        vx += __shfl_xor(vx, 8); vy += __shfl_xor(vy, 8);
-        vx += __shfl_xor(vx, 16); vy += __shfl_xor(vy, 16);
-        vx += __shfl_xor(vx, 32); vy += __shfl_xor(vy, 32);
+        const double vx = colsum_rows<8>(vacc[i].x), vy = colsum_rows<8>(vacc[i].y);
         if ((tid & 63) < 8) reinterpret_cast<double2 *>(part + (tid >> 6) * RP)[8 * i + k8] = double2{vx, vy};
     }
 }
