@@ -111,7 +111,9 @@ __device__ __forceinline__ double wave_max(double v) {
 // Must be called in workgroup-uniform control flow by ALL NT threads: wave_sum's DPP broadcast reads lane 63 of every wave (an inactive lane there is
 // garbage, not a smaller sum), and the barriers below need every wave.
 static_assert(NT % 64 == 0, "block_reduce: whole waves only");
-template <int K>
+// TRAIL false: no barrier behind the reads of `red` -- for callers that give every call site of a loop its own buffer (the next write to it is then at least
+// one barrier away) and that synchronise before anybody else's LDS data is touched
+template <int K, bool TRAIL = true>
 __device__ __forceinline__ void block_reduce(double (&v)[K], unsigned maxmask, double *red) {
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 #pragma unroll
@@ -131,7 +133,7 @@ __device__ __forceinline__ void block_reduce(double (&v)[K], unsigned maxmask, d
         for (int w = 1; w < NW; w++) a = ((maxmask >> k) & 1u) ? fmax(a, t[w]) : a + t[w];
         v[k] = a;
     }
-    __syncthreads();
+    if constexpr (TRAIL) __syncthreads();
 }
 
 // ------------------------------------------------------------------------------------------------

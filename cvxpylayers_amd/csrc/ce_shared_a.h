@@ -171,6 +171,9 @@ k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, long
     }
     __syncthreads();
 
+    // the producers of the passes' y-side operand (v_y, q) also drop the entries of the dense rows into wyd[slot] (zero padded once): every thread calls it for the rows it writes
+    auto to_wyd = [&](int i, double v) { if constexpr (RP > 0) { const int a = F.rowslot[i]; if (a >= 0) wyd[a] = v; } };
+    if constexpr (RP > 0) { for (int a = tid; a < RP; a += NT) wyd[a] = 0.0; }
     // sink(i, DPi(hs * h)_i) for every row i.  h must be complete (synchronised) on entry; every thread calls it.  The value of row i depends on
     // h_i, on per-cone sums taken in a first phase (one barrier) and, for PSD blocks, on the whole block (copied to a matrix before any sink of
     // the block runs): sinks may therefore overwrite h_i.  No trailing barrier.
@@ -240,8 +243,7 @@ k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, long
     // column and fy(i, (A xin)_i) for every row (solver-form A = -A_cvx: the stored values carry the boundary's sign).
     auto both_products = [&](const double *yin, const double *xin, auto &&fx, auto &&fy) {
         if constexpr (RP > 0) {
-            for (int a = tid; a < RP; a += NT) wyd[a] = a < F.r ? yin[F.drow[a]] : 0.0;
-            __syncthreads();
+            // (wyd = the dense rows' entries of yin: written by whoever produced yin -- to_wyd below -- so that the pass starts without a gather phase and its barrier)
             sa_fused_pass<NT, RP>(F.AdT, n, wyd, xin,
                                   [&](int j, int k8) { double acc = 0; for (int k = F.scol_ptr[j] + k8; k < F.scol_ptr[j + 1]; k += 8) { const int i = F.scol_row[k]; acc = fma(F.srow_val[i], yin[i], acc); } return acc; },
                                   fx, part, F.sing_i, F.sing_v, yin, cq, sqk);
@@ -309,8 +311,10 @@ k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, long
     // (sum of squares, tau-row dot product) over the workgroup in one reduction
     // (the sums come back workgroup-uniform: through readfirstlane they and every scalar of the recurrences computed from them are known to be uniform and live in
     // scalar registers across the phases -- ~20 loop-carried doubles that otherwise hold 40 VGPRs of a kernel that sits at its 168-VGPR ceiling)
-    auto sum_two = [&](double v, double w, double &wsum) -> double { double r[2] = {v, w}; block_reduce<2>(r, 0u, red); wsum = uniform_d(r[1]); return uniform_d(r[0]); };
-    auto sum_three = [&](double v, double w, double u3, double &wsum, double &usum) -> double { double r[3] = {v, w, u3}; block_reduce<3>(r, 0u, red); wsum = uniform_d(r[1]); usum = uniform_d(r[2]); return uniform_d(r[0]); };
+    // One barrier per reduction: the two call sites of the iteration own separate halves of `red` (NW * 8 doubles), each written again an iteration (many barriers) later;
+    // every phase that follows a reduction synchronises before it reads another thread's vector entries.
+    auto sum_two = [&](double v, double w, double &wsum) -> double { double r[2] = {v, w}; block_reduce<2, false>(r, 0u, red); wsum = uniform_d(r[1]); return uniform_d(r[0]); };
+    auto sum_three = [&](double v, double w, double u3, double &wsum, double &usum) -> double { double r[3] = {v, w, u3}; block_reduce<3, false>(r, 0u, red + NW * 4); wsum = uniform_d(r[1]); usum = uniform_d(r[2]); return uniform_d(r[0]); };
 
     // ---- LSQR (Paige & Saunders) on  N r = dz,  N = M^T  (the tau components ut, vt, wt, rt are workgroup-uniform scalars in registers)
     //      N   (r_x, r_y, r_t) = ( -A^T r_y - c r_t ,  DPi(A r_x - b r_t - r_y) + r_y ,  c.r_x + b.r_y )
@@ -326,7 +330,7 @@ k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, long
     double beta = bnorm, ib = 1.0 / safe(beta);
     // u <- u / beta ;  q = DPi(uy) ;  v = N^T u
     for (int j = tid; j < n; j += NT) ux[j] *= ib;
-    dproj(uy, ib, [&](int i, double o) { qv[i] = o; });
+    dproj(uy, ib, [&](int i, double o) { qv[i] = o; to_wyd(i, o); });
     if (ntri > 0) __syncthreads();                       // a triple's thread reads three rows of uy that other threads rescale below
     for (int i = tid; i < m; i += NT) uy[i] *= ib;       // (every other read of uy by dproj is behind one of its barriers, or by the row's own thread)
     ut *= ib;
@@ -344,7 +348,7 @@ k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, long
     {
         const double ia = 1.0 / safe(alfa);
         for (int j = tid; j < n; j += NT) { const double v = vx[j] * ia; vx[j] = v; wx[j] = v; wsq = fma(v, v, wsq); }
-        for (int i = tid; i < m; i += NT) { const double v = vy[i] * ia; vy[i] = v; wy[i] = v; wsq = fma(v, v, wsq); }
+        for (int i = tid; i < m; i += NT) { const double v = vy[i] * ia; vy[i] = v; wy[i] = v; wsq = fma(v, v, wsq); to_wyd(i, v); }
         vt *= ia; wt = vt;
     }
     __syncthreads();
@@ -374,7 +378,7 @@ k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, long
         anorm = sqrt(anorm * anorm + alfa * alfa + beta * beta);
         // u = u-hat / beta ;  q = DPi(uy) ;  (tx, ty) = N^T u ;  v-hat = t - beta v
         for (int j = tid; j < n; j += NT) ux[j] *= ib;
-        dproj(uy, ib, [&](int i, double o) { qv[i] = o; });
+        dproj(uy, ib, [&](int i, double o) { qv[i] = o; to_wyd(i, o); });
         if (ntri > 0) __syncthreads();
         for (int i = tid; i < m; i += NT) uy[i] *= ib;
         ut *= ib;
@@ -394,7 +398,7 @@ k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, long
         const double t1 = phi / safe(rho), t2 = -theta / safe(rho), ia = 1.0 / safe(alfa);
         wsq = 0;
         for (int j = tid; j < n; j += NT) { const double v = vx[j] * ia, w = wx[j], wn = v + t2 * w; vx[j] = v; rx[j] += t1 * w; wx[j] = wn; wsq = fma(wn, wn, wsq); }
-        for (int i = tid; i < m; i += NT) { const double v = vy[i] * ia, w = wy[i], wn = v + t2 * w; vy[i] = v; ry[i] += t1 * w; wy[i] = wn; wsq = fma(wn, wn, wsq); }
+        for (int i = tid; i < m; i += NT) { const double v = vy[i] * ia, w = wy[i], wn = v + t2 * w; vy[i] = v; ry[i] += t1 * w; wy[i] = wn; wsq = fma(wn, wn, wsq); to_wyd(i, v); }
         ddnorm += wsum / (safe(rho) * safe(rho));
         { vt *= ia; rt = fma(t1, wt, rt); wt = fma(t2, wt, vt); }
         __syncthreads();
