@@ -7,7 +7,7 @@ template <bool A_LDS, bool G_LDS>
 __global__ void __launch_bounds__(NT)
 k_forward(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__restrict__ qv, long sqk, long sqb,
           double *__restrict__ xo, double *__restrict__ yo, double *__restrict__ so, int *__restrict__ iters_o,
-          int *__restrict__ status_o, double *__restrict__ resid_o, double *gwsA, double *gwsG) {
+          int *__restrict__ status_o, double *__restrict__ resid_o, double *gwsA, double *gwsG, double *aa_ws) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     const int tid = threadIdx.x, inst = blockIdx.x;
     const int n = T.n, m = T.m, l = n + m + 1, lda = T.lda, ldg = T.ldg, nq = T.nq, z = T.z;
@@ -340,18 +340,74 @@ k_forward(DevT T, ce_settings S, const double *__restrict__ Avals, const double 
     double sum_log = 0, res_pri = NAN, res_dual = NAN, gap = NAN;
     double tau = 0, kap = 0, ctx = 0, bty = 0;
 
+    // Anderson acceleration of the iteration map w -> F(w): type I, ONE secant pair, residual safeguard, switched off after AA_MAX_REJECT rejections -- the algorithm of
+    // k_fwd2 / k_sa_fwd and of the oracle with aa_mem = 1 (oracle/cone_oracle.c solve_one; SCS's acceleration_lookback / acceleration_interval).  Every aa_int
+    // iterations, with x = input and f = output of the last iteration, g = x - f, s = x - x_prev, y = g - g_prev, d = f - f_prev:  w <- f - (s.g / (s.y + 1e-8 |s||y|)) d;
+    // the next iteration's residual is the safeguard.  The four history vectors (x_prev, f_prev, f_save, w_prev) live in GLOBAL memory (aa_ws: [B][4][lp]; this kernel
+    // serves the templates whose iterates already fill LDS): they are touched on two of every aa_int iterations, each entry by the thread that owns it.
+    const int lp = l + (l & 1);
+    bool aa_on = S.acceleration_lookback > 0 && aa_ws != nullptr, aa_pending = false, aa_stale = false;
+    const int aa_int = S.acceleration_interval > 0 ? S.acceleration_interval : 10;
+    int aa_iter = 0, aa_rej = 0;
+    double aa_normg = 0, aa_hs = 1.0;     // |g| before the step ; factor the stored history has to be scaled by (the renormalisations of w since it was stored)
+    double *const aaXP = aa_ws ? aa_ws + (size_t)inst * 4 * lp : nullptr, *const aaFP = aaXP + lp, *const aaFS = aaFP + lp, *const aaWP = aaFS + lp;
+
     for (iter = 0; iter < S.max_iters; iter++) {
         const bool check = (iter % CONVERGED_INTERVAL) == 0;
+        if (aa_on) {
+            bool w_changed = false;
+            if (aa_pending) {      // safeguard: residual of the map at the accelerated point against the residual before the step
+                double rs[1] = {0};
+                for (int e = tid; e < l; e += NT) { const double dd = aaWP[e] - w[e]; rs[0] = fma(dd, dd, rs[0]); }
+                block_reduce<1>(rs, 0u, red);
+                if (!(sqrt(rs[0]) <= aa_normg)) {
+                    for (int e = tid; e < l; e += NT) w[e] = aaFS[e] * aa_hs;
+                    aa_iter = 0; w_changed = true;
+                    if (++aa_rej >= AA_MAX_REJECT) aa_on = false;
+                }
+                aa_pending = false;
+            }
+            if (aa_on && iter > 0 && iter % aa_int == 0 && !aa_stale) {      // (aa_stale: w_prev predates a rescale)
+                if (aa_iter > 0) {
+                    double rr[5] = {0, 0, 0, 0, 0};
+                    for (int e = tid; e < l; e += NT) {
+                        const double xv = aaWP[e], fv = w[e], gv = xv - fv, xp = aaXP[e] * aa_hs, fp = aaFP[e] * aa_hs;
+                        const double sv = xv - xp, yv = gv - (xp - fp);
+                        rr[0] = fma(sv, sv, rr[0]); rr[1] = fma(yv, yv, rr[1]); rr[2] = fma(sv, yv, rr[2]); rr[3] = fma(sv, gv, rr[3]); rr[4] = fma(gv, gv, rr[4]);
+                    }
+                    block_reduce<5>(rr, 0u, red);
+                    const double mm = rr[2] + 1e-8 * sqrt(rr[0]) * sqrt(rr[1]), gam = rr[3] / mm;
+                    const bool ok = fabs(mm) > 1e-300 && fabs(gam) < 1e10;
+                    for (int e = tid; e < l; e += NT) {
+                        const double xv = aaWP[e], fv = w[e], fp = aaFP[e] * aa_hs;
+                        aaXP[e] = xv; aaFP[e] = fv;
+                        if (ok) { aaFS[e] = fv; w[e] = fv - gam * (fv - fp); }
+                    }
+                    aa_hs = 1.0;
+                    if (ok) { aa_normg = sqrt(rr[4]); aa_pending = true; w_changed = true; } else aa_iter = 0;
+                } else {
+                    for (int e = tid; e < l; e += NT) { aaXP[e] = aaWP[e]; aaFP[e] = w[e]; }
+                    aa_hs = 1.0;
+                }
+                aa_iter++;
+            }
+            if (w_changed && !(check && iter > 0)) { __syncthreads(); phiw_partials(); __syncthreads(); }      // (the renormalisation below recomputes phi . w itself)
+            else if (w_changed) __syncthreads();
+        }
         if (check && iter > 0) {   // keep the homogeneous iterate in range
             double r[1] = {0};
             for (int e = tid; e < l; e += NT) r[0] += w[e] * w[e];
             block_reduce<1>(r, 0u, red);
             const double nw = sqrt(r[0]);
-            if (nw > 0) { const double f = sqrt((double)l) / nw; for (int e = tid; e < l; e += NT) w[e] *= f; }
+            if (nw > 0) {
+                const double f = sqrt((double)l) / nw; for (int e = tid; e < l; e += NT) w[e] *= f;
+                if (aa_on) { aa_hs *= f; aa_normg *= f; }      // the map is positively homogeneous: the stored history scales with w (lazily)
+            }
             __syncthreads();
             phiw_partials();
             __syncthreads();
         }
+        if (aa_on && (aa_pending || (iter + 1) % aa_int == 0)) { aa_stale = false; for (int e = tid; e < l; e += NT) aaWP[e] = w[e]; }      // input of this iteration, where the next one needs it
         // S1: A^T w_y
         AT_times(w + n, part);
         __syncthreads();
@@ -466,7 +522,7 @@ k_forward(DevT T, ce_settings S, const double *__restrict__ Avals, const double 
                                 const double d0 = u[n + i] + w[n + i] - 2 * ut[n + i];   // = rsk_y * Dy
                                 w[n + i] = d0 * dy_ratio + 2 * ut[n + i] - u[n + i];
                             }
-                            sum_log = 0; n_log = 0; last_scale_iter = iter; scale = ns2;
+                            sum_log = 0; n_log = 0; last_scale_iter = iter; scale = ns2; aa_iter = 0; aa_pending = false; aa_stale = true;
                             __syncthreads();
                             refactor();
                             phiw_partials();

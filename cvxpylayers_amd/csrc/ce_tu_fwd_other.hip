@@ -21,7 +21,7 @@ int ce_launch_fwd_rt(int variant, int B, size_t lds, hipStream_t st, const CeFwd
     return 0;
 }
 int ce_launch_fwd_generic(int mode, int B, size_t lds, hipStream_t st, const CeFwdArgs &a) {
-#define LAUNCH_F(AL, GL) hipLaunchKernelGGL((k_forward<AL, GL>), dim3(B), dim3(NT), lds, st, a.T, a.S, a.Abm, a.q, a.sqk, a.sqb, a.x, a.y, a.s, a.iters, a.status, a.resid, a.gA, a.gG)
+#define LAUNCH_F(AL, GL) hipLaunchKernelGGL((k_forward<AL, GL>), dim3(B), dim3(NT), lds, st, a.T, a.S, a.Abm, a.q, a.sqk, a.sqb, a.x, a.y, a.s, a.iters, a.status, a.resid, a.gA, a.gG, a.aa_ws)
     switch (mode) {
     case 0: LAUNCH_F(true, true); break;
     case 1: LAUNCH_F(true, false); break;

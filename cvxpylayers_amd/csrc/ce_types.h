@@ -33,6 +33,7 @@ struct CeFwdArgs {
     double *gA, *gG;            // global residency workspaces of the size-generic kernel
     int *iters2;                // k_fwd2: second copy of the iteration counts (engine-owned; NULL: not wanted)
     const int *order;           // k_fwd2: workgroup -> instance (NULL: identity); longest-first dispatch from the previous call's iteration counts
+    double *aa_ws;              // size-generic kernel: Anderson-acceleration history, [B][4][lp] doubles of global memory (NULL: plain iteration)
 };
 struct CeBwdArgs {
     DevT T; int nkcap, ldk;

@@ -249,7 +249,8 @@ extern "C" {
 
 const char *ce_last_error(void) { return g_err.c_str(); }
 int ce_abi_version(void) { return CE_ABI_VERSION; }
-int ce_acceleration_available(ce_handle h) { return (h && h->fwd_mode == 4 && h->aa_ok) ? 1 : 0; }
+// k_fwd2 when its history fits LDS; the size-generic kernel k_forward (history in global memory).  Not the first-generation register-tiled k_forward_rt.
+int ce_acceleration_available(ce_handle h) { return (h && ((h->fwd_mode == 4 && h->aa_ok) || h->fwd_mode <= 2)) ? 1 : 0; }
 int ce_struct_size(int which) { return which == 0 ? (int)sizeof(ce_template) : which == 1 ? (int)sizeof(ce_settings) : -1; }
 
 void ce_default_settings(ce_settings *s) {
@@ -589,7 +590,7 @@ int ce_solve_qp(ce_handle h, int B, const double *A_vals, long sA_k, long sA_b, 
     // (PSD / exponential / power cones beyond k_fwd2's sizes run on the size-generic kernel: fwd_mode 0..2)
     if ((h->T.ns > 0 || h->T.nep + h->T.np > 0) && h->fwd_mode == 3) { g_err = "PSD / exponential / power cones: internal error, k_forward_rt selected"; return CE_E_UNSUPPORTED; }
     ce_settings S; if (settings) S = *settings; else ce_default_settings(&S);
-    if (!(h->fwd_mode == 4 && h->aa_ok)) S.acceleration_lookback = 0;       // only k_fwd2 implements it (and only when its vectors fit LDS)
+    if (!ce_acceleration_available(h)) S.acceleration_lookback = 0;          // k_fwd2 (when its vectors fit LDS) and the size-generic kernel implement it
     if (S.acceleration_interval <= 0) S.acceleration_interval = 10;
     const double *Abm = nullptr;
     int rc = to_batch_major(h, B, A_vals, sA_k, sA_b, st, &Abm);
@@ -603,10 +604,18 @@ int ce_solve_qp(ce_handle h, int B, const double *A_vals, long sA_k, long sA_b, 
         if (rc) return rc;
         gG = h->gws; gA = h->gws + (size_t)B * perG;
     }
+    double *aa_ws = nullptr;
+    if (h->fwd_mode <= 2 && S.acceleration_lookback > 0) {      // the size-generic kernel keeps the acceleration history in global memory ([B][4][lp], shared with the shared-A kernel's)
+        const size_t l = (size_t)T.n + T.m + 1, lp = l + (l & 1);
+        rc = ensure(&h->d_aa_ws, &h->aa_ws_bytes, sizeof(double) * (size_t)B * 4 * lp);
+        if (rc) return rc;
+        aa_ws = h->d_aa_ws;
+    }
     bool fa_iters2 = false;
     {
         ProfScope ps(h, 0, st);
         CeFwdArgs fa{};
+        fa.aa_ws = aa_ws;
         fa.T = T; fa.S = S; fa.Abm = Abm; fa.q = q_vals; fa.sqk = sq_k; fa.sqb = sq_b; fa.idx_at = h->d_idx_at; fa.idx_ar = h->d_idx_ar; fa.idx_b = h->d_idx_b;
         fa.x = x; fa.y = y; fa.s = s; fa.iters = iters; fa.status = status; fa.resid = resid; fa.P = P_vals; fa.nnz_p = h->nnz_p; fa.idx_p = h->d_idx_p; fa.gA = gA; fa.gG = gG;
         int lrc;

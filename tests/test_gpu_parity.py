@@ -800,3 +800,35 @@ def test_two_tile_adjoint_plan_gives_the_single_tile_gradients(monkeypatch):
     for key in ("two", "forced"):
         for a_, b_ in zip(outs[key], outs["single"]):
             assert torch.equal(a_, b_), key
+
+
+def test_anderson_acceleration_in_the_size_generic_kernel_matches_the_oracle(monkeypatch):
+    """k_forward (templates beyond the register-tiled kernels; here forced with CE_FORCE_GENERIC) runs the one-pair Anderson acceleration of k_fwd2 / k_sa_fwd with its
+    history in global memory: the oracle with aa_mem = 1 is the same algorithm (iteration counts within a check interval, same solutions, fewer iterations than the
+    plain iteration), and a positive acceleration_lookback is honoured without a warning."""
+    import warnings
+    from oracle import oracle
+    from cvxpylayers_amd.interfaces.mi355_if import ConeEngine, make_settings
+    monkeypatch.setenv("CE_FORCE_GENERIC", "1")
+    cfg = P.CONFIGS["M"]; n, cones, B = cfg["n"], cfg["cones"], 32
+    tpl = P.dense_template(n, cones)
+    A, b, c = P.generate(n, cones, B, seed=2)
+    eng = ConeEngine(tpl.indices, tpl.indptr, tpl.n, tpl.m, cones, torch.device("cuda", 0))
+    assert eng.launch_info()["fwd_mode"] <= 2
+    A_eval, q_eval = tpl.values_from_dense(A, b, c)
+    A_bm = eng.to_batch_major(torch.from_numpy(A_eval).cuda()); q_t = torch.from_numpy(q_eval).cuda()
+    for eps in (1e-4, 1e-8):
+        ref = oracle.solve_batch(A, b, c, cones, eps=eps, max_iters=20000, acceleration_lookback=1)
+        plain = oracle.solve_batch(A, b, c, cones, eps=eps, max_iters=20000)
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")
+            x, y, s, iters, status, resid = eng.solve(A_bm, q_t, make_settings(dict(eps=eps, max_iters=20000, acceleration_lookback=1)))
+        assert eng.last_acceleration
+        assert (status.cpu().numpy() == 1).all() and (ref["status"] == 1).all()
+        tol = max(1e-6, 20 * eps)
+        for got, want in ((x, ref["x"]), (y, ref["y"]), (s, ref["s"])):
+            err = np.abs(got.cpu().numpy() - want).max(axis=1) / (1 + np.abs(want).max(axis=1))
+            assert err.max() < tol, err.max()
+        it = iters.cpu().numpy()
+        assert np.mean(np.abs(it - ref["iters"]) <= 25) > 0.9, (it, ref["iters"])       # a borderline safeguard decision may shift an instance
+        assert it.mean() < plain["iters"].mean()
