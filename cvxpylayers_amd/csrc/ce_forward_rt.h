@@ -88,7 +88,7 @@ template <int CH1, int T1, int TG, int CH2, int T2, int VP, int WPE>
 __global__ void __launch_bounds__(NT2, WPE)
 k_forward_rt(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__restrict__ qv, long sqk, long sqb,
              double *__restrict__ xo, double *__restrict__ yo, double *__restrict__ so, int *__restrict__ iters_o,
-             int *__restrict__ status_o, double *__restrict__ resid_o) {
+             int *__restrict__ status_o, double *__restrict__ resid_o, double *aa_ws) {
     extern __shared__ __attribute__((aligned(16))) double sm[];
     // ---- compile-time LDS layout (doubles)
     constexpr int O_BV = 0 * VP, O_CV = 1 * VP, O_DV = 2 * VP, O_EV = 3 * VP, O_G = 4 * VP, O_W = 5 * VP, O_UT = 6 * VP,
@@ -350,6 +350,15 @@ k_forward_rt(DevT T, ce_settings S, const double *__restrict__ Avals, const doub
         __syncthreads();
     };
 
+    // Anderson acceleration (one secant pair, residual safeguard: the algorithm of k_fwd2 / k_sa_fwd / k_forward and of the oracle with aa_mem = 1); the four history
+    // vectors of the instance live in global memory (aa_ws [B][4][lp]), entry e is only ever touched by thread e
+    const int lp_aa = l + (l & 1);
+    bool aa_on = S.acceleration_lookback > 0 && aa_ws != nullptr, aa_pending = false, aa_stale = false;
+    const int aa_int = S.acceleration_interval > 0 ? S.acceleration_interval : 10;
+    int aa_iter = 0, aa_rej = 0;
+    double aa_normg = 0, aa_hs = 1.0;
+    double *const aaXP = aa_ws ? aa_ws + (size_t)blockIdx.x * 4 * lp_aa : nullptr, *const aaFP = aaXP + lp_aa, *const aaFS = aaFP + lp_aa, *const aaWP = aaFS + lp_aa;
+
     // Outer loop: (re)factor, then iterate until convergence / iteration limit / a rescale request.  Keeping refactor()
     // out of the hot loop keeps its (large, fully unrolled) code and register pressure away from the iteration.
     for (bool done = false; !done;) {
@@ -368,16 +377,57 @@ k_forward_rt(DevT T, ce_settings S, const double *__restrict__ Avals, const doub
         const double *Arow = A + (rowok ? i2 : 0) * lda + c2;
         const bool check = (iter % CONVERGED_INTERVAL) == 0;
         const bool last = iter + 1 >= S.max_iters;
+        if (aa_on) {
+            bool w_changed = false;
+            if (aa_pending) {      // safeguard: residual of the map at the accelerated point against the residual before the step
+                double rs[1] = {0};
+                if (e < l) { const double dd = aaWP[e] - sm[O_W + e]; rs[0] = dd * dd; }
+                block_reduce_n<1, NW2>(rs, 0u, red);
+                if (!(sqrt(rs[0]) <= aa_normg)) {
+                    if (e < l) sm[O_W + e] = aaFS[e] * aa_hs;
+                    aa_iter = 0; w_changed = true;
+                    if (++aa_rej >= AA_MAX_REJECT) aa_on = false;
+                }
+                aa_pending = false;
+            }
+            if (aa_on && iter > 0 && iter % aa_int == 0 && !aa_stale) {
+                if (aa_iter > 0) {
+                    double rr[5] = {0, 0, 0, 0, 0}, xv = 0, fv = 0, fp = 0;
+                    if (e < l) {
+                        xv = aaWP[e]; fv = sm[O_W + e]; fp = aaFP[e] * aa_hs;
+                        const double gv = xv - fv, xp = aaXP[e] * aa_hs, sv = xv - xp, yv = gv - (xp - fp);
+                        rr[0] = sv * sv; rr[1] = yv * yv; rr[2] = sv * yv; rr[3] = sv * gv; rr[4] = gv * gv;
+                    }
+                    block_reduce_n<5, NW2>(rr, 0u, red);
+                    const double mm = rr[2] + 1e-8 * sqrt(rr[0]) * sqrt(rr[1]), gam = rr[3] / mm;
+                    const bool ok = fabs(mm) > 1e-300 && fabs(gam) < 1e10;
+                    if (e < l) { aaXP[e] = xv; aaFP[e] = fv; if (ok) { aaFS[e] = fv; sm[O_W + e] = fv - gam * (fv - fp); } }
+                    aa_hs = 1.0;
+                    if (ok) { aa_normg = sqrt(rr[4]); aa_pending = true; w_changed = true; } else aa_iter = 0;
+                } else {
+                    if (e < l) { aaXP[e] = aaWP[e]; aaFP[e] = sm[O_W + e]; }
+                    aa_hs = 1.0;
+                }
+                aa_iter++;
+            }
+            if (w_changed) {      // phi . w of the new input (the renormalisation below recomputes it again on check iterations)
+                __syncthreads();
+                { double a_ = (e < l - 1) ? sm[O_PHI + e] * sm[O_W + e] : 0.0; a_ = wave_reduce_dpp<false>(a_); if ((e & 63) == 0) sm[O_WP + (e >> 6)] = a_; }
+                __syncthreads();
+            }
+        }
         if (check && iter > 0) {   // keep the homogeneous iterate in range
             const double we = (e < l) ? sm[O_W + e] : 0.0;
             double r[1] = {we * we};
             block_reduce_n<1, NW2>(r, 0u, red);
             const double nw = sqrt(r[0]);
             if (nw > 0 && e < l) sm[O_W + e] = we * (sqrt((double)l) / nw);
+            if (nw > 0 && aa_on) { const double f = sqrt((double)l) / nw; aa_hs *= f; aa_normg *= f; }      // the stored history scales with w (lazily)
             __syncthreads();
             { double a_ = (e < l - 1) ? sm[O_PHI + e] * sm[O_W + e] : 0.0; a_ = wave_reduce_dpp<false>(a_); if ((e & 63) == 0) sm[O_WP + (e >> 6)] = a_; }
             __syncthreads();
         }
+        if (aa_on && (aa_pending || (iter + 1) % aa_int == 0)) { aa_stale = false; if (e < l) aaWP[e] = sm[O_W + e]; }      // input of this iteration, where the next one needs it
         // P1a: t = rho_x w_x - A^T w_y
         {
             const double a = tile_dot<CH1, T1>(at1, sm + O_W + n + c1);
@@ -505,7 +555,7 @@ k_forward_rt(DevT T, ce_settings S, const double *__restrict__ Avals, const doub
                                 const double d0 = ue + sm[O_W + e] - 2 * ute;
                                 sm[O_W + e] = d0 * dy_ratio + 2 * ute - ue;
                             }
-                            n_log = 0; last_scale_iter = iter; scale = ns2;
+                            n_log = 0; last_scale_iter = iter; scale = ns2; aa_iter = 0; aa_pending = false; aa_stale = true;
                             __syncthreads();
                             sc[SC_SUMLOG] = 0.0;
                             rescale = true;

@@ -10,7 +10,7 @@ namespace {
 }  // namespace
 
 int ce_launch_fwd_rt(int variant, int B, size_t lds, hipStream_t st, const CeFwdArgs &a) {
-#define LAUNCH_RT(...) hipLaunchKernelGGL((k_forward_rt<__VA_ARGS__>), dim3(B), dim3(NT2), lds, st, a.T, a.S, a.Abm, a.q, a.sqk, a.sqb, a.x, a.y, a.s, a.iters, a.status, a.resid)
+#define LAUNCH_RT(...) hipLaunchKernelGGL((k_forward_rt<__VA_ARGS__>), dim3(B), dim3(NT2), lds, st, a.T, a.S, a.Abm, a.q, a.sqk, a.sqb, a.x, a.y, a.s, a.iters, a.status, a.resid, a.aa_ws)
     switch (variant) {
     case 0: LAUNCH_RT(8, 13, 7, 4, 13, 160, 4); break;
     case 1: LAUNCH_RT(8, 16, 8, 4, 16, 208, 4); break;

@@ -249,8 +249,8 @@ extern "C" {
 
 const char *ce_last_error(void) { return g_err.c_str(); }
 int ce_abi_version(void) { return CE_ABI_VERSION; }
-// k_fwd2 when its history fits LDS; the size-generic kernel k_forward (history in global memory).  Not the first-generation register-tiled k_forward_rt.
-int ce_acceleration_available(ce_handle h) { return (h && ((h->fwd_mode == 4 && h->aa_ok) || h->fwd_mode <= 2)) ? 1 : 0; }
+// k_fwd2 when its history fits LDS; the first-generation register-tiled k_forward_rt and the size-generic k_forward keep the history in global memory.
+int ce_acceleration_available(ce_handle h) { return (h && ((h->fwd_mode == 4 && h->aa_ok) || h->fwd_mode <= 3)) ? 1 : 0; }
 int ce_struct_size(int which) { return which == 0 ? (int)sizeof(ce_template) : which == 1 ? (int)sizeof(ce_settings) : -1; }
 
 void ce_default_settings(ce_settings *s) {
@@ -605,7 +605,7 @@ int ce_solve_qp(ce_handle h, int B, const double *A_vals, long sA_k, long sA_b, 
         gG = h->gws; gA = h->gws + (size_t)B * perG;
     }
     double *aa_ws = nullptr;
-    if (h->fwd_mode <= 2 && S.acceleration_lookback > 0) {      // the size-generic kernel keeps the acceleration history in global memory ([B][4][lp], shared with the shared-A kernel's)
+    if (h->fwd_mode <= 3 && S.acceleration_lookback > 0) {      // k_forward_rt and the size-generic kernel keep the acceleration history in global memory ([B][4][lp], shared with the shared-A kernel's)
         const size_t l = (size_t)T.n + T.m + 1, lp = l + (l & 1);
         rc = ensure(&h->d_aa_ws, &h->aa_ws_bytes, sizeof(double) * (size_t)B * 4 * lp);
         if (rc) return rc;

@@ -802,19 +802,21 @@ def test_two_tile_adjoint_plan_gives_the_single_tile_gradients(monkeypatch):
             assert torch.equal(a_, b_), key
 
 
-def test_anderson_acceleration_in_the_size_generic_kernel_matches_the_oracle(monkeypatch):
-    """k_forward (templates beyond the register-tiled kernels; here forced with CE_FORCE_GENERIC) runs the one-pair Anderson acceleration of k_fwd2 / k_sa_fwd with its
-    history in global memory: the oracle with aa_mem = 1 is the same algorithm (iteration counts within a check interval, same solutions, fewer iterations than the
-    plain iteration), and a positive acceleration_lookback is honoured without a warning."""
+@pytest.mark.parametrize("kernel", ["generic", "rt"])
+def test_anderson_acceleration_in_the_fallback_forward_kernels_matches_the_oracle(monkeypatch, kernel):
+    """k_forward (size-generic: templates beyond the register-tiled kernels) and k_forward_rt (first-generation register-tiled kernel), forced here with CE_FORCE_GENERIC /
+    CE_FWD=rt, run the one-pair Anderson acceleration of k_fwd2 / k_sa_fwd with their history in global memory: the oracle with aa_mem = 1 is the same algorithm (iteration
+    counts within a check interval, same solutions, fewer iterations than the plain iteration), and a positive acceleration_lookback is honoured without a warning."""
     import warnings
     from oracle import oracle
     from cvxpylayers_amd.interfaces.mi355_if import ConeEngine, make_settings
-    monkeypatch.setenv("CE_FORCE_GENERIC", "1")
+    if kernel == "generic": monkeypatch.setenv("CE_FORCE_GENERIC", "1")
+    else: monkeypatch.setenv("CE_FWD", "rt")
     cfg = P.CONFIGS["M"]; n, cones, B = cfg["n"], cfg["cones"], 32
     tpl = P.dense_template(n, cones)
     A, b, c = P.generate(n, cones, B, seed=2)
     eng = ConeEngine(tpl.indices, tpl.indptr, tpl.n, tpl.m, cones, torch.device("cuda", 0))
-    assert eng.launch_info()["fwd_mode"] <= 2
+    assert (eng.launch_info()["fwd_mode"] <= 2) if kernel == "generic" else (eng.launch_info()["fwd_mode"] == 3), eng.launch_info()
     A_eval, q_eval = tpl.values_from_dense(A, b, c)
     A_bm = eng.to_batch_major(torch.from_numpy(A_eval).cuda()); q_t = torch.from_numpy(q_eval).cuda()
     for eps in (1e-4, 1e-8):
