@@ -96,7 +96,8 @@ void ce_default_settings(ce_settings *s);
 int ce_abi_version(void);
 int ce_struct_size(int which);
 /* 1 when ce_solve / ce_solve_qp on this engine honour ce_settings.acceleration_lookback > 0 (second-generation forward kernel with
- * room for its five extra vectors in LDS), else 0: the request is ignored on that engine (plain iteration). */
+ * room for its five extra vectors in LDS; the first-generation and size-generic kernels, which keep them in global memory), else 0: the
+ * request is ignored on that engine (plain iteration). */
 int ce_acceleration_available(ce_handle h);
 
 int ce_create(const ce_template *tpl, int device, ce_handle *out);
