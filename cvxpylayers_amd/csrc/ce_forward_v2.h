@@ -38,6 +38,19 @@ struct F2 {
     static_assert(CHT <= 16 && CHA <= 16 && CHG <= 16, "DPP butterflies stay inside a row of 16 lanes");
 };
 
+// structural zeros of a gathered tile (index -1: the load went through a clamped index, i.e. read entry 0 of THIS instance's values): multiplied by a 0 / 1 mask.
+// The selecting form (-DF2_MASK_MUL=0; ADVICE round 5: a non-finite entry 0 then stays in its own slot instead of turning the tile's structural zeros into NaN)
+// costs two v_cndmask per entry against one v_mul_f64: k_fwd2 1.526 against 1.498 ms, the step 2.18-2.22 against 2.11-2.16 ms on the same box
+// (profiles/r06/o_ab_gather_mask_select_slower.log).  An instance whose entry 0 is not finite has no solution either way -- the mask only decides which of ITS
+// slots carry the NaN -- so the faster form stays.
+#ifndef F2_MASK_MUL
+#define F2_MASK_MUL 1
+#endif
+#if F2_MASK_MUL
+#define F2_SEL(ix, expr) ((expr) * ((ix) >= 0 ? 1.0 : 0.0))
+#else
+#define F2_SEL(ix, expr) ((ix) >= 0 ? (expr) : 0.0)
+#endif
 // a value that is equal in every lane, moved to scalar registers (frees VGPRs in the iteration loop)
 __device__ __forceinline__ double uniform_d(double v) {
     const int lo = __builtin_amdgcn_readfirstlane(__double2loint(v)), hi = __builtin_amdgcn_readfirstlane(__double2hiint(v));
@@ -593,12 +606,12 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
     auto materialize_at = [&](const Co &co) {
         const double ej = sm[L::O_EV + (co.j1 < NP ? co.j1 : 0)];
         const double *dv = sm + L::O_DV + T1 * co.c1;
-        gather_tile<T1>(idx_at, co.t, vals, [&](int k, int ix, double v) { at[k] = ix >= 0 ? -v * (dv[k] * ej) : 0.0; });
+        gather_tile<T1>(idx_at, co.t, vals, [&](int k, int ix, double v) { at[k] = F2_SEL(ix, -v * (dv[k] * ej)); });
     };
     auto materialize_ar = [&](const Co &co) {
         const double di = sm[L::O_DV + (co.i2 < MP ? co.i2 : 0)];
         const double *evs = sm + L::O_EV + T2 * co.c2;
-        gather_tile<T2>(idx_ar, co.t, vals, [&](int k, int ix, double v) { ar[k] = ix >= 0 ? -v * (di * evs[k]) : 0.0; });
+        gather_tile<T2>(idx_ar, co.t, vals, [&](int k, int ix, double v) { ar[k] = F2_SEL(ix, -v * (di * evs[k])); });
     };
     // P-hat row segment of the (jg, cg) layout, re-materialised wherever it is needed (S formation, P-hat g_x, the residual check)
     double gPg = 0;                                                  // g_x^T P-hat g_x
@@ -607,7 +620,7 @@ k_fwd2(DevT T, ce_settings S, const double *__restrict__ Avals, const double *__
         const double *pv = Pvals_g + (size_t)inst * nnzP;
         const double ej = sm[L::O_EV + (co.jg < NP ? co.jg : 0)];
         const double *evs = sm + L::O_EV + TG * co.cg;
-        gather_tile<TG>(idx_p, co.t, pv, [&](int k, int ix, double v) { pg[k] = ix >= 0 ? v * (ej * evs[k]) : 0.0; });
+        gather_tile<TG>(idx_p, co.t, pv, [&](int k, int ix, double v) { pg[k] = F2_SEL(ix, v * (ej * evs[k])); });
     };
     // The column groups j1 == n and j1 == n + 1 (idle in the A^T product) carry phi as two extra "columns", so that the
     // A^T w_y phase also yields phi_y . w_y and phi_x . w_x (the numerator of tau-tilde) without a separate reduction.
