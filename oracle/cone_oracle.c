@@ -755,6 +755,94 @@ static int lsqr_MT(const adj_op *op, const double *bvec, int N, double *x, const
     return itn;
 }
 
+/* LSMR (Fong & Saunders 2011, "LSMR: an iterative algorithm for sparse least-squares problems"; the recurrences and stopping tests as scipy.sparse.linalg.lsmr states
+ * them, damp = 0, zero start): diffcp's mode="lsmr".  Generic over the operator so that tests can pin the recurrence on an explicit matrix against scipy
+ * (oc_lsmr_dense below); solve_and_derivative's adjoint runs it on MT like lsqr_MT.  work: 2 * mrows + 3 * ncols doubles, mrows >= ncols.  Returns the iteration count. */
+typedef void (*lsmr_apply)(const void *ctx, const double *in, double *out);
+static void sym_ortho(double a, double b, double *c, double *s, double *r) {
+    if (b == 0) { *c = a == 0 ? 1.0 : (a > 0 ? 1.0 : -1.0); *s = 0; *r = fabs(a); }
+    else if (a == 0) { *c = 0; *s = b > 0 ? 1.0 : -1.0; *r = fabs(b); }
+    else if (fabs(b) > fabs(a)) { double tau = a / b; *s = (b > 0 ? 1.0 : -1.0) / sqrt(1 + tau * tau); *c = *s * tau; *r = b / *s; }
+    else { double tau = b / a; *c = (a > 0 ? 1.0 : -1.0) / sqrt(1 + tau * tau); *s = *c * tau; *r = a / *c; }
+}
+static int lsmr_core(lsmr_apply A_mul, lsmr_apply AT_mul, const void *ctx, int mrows, int ncols, const double *bvec, double *x,
+                     double atol, double btol, double conlim, int maxiter, double *work) {
+    double *u = work, *tmpm = u + mrows, *v = tmpm + mrows, *h = v + ncols, *hbar = h + ncols;      /* (tmpm is the scratch of both products: mrows >= ncols) */
+    memset(x, 0, sizeof(double) * ncols);
+    memcpy(u, bvec, sizeof(double) * mrows);
+    double normb = norm2(bvec, mrows), beta = normb, alpha = 0;
+    if (beta > 0) { for (int i = 0; i < mrows; i++) u[i] /= beta; AT_mul(ctx, u, v); alpha = norm2(v, ncols); } else memset(v, 0, sizeof(double) * ncols);
+    if (alpha > 0) for (int j = 0; j < ncols; j++) v[j] /= alpha;
+    double zetabar = alpha * beta, alphabar = alpha, rho = 1, rhobar = 1, cbar = 1, sbar = 0;
+    memcpy(h, v, sizeof(double) * ncols); memset(hbar, 0, sizeof(double) * ncols);
+    double betadd = beta, betad = 0, rhodold = 1, tautildeold = 0, thetatilde = 0, zeta = 0, d = 0;
+    double normA2 = alpha * alpha, maxrbar = 0, minrbar = 1e100;
+    const double ctol = conlim > 0 ? 1.0 / conlim : 0;
+    if (alpha * beta == 0) return 0;
+    int itn = 0;
+    while (itn < maxiter) {
+        itn++;
+        A_mul(ctx, v, tmpm);
+        for (int i = 0; i < mrows; i++) u[i] = tmpm[i] - alpha * u[i];
+        beta = norm2(u, mrows);
+        if (beta > 0) {
+            for (int i = 0; i < mrows; i++) u[i] /= beta;
+            AT_mul(ctx, u, tmpm);
+            for (int j = 0; j < ncols; j++) v[j] = tmpm[j] - beta * v[j];
+            alpha = norm2(v, ncols);
+            if (alpha > 0) for (int j = 0; j < ncols; j++) v[j] /= alpha;
+        }
+        /* damp = 0: the first rotation is trivial */
+        double chat, shat, alphahat; sym_ortho(alphabar, 0.0, &chat, &shat, &alphahat);
+        const double rhoold = rho; double c, s_; sym_ortho(alphahat, beta, &c, &s_, &rho);
+        const double thetanew = s_ * alpha; alphabar = c * alpha;
+        const double rhobarold = rhobar, zetaold = zeta, thetabar = sbar * rho, rhotemp = cbar * rho;
+        sym_ortho(cbar * rho, thetanew, &cbar, &sbar, &rhobar);
+        zeta = cbar * zetabar; zetabar = -sbar * zetabar;
+        const double f1 = -(thetabar * rho / (rhoold * rhobarold)), f2 = zeta / (rho * rhobar), f3 = -(thetanew / rho);
+        double xx = 0;
+        for (int j = 0; j < ncols; j++) { const double hb = hbar[j] * f1 + h[j]; hbar[j] = hb; const double xv = x[j] + f2 * hb; x[j] = xv; xx += xv * xv; h[j] = h[j] * f3 + v[j]; }
+        const double betaacute = chat * betadd, betacheck = -shat * betadd;
+        const double betahat = c * betaacute; betadd = -s_ * betaacute;
+        const double thetatildeold = thetatilde; double ctildeold, stildeold, rhotildeold; sym_ortho(rhodold, thetabar, &ctildeold, &stildeold, &rhotildeold);
+        thetatilde = stildeold * rhobar; rhodold = ctildeold * rhobar; betad = -stildeold * betad + ctildeold * betahat;
+        tautildeold = (zetaold - thetatildeold * tautildeold) / rhotildeold;
+        const double taud = (zeta - thetatilde * tautildeold) / rhodold;
+        d += betacheck * betacheck;
+        const double normr = sqrt(d + (betad - taud) * (betad - taud) + betadd * betadd);
+        normA2 += beta * beta; const double normA = sqrt(normA2); normA2 += alpha * alpha;
+        if (rhobarold > maxrbar) maxrbar = rhobarold;
+        if (itn > 1 && rhobarold < minrbar) minrbar = rhobarold;
+        const double condA = (maxrbar > rhotemp ? maxrbar : rhotemp) / (minrbar < rhotemp ? minrbar : rhotemp);
+        const double normar = fabs(zetabar), normx = sqrt(xx);
+        const double test1 = normr / normb, test2 = (normA * normr) != 0 ? normar / (normA * normr) : INFINITY, test3 = 1 / condA;
+        const double t1 = test1 / (1 + normA * normx / normb), rtol = btol + atol * normA * normx / normb;
+        if (1 + test3 <= 1 || 1 + test2 <= 1 || 1 + t1 <= 1) break;
+        if (test3 <= ctol || test2 <= atol || test1 <= rtol) break;
+    }
+    return itn;
+}
+static void lsmr_op_MT(const void *ctx, const double *in, double *out) { apply_MT((const adj_op *)ctx, in, out); }
+static void lsmr_op_M(const void *ctx, const double *in, double *out) { apply_M((const adj_op *)ctx, in, out); }
+static int lsmr_MT(const adj_op *op, const double *bvec, int N, double *x, const oc_opts *o, double *work) {
+    return lsmr_core(lsmr_op_MT, lsmr_op_M, op, N, N, bvec, x, o->lsqr_atol, o->lsqr_btol, o->lsqr_conlim, o->lsqr_iter_lim > 0 ? o->lsqr_iter_lim : 2 * N, work);
+}
+/* the same recurrence on an explicit row-major matrix A (mrows x ncols): test entry point (tests/test_oracle_known_answers.py pins it on scipy.sparse.linalg.lsmr) */
+typedef struct { int mrows, ncols; const double *A; } lsmr_dense_ctx;
+static void lsmr_dense_A(const void *ctx, const double *in, double *out) { const lsmr_dense_ctx *c = ctx; for (int i = 0; i < c->mrows; i++) out[i] = dot(c->A + (size_t)i * c->ncols, in, c->ncols); }
+static void lsmr_dense_AT(const void *ctx, const double *in, double *out) {
+    const lsmr_dense_ctx *c = ctx; memset(out, 0, sizeof(double) * c->ncols);
+    for (int i = 0; i < c->mrows; i++) for (int j = 0; j < c->ncols; j++) out[j] += c->A[(size_t)i * c->ncols + j] * in[i];
+}
+int oc_lsmr_dense(int mrows, int ncols, const double *A, const double *b, double atol, double btol, double conlim, int maxiter, double *x) {
+    if (mrows < ncols) return -1;          /* (lsmr_core's scratch vector serves both sides: mrows >= ncols; the adjoint's operator is square) */
+    lsmr_dense_ctx c = { mrows, ncols, A };
+    double *work = calloc((size_t)2 * mrows + 3 * (size_t)ncols, sizeof(double));
+    const int it = lsmr_core(lsmr_dense_A, lsmr_dense_AT, &c, mrows, ncols, b, x, atol, btol, conlim, maxiter, work);
+    free(work);
+    return it;
+}
+
 /* dense: build MT column by column, Gaussian elimination with complete pivoting, rank-revealing (the
  * embedding makes M singular along z; the system is consistent; free variables set to zero). */
 static void dense_solve_MT(const adj_op *op, const double *bvec, int N, double *x) {
@@ -808,6 +896,7 @@ static int adjoint_one(int n, int m, const double *A, const double *b, const dou
     int itn = 0;
     if (norm_inf(dz, N) == 0) memset(r, 0, sizeof(double) * N);
     else if (o->adj_mode == 1) dense_solve_MT(&op, dz, N, r);
+    else if (o->adj_mode == 2) itn = lsmr_MT(&op, dz, N, r, o, work);
     else itn = lsqr_MT(&op, dz, N, r, o, work);
     /* dQ = r Pi(z)^T antisymmetrised, Pi(z) = (x, y, 1) */
     const double *rx = r, *ry = r + n; double rt = r[N - 1];

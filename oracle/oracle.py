@@ -69,7 +69,7 @@ def make_opts(**kw) -> Opts:
         o.eps_rel = e
     mode = kw.pop("mode", None)
     if mode is not None:
-        o.adj_mode = {"lsqr": 0, "dense": 1}[mode]
+        o.adj_mode = {"lsqr": 0, "dense": 1, "lsmr": 2}[mode]
     if "acceleration_lookback" in kw:       # SCS names: lookback = memory (0 = off, the default here), interval
         o.aa_mem = int(kw.pop("acceleration_lookback"))
     if "acceleration_interval" in kw:

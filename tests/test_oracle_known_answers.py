@@ -327,3 +327,40 @@ def test_anderson_acceleration_reaches_the_same_solution_in_fewer_iterations():
         assert (acc["status"] == 1).all()
         np.testing.assert_allclose(acc["x"], plain["x"], atol=1e-6)
         assert acc["iters"].mean() < plain["iters"].mean()
+
+
+def test_lsmr_recurrence_is_scipys_and_the_lsmr_adjoint_agrees_with_the_dense_elimination():
+    """mode="lsmr" (diffcp's third adjoint mode): the oracle's LSMR (Fong & Saunders 2011) is pinned on scipy.sparse.linalg.lsmr -- same iterates at fixed iteration
+    counts, same stopping iteration -- through oc_lsmr_dense (the recurrence on an explicit matrix); on regular adjoint systems it returns the dense elimination's
+    gradients, like the LSQR mode."""
+    import ctypes as C
+    import scipy.sparse.linalg as sl
+    lib = oracle.lib()
+    lib.oc_lsmr_dense.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_int, C.c_void_p]
+    lib.oc_lsmr_dense.restype = C.c_int
+    rng = np.random.default_rng(0)
+    for (m, n) in ((40, 30), (25, 25)):
+        A = np.ascontiguousarray(rng.standard_normal((m, n))); b = rng.standard_normal(m)
+        for maxiter in (1, 2, 5, 10):
+            x = np.zeros(n)
+            it = lib.oc_lsmr_dense(m, n, A.ctypes.data, b.ctypes.data, 0.0, 0.0, 0.0, maxiter, x.ctypes.data)
+            ref = sl.lsmr(A, b, atol=0, btol=0, conlim=0, maxiter=maxiter)
+            assert it == ref[2] and np.abs(x - ref[0]).max() < 1e-13 * (1 + np.abs(ref[0]).max())
+        x = np.zeros(n)
+        it = lib.oc_lsmr_dense(m, n, A.ctypes.data, b.ctypes.data, 1e-10, 1e-10, 1e8, 10 * n, x.ctypes.data)
+        ref = sl.lsmr(A, b, atol=1e-10, btol=1e-10, conlim=1e8, maxiter=10 * n)
+        assert abs(it - ref[2]) <= 1 and np.abs(x - ref[0]).max() < 1e-8 * (1 + np.abs(ref[0]).max())
+    # the adjoint: LSMR against the dense elimination and LSQR on regular systems (strictly feasible SOCP of the metric shape, small)
+    n, cones, B = 12, {"z": 2, "l": 5, "q": [4, 3]}, 6
+    from cvxpylayers_amd import problems as P
+    A, b, c = P.generate(n, cones, B, seed=4)
+    sol = oracle.solve_batch(A, b, c, cones, eps=1e-10, max_iters=100000)
+    assert (sol["status"] == 1).all()
+    dx = rng.standard_normal((B, n)); dy = np.zeros_like(sol["y"])
+    gd = oracle.adjoint_batch(A, b, c, cones, sol["x"], sol["y"], sol["s"], dx, dy, mode="dense")
+    gm = oracle.adjoint_batch(A, b, c, cones, sol["x"], sol["y"], sol["s"], dx, dy, mode="lsmr", lsqr_atol=1e-13, lsqr_btol=1e-13, lsqr_iter_lim=5000)
+    gq = oracle.adjoint_batch(A, b, c, cones, sol["x"], sol["y"], sol["s"], dx, dy, mode="lsqr", lsqr_atol=1e-13, lsqr_btol=1e-13, lsqr_iter_lim=5000)
+    for k in ("dA", "db", "dc"):
+        sc = 1 + np.abs(gd[k]).max()
+        assert np.abs(gm[k] - gd[k]).max() < 1e-6 * sc, (k, np.abs(gm[k] - gd[k]).max())
+        assert np.abs(gm[k] - gq[k]).max() < 1e-6 * sc
