@@ -13,7 +13,7 @@ SO_PATH = os.environ.get("CE_ENGINE_SO") or os.path.join(_HERE, "csrc", "libcone
 
 # every symbol include/cone_engine.h declares
 SYMBOLS = ["ce_abi_version", "ce_struct_size", "ce_acceleration_available", "ce_default_settings", "ce_create", "ce_destroy", "ce_last_error", "ce_solve", "ce_vjp", "ce_solve_shared_a", "ce_vjp_shared_a", "ce_vjp_lsqr", "ce_qp_native", "ce_solve_qp", "ce_vjp_qp",
-           "ce_transpose", "ce_status_summary", "ce_parammap_apply", "ce_parammap_apply2", "ce_ca_step", "ce_ca_check", "ce_ca_psd", "ce_ca_psd_mfma", "ce_ca_triples", "ce_ca_triple_jac", "ce_ca_update", "ce_ca_finish", "ce_set_profiling", "ce_get_profile", "ce_reset_profile", "ce_get_launch_info", "ce_set_dispatch_history", "ce_set_adjoint_resolve", "ce_adjoint_ns_variant"]
+           "ce_transpose", "ce_status_summary", "ce_parammap_apply", "ce_parammap_apply2", "ce_ca_step", "ce_ca_check", "ce_ca_psd", "ce_ca_psd_mfma", "ce_ca_triples", "ce_ca_triple_jac", "ce_ca_update", "ce_ca_finish", "ce_set_profiling", "ce_get_profile", "ce_reset_profile", "ce_get_launch_info", "ce_set_dispatch_history", "ce_set_adjoint_resolve", "ce_adjoint_ns_variant", "ce_set_lsqr_variant"]
 
 
 class CeTemplate(C.Structure):
@@ -99,6 +99,7 @@ def lib():
     L.ce_set_dispatch_history.argtypes = [vp, C.c_int]
     L.ce_adjoint_ns_variant.argtypes = [vp]
     L.ce_set_adjoint_resolve.argtypes = [vp, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int]
+    L.ce_set_lsqr_variant.argtypes = [vp, C.c_int]; L.ce_set_lsqr_variant.restype = C.c_int
     L.ce_get_launch_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     _LIB = L
     return L

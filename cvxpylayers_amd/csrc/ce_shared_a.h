@@ -52,16 +52,18 @@ __device__ __forceinline__ void sa_spmv(const int *__restrict__ ptr, const int *
 
 // LDS doubles.  nvv: rows in front of the first PSD block (v = y - s is kept for those only; PSD blocks read y - s once, at the start).
 // The partial sums of the dense-row products (2 NT doubles) share the PSD scratch matrices when the template has PSD blocks.
-__host__ __device__ inline size_t sa_lsqr_lds_doubles(int n, int m, int nq, int ns, int maxs, int RP, int nvv, int ntri = 0) {
+__host__ __device__ inline size_t sa_lsqr_lds_doubles(int n, int m, int nq, int ns, int maxs, int RP, int nvv, int ntri = 0, int lsmr = 0) {
     const int kp = ns > 0 ? psd_mfma_kp(maxs) : 0;
     return (size_t)(RP > 0 ? 2 * RP + (ns > 0 ? 0 : 2 * NT) : 0) + (size_t)(ns > 0 ? (2 * ns + 2) * kp * (kp + 1) + 2 * kp + 8 : 0) + NW * 8 +
-           (size_t)(nvv + (nvv & 1)) + 6 * (size_t)m + 4 * (size_t)n + 5 * (size_t)(nq > 0 ? nq : 1) + 16 + 9 * (size_t)ntri + (ntri & 1);
+           (size_t)(nvv + (nvv & 1)) + 6 * (size_t)m + 4 * (size_t)n + 5 * (size_t)(nq > 0 ? nq : 1) + 16 + 9 * (size_t)ntri + (ntri & 1) + (lsmr ? (size_t)m + n : 0);      // (LSMR: one more vector, h-bar)
 }
 
 // RP > 0: A is applied through its split into singleton rows and r <= RP dense rows (ce_shared_a_ops.h: balanced, wide loads); RP == 0: through
 // the CSR / CSC structure (any sparsity pattern, but rows of very different lengths serialise on the longest).
 // HPSD / HTRI: the template has PSD blocks / exponential-power triples (false: their code is compiled out -- the plain-cone instantiation carried 50 spilled VGPRs of it)
-template <int RP, bool HPSD = true, bool HTRI = true>
+// LSMR: the same Golub-Kahan bidiagonalisation driven by Fong & Saunders' LSMR recurrences and stopping tests (diffcp's mode="lsmr"; oracle/cone_oracle.c lsmr_core,
+// pinned on scipy.sparse.linalg.lsmr): every product, cone derivative and reduction below is shared, the solution update needs one more vector (h-bar) and |x|.
+template <int RP, bool HPSD = true, bool HTRI = true, bool LSMR = false>
 __global__ void __launch_bounds__(NT, 3)
 k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, long sAb, int per_inst, const double *__restrict__ qg, long sqk, long sqb, const double *__restrict__ xg, const double *__restrict__ yg,
           const double *__restrict__ sg, const double *__restrict__ dxg, const double *__restrict__ dyg, double *__restrict__ dAo,
@@ -92,6 +94,7 @@ k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, long
     double *vv = p; p += nvv;          // v = y - s, rows in front of the PSD blocks
     double *uy = p; p += m; double *vy = p; p += m; double *wy = p; p += m; double *ry = p; p += m; double *ty = p; p += m; double *qv = p; p += m;
     double *ux = p; p += n; double *vx = p; p += n; double *wx = p; p += n; double *rx = p; p += n;
+    double *hby = p; if (LSMR) p += m; double *hbx = p; if (LSMR) p += n;          // LSMR: h-bar (w plays h, r plays x)
     double *socs = p; p += 5 * (nq > 0 ? nq : 1);          // per cone: t, |z|, case, z.h ; then h_0 per cone
     p += (size_t)(p - sm) & 1;
     double *Jt = p; p += 9 * (size_t)ntri;                    // exponential / power triples: symmetrised 3 x 3 derivative of the dual-cone projection
@@ -320,8 +323,8 @@ k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, long
     //      N   (r_x, r_y, r_t) = ( -A^T r_y - c r_t ,  DPi(A r_x - b r_t - r_y) + r_y ,  c.r_x + b.r_y )
     //      N^T (p_x, p_y, p_t) = (  A^T q + c p_t   , -A p_x + b p_t - q + p_y          , -c.p_x - b.q   ),     q = DPi(p_y)
     double acc = 0, acct = 0, dsum = 0;
-    for (int j = tid; j < n; j += NT) { const double v = dxg[(size_t)inst * n + j]; ux[j] = v; rx[j] = 0.0; acc = fma(v, v, acc); acct = fma(x[j], v, acct); }
-    for (int i = tid; i < m; i += NT) { const double v = dyg[(size_t)inst * m + i]; ty[i] = v; ry[i] = 0.0; acct = fma(y[i], v, acct); }
+    for (int j = tid; j < n; j += NT) { const double v = dxg[(size_t)inst * n + j]; ux[j] = v; rx[j] = 0.0; if constexpr (LSMR) hbx[j] = 0.0; acc = fma(v, v, acc); acct = fma(x[j], v, acct); }
+    for (int i = tid; i < m; i += NT) { const double v = dyg[(size_t)inst * m + i]; ty[i] = v; ry[i] = 0.0; if constexpr (LSMR) hby[i] = 0.0; acct = fma(y[i], v, acct); }
     __syncthreads();
     dproj(ty, 1.0, [&](int i, double o) { uy[i] = o; acc = fma(o, o, acc); });
     acc = sum_two(acc, acct, dsum);
@@ -353,6 +356,15 @@ k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, long
     }
     __syncthreads();
     double rhobar = alfa, phibar = beta, anorm = 0, xxnorm = 0, zz = 0, cs2 = -1, sn2 = 0;
+    // LSMR's scalars (scipy.sparse.linalg.lsmr's names; damp = 0)
+    double zetabar = alfa * beta, alphabar = alfa, mrho = 1, mrhobar = 1, cbar = 1, sbar = 0, hbt = 0;
+    double betadd = beta, betad = 0, rhodold = 1, tautildeold = 0, thetatilde = 0, zeta = 0, normA2 = alfa * alfa, maxrbar = 0, minrbar = 1e100;
+    auto sym_ortho = [](double a, double b, double &c, double &s_, double &r_) {
+        if (b == 0) { c = a == 0 ? 1.0 : (a > 0 ? 1.0 : -1.0); s_ = 0; r_ = fabs(a); }
+        else if (a == 0) { c = 0; s_ = b > 0 ? 1.0 : -1.0; r_ = fabs(b); }
+        else if (fabs(b) > fabs(a)) { const double tau = a / b; s_ = (b > 0 ? 1.0 : -1.0) / sqrt(1 + tau * tau); c = s_ * tau; r_ = b / s_; }
+        else { const double tau = b / a; c = (a > 0 ? 1.0 : -1.0) / sqrt(1 + tau * tau); s_ = c * tau; r_ = a / c; }
+    };
     bool live = bnorm > 0 && alfa * beta > 0;
     int itn = 0;
 #ifdef CE_TIMING
@@ -392,6 +404,40 @@ k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, long
         vt = TAU ? -dsum - beta * vt : 0.0;
         alfa = sqrt(fma(vt, vt, acc));
         LS_T(5);
+        if constexpr (LSMR) {
+            double chat, shat, alphahat; sym_ortho(alphabar, 0.0, chat, shat, alphahat);
+            const double rhoold = mrho; double c_, s_; sym_ortho(alphahat, beta, c_, s_, mrho);
+            const double thetanew = s_ * alfa; alphabar = c_ * alfa;
+            const double rhobarold = mrhobar, zetaold = zeta, thetabar = sbar * mrho, rhotemp = cbar * mrho;
+            { double cb, sb, rb; sym_ortho(cbar * mrho, thetanew, cb, sb, rb); cbar = cb; sbar = sb; mrhobar = rb; }
+            zeta = cbar * zetabar; zetabar = -sbar * zetabar;
+            const double f1 = -(thetabar * mrho / (rhoold * rhobarold)), f2 = zeta / (mrho * mrhobar), f3 = -(thetanew / mrho), ia = 1.0 / safe(alfa);
+            double xx[1] = {0};
+            for (int j = tid; j < n; j += NT) { const double v = vx[j] * ia, hh = wx[j], hb = fma(hbx[j], f1, hh), xv = fma(f2, hb, rx[j]); vx[j] = v; hbx[j] = hb; rx[j] = xv; wx[j] = fma(hh, f3, v); xx[0] = fma(xv, xv, xx[0]); }
+            for (int i = tid; i < m; i += NT) { const double v = vy[i] * ia, hh = wy[i], hb = fma(hby[i], f1, hh), xv = fma(f2, hb, ry[i]); vy[i] = v; hby[i] = hb; ry[i] = xv; wy[i] = fma(hh, f3, v); xx[0] = fma(xv, xv, xx[0]); to_wyd(i, v); }
+            { vt *= ia; hbt = fma(hbt, f1, wt); rt = fma(f2, hbt, rt); wt = fma(wt, f3, vt); }
+            block_reduce<1>(xx, 0u, red + NW * 7);          // |x| (its own four doubles of `red`; ends synchronised: the vectors above are complete for the next products)
+            const double normx = sqrt(fma(rt, rt, xx[0]));
+            const double betaacute = chat * betadd, betacheck = -shat * betadd;
+            const double betahat = c_ * betaacute; betadd = -s_ * betaacute;
+            const double thetatildeold = thetatilde; double ctildeold, stildeold, rhotildeold; sym_ortho(rhodold, thetabar, ctildeold, stildeold, rhotildeold);
+            thetatilde = stildeold * mrhobar; rhodold = ctildeold * mrhobar; betad = -stildeold * betad + ctildeold * betahat;
+            tautildeold = (zetaold - thetatildeold * tautildeold) / rhotildeold;
+            const double taud = (zeta - thetatilde * tautildeold) / rhodold;
+            ddnorm += betacheck * betacheck;          // (scipy's d)
+            const double normr = sqrt(ddnorm + (betad - taud) * (betad - taud) + betadd * betadd);
+            normA2 += beta * beta; const double normA = sqrt(normA2); normA2 += alfa * alfa;
+            maxrbar = fmax(maxrbar, rhobarold);
+            if (itn > 1) minrbar = fmin(minrbar, rhobarold);
+            const double condA = fmax(maxrbar, rhotemp) / fmin(minrbar, rhotemp);
+            const double normar = fabs(zetabar);
+            const double test1 = normr / safe(bnorm), test2 = (normA * normr) != 0 ? normar / (normA * normr) : 1e300, test3 = 1.0 / condA;
+            const double tt1 = test1 / (1.0 + normA * normx / safe(bnorm)), rtol = btol + atol * normA * normx / safe(bnorm);
+            if (test1 <= rtol || test2 <= atol || test3 <= ctol || 1.0 + test3 <= 1.0 || 1.0 + test2 <= 1.0 || 1.0 + tt1 <= 1.0) live = false;
+            zetabar = uniform_d(zetabar); alphabar = uniform_d(alphabar); mrho = uniform_d(mrho); mrhobar = uniform_d(mrhobar); cbar = uniform_d(cbar); sbar = uniform_d(sbar); hbt = uniform_d(hbt);
+            betadd = uniform_d(betadd); betad = uniform_d(betad); rhodold = uniform_d(rhodold); tautildeold = uniform_d(tautildeold); thetatilde = uniform_d(thetatilde); zeta = uniform_d(zeta);
+            normA2 = uniform_d(normA2); maxrbar = uniform_d(maxrbar); minrbar = uniform_d(minrbar);
+        } else {
         const double rho = sqrt(rhobar * rhobar + beta * beta);
         const double cs_ = rhobar / safe(rho), sn = beta / safe(rho);
         const double theta = sn * alfa; rhobar = -cs_ * alfa; const double phi = cs_ * phibar; phibar = sn * phibar; const double tau = sn * phi;
@@ -414,6 +460,7 @@ k_sa_lsqr(DevT T, SaStruct S, SaSplit F, const double *__restrict__ Avals0, long
         // conlim (1e8: ill-conditioned systems stop HERE, long before atol / btol are met) and the three machine-precision tests
         const double test3 = 1.0 / (anorm * sqrt(ddnorm) + 1e-300), tt1 = test1 / (1.0 + anorm * xnorm / safe(bnorm));
         if (test1 <= rtol || test2 <= atol || test3 <= ctol || 1.0 + test3 <= 1.0 || 1.0 + test2 <= 1.0 || 1.0 + tt1 <= 1.0) live = false;
+        }
         alfa = uniform_d(alfa); beta = uniform_d(beta); ut = uniform_d(ut); vt = uniform_d(vt); wt = uniform_d(wt); rt = uniform_d(rt);
         rhobar = uniform_d(rhobar); phibar = uniform_d(phibar); anorm = uniform_d(anorm); xxnorm = uniform_d(xxnorm); zz = uniform_d(zz);
         cs2 = uniform_d(cs2); sn2 = uniform_d(sn2); ddnorm = uniform_d(ddnorm);

@@ -72,6 +72,7 @@ struct ce_engine {
     // split of the A part into singleton rows and sp_r <= 64 dense rows (ce_shared_a_ops.h); sp_RP == 0: more than 64 rows with several entries
     int sp_r = 0, sp_RP = 0;
     bool sa_fwd_attr = false, sa_lsqr_attr = false, sa_lsqr_mi_attr = false;
+    int lsqr_variant = 0;                          // 0: LSQR, 1: LSMR (ce_set_lsqr_variant; the calls that solve EVERY instance iteratively: ce_vjp_shared_a, ce_vjp_lsqr)
     int *d_summary = nullptr; unsigned summary_next = 0;   // ce_status_summary staging (8 slots of 3 ints)
     double *d_qT = nullptr; size_t qT_bytes = 0;         // batch-major copy of the objective values for the LSQR adjoint kernels (vjp_lsqr_launch)
     double *d_aa_ws = nullptr; size_t aa_ws_bytes = 0;   // Anderson-acceleration history of the shared-A forward kernel ([B][4][lp])
@@ -250,6 +251,11 @@ extern "C" {
 const char *ce_last_error(void) { return g_err.c_str(); }
 int ce_abi_version(void) { return CE_ABI_VERSION; }
 // k_fwd2 when its history fits LDS; the first-generation register-tiled k_forward_rt and the size-generic k_forward keep the history in global memory.
+int ce_set_lsqr_variant(ce_handle h, int variant) {
+    if (!h || variant < 0 || variant > 1) { g_err = "ce_set_lsqr_variant: variant must be 0 (LSQR) or 1 (LSMR)"; return CE_E_BADARG; }
+    h->lsqr_variant = variant;
+    return CE_OK;
+}
 int ce_acceleration_available(ce_handle h) { return (h && ((h->fwd_mode == 4 && h->aa_ok) || h->fwd_mode <= 3)) ? 1 : 0; }
 int ce_struct_size(int which) { return which == 0 ? (int)sizeof(ce_template) : which == 1 ? (int)sizeof(ce_settings) : -1; }
 
@@ -1004,8 +1010,9 @@ static int vjp_lsqr_launch(ce_handle h, int B, const double *A_vals0, long sA_b,
     int RP = h->sp_RP;
     if (const char *e = getenv("CE_SA_SPLIT")) { if (atoi(e) == 0) RP = 0; }
     if (per_inst) RP = 0;      // the split's dense rows are ONE matrix (instance 0's values); per-instance values go through the CSR / CSC products
-    if (RP > 0 && sa_lsqr_lds_doubles(T.n, T.m, T.nq, T.ns, T.maxs, RP, h->psd_first, T.nep + T.np) * 8 > LDS_LIMIT) RP = 0;
-    size_t lds = sa_lsqr_lds_doubles(T.n, T.m, T.nq, T.ns, T.maxs, RP, h->psd_first, T.nep + T.np) * 8;
+    const int lsmr = (h->lsqr_variant == 1 && !sel) ? 1 : 0;      // (the re-solve list of ce_vjp stays diffcp's default, LSQR)
+    if (RP > 0 && sa_lsqr_lds_doubles(T.n, T.m, T.nq, T.ns, T.maxs, RP, h->psd_first, T.nep + T.np, lsmr) * 8 > LDS_LIMIT) RP = 0;
+    size_t lds = sa_lsqr_lds_doubles(T.n, T.m, T.nq, T.ns, T.maxs, RP, h->psd_first, T.nep + T.np, lsmr) * 8;
     if (lds > LDS_LIMIT) { g_err = "shared-A adjoint kernel: the LSQR vectors of one instance do not fit LDS"; return CE_E_TOO_LARGE; }
     // per-instance A: staged dense in LDS when it fits behind the vectors with three workgroups per CU to spare (CE_LSQR_A_LDS=0 disables)
     int a_lds = 0;
@@ -1019,6 +1026,7 @@ static int vjp_lsqr_launch(ce_handle h, int B, const double *A_vals0, long sA_b,
 #define SA_ATTR(...) HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_sa_lsqr<__VA_ARGS__>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_LIMIT))
         SA_ATTR(0); SA_ATTR(16); SA_ATTR(32); SA_ATTR(64); SA_ATTR(0, false, false); SA_ATTR(16, false, false); SA_ATTR(32, false, false); SA_ATTR(64, false, false);
         SA_ATTR(16, true, false); SA_ATTR(32, true, false); SA_ATTR(64, true, false);
+        SA_ATTR(0, true, true, true); SA_ATTR(16, true, true, true); SA_ATTR(32, true, true, true); SA_ATTR(64, true, true, true);
 #undef SA_ATTR
         h->sa_lsqr_attr = true;
     }
@@ -1043,7 +1051,7 @@ static int vjp_lsqr_launch(ce_handle h, int B, const double *A_vals0, long sA_b,
     // Several instances per workgroup share the stream over A_d^T (ce_shared_a_mi.h) where the template allows it: plain cones, the split's products, the solution
     // in the owners' registers, no re-solve list, and enough instances to fill the device either way.  CE_SA_LSQR_NI=1 keeps one instance per workgroup (A/B), 2 / 3 force.
     int ni = 0;
-    if (RP > 0 && !per_inst && !sel && T.ns == 0 && T.nep + T.np == 0 && T.n <= SAMI_EL * 256 && T.m <= SAMI_EL * 256) {
+    if (RP > 0 && !per_inst && !sel && !lsmr && T.ns == 0 && T.nep + T.np == 0 && T.n <= SAMI_EL * 256 && T.m <= SAMI_EL * 256) {
         ni = 0;      // (measured slower than one instance per workgroup at config 5: profiles/r06/n_*; opt-in)
         if (const char *e = getenv("CE_SA_LSQR_NI")) { const int v = atoi(e); ni = (v == 2 || v == 3) ? v : 0; }
         while (ni >= 2 && sa_lsqr_mi_lds_doubles(T.n, T.m, T.nq, RP, ni) * 8 > LDS_LIMIT) ni--;
@@ -1072,7 +1080,8 @@ static int vjp_lsqr_launch(ce_handle h, int B, const double *A_vals0, long sA_b,
         // plain cones / PSD without triples: instantiations without the other cones' code (CE_SA_LSQR_SPEC=0: the general kernel)
         const bool tri = T.nep + T.np > 0, psd = T.ns > 0;
         int spec = 1; if (const char *e = getenv("CE_SA_LSQR_SPEC")) spec = atoi(e);
-        if (spec && !tri && !psd) { if (RP == 0) LAUNCH_SAL(0, false, false); else if (RP == 16) LAUNCH_SAL(16, false, false); else if (RP == 32) LAUNCH_SAL(32, false, false); else LAUNCH_SAL(64, false, false); }
+        if (lsmr) { if (RP == 0) LAUNCH_SAL(0, true, true, true); else if (RP == 16) LAUNCH_SAL(16, true, true, true); else if (RP == 32) LAUNCH_SAL(32, true, true, true); else LAUNCH_SAL(64, true, true, true); }
+        else if (spec && !tri && !psd) { if (RP == 0) LAUNCH_SAL(0, false, false); else if (RP == 16) LAUNCH_SAL(16, false, false); else if (RP == 32) LAUNCH_SAL(32, false, false); else LAUNCH_SAL(64, false, false); }
         else if (spec && !tri && RP > 0) { if (RP == 16) LAUNCH_SAL(16, true, false); else if (RP == 32) LAUNCH_SAL(32, true, false); else LAUNCH_SAL(64, true, false); }
         else if (RP == 0) LAUNCH_SAL(0); else if (RP == 16) LAUNCH_SAL(16); else if (RP == 32) LAUNCH_SAL(32); else LAUNCH_SAL(64);
 #undef LAUNCH_SAL

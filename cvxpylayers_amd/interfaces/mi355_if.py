@@ -50,13 +50,20 @@ LSQR_ATOL, LSQR_BTOL = 1e-8, 1e-8
 
 
 def lsqr_rule(merged_args: dict, n: int, m: int) -> tuple:
-    """(atol, btol, iter_lim, system) of the shared-A adjoint from merged solver_args; defaults = diffcp's"""
+    """(atol, btol, iter_lim, system, method) of the iterative adjoint from merged solver_args; defaults = diffcp's.  method: "lsqr", or "lsmr" for diffcp's mode="lsmr"
+    (the same operator and tolerances under Fong & Saunders' LSMR recurrences and stopping tests: ce_set_lsqr_variant)"""
     lim = merged_args.get("lsqr_iter_lim")
     system = str(merged_args.get("adjoint_system", "full"))
     if system not in ("full", "reduced"):
         raise ValueError(f"MI355 solver: adjoint_system must be 'full' or 'reduced', got {system!r}")
     return (float(merged_args.get("lsqr_atol", LSQR_ATOL)), float(merged_args.get("lsqr_btol", LSQR_BTOL)),
-            int(lim) if lim not in (None, 0) else 2 * (n + m + 1), system)
+            int(lim) if lim not in (None, 0) else 2 * (n + m + 1), system, "lsmr" if str(merged_args.get("mode", "")) == "lsmr" else "lsqr")
+
+
+def unpack_rule(lsqr, n: int, m: int) -> tuple:
+    """(atol, btol, iter_lim, system, method) from a rule of three to five entries (callers of ConeEngine.vjp pass what they care about); None = diffcp's defaults"""
+    t = tuple(lsqr) if lsqr is not None else lsqr_rule({}, n, m)
+    return t + ("full", "lsqr")[len(t) - 3:] if len(t) < 5 else t[:5]
 
 
 
@@ -68,7 +75,7 @@ def adjoint_mode(merged_args: dict) -> str:
     "dense" -> "dense": the elimination alone (a basic solution on rank-deficient systems);
     "lsqr" -> diffcp's LSQR on the full (n + m + 1) system with its stopping rule for every instance (ce_vjp_lsqr).  Shared-A templates run LSQR whatever the mode says."""
     mode = str(merged_args.get("mode", ""))
-    return "lsqr" if mode == "lsqr" else ("dense" if mode == "dense" else "direct")
+    return "lsqr" if mode in ("lsqr", "lsmr") else ("dense" if mode == "dense" else "direct")          # ("lsmr": the iterative path with LSMR's recurrences, lsqr_rule()[4])
 
 
 _WARNED: set = set()
@@ -92,7 +99,7 @@ def note_ignored_args(merged_args: dict, explicit_lookback: bool):
                    " runs as type-I Anderson acceleration with a ONE-pair history (memory 1), not a " + str(int(lb)) + "-pair history; "
                    "pass acceleration_lookback=1 to say so explicitly, 0 to iterate plainly")
     for k in ("mode", "solve_method", "n_jobs_forward", "n_jobs_backward"):
-        if k == "mode" and str(merged_args.get(k)) in ("lsqr", "dense"):          # acted on: adjoint_mode()
+        if k == "mode" and str(merged_args.get(k)) in ("lsqr", "lsmr", "dense"):          # acted on: adjoint_mode()
             continue
         if k in merged_args:
             _warn_once(k, f"MI355 solver: solver_args[{k!r}]={merged_args[k]!r} is accepted for compatibility with the DIFFCP plugin and ignored "
@@ -373,17 +380,25 @@ class ConeEngine:
             from cvxpylayers_amd.interfaces.const_a import vjp_const_a      # shared A: batched LSQR with GEMMs over the batch
             if q_eval is None:          # direct engine users: the objective of the most recent solve() of this very value buffer, else the reduced system
                 q_eval = self._recent_q(A_bm)
-            atol, btol, lim, system = (tuple(lsqr) + ("full",))[:4] if lsqr is not None else lsqr_rule({}, self.n, self.m)
+            atol, btol, lim, system, method = unpack_rule(lsqr, self.n, self.m)
             if system == "reduced":
                 q_eval = None
-            return vjp_const_a(self, A_bm, x, y, s, dx, dy, batch_minor_out=batch_minor_out, atol=atol, btol=btol, iter_lim=lim, q_eval=q_eval)
+            _lib.check(_lib.lib().ce_set_lsqr_variant(self._h, 1 if method == "lsmr" else 0), "ce_set_lsqr_variant")
+            try:
+                return vjp_const_a(self, A_bm, x, y, s, dx, dy, batch_minor_out=batch_minor_out, atol=atol, btol=btol, iter_lim=lim, q_eval=q_eval)
+            finally:
+                _lib.lib().ce_set_lsqr_variant(self._h, 0)
         if path == "per_instance_lsqr":      # solver_args mode="lsqr" on a per-instance-A template: diffcp's LSQR instead of the direct elimination
             if P_bm is not None:
                 raise ValueError("MI355 solver: mode='lsqr' is not available with a quadratic objective inside the kernels (CE_QP_EPIGRAPH=1 brings the problem to cone form)")
-            atol, btol, lim, system = (tuple(lsqr) + ("full",))[:4] if lsqr is not None else lsqr_rule({}, self.n, self.m)
+            atol, btol, lim, system, method = unpack_rule(lsqr, self.n, self.m)
             if q_eval is None and system != "reduced":
                 q_eval = self._recent_q(A_bm)
-            out = self._vjp_lsqr(A_bm, x, y, s, dx, dy, batch_minor_out, atol, btol, lim, None if system == "reduced" else q_eval)
+            _lib.check(_lib.lib().ce_set_lsqr_variant(self._h, 1 if method == "lsmr" else 0), "ce_set_lsqr_variant")
+            try:
+                out = self._vjp_lsqr(A_bm, x, y, s, dx, dy, batch_minor_out, atol, btol, lim, None if system == "reduced" else q_eval)
+            finally:
+                _lib.lib().ce_set_lsqr_variant(self._h, 0)
             if out is not None:
                 return out
             path = "per_instance"          # (the LSQR vectors of one instance exceed LDS: warned once, the direct elimination + re-solve serves the call)
@@ -395,7 +410,7 @@ class ConeEngine:
         if P_bm is None and q_eval is not None and path != "per_instance_dense":          # (q_eval must be given explicitly here: without it, the elimination alone)
             qd = q_eval.detach().to(dtype=torch.float64, device=dev)
             q_args = (qd.data_ptr(), qd.stride(0), qd.stride(1))
-            rule = (tuple(lsqr) + ("full",))[:4] if lsqr is not None else lsqr_rule({}, self.n, self.m)
+            rule = unpack_rule(lsqr, self.n, self.m)[:4]
             if rule[:3] != getattr(self, "_resolve_rule", None):
                 _lib.check(_lib.lib().ce_set_adjoint_resolve(self._h, 1, float(rule[0]), float(rule[1]), 1e8, int(rule[2])), "ce_set_adjoint_resolve")
                 self._resolve_rule = rule[:3]

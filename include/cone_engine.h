@@ -95,6 +95,10 @@ void ce_default_settings(ce_settings *s);
 #define CE_ABI_VERSION 11
 int ce_abi_version(void);
 int ce_struct_size(int which);
+/* The iterative adjoint solver of ce_vjp_shared_a / ce_vjp_lsqr (the calls that solve EVERY instance iteratively): 0 = LSQR (Paige & Saunders; diffcp's default
+ * mode, diffcp_if.py:86), 1 = LSMR (Fong & Saunders; diffcp's mode="lsmr": same operator, same atol / btol / conlim / iter_lim arguments, scipy.sparse.linalg.lsmr's
+ * recurrences and stopping tests).  Engine state, default 0; the re-solve of rank-deficient instances inside ce_vjp always runs LSQR.  CE_E_BADARG for other values. */
+int ce_set_lsqr_variant(ce_handle h, int variant);
 /* 1 when ce_solve / ce_solve_qp on this engine honour ce_settings.acceleration_lookback > 0 (second-generation forward kernel with
  * room for its five extra vectors in LDS; the first-generation and size-generic kernels, which keep them in global memory), else 0: the
  * request is ignored on that engine (plain iteration). */

@@ -184,3 +184,93 @@ def test_default_solver_args_through_the_plugin_give_diffcps_element_and_report_
     kb = {int(tpl.indices[k]): k for k in range(tpl.nnz_aug) if cols[k] == n}
     assert np.abs(grads["default"][kb[0]][:3] - grads["default"][kb[1]][:3]).max() < 1e-6 * scale
     assert np.abs(grads["dense"][kb[0]][:3] - grads["dense"][kb[1]][:3]).max() > 1e-3
+
+
+def test_lsmr_mode_matches_the_oracles_lsmr_and_the_direct_elimination():
+    """solver_args mode="lsmr" (diffcp's third adjoint mode): k_sa_lsqr<..., LSMR> -- the LSQR kernel's bidiagonalisation under Fong & Saunders' recurrences and stopping
+    tests (ce_set_lsqr_variant) -- against the oracle's LSMR (oracle/cone_oracle.c lsmr_core, pinned on scipy.sparse.linalg.lsmr by the CPU suite): same gradients at a
+    tight rule, the elimination's gradients on a regular system, the oracle's iteration counts at diffcp's rule; on a shared-A template too; through the plugin, silently."""
+    cfg = P.CONFIGS["M"]; n, cones = cfg["n"], cfg["cones"]
+    oracle, tpl, (A, b, c), ref, eng, A_bm, (xr, yr, sr), dx, dy, q_t = _setup(n, cones, 24, 1, 1e-9)
+    dxt, dyt = torch.from_numpy(dx).cuda(), torch.from_numpy(dy).cuda()
+    dA_d, dq_d, _ = eng.vjp(A_bm, xr, yr, sr, dxt, dyt, path="per_instance")
+    dA_m, dq_m, adj = eng.vjp(A_bm, xr, yr, sr, dxt, dyt, path="per_instance_lsqr", lsqr=TIGHT_LSQR + ("full", "lsmr"), q_eval=q_t)
+    torch.cuda.synchronize()
+    assert (adj.cpu().numpy() == 0).all()
+    g = oracle.adjoint_batch(A, b, c, cones, ref["x"], ref["y"], ref["s"], dx, dy, mode="lsmr", lsqr_atol=TIGHT_LSQR[0], lsqr_btol=TIGHT_LSQR[1], lsqr_iter_lim=TIGHT_LSQR[2])
+    want = _want(tpl, g, n)
+    scale = 1 + np.abs(want).max()
+    assert np.abs(dA_m.cpu().numpy() - want).max() < 1e-6 * scale
+    assert np.abs(dA_m.cpu().numpy() - dA_d.cpu().numpy()).max() < 1e-5 * scale          # regular system: one solution
+    assert np.abs(dq_m.cpu().numpy()[:n] - g["dc"].T).max() < 1e-6 * (1 + np.abs(g["dc"]).max())
+    # diffcp's tolerances: the iteration counts are the oracle's LSMR's (and not LSQR's: the two stop at different iterations)
+    dA_r, dq_r, adj_r = eng.vjp(A_bm, xr, yr, sr, dxt, dyt, path="per_instance_lsqr", lsqr=(1e-8, 1e-8, 2 * (tpl.n + tpl.m + 1), "full", "lsmr"), q_eval=q_t)
+    torch.cuda.synchronize()
+    g_r = oracle.adjoint_batch(A, b, c, cones, ref["x"], ref["y"], ref["s"], dx, dy, mode="lsmr")
+    it_e, it_o = eng.last_lsqr_iters.cpu().numpy(), g_r["lsqr_iters"]
+    assert np.abs(it_e - it_o).max() <= 3 + 0.05 * it_o.max(), (it_e, it_o)
+    assert np.abs(dA_r.cpu().numpy() - _want(tpl, g_r, n)).max() < 1e-5 * scale
+    # the variant is per call: the next LSQR call is LSQR again
+    dA_l, _, _ = eng.vjp(A_bm, xr, yr, sr, dxt, dyt, path="per_instance_lsqr", q_eval=q_t)
+    g_l = oracle.adjoint_batch(A, b, c, cones, ref["x"], ref["y"], ref["s"], dx, dy, mode="lsqr")
+    assert np.abs(eng.last_lsqr_iters.cpu().numpy() - g_l["lsqr_iters"]).max() <= 3 + 0.05 * g_l["lsqr_iters"].max()
+
+
+def test_mode_lsmr_through_the_plugin_is_silent_and_differs_from_nothing_but_the_solver():
+    from cvxpylayers_amd.interfaces.mi355_if import MI355_ctx, _CvxpyLayer
+    cfg = P.CONFIGS["M"]; n, cones, B = cfg["n"], cfg["cones"], 16
+    tpl = P.dense_template(n, cones)
+    A, b, c = P.generate(n, cones, B, seed=5)
+    A_eval, q_eval = tpl.values_from_dense(A, b, c)
+    outs = {}
+    for mode in ("lsqr", "lsmr"):
+        ctx = MI355_ctx(None, tpl.problem_data_index, cones, options={"eps": 1e-9, "max_iters": 100000, "mode": mode, "lsqr_atol": 1e-12, "lsqr_btol": 1e-12, "lsqr_iter_lim": 20000})
+        A_t = torch.from_numpy(A_eval).cuda().requires_grad_(); q_t = torch.from_numpy(q_eval).cuda().requires_grad_()
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")
+            p, d, info, _ = _CvxpyLayer.apply(None, q_t, A_t, ctx, {}, True, None)
+            (p * torch.arange(1, p.numel() + 1, device=p.device, dtype=p.dtype).reshape(p.shape) / p.numel()).sum().backward()
+        outs[mode] = (A_t.grad.cpu().numpy().copy(), q_t.grad.cpu().numpy().copy())
+    for a, b_ in zip(outs["lsqr"], outs["lsmr"]):
+        assert np.abs(a - b_).max() < 1e-6 * (1 + np.abs(a).max())          # regular systems: both converge to the one solution
+        assert np.abs(a - b_).max() > 0                                      # ... along different iterates
+
+
+def test_lsmr_on_a_shared_A_template_matches_the_oracle(monkeypatch):
+    """the shared-A adjoint (ce_vjp_shared_a: the split products of k_sa_lsqr<RP>) under LSMR, against the oracle's LSMR at a tight rule and at diffcp's tolerances"""
+    from oracle import oracle
+    from cvxpylayers_amd.interfaces.mi355_if import ConeEngine, make_settings
+    B = 6
+    A, b, c, cones, tpl = P.portfolio_c5_batch(B, seed=3, nw=60, kf=9)
+    Ab = np.broadcast_to(A, (B,) + A.shape).copy(); bb = np.broadcast_to(b, (B,) + b.shape).copy()
+    ref = oracle.solve_batch(Ab, bb, c, cones, eps=1e-8, max_iters=200000)
+    assert (ref["status"] == 1).all()
+    monkeypatch.setenv("CE_CONST_A", "1")
+    A_eval, q_eval = tpl.values_from_dense(Ab, bb, c)
+    eng = ConeEngine(tpl.indices, tpl.indptr, tpl.n, tpl.m, cones, torch.device("cuda", 0))
+    A_bm = torch.from_numpy(A_eval).cuda().t().contiguous(); q_t = torch.from_numpy(q_eval).cuda()
+    xo, yo, so = (torch.from_numpy(ref[k]).cuda() for k in ("x", "y", "s"))
+    dx = np.random.default_rng(2).standard_normal((B, tpl.n)); dy = np.zeros_like(ref["y"])
+    dA, dq, adj = eng.vjp(A_bm, xo, yo, so, torch.from_numpy(dx).cuda(), torch.from_numpy(dy).cuda(), path="const_a", lsqr=TIGHT_LSQR + ("full", "lsmr"), q_eval=q_t)
+    torch.cuda.synchronize()
+    g = oracle.adjoint_batch(Ab, bb, c, cones, ref["x"], ref["y"], ref["s"], dx, dy, mode="lsmr", lsqr_atol=TIGHT_LSQR[0], lsqr_btol=TIGHT_LSQR[1], lsqr_iter_lim=TIGHT_LSQR[2])
+    want = _want(tpl, g, tpl.n)
+    assert np.abs(dA.cpu().numpy() - want).max() < 1e-6 * (1 + np.abs(want).max())
+    assert np.abs(dq.cpu().numpy()[:tpl.n] - g["dc"].T).max() < 1e-6 * (1 + np.abs(g["dc"]).max())
+    # iteration counts at diffcp's tolerances (at 1e-12 both sides stop on rounding-level quantities, a few dozen iterations apart)
+    dA2, dq2, adj2 = eng.vjp(A_bm, xo, yo, so, torch.from_numpy(dx).cuda(), torch.from_numpy(dy).cuda(), path="const_a", lsqr=(1e-8, 1e-8, 2 * (tpl.n + tpl.m + 1), "full", "lsmr"), q_eval=q_t)
+    torch.cuda.synchronize()
+    g2 = oracle.adjoint_batch(Ab, bb, c, cones, ref["x"], ref["y"], ref["s"], dx, dy, mode="lsmr")
+    it_e, it_o = eng.last_lsqr_iters.cpu().numpy(), g2["lsqr_iters"]
+    assert np.abs(it_e - it_o).max() <= 3 + 0.12 * it_o.max(), (it_e, it_o)          # (this template: the engine's LSQR and LSMR both stop 5-10 % before the oracle's at 1e-8: scripts/probes/lsmr_counts_check.py)
+    # the recurrence itself: after THREE iterations (no stopping test involved) the iterates are the oracle's to rounding
+    from cvxpylayers_amd.interfaces.const_a import vjp_const_a
+    from cvxpylayers_amd import _lib
+    _lib.lib().ce_set_lsqr_variant(eng._h, 1)
+    try:
+        dA3, dq3, _ = vjp_const_a(eng, A_bm, xo, yo, so, torch.from_numpy(dx).cuda(), torch.from_numpy(dy).cuda(), atol=0.0, btol=0.0, iter_lim=3, q_eval=q_t, conlim=0.0)
+    finally:
+        _lib.lib().ce_set_lsqr_variant(eng._h, 0)
+    g3 = oracle.adjoint_batch(Ab, bb, c, cones, ref["x"], ref["y"], ref["s"], dx, dy, mode="lsmr", lsqr_atol=0.0, lsqr_btol=0.0, lsqr_iter_lim=3, lsqr_conlim=0.0)
+    assert (eng.last_lsqr_iters.cpu().numpy() == 3).all() and (g3["lsqr_iters"] == 3).all()
+    assert np.abs(dq3.cpu().numpy()[:tpl.n] - g3["dc"].T).max() < 1e-12 * (1 + np.abs(g3["dc"]).max())

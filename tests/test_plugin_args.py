@@ -32,15 +32,18 @@ def test_lookback_zero_and_one_are_exactly_what_runs(lb):
     assert not w
 
 
-def test_mode_lsqr_and_dense_are_acted_on_other_modes_and_n_jobs_are_reported():
+def test_mode_lsqr_lsmr_and_dense_are_acted_on_other_modes_and_n_jobs_are_reported():
     m = _fresh()
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
         m.note_ignored_args({"acceleration_lookback": 0, "mode": "lsqr", "n_jobs_forward": 4}, explicit_lookback=True)          # mode="lsqr": diffcp's LSQR adjoint (ce_vjp_lsqr)
         m.note_ignored_args({"acceleration_lookback": 0, "mode": "dense", "n_jobs_backward": -1}, explicit_lookback=True)       # mode="dense": the direct elimination
-        m.note_ignored_args({"acceleration_lookback": 0, "mode": "lsmr"}, explicit_lookback=True)
+        m.note_ignored_args({"acceleration_lookback": 0, "mode": "lsmr"}, explicit_lookback=True)                               # mode="lsmr": the iterative adjoint under LSMR's recurrences (ce_set_lsqr_variant)
+        m.note_ignored_args({"acceleration_lookback": 0, "mode": "bicg"}, explicit_lookback=True)
     msgs = [str(x.message) for x in w]
-    assert len(msgs) == 3 and any("'mode'" in t and "lsmr" in t for t in msgs) and any("n_jobs_forward" in t for t in msgs) and any("n_jobs_backward" in t for t in msgs)
+    assert len(msgs) == 3 and any("'mode'" in t and "bicg" in t for t in msgs) and any("n_jobs_forward" in t for t in msgs) and any("n_jobs_backward" in t for t in msgs)
+    assert m.adjoint_mode({"mode": "lsmr"}) == "lsqr" and m.lsqr_rule({"mode": "lsmr"}, 3, 4)[4] == "lsmr" and m.lsqr_rule({"mode": "lsqr"}, 3, 4)[4] == "lsqr"
+    assert m.unpack_rule((1e-9, 1e-9, 7), 3, 4) == (1e-9, 1e-9, 7, "full", "lsqr") and m.unpack_rule((1e-9, 1e-9, 7, "reduced"), 3, 4)[3:] == ("reduced", "lsqr") and m.unpack_rule(None, 3, 4)[2] == 16
     assert m.adjoint_mode({"mode": "lsqr"}) == "lsqr" and m.adjoint_mode({"mode": "dense"}) == "dense" and m.adjoint_mode({}) == "direct"      # (default: elimination + device-side LSQR re-solve of rank-deficient instances; "dense": the elimination alone)
     # and they still pass validation (unknown names do not)
     m.make_settings({"mode": "lsqr", "n_jobs_forward": 4, "eps": 1e-6})
